@@ -1,0 +1,178 @@
+"""ctypes binding of the C ABI declared in include/dsa.h.
+
+`Binding(path, prefix)` binds one shared library whose entry points are named
+`<prefix>_*`.  The product library is `libdsa_hip.so` with prefix ``dsa``
+(see :func:`product`).  The CPU oracle under ``oracle/`` exports the same call
+shapes with prefix ``ora`` and is bound ONLY by tests / smoke / the bench's
+cpu_baseline leg — nothing in this package loads it.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+I64 = C.c_int64
+I32 = C.c_int32
+F64 = C.c_double
+P_I64 = C.POINTER(C.c_int64)
+P_F64 = C.POINTER(C.c_double)
+P_U8 = C.POINTER(C.c_uint8)
+P_I32 = C.POINTER(C.c_int32)
+VP = C.c_void_p
+
+INFO_COUNT = 16
+INFO = dict(capacity=0, segment_capacity=1, nb_segments=2, nb_elements=3, height=4,
+            nb_partitions=5, table_len=6, stat_window_slots=7, stat_rebalances=8,
+            stat_extends=9, stat_shrinks=10)
+
+OK, EARG, EBOUNDS, EDELETED, EFULL, EMODE, EASSERT, EHIP, ECAP, EKEY = range(10)
+STATUS_NAMES = ["OK", "EARG", "EBOUNDS", "EDELETED", "EFULL", "EMODE", "EASSERT", "EHIP", "ECAP", "EKEY"]
+
+
+class DsaError(RuntimeError):
+    """Base class; `.code` is the C status.  Subclasses mirror the Julia exception types."""
+
+    def __init__(self, code, msg):
+        super().__init__(f"{STATUS_NAMES[code] if 0 <= code < len(STATUS_NAMES) else code}: {msg}")
+        self.code = code
+
+
+class DsaArgumentError(DsaError, ValueError):      # Julia ArgumentError
+    pass
+
+
+class DsaBoundsError(DsaError, IndexError):        # Julia BoundsError
+    pass
+
+
+class DsaErrorException(DsaError):                 # Julia ErrorException / AssertionError
+    pass
+
+
+def _exc_for(code, msg):
+    if code in (EARG, EKEY):
+        return DsaArgumentError(code, msg)
+    if code == EBOUNDS:
+        return DsaBoundsError(code, msg)
+    return DsaErrorException(code, msg)
+
+
+# name -> argtypes (restype is always int32 unless listed in _SPECIAL)
+_SIGS = {
+    "vec_create": [P_I64, P_F64, I64, I32, I64, C.POINTER(VP)],
+    "vec_create_empty": [C.POINTER(VP)],
+    "vec_destroy": [VP],
+    "vec_get": [VP, I64, P_F64],
+    "vec_get_batch": [VP, P_I64, I64, P_F64],
+    "vec_set": [VP, I64, F64],
+    "vec_set_batch": [VP, P_I64, P_F64, I64],
+    "vec_nnz": [VP, P_I64],
+    "vec_len": [VP, P_I64],
+    "vec_shrink_size": [VP],
+    "vec_nonzeros": [VP, P_I64, P_F64, I64, P_I64],
+    "vec_info": [VP, P_I64],
+    "vec_export_layout": [VP, P_I64, P_F64, P_U8, I64],
+    "vec_rebalance_root": [VP],
+    "pcsc_create": [P_I64, I64, P_I64, P_F64, I32, C.POINTER(VP)],
+    "pcsc_create_empty": [C.POINTER(VP)],
+    "pcsc_destroy": [VP],
+    "pcsc_get": [VP, I64, I64, P_F64],
+    "pcsc_set": [VP, F64, I64, I64],
+    "pcsc_deletepartition": [VP, I64],
+    "pcsc_nnz": [VP, P_I64],
+    "pcsc_nbpartitions": [VP, P_I64],
+    "pcsc_info": [VP, P_I64],
+    "pcsc_export_layout": [VP, P_I64, P_F64, P_U8, I64, P_I64, I64],
+    "mat_create_from_coo": [P_I64, P_I64, P_F64, I64, I64, I64, C.POINTER(VP)],
+    "mat_create_empty": [I32, C.POINTER(VP)],
+    "mat_destroy": [VP],
+    "mat_set": [VP, F64, I64, I64],
+    "mat_set_batch": [VP, P_I64, P_I64, P_F64, I64],
+    "mat_get": [VP, I64, I64, P_F64],
+    "mat_get_batch": [VP, P_I64, P_I64, I64, P_F64],
+    "mat_addrow": [VP, I64, P_I64, P_F64, I64],
+    "mat_closefillmode": [VP],
+    "mat_deletecolumn": [VP, I64],
+    "mat_deleterow": [VP, I64],
+    "mat_col_view": [VP, I64, P_I64, P_F64, I64, P_I64],
+    "mat_row_view": [VP, I64, P_I64, P_F64, I64, P_I64],
+    "mat_nnz": [VP, P_I64],
+    "mat_size": [VP, P_I64, P_I64],
+    "mat_nbpartitions": [VP, I32, P_I64],
+    "mat_info": [VP, I32, P_I64],
+    "mat_export_layout": [VP, I32, P_I64, P_F64, P_U8, I64, P_I64, P_I64, P_U8, I64],
+    "mat_rebalance_root": [VP, I32],
+    "mat_spmv_dense": [VP, I32, P_F64, I64, P_F64, I64],
+    "mat_spmv_sparse": [VP, I32, P_I64, P_F64, I64, P_I64, P_F64, I64, P_I64],
+}
+# entry points only the HIP product library has
+_DEVICE_SIGS = {
+    "device_count": [P_I32],
+    "set_device": [I32],
+    "mat_spmv_dense_dev": [VP, I32, I32, VP, I64, VP, I64],
+    "mat_set_stream": [VP, VP],
+    "vec_set_stream": [VP, VP],
+    "mat_sync": [VP],
+    "vec_sync": [VP],
+}
+
+
+def _i64(a):
+    a = np.ascontiguousarray(a, dtype=np.int64)
+    return a, a.ctypes.data_as(P_I64)
+
+
+def _f64(a):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return a, a.ctypes.data_as(P_F64)
+
+
+class Binding:
+    def __init__(self, path: str, prefix: str, device_api: bool):
+        self.path = path
+        self.prefix = prefix
+        self.lib = C.CDLL(path)
+        self.device_api = device_api
+        sigs = dict(_SIGS)
+        if device_api:
+            sigs.update(_DEVICE_SIGS)
+        for name, argtypes in sigs.items():
+            fn = getattr(self.lib, f"{prefix}_{name}")   # AttributeError if the symbol is missing
+            fn.argtypes = argtypes
+            fn.restype = I32
+            setattr(self, "_" + name, fn)
+        self._errmsg = getattr(self.lib, f"{prefix}_last_error_message")
+        self._errmsg.restype = C.c_char_p
+        self._errmsg.argtypes = []
+
+    @staticmethod
+    def declared_symbols(device_api: bool):
+        names = list(_SIGS) + (list(_DEVICE_SIGS) if device_api else []) + ["last_error_message"]
+        return names
+
+    def call(self, name, *args):
+        rc = getattr(self, "_" + name)(*args)
+        if rc != OK:
+            raise _exc_for(rc, self._errmsg().decode("utf-8", "replace"))
+
+
+_PRODUCT = None
+
+
+def product_library_path() -> str:
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libdsa_hip.so")
+
+
+def product() -> Binding:
+    """The HIP product library.  Fails loudly if it has not been built — there is no fallback."""
+    global _PRODUCT
+    if _PRODUCT is None:
+        path = product_library_path()
+        if not os.path.exists(path):
+            raise RuntimeError(
+                f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+        _PRODUCT = Binding(path, "dsa", device_api=True)
+    return _PRODUCT

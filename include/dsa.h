@@ -1,0 +1,177 @@
+/* include/dsa.h — C ABI of libdsa_hip.so, the MI355X (gfx950) packed-memory-array /
+ * packed-CSR engine.  This is the drop-in boundary a Julia host module `ccall`s
+ * (see INTEGRATION.md for the binding).  The reference package
+ * (atoptima/DynamicSparseArrays.jl v0.7.2) has no FFI of its own: each entry point
+ * below replaces the Julia method cited next to it (paths relative to the
+ * reference checkout).
+ *
+ * Conventions
+ *   - K = L = Int64, T = Float64; semaphore key is 0
+ *     (src/pcsr.jl:23), so 0 is rejected as a row/column key of a matrix.
+ *   - All indices / positions crossing the ABI are 1-BASED, like the reference.
+ *   - Inputs are borrowed host pointers valid for the call only; outputs are
+ *     caller-allocated host buffers with explicit capacities.  `*_dev` entry points
+ *     take DEVICE pointers (HBM-resident) and enqueue on the handle's stream.
+ *   - Every function returns an int32 status; no exceptions cross the boundary.
+ *     dsa_last_error_message() returns the text of the last failure on this thread.
+ *   - A handle is single-writer / not thread-safe (as the reference).  All slot
+ *     storage, occupancy bitmaps, semaphore and column-key tables live in HBM.
+ *   - There is NO CPU fallback: every data-path operation runs HIP kernels and
+ *     fails with DSA_EHIP if no gfx950 device is usable.
+ */
+#ifndef DSA_H
+#define DSA_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* status codes; each mirrors a reference exception site */
+enum {
+    DSA_OK = 0,
+    DSA_EARG = 1,      /* ArgumentError: src/vector.jl:49-50, src/pcsr.jl:208,439-442, src/views.jl:12 */
+    DSA_EBOUNDS = 2,   /* BoundsError:   src/pcsr.jl:190, src/moves.jl:10-11 */
+    DSA_EDELETED = 3,  /* "The partition has been deleted."  src/pcsr.jl:299 */
+    DSA_EFULL = 4,     /* "No empty cell to insert a new element."  src/writes.jl:39 */
+    DSA_EMODE = 5,     /* fill-mode misuse: src/matrix.jl:73,84,96,105,127 ; src/buffer.jl:13 */
+    DSA_EASSERT = 6,   /* reference @assert sites: src/pcsr.jl:124,132,173,182 */
+    DSA_EHIP = 7,      /* HIP runtime failure / no device */
+    DSA_ECAP = 8,      /* caller-provided output buffer too small */
+    DSA_EKEY = 9       /* reserved key 0 used as a matrix row/column key */
+};
+
+enum { DSA_COMBINE_ADD = 0, DSA_COMBINE_MUL = 1, DSA_COMBINE_LAST = 2 };
+enum { DSA_COLMAJOR = 0, DSA_ROWMAJOR = 1 };
+
+/* index of the scalars returned by the *_info calls */
+enum {
+    DSA_INFO_CAPACITY = 0,        /* pma.capacity            src/pma.jl:9  */
+    DSA_INFO_SEGMENT_CAPACITY = 1,/* pma.segment_capacity    src/pma.jl:10 */
+    DSA_INFO_NB_SEGMENTS = 2,     /* pma.nb_segments         src/pma.jl:11 */
+    DSA_INFO_NB_ELEMENTS = 3,     /* pma.nb_elements         src/pma.jl:12 */
+    DSA_INFO_HEIGHT = 4,          /* pma.height              src/pma.jl:15 */
+    DSA_INFO_NB_PARTITIONS = 5,   /* pcsc.nb_partitions      src/pcsr.jl:5  (vector: length n, src/vector.jl:2) */
+    DSA_INFO_TABLE_LEN = 6,       /* length(pcsc.semaphores) == length(col_keys) (tombstones included) */
+    DSA_INFO_STAT_WINDOW_SLOTS = 7,/* instrumentation: slots inside pack/spread windows so far */
+    DSA_INFO_STAT_REBALANCES = 8, /* instrumentation: number of pack/spread windows so far */
+    DSA_INFO_STAT_EXTENDS = 9,
+    DSA_INFO_STAT_SHRINKS = 10,
+    DSA_INFO_COUNT = 16
+};
+
+typedef struct dsa_vec dsa_vec_t;    /* DynamicSparseVector   src/vector.jl:1-4   */
+typedef struct dsa_pcsc dsa_pcsc_t;  /* PackedCSC             src/pcsr.jl:4-9     */
+typedef struct dsa_mat dsa_mat_t;    /* DynamicSparseMatrix   src/matrix.jl:1-8   */
+
+const char* dsa_last_error_message(void);
+/* number of usable gfx950 devices and selection of the device new handles live on */
+int32_t dsa_device_count(int32_t* count);
+int32_t dsa_set_device(int32_t device);
+
+/* ---------------- DynamicSparseVector (one PMA) ---------------- */
+/* dynamicsparsevec(I, V, combine, n)  src/vector.jl:44-62 ; len < 0 => _guess_length(I) (:6) */
+int32_t dsa_vec_create(const int64_t* keys, const double* vals, int64_t n, int32_t combine_op,
+                       int64_t len, dsa_vec_t** out);
+/* dynamicsparsevec(Int[], Float64[]) -> PackedMemoryArray(K,T)  src/pma.jl:86-91 */
+int32_t dsa_vec_create_empty(dsa_vec_t** out);
+int32_t dsa_vec_destroy(dsa_vec_t* h);
+/* getindex(v, key)  src/vector.jl:73 -> src/pma.jl:189-193 */
+int32_t dsa_vec_get(dsa_vec_t* h, int64_t key, double* out);
+int32_t dsa_vec_get_batch(dsa_vec_t* h, const int64_t* keys, int64_t n, double* out);
+/* setindex!(v, value, key)  src/vector.jl:76-81 -> src/pma.jl:196-213 */
+int32_t dsa_vec_set(dsa_vec_t* h, int64_t key, double val);
+/* n sequential setindex! calls, applied in order (sequential-equivalent batch) */
+int32_t dsa_vec_set_batch(dsa_vec_t* h, const int64_t* keys, const double* vals, int64_t n);
+/* nnz(v) src/vector.jl:88 ; length(v) :69 ; shrink_size!(v) :64 */
+int32_t dsa_vec_nnz(dsa_vec_t* h, int64_t* out);
+int32_t dsa_vec_len(dsa_vec_t* h, int64_t* out);
+int32_t dsa_vec_shrink_size(dsa_vec_t* h);
+/* iterate(v) src/vector.jl:71 / nonzeroinds+nonzeros :93-109 : stored entries in slot order */
+int32_t dsa_vec_nonzeros(dsa_vec_t* h, int64_t* keys, double* vals, int64_t cap, int64_t* n_out);
+int32_t dsa_vec_info(dsa_vec_t* h, int64_t info[DSA_INFO_COUNT]);
+/* parity probe / snapshot: slot array (keys, vals, occ[i] in {0,1}), cap >= capacity */
+int32_t dsa_vec_export_layout(dsa_vec_t* h, int64_t* keys, double* vals, uint8_t* occ, int64_t cap);
+/* _even_rebalance!(pma, 1, capacity, nb_elements) on the whole array  src/pma.jl:94-103
+ * (benchmark / test hook for the full-window pack+spread kernel; layout-idempotent) */
+int32_t dsa_vec_rebalance_root(dsa_vec_t* h);
+
+/* ---------------- PackedCSC (integer-indexed partitions) ---------------- */
+/* PackedCSC(row_keys::Vector{Vector}, values::Vector{Vector}, combine)  src/pcsr.jl:26-63
+ * given CSC-style: partition p holds entries [colptr[p], colptr[p+1]) (0-based offsets, nparts+1 entries) */
+int32_t dsa_pcsc_create(const int64_t* colptr, int64_t nparts, const int64_t* row_keys,
+                        const double* vals, int32_t combine_op, dsa_pcsc_t** out);
+int32_t dsa_pcsc_create_empty(dsa_pcsc_t** out);                       /* src/pcsr.jl:65-68 */
+int32_t dsa_pcsc_destroy(dsa_pcsc_t* h);
+int32_t dsa_pcsc_get(dsa_pcsc_t* h, int64_t key, int64_t partition, double* out);   /* src/pcsr.jl:228-232 */
+int32_t dsa_pcsc_set(dsa_pcsc_t* h, double val, int64_t key, int64_t partition);    /* src/pcsr.jl:294-310 */
+int32_t dsa_pcsc_deletepartition(dsa_pcsc_t* h, int64_t partition);                 /* src/pcsr.jl:188-204 */
+int32_t dsa_pcsc_nnz(dsa_pcsc_t* h, int64_t* out);                                  /* src/pcsr.jl:11 */
+int32_t dsa_pcsc_nbpartitions(dsa_pcsc_t* h, int64_t* out);                         /* src/pcsr.jl:21 */
+int32_t dsa_pcsc_info(dsa_pcsc_t* h, int64_t info[DSA_INFO_COUNT]);
+/* semaphores[id] = slot of partition id's semaphore, 0 = nothing (tombstone) */
+int32_t dsa_pcsc_export_layout(dsa_pcsc_t* h, int64_t* keys, double* vals, uint8_t* occ, int64_t cap,
+                               int64_t* semaphores, int64_t table_cap);
+
+/* ---------------- DynamicSparseMatrix (colmajor + rowmajor MappedPackedCSC, or fill buffer) ---------------- */
+/* dynamicsparse(I, J, V, m, n)  src/matrix.jl:15-19 -> dynamicsparsecolmajor src/pcsr.jl:433-445 (x2) ;
+ * m, n < 0 => _guess_length */
+int32_t dsa_mat_create_from_coo(const int64_t* I, const int64_t* J, const double* V, int64_t nnz,
+                                int64_t m, int64_t n, dsa_mat_t** out);
+/* dynamicsparse(K, L, T; fill_mode)  src/matrix.jl:31-41 */
+int32_t dsa_mat_create_empty(int32_t fill_mode, dsa_mat_t** out);
+int32_t dsa_mat_destroy(dsa_mat_t* h);
+/* setindex!(m, val, row, col)  src/matrix.jl:43-62 (fill mode: addelem! src/buffer.jl:20-31) */
+int32_t dsa_mat_set(dsa_mat_t* h, double val, int64_t row, int64_t col);
+/* n sequential setindex! calls in order */
+int32_t dsa_mat_set_batch(dsa_mat_t* h, const int64_t* I, const int64_t* J, const double* V, int64_t n);
+/* getindex(m, row, col)  src/matrix.jl:64-68 */
+int32_t dsa_mat_get(dsa_mat_t* h, int64_t row, int64_t col, double* out);
+int32_t dsa_mat_get_batch(dsa_mat_t* h, const int64_t* I, const int64_t* J, int64_t n, double* out);
+/* addrow!(matrix, row, colids, vals)  src/matrix.jl:113-124 (fill mode: src/buffer.jl:10-18) */
+int32_t dsa_mat_addrow(dsa_mat_t* h, int64_t row, const int64_t* colids, const double* vals, int64_t n);
+/* closefillmode!  src/matrix.jl:126-134 */
+int32_t dsa_mat_closefillmode(dsa_mat_t* h);
+/* deletecolumn! / deleterow!  src/matrix.jl:95-111 */
+int32_t dsa_mat_deletecolumn(dsa_mat_t* h, int64_t col);
+int32_t dsa_mat_deleterow(dsa_mat_t* h, int64_t row);
+/* @view m[:, col] / @view m[row, :] iteration  src/matrix.jl:70-93, src/views.jl:15-35 */
+int32_t dsa_mat_col_view(dsa_mat_t* h, int64_t col, int64_t* rows, double* vals, int64_t cap, int64_t* n_out);
+int32_t dsa_mat_row_view(dsa_mat_t* h, int64_t row, int64_t* cols, double* vals, int64_t cap, int64_t* n_out);
+/* nnz(m) src/matrix.jl:91 ; size(m) :92 ; nbpartitions(orientation) src/pcsr.jl:21-22 */
+int32_t dsa_mat_nnz(dsa_mat_t* h, int64_t* out);
+int32_t dsa_mat_size(dsa_mat_t* h, int64_t* m, int64_t* n);
+int32_t dsa_mat_nbpartitions(dsa_mat_t* h, int32_t orientation, int64_t* out);
+int32_t dsa_mat_info(dsa_mat_t* h, int32_t orientation, int64_t info[DSA_INFO_COUNT]);
+/* parity probe: slot array + semaphores[id] (0 = nothing) + col_keys[id] with col_live[id] in {0,1} */
+int32_t dsa_mat_export_layout(dsa_mat_t* h, int32_t orientation, int64_t* keys, double* vals,
+                              uint8_t* occ, int64_t cap, int64_t* semaphores, int64_t* col_keys,
+                              uint8_t* col_live, int64_t table_cap);
+/* _even_rebalance!(pcsc, 1, capacity, nb_elements) of one orientation  src/pcsr.jl:88-97 */
+int32_t dsa_mat_rebalance_root(dsa_mat_t* h, int32_t orientation);
+
+/* ---- SpMV:  mat * v, transpose(mat) * v   src/operations.jl:14-60 -> _mul :107-135 ---- */
+/* dense x (every index of x is a stored entry), dense y of length ny; rows never touched are 0.
+ * transpose = 0: y = A x  (nx >= #cols used, ny = m) ; transpose = 1: y = A' x. */
+int32_t dsa_mat_spmv_dense(dsa_mat_t* h, int32_t transpose, const double* x, int64_t nx,
+                           double* y, int64_t ny);
+/* sparse x given by its stored entries (xi ascending) ; result = touched rows only, ascending,
+ * stored zeros kept: the shape of _mul_output(result, n)  src/operations.jl:11-12 */
+int32_t dsa_mat_spmv_sparse(dsa_mat_t* h, int32_t transpose, const int64_t* xi, const double* xv,
+                            int64_t nx, int64_t* yi, double* yv, int64_t cap, int64_t* n_out);
+/* same as dsa_mat_spmv_dense with x, y resident in HBM; asynchronous on the handle's stream.
+ * algo: 0 = gather over the twin orientation (default), 1 = scatter over the reference's own
+ * orientation with fp64 atomics (the literal _mul loop nest) */
+int32_t dsa_mat_spmv_dense_dev(dsa_mat_t* h, int32_t transpose, int32_t algo, const double* d_x,
+                               int64_t nx, double* d_y, int64_t ny);
+/* stream control for *_dev entry points (hipStream_t passed as void*; NULL = legacy default stream) */
+int32_t dsa_mat_set_stream(dsa_mat_t* h, void* hip_stream);
+int32_t dsa_vec_set_stream(dsa_vec_t* h, void* hip_stream);
+int32_t dsa_mat_sync(dsa_mat_t* h);
+int32_t dsa_vec_sync(dsa_vec_t* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DSA_H */
