@@ -1,0 +1,166 @@
+// csrc/dsa_dev.h — shared declarations of the gfx950 PMA / PCSR engine.
+//
+// Physical layout in HBM (ours; the LOGICAL slot array it encodes is bit-identical to the
+// reference's Elements{K,T}, src/DynamicSparseArrays.jl:18):
+//   int64  keys[cap_alloc]        8 B / slot   (coalesced streams for SpMV / rebalance)
+//   double vals[cap_alloc]        8 B / slot
+//   uint64 occ [cap_alloc / 64]   1 bit / slot — bit i of word w <=> slot 64*w+i (0-based) holds a
+//                                 tuple; one word is exactly one wave64 ballot.  Bits >= capacity are 0.
+//   int64  sems[table_cap]        semaphores[id] = 1-based slot of partition id's semaphore, 0 = nothing
+//   int64  col_keys[table_cap] + uint8 col_live[table_cap]   (MappedPackedCSC.col_keys, src/pcsr.jl:16-19)
+// Positions in device code are 1-based like the reference; array index = pos - 1.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dsa {
+
+constexpr int WAVE = 64;
+constexpr int64_t SEM_KEY = 0;            // semaphore_key(::Type{<:Integer})  src/pcsr.jl:23
+constexpr int MAX_LEVELS = 48;
+
+// ---- control block shared by host and the sequencer kernel (one per PMA) ----------------------
+enum SeqStatus : int32_t {
+    SEQ_DONE = 0,
+    SEQ_Y_REBALANCE = 1,   // host must run the big pack+spread on [y_ws, y_we] with y_m cells
+    SEQ_Y_EXTEND = 2,      // root density > t  -> _extend!  (src/pma.jl:143-151) then root rebalance
+    SEQ_Y_SHRINK = 3,      // root density < p  -> pack + _shrink! (src/pma.jl:135-139,153-161)
+    SEQ_Y_TABLE_GROW = 4,  // semaphore / col_keys tables are full; re-run the op after growing
+    SEQ_ERROR = 5
+};
+
+struct Ctl {
+    // PackedMemoryArray scalars (src/pma.jl:8-24)
+    int64_t capacity, segment_capacity, nb_segments, nb_elements, height;
+    // integer form of the density thresholds: level h (window W_h = seg*2^h) is accepted iff
+    // lo[h] <= count <= hi[h]  <=>  p_0+p_d*h <= count/W_h <= t_0+t_d*h in Float64 (W_h is a power
+    // of two, so count/W_h and p*W_h are exact).  Computed on the host in plain IEEE doubles.
+    int64_t lo[MAX_LEVELS], hi[MAX_LEVELS];
+    // PackedCSC tables
+    int64_t nb_partitions, table_len, table_cap;
+    // batch progress / yield mailbox
+    int64_t next_op;
+    int32_t status, err;
+    int64_t y_ws, y_we, y_m;
+    int64_t err_op;
+    // instrumentation
+    int64_t stat_window_slots, stat_rebalances, stat_extends, stat_shrinks, stat_small_rebalances;
+    // vector length n (src/vector.jl:2) is host-only
+};
+
+enum OpKind : int32_t {
+    OP_VEC_SET = 0,        // setindex!(pma, v, key)                    src/pma.jl:196-213       a=key
+    OP_PCSC_SET = 1,       // setindex!(pcsc, v, key, partition)        src/pcsr.jl:294-310      a=key b=partition
+    OP_MPCSC_SET = 2,      // setindex!(mpcsc, v, row, col)             src/pcsr.jl:341-351      a=row b=col
+    OP_DELETE_PARTITION = 3,   // deletepartition!(pcsc, p)             src/pcsr.jl:188-204      b=partition
+    OP_MPCSC_DELETECOLUMN = 4  // deletecolumn!(mpcsc, col)             src/pcsr.jl:206-212      b=col
+};
+
+struct Op {
+    int64_t a, b;
+    double v;
+    int32_t kind, pad;
+};
+
+// error codes (include/dsa.h)
+enum : int32_t { E_OK = 0, E_ARG = 1, E_BOUNDS = 2, E_DELETED = 3, E_FULL = 4, E_MODE = 5, E_ASSERT = 6, E_HIP = 7, E_CAP = 8, E_KEY = 9 };
+
+#if defined(__HIPCC__)
+// ---- bit helpers --------------------------------------------------------------------------------
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+__device__ __forceinline__ uint64_t mask_lt(int i) { return i <= 0 ? 0ull : (i >= 64 ? ~0ull : ((1ull << i) - 1ull)); }   // bits [0, i)
+__device__ __forceinline__ bool occ_test(const uint64_t* occ, int64_t pos) {
+    const int64_t i = pos - 1;
+    return (occ[i >> 6] >> (i & 63)) & 1ull;
+}
+__device__ __forceinline__ int popc64(uint64_t x) { return __popcll(x); }
+
+// ---- spread! geometry (src/moves.jl:120-171) ------------------------------------------------------
+// After spread! of m cells over a W-slot window, the empty slots are exactly the offsets
+//   D(k) = floor(fl(k * fl(W / E))),  k = 1..E,  E = W - m         (1-based offsets in the window)
+// evaluated in IEEE Float64; the m cells fill the other offsets in order.
+struct SpreadGeom {
+    int64_t W, E;
+    double f;       // fl(W / E)   (unused when E == 0)
+    double inv_f;   // E / W, only a starting guess
+};
+__device__ __host__ inline SpreadGeom make_geom(int64_t W, int64_t m) {
+    SpreadGeom g;
+    g.W = W; g.E = W - m;
+    g.f = g.E > 0 ? (double)W / (double)g.E : 0.0;
+    g.inv_f = (double)g.E / (double)W;
+    return g;
+}
+__device__ __forceinline__ int64_t gap_D(const SpreadGeom& g, int64_t k) {
+    return (int64_t)floor(__dmul_rn((double)k, g.f));
+}
+// number of empty offsets <= q, q in [0, W]
+__device__ __forceinline__ int64_t gaps_le(const SpreadGeom& g, int64_t q) {
+    if (g.E <= 0) return 0;
+    int64_t k = (int64_t)((double)q * g.inv_f);
+    if (k > g.E) k = g.E;
+    if (k < 0) k = 0;
+    while (k < g.E && gap_D(g, k + 1) <= q) ++k;
+    while (k > 0 && gap_D(g, k) > q) --k;
+    return k;
+}
+// offset q in [1, W]: returns true if q is a gap; otherwise *rank = 1-based rank of the cell landing on q
+__device__ __forceinline__ bool slot_is_gap(const SpreadGeom& g, int64_t q, int64_t* rank) {
+    const int64_t k = gaps_le(g, q);
+    if (k > 0 && gap_D(g, k) == q) return true;
+    *rank = q - k;
+    return false;
+}
+// bit-interleave: bit i of x -> bit 2i
+__device__ __forceinline__ uint64_t spread_bits32(uint32_t x) {
+    uint64_t v = x;
+    v = (v | (v << 16)) & 0x0000FFFF0000FFFFull;
+    v = (v | (v << 8)) & 0x00FF00FF00FF00FFull;
+    v = (v | (v << 4)) & 0x0F0F0F0F0F0F0F0Full;
+    v = (v | (v << 2)) & 0x3333333333333333ull;
+    v = (v | (v << 1)) & 0x5555555555555555ull;
+    return v;
+}
+#endif  // __HIPCC__
+
+// ---- host-side launch wrappers (defined in the .hip files) ----------------------------------------
+struct RebalanceWork {   // scratch owned by a PMA for the big pack+spread
+    uint32_t* tile_cnt;    // one counter per 4096-slot source tile
+    uint32_t* tile_off;    // exclusive prefix
+    int64_t tiles_cap;
+};
+
+// gathers the m occupied cells of src[src_ws..src_we] (in order) and spreads them over
+// dst[dst_ws..dst_we]; writes every dst slot, the dst occupancy words and, if sems != nullptr,
+// semaphores[id] for every cell with key == 0.  src_packed: the cells are src slots src_ws..src_ws+m-1.
+hipError_t launch_rebalance(const int64_t* src_keys, const double* src_vals, const uint64_t* src_occ,
+                            int64_t src_ws, int64_t src_we, bool src_packed,
+                            int64_t* dst_keys, double* dst_vals, uint64_t* dst_occ,
+                            int64_t dst_ws, int64_t dst_we, int64_t m, int64_t* sems,
+                            RebalanceWork* work, hipStream_t stream);
+// clears occupancy bits of slots [from, to] (1-based, inclusive); from/to word-aligned or inside one word
+hipError_t launch_clear_occ(uint64_t* occ, int64_t from, int64_t to, hipStream_t stream);
+
+hipError_t launch_sequencer(int64_t* keys, double* vals, uint64_t* occ, int64_t* sems, int64_t* col_keys,
+                            uint8_t* col_live, Ctl* ctl, const Op* ops, int64_t n_ops, hipStream_t stream);
+
+// batched read-only lookups.  mode 0: getindex(pma, key) ; 1: getindex(pcsc, key, partition) ;
+// 2: getindex(mpcsc, row, col).  err_out: first error code (0 if none)
+hipError_t launch_get_batch(int mode, const int64_t* keys, const double* vals, const uint64_t* occ, int64_t capacity,
+                            const int64_t* sems, const int64_t* col_keys, const uint8_t* col_live, int64_t table_len,
+                            const int64_t* qa, const int64_t* qb, int64_t n, double* out, int32_t* err_out,
+                            hipStream_t stream);
+// partition slot range lookup for views: out[0] = from (first slot after the semaphore), out[1] = to, or 0,0 if missing
+hipError_t launch_partition_range(const int64_t* sems, const int64_t* col_keys, const uint8_t* col_live,
+                                  int64_t table_len, int64_t capacity, int64_t col, int64_t* out, hipStream_t stream);
+
+// y = P x over one orientation P, gather form: y[part_key[p]] = sum over partition p of val * x[key]
+hipError_t launch_spmv_gather(const int64_t* keys, const double* vals, const uint64_t* occ, int64_t capacity,
+                              const int64_t* sems, const int64_t* part_keys, const uint8_t* part_live, int64_t table_len,
+                              const double* x, int64_t nx, double* y, int64_t ny, int pattern, hipStream_t stream);
+// y[key] += x[part_key[p]] * val, scatter form with fp64 atomics (the literal _mul loop nest)
+hipError_t launch_spmv_scatter(const int64_t* keys, const double* vals, const uint64_t* occ, int64_t capacity,
+                               const int64_t* sems, const int64_t* part_keys, const uint8_t* part_live, int64_t table_len,
+                               const double* x, int64_t nx, double* y, int64_t ny, hipStream_t stream);
+
+}  // namespace dsa

@@ -1,0 +1,1033 @@
+// csrc/dsa_host.hip — host side of libdsa_hip.so: handles, HBM management, bulk construction
+// (K-build), the yield loop around the on-device write sequencer, and the C ABI of include/dsa.h.
+//
+// Everything that touches slots runs on the GPU (rebalance.hip, sequencer.hip, spmv.hip).  The host
+// keeps only: the control scalars of each PMA (mirrored from the device control block), the integer
+// density bounds derived from the reference's Float64 thresholds (src/pma.jl:58,70,87 and :120-121),
+// the fill-mode staging buffer (src/buffer.jl — a host Dict in the reference as well) and the sort of
+// the (col,row) pairs of the bulk builder (src/pcsr.jl:359-363; device sort is a SURVEY §8f item).
+// There is no CPU fallback for any slot operation.
+#include "../../include/dsa.h"
+#include "dsa_dev.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+using namespace dsa;
+
+namespace {
+
+thread_local std::string g_err;
+
+struct Fail { int32_t code; std::string msg; };
+[[noreturn]] void fail(int32_t code, const std::string& msg) { throw Fail{code, msg}; }
+
+#define HIPCHK(expr)                                                                               \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess) fail(DSA_EHIP, std::string(#expr) + ": " + hipGetErrorString(_e));   \
+    } while (0)
+
+#define API_TRY try {
+#define API_CATCH                                                              \
+    } catch (const Fail& f) { g_err = f.msg; return f.code;                    \
+    } catch (const std::bad_alloc&) { g_err = "host allocation failed"; return DSA_EHIP; \
+    } catch (const std::exception& e) { g_err = e.what(); return DSA_EASSERT; } \
+    return DSA_OK;
+
+int g_device = 0;
+
+// capacity = 2^ceil(Int, log2(ceil(n / t_h)))   src/pma.jl:64,81,88 (Float64 arithmetic, App. A.1)
+int64_t capacity_for(int64_t n) {
+    const double c = std::ceil((double)n / 0.7);
+    const int64_t e = (int64_t)std::ceil(std::log2(c));
+    return (int64_t)1 << e;
+}
+
+// ------------------------------------------------------------------------------------------------
+// One packed-memory array resident in HBM, optionally with PackedCSC / MappedPackedCSC tables
+// ------------------------------------------------------------------------------------------------
+struct Pma {
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int64_t* keys[2] = {nullptr, nullptr};
+    double* vals[2] = {nullptr, nullptr};
+    uint64_t* occ[2] = {nullptr, nullptr};
+    int cur = 0;
+    int64_t cap_alloc = 0;        // slots allocated per buffer
+    int64_t occ_words = 0;        // words allocated per bitmap (whole 64-word tiles)
+    bool has_sems = false, has_cols = false;
+    int64_t* sems = nullptr; int64_t* col_keys = nullptr; uint8_t* col_live = nullptr;
+    Ctl* d_ctl = nullptr;
+    Ctl* h_ctl = nullptr;         // pinned host mirror
+    RebalanceWork work{nullptr, nullptr, 0};
+    Op* d_ops = nullptr; int64_t ops_cap = 0;
+    double* d_q = nullptr; int64_t q_cap = 0;      // scratch for lookups (3 arrays of q_cap)
+    int32_t* d_err = nullptr;
+    int64_t* d_small = nullptr;                     // 8 x int64 scratch
+    // thresholds  src/pma.jl:58,70,87
+    double t_h = 0.7, t_0 = 0.92, p_h = 0.3, p_0 = 0.08, t_d = 0.0, p_d = 0.0;
+
+    int64_t capacity() const { return h_ctl->capacity; }
+    int64_t* K() const { return keys[cur]; }
+    double* V() const { return vals[cur]; }
+    uint64_t* O() const { return occ[cur]; }
+};
+
+void pma_free_buffers(Pma& P) {
+    for (int b = 0; b < 2; ++b) {
+        if (P.keys[b]) hipFree(P.keys[b]);
+        if (P.vals[b]) hipFree(P.vals[b]);
+        if (P.occ[b]) hipFree(P.occ[b]);
+        P.keys[b] = nullptr; P.vals[b] = nullptr; P.occ[b] = nullptr;
+    }
+    if (P.work.tile_cnt) hipFree(P.work.tile_cnt);
+    if (P.work.tile_off) hipFree(P.work.tile_off);
+    P.work = RebalanceWork{nullptr, nullptr, 0};
+}
+
+void pma_destroy(Pma& P) {
+    if (P.stream) hipStreamSynchronize(P.stream);
+    pma_free_buffers(P);
+    if (P.sems) hipFree(P.sems);
+    if (P.col_keys) hipFree(P.col_keys);
+    if (P.col_live) hipFree(P.col_live);
+    if (P.d_ctl) hipFree(P.d_ctl);
+    if (P.h_ctl) hipHostFree(P.h_ctl);
+    if (P.d_ops) hipFree(P.d_ops);
+    if (P.d_q) hipFree(P.d_q);
+    if (P.d_err) hipFree(P.d_err);
+    if (P.d_small) hipFree(P.d_small);
+    if (P.own_stream && P.stream) hipStreamDestroy(P.stream);
+    P = Pma();
+}
+
+int64_t occ_words_for(int64_t slots) {
+    const int64_t w = (slots + 63) / 64;
+    return ((w + 63) / 64) * 64;      // whole 64-word tiles (k_tile_count / k_move read lane <-> word)
+}
+
+void alloc_one_buffer(Pma& P, int b, int64_t slots) {
+    HIPCHK(hipMalloc(&P.keys[b], (size_t)slots * sizeof(int64_t)));
+    HIPCHK(hipMalloc(&P.vals[b], (size_t)slots * sizeof(double)));
+    const int64_t words = occ_words_for(slots);
+    HIPCHK(hipMalloc(&P.occ[b], (size_t)words * sizeof(uint64_t)));
+    HIPCHK(hipMemsetAsync(P.occ[b], 0, (size_t)words * sizeof(uint64_t), P.stream));
+}
+
+void alloc_work(Pma& P, int64_t slots) {
+    if (P.work.tile_cnt) { hipFree(P.work.tile_cnt); hipFree(P.work.tile_off); }
+    P.work.tiles_cap = slots / 4096 + 8;
+    HIPCHK(hipMalloc(&P.work.tile_cnt, (size_t)P.work.tiles_cap * sizeof(uint32_t)));
+    HIPCHK(hipMalloc(&P.work.tile_off, (size_t)P.work.tiles_cap * sizeof(uint32_t)));
+}
+
+void pma_init_common(Pma& P, bool sems, bool cols) {
+    HIPCHK(hipSetDevice(g_device));
+    HIPCHK(hipStreamCreateWithFlags(&P.stream, hipStreamNonBlocking));
+    P.own_stream = true;
+    P.has_sems = sems; P.has_cols = cols;
+    HIPCHK(hipMalloc(&P.d_ctl, sizeof(Ctl)));
+    HIPCHK(hipHostMalloc(&P.h_ctl, sizeof(Ctl), hipHostMallocDefault));
+    std::memset(P.h_ctl, 0, sizeof(Ctl));
+    HIPCHK(hipMalloc(&P.d_err, sizeof(int32_t)));
+    HIPCHK(hipMalloc(&P.d_small, 8 * sizeof(int64_t)));
+}
+
+void ensure_tables(Pma& P, int64_t need) {
+    if (!P.has_sems) return;
+    if (need <= P.h_ctl->table_cap) return;
+    int64_t ncap = std::max<int64_t>(64, P.h_ctl->table_cap * 2);
+    while (ncap < need) ncap *= 2;
+    int64_t* ns = nullptr; int64_t* nk = nullptr; uint8_t* nl = nullptr;
+    HIPCHK(hipMalloc(&ns, (size_t)ncap * sizeof(int64_t)));
+    HIPCHK(hipMemsetAsync(ns, 0, (size_t)ncap * sizeof(int64_t), P.stream));
+    const int64_t len = P.h_ctl->table_len;
+    if (P.sems && len > 0) HIPCHK(hipMemcpyAsync(ns, P.sems, (size_t)len * sizeof(int64_t), hipMemcpyDeviceToDevice, P.stream));
+    if (P.has_cols) {
+        HIPCHK(hipMalloc(&nk, (size_t)ncap * sizeof(int64_t)));
+        HIPCHK(hipMalloc(&nl, (size_t)ncap));
+        HIPCHK(hipMemsetAsync(nk, 0, (size_t)ncap * sizeof(int64_t), P.stream));
+        HIPCHK(hipMemsetAsync(nl, 0, (size_t)ncap, P.stream));
+        if (P.col_keys && len > 0) {
+            HIPCHK(hipMemcpyAsync(nk, P.col_keys, (size_t)len * sizeof(int64_t), hipMemcpyDeviceToDevice, P.stream));
+            HIPCHK(hipMemcpyAsync(nl, P.col_live, (size_t)len, hipMemcpyDeviceToDevice, P.stream));
+        }
+    }
+    HIPCHK(hipStreamSynchronize(P.stream));
+    if (P.sems) hipFree(P.sems);
+    if (P.col_keys) hipFree(P.col_keys);
+    if (P.col_live) hipFree(P.col_live);
+    P.sems = ns; P.col_keys = nk; P.col_live = nl;
+    P.h_ctl->table_cap = ncap;
+}
+
+// integer density bounds of every level (see Ctl) from the reference's Float64 thresholds
+void compute_bounds(Pma& P) {
+    Ctl& c = *P.h_ctl;
+    if (c.height + 1 > MAX_LEVELS) fail(DSA_EARG, "PMA too tall");
+    P.t_d = (P.t_h - P.t_0) / (double)c.height;      // src/pma.jl:47-48,147-148,157-158
+    P.p_d = (P.p_h - P.p_0) / (double)c.height;
+    for (int64_t h = 0; h <= c.height; ++h) {
+        const double W = (double)(c.segment_capacity << h);
+        volatile double pm = P.p_d * (double)h;        // separate multiply and add, as Julia evaluates them
+        volatile double tm = P.t_d * (double)h;
+        const double p = P.p_0 + pm;
+        const double t = P.t_0 + tm;
+        c.lo[h] = (int64_t)std::ceil(p * W);           // p <= count/W  <=>  count >= ceil(p*W)   (W = 2^k: exact)
+        c.hi[h] = (int64_t)std::floor(t * W);          // count/W <= t  <=>  count <= floor(t*W)
+    }
+}
+
+// _pma geometry  src/pma.jl:42-49
+void set_geometry_for_new(Pma& P, int64_t capacity, int64_t nb_elements) {
+    Ctl& c = *P.h_ctl;
+    const double lc = std::log2((double)capacity);
+    const int64_t nb_segs = (int64_t)1 << (int64_t)std::ceil(std::log2((double)capacity / lc));
+    c.capacity = capacity;
+    c.nb_segments = nb_segs;
+    c.segment_capacity = capacity / nb_segs;
+    c.height = (int64_t)std::log2((double)nb_segs);
+    c.nb_elements = nb_elements;
+    compute_bounds(P);
+}
+
+void upload_ctl(Pma& P) {
+    HIPCHK(hipMemcpyAsync(P.d_ctl, P.h_ctl, sizeof(Ctl), hipMemcpyHostToDevice, P.stream));
+    HIPCHK(hipStreamSynchronize(P.stream));   // h_ctl is reused as the download target
+}
+void download_ctl(Pma& P) {
+    HIPCHK(hipMemcpyAsync(P.h_ctl, P.d_ctl, sizeof(Ctl), hipMemcpyDeviceToHost, P.stream));
+    HIPCHK(hipStreamSynchronize(P.stream));
+}
+
+// grow both slot buffers to at least `slots` (contents of the current buffer are preserved)
+void ensure_capacity_alloc(Pma& P, int64_t slots) {
+    if (slots <= P.cap_alloc) return;
+    int64_t n = std::max<int64_t>(P.cap_alloc, 4096);
+    while (n < slots) n *= 2;
+    int64_t* ok[2] = {P.keys[0], P.keys[1]}; double* ov[2] = {P.vals[0], P.vals[1]}; uint64_t* oo[2] = {P.occ[0], P.occ[1]};
+    const int64_t old_words = P.occ_words, old_slots = P.cap_alloc;
+    for (int b = 0; b < 2; ++b) { P.keys[b] = nullptr; P.vals[b] = nullptr; P.occ[b] = nullptr; }
+    for (int b = 0; b < 2; ++b) alloc_one_buffer(P, b, n);
+    if (ok[P.cur] != nullptr && old_slots > 0) {
+        HIPCHK(hipMemcpyAsync(P.keys[P.cur], ok[P.cur], (size_t)old_slots * sizeof(int64_t), hipMemcpyDeviceToDevice, P.stream));
+        HIPCHK(hipMemcpyAsync(P.vals[P.cur], ov[P.cur], (size_t)old_slots * sizeof(double), hipMemcpyDeviceToDevice, P.stream));
+        HIPCHK(hipMemcpyAsync(P.occ[P.cur], oo[P.cur], (size_t)old_words * sizeof(uint64_t), hipMemcpyDeviceToDevice, P.stream));
+    }
+    HIPCHK(hipStreamSynchronize(P.stream));
+    for (int b = 0; b < 2; ++b) { if (ok[b]) hipFree(ok[b]); if (ov[b]) hipFree(ov[b]); if (oo[b]) hipFree(oo[b]); }
+    P.cap_alloc = n;
+    P.occ_words = occ_words_for(n);
+    alloc_work(P, n);
+}
+
+// pack + spread of the whole array into the other buffer: cells of cur[1..src_cap] -> alt[1..new_cap]
+// (root _even_rebalance!, _extend!, pack! + _shrink!)  src/pma.jl:94-103,135-161
+void root_rebalance(Pma& P, int64_t src_cap, int64_t new_cap, int64_t m, bool src_packed) {
+    ensure_capacity_alloc(P, std::max(src_cap, new_cap));
+    const int alt = 1 - P.cur;
+    hipError_t e = launch_rebalance(P.keys[P.cur], P.vals[P.cur], P.occ[P.cur], 1, src_cap, src_packed,
+                                    P.keys[alt], P.vals[alt], P.occ[alt], 1, new_cap, m,
+                                    P.has_sems ? P.sems : nullptr, &P.work, P.stream);
+    if (e != hipSuccess) fail(DSA_EHIP, std::string("rebalance launch: ") + hipGetErrorString(e));
+    // bits beyond the new capacity must be zero in the buffer that becomes current
+    const int64_t first_word = (new_cap + 63) / 64;
+    if (first_word < P.occ_words)
+        HIPCHK(hipMemsetAsync(P.occ[alt] + first_word, 0, (size_t)(P.occ_words - first_word) * sizeof(uint64_t), P.stream));
+    P.cur = alt;
+}
+
+// in-place semantic for an interior window: rebalance into the alternate buffer, copy the window back
+void window_rebalance(Pma& P, int64_t ws, int64_t we, int64_t m) {
+    if (ws == 1 && we == P.capacity()) { root_rebalance(P, P.capacity(), P.capacity(), m, false); return; }
+    const int alt = 1 - P.cur;
+    hipError_t e = launch_rebalance(P.K(), P.V(), P.O(), ws, we, false, P.keys[alt], P.vals[alt], P.occ[alt], ws, we, m,
+                                    P.has_sems ? P.sems : nullptr, &P.work, P.stream);
+    if (e != hipSuccess) fail(DSA_EHIP, std::string("rebalance launch: ") + hipGetErrorString(e));
+    const int64_t W = we - ws + 1;
+    HIPCHK(hipMemcpyAsync(P.K() + (ws - 1), P.keys[alt] + (ws - 1), (size_t)W * sizeof(int64_t), hipMemcpyDeviceToDevice, P.stream));
+    HIPCHK(hipMemcpyAsync(P.V() + (ws - 1), P.vals[alt] + (ws - 1), (size_t)W * sizeof(double), hipMemcpyDeviceToDevice, P.stream));
+    HIPCHK(hipMemcpyAsync(P.O() + ((ws - 1) >> 6), P.occ[alt] + ((ws - 1) >> 6), (size_t)(W >> 6) * sizeof(uint64_t),
+                          hipMemcpyDeviceToDevice, P.stream));
+}
+
+// PackedMemoryArray(keys, values; sort=false) + _pma  src/pma.jl:42-55,69-84 from an already ordered
+// cell stream; n == 0 -> PackedMemoryArray(K, T) (capacity for 100 expected cells)  src/pma.jl:86-91
+void build_from_packed(Pma& P, const std::vector<int64_t>& keys, const std::vector<double>& vals) {
+    const int64_t n = (int64_t)keys.size();
+    const int64_t capacity = capacity_for(n == 0 ? 100 : n);
+    set_geometry_for_new(P, capacity, n);
+    ensure_capacity_alloc(P, 2 * capacity);
+    if (n > 0) {
+        HIPCHK(hipMemcpyAsync(P.K(), keys.data(), (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, P.stream));
+        HIPCHK(hipMemcpyAsync(P.V(), vals.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice, P.stream));
+    }
+    // _even_rebalance!(pma, 1, capacity, n): a no-op when the array is exactly one leaf (src/pma.jl:96-99)
+    P.h_ctl->stat_rebalances = 0; P.h_ctl->stat_window_slots = 0;
+    if (capacity != P.h_ctl->segment_capacity) { P.h_ctl->stat_rebalances = 1; P.h_ctl->stat_window_slots = capacity; }
+    root_rebalance(P, std::max<int64_t>(n, 1), capacity, n, true);
+    upload_ctl(P);
+}
+
+void ensure_ops(Pma& P, int64_t n) {
+    if (n <= P.ops_cap) return;
+    if (P.d_ops) hipFree(P.d_ops);
+    P.ops_cap = std::max<int64_t>(n, 1024);
+    HIPCHK(hipMalloc(&P.d_ops, (size_t)P.ops_cap * sizeof(Op)));
+}
+
+int32_t seq_err_to_status(int32_t e) { return e == 0 ? DSA_EASSERT : e; }
+
+const char* err_text(int32_t e) {
+    switch (e) {
+        case DSA_EARG: return "column does not exist.";
+        case DSA_EBOUNDS: return "cannot access partition at this index";
+        case DSA_EDELETED: return "The partition has been deleted.";
+        case DSA_EFULL: return "No empty cell to insert a new element.";
+        case DSA_EASSERT: return "reference assertion failed (tombstoned partition in the way)";
+        default: return "sequencer error";
+    }
+}
+
+// Runs `ops` in order on the device.  Returns the number of ops fully applied; *err receives the
+// status of the failing op (0 if all were applied).
+int64_t run_ops(Pma& P, const std::vector<Op>& ops, int32_t* err) {
+    *err = 0;
+    const int64_t n = (int64_t)ops.size();
+    if (n == 0) return 0;
+    ensure_ops(P, n);
+    HIPCHK(hipMemcpyAsync(P.d_ops, ops.data(), (size_t)n * sizeof(Op), hipMemcpyHostToDevice, P.stream));
+    P.h_ctl->next_op = 0; P.h_ctl->status = 0; P.h_ctl->err = 0;
+    upload_ctl(P);
+    for (int64_t guard = 0;; ++guard) {
+        hipError_t e = launch_sequencer(P.K(), P.V(), P.O(), P.has_sems ? P.sems : nullptr, P.has_cols ? P.col_keys : nullptr,
+                                        P.has_cols ? P.col_live : nullptr, P.d_ctl, P.d_ops, n, P.stream);
+        if (e != hipSuccess) fail(DSA_EHIP, std::string("sequencer launch: ") + hipGetErrorString(e));
+        download_ctl(P);
+        Ctl& c = *P.h_ctl;
+        switch (c.status) {
+            case SEQ_DONE:
+                return n;
+            case SEQ_ERROR:
+                *err = seq_err_to_status(c.err);
+                return c.next_op;
+            case SEQ_Y_REBALANCE:
+                window_rebalance(P, c.y_ws, c.y_we, c.y_m);
+                break;
+            case SEQ_Y_EXTEND: {       // _extend!  src/pma.jl:143-151 then _even_rebalance!(1, capacity, count)
+                const int64_t old_cap = c.capacity;
+                c.capacity *= 2; c.nb_segments *= 2; c.height += 1;
+                compute_bounds(P);
+                c.stat_extends += 1; c.stat_rebalances += 1; c.stat_window_slots += c.capacity;
+                root_rebalance(P, old_cap, c.capacity, c.y_m, false);
+                break;
+            }
+            case SEQ_Y_SHRINK: {       // pack! + _shrink!  src/pma.jl:135-139,153-161 then _even_rebalance!
+                const int64_t old_cap = c.capacity;
+                c.capacity /= 2; c.nb_segments /= 2; c.height -= 1;
+                compute_bounds(P);
+                c.stat_shrinks += 1; c.stat_rebalances += 1; c.stat_window_slots += c.capacity;
+                root_rebalance(P, old_cap, c.capacity, c.y_m, false);
+                break;
+            }
+            case SEQ_Y_TABLE_GROW:
+                ensure_tables(P, c.table_len + 1);
+                break;
+            default:
+                fail(DSA_EASSERT, "unknown sequencer status");
+        }
+        upload_ctl(P);
+        if (guard > 4 * n + 1000000) fail(DSA_EASSERT, "sequencer made no progress");
+    }
+}
+
+void pma_info(Pma& P, int64_t nb_partitions_or_len, int64_t* info) {
+    const Ctl& c = *P.h_ctl;
+    std::memset(info, 0, sizeof(int64_t) * DSA_INFO_COUNT);
+    info[DSA_INFO_CAPACITY] = c.capacity;
+    info[DSA_INFO_SEGMENT_CAPACITY] = c.segment_capacity;
+    info[DSA_INFO_NB_SEGMENTS] = c.nb_segments;
+    info[DSA_INFO_NB_ELEMENTS] = c.nb_elements;
+    info[DSA_INFO_HEIGHT] = c.height;
+    info[DSA_INFO_NB_PARTITIONS] = nb_partitions_or_len;
+    info[DSA_INFO_TABLE_LEN] = c.table_len;
+    info[DSA_INFO_STAT_WINDOW_SLOTS] = c.stat_window_slots;
+    info[DSA_INFO_STAT_REBALANCES] = c.stat_rebalances;
+    info[DSA_INFO_STAT_EXTENDS] = c.stat_extends;
+    info[DSA_INFO_STAT_SHRINKS] = c.stat_shrinks;
+}
+
+void export_slots(Pma& P, int64_t* keys, double* vals, uint8_t* occ, int64_t cap) {
+    const int64_t c = P.capacity();
+    if (cap < c) fail(DSA_ECAP, "output buffers smaller than capacity");
+    std::vector<uint64_t> words((size_t)((c + 63) / 64));
+    HIPCHK(hipMemcpyAsync(keys, P.K(), (size_t)c * sizeof(int64_t), hipMemcpyDeviceToHost, P.stream));
+    HIPCHK(hipMemcpyAsync(vals, P.V(), (size_t)c * sizeof(double), hipMemcpyDeviceToHost, P.stream));
+    HIPCHK(hipMemcpyAsync(words.data(), P.O(), words.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, P.stream));
+    HIPCHK(hipStreamSynchronize(P.stream));
+    for (int64_t i = 0; i < c; ++i) {
+        const uint8_t o = (words[(size_t)(i >> 6)] >> (i & 63)) & 1ull;
+        occ[i] = o;
+        if (!o) { keys[i] = 0; vals[i] = 0.0; }
+    }
+}
+
+void export_tables(Pma& P, int64_t* semaphores, int64_t* col_keys, uint8_t* col_live, int64_t table_cap) {
+    const int64_t tl = P.h_ctl->table_len;
+    if (table_cap < tl) fail(DSA_ECAP, "table buffers too small");
+    if (tl == 0) return;
+    HIPCHK(hipMemcpyAsync(semaphores, P.sems, (size_t)tl * sizeof(int64_t), hipMemcpyDeviceToHost, P.stream));
+    if (col_keys) {
+        HIPCHK(hipMemcpyAsync(col_keys, P.col_keys, (size_t)tl * sizeof(int64_t), hipMemcpyDeviceToHost, P.stream));
+        HIPCHK(hipMemcpyAsync(col_live, P.col_live, (size_t)tl, hipMemcpyDeviceToHost, P.stream));
+    }
+    HIPCHK(hipStreamSynchronize(P.stream));
+    if (col_keys) for (int64_t i = 0; i < tl; ++i) if (!col_live[i]) col_keys[i] = 0;
+}
+
+void ensure_q(Pma& P, int64_t n) {
+    if (n <= P.q_cap) return;
+    if (P.d_q) hipFree(P.d_q);
+    P.q_cap = std::max<int64_t>(n, 256);
+    HIPCHK(hipMalloc(&P.d_q, (size_t)P.q_cap * 3 * sizeof(double)));
+}
+
+// batched getindex on the device; mode as in launch_get_batch
+void get_batch(Pma& P, int mode, const int64_t* qa, const int64_t* qb, int64_t n, double* out) {
+    if (n <= 0) return;
+    ensure_q(P, n);
+    int64_t* d_qa = reinterpret_cast<int64_t*>(P.d_q);
+    int64_t* d_qb = d_qa + P.q_cap;
+    double* d_out = P.d_q + 2 * P.q_cap;
+    HIPCHK(hipMemcpyAsync(d_qa, qa, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, P.stream));
+    if (qb) HIPCHK(hipMemcpyAsync(d_qb, qb, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, P.stream));
+    HIPCHK(hipMemsetAsync(P.d_err, 0, sizeof(int32_t), P.stream));
+    hipError_t e = launch_get_batch(mode, P.K(), P.V(), P.O(), P.capacity(), P.sems, P.col_keys, P.col_live, P.h_ctl->table_len,
+                                    d_qa, d_qb, n, d_out, P.d_err, P.stream);
+    if (e != hipSuccess) fail(DSA_EHIP, std::string("get launch: ") + hipGetErrorString(e));
+    int32_t err = 0;
+    HIPCHK(hipMemcpyAsync(out, d_out, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, P.stream));
+    HIPCHK(hipMemcpyAsync(&err, P.d_err, sizeof(int32_t), hipMemcpyDeviceToHost, P.stream));
+    HIPCHK(hipStreamSynchronize(P.stream));
+    if (err) fail(err, err == DSA_EBOUNDS ? "partition index out of range" : "partition has no semaphore");
+}
+
+// stored cells of the slot range [from, to] in slot order
+void read_range(Pma& P, int64_t from, int64_t to, std::vector<int64_t>& ks, std::vector<double>& vs) {
+    ks.clear(); vs.clear();
+    if (to < from) return;
+    const int64_t n = to - from + 1;
+    const int64_t w0 = (from - 1) >> 6, w1 = (to - 1) >> 6;
+    std::vector<int64_t> k((size_t)n); std::vector<double> v((size_t)n); std::vector<uint64_t> o((size_t)(w1 - w0 + 1));
+    HIPCHK(hipMemcpyAsync(k.data(), P.K() + (from - 1), (size_t)n * sizeof(int64_t), hipMemcpyDeviceToHost, P.stream));
+    HIPCHK(hipMemcpyAsync(v.data(), P.V() + (from - 1), (size_t)n * sizeof(double), hipMemcpyDeviceToHost, P.stream));
+    HIPCHK(hipMemcpyAsync(o.data(), P.O() + w0, o.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, P.stream));
+    HIPCHK(hipStreamSynchronize(P.stream));
+    for (int64_t i = 0; i < n; ++i) {
+        const int64_t s = from - 1 + i;
+        if ((o[(size_t)((s >> 6) - w0)] >> (s & 63)) & 1ull) { ks.push_back(k[(size_t)i]); vs.push_back(v[(size_t)i]); }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host-side preparation of the bulk builders
+// ------------------------------------------------------------------------------------------------
+double combine_apply(int32_t op, double a, double b) {
+    switch (op) {
+        case DSA_COMBINE_ADD: return a + b;
+        case DSA_COMBINE_MUL: return a * b;
+        default: return b;
+    }
+}
+
+// _prepare_keys_vals!  src/vector.jl:10-36 : stable sort by key, left fold of duplicates
+void prepare_keys_vals(std::vector<int64_t>& keys, std::vector<double>& vals, int32_t combine) {
+    const size_t n = keys.size();
+    if (n == 0) return;
+    std::vector<uint32_t> perm(n);
+    std::iota(perm.begin(), perm.end(), 0u);
+    std::stable_sort(perm.begin(), perm.end(), [&](uint32_t a, uint32_t b) { return keys[a] < keys[b]; });
+    std::vector<int64_t> k2; std::vector<double> v2;
+    k2.reserve(n); v2.reserve(n);
+    for (size_t i = 0; i < n; ++i) {
+        const int64_t k = keys[perm[i]]; const double v = vals[perm[i]];
+        if (!k2.empty() && k2.back() == k) v2.back() = combine_apply(combine, v2.back(), v);
+        else { k2.push_back(k); v2.push_back(v); }
+    }
+    keys.swap(k2); vals.swap(v2);
+}
+
+// _dynamicsparse  src/pcsr.jl:354-431 + PackedCSC ctor :26-63 : (part, key, val) triples -> the ordered
+// cell stream [sem(0,id), entries...] per partition, and the partition keys.  The reference's QuickSort
+// is unstable; duplicates are folded here in input order (one of its legal outcomes).
+void build_cell_stream(const int64_t* part, const int64_t* key, const double* val, int64_t nnz, int32_t combine,
+                       std::vector<int64_t>& ck, std::vector<int64_t>& out_keys, std::vector<double>& out_vals) {
+    struct T { int64_t p, k; uint32_t i; };
+    std::vector<T> t((size_t)nnz);
+    for (int64_t i = 0; i < nnz; ++i) t[(size_t)i] = T{part[i], key[i], (uint32_t)i};
+    std::sort(t.begin(), t.end(), [](const T& a, const T& b) {
+        if (a.p != b.p) return a.p < b.p;
+        if (a.k != b.k) return a.k < b.k;
+        return a.i < b.i;
+    });
+    ck.clear(); out_keys.clear(); out_vals.clear();
+    out_keys.reserve((size_t)nnz + (size_t)nnz / 4 + 16); out_vals.reserve((size_t)nnz + (size_t)nnz / 4 + 16);
+    for (size_t j = 0; j < t.size(); ++j) {
+        const bool new_part = (j == 0 || t[j].p != t[j - 1].p);
+        if (new_part) {
+            ck.push_back(t[j].p);
+            out_keys.push_back(SEM_KEY);
+            out_vals.push_back((double)ck.size());
+        }
+        if (!new_part && t[j].k == t[j - 1].k) out_vals.back() = combine_apply(combine, out_vals.back(), val[t[j].i]);
+        else { out_keys.push_back(t[j].k); out_vals.push_back(val[t[j].i]); }
+    }
+}
+
+// semaphores[] positions are written by the spread kernel; col_keys / live come from the host
+void mpcsc_build(Pma& P, const int64_t* part, const int64_t* key, const double* val, int64_t nnz, int32_t combine) {
+    std::vector<int64_t> ck, ks; std::vector<double> vs;
+    if (nnz > 0) build_cell_stream(part, key, val, nnz, combine, ck, ks, vs);
+    const int64_t np = (int64_t)ck.size();
+    P.h_ctl->nb_partitions = np; P.h_ctl->table_len = np;
+    ensure_tables(P, std::max<int64_t>(2 * np, 64));
+    if (np > 0 && P.has_cols) {
+        std::vector<uint8_t> live((size_t)np, 1);
+        HIPCHK(hipMemcpyAsync(P.col_keys, ck.data(), (size_t)np * sizeof(int64_t), hipMemcpyHostToDevice, P.stream));
+        HIPCHK(hipMemcpyAsync(P.col_live, live.data(), (size_t)np, hipMemcpyHostToDevice, P.stream));
+        HIPCHK(hipStreamSynchronize(P.stream));
+    }
+    build_from_packed(P, ks, vs);
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// handles
+// ------------------------------------------------------------------------------------------------
+struct dsa_vec { Pma P; int64_t n = 0; };
+struct dsa_pcsc { Pma P; };
+struct FillBuffer {     // Buffer  src/buffer.jl:1-4 (host staging in the reference too)
+    std::unordered_map<int64_t, size_t> index;
+    std::vector<int64_t> rowids;
+    std::vector<std::vector<int64_t>> colids;
+    std::vector<std::vector<double>> vals;
+    int64_t length = 0;
+};
+struct dsa_mat {
+    int64_t m = 0, n = 0;
+    bool fillmode = false;
+    FillBuffer buf;
+    bool has_major = false;
+    Pma col, row;          // colmajor / rowmajor MappedPackedCSC
+    double* d_x = nullptr; double* d_y = nullptr; int64_t x_cap = 0, y_cap = 0;
+};
+
+namespace {
+
+void mat_build_major(dsa_mat* h, const int64_t* I, const int64_t* J, const double* V, int64_t nnz) {
+    pma_init_common(h->col, true, true);
+    pma_init_common(h->row, true, true);
+    mpcsc_build(h->col, J, I, V, nnz, DSA_COMBINE_ADD);      // dynamicsparsecolmajor(I, J, V)
+    mpcsc_build(h->row, I, J, V, nnz, DSA_COMBINE_ADD);      // dynamicsparsecolmajor(J, I, V)
+    h->has_major = true;
+}
+
+Pma& orient(dsa_mat* h, int32_t o) {
+    if (!h->has_major) fail(DSA_EMODE, "matrix is in fill mode");
+    if (o != DSA_COLMAJOR && o != DSA_ROWMAJOR) fail(DSA_EARG, "orientation must be 0 or 1");
+    return o == DSA_COLMAJOR ? h->col : h->row;
+}
+
+void check_key(int64_t k) { if (k == 0) fail(DSA_EKEY, "0 is the reserved semaphore key (src/pcsr.jl:23)"); }
+
+Op make_op(int32_t kind, int64_t a, int64_t b, double v) { Op o; o.a = a; o.b = b; o.v = v; o.kind = kind; o.pad = 0; return o; }
+
+// setindex! on both orientations for ops [0, n)  src/matrix.jl:53-59
+void mat_apply_sets(dsa_mat* h, const int64_t* I, const int64_t* J, const double* V, int64_t n) {
+    std::vector<Op> oc((size_t)n), orw((size_t)n);
+    for (int64_t k = 0; k < n; ++k) {
+        oc[(size_t)k] = make_op(OP_MPCSC_SET, I[k], J[k], V[k]);      // colmajor[row, col] = val
+        orw[(size_t)k] = make_op(OP_MPCSC_SET, J[k], I[k], V[k]);     // rowmajor[col, row] = val
+    }
+    int32_t err = 0;
+    const int64_t done = run_ops(h->col, oc, &err);
+    for (int64_t k = 0; k < done; ++k) if (V[k] != 0.0) { h->m = std::max(h->m, I[k]); h->n = std::max(h->n, J[k]); }
+    if (err) {
+        // the failing write had already updated size(m) in the reference (src/matrix.jl:44-47)
+        if (V[done] != 0.0) { h->m = std::max(h->m, I[done]); h->n = std::max(h->n, J[done]); }
+        orw.resize((size_t)done);
+        int32_t e2 = 0;
+        run_ops(h->row, orw, &e2);
+        fail(err, err_text(err));
+    }
+    run_ops(h->row, orw, &err);
+    if (err) fail(err, err_text(err));
+}
+
+void col_view_of(Pma& P, int64_t col, std::vector<int64_t>& ks, std::vector<double>& vs) {
+    ks.clear(); vs.clear();
+    hipError_t e = launch_partition_range(P.sems, P.col_keys, P.col_live, P.h_ctl->table_len, P.capacity(), col, P.d_small, P.stream);
+    if (e != hipSuccess) fail(DSA_EHIP, std::string("range launch: ") + hipGetErrorString(e));
+    int64_t r[4] = {0, 0, 0, 0};
+    HIPCHK(hipMemcpyAsync(r, P.d_small, sizeof(r), hipMemcpyDeviceToHost, P.stream));
+    HIPCHK(hipStreamSynchronize(P.stream));
+    if (r[2] != 0) fail((int32_t)r[2], "partition has no semaphore");
+    if (r[0] == 0) return;       // empty view: the column does not exist (src/views.jl:17,24)
+    read_range(P, r[0], r[1], ks, vs);
+}
+
+void ensure_xy(dsa_mat* h, int64_t nx, int64_t ny) {
+    if (nx > h->x_cap) { if (h->d_x) hipFree(h->d_x); h->x_cap = std::max<int64_t>(nx, 1024); HIPCHK(hipMalloc(&h->d_x, (size_t)h->x_cap * sizeof(double))); }
+    if (ny > h->y_cap) { if (h->d_y) hipFree(h->d_y); h->y_cap = std::max<int64_t>(ny, 1024); HIPCHK(hipMalloc(&h->d_y, (size_t)h->y_cap * sizeof(double))); }
+}
+
+// mat * v walks the colmajor orientation in the reference (src/operations.jl:14-24), transpose(mat) * v the
+// rowmajor one (:26-36).  Gather form: the twin orientation, whose partitions are the OUTPUT index.
+void spmv_dev(dsa_mat* h, int32_t transpose, int32_t algo, const double* d_x, int64_t nx, double* d_y, int64_t ny, hipStream_t s,
+              int pattern = 0) {
+    if (!h->has_major) fail(DSA_EMODE, "matrix is in fill mode");
+    hipError_t e;
+    if (algo == 0) {
+        Pma& P = transpose ? h->col : h->row;
+        e = launch_spmv_gather(P.K(), P.V(), P.O(), P.capacity(), P.sems, P.col_keys, P.col_live, P.h_ctl->table_len, d_x, nx, d_y, ny, pattern, s);
+    } else if (algo == 1) {
+        Pma& P = transpose ? h->row : h->col;
+        e = launch_spmv_scatter(P.K(), P.V(), P.O(), P.capacity(), P.sems, P.col_keys, P.col_live, P.h_ctl->table_len, d_x, nx, d_y, ny, s);
+    } else {
+        fail(DSA_EARG, "algo must be 0 (gather) or 1 (scatter)");
+    }
+    if (e != hipSuccess) fail(DSA_EHIP, std::string("spmv launch: ") + hipGetErrorString(e));
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+const char* dsa_last_error_message(void) { return g_err.c_str(); }
+
+int32_t dsa_device_count(int32_t* count) {
+    API_TRY
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *count = 0; fail(DSA_EHIP, std::string("hipGetDeviceCount: ") + hipGetErrorString(e)); }
+    *count = n;
+    API_CATCH
+}
+int32_t dsa_set_device(int32_t device) {
+    API_TRY
+    HIPCHK(hipSetDevice(device));
+    g_device = device;
+    API_CATCH
+}
+
+// ---------------- vector ----------------
+int32_t dsa_vec_create(const int64_t* keys, const double* vals, int64_t n, int32_t combine_op, int64_t len, dsa_vec_t** out) {
+    API_TRY
+    if (n < 0) fail(DSA_EARG, "negative length");
+    std::vector<int64_t> k(keys, keys + n); std::vector<double> v(vals, vals + n);
+    if (len < 0) { len = 0; for (int64_t x : k) len = std::max(len, x); }      // _guess_length  src/vector.jl:6
+    prepare_keys_vals(k, v, combine_op);
+    auto* h = new dsa_vec();
+    try {
+        pma_init_common(h->P, false, false);
+        build_from_packed(h->P, k, v);
+    } catch (...) { pma_destroy(h->P); delete h; throw; }
+    h->n = len;
+    *out = h;
+    API_CATCH
+}
+int32_t dsa_vec_create_empty(dsa_vec_t** out) { return dsa_vec_create(nullptr, nullptr, 0, DSA_COMBINE_ADD, -1, out); }
+int32_t dsa_vec_destroy(dsa_vec_t* h) { if (h) { pma_destroy(h->P); delete h; } return DSA_OK; }
+
+int32_t dsa_vec_get_batch(dsa_vec_t* h, const int64_t* keys, int64_t n, double* out) {
+    API_TRY get_batch(h->P, 0, keys, nullptr, n, out); API_CATCH
+}
+int32_t dsa_vec_get(dsa_vec_t* h, int64_t key, double* out) { return dsa_vec_get_batch(h, &key, 1, out); }
+
+int32_t dsa_vec_set_batch(dsa_vec_t* h, const int64_t* keys, const double* vals, int64_t n) {
+    API_TRY
+    std::vector<Op> ops((size_t)n);
+    for (int64_t i = 0; i < n; ++i) ops[(size_t)i] = make_op(OP_VEC_SET, keys[i], 0, vals[i]);
+    int32_t err = 0;
+    const int64_t done = run_ops(h->P, ops, &err);
+    const int64_t upto = err ? std::min(done + 1, n) : done;          // v.n is updated before the write (src/vector.jl:77-79)
+    for (int64_t i = 0; i < upto; ++i) if (vals[i] != 0.0) h->n = std::max(h->n, keys[i]);
+    if (err) fail(err, err_text(err));
+    API_CATCH
+}
+int32_t dsa_vec_set(dsa_vec_t* h, int64_t key, double val) { return dsa_vec_set_batch(h, &key, &val, 1); }
+int32_t dsa_vec_nnz(dsa_vec_t* h, int64_t* out) { *out = h->P.h_ctl->nb_elements; return DSA_OK; }
+int32_t dsa_vec_len(dsa_vec_t* h, int64_t* out) { *out = h->n; return DSA_OK; }
+
+int32_t dsa_vec_nonzeros(dsa_vec_t* h, int64_t* keys, double* vals, int64_t cap, int64_t* n_out) {
+    API_TRY
+    std::vector<int64_t> ks; std::vector<double> vs;
+    read_range(h->P, 1, h->P.capacity(), ks, vs);
+    if ((int64_t)ks.size() > cap) fail(DSA_ECAP, "output buffers too small");
+    std::copy(ks.begin(), ks.end(), keys); std::copy(vs.begin(), vs.end(), vals);
+    *n_out = (int64_t)ks.size();
+    API_CATCH
+}
+int32_t dsa_vec_shrink_size(dsa_vec_t* h) {     // shrink_size!  src/vector.jl:64 (+ _guess_length :7-8)
+    API_TRY
+    std::vector<int64_t> ks; std::vector<double> vs;
+    read_range(h->P, 1, h->P.capacity(), ks, vs);
+    int64_t n = 0;
+    for (int64_t k : ks) n = std::max(n, k);
+    h->n = n;
+    API_CATCH
+}
+int32_t dsa_vec_info(dsa_vec_t* h, int64_t* info) { pma_info(h->P, h->n, info); return DSA_OK; }
+int32_t dsa_vec_export_layout(dsa_vec_t* h, int64_t* keys, double* vals, uint8_t* occ, int64_t cap) {
+    API_TRY export_slots(h->P, keys, vals, occ, cap); API_CATCH
+}
+int32_t dsa_vec_rebalance_root(dsa_vec_t* h) {
+    API_TRY
+    Pma& P = h->P;
+    if (P.capacity() != P.h_ctl->segment_capacity) {
+        P.h_ctl->stat_rebalances += 1; P.h_ctl->stat_window_slots += P.capacity();
+        root_rebalance(P, P.capacity(), P.capacity(), P.h_ctl->nb_elements, false);
+    }
+    API_CATCH
+}
+int32_t dsa_vec_set_stream(dsa_vec_t* h, void* s) {
+    API_TRY
+    HIPCHK(hipStreamSynchronize(h->P.stream));
+    if (h->P.own_stream) hipStreamDestroy(h->P.stream);
+    h->P.stream = (hipStream_t)s; h->P.own_stream = false;
+    API_CATCH
+}
+int32_t dsa_vec_sync(dsa_vec_t* h) { API_TRY HIPCHK(hipStreamSynchronize(h->P.stream)); API_CATCH }
+
+// ---------------- PackedCSC ----------------
+int32_t dsa_pcsc_create(const int64_t* colptr, int64_t nparts, const int64_t* row_keys, const double* vals,
+                        int32_t combine_op, dsa_pcsc_t** out) {
+    API_TRY
+    if (nparts <= 0) fail(DSA_EARG, "PackedCSC needs at least one partition");
+    std::vector<int64_t> ks; std::vector<double> vs;
+    for (int64_t p = 0; p < nparts; ++p) {        // src/pcsr.jl:36-51
+        ks.push_back(SEM_KEY); vs.push_back((double)(p + 1));
+        std::vector<int64_t> nk(row_keys + colptr[p], row_keys + colptr[p + 1]);
+        std::vector<double> nv(vals + colptr[p], vals + colptr[p + 1]);
+        prepare_keys_vals(nk, nv, combine_op);
+        ks.insert(ks.end(), nk.begin(), nk.end()); vs.insert(vs.end(), nv.begin(), nv.end());
+    }
+    auto* h = new dsa_pcsc();
+    try {
+        pma_init_common(h->P, true, false);
+        h->P.h_ctl->nb_partitions = nparts; h->P.h_ctl->table_len = nparts;
+        ensure_tables(h->P, std::max<int64_t>(2 * nparts, 64));
+        build_from_packed(h->P, ks, vs);
+    } catch (...) { pma_destroy(h->P); delete h; throw; }
+    *out = h;
+    API_CATCH
+}
+int32_t dsa_pcsc_create_empty(dsa_pcsc_t** out) {
+    API_TRY
+    auto* h = new dsa_pcsc();
+    try {
+        pma_init_common(h->P, true, false);
+        ensure_tables(h->P, 64);
+        build_from_packed(h->P, {}, {});
+    } catch (...) { pma_destroy(h->P); delete h; throw; }
+    *out = h;
+    API_CATCH
+}
+int32_t dsa_pcsc_destroy(dsa_pcsc_t* h) { if (h) { pma_destroy(h->P); delete h; } return DSA_OK; }
+int32_t dsa_pcsc_get(dsa_pcsc_t* h, int64_t key, int64_t partition, double* out) {
+    API_TRY get_batch(h->P, 1, &key, &partition, 1, out); API_CATCH
+}
+int32_t dsa_pcsc_set(dsa_pcsc_t* h, double val, int64_t key, int64_t partition) {
+    API_TRY
+    if (partition > h->P.h_ctl->table_len + (1 << 24)) fail(DSA_EARG, "partition index unreasonably far past the last partition");
+    std::vector<Op> ops{make_op(OP_PCSC_SET, key, partition, val)};
+    int32_t err = 0;
+    run_ops(h->P, ops, &err);
+    if (err) fail(err, err_text(err));
+    API_CATCH
+}
+int32_t dsa_pcsc_deletepartition(dsa_pcsc_t* h, int64_t partition) {
+    API_TRY
+    std::vector<Op> ops{make_op(OP_DELETE_PARTITION, 0, partition, 0.0)};
+    int32_t err = 0;
+    run_ops(h->P, ops, &err);
+    if (err) fail(err, err_text(err));
+    API_CATCH
+}
+int32_t dsa_pcsc_nnz(dsa_pcsc_t* h, int64_t* out) { *out = h->P.h_ctl->nb_elements - h->P.h_ctl->nb_partitions; return DSA_OK; }
+int32_t dsa_pcsc_nbpartitions(dsa_pcsc_t* h, int64_t* out) { *out = h->P.h_ctl->nb_partitions; return DSA_OK; }
+int32_t dsa_pcsc_info(dsa_pcsc_t* h, int64_t* info) { pma_info(h->P, h->P.h_ctl->nb_partitions, info); return DSA_OK; }
+int32_t dsa_pcsc_export_layout(dsa_pcsc_t* h, int64_t* keys, double* vals, uint8_t* occ, int64_t cap,
+                               int64_t* semaphores, int64_t table_cap) {
+    API_TRY
+    export_slots(h->P, keys, vals, occ, cap);
+    export_tables(h->P, semaphores, nullptr, nullptr, table_cap);
+    API_CATCH
+}
+
+// ---------------- matrix ----------------
+int32_t dsa_mat_create_from_coo(const int64_t* I, const int64_t* J, const double* V, int64_t nnz, int64_t m, int64_t n,
+                                dsa_mat_t** out) {
+    API_TRY
+    if (nnz < 0) fail(DSA_EARG, "negative length");
+    if (nnz > 0xffffffffll) fail(DSA_EARG, "more than 2^32-1 triples in one call");
+    for (int64_t k = 0; k < nnz; ++k) { check_key(I[k]); check_key(J[k]); }
+    if (m < 0) { m = 0; for (int64_t k = 0; k < nnz; ++k) m = std::max(m, I[k]); }
+    if (n < 0) { n = 0; for (int64_t k = 0; k < nnz; ++k) n = std::max(n, J[k]); }
+    auto* h = new dsa_mat();
+    try { mat_build_major(h, I, J, V, nnz); } catch (...) { pma_destroy(h->col); pma_destroy(h->row); delete h; throw; }
+    h->m = m; h->n = n;
+    *out = h;
+    API_CATCH
+}
+int32_t dsa_mat_create_empty(int32_t fill_mode, dsa_mat_t** out) {
+    API_TRY
+    auto* h = new dsa_mat();
+    if (fill_mode) {
+        HIPCHK(hipSetDevice(g_device));     // fail loudly without a device even though nothing is allocated yet
+        h->fillmode = true;
+    } else {
+        try { mat_build_major(h, nullptr, nullptr, nullptr, 0); } catch (...) { pma_destroy(h->col); pma_destroy(h->row); delete h; throw; }
+    }
+    *out = h;
+    API_CATCH
+}
+int32_t dsa_mat_destroy(dsa_mat_t* h) {
+    if (h) {
+        if (h->has_major) { pma_destroy(h->col); pma_destroy(h->row); }
+        if (h->d_x) hipFree(h->d_x);
+        if (h->d_y) hipFree(h->d_y);
+        delete h;
+    }
+    return DSA_OK;
+}
+
+static void fill_addelem(FillBuffer& b, int64_t row, int64_t col, double val) {   // addelem!  src/buffer.jl:20-31
+    auto it = b.index.find(row);
+    size_t r;
+    if (it == b.index.end()) {
+        r = b.rowids.size();
+        b.index.emplace(row, r);
+        b.rowids.push_back(row); b.colids.emplace_back(); b.vals.emplace_back();
+    } else r = it->second;
+    b.colids[r].push_back(col); b.vals[r].push_back(val);
+    b.length += 1;
+}
+
+int32_t dsa_mat_set_batch(dsa_mat_t* h, const int64_t* I, const int64_t* J, const double* V, int64_t n) {
+    API_TRY
+    for (int64_t k = 0; k < n; ++k) { check_key(I[k]); check_key(J[k]); }
+    if (h->fillmode) {
+        for (int64_t k = 0; k < n; ++k) {
+            if (V[k] != 0.0) { h->m = std::max(h->m, I[k]); h->n = std::max(h->n, J[k]); }
+            fill_addelem(h->buf, I[k], J[k], V[k]);
+        }
+    } else {
+        mat_apply_sets(h, I, J, V, n);
+    }
+    API_CATCH
+}
+int32_t dsa_mat_set(dsa_mat_t* h, double val, int64_t row, int64_t col) { return dsa_mat_set_batch(h, &row, &col, &val, 1); }
+
+int32_t dsa_mat_get_batch(dsa_mat_t* h, const int64_t* I, const int64_t* J, int64_t n, double* out) {
+    API_TRY
+    if (h->fillmode) fail(DSA_EMODE, "getindex(row, col) is not available in fill mode.");
+    get_batch(h->col, 2, I, J, n, out);
+    API_CATCH
+}
+int32_t dsa_mat_get(dsa_mat_t* h, int64_t row, int64_t col, double* out) { return dsa_mat_get_batch(h, &row, &col, 1, out); }
+
+int32_t dsa_mat_addrow(dsa_mat_t* h, int64_t row, const int64_t* colids, const double* vals, int64_t n) {
+    API_TRY
+    check_key(row);
+    for (int64_t k = 0; k < n; ++k) check_key(colids[k]);
+    if (h->fillmode) {     // addrow!(buffer, ...)  src/buffer.jl:10-18
+        FillBuffer& b = h->buf;
+        if (b.index.count(row)) fail(DSA_EMODE, "Row already written in dynamic sparse matrix buffer.");
+        std::vector<size_t> perm((size_t)n);
+        std::iota(perm.begin(), perm.end(), (size_t)0);
+        std::stable_sort(perm.begin(), perm.end(), [&](size_t a, size_t c) { return colids[a] < colids[c]; });
+        const size_t r = b.rowids.size();
+        b.index.emplace(row, r);
+        b.rowids.push_back(row); b.colids.emplace_back((size_t)n); b.vals.emplace_back((size_t)n);
+        for (size_t i = 0; i < (size_t)n; ++i) { b.colids[r][i] = colids[perm[i]]; b.vals[r][i] = vals[perm[i]]; }
+        b.length += n;
+    } else {               // src/matrix.jl:119-121
+        std::vector<int64_t> rows((size_t)n, row);
+        mat_apply_sets(h, rows.data(), colids, vals, n);
+    }
+    API_CATCH
+}
+
+int32_t dsa_mat_closefillmode(dsa_mat_t* h) {     // closefillmode!  src/matrix.jl:126-134
+    API_TRY
+    if (!h->fillmode) fail(DSA_EMODE, "Cannot close fill mode because matrix is not in fill mode.");
+    std::vector<int64_t> I, J; std::vector<double> V;     // get_rowids_colids_vals  src/buffer.jl:33-50
+    I.reserve((size_t)h->buf.length); J.reserve((size_t)h->buf.length); V.reserve((size_t)h->buf.length);
+    for (size_t r = 0; r < h->buf.rowids.size(); ++r)
+        for (size_t i = 0; i < h->buf.vals[r].size(); ++i) {
+            I.push_back(h->buf.rowids[r]); J.push_back(h->buf.colids[r][i]); V.push_back(h->buf.vals[r][i]);
+        }
+    mat_build_major(h, I.data(), J.data(), V.data(), (int64_t)I.size());
+    h->fillmode = false;
+    h->buf = FillBuffer();
+    API_CATCH
+}
+
+int32_t dsa_mat_deletecolumn(dsa_mat_t* h, int64_t col) {      // src/matrix.jl:95-102
+    API_TRY
+    if (h->fillmode) fail(DSA_EMODE, "Cannot delete a column in fill mode");
+    std::vector<int64_t> rows; std::vector<double> vals;
+    col_view_of(h->col, col, rows, vals);
+    std::vector<Op> ops;
+    for (int64_t r : rows) ops.push_back(make_op(OP_MPCSC_SET, col, r, 0.0));     // rowmajor[col, row] = 0
+    int32_t err = 0;
+    run_ops(h->row, ops, &err);
+    if (err) fail(err, err_text(err));
+    std::vector<Op> del{make_op(OP_MPCSC_DELETECOLUMN, 0, col, 0.0)};
+    run_ops(h->col, del, &err);
+    if (err) fail(err, err_text(err));
+    API_CATCH
+}
+int32_t dsa_mat_deleterow(dsa_mat_t* h, int64_t row) {         // src/matrix.jl:104-111
+    API_TRY
+    if (h->fillmode) fail(DSA_EMODE, "Cannot delete a row in fill mode");
+    std::vector<int64_t> cols; std::vector<double> vals;
+    col_view_of(h->row, row, cols, vals);
+    std::vector<Op> ops;
+    for (int64_t c : cols) ops.push_back(make_op(OP_MPCSC_SET, row, c, 0.0));     // colmajor[row, col] = 0
+    int32_t err = 0;
+    run_ops(h->col, ops, &err);
+    if (err) fail(err, err_text(err));
+    std::vector<Op> del{make_op(OP_MPCSC_DELETECOLUMN, 0, row, 0.0)};
+    run_ops(h->row, del, &err);
+    if (err) fail(err, err_text(err));
+    API_CATCH
+}
+
+static int32_t view_impl(dsa_mat_t* h, int32_t o, int64_t key, int64_t* ks, double* vs, int64_t cap, int64_t* n_out) {
+    API_TRY
+    if (h->fillmode) fail(DSA_EMODE, "View not available in fill mode.");
+    std::vector<int64_t> k; std::vector<double> v;
+    col_view_of(orient(h, o), key, k, v);
+    if ((int64_t)k.size() > cap) fail(DSA_ECAP, "output buffers too small");
+    std::copy(k.begin(), k.end(), ks); std::copy(v.begin(), v.end(), vs);
+    *n_out = (int64_t)k.size();
+    API_CATCH
+}
+int32_t dsa_mat_col_view(dsa_mat_t* h, int64_t col, int64_t* rows, double* vals, int64_t cap, int64_t* n_out) {
+    return view_impl(h, DSA_COLMAJOR, col, rows, vals, cap, n_out);
+}
+int32_t dsa_mat_row_view(dsa_mat_t* h, int64_t row, int64_t* cols, double* vals, int64_t cap, int64_t* n_out) {
+    return view_impl(h, DSA_ROWMAJOR, row, cols, vals, cap, n_out);
+}
+int32_t dsa_mat_nnz(dsa_mat_t* h, int64_t* out) {      // nnz(m) = nnz(m.rowmajor)  src/matrix.jl:91
+    API_TRY Pma& P = orient(h, DSA_ROWMAJOR); *out = P.h_ctl->nb_elements - P.h_ctl->nb_partitions; API_CATCH
+}
+int32_t dsa_mat_size(dsa_mat_t* h, int64_t* m, int64_t* n) { *m = h->m; *n = h->n; return DSA_OK; }
+int32_t dsa_mat_nbpartitions(dsa_mat_t* h, int32_t o, int64_t* out) { API_TRY *out = orient(h, o).h_ctl->nb_partitions; API_CATCH }
+int32_t dsa_mat_info(dsa_mat_t* h, int32_t o, int64_t* info) { API_TRY Pma& P = orient(h, o); pma_info(P, P.h_ctl->nb_partitions, info); API_CATCH }
+int32_t dsa_mat_export_layout(dsa_mat_t* h, int32_t o, int64_t* keys, double* vals, uint8_t* occ, int64_t cap,
+                              int64_t* semaphores, int64_t* col_keys, uint8_t* col_live, int64_t table_cap) {
+    API_TRY
+    Pma& P = orient(h, o);
+    export_slots(P, keys, vals, occ, cap);
+    export_tables(P, semaphores, col_keys, col_live, table_cap);
+    API_CATCH
+}
+int32_t dsa_mat_rebalance_root(dsa_mat_t* h, int32_t o) {
+    API_TRY
+    Pma& P = orient(h, o);
+    if (P.capacity() != P.h_ctl->segment_capacity) {
+        P.h_ctl->stat_rebalances += 1; P.h_ctl->stat_window_slots += P.capacity();
+        root_rebalance(P, P.capacity(), P.capacity(), P.h_ctl->nb_elements, false);
+    }
+    API_CATCH
+}
+
+int32_t dsa_mat_spmv_dense_dev(dsa_mat_t* h, int32_t transpose, int32_t algo, const double* d_x, int64_t nx, double* d_y, int64_t ny) {
+    API_TRY
+    Pma& P = transpose ? h->col : h->row;
+    spmv_dev(h, transpose, algo, d_x, nx, d_y, ny, P.stream);
+    API_CATCH
+}
+
+int32_t dsa_mat_spmv_dense(dsa_mat_t* h, int32_t transpose, const double* x, int64_t nx, double* y, int64_t ny) {
+    API_TRY
+    if (!h->has_major) fail(DSA_EMODE, "matrix is in fill mode");
+    if (nx < 0 || ny < 0) fail(DSA_EARG, "negative length");
+    ensure_xy(h, nx, ny);
+    Pma& P = transpose ? h->col : h->row;
+    if (nx > 0) HIPCHK(hipMemcpyAsync(h->d_x, x, (size_t)nx * sizeof(double), hipMemcpyHostToDevice, P.stream));
+    if (ny > 0) {
+        spmv_dev(h, transpose, 0, h->d_x, nx, h->d_y, ny, P.stream);
+        HIPCHK(hipMemcpyAsync(y, h->d_y, (size_t)ny * sizeof(double), hipMemcpyDeviceToHost, P.stream));
+    }
+    HIPCHK(hipStreamSynchronize(P.stream));
+    API_CATCH
+}
+
+// sparse x: densify x, run the gather kernel for the values and once more on the 0/1 pattern of x to
+// obtain the touched rows (the result shape of _mul_output, src/operations.jl:11-12)
+int32_t dsa_mat_spmv_sparse(dsa_mat_t* h, int32_t transpose, const int64_t* xi, const double* xv, int64_t nx,
+                            int64_t* yi, double* yv, int64_t cap, int64_t* n_out) {
+    API_TRY
+    if (!h->has_major) fail(DSA_EMODE, "matrix is in fill mode");
+    const int64_t ny = transpose ? h->n : h->m;
+    int64_t nxd = 0;
+    for (int64_t i = 0; i < nx; ++i) {
+        if (i > 0 && xi[i] <= xi[i - 1]) fail(DSA_EARG, "indices of x must be strictly ascending");
+        nxd = std::max(nxd, xi[i]);
+    }
+    *n_out = 0;
+    if (ny <= 0 || nxd <= 0) return DSA_OK;
+    std::vector<double> xd((size_t)nxd, 0.0), xf((size_t)nxd, 0.0);
+    for (int64_t i = 0; i < nx; ++i) if (xi[i] >= 1) { xd[(size_t)(xi[i] - 1)] = xv[i]; xf[(size_t)(xi[i] - 1)] = 1.0; }
+    ensure_xy(h, nxd, 2 * ny);
+    Pma& P = transpose ? h->col : h->row;
+    std::vector<double> y((size_t)ny), pat((size_t)ny);
+    HIPCHK(hipMemcpyAsync(h->d_x, xd.data(), (size_t)nxd * sizeof(double), hipMemcpyHostToDevice, P.stream));
+    spmv_dev(h, transpose, 0, h->d_x, nxd, h->d_y, ny, P.stream);
+    HIPCHK(hipMemcpyAsync(y.data(), h->d_y, (size_t)ny * sizeof(double), hipMemcpyDeviceToHost, P.stream));
+    HIPCHK(hipStreamSynchronize(P.stream));
+    HIPCHK(hipMemcpyAsync(h->d_x, xf.data(), (size_t)nxd * sizeof(double), hipMemcpyHostToDevice, P.stream));
+    // pattern pass: same kernel, every cell whose x entry is stored contributes 1 -> touched rows
+    spmv_dev(h, transpose, 0, h->d_x, nxd, h->d_y + ny, ny, P.stream, 1);
+    HIPCHK(hipMemcpyAsync(pat.data(), h->d_y + ny, (size_t)ny * sizeof(double), hipMemcpyDeviceToHost, P.stream));
+    HIPCHK(hipStreamSynchronize(P.stream));
+    int64_t cnt = 0;
+    for (int64_t r = 0; r < ny; ++r) if (pat[(size_t)r] != 0.0) {
+        if (cnt >= cap) fail(DSA_ECAP, "output buffers too small");
+        yi[cnt] = r + 1; yv[cnt] = y[(size_t)r]; ++cnt;
+    }
+    *n_out = cnt;
+    API_CATCH
+}
+
+int32_t dsa_mat_set_stream(dsa_mat_t* h, void* s) {
+    API_TRY
+    if (!h->has_major) fail(DSA_EMODE, "matrix is in fill mode");
+    for (Pma* P : {&h->col, &h->row}) {
+        HIPCHK(hipStreamSynchronize(P->stream));
+        if (P->own_stream) hipStreamDestroy(P->stream);
+        P->stream = (hipStream_t)s; P->own_stream = false;
+    }
+    API_CATCH
+}
+int32_t dsa_mat_sync(dsa_mat_t* h) {
+    API_TRY
+    if (h->has_major) { HIPCHK(hipStreamSynchronize(h->col.stream)); HIPCHK(hipStreamSynchronize(h->row.stream)); }
+    API_CATCH
+}
+
+}  // extern "C"

@@ -1,0 +1,236 @@
+// csrc/rebalance.hip — K-pack + K-spread fused: the grid-wide window rebalance for gfx950.
+//
+// Reproduces  pack!  (src/moves.jl:94-110)  followed by  spread!  (src/moves.jl:120-171) of the
+// reference — i.e. _even_rebalance! (src/pma.jl:94-103, src/pcsr.jl:88-97), the full spread of
+// _pma (src/pma.jl:42-55) and the pack + _shrink! / _extend! paths (src/pma.jl:135-161) — as ONE
+// out-of-place pass: the r-th occupied source cell goes straight to the r-th non-gap offset of the
+// destination window, whose gaps sit at the closed-form offsets floor(fl(k*fl(W/E))) (dsa_dev.h).
+//
+// Bound: HBM.  Algorithmic bytes per W-slot window = 2 * 16 * W (read + write every slot);
+// the occupancy bitmap (W/8 B each way) and the tile counters are not counted.
+//
+//   k_tile_count : one wave per 4096-slot source tile, lane <-> occupancy word, popcount + wave reduce
+//   k_tile_scan  : one workgroup, exclusive prefix of the tile counts
+//   k_move       : one workgroup per 2048-slot DESTINATION tile.  Source cells whose rank falls in
+//                  the tile are compacted into LDS with wave64 ballot-style prefix popcounts (only
+//                  occupancy words that intersect the rank range are touched, so each source line is
+//                  read ~once), then every destination slot — gaps included, so lines are written
+//                  whole — is stored as 16-byte key / value pairs, the occupancy words are rebuilt
+//                  from two ballots, and semaphore positions are scattered to the table.
+#include "dsa_dev.h"
+
+namespace dsa {
+
+constexpr int SRC_TILE_WORDS = 64;                 // 4096 slots
+constexpr int64_t SRC_TILE = 64 * SRC_TILE_WORDS;
+constexpr int DST_TILE = 2048;
+constexpr int MOVE_BLOCK = 256;
+
+__device__ __forceinline__ uint64_t range_mask_for_word(int64_t w, int64_t lo0, int64_t hi0) {
+    // bits of word w (slots 64w .. 64w+63, 0-based) that lie inside [lo0, hi0] (0-based, inclusive)
+    const int64_t b = w << 6;
+    int64_t a = lo0 - b, z = hi0 - b;
+    if (z < 0 || a > 63) return 0ull;
+    if (a < 0) a = 0;
+    if (z > 63) z = 63;
+    const uint64_t upto = (z == 63) ? ~0ull : ((1ull << (z + 1)) - 1ull);
+    return upto & ~mask_lt((int)a);
+}
+
+__device__ __forceinline__ uint32_t wave_reduce_add(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v) {
+    const int lane = lane_id();
+    uint32_t x = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t y = __shfl_up(x, o, 64);
+        if (lane >= o) x += y;
+    }
+    return x - v;
+}
+
+__global__ __launch_bounds__(64) void k_tile_count(const uint64_t* __restrict__ occ, int64_t lo0, int64_t hi0,
+                                                   int64_t w0, int64_t nwords, uint32_t* __restrict__ tile_cnt) {
+    const int64_t t = blockIdx.x;
+    const int64_t w = t * SRC_TILE_WORDS + threadIdx.x;
+    uint32_t pc = 0;
+    if (w < nwords) pc = popc64(occ[w0 + w] & range_mask_for_word(w0 + w, lo0, hi0));
+    pc = wave_reduce_add(pc);
+    if (threadIdx.x == 0) tile_cnt[t] = pc;
+}
+
+__global__ __launch_bounds__(1024) void k_tile_scan(const uint32_t* __restrict__ cnt, uint32_t* __restrict__ off, int64_t n) {
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t carry_s;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < n; base += 1024) {
+        const int64_t i = base + tid;
+        const uint32_t v = i < n ? cnt[i] : 0u;
+        const uint32_t ex = wave_excl_scan(v);
+        if (lane == 63) wsum[wv] = ex + v;
+        __syncthreads();
+        uint32_t woff = 0;
+        for (int k = 0; k < wv; ++k) woff += wsum[k];
+        const uint32_t carry = carry_s;
+        if (i < n) off[i] = carry + woff + ex;
+        __syncthreads();
+        if (tid == 1023) carry_s = carry + woff + ex + v;
+        __syncthreads();
+    }
+    if (tid == 0) off[n] = carry_s;
+}
+
+struct MoveArgs {
+    const int64_t* src_keys; const double* src_vals; const uint64_t* src_occ;
+    int64_t src_lo0, src_hi0;      // 0-based inclusive source slot range
+    int64_t src_w0;                // first source occupancy word
+    int64_t* dst_keys; double* dst_vals; uint64_t* dst_occ;
+    int64_t dst_lo0;               // 0-based first destination slot (multiple of the window size)
+    int64_t Wd, m;
+    int64_t* sems;
+    const uint32_t* tile_off; int64_t ntiles;
+};
+
+template <bool PACKED>
+__global__ __launch_bounds__(MOVE_BLOCK) void k_move(MoveArgs a) {
+    __shared__ int64_t sK[DST_TILE];
+    __shared__ double sV[DST_TILE];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const SpreadGeom g = make_geom(a.Wd, a.m);
+    const int64_t q0 = (int64_t)blockIdx.x * DST_TILE;          // this tile covers offsets q0+1 .. qend
+    const int64_t qend = (q0 + DST_TILE < a.Wd) ? q0 + DST_TILE : a.Wd;
+    const int64_t kA = gaps_le(g, q0), kB = gaps_le(g, qend);
+    const int64_t R0 = q0 - kA;                                  // cells placed before this tile
+    const int64_t cnt = (qend - q0) - (kB - kA);                 // cells landing in this tile: ranks R0+1..R0+cnt
+
+    if (!PACKED && cnt > 0) {
+        // first source tile holding rank R0+1: the largest t with tile_off[t] <= R0
+        int64_t lo = 0, hi = a.ntiles - 1;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi + 1) >> 1;
+            if ((int64_t)a.tile_off[mid] <= R0) lo = mid; else hi = mid - 1;
+        }
+        for (int64_t t = lo; t < a.ntiles && (int64_t)a.tile_off[t] < R0 + cnt; ++t) {
+            const int64_t base = a.tile_off[t];
+            const int64_t wl = a.src_w0 + t * SRC_TILE_WORDS + lane;       // lane <-> word of the tile
+            const uint64_t myword = a.src_occ[wl] & range_mask_for_word(wl, a.src_lo0, a.src_hi0);
+            const uint32_t mypc = popc64(myword);
+            const uint32_t myoff = wave_excl_scan(mypc);
+            for (int w = wv; w < SRC_TILE_WORDS; w += MOVE_BLOCK / 64) {
+                const uint64_t mask = __shfl(myword, w, 64);
+                const int64_t off = base + (int64_t)__shfl(myoff, w, 64);
+                const int pc = popc64(mask);
+                if (pc == 0 || off + pc <= R0 || off >= R0 + cnt) continue;   // wave-uniform
+                if ((mask >> lane) & 1ull) {
+                    const int64_t rank = off + popc64(mask & mask_lt(lane)) + 1;
+                    if (rank > R0 && rank <= R0 + cnt) {
+                        const int64_t s = ((a.src_w0 + t * SRC_TILE_WORDS + w) << 6) + lane;
+                        sK[rank - R0 - 1] = a.src_keys[s];
+                        sV[rank - R0 - 1] = a.src_vals[s];
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- write phase: lane <-> 2 adjacent destination slots, 128 slots per wave-iteration ----
+    constexpr int PER_WAVE = DST_TILE / (MOVE_BLOCK / 64);   // 512
+#pragma unroll 1
+    for (int it = 0; it < PER_WAVE / 128; ++it) {
+        const int64_t gq = q0 + (int64_t)wv * PER_WAVE + it * 128;   // 0-based offset of the 128-slot group
+        if (gq >= a.Wd) break;                                        // wave-uniform
+        const int64_t qa = gq + 2 * lane + 1;                         // 1-based offsets qa, qa+1
+        int64_t k2[2] = {0, 0};
+        double v2[2] = {0.0, 0.0};
+        bool o2[2] = {false, false};
+        if (qa <= a.Wd) {
+            int64_t k = gaps_le(g, qa);
+            bool gap = (k > 0 && gap_D(g, k) == qa);
+            int64_t rank = qa - k;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if (j == 1) {
+                    gap = false;
+                    if (k < g.E && gap_D(g, k + 1) == qa + 1) { ++k; gap = true; }
+                    rank = qa + 1 - k;
+                }
+                if (!gap) {
+                    o2[j] = true;
+                    if (PACKED) {
+                        k2[j] = a.src_keys[a.src_lo0 + rank - 1];
+                        v2[j] = a.src_vals[a.src_lo0 + rank - 1];
+                    } else {
+                        k2[j] = sK[rank - R0 - 1];
+                        v2[j] = sV[rank - R0 - 1];
+                    }
+                    if (a.sems != nullptr && k2[j] == SEM_KEY) a.sems[(int64_t)v2[j] - 1] = a.dst_lo0 + qa + j;   // 1-based slot
+                }
+            }
+            const int64_t d = a.dst_lo0 + qa - 1;
+            *reinterpret_cast<longlong2*>(a.dst_keys + d) = make_longlong2(k2[0], k2[1]);
+            *reinterpret_cast<double2*>(a.dst_vals + d) = make_double2(v2[0], v2[1]);
+        }
+        const uint64_t be = __ballot(o2[0]);
+        const uint64_t bo = __ballot(o2[1]);
+        if (lane == 0) {
+            const int64_t w = (a.dst_lo0 + gq) >> 6;
+            a.dst_occ[w] = spread_bits32((uint32_t)be) | (spread_bits32((uint32_t)bo) << 1);
+            if (gq + 64 < a.Wd)
+                a.dst_occ[w + 1] = spread_bits32((uint32_t)(be >> 32)) | (spread_bits32((uint32_t)(bo >> 32)) << 1);
+        }
+    }
+}
+
+__global__ void k_clear_occ(uint64_t* occ, int64_t lo0, int64_t hi0) {
+    const int64_t w0 = lo0 >> 6, w1 = hi0 >> 6;
+    for (int64_t w = w0 + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; w <= w1; w += (int64_t)gridDim.x * blockDim.x)
+        occ[w] &= ~range_mask_for_word(w, lo0, hi0);
+}
+
+hipError_t launch_clear_occ(uint64_t* occ, int64_t from, int64_t to, hipStream_t stream) {
+    if (to < from) return hipSuccess;
+    const int64_t nwords = ((to - 1) >> 6) - ((from - 1) >> 6) + 1;
+    const int blocks = (int)((nwords + 255) / 256 > 1024 ? 1024 : (nwords + 255) / 256);
+    hipLaunchKernelGGL(k_clear_occ, dim3(blocks), dim3(256), 0, stream, occ, from - 1, to - 1);
+    return hipGetLastError();
+}
+
+hipError_t launch_rebalance(const int64_t* src_keys, const double* src_vals, const uint64_t* src_occ,
+                            int64_t src_ws, int64_t src_we, bool src_packed,
+                            int64_t* dst_keys, double* dst_vals, uint64_t* dst_occ,
+                            int64_t dst_ws, int64_t dst_we, int64_t m, int64_t* sems,
+                            RebalanceWork* work, hipStream_t stream) {
+    MoveArgs a;
+    a.src_keys = src_keys; a.src_vals = src_vals; a.src_occ = src_occ;
+    a.src_lo0 = src_ws - 1; a.src_hi0 = src_we - 1;
+    a.src_w0 = a.src_lo0 >> 6;
+    a.dst_keys = dst_keys; a.dst_vals = dst_vals; a.dst_occ = dst_occ;
+    a.dst_lo0 = dst_ws - 1;
+    a.Wd = dst_we - dst_ws + 1; a.m = m;
+    a.sems = sems;
+    a.tile_off = nullptr; a.ntiles = 0;
+    const int64_t ndst = (a.Wd + DST_TILE - 1) / DST_TILE;
+    if (src_packed) {
+        hipLaunchKernelGGL(k_move<true>, dim3((unsigned)ndst), dim3(MOVE_BLOCK), 0, stream, a);
+        return hipGetLastError();
+    }
+    const int64_t nwords = (a.src_hi0 >> 6) - a.src_w0 + 1;
+    const int64_t ntiles = (nwords + SRC_TILE_WORDS - 1) / SRC_TILE_WORDS;
+    if (ntiles + 1 > work->tiles_cap) return hipErrorInvalidValue;
+    // the occupancy array is allocated in whole 64-word tiles (see Pma::alloc), so lane <-> word reads stay in bounds
+    hipLaunchKernelGGL(k_tile_count, dim3((unsigned)ntiles), dim3(64), 0, stream, src_occ, a.src_lo0, a.src_hi0,
+                       a.src_w0, nwords, work->tile_cnt);
+    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, stream, work->tile_cnt, work->tile_off, ntiles);
+    a.tile_off = work->tile_off; a.ntiles = ntiles;
+    hipLaunchKernelGGL(k_move<false>, dim3((unsigned)ndst), dim3(MOVE_BLOCK), 0, stream, a);
+    return hipGetLastError();
+}
+
+}  // namespace dsa

@@ -1,0 +1,660 @@
+// csrc/sequencer.hip — the on-device write sequencer (K-find, K-shift, K-density, small-window
+// K-rebalance) for gfx950.
+//
+// The reference has no batched insert: every setindex! depends on the slot layout left by the
+// previous one (src/pma.jl:196-213, src/pcsr.jl:294-351).  A batch is therefore DEFINED as "apply the
+// reference's setindex! in order", and one persistent 256-thread workgroup executes the whole batch
+// on the device so that no host round trip is paid per element.  The control flow is executed
+// redundantly and uniformly by all threads (same loads, same decisions); the data-moving steps are
+// workgroup-parallel primitives:
+//     d_find              exact emulation of the gap-tolerant bisection  src/finds.jl:29-57
+//     blk_shift_right/left   _movecellstoright!/left! incl. semaphore fix-up  src/moves.jl:7-85
+//     d_look_for_rebalance   density-threshold scan on the occupancy bitmap (popcounts) with the
+//                            integer thresholds of Ctl  src/pma.jl:105-141, src/utils.jl:48-58
+//     blk_rebalance_small    pack! + spread! of a window <= 8192 slots through LDS: ballot-style
+//                            prefix popcounts compact the cells, closed-form gap offsets place them
+//                            (src/moves.jl:94-171)
+// Windows larger than that, _extend! / _shrink!, and table growth are handed back to the host
+// ("yield"), which runs the grid-wide kernel of rebalance.hip and relaunches the sequencer.
+#include "dsa_dev.h"
+
+namespace dsa {
+
+constexpr int SEQ_BLOCK = 256;
+constexpr int64_t SMALL_W = 8192;
+
+// result of one op: 0 = finished, otherwise a SeqStatus; RERUN is OR-ed in when the op must be
+// executed again from the top after the host has serviced the yield
+constexpr int RERUN = 0x100;
+
+struct Seq {
+    int64_t* keys; double* vals; uint64_t* occ;
+    int64_t* sems; int64_t* col_keys; uint8_t* col_live;
+    Ctl* ctl;
+    int64_t capacity, seg, height, nb_elements, nb_partitions, table_len, table_cap;
+    int64_t stat_window_slots, stat_rebalances, stat_small;
+    int64_t y_ws, y_we, y_m;
+    int32_t err;
+    int64_t* sK; double* sV;       // LDS staging for the small-window rebalance
+    uint32_t* sWordOff;            // [SMALL_W/64 + 1]
+    int64_t* sRed;                 // [SEQ_BLOCK/64] block-reduce scratch
+};
+
+// ---- bitmap scans (uniform, executed by every thread) -------------------------------------------
+// _nextemptypos(array, from)  src/utils.jl:3-10
+__device__ int64_t d_next_empty(const uint64_t* occ, int64_t from, int64_t capacity) {
+    if (from + 1 > capacity) return 0;
+    const int64_t i = from;                 // 0-based index of position from+1
+    int64_t w = i >> 6;
+    uint64_t word = ~occ[w] & ~mask_lt((int)(i & 63));
+    const int64_t lastw = (capacity - 1) >> 6;
+    while (true) {
+        if (word) {
+            const int64_t p = (w << 6) + __ffsll((unsigned long long)word);   // 1-based position
+            return p <= capacity ? p : 0;
+        }
+        if (++w > lastw) return 0;
+        word = ~occ[w];
+    }
+}
+// _previousemptypos(array, from)  src/utils.jl:21-28
+__device__ int64_t d_prev_empty(const uint64_t* occ, int64_t from) {
+    if (from - 1 < 1) return 0;
+    const int64_t i = from - 2;             // 0-based index of position from-1
+    int64_t w = i >> 6;
+    const int b = (int)(i & 63);
+    uint64_t word = ~occ[w] & (b == 63 ? ~0ull : mask_lt(b + 1));
+    while (true) {
+        if (word) return (w << 6) + (63 - __clzll((long long)word)) + 1;
+        if (--w < 0) return 0;
+        word = ~occ[w];
+    }
+}
+// largest occupied position in [lo, pos], or lo-1  (the walk-left loops of src/finds.jl:33-35,50-52)
+__device__ int64_t d_prev_occupied(const uint64_t* occ, int64_t pos, int64_t lo) {
+    if (pos < lo) return lo - 1;
+    const int64_t i = pos - 1;
+    int64_t w = i >> 6;
+    const int b = (int)(i & 63);
+    uint64_t word = occ[w] & (b == 63 ? ~0ull : mask_lt(b + 1));
+    const int64_t low = (lo - 1) >> 6;
+    while (true) {
+        if (word) {
+            const int64_t p = (w << 6) + (63 - __clzll((long long)word)) + 1;
+            return p >= lo ? p : lo - 1;
+        }
+        if (--w < low) return lo - 1;
+        word = occ[w];
+    }
+}
+
+struct DFound { int64_t pos; int64_t key; double val; bool has; };
+
+// find(array, key, from, to)  src/finds.jl:29-57 — same probes, same answers
+__device__ DFound d_find(const int64_t* keys, const double* vals, const uint64_t* occ, int64_t key, int64_t from, int64_t to) {
+    while (from <= to) {
+        const int64_t mid = (from + to) >> 1;
+        const int64_t i = d_prev_occupied(occ, mid, from);
+        if (i < from) {
+            from = mid + 1;
+        } else {
+            const int64_t ck = keys[i - 1];
+            if (ck > key) to = i - 1;
+            else if (ck < key) from = mid + 1;
+            else return DFound{i, ck, vals[i - 1], true};
+        }
+    }
+    const int64_t i = to >= 1 ? d_prev_occupied(occ, to, 1) : 0;
+    if (i > 0) return DFound{i, keys[i - 1], vals[i - 1], true};
+    return DFound{0, 0, 0.0, false};
+}
+
+struct DFoundKey { int64_t pos; int64_t key; bool has; };
+// find(col_keys, key)  src/finds.jl:59-61 on a Vector{Union{Nothing,L}}
+__device__ DFoundKey d_find_table(const int64_t* ck, const uint8_t* live, int64_t len, int64_t key) {
+    int64_t from = 1, to = len;
+    while (from <= to) {
+        const int64_t mid = (from + to) >> 1;
+        int64_t i = mid;
+        while (i >= from && !live[i - 1]) --i;
+        if (i < from) {
+            from = mid + 1;
+        } else {
+            const int64_t c = ck[i - 1];
+            if (c > key) to = i - 1;
+            else if (c < key) from = mid + 1;
+            else return DFoundKey{i, c, true};
+        }
+    }
+    int64_t i = to;
+    while (i > 0 && !live[i - 1]) --i;
+    if (i > 0) return DFoundKey{i, ck[i - 1], true};
+    return DFoundKey{0, 0, false};
+}
+
+// _nextnonemptypos(semaphores, from)  src/utils.jl:12-19
+__device__ int64_t d_next_live_sem(const int64_t* sems, int64_t from, int64_t len) {
+    int64_t pos = from + 1;
+    while (pos <= len) {
+        if (sems[pos - 1] != 0) return pos;
+        ++pos;
+    }
+    return 0;
+}
+
+// ---- workgroup-parallel primitives ------------------------------------------------------------------
+__device__ __forceinline__ uint64_t word_range_mask(int64_t w, int64_t lo0, int64_t hi0) {
+    const int64_t b = w << 6;
+    int64_t a = lo0 - b, z = hi0 - b;
+    if (z < 0 || a > 63) return 0ull;
+    if (a < 0) a = 0;
+    if (z > 63) z = 63;
+    const uint64_t upto = (z == 63) ? ~0ull : ((1ull << (z + 1)) - 1ull);
+    return upto & ~mask_lt((int)a);
+}
+
+// _nbcells(array, from, to), `to` excluded  src/utils.jl:48-58
+__device__ int64_t blk_count(Seq& S, int64_t from, int64_t to) {
+    if (from >= to) return 0;
+    const int64_t lo0 = from - 1, hi0 = to - 2;
+    const int64_t w0 = lo0 >> 6, w1 = hi0 >> 6;
+    if (w1 - w0 < 8) {                                   // tiny range: every thread counts it itself
+        int64_t c = 0;
+        for (int64_t w = w0; w <= w1; ++w) c += popc64(S.occ[w] & word_range_mask(w, lo0, hi0));
+        return c;
+    }
+    int64_t c = 0;
+    for (int64_t w = w0 + threadIdx.x; w <= w1; w += SEQ_BLOCK) c += popc64(S.occ[w] & word_range_mask(w, lo0, hi0));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) S.sRed[threadIdx.x >> 6] = c;
+    __syncthreads();
+    int64_t tot = 0;
+#pragma unroll
+    for (int k = 0; k < SEQ_BLOCK / 64; ++k) tot += S.sRed[k];
+    return tot;
+}
+
+// cells [a, b-1] move one slot to the right (b is empty)  _moverightloop!  src/moves.jl:16-42
+__device__ void blk_shift_right(Seq& S, int64_t a, int64_t b) {
+    for (int64_t hi = b - 1; hi >= a; hi -= SEQ_BLOCK) {
+        const int64_t p = hi - threadIdx.x;
+        const bool act = p >= a;
+        int64_t k = 0; double v = 0.0;
+        if (act) { k = S.keys[p - 1]; v = S.vals[p - 1]; }
+        __syncthreads();
+        if (act) {
+            S.keys[p] = k; S.vals[p] = v;
+            if (S.sems != nullptr && k == SEM_KEY) S.sems[(int64_t)v - 1] = p + 1;
+        }
+        __syncthreads();
+    }
+}
+// cells [a+1, b] move one slot to the left (a is empty); the cell at b may itself be empty
+// (last_occ == false)  _moveleftloop!  src/moves.jl:59-85
+__device__ void blk_shift_left(Seq& S, int64_t a, int64_t b, bool last_occ) {
+    for (int64_t lo = a + 1; lo <= b; lo += SEQ_BLOCK) {
+        const int64_t p = lo + threadIdx.x;
+        const bool act = p <= b && (p < b || last_occ);
+        int64_t k = 0; double v = 0.0;
+        if (act) { k = S.keys[p - 1]; v = S.vals[p - 1]; }
+        __syncthreads();
+        if (act) {
+            S.keys[p - 2] = k; S.vals[p - 2] = v;
+            if (S.sems != nullptr && k == SEM_KEY) S.sems[(int64_t)v - 1] = p - 1;
+        }
+        __syncthreads();
+    }
+}
+
+__device__ __forceinline__ void occ_set(Seq& S, int64_t pos) { S.occ[(pos - 1) >> 6] |= 1ull << ((pos - 1) & 63); }
+__device__ __forceinline__ void occ_clear(Seq& S, int64_t pos) { S.occ[(pos - 1) >> 6] &= ~(1ull << ((pos - 1) & 63)); }
+
+__device__ __forceinline__ uint32_t seq_wave_excl_scan(uint32_t v) {
+    const int lane = lane_id();
+    uint32_t x = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t y = __shfl_up(x, o, 64);
+        if (lane >= o) x += y;
+    }
+    return x - v;
+}
+
+// pack! + spread! of [ws, we] (W <= SMALL_W) holding m cells  src/moves.jl:94-171
+__device__ void blk_rebalance_small(Seq& S, int64_t ws, int64_t we, int64_t m) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int64_t W = we - ws + 1;
+    const int64_t lo0 = ws - 1;
+    const int64_t w0 = lo0 >> 6;
+    const SpreadGeom g = make_geom(W, m);
+    if (W >= 64) {
+        const int nwords = (int)(W >> 6);              // <= 128
+        // exclusive prefix of the per-word popcounts (two wave scans)
+        if (wv < 2) {
+            const int w = wv * 64 + lane;
+            const uint32_t pc = w < nwords ? (uint32_t)popc64(S.occ[w0 + w]) : 0u;
+            const uint32_t ex = seq_wave_excl_scan(pc);
+            if (w < nwords) S.sWordOff[w] = ex;
+            if (lane == 63) S.sRed[wv] = ex + pc;
+        }
+        __syncthreads();
+        const uint32_t add = (uint32_t)S.sRed[0];
+        for (int w = wv; w < nwords; w += SEQ_BLOCK / 64) {
+            const uint64_t mask = S.occ[w0 + w];
+            if ((mask >> lane) & 1ull) {
+                const uint32_t r = S.sWordOff[w] + (w >= 64 ? add : 0u) + (uint32_t)popc64(mask & mask_lt(lane));
+                const int64_t s = ((w0 + w) << 6) + lane;
+                S.sK[r] = S.keys[s];
+                S.sV[r] = S.vals[s];
+            }
+        }
+        __syncthreads();
+        for (int64_t base = 0; base < W; base += SEQ_BLOCK) {
+            const int64_t q = base + tid + 1;          // 1-based offset; W is a multiple of 64, block covers 4 words
+            bool occd = false;
+            if (q <= W) {
+                int64_t rank;
+                if (!slot_is_gap(g, q, &rank)) {
+                    occd = true;
+                    const int64_t k = S.sK[rank - 1];
+                    const double v = S.sV[rank - 1];
+                    S.keys[lo0 + q - 1] = k;
+                    S.vals[lo0 + q - 1] = v;
+                    if (S.sems != nullptr && k == SEM_KEY) S.sems[(int64_t)v - 1] = lo0 + q;
+                }
+            }
+            const uint64_t b = __ballot(occd);
+            if (lane == 0 && base + wv * 64 < W) S.occ[w0 + ((base + wv * 64) >> 6)] = b;
+        }
+    } else {
+        // the window lives inside one occupancy word; wave 0 handles it
+        const int bit0 = (int)(lo0 & 63);
+        const uint64_t wmask = ((1ull << W) - 1ull) << bit0;
+        const uint64_t word = S.occ[w0];
+        __syncthreads();                                // everyone has read the old word
+        if (wv == 0) {
+            const uint64_t mask = (word & wmask) >> bit0;
+            if (lane < W && ((mask >> lane) & 1ull)) {
+                const int r = popc64(mask & mask_lt(lane));
+                S.sK[r] = S.keys[lo0 + lane];
+                S.sV[r] = S.vals[lo0 + lane];
+            }
+            // single wave: LDS writes above are visible to the same wave after the implicit wave sync
+            __builtin_amdgcn_s_waitcnt(0xc07f);        // lgkmcnt(0)
+            bool occd = false;
+            const int64_t q = lane + 1;
+            if (q <= W) {
+                int64_t rank;
+                if (!slot_is_gap(g, q, &rank)) {
+                    occd = true;
+                    const int64_t k = S.sK[rank - 1];
+                    const double v = S.sV[rank - 1];
+                    S.keys[lo0 + q - 1] = k;
+                    S.vals[lo0 + q - 1] = v;
+                    if (S.sems != nullptr && k == SEM_KEY) S.sems[(int64_t)v - 1] = lo0 + q;
+                }
+            }
+            const uint64_t b = __ballot(occd);
+            if (lane == 0) S.occ[w0] = (word & ~wmask) | (b << bit0);
+        }
+    }
+    __syncthreads();
+    S.stat_small += 1;
+}
+
+// ---- the density-threshold scan  _look_for_rebalance!  src/pma.jl:105-141 -------------------------------
+// returns 0 (nothing more to do) or a yield status
+__device__ int d_after_count_change(Seq& S, int64_t pos) {
+    int64_t prev_ws = pos, prev_we = pos - 1;
+    int64_t left = 0, right = 0;
+    int64_t ws = 1, we = S.capacity;
+    bool accepted = false;
+    for (int64_t h = 0; h <= S.height; ++h) {
+        const int64_t W = S.seg << h;
+        ws = ((pos - 1) / W) * W + 1;
+        we = ws + W - 1;
+        left += blk_count(S, ws, prev_ws);
+        right += blk_count(S, prev_we + 1, we + 1);
+        const int64_t c = left + right;
+        if (S.ctl->lo[h] <= c && c <= S.ctl->hi[h]) { accepted = true; break; }
+        prev_ws = ws; prev_we = we;
+    }
+    const int64_t count = left + right;
+    if (!accepted) {
+        const int64_t H = S.height;
+        if (count > S.ctl->hi[H]) { S.y_m = count; return SEQ_Y_EXTEND; }
+        if (count < S.ctl->lo[H] && S.height > 1) { S.y_m = count; return SEQ_Y_SHRINK; }
+        ws = 1; we = S.capacity;
+    }
+    // _even_rebalance!  src/pma.jl:94-103 / src/pcsr.jl:88-97
+    const int64_t W = we - ws + 1;
+    if (W == S.seg) return 0;
+    S.stat_rebalances += 1; S.stat_window_slots += W;
+    if (W <= SMALL_W) { blk_rebalance_small(S, ws, we, count); return 0; }
+    S.y_ws = ws; S.y_we = we; S.y_m = count;
+    return SEQ_Y_REBALANCE;
+}
+
+// _insert!(array, key, value, pos, semaphores)  src/writes.jl:26-43 ; returns the insertion position or 0 (EFULL)
+__device__ int64_t d_insert_after(Seq& S, int64_t key, double val, int64_t pos) {
+    const int64_t ne = d_next_empty(S.occ, pos, S.capacity);
+    const int64_t pe = ne != 0 ? 0 : d_prev_empty(S.occ, pos);
+    const bool last_occ = (ne == 0 && pe != 0) ? occ_test(S.occ, pos) : true;
+    __syncthreads();                       // every thread has finished reading the bitmap
+    if (ne != 0) {
+        blk_shift_right(S, pos + 1, ne);
+        if (threadIdx.x == 0) { S.keys[pos] = key; S.vals[pos] = val; occ_set(S, ne); }
+        __syncthreads();
+        return pos + 1;
+    }
+    if (pe == 0) { S.err = E_FULL; return 0; }
+    blk_shift_left(S, pe, pos, last_occ);
+    if (threadIdx.x == 0) {
+        S.keys[pos - 1] = key; S.vals[pos - 1] = val;
+        // occupancy after the shift: bits [pe, pos-1] take the old bits [pe+1, pos]; (pe, pos-1] were all ones
+        if (pe < pos - 1) { occ_set(S, pe); if (!last_occ) occ_clear(S, pos - 1); }
+        else if (last_occ) occ_set(S, pe);
+        occ_set(S, pos);
+    }
+    __syncthreads();
+    return pos;
+}
+
+// setindex!(pma, value, key)  src/pma.jl:196-213 restricted to [from, to] like insert!/delete! of
+// src/writes.jl:14-23,57-63 ; del_from is the (possibly wider) range of the delete path (src/pcsr.jl:302-307)
+__device__ int d_set_in_range(Seq& S, int64_t key, double val, int64_t from, int64_t to, int64_t del_from) {
+    if (val != 0.0) {
+        const DFound f = d_find(S.keys, S.vals, S.occ, key, from, to);
+        if (f.has && f.key == key && from <= f.pos && f.pos <= to) {
+            __syncthreads();
+            if (threadIdx.x == 0) S.vals[f.pos - 1] = val;
+            __syncthreads();
+            return 0;
+        }
+        __syncthreads();
+        const int64_t ip = d_insert_after(S, key, val, f.pos);
+        if (ip == 0) return SEQ_ERROR;
+        S.nb_elements += 1;
+        return d_after_count_change(S, ip);
+    }
+    const DFound f = d_find(S.keys, S.vals, S.occ, key, del_from, to);
+    if (f.has && f.key == key) {
+        __syncthreads();
+        if (threadIdx.x == 0) occ_clear(S, f.pos);
+        __syncthreads();
+        S.nb_elements -= 1;
+        return d_after_count_change(S, f.pos);
+    }
+    return 0;
+}
+
+// addpartition!(pcsc)  src/pcsr.jl:99-112
+__device__ int d_addpartition_append(Seq& S) {
+    if (S.table_len + 1 > S.table_cap) return SEQ_Y_TABLE_GROW | RERUN;
+    const int64_t sem_pos = S.capacity;
+    S.nb_partitions += 1;
+    __syncthreads();
+    if (threadIdx.x == 0) S.sems[S.table_len] = sem_pos;
+    __syncthreads();
+    S.table_len += 1;
+    const double sem_val = (double)S.table_len;
+    const int64_t ip = d_insert_after(S, SEM_KEY, sem_val, sem_pos);
+    if (ip == 0) return SEQ_ERROR;
+    S.nb_elements += 1;
+    const int r = d_after_count_change(S, ip);
+    return r ? (r | RERUN) : 0;
+}
+
+// addcolumn! (src/pcsr.jl:148-169) + addpartition!(pcsc, prev) (src/pcsr.jl:114-146); col_keys may be null (plain PackedCSC)
+__device__ int d_addpartition_middle(Seq& S, int64_t prev, bool with_col, int64_t col) {
+    // prev = prev_sem_id = prev_col_pos ; the new partition gets id prev+1 (0-based table index prev)
+    if (prev + 1 < 1 || prev + 1 > S.table_len) { S.err = E_BOUNDS; return SEQ_ERROR; }
+    const int64_t target = S.sems[prev];
+    int64_t sem_pos = 0;
+    if (target == 0) {
+        const int64_t next = d_next_live_sem(S.sems, prev + 1, S.table_len);
+        if (next == 0) { S.err = E_BOUNDS; return SEQ_ERROR; }      // semaphores[0] in the reference (App. A.6 (3))
+        sem_pos = S.sems[next - 1] - 1;
+        __syncthreads();
+        if (with_col && threadIdx.x == 0) { S.col_keys[prev] = col; S.col_live[prev] = 1; }
+    } else {
+        if (S.table_len + 1 > S.table_cap) return SEQ_Y_TABLE_GROW | RERUN;
+        // reference @assert !isnothing(moved_sem_pos) (src/pcsr.jl:132): no tombstone may be shifted
+        int bad = 0;
+        for (int64_t i = prev + threadIdx.x; i < S.table_len; i += SEQ_BLOCK) if (S.sems[i] == 0) bad = 1;
+        if (__syncthreads_or(bad)) { S.err = E_ASSERT; return SEQ_ERROR; }
+        sem_pos = target - 1;
+        // shift tables one entry to the right from index prev, highest chunk first
+        for (int64_t hi = S.table_len - 1; hi >= prev; hi -= SEQ_BLOCK) {
+            const int64_t i = hi - threadIdx.x;
+            const bool act = i >= prev;
+            int64_t sp = 0, ck = 0; uint8_t lv = 0;
+            if (act) { sp = S.sems[i]; if (with_col) { ck = S.col_keys[i]; lv = S.col_live[i]; } }
+            __syncthreads();
+            if (act) {
+                S.sems[i + 1] = sp;
+                if (with_col) { S.col_keys[i + 1] = ck; S.col_live[i + 1] = lv; }
+                S.vals[sp - 1] = (double)(i + 2);       // the semaphore of id i+1 becomes id i+2
+            }
+            __syncthreads();
+        }
+        if (with_col && threadIdx.x == 0) { S.col_keys[prev] = col; S.col_live[prev] = 1; }
+        S.table_len += 1;
+    }
+    __syncthreads();
+    S.nb_partitions += 1;
+    const double sem_val = (double)(prev + 1);
+    const int64_t ip = d_insert_after(S, SEM_KEY, sem_val, sem_pos);
+    if (ip == 0) return SEQ_ERROR;
+    if (threadIdx.x == 0) S.sems[prev] = ip;
+    __syncthreads();
+    S.nb_elements += 1;
+    const int r = d_after_count_change(S, ip);
+    return r ? (r | RERUN) : 0;
+}
+
+// _pos_of_partition_end  src/pcsr.jl:177-186
+__device__ int64_t d_partition_end(Seq& S, int64_t partition) {
+    const int64_t next = d_next_live_sem(S.sems, partition, S.table_len);
+    return next != 0 ? S.sems[next - 1] - 1 : S.capacity;
+}
+
+// setindex!(pcsc, value, key, partition)  src/pcsr.jl:294-339
+__device__ int d_pcsc_set(Seq& S, double val, int64_t key, int64_t partition) {
+    if (partition < 1) { S.err = E_BOUNDS; return SEQ_ERROR; }
+    while (partition > S.table_len) {                   // _add_partitions!  :312-319
+        const int r = d_addpartition_append(S);
+        if (r) return r;
+    }
+    const int64_t from = S.sems[partition - 1];
+    if (from == 0) { S.err = E_DELETED; return SEQ_ERROR; }
+    const int64_t to = d_partition_end(S, partition);
+    return d_set_in_range(S, key, val, from + 1, to, from);
+}
+
+// deletepartition!  src/pcsr.jl:188-204
+__device__ int d_deletepartition(Seq& S, int64_t partition) {
+    if (!(1 <= partition && partition <= S.table_len)) { S.err = E_BOUNDS; return SEQ_ERROR; }
+    S.nb_partitions -= 1;
+    const int64_t sem_pos = S.sems[partition - 1];
+    if (sem_pos == 0) { S.err = E_ASSERT; return SEQ_ERROR; }
+    const int64_t end = d_partition_end(S, partition);
+    // purge!(array, sem_pos, end)  src/writes.jl:80-91
+    const int64_t nb = blk_count(S, sem_pos, end + 1);
+    __syncthreads();
+    {
+        const int64_t lo0 = sem_pos - 1, hi0 = end - 1;
+        const int64_t w0 = lo0 >> 6, w1 = hi0 >> 6;
+        for (int64_t w = w0 + threadIdx.x; w <= w1; w += SEQ_BLOCK) S.occ[w] &= ~word_range_mask(w, lo0, hi0);
+    }
+    if (threadIdx.x == 0) S.sems[partition - 1] = 0;
+    __syncthreads();
+    const int64_t mid = sem_pos + (end - sem_pos) / 2;
+    if (nb > 0) {
+        S.nb_elements -= nb;
+        return d_after_count_change(S, mid);
+    }
+    return 0;
+}
+
+__device__ int d_exec(Seq& S, const Op& op) {
+    switch (op.kind) {
+        case OP_VEC_SET:
+            return d_set_in_range(S, op.a, op.v, 1, S.capacity, 1);
+        case OP_PCSC_SET:
+            return d_pcsc_set(S, op.v, op.a, op.b);
+        case OP_MPCSC_SET: {       // setindex!(mpcsc, value, row, col)  src/pcsr.jl:341-351
+            const DFoundKey f = d_find_table(S.col_keys, S.col_live, S.table_len, op.b);
+            int64_t col_pos = f.pos;
+            if (!(f.has && f.key == op.b)) {
+                if (f.pos == S.table_len) {
+                    if (S.table_len + 1 > S.table_cap) return SEQ_Y_TABLE_GROW | RERUN;
+                    __syncthreads();
+                    if (threadIdx.x == 0) { S.col_keys[S.table_len] = op.b; S.col_live[S.table_len] = 1; }
+                    __syncthreads();
+                    const int r = d_addpartition_append(S);
+                    if (r) return r;
+                    col_pos = S.table_len;
+                } else {
+                    const int r = d_addpartition_middle(S, f.pos, true, op.b);
+                    if (r) return r;
+                    col_pos = f.pos + 1;
+                }
+            }
+            return d_pcsc_set(S, op.v, op.a, col_pos);
+        }
+        case OP_DELETE_PARTITION:
+            return d_deletepartition(S, op.b);
+        case OP_MPCSC_DELETECOLUMN: {   // deletecolumn!(mpcsc, col)  src/pcsr.jl:206-212
+            const DFoundKey f = d_find_table(S.col_keys, S.col_live, S.table_len, op.b);
+            if (!(f.has && f.key == op.b)) { S.err = E_ARG; return SEQ_ERROR; }
+            __syncthreads();
+            if (threadIdx.x == 0) S.col_live[f.pos - 1] = 0;
+            __syncthreads();
+            return d_deletepartition(S, f.pos);
+        }
+        default:
+            S.err = E_ARG;
+            return SEQ_ERROR;
+    }
+}
+
+__global__ __launch_bounds__(SEQ_BLOCK) void k_sequencer(int64_t* keys, double* vals, uint64_t* occ, int64_t* sems,
+                                                         int64_t* col_keys, uint8_t* col_live, Ctl* ctl,
+                                                         const Op* ops, int64_t n_ops) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    __shared__ int64_t sRed[SEQ_BLOCK / 64];
+    __shared__ uint32_t sWordOff[SMALL_W / 64 + 1];
+    Seq S;
+    S.keys = keys; S.vals = vals; S.occ = occ; S.sems = sems; S.col_keys = col_keys; S.col_live = col_live; S.ctl = ctl;
+    S.capacity = ctl->capacity; S.seg = ctl->segment_capacity; S.height = ctl->height;
+    S.nb_elements = ctl->nb_elements; S.nb_partitions = ctl->nb_partitions;
+    S.table_len = ctl->table_len; S.table_cap = ctl->table_cap;
+    S.stat_window_slots = ctl->stat_window_slots; S.stat_rebalances = ctl->stat_rebalances;
+    S.stat_small = ctl->stat_small_rebalances;
+    S.y_ws = S.y_we = S.y_m = 0; S.err = 0;
+    S.sK = reinterpret_cast<int64_t*>(lds);
+    S.sV = reinterpret_cast<double*>(lds + SMALL_W * sizeof(int64_t));
+    S.sWordOff = sWordOff; S.sRed = sRed;
+
+    int64_t i = ctl->next_op;
+    int status = SEQ_DONE;
+    for (; i < n_ops; ++i) {
+        const Op op = ops[i];
+        const int r = d_exec(S, op);
+        if (r != 0) {
+            status = r & 0xff;
+            if (!(r & RERUN) && status != SEQ_ERROR) ++i;      // the op itself is complete once the host has acted
+            break;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        ctl->next_op = i;
+        ctl->status = status;
+        ctl->err = S.err;
+        ctl->err_op = (status == SEQ_ERROR) ? i : -1;
+        ctl->nb_elements = S.nb_elements; ctl->nb_partitions = S.nb_partitions; ctl->table_len = S.table_len;
+        ctl->y_ws = S.y_ws; ctl->y_we = S.y_we; ctl->y_m = S.y_m;
+        ctl->stat_window_slots = S.stat_window_slots; ctl->stat_rebalances = S.stat_rebalances;
+        ctl->stat_small_rebalances = S.stat_small;
+    }
+}
+
+hipError_t launch_sequencer(int64_t* keys, double* vals, uint64_t* occ, int64_t* sems, int64_t* col_keys,
+                            uint8_t* col_live, Ctl* ctl, const Op* ops, int64_t n_ops, hipStream_t stream) {
+    static bool configured = false;
+    const size_t lds_bytes = (size_t)SMALL_W * (sizeof(int64_t) + sizeof(double));
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_sequencer),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return e;
+        configured = true;
+    }
+    hipLaunchKernelGGL(k_sequencer, dim3(1), dim3(SEQ_BLOCK), lds_bytes, stream, keys, vals, occ, sems, col_keys, col_live,
+                       ctl, ops, n_ops);
+    return hipGetLastError();
+}
+
+// ---- batched read-only lookups -----------------------------------------------------------------------
+// getindex(pma,key) src/pma.jl:189-193 ; getindex(pcsc,key,partition) src/pcsr.jl:222-232 ;
+// getindex(mpcsc,row,col) src/pcsr.jl:261-267.  One lane per query; each lane replays the reference's bisection.
+__global__ void k_get_batch(int mode, const int64_t* keys, const double* vals, const uint64_t* occ, int64_t capacity,
+                            const int64_t* sems, const int64_t* col_keys, const uint8_t* col_live, int64_t table_len,
+                            const int64_t* qa, const int64_t* qb, int64_t n, double* out, int32_t* err_out) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t key = qa[i];
+    int64_t from = 1, to = capacity;
+    if (mode != 0) {
+        int64_t partition = qb[i];
+        if (mode == 2) {
+            const DFoundKey f = d_find_table(col_keys, col_live, table_len, qb[i]);
+            if (!(f.has && f.key == qb[i])) { out[i] = 0.0; return; }
+            partition = f.pos;
+        }
+        if (partition < 1 || partition > table_len) { atomicCAS(err_out, 0, E_BOUNDS); out[i] = 0.0; return; }
+        from = sems[partition - 1];
+        if (from == 0) { atomicCAS(err_out, 0, E_ASSERT); out[i] = 0.0; return; }   // _pos_of_partition_start @assert
+        const int64_t next = d_next_live_sem(sems, partition, table_len);
+        to = next != 0 ? sems[next - 1] - 1 : capacity;
+    }
+    const DFound f = d_find(keys, vals, occ, key, from, to);
+    out[i] = (f.has && f.key == key) ? f.val : 0.0;
+}
+
+hipError_t launch_get_batch(int mode, const int64_t* keys, const double* vals, const uint64_t* occ, int64_t capacity,
+                            const int64_t* sems, const int64_t* col_keys, const uint8_t* col_live, int64_t table_len,
+                            const int64_t* qa, const int64_t* qb, int64_t n, double* out, int32_t* err_out,
+                            hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    const int block = 64;
+    hipLaunchKernelGGL(k_get_batch, dim3((unsigned)((n + block - 1) / block)), dim3(block), 0, stream, mode, keys, vals, occ,
+                       capacity, sems, col_keys, col_live, table_len, qa, qb, n, out, err_out);
+    return hipGetLastError();
+}
+
+// view(mpcsc, :, col)  src/views.jl:15-35 : slot range of the column
+__global__ void k_partition_range(const int64_t* sems, const int64_t* col_keys, const uint8_t* col_live, int64_t table_len,
+                                  int64_t capacity, int64_t col, int64_t* out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    out[0] = 0; out[1] = 0; out[2] = 0;
+    const DFoundKey f = d_find_table(col_keys, col_live, table_len, col);
+    if (!(f.has && f.key == col)) return;
+    const int64_t from = sems[f.pos - 1];
+    if (from == 0) { out[2] = E_ASSERT; return; }
+    const int64_t next = d_next_live_sem(sems, f.pos, table_len);
+    out[0] = from + 1;
+    out[1] = next != 0 ? sems[next - 1] - 1 : capacity;
+    out[2] = 0;
+    out[3] = f.pos;
+}
+hipError_t launch_partition_range(const int64_t* sems, const int64_t* col_keys, const uint8_t* col_live,
+                                  int64_t table_len, int64_t capacity, int64_t col, int64_t* out, hipStream_t stream) {
+    hipLaunchKernelGGL(k_partition_range, dim3(1), dim3(64), 0, stream, sems, col_keys, col_live, table_len, capacity, col, out);
+    return hipGetLastError();
+}
+
+}  // namespace dsa

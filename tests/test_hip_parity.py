@@ -1,0 +1,403 @@
+"""GPU parity tests (run on a real MI355X with `-m gpu`): the HIP library, called through the C ABI,
+against (1) the reference's own golden vectors, (2) the survey digests and (3) the CPU oracle slot for
+slot on seeded inputs.  Integer keys, slot positions, semaphore tables: bit-exact.  Float64 SpMV
+accumulations: relative 1e-12 (north_star tolerance)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import ka
+from scenario import run_scenario
+from util import SplitMix64, check_key_order, check_semaphores, layouts_equal, splitmix_array, unit12_array
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+with open(os.path.join(HERE, "golden", "reference_cases.json")) as f:
+    CASES = json.load(f)
+with open(os.path.join(HERE, "golden", "survey_known_answers.json")) as f:
+    KA = json.load(f)
+
+RTOL = 1e-12
+
+
+def subset_equal(got, exp, path=""):
+    for k, v in exp.items():
+        if k.startswith("_"):
+            continue
+        assert k in got, path + k
+        if isinstance(v, dict):
+            subset_equal(got[k], v, path + k + ".")
+        else:
+            assert got[k] == v, (path + k, got[k], v)
+
+
+def assert_vec_equal(a, b):
+    ia, ib = a.info(), b.info()
+    for k in ("capacity", "segment_capacity", "nb_segments", "nb_elements", "height"):
+        assert ia[k] == ib[k], (k, ia, ib)
+    assert len(a) == len(b)
+    assert layouts_equal(a.export_layout(), b.export_layout())
+
+
+def assert_mat_equal(a, b):
+    assert a.size() == b.size()
+    for o in (0, 1):
+        La, Lb = a.export_layout(o), b.export_layout(o)
+        for k in ("capacity", "segment_capacity", "nb_segments", "nb_elements", "height", "nb_partitions", "table_len"):
+            assert La["info"][k] == Lb["info"][k], (o, k, La["info"], Lb["info"])
+        assert layouts_equal((La["keys"], La["vals"], La["occ"]), (Lb["keys"], Lb["vals"], Lb["occ"])), o
+        assert np.array_equal(La["semaphores"], Lb["semaphores"]), o
+        assert np.array_equal(La["col_live"], Lb["col_live"]), o
+        assert np.array_equal(La["col_keys"], Lb["col_keys"]), o
+
+
+# ---------------------------------------------------------------- golden vectors of the reference
+@pytest.mark.parametrize("sc", CASES["scenarios"], ids=lambda s: s["name"])
+def test_reference_scenarios_on_hip(dsa, hip, sc):
+    run_scenario(dsa, hip, sc)
+
+
+def test_survey_known_answers_on_hip(dsa, hip):
+    subset_equal(ka.ka4(dsa, hip), KA["ka4"])
+    subset_equal(ka.ka5(dsa, hip), KA["ka5"])
+    exp = json.loads(json.dumps(KA["ka6"]))
+    exp["c"].pop("shrinks")
+    subset_equal(ka.ka6(dsa, hip, batch=True), exp)
+    got = ka.ka7_9(dsa, hip, batch=True)
+    y4 = got["ka7"].pop("y4")
+    exp7 = {k: json.loads(json.dumps(KA[k])) for k in ("ka7", "ka8", "ka9")}
+    y4_exp = exp7["ka7"].pop("y4")
+    subset_equal(got, exp7)
+    for a, e in zip(y4, y4_exp):
+        assert abs(float.fromhex(a) - float.fromhex(e)) <= RTOL * abs(float.fromhex(e))
+
+
+# ---------------------------------------------------------------- full-window rebalance (pack + spread)
+FP_EDGE = [(64, 15), (128, 25), (128, 21), (64, 1), (64, 63), (64, 64), (64, 0), (2, 1), (4, 3), (8, 8), (16, 1)]
+
+
+@pytest.mark.parametrize("cap,m", FP_EDGE + [(1 << 10, 1), (1 << 12, 2867), (1 << 14, 11468), (1 << 15, 9830),
+                                             (1 << 16, 45875), (1 << 18, 100000), (1 << 20, 734003)])
+def test_bulk_spread_matches_oracle(dsa, hip, oracle, cap, m):
+    """dynamicsparsevec of n keys -> capacity rule + one full-array spread (src/pma.jl:42-55,69-84).
+    (W, E) pairs of SURVEY App. A.3 where floor(fl(k*fl(W/E))) != floor(kW/E) are included via n."""
+    # choose n so that capacity_for(n) == cap when possible, else just use m keys
+    n = m if m > 0 else 0
+    keys = (np.arange(1, n + 1) * 3).astype(np.int64)
+    vals = unit12_array(11, n) if n else np.zeros(0)
+    a = dsa.dynamicsparsevec(keys, vals, binding=hip)
+    b = dsa.dynamicsparsevec(keys, vals, binding=oracle)
+    assert_vec_equal(a, b)
+
+
+@pytest.mark.parametrize("n", [5, 45, 100, 1000, 5000, 70000, 300000, 1000003])
+def test_rebalance_root_idempotent_and_equal(dsa, hip, oracle, n):
+    keys = np.cumsum(1 + (splitmix_array(3, n) % np.uint64(5)).astype(np.int64))
+    vals = unit12_array(4, n)
+    a = dsa.dynamicsparsevec(keys, vals, binding=hip)
+    b = dsa.dynamicsparsevec(keys, vals, binding=oracle)
+    assert_vec_equal(a, b)
+    # punch holes (deletes that do not trigger a rebalance are fine too), then rebalance the root window
+    dele = keys[:: 7][: min(2000, n // 7)]
+    a.set_batch(dele, np.zeros(len(dele)))
+    b.set_batch(dele, np.zeros(len(dele)))
+    assert_vec_equal(a, b)
+    a.rebalance_root()
+    b.rebalance_root()
+    assert_vec_equal(a, b)
+    a.rebalance_root()
+    assert_vec_equal(a, b)
+
+
+# ---------------------------------------------------------------- batched writes through the device sequencer
+@pytest.mark.parametrize("seed,n0,nops,keyspace", [(1, 0, 3000, 10 ** 6), (2, 1000, 5000, 5000), (3, 10000, 20000, 10 ** 7),
+                                                   (4, 50, 4000, 300)])
+def test_vec_mixed_batch_matches_oracle(dsa, hip, oracle, seed, n0, nops, keyspace):
+    g = SplitMix64(seed)
+    keys0 = sorted({1 + g.next() % keyspace for _ in range(n0)})
+    vals0 = [g.unit12() for _ in keys0]
+    a = dsa.dynamicsparsevec(keys0, vals0, binding=hip)
+    b = dsa.dynamicsparsevec(keys0, vals0, binding=oracle)
+    ks, vs = [], []
+    for _ in range(nops):
+        r = g.next() % 10
+        k = 1 + g.next() % keyspace
+        ks.append(k)
+        vs.append(0.0 if r < 3 else g.unit12())
+    a.set_batch(ks, vs)
+    b.set_batch(ks, vs)
+    assert_vec_equal(a, b)
+    q = [1 + g.next() % keyspace for _ in range(500)] + ks[:500]
+    assert np.array_equal(a.get_batch(q), b.get_batch(q))
+    assert a.nnz() == b.nnz()
+
+
+def test_c1_plumbing_vector_10k_plus_1k_ops(dsa, hip, oracle):
+    """BASELINE config 1: 10k-nnz vector + 1k mixed setindex! (70% new / 20% overwrite / 10% delete)."""
+    g = SplitMix64(1)
+    seen, keys = set(), []
+    while len(keys) < 10000:
+        k = 1 + g.next() % 10 ** 7
+        if k not in seen:
+            seen.add(k)
+            keys.append(k)
+    g6 = SplitMix64(6)
+    vals = [g6.unit12() for _ in keys]
+    a = dsa.dynamicsparsevec(keys, vals, binding=hip)
+    b = dsa.dynamicsparsevec(keys, vals, binding=oracle)
+    assert a.info()["capacity"] == 1 << 14
+    g2 = SplitMix64(2)
+    ks, vs = [], []
+    for _ in range(1000):
+        r = g2.next() % 10
+        if r < 7:
+            ks.append(1 + g2.next() % 10 ** 7); vs.append(g2.unit12())
+        elif r < 9:
+            ks.append(keys[g2.next() % len(keys)]); vs.append(g2.unit12())
+        else:
+            ks.append(keys[g2.next() % len(keys)]); vs.append(0.0)
+    for k, v in zip(ks[:200], vs[:200]):      # single-op entry point
+        a[k] = v
+        b[k] = v
+    a.set_batch(ks[200:], vs[200:])
+    b.set_batch(ks[200:], vs[200:])
+    assert_vec_equal(a, b)
+
+
+@pytest.mark.parametrize("n0,napp", [(700, 300), (44000, 6000), (175000, 40000)])
+def test_ascending_appends_trigger_big_windows_and_extend(dsa, hip, oracle, n0, napp):
+    """The append pattern of BASELINE config 2 (scaled): escalates through every window level, the
+    grid-wide rebalance kernel (windows > 8192 slots) and _extend!."""
+    keys0 = np.arange(1, n0 + 1, dtype=np.int64) * 2
+    vals0 = unit12_array(3, n0)
+    a = dsa.dynamicsparsevec(keys0, vals0, binding=hip)
+    b = dsa.dynamicsparsevec(keys0, vals0, binding=oracle)
+    app = np.arange(2 * n0 + 1, 2 * n0 + 1 + napp, dtype=np.int64)
+    vapp = unit12_array(5, napp)
+    a.set_batch(app, vapp)
+    b.set_batch(app, vapp)
+    assert_vec_equal(a, b)
+    ia, ib = a.info(), b.info()
+    assert ia["stat_extends"] == ib["stat_extends"] and ia["stat_window_slots"] == ib["stat_window_slots"]
+    assert ia["stat_rebalances"] == ib["stat_rebalances"]
+    # descending deletes: shrink path
+    a.set_batch(app[::-1], np.zeros(napp))
+    b.set_batch(app[::-1], np.zeros(napp))
+    assert_vec_equal(a, b)
+
+
+def test_c2_full_scale_batches(dsa, hip, oracle):
+    """BASELINE config 2 at full size: 2^20-slot PMA (700k keys), batch A = 100k ascending appends
+    (one 2^20-slot root rebalance + one extend to 2^21), batch B = 100k uniform odd keys."""
+    n0 = 700000
+    keys0 = np.arange(1, n0 + 1, dtype=np.int64) * 2
+    a = dsa.dynamicsparsevec(keys0, unit12_array(3, n0), binding=hip)
+    b = dsa.dynamicsparsevec(keys0, unit12_array(3, n0), binding=oracle)
+    assert a.info()["capacity"] == 1 << 20 and a.info()["segment_capacity"] == 16 and a.info()["height"] == 16
+    app = np.arange(1400001, 1500001, dtype=np.int64)
+    va = unit12_array(3, 100000)
+    a.set_batch(app, va)
+    b.set_batch(app, va)
+    assert_vec_equal(a, b)
+    ia = a.info()
+    assert ia["capacity"] == 1 << 21 and ia["stat_extends"] == 1
+    assert ia["stat_window_slots"] == b.info()["stat_window_slots"]
+    odd = np.unique(1 + 2 * (splitmix_array(4, 120000) % np.uint64(700000)).astype(np.int64))[:100000]
+    rng = np.random.default_rng(4)
+    rng.shuffle(odd)
+    vb = unit12_array(4, len(odd))
+    a.set_batch(odd, vb)
+    b.set_batch(odd, vb)
+    assert_vec_equal(a, b)
+
+
+# ---------------------------------------------------------------- PackedCSC / matrix writes
+def rand_matrix_ops(seed, nrow, ncol, nops, pzero=0.25):
+    g = SplitMix64(seed)
+    I, J, V = [], [], []
+    for _ in range(nops):
+        I.append(1 + g.next() % nrow)
+        J.append(1 + g.next() % ncol)
+        V.append(0.0 if g.next() % 100 < pzero * 100 else float(1 + g.next() % 9))
+    return I, J, V
+
+
+@pytest.mark.parametrize("seed,nrow,ncol,nnz0,nops", [(11, 40, 60, 1, 2500), (12, 300, 200, 5000, 6000),
+                                                      (13, 2000, 3000, 60000, 30000), (14, 7, 5, 10, 800)])
+def test_matrix_random_writes_match_oracle(dsa, hip, oracle, seed, nrow, ncol, nnz0, nops):
+    I0, J0, V0 = rand_matrix_ops(seed, nrow, ncol, nnz0, pzero=0.0)
+    a = dsa.dynamicsparse(I0, J0, V0, binding=hip)
+    b = dsa.dynamicsparse(I0, J0, V0, binding=oracle)
+    assert_mat_equal(a, b)
+    I, J, V = rand_matrix_ops(seed + 100, nrow + 10, ncol + 10, nops)
+    a.set_batch(I, J, V)
+    b.set_batch(I, J, V)
+    assert_mat_equal(a, b)
+    L = a.export_layout(0)
+    check_semaphores(L["keys"], L["vals"], L["occ"], L["semaphores"])
+    check_key_order(L["keys"], L["occ"])
+    q = rand_matrix_ops(seed + 200, nrow + 10, ncol + 10, 1000)
+    assert np.array_equal(a.get_batch(q[0], q[1]), b.get_batch(q[0], q[1]))
+    assert a.nnz() == b.nnz()
+    # column / row deletion (tombstones), then more writes that avoid the documented crash paths
+    cols = sorted({1 + (s % ncol) for s in range(3, 40, 7)})
+    for c in cols:
+        for m_ in (a, b):
+            try:
+                m_.deletecolumn(c)
+            except dsa.DsaArgumentError:
+                pass
+    assert_mat_equal(a, b)
+    x = unit12_array(seed, max(a.size()) + 5)
+    ya = a.mul(x[: a.size()[1]])
+    yb = b.mul(x[: b.size()[1]])
+    np.testing.assert_allclose(ya, yb, rtol=RTOL, atol=0)
+    yta = a.mul(x[: a.size()[0]], transpose=True)
+    ytb = b.mul(x[: b.size()[0]], transpose=True)
+    np.testing.assert_allclose(yta, ytb, rtol=RTOL, atol=0)
+
+
+def test_matrix_from_empty_streaming_columns_c5_scaled(dsa, hip, oracle):
+    """BASELINE config 5 (scaled): stream new columns element by element into an empty matrix,
+    SpMV every few hundred columns, compared with the oracle."""
+    m_rows, ncols, per = 500, 600, 8
+    a = dsa.dynamicsparse(fill_mode=False, binding=hip)
+    b = dsa.dynamicsparse(fill_mode=False, binding=oracle)
+    g = SplitMix64(11)
+    gv = SplitMix64(12)
+    x = unit12_array(13, ncols)
+    for start in range(0, ncols, 150):
+        I, J, V = [], [], []
+        for j in range(start + 1, min(start + 150, ncols) + 1):
+            rows = set()
+            while len(rows) < per:
+                rows.add(1 + g.next() % m_rows)
+            for r in sorted(rows):
+                I.append(r); J.append(j); V.append(gv.unit12())
+        a.set_batch(I, J, V)
+        b.set_batch(I, J, V)
+        assert_mat_equal(a, b)
+        ya = a.mul(x[: a.size()[1]])
+        yb = b.mul(x[: b.size()[1]])
+        np.testing.assert_allclose(ya, yb, rtol=RTOL, atol=0)
+
+
+def test_error_codes_match_reference_sites(dsa, hip):
+    a = dsa.dynamicsparse([1, 2], [1, 2], [1.0, 2.0], binding=hip)
+    with pytest.raises(dsa.DsaArgumentError):
+        a.deletecolumn(99)                      # src/pcsr.jl:208
+    with pytest.raises(dsa.DsaArgumentError):
+        a[0, 1] = 1.0                           # reserved semaphore key
+    with pytest.raises(dsa.DsaErrorException):
+        a.closefillmode()                       # src/matrix.jl:127
+    p = dsa.packedcsc([[1, 2], [3]], [[1.0, 2.0], [3.0]], binding=hip)
+    p.deletepartition(1)
+    with pytest.raises(dsa.DsaErrorException) as ei:
+        p[1, 1] = 5.0                           # src/pcsr.jl:299
+    assert ei.value.code == dsa.binding.EDELETED
+    with pytest.raises(dsa.DsaBoundsError):
+        p.deletepartition(7)                    # src/pcsr.jl:190
+
+
+# ---------------------------------------------------------------- SpMV
+@pytest.mark.parametrize("m,n,per_col,seed", [(50, 40, 3, 1), (3000, 2500, 7, 2), (100000, 80000, 10, 3), (64, 100000, 2, 4)])
+def test_spmv_matches_oracle(dsa, hip, oracle, m, n, per_col, seed):
+    rows = 1 + (splitmix_array(seed, n * per_col) % np.uint64(m)).astype(np.int64)
+    cols = np.repeat(np.arange(1, n + 1, dtype=np.int64), per_col)
+    # integer-valued floats: duplicate (i,j) fold order is irrelevant
+    vals = (1 + splitmix_array(seed + 1, n * per_col) % np.uint64(9)).astype(np.float64)
+    a = dsa.dynamicsparse(rows, cols, vals, m, n, binding=hip)
+    b = dsa.dynamicsparse(rows, cols, vals, m, n, binding=oracle)
+    assert_mat_equal(a, b)
+    x = unit12_array(seed + 2, max(m, n))
+    for transpose, nx in ((False, n), (True, m)):
+        ya = a.mul(x[:nx], transpose=transpose)
+        yb = b.mul(x[:nx], transpose=transpose)
+        np.testing.assert_allclose(ya, yb, rtol=RTOL, atol=0)
+    # sparse x: touched-row pattern and values
+    xi = np.unique(1 + (splitmix_array(seed + 3, 200) % np.uint64(n)).astype(np.int64))
+    xv = unit12_array(seed + 4, len(xi))
+    ia, va = a.mul((xi, xv))
+    ib, vb = b.mul((xi, xv))
+    assert np.array_equal(ia, ib)
+    np.testing.assert_allclose(va, vb, rtol=RTOL, atol=0)
+
+
+def test_spmv_long_rows_and_tile_straddling(dsa, hip, oracle):
+    """A few very long rows (thousands of cells: many 2048-slot tiles per row) next to short ones."""
+    n = 30000
+    I = np.concatenate([np.full(n, 1), np.full(n // 2, 2), np.arange(3, 3 + 2000), np.full(n, 9000)])
+    J = np.concatenate([np.arange(1, n + 1), np.arange(1, n + 1, 2), np.arange(1, 2001), np.arange(1, n + 1)])
+    V = unit12_array(21, len(I))
+    a = dsa.dynamicsparse(I, J, V, binding=hip)
+    b = dsa.dynamicsparse(I, J, V, binding=oracle)
+    assert_mat_equal(a, b)
+    x = unit12_array(22, n)
+    np.testing.assert_allclose(a.mul(x), b.mul(x), rtol=RTOL, atol=0)
+    np.testing.assert_allclose(a.mul(x[:9000], transpose=True), b.mul(x[:9000], transpose=True), rtol=RTOL, atol=0)
+
+
+def test_spmv_device_pointers_gather_and_scatter(dsa, hip, oracle):
+    import ctypes as C
+    import torch
+    m, n, per = 20000, 15000, 6
+    rows = 1 + (splitmix_array(5, n * per) % np.uint64(m)).astype(np.int64)
+    cols = np.repeat(np.arange(1, n + 1, dtype=np.int64), per)
+    vals = (1 + splitmix_array(6, n * per) % np.uint64(9)).astype(np.float64)
+    a = dsa.dynamicsparse(rows, cols, vals, m, n, binding=hip)
+    b = dsa.dynamicsparse(rows, cols, vals, m, n, binding=oracle)
+    x = unit12_array(7, max(m, n))
+    dev = torch.device("cuda:0")
+    hip.call("mat_set_stream", a.h, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    for transpose, nx, ny in ((0, n, m), (1, m, n)):
+        xd = torch.from_numpy(x[:nx].copy()).to(dev)
+        ref = b.mul(x[:nx], transpose=bool(transpose))
+        for algo in (0, 1):
+            yd = torch.full((ny,), 7.0, dtype=torch.float64, device=dev)
+            hip.call("mat_spmv_dense_dev", a.h, transpose, algo, C.c_void_p(xd.data_ptr()), nx, C.c_void_p(yd.data_ptr()), ny)
+            torch.cuda.synchronize()
+            np.testing.assert_allclose(yd.cpu().numpy(), ref, rtol=RTOL, atol=0)
+
+
+def test_c3_scale_build_and_spmv_properties(dsa, hip):
+    """BASELINE config 3 at a quarter of full size on the GPU alone (the oracle needs tens of seconds
+    there): size-independent properties — capacity rule, sorted partitions, semaphore table,
+    linearity of SpMV, A x vs A' (checksum identity  1' (A x) == (A' 1)' x)."""
+    m = n = 250000
+    per = 10
+    rows = 1 + (splitmix_array(5, n * per) % np.uint64(m)).astype(np.int64)
+    cols = np.repeat(np.arange(1, n + 1, dtype=np.int64), per)
+    vals = unit12_array(6, n * per)
+    key = cols * (m + 1) + rows
+    _, first = np.unique(key, return_index=True)          # duplicate-free
+    rows, cols, vals = rows[first], cols[first], vals[first]
+    a = dsa.dynamicsparse(rows, cols, vals, m, n, binding=hip)
+    for o in (0, 1):
+        L = a.export_layout(o)
+        nelem = len(rows) + L["info"]["nb_partitions"]
+        assert L["info"]["nb_elements"] == nelem
+        assert L["info"]["capacity"] == 1 << int(np.ceil(np.log2(np.ceil(nelem / 0.7))))
+        assert int(L["occ"].sum()) == nelem
+        occ = L["occ"].astype(bool)
+        k = L["keys"][occ]
+        sem = k == 0
+        assert int(sem.sum()) == L["info"]["nb_partitions"]
+        pos = np.nonzero(occ)[0] + 1
+        assert np.array_equal(pos[sem], L["semaphores"])            # table <-> slots
+        assert np.array_equal(L["vals"][occ][sem], np.arange(1, sem.sum() + 1, dtype=np.float64))
+        d = np.diff(k)
+        assert np.all((d > 0) | sem[1:] | sem[:-1])                 # ascending keys inside partitions
+        assert np.all(np.diff(L["col_keys"]) > 0)
+    x1 = unit12_array(7, n)
+    x2 = unit12_array(8, n)
+    y1, y2, y12 = a.mul(x1), a.mul(x2), a.mul(x1 + 2.0 * x2)
+    np.testing.assert_allclose(y12, y1 + 2.0 * y2, rtol=1e-11, atol=0)
+    ones = np.ones(m)
+    colsum = a.mul(ones, transpose=True)
+    assert abs(y1.sum() - colsum @ x1) <= 1e-10 * abs(y1.sum())
+    # independent value check with scipy on the same triplets
+    import scipy.sparse as sp
+    A = sp.csr_matrix((vals, (rows - 1, cols - 1)), shape=(m, n))
+    np.testing.assert_allclose(y1, A @ x1, rtol=1e-12, atol=0)
