@@ -1,0 +1,274 @@
+#!/usr/bin/env python3
+"""bench.py — SpMV GB/s (% of HBM roofline) on the 10M-nnz PCSR of BASELINE.json, 1 -> N MI355X,
+plus inserts/s and rebalance GB/s as extra fields of the same JSON line.
+
+A "step" is one pass of the hot path over one batch of synthetic input: y = A x on the
+device-resident PCSR (config C3 of SURVEY.md §8d: 1M x 1M Float64, 10 entries per column = 10M nnz,
+dense x), followed — when N > 1 — by the RCCL all-reduce of y over xGMI.  Multi-GPU is weak scaling by
+column range: rank g owns columns (g*1M, (g+1)*1M] of a 1M x (N*1M) matrix (10M nnz per GPU) and the
+matching slice of x; the only data-path collective is the all-reduce of the 1M-entry y.
+
+Launch: python bench.py --gpus 1            (default)
+        python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+
+M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def splitmix_array(seed, n, start=0):
+    with np.errstate(over="ignore"):
+        idx = np.arange(start + 1, start + n + 1, dtype=np.uint64)
+        z = np.uint64(seed) + idx * np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+
+def unit12(seed, n, start=0):
+    return 1.0 + (splitmix_array(seed, n, start) >> np.uint64(11)).astype(np.float64) * 2.0 ** -53
+
+
+def c3_triplets(m, ncols, per, col0, seed_rows, seed_vals):
+    """every column gets exactly `per` distinct rows 1 + z % m (re-draw on in-column duplicate)."""
+    n = ncols * per
+    rows = 1 + (splitmix_array(seed_rows, n, start=col0 * per) % np.uint64(m)).astype(np.int64)
+    cols_local = np.repeat(np.arange(ncols, dtype=np.int64), per)
+    extra = 0
+    while True:
+        key = cols_local * np.int64(m + 1) + rows
+        order = np.argsort(key, kind="stable")
+        ks = key[order]
+        dup = np.zeros(n, dtype=bool)
+        dup[order[1:]] = ks[1:] == ks[:-1]
+        nd = int(dup.sum())
+        if nd == 0:
+            break
+        rows[dup] = 1 + (splitmix_array(seed_rows + 1000 + extra, nd) % np.uint64(m)).astype(np.int64)
+        extra += 1
+    vals = unit12(seed_vals, n, start=col0 * per)
+    return rows, cols_local + 1 + col0, vals
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--rows", type=int, default=1_000_000)
+    ap.add_argument("--cols-per-gpu", type=int, default=1_000_000)
+    ap.add_argument("--per-col", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the inserts/s and rebalance legs")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    import dsa_loader
+    dsa = dsa_loader.load()
+    hip = dsa.product()                      # raises if libdsa_hip.so is missing: no fallback
+    hip.call("set_device", local_rank)
+
+    m, ncl, per = args.rows, args.cols_per_gpu, args.per_col
+    col0 = rank * ncl
+    t0 = time.time()
+    I, J, V = c3_triplets(m, ncl, per, col0, seed_rows=5, seed_vals=6)
+    # the shard is the reference-layout PCSR of its own sub-matrix: local column keys 1..ncl
+    A = dsa.dynamicsparse(I, J - col0, V, m, ncl, binding=hip)
+    build_s = time.time() - t0
+    info_row = A.info(dsa.ROWMAJOR)
+    cap = info_row["capacity"]
+    nnz = len(I)
+
+    stream = torch.cuda.current_stream()
+    hip.call("mat_set_stream", A.h, C.c_void_p(stream.cuda_stream))
+    x = torch.from_numpy(unit12(7, ncl, start=col0)).to(dev)
+    y = torch.zeros(m, dtype=torch.float64, device=dev)
+    xp, yp = C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr())
+
+    def spmv():
+        hip.call("mat_spmv_dense_dev", A.h, 0, 0, xp, ncl, yp, m)
+
+    def step():
+        spmv()
+        if world > 1:
+            dist.all_reduce(y, op=dist.ReduceOp.SUM)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t1 = time.perf_counter()
+    for k in range(args.steps):
+        ev[k][0].record(stream)
+        spmv()
+        ev[k][1].record(stream)
+        if world > 1:
+            dist.all_reduce(y, op=dist.ReduceOp.SUM)
+    barrier()
+    elapsed = time.perf_counter() - t1
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    ms_per_step = elapsed * 1e3 / args.steps
+
+    # algorithmic bytes of one SpMV launch: 16 B per streamed slot + x read + y written
+    bytes_launch = 16 * cap + 8 * ncl + 8 * m
+    useful_bytes = 16 * nnz + 8 * ncl + 8 * m
+    value = world * bytes_launch / 1e9 / (ms_per_step / 1e3)
+    achieved = bytes_launch / 1e9 / (kern_ms / 1e3)
+
+    out = {
+        "metric": "spmv_gbps_10M_nnz_pcsr",
+        "value": round(value, 2),
+        "unit": "GB/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 5),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": "C3: PCSR %dx%d Float64, %d nnz per GPU, dense-x SpMV y=A*x (gather over the rowmajor twin)"
+                               % (m, ncl * world, nnz),
+                   "capacity_slots": cap, "density": round((nnz + m) / cap, 4), "sharding": "column-range x%d" % world,
+                   "collective": "RCCL all_reduce(y, %d f64)" % m if world > 1 else "none"},
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                     "kernel": "dsa::k_spmv<false> (+ 8 MB y memset)", "algorithmic_bytes": bytes_launch,
+                     "kernel_ms": round(kern_ms, 5),
+                     "useful_bytes_no_gaps": useful_bytes,
+                     "useful_gbps": round(useful_bytes / 1e9 / (kern_ms / 1e3), 2)},
+        "nnz_per_s": round(world * nnz / (ms_per_step / 1e3), 1),
+        "build_s": round(build_s, 2),
+    }
+
+    if rank == 0 and not args.no_extras:
+        out.update(extras(dsa, hip, torch, A, dev))
+    if rank == 0 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(dsa, m, per)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+def extras(dsa, hip, torch, A, dev):
+    """rebalance roofline (full 2^24-slot window of the 10M-nnz PCSR) and inserts/s (config C2)."""
+    res = {}
+    stream = torch.cuda.current_stream()
+    # --- full-window pack+spread of the colmajor PCSR array (incl. semaphore scatter)
+    cap = A.info(dsa.COLMAJOR)["capacity"]
+    for _ in range(3):
+        A.rebalance_root(dsa.COLMAJOR)
+    torch.cuda.synchronize()
+    reps = 20
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for _ in range(reps):
+        A.rebalance_root(dsa.COLMAJOR)
+    e1.record(stream)
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    b = 32 * cap
+    res["roofline_rebalance"] = {"bound": "hbm", "achieved": round(b / 1e9 / (ms / 1e3), 2), "peak": HBM_PEAK_GBS,
+                                 "unit": "GB/s", "frac": round(b / 1e9 / (ms / 1e3) / HBM_PEAK_GBS, 4),
+                                 "window_slots": cap, "algorithmic_bytes": b, "ms": round(ms, 5),
+                                 "kernels": "k_tile_count + k_tile_scan + k_move<false>"}
+    # --- C2: 2^20-slot PMA, 100k ascending appends (batch A) and 100k uniform odd keys (batch B)
+    n0 = 700000
+    keys0 = np.arange(1, n0 + 1, dtype=np.int64) * 2
+    v = dsa.dynamicsparsevec(keys0, unit12(3, n0), binding=hip)
+    app = np.arange(1400001, 1500001, dtype=np.int64)
+    t = time.perf_counter()
+    v.set_batch(app, unit12(3, 100000))
+    ta = time.perf_counter() - t
+    info = v.info()
+    odd = np.unique(1 + 2 * (splitmix_array(4, 120000) % np.uint64(700000)).astype(np.int64))[:100000]
+    np.random.default_rng(4).shuffle(odd)
+    t = time.perf_counter()
+    v.set_batch(odd, unit12(4, len(odd)))
+    tb = time.perf_counter() - t
+    res["inserts_per_s"] = {"batch_A_ascending_appends": round(100000 / ta, 1), "batch_B_uniform": round(len(odd) / tb, 1),
+                            "config": "C2: 2^20-slot PMA (700k keys) + 100k batched inserts, whole dsa_vec_set_batch call incl. H2D",
+                            "window_slots_per_insert_A": round(info["stat_window_slots"] / 100000, 1),
+                            "extends": info["stat_extends"]}
+    return res
+
+
+def cpu_baseline(dsa, m, per):
+    """The CPU oracle (a single-thread C++ restatement of the reference; the Julia reference cannot run
+    here) on a bounded sample of the same workload: the first 100k columns of the C3 matrix."""
+    import multiprocessing
+    ora_path = os.path.join(ROOT, "oracle", "liboracle.so")
+    if not os.path.exists(ora_path):
+        import subprocess
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "liboracle.so"])
+    ora = dsa.Binding(ora_path, "ora", device_api=False)
+    ncs = 400_000
+    I, J, V = c3_triplets(m, ncs, per, 0, seed_rows=5, seed_vals=6)
+    t = time.perf_counter()
+    B = dsa.dynamicsparse(I, J, V, m, ncs, binding=ora)
+    tb = time.perf_counter() - t
+    x = unit12(7, ncs)
+    cap = B.info(dsa.COLMAJOR)["capacity"]
+    reps = 3
+    t = time.perf_counter()
+    for _ in range(reps):
+        B.mul(x)                                  # _mul with the reference's Dict accumulator
+    ts = (time.perf_counter() - t) / reps
+    bytes_ = 16 * cap + 8 * ncs + 8 * m
+    xx, xp = dsa.binding._f64(x)
+    yy = np.empty(m)
+    lib = ora.lib
+    lib.ora_mat_spmv_dense_fastacc.argtypes = [C.c_void_p, C.c_int32, dsa.binding.P_F64, C.c_int64, dsa.binding.P_F64, C.c_int64]
+    t = time.perf_counter()
+    for _ in range(reps):
+        lib.ora_mat_spmv_dense_fastacc(B.h, 0, xp, ncs, yy.ctypes.data_as(dsa.binding.P_F64), m)
+    tf = (time.perf_counter() - t) / reps
+    return {"value": round(bytes_ / 1e9 / ts, 4), "unit": "GB/s", "cores": 1, "kind": "port",
+            "sample": "first 400k columns of the C3 matrix (1M x 400k, %d nnz, colmajor capacity %d): y = A*x with the "
+                      "reference's Dict accumulator (src/operations.jl:101), 1 thread of %d host cores" % (len(I), cap, multiprocessing.cpu_count()),
+            "nnz_per_s": round(len(I) / ts, 1),
+            "dense_accumulator_gbps": round(bytes_ / 1e9 / tf, 4), "dense_accumulator_nnz_per_s": round(len(I) / tf, 1),
+            "build_s": round(tb, 2)}
+
+
+if __name__ == "__main__":
+    main()

@@ -165,11 +165,34 @@ def product_library_path() -> str:
     return os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libdsa_hip.so")
 
 
+def _share_hip_runtime_with_torch():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so (soname libamdhip64.so.7).  Two HIP runtimes
+    in one process cannot both open the GPU, so when torch is installed its copy is loaded first
+    (without importing torch): libdsa_hip.so's DT_NEEDED `libamdhip64.so.7` then resolves to it, and a
+    later `import torch` finds the very same file already mapped."""
+    import importlib.util
+    import sys
+    if os.environ.get("DSA_HIP_RUNTIME", "torch") != "torch":
+        return
+    if "torch" in sys.modules:
+        return          # torch's runtime is already mapped
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
 def product() -> Binding:
     """The HIP product library.  Fails loudly if it has not been built — there is no fallback."""
     global _PRODUCT
     if _PRODUCT is None:
         path = product_library_path()
+        _share_hip_runtime_with_torch()
         if not os.path.exists(path):
             raise RuntimeError(
                 f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
