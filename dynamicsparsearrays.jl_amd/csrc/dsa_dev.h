@@ -91,22 +91,28 @@ __device__ __host__ inline SpreadGeom make_geom(int64_t W, int64_t m) {
     g.inv_f = (double)g.E / (double)W;
     return g;
 }
-__device__ __forceinline__ int64_t gap_D(const SpreadGeom& g, int64_t k) {
-    return (int64_t)floor(__dmul_rn((double)k, g.f));
+// Window sizes are < 2^31 slots (checked on the host), so offsets / gap indices fit int32 and the
+// int <-> double conversions are single instructions (v_cvt_f64_i32 / v_cvt_i32_f64).
+__device__ __forceinline__ int gap_D(const SpreadGeom& g, int k) {
+    return (int)floor(__dmul_rn((double)k, g.f));
 }
-// number of empty offsets <= q, q in [0, W]
-__device__ __forceinline__ int64_t gaps_le(const SpreadGeom& g, int64_t q) {
-    if (g.E <= 0) return 0;
-    int64_t k = (int64_t)((double)q * g.inv_f);
-    if (k > g.E) k = g.E;
+// number of empty offsets <= q, q in [0, W].  D(k) <= q  <=>  k*f < q+1, so the count is within one of
+// floor((q+1)*E/W); the two fix-up loops make it exact for the Float64 D and almost never iterate twice.
+__device__ __forceinline__ int gaps_le(const SpreadGeom& g, int q) {
+    const int E = (int)g.E;
+    if (E <= 0) return 0;
+    int k = (int)((double)(q + 1) * g.inv_f);
+    if (k > E) k = E;
     if (k < 0) k = 0;
-    while (k < g.E && gap_D(g, k + 1) <= q) ++k;
+#pragma clang loop vectorize(disable) unroll(disable)
+    while (k < E && gap_D(g, k + 1) <= q) ++k;
+#pragma clang loop vectorize(disable) unroll(disable)
     while (k > 0 && gap_D(g, k) > q) --k;
     return k;
 }
 // offset q in [1, W]: returns true if q is a gap; otherwise *rank = 1-based rank of the cell landing on q
-__device__ __forceinline__ bool slot_is_gap(const SpreadGeom& g, int64_t q, int64_t* rank) {
-    const int64_t k = gaps_le(g, q);
+__device__ __forceinline__ bool slot_is_gap(const SpreadGeom& g, int q, int* rank) {
+    const int k = gaps_le(g, q);
     if (k > 0 && gap_D(g, k) == q) return true;
     *rank = q - k;
     return false;

@@ -18,6 +18,7 @@
 //                  whole — is stored as 16-byte key / value pairs, the occupancy words are rebuilt
 //                  from two ballots, and semaphore positions are scattered to the table.
 #include "dsa_dev.h"
+#include <cstdlib>
 
 namespace dsa {
 
@@ -95,6 +96,7 @@ struct MoveArgs {
     int64_t Wd, m;
     int64_t* sems;
     const uint32_t* tile_off; int64_t ntiles;
+    int dbg;   // DSA_DBG_MOVE ablation knob (dev only): 1 = skip staging, 2 = skip the write phase
 };
 
 template <bool PACKED>
@@ -105,11 +107,11 @@ __global__ __launch_bounds__(MOVE_BLOCK) void k_move(MoveArgs a) {
     const SpreadGeom g = make_geom(a.Wd, a.m);
     const int64_t q0 = (int64_t)blockIdx.x * DST_TILE;          // this tile covers offsets q0+1 .. qend
     const int64_t qend = (q0 + DST_TILE < a.Wd) ? q0 + DST_TILE : a.Wd;
-    const int64_t kA = gaps_le(g, q0), kB = gaps_le(g, qend);
+    const int64_t kA = gaps_le(g, (int)q0), kB = gaps_le(g, (int)qend);
     const int64_t R0 = q0 - kA;                                  // cells placed before this tile
     const int64_t cnt = (qend - q0) - (kB - kA);                 // cells landing in this tile: ranks R0+1..R0+cnt
 
-    if (!PACKED && cnt > 0) {
+    if (!PACKED && cnt > 0 && a.dbg != 1) {
         // first source tile holding rank R0+1: the largest t with tile_off[t] <= R0
         int64_t lo = 0, hi = a.ntiles - 1;
         while (lo < hi) {
@@ -122,23 +124,34 @@ __global__ __launch_bounds__(MOVE_BLOCK) void k_move(MoveArgs a) {
             const uint64_t myword = a.src_occ[wl] & range_mask_for_word(wl, a.src_lo0, a.src_hi0);
             const uint32_t mypc = popc64(myword);
             const uint32_t myoff = wave_excl_scan(mypc);
-            for (int w = wv; w < SRC_TILE_WORDS; w += MOVE_BLOCK / 64) {
-                const uint64_t mask = __shfl(myword, w, 64);
-                const int64_t off = base + (int64_t)__shfl(myoff, w, 64);
-                const int pc = popc64(mask);
-                if (pc == 0 || off + pc <= R0 || off >= R0 + cnt) continue;   // wave-uniform
-                if ((mask >> lane) & 1ull) {
-                    const int64_t rank = off + popc64(mask & mask_lt(lane)) + 1;
-                    if (rank > R0 && rank <= R0 + cnt) {
-                        const int64_t s = ((a.src_w0 + t * SRC_TILE_WORDS + w) << 6) + lane;
-                        sK[rank - R0 - 1] = a.src_keys[s];
-                        sV[rank - R0 - 1] = a.src_vals[s];
-                    }
+            // wave wv owns 16 consecutive words of the tile; 4 words per step so that 8 loads are in flight
+            constexpr int WPW = SRC_TILE_WORDS / (MOVE_BLOCK / 64);
+#pragma unroll 1
+            for (int wb = wv * WPW; wb < (wv + 1) * WPW; wb += 4) {
+                int64_t kk[4]; double vv[4]; int64_t rk[4]; bool act[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int w = wb + u;
+                    const uint64_t mask = __shfl(myword, w, 64);
+                    const int64_t off = base + (int64_t)__shfl(myoff, w, 64);
+                    const int pc = popc64(mask);
+                    const bool wact = pc != 0 && off + pc > R0 && off < R0 + cnt;      // wave-uniform
+                    rk[u] = off + popc64(mask & mask_lt(lane)) + 1;
+                    act[u] = wact && ((mask >> lane) & 1ull) && rk[u] > R0 && rk[u] <= R0 + cnt;
+                    // unconditional loads (inactive lanes read the word's first slot, which is inside the
+                    // allocation) so that all eight loads of the step are in flight together
+                    const int64_t s = ((a.src_w0 + t * SRC_TILE_WORDS + w) << 6) + (act[u] ? lane : 0);
+                    kk[u] = __builtin_nontemporal_load(a.src_keys + s);
+                    vv[u] = __builtin_nontemporal_load(a.src_vals + s);
                 }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (act[u]) { sK[rk[u] - R0 - 1] = kk[u]; sV[rk[u] - R0 - 1] = vv[u]; }
             }
         }
     }
     __syncthreads();
+    if (a.dbg == 2) return;
 
     // ---- write phase: lane <-> 2 adjacent destination slots, 128 slots per wave-iteration ----
     constexpr int PER_WAVE = DST_TILE / (MOVE_BLOCK / 64);   // 512
@@ -151,14 +164,15 @@ __global__ __launch_bounds__(MOVE_BLOCK) void k_move(MoveArgs a) {
         double v2[2] = {0.0, 0.0};
         bool o2[2] = {false, false};
         if (qa <= a.Wd) {
-            int64_t k = gaps_le(g, qa);
-            bool gap = (k > 0 && gap_D(g, k) == qa);
+            const int E = (int)g.E;
+            int k = gaps_le(g, (int)qa);
+            bool gap = (k > 0 && gap_D(g, k) == (int)qa);
             int64_t rank = qa - k;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 if (j == 1) {
                     gap = false;
-                    if (k < g.E && gap_D(g, k + 1) == qa + 1) { ++k; gap = true; }
+                    if (k < E && gap_D(g, k + 1) == (int)qa + 1) { ++k; gap = true; }
                     rank = qa + 1 - k;
                 }
                 if (!gap) {
@@ -216,6 +230,7 @@ hipError_t launch_rebalance(const int64_t* src_keys, const double* src_vals, con
     a.Wd = dst_we - dst_ws + 1; a.m = m;
     a.sems = sems;
     a.tile_off = nullptr; a.ntiles = 0;
+    { static const char* e = getenv("DSA_DBG_MOVE"); a.dbg = e ? atoi(e) : 0; }
     const int64_t ndst = (a.Wd + DST_TILE - 1) / DST_TILE;
     if (src_packed) {
         hipLaunchKernelGGL(k_move<true>, dim3((unsigned)ndst), dim3(MOVE_BLOCK), 0, stream, a);

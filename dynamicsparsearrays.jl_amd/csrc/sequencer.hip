@@ -252,10 +252,10 @@ __device__ void blk_rebalance_small(Seq& S, int64_t ws, int64_t we, int64_t m) {
         }
         __syncthreads();
         for (int64_t base = 0; base < W; base += SEQ_BLOCK) {
-            const int64_t q = base + tid + 1;          // 1-based offset; W is a multiple of 64, block covers 4 words
+            const int q = (int)base + tid + 1;         // 1-based offset; W is a multiple of 64, block covers 4 words
             bool occd = false;
             if (q <= W) {
-                int64_t rank;
+                int rank;
                 if (!slot_is_gap(g, q, &rank)) {
                     occd = true;
                     const int64_t k = S.sK[rank - 1];
@@ -284,9 +284,9 @@ __device__ void blk_rebalance_small(Seq& S, int64_t ws, int64_t we, int64_t m) {
             // single wave: LDS writes above are visible to the same wave after the implicit wave sync
             __builtin_amdgcn_s_waitcnt(0xc07f);        // lgkmcnt(0)
             bool occd = false;
-            const int64_t q = lane + 1;
+            const int q = lane + 1;
             if (q <= W) {
-                int64_t rank;
+                int rank;
                 if (!slot_is_gap(g, q, &rank)) {
                     occd = true;
                     const int64_t k = S.sK[rank - 1];

@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Kernel micro-bench on the C3 matrix (dev tool): times the SpMV and the root rebalance with HIP
+events on the launch stream.  Usage: python tools/kbench.py [--small]"""
+import ctypes as C
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+import dsa_loader  # noqa: E402
+
+dsa = dsa_loader.load()
+hip = dsa.product()
+small = "--small" in sys.argv
+m = ncl = 250_000 if small else 1_000_000
+I, J, V = bench.c3_triplets(m, ncl, 10, 0, 5, 6)
+t = time.time()
+A = dsa.dynamicsparse(I, J, V, m, ncl, binding=hip)
+print("build %.2fs cap %d" % (time.time() - t, A.info(1)["capacity"]))
+stream = torch.cuda.current_stream()
+hip.call("mat_set_stream", A.h, C.c_void_p(stream.cuda_stream))
+dev = torch.device("cuda:0")
+x = torch.from_numpy(bench.unit12(7, ncl)).to(dev)
+y = torch.zeros(m, dtype=torch.float64, device=dev)
+cap = A.info(1)["capacity"]
+
+
+def timeit(fn, reps=30, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for _ in range(reps):
+        fn()
+    e1.record(stream)
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e3   # us
+
+
+for label, algo, tr, nx in (("gather A*x", 0, 0, ncl), ("gather A*x, nx=0 (no x gather)", 0, 0, 0),
+                            ("gather A'*x", 0, 1, m), ("scatter A*x", 1, 0, ncl)):
+    us = timeit(lambda: hip.call("mat_spmv_dense_dev", A.h, tr, algo, C.c_void_p(x.data_ptr()), nx, C.c_void_p(y.data_ptr()), m))
+    b = 16 * cap + 8 * ncl + 8 * m
+    print("%-34s %8.1f us  %7.1f GB/s (%.1f%% of 8 TB/s)" % (label, us, b / us / 1e3, b / us / 1e3 / 80))
+for o in (0, 1):
+    us = timeit(lambda: A.rebalance_root(o), reps=20)
+    b = 32 * cap
+    print("rebalance root orient %d            %8.1f us  %7.1f GB/s (%.1f%%)" % (o, us, b / us / 1e3, b / us / 1e3 / 80))
+ys = torch.zeros(m, dtype=torch.float64, device=dev)
+us = timeit(lambda: ys.copy_(y))
+print("torch copy 8MB %.1f us" % us)
+big = torch.empty(cap * 2, dtype=torch.float64, device=dev)
+big2 = torch.empty(cap * 2, dtype=torch.float64, device=dev)
+us = timeit(lambda: big2.copy_(big))
+print("torch D2D copy %d MB: %.1f us -> %.1f GB/s (read+write)" % (cap * 16 >> 20, us, 2 * cap * 16 / us / 1e3))
