@@ -96,6 +96,7 @@ struct MoveArgs {
     int64_t Wd, m;
     int64_t* sems;
     const uint32_t* tile_off; int64_t ntiles;
+    double tiles_per_cell;          // ntiles / m: interpolation guess for the source tile of a rank
     int dbg;   // DSA_DBG_MOVE ablation knob (dev only): 1 = skip staging, 2 = skip the write phase
 };
 
@@ -111,43 +112,73 @@ __global__ __launch_bounds__(MOVE_BLOCK) void k_move(MoveArgs a) {
     const int64_t R0 = q0 - kA;                                  // cells placed before this tile
     const int64_t cnt = (qend - q0) - (kB - kA);                 // cells landing in this tile: ranks R0+1..R0+cnt
 
-    if (!PACKED && cnt > 0 && a.dbg != 1) {
-        // first source tile holding rank R0+1: the largest t with tile_off[t] <= R0
-        int64_t lo = 0, hi = a.ntiles - 1;
-        while (lo < hi) {
-            const int64_t mid = (lo + hi + 1) >> 1;
-            if ((int64_t)a.tile_off[mid] <= R0) lo = mid; else hi = mid - 1;
+    if (!PACKED) {
+        // ---- locate the first source tile holding rank R0+1: the largest t with tile_off[t] <= R0.
+        // Interpolated guess + short walk (cell density is near-uniform after a spread); bisection fallback.
+        int64_t lo = 0;
+        if (cnt > 0) {
+            lo = (int64_t)((double)R0 * a.tiles_per_cell);
+            if (lo > a.ntiles - 1) lo = a.ntiles - 1;
+            int steps = 0;
+            while (steps < 6) {
+                const int64_t o0 = a.tile_off[lo], o1 = a.tile_off[lo + 1];
+                if (o0 > R0) { if (lo == 0) break; --lo; }
+                else if (o1 <= R0 && lo < a.ntiles - 1) ++lo;
+                else break;
+                ++steps;
+            }
+            if (steps >= 6) {
+                int64_t l = 0, h = a.ntiles - 1;
+                while (l < h) {
+                    const int64_t mid = (l + h + 1) >> 1;
+                    if ((int64_t)a.tile_off[mid] <= R0) l = mid; else h = mid - 1;
+                }
+                lo = l;
+            }
         }
-        for (int64_t t = lo; t < a.ntiles && (int64_t)a.tile_off[t] < R0 + cnt; ++t) {
-            const int64_t base = a.tile_off[t];
-            const int64_t wl = a.src_w0 + t * SRC_TILE_WORDS + lane;       // lane <-> word of the tile
-            const uint64_t myword = a.src_occ[wl] & range_mask_for_word(wl, a.src_lo0, a.src_hi0);
+        // ---- passes of MOVE_BLOCK/64 source tiles: wave w describes tile tb+w (word masks + rank bases) in LDS,
+        //      then the intersecting words are dealt round-robin to the waves, 4 words (8 loads) per step.
+        __shared__ uint64_t sWM[MOVE_BLOCK];
+        __shared__ int32_t sWB[MOVE_BLOCK];        // rank base of the word relative to R0 (clamped)
+        for (int64_t tb = lo; cnt > 0 && tb < a.ntiles && (int64_t)a.tile_off[tb] < R0 + cnt; tb += MOVE_BLOCK / 64) {
+            const int64_t t = tb + wv;
+            uint64_t myword = 0;
+            int64_t base = (int64_t)1 << 40;
+            if (t < a.ntiles) {
+                const int64_t wl = a.src_w0 + t * SRC_TILE_WORDS + lane;       // lane <-> word of the tile
+                myword = a.src_occ[wl] & range_mask_for_word(wl, a.src_lo0, a.src_hi0);
+                base = a.tile_off[t];
+            }
             const uint32_t mypc = popc64(myword);
-            const uint32_t myoff = wave_excl_scan(mypc);
-            // wave wv owns 16 consecutive words of the tile; 4 words per step so that 8 loads are in flight
-            constexpr int WPW = SRC_TILE_WORDS / (MOVE_BLOCK / 64);
+            const int64_t wbase = base + wave_excl_scan(mypc) - R0;            // cells of earlier words, relative to R0
+            sWM[tid] = myword;
+            sWB[tid] = (int32_t)(wbase < -(1 << 30) ? -(1 << 30) : (wbase > (1 << 30) ? (1 << 30) : wbase));
+            const int before = __syncthreads_count(mypc == 0 ? (wbase <= 0) : (wbase + mypc <= 0));   // words entirely in front
+            const int notafter = __syncthreads_count(wbase < cnt);                                      // words starting before the end
+            // empty words in front of the range are counted in `before`; words [before, notafter) may intersect
 #pragma unroll 1
-            for (int wb = wv * WPW; wb < (wv + 1) * WPW; wb += 4) {
-                int64_t kk[4]; double vv[4]; int64_t rk[4]; bool act[4];
+            for (int jb = before + wv * 4; jb < notafter; jb += MOVE_BLOCK / 64 * 4) {
+                int64_t kk[4]; double vv[4]; int rk[4]; bool act[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const int w = wb + u;
-                    const uint64_t mask = __shfl(myword, w, 64);
-                    const int64_t off = base + (int64_t)__shfl(myoff, w, 64);
-                    const int pc = popc64(mask);
-                    const bool wact = pc != 0 && off + pc > R0 && off < R0 + cnt;      // wave-uniform
-                    rk[u] = off + popc64(mask & mask_lt(lane)) + 1;
-                    act[u] = wact && ((mask >> lane) & 1ull) && rk[u] > R0 && rk[u] <= R0 + cnt;
-                    // unconditional loads (inactive lanes read the word's first slot, which is inside the
-                    // allocation) so that all eight loads of the step are in flight together
-                    const int64_t s = ((a.src_w0 + t * SRC_TILE_WORDS + w) << 6) + (act[u] ? lane : 0);
-                    kk[u] = __builtin_nontemporal_load(a.src_keys + s);
-                    vv[u] = __builtin_nontemporal_load(a.src_vals + s);
+                    const int j = jb + u;
+                    const bool in = j < notafter;
+                    const uint64_t mask = in ? sWM[j] : 0ull;
+                    const int off = in ? sWB[j] : 0;
+                    rk[u] = off + popc64(mask & mask_lt(lane));                 // 0-based rank relative to R0
+                    act[u] = ((mask >> lane) & 1ull) && rk[u] >= 0 && rk[u] < cnt;
+                    const int64_t word_index = a.src_w0 + (tb + (j >> 6)) * SRC_TILE_WORDS + (j & 63);
+                    // unconditional loads (inactive lanes read the word's first slot, inside the allocation)
+                    const int64_t s = (word_index << 6) + (act[u] ? lane : 0);
+                    const int64_t s_safe = in ? s : a.src_lo0;
+                    kk[u] = __builtin_nontemporal_load(a.src_keys + s_safe);
+                    vv[u] = __builtin_nontemporal_load(a.src_vals + s_safe);
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
-                    if (act[u]) { sK[rk[u] - R0 - 1] = kk[u]; sV[rk[u] - R0 - 1] = vv[u]; }
+                    if (act[u]) { sK[rk[u]] = kk[u]; sV[rk[u]] = vv[u]; }
             }
+            __syncthreads();
         }
     }
     __syncthreads();
@@ -184,7 +215,7 @@ __global__ __launch_bounds__(MOVE_BLOCK) void k_move(MoveArgs a) {
                         k2[j] = sK[rank - R0 - 1];
                         v2[j] = sV[rank - R0 - 1];
                     }
-                    if (a.sems != nullptr && k2[j] == SEM_KEY) a.sems[(int64_t)v2[j] - 1] = a.dst_lo0 + qa + j;   // 1-based slot
+                    if (a.sems != nullptr && a.dbg != 3 && k2[j] == SEM_KEY) a.sems[(int64_t)v2[j] - 1] = a.dst_lo0 + qa + j;   // 1-based slot
                 }
             }
             const int64_t d = a.dst_lo0 + qa - 1;
@@ -229,7 +260,7 @@ hipError_t launch_rebalance(const int64_t* src_keys, const double* src_vals, con
     a.dst_lo0 = dst_ws - 1;
     a.Wd = dst_we - dst_ws + 1; a.m = m;
     a.sems = sems;
-    a.tile_off = nullptr; a.ntiles = 0;
+    a.tile_off = nullptr; a.ntiles = 0; a.tiles_per_cell = 0.0;
     { static const char* e = getenv("DSA_DBG_MOVE"); a.dbg = e ? atoi(e) : 0; }
     const int64_t ndst = (a.Wd + DST_TILE - 1) / DST_TILE;
     if (src_packed) {
@@ -244,6 +275,7 @@ hipError_t launch_rebalance(const int64_t* src_keys, const double* src_vals, con
                        a.src_w0, nwords, work->tile_cnt);
     hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, stream, work->tile_cnt, work->tile_off, ntiles);
     a.tile_off = work->tile_off; a.ntiles = ntiles;
+    a.tiles_per_cell = m > 0 ? (double)ntiles / (double)m : 0.0;
     hipLaunchKernelGGL(k_move<false>, dim3((unsigned)ndst), dim3(MOVE_BLOCK), 0, stream, a);
     return hipGetLastError();
 }

@@ -60,3 +60,8 @@ big = torch.empty(cap * 2, dtype=torch.float64, device=dev)
 big2 = torch.empty(cap * 2, dtype=torch.float64, device=dev)
 us = timeit(lambda: big2.copy_(big))
 print("torch D2D copy %d MB: %.1f us -> %.1f GB/s (read+write)" % (cap * 16 >> 20, us, 2 * cap * 16 / us / 1e3))
+
+us = timeit(lambda: big2.zero_())
+print("torch memset %d MB: %.1f us -> %.1f GB/s (write only)" % (cap * 16 >> 20, us, cap * 16 / us / 1e3))
+us = timeit(lambda: big.sum())
+print("torch sum (read only) %d MB: %.1f us -> %.1f GB/s" % (cap * 16 >> 20, us, cap * 16 / us / 1e3))
