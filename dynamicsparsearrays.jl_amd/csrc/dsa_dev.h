@@ -117,6 +117,24 @@ __device__ __forceinline__ bool slot_is_gap(const SpreadGeom& g, int q, int* ran
     *rank = q - k;
     return false;
 }
+// Two adjacent offsets q, q+1 at once with two evaluations of D in the common case:
+// *k = number of gaps <= q ; gap0 / gap1 = whether q / q+1 are gaps.
+__device__ __forceinline__ void gap_pair(const SpreadGeom& g, int q, int* k_out, bool* gap0, bool* gap1) {
+    const int E = (int)g.E;
+    if (E <= 0) { *k_out = 0; *gap0 = false; *gap1 = false; return; }
+    int k = (int)((double)(q + 1) * g.inv_f);
+    if (k > E) k = E;
+    if (k < 0) k = 0;
+    int d0 = k > 0 ? gap_D(g, k) : 0;                 // D(k)   (0 when k == 0: smaller than every offset)
+    int d1 = k < E ? gap_D(g, k + 1) : 0x7fffffff;    // D(k+1)
+#pragma clang loop vectorize(disable) unroll(disable)
+    while (d1 <= q) { ++k; d0 = d1; d1 = k < E ? gap_D(g, k + 1) : 0x7fffffff; }
+#pragma clang loop vectorize(disable) unroll(disable)
+    while (k > 0 && d0 > q) { --k; d1 = d0; d0 = k > 0 ? gap_D(g, k) : 0; }
+    *k_out = k;
+    *gap0 = (k > 0 && d0 == q);
+    *gap1 = (d1 == q + 1);
+}
 // bit-interleave: bit i of x -> bit 2i
 __device__ __forceinline__ uint64_t spread_bits32(uint32_t x) {
     uint64_t v = x;

@@ -61,6 +61,7 @@ struct Pma {
     int cur = 0;
     int64_t cap_alloc = 0;        // slots allocated per buffer
     int64_t occ_words = 0;        // words allocated per bitmap (whole 64-word tiles)
+    int64_t occ_dirty[2] = {0, 0}; // high-water mark: words >= occ_dirty[b] of bitmap b are known to be zero
     bool has_sems = false, has_cols = false;
     int64_t* sems = nullptr; int64_t* col_keys = nullptr; uint8_t* col_live = nullptr;
     Ctl* d_ctl = nullptr;
@@ -222,6 +223,7 @@ void ensure_capacity_alloc(Pma& P, int64_t slots) {
     }
     HIPCHK(hipStreamSynchronize(P.stream));
     for (int b = 0; b < 2; ++b) { if (ok[b]) hipFree(ok[b]); if (ov[b]) hipFree(ov[b]); if (oo[b]) hipFree(oo[b]); }
+    P.occ_dirty[1 - P.cur] = 0;                       // fresh, zero-filled; occ_dirty[cur] keeps its value
     P.cap_alloc = n;
     P.occ_words = occ_words_for(n);
     alloc_work(P, n);
@@ -236,10 +238,12 @@ void root_rebalance(Pma& P, int64_t src_cap, int64_t new_cap, int64_t m, bool sr
                                     P.keys[alt], P.vals[alt], P.occ[alt], 1, new_cap, m,
                                     P.has_sems ? P.sems : nullptr, &P.work, P.stream);
     if (e != hipSuccess) fail(DSA_EHIP, std::string("rebalance launch: ") + hipGetErrorString(e));
-    // bits beyond the new capacity must be zero in the buffer that becomes current
+    // bits beyond the new capacity must be zero in the buffer that becomes current; only the words that
+    // may still hold stale bits (below the buffer's high-water mark) are cleared
     const int64_t first_word = (new_cap + 63) / 64;
-    if (first_word < P.occ_words)
-        HIPCHK(hipMemsetAsync(P.occ[alt] + first_word, 0, (size_t)(P.occ_words - first_word) * sizeof(uint64_t), P.stream));
+    if (first_word < P.occ_dirty[alt])
+        HIPCHK(hipMemsetAsync(P.occ[alt] + first_word, 0, (size_t)(P.occ_dirty[alt] - first_word) * sizeof(uint64_t), P.stream));
+    P.occ_dirty[alt] = first_word;
     P.cur = alt;
 }
 
@@ -251,6 +255,7 @@ void window_rebalance(Pma& P, int64_t ws, int64_t we, int64_t m) {
                                     P.has_sems ? P.sems : nullptr, &P.work, P.stream);
     if (e != hipSuccess) fail(DSA_EHIP, std::string("rebalance launch: ") + hipGetErrorString(e));
     const int64_t W = we - ws + 1;
+    P.occ_dirty[alt] = std::max<int64_t>(P.occ_dirty[alt], (we + 63) / 64);
     HIPCHK(hipMemcpyAsync(P.K() + (ws - 1), P.keys[alt] + (ws - 1), (size_t)W * sizeof(int64_t), hipMemcpyDeviceToDevice, P.stream));
     HIPCHK(hipMemcpyAsync(P.V() + (ws - 1), P.vals[alt] + (ws - 1), (size_t)W * sizeof(double), hipMemcpyDeviceToDevice, P.stream));
     HIPCHK(hipMemcpyAsync(P.O() + ((ws - 1) >> 6), P.occ[alt] + ((ws - 1) >> 6), (size_t)(W >> 6) * sizeof(uint64_t),

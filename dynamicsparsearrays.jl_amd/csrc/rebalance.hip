@@ -112,7 +112,10 @@ __global__ __launch_bounds__(MOVE_BLOCK) void k_move(MoveArgs a) {
     const int64_t R0 = q0 - kA;                                  // cells placed before this tile
     const int64_t cnt = (qend - q0) - (kB - kA);                 // cells landing in this tile: ranks R0+1..R0+cnt
 
-    if (!PACKED) {
+    if (!PACKED && a.dbg == 1) {      // ablation: no staging, harmless LDS contents
+        for (int i = tid; i < DST_TILE; i += MOVE_BLOCK) { sK[i] = 1; sV[i] = 1.0; }
+    }
+    if (!PACKED && a.dbg != 1) {
         // ---- locate the first source tile holding rank R0+1: the largest t with tile_off[t] <= R0.
         // Interpolated guess + short walk (cell density is near-uniform after a spread); bisection fallback.
         int64_t lo = 0;
@@ -186,7 +189,7 @@ __global__ __launch_bounds__(MOVE_BLOCK) void k_move(MoveArgs a) {
 
     // ---- write phase: lane <-> 2 adjacent destination slots, 128 slots per wave-iteration ----
     constexpr int PER_WAVE = DST_TILE / (MOVE_BLOCK / 64);   // 512
-#pragma unroll 1
+#pragma unroll
     for (int it = 0; it < PER_WAVE / 128; ++it) {
         const int64_t gq = q0 + (int64_t)wv * PER_WAVE + it * 128;   // 0-based offset of the 128-slot group
         if (gq >= a.Wd) break;                                        // wave-uniform
@@ -195,17 +198,13 @@ __global__ __launch_bounds__(MOVE_BLOCK) void k_move(MoveArgs a) {
         double v2[2] = {0.0, 0.0};
         bool o2[2] = {false, false};
         if (qa <= a.Wd) {
-            const int E = (int)g.E;
-            int k = gaps_le(g, (int)qa);
-            bool gap = (k > 0 && gap_D(g, k) == (int)qa);
-            int64_t rank = qa - k;
+            int k; bool gp[2];
+            gap_pair(g, (int)qa, &k, &gp[0], &gp[1]);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                if (j == 1) {
-                    gap = false;
-                    if (k < E && gap_D(g, k + 1) == (int)qa + 1) { ++k; gap = true; }
-                    rank = qa + 1 - k;
-                }
+                const bool gap = gp[j];
+                if (j == 1 && gap) ++k;
+                const int64_t rank = qa + j - k;
                 if (!gap) {
                     o2[j] = true;
                     if (PACKED) {
@@ -219,8 +218,12 @@ __global__ __launch_bounds__(MOVE_BLOCK) void k_move(MoveArgs a) {
                 }
             }
             const int64_t d = a.dst_lo0 + qa - 1;
-            *reinterpret_cast<longlong2*>(a.dst_keys + d) = make_longlong2(k2[0], k2[1]);
-            *reinterpret_cast<double2*>(a.dst_vals + d) = make_double2(v2[0], v2[1]);
+            typedef long long ll2v __attribute__((ext_vector_type(2)));
+            typedef double d2v __attribute__((ext_vector_type(2)));
+            ll2v kv; kv.x = k2[0]; kv.y = k2[1];
+            d2v vv2; vv2.x = v2[0]; vv2.y = v2[1];
+            __builtin_nontemporal_store(kv, reinterpret_cast<ll2v*>(a.dst_keys + d));
+            __builtin_nontemporal_store(vv2, reinterpret_cast<d2v*>(a.dst_vals + d));
         }
         const uint64_t be = __ballot(o2[0]);
         const uint64_t bo = __ballot(o2[1]);
