@@ -95,8 +95,9 @@ def main():
     hip = dsa.product()                      # raises if libdsa_hip.so is missing: no fallback
     hip.call("set_device", local_rank)
 
+    from dsa_amd import sharding
     m, ncl, per = args.rows, args.cols_per_gpu, args.per_col
-    col0 = rank * ncl
+    col0, ncl = sharding.column_range(rank, world, world * ncl)     # contiguous column-key range of this rank
     t0 = time.time()
     I, J, V = c3_triplets(m, ncl, per, col0, seed_rows=5, seed_vals=6)
     # the shard is the reference-layout PCSR of its own sub-matrix: local column keys 1..ncl

@@ -101,9 +101,10 @@ __global__ __launch_bounds__(SP_BLOCK) void k_spmv(const int64_t* __restrict__ k
         const int64_t s = b0 + ls;
         bit[j] = false; k[j] = -1; v[j] = 0.0;
         if (ls < tile_end) {
-            const uint64_t word = occ[s >> 6];
+            // streamed once: non-temporal, so that the slot streams do not evict x from the XCD's L2
+            const uint64_t word = __builtin_nontemporal_load(occ + (s >> 6));
             bit[j] = (word >> lane) & 1ull;
-            if (bit[j]) { k[j] = keys[s]; v[j] = vals[s]; }
+            if (bit[j]) { k[j] = __builtin_nontemporal_load(keys + s); v[j] = __builtin_nontemporal_load(vals + s); }
         }
     }
     int nsem = 0;

@@ -1,0 +1,73 @@
+"""CPU test of the N > 1 path: world_size-2 gloo, column-range sharding + all-reduce of y.
+The local SpMV runs on the CPU oracle here (there is no GPU in the build container); on the GPU the
+same ColumnShard code runs on the HIP library with RCCL (bench.py)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _make_problem():
+    rng = np.random.default_rng(7)
+    m, n, nnz = 300, 401, 4000          # odd n: uneven column ranges
+    I = rng.integers(1, m + 1, nnz)
+    J = rng.integers(1, n + 1, nnz)
+    V = rng.integers(1, 10, nnz).astype(np.float64)
+    x = 1.0 + rng.random(n)
+    return m, n, I, J, V, x
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    import dsa_loader
+    dsa = dsa_loader.load()
+    from dsa_amd import sharding          # registered by dsa_loader
+    ora = dsa.Binding(os.path.join(ROOT, "oracle", "liboracle.so"), "ora", device_api=False)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    m, n, I, J, V, x = _make_problem()
+    sh = sharding.ColumnShard(dsa, I, J, V, m, n, rank, world, binding=ora)
+    y = sh.spmv(sh.x_slice(x))
+    # a write routed to its owner shard, then another product
+    sh.set(5, 400, 3.5)
+    sh.set(7, 2, 1.25)
+    y2 = sh.spmv(sh.x_slice(x))
+    np.save(os.path.join(out_dir, f"y_{rank}.npy"), np.stack([y, y2]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_column_sharded_spmv_world2(dsa, oracle, tmp_path):
+    from dsa_amd import sharding
+    world = 2
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    m, n, I, J, V, x = _make_problem()
+    full = dsa.dynamicsparse(I, J, V, m, n, binding=oracle)
+    ref = full.mul(x)
+    full[5, 400] = 3.5
+    full[7, 2] = 1.25
+    ref2 = full.mul(x)
+    for r in range(world):
+        got = np.load(os.path.join(str(tmp_path), f"y_{r}.npy"))
+        np.testing.assert_allclose(got[0], ref, rtol=1e-12, atol=0)
+        np.testing.assert_allclose(got[1], ref2, rtol=1e-12, atol=0)
+    # the column ranges tile 1..n exactly
+    cover = []
+    for r in range(world):
+        c0, nc = sharding.column_range(r, world, n)
+        cover += list(range(c0 + 1, c0 + nc + 1))
+    assert cover == list(range(1, n + 1))
+    assert sharding.owner_of_column(400, world, n) == 1 and sharding.owner_of_column(2, world, n) == 0

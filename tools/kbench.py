@@ -65,3 +65,10 @@ us = timeit(lambda: big2.zero_())
 print("torch memset %d MB: %.1f us -> %.1f GB/s (write only)" % (cap * 16 >> 20, us, cap * 16 / us / 1e3))
 us = timeit(lambda: big.sum())
 print("torch sum (read only) %d MB: %.1f us -> %.1f GB/s" % (cap * 16 >> 20, us, cap * 16 / us / 1e3))
+
+# random 8-byte gather rate of the hardware for different table sizes (torch index_select)
+for nx_, label in ((1_000_000, "8 MB"), (500_000, "4 MB"), (250_000, "2 MB"), (125_000, "1 MB"), (4_000_000, "32 MB")):
+    xt = torch.rand(nx_, dtype=torch.float64, device=dev)
+    idx = torch.randint(0, nx_, (11_000_000,), device=dev, dtype=torch.int64)
+    us = timeit(lambda: torch.index_select(xt, 0, idx))
+    print("torch gather 11M x f64 from %s table: %.1f us -> %.1f G gathers/s" % (label, us, 11e6 / us / 1e3))
