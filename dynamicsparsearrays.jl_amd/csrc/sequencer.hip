@@ -109,6 +109,63 @@ __device__ DFound d_find(const int64_t* keys, const double* vals, const uint64_t
     return DFound{0, 0, 0.0, false};
 }
 
+// smallest occupied position in (pos, hi], or 0
+__device__ int64_t d_next_occupied(const uint64_t* occ, int64_t pos, int64_t hi) {
+    if (pos + 1 > hi) return 0;
+    const int64_t i = pos;                  // 0-based index of position pos+1
+    int64_t w = i >> 6;
+    uint64_t word = occ[w] & ~mask_lt((int)(i & 63));
+    const int64_t lastw = (hi - 1) >> 6;
+    while (true) {
+        if (word) {
+            const int64_t p = (w << 6) + __ffsll((unsigned long long)word);
+            return p <= hi ? p : 0;
+        }
+        if (++w > lastw) return 0;
+        word = occ[w];
+    }
+}
+
+// K-find, wave-parallel form.  Same answer as d_find / the reference bisection whenever, inside
+// [from, to], every occupied key < `key` precedes every occupied key > `key` (true for a vector's PMA, for
+// a partition without its semaphore, and for a partition WITH its semaphore when key > 0).  Then find()
+// returns: the cell holding `key` if present; else the last cell of the range with a smaller key; else the
+// nearest occupied cell left of `from`; else (0, nothing)  (src/finds.jl:29-57).  A 64-ary search on slot
+// positions: each round every lane probes one position (nearest occupied cell at or before it, via the
+// bitmap), one ballot narrows the interval 64-fold: ~log64(range) dependent round trips instead of log2.
+__device__ DFound d_find_fast(const int64_t* keys, const double* vals, const uint64_t* occ, int64_t key, int64_t from, int64_t to) {
+    const int lane = lane_id();
+    int64_t pstar;
+    if (to < from) {
+        pstar = to;
+    } else {
+        int64_t L = from - 1, H = to;        // invariant: every occupied cell of [from, L] has a key < `key`; the boundary lies in [L, H]
+        while (H - L > 64) {
+            const int64_t width = H - L;
+            const int64_t p = L + (width * (lane + 1)) / 64;
+            const int64_t q = d_prev_occupied(occ, p, L + 1);
+            bool pr = true;
+            if (q > L) pr = keys[q - 1] < key;
+            const uint64_t nb = ~__ballot(pr);
+            const int j = nb ? __ffsll((unsigned long long)nb) - 1 : 64;      // lanes 0..j-1 true, lane j false
+            const int64_t pj = L + (width * (j + 1)) / 64;
+            const int64_t pj1 = L + (width * j) / 64;
+            if (j < 64) H = pj - 1;
+            L = pj1;
+        }
+        const int64_t p = L + 1 + lane;
+        bool viol = false;
+        if (p <= H && occ_test(occ, p)) viol = keys[p - 1] >= key;
+        const uint64_t b = __ballot(viol);
+        pstar = b ? L + __ffsll((unsigned long long)b) - 1 : H;
+        const int64_t nxt = d_next_occupied(occ, pstar, to);
+        if (nxt != 0 && keys[nxt - 1] == key) return DFound{nxt, key, vals[nxt - 1], true};
+    }
+    const int64_t i = pstar >= 1 ? d_prev_occupied(occ, pstar, 1) : 0;      // may lie left of `from`, like the reference
+    if (i > 0) return DFound{i, keys[i - 1], vals[i - 1], true};
+    return DFound{0, 0, 0.0, false};
+}
+
 struct DFoundKey { int64_t pos; int64_t key; bool has; };
 // find(col_keys, key)  src/finds.jl:59-61 on a Vector{Union{Nothing,L}}
 __device__ DFoundKey d_find_table(const int64_t* ck, const uint8_t* live, int64_t len, int64_t key) {
@@ -127,6 +184,38 @@ __device__ DFoundKey d_find_table(const int64_t* ck, const uint8_t* live, int64_
         }
     }
     int64_t i = to;
+    while (i > 0 && !live[i - 1]) --i;
+    if (i > 0) return DFoundKey{i, ck[i - 1], true};
+    return DFoundKey{0, 0, false};
+}
+
+// wave-parallel form of d_find_table (live column keys are strictly ascending)
+__device__ DFoundKey d_find_table_fast(const int64_t* ck, const uint8_t* live, int64_t len, int64_t key) {
+    const int lane = lane_id();
+    int64_t L = 0, H = len;
+    while (H - L > 64) {
+        const int64_t width = H - L;
+        const int64_t p = L + (width * (lane + 1)) / 64;
+        int64_t q = p;
+        while (q > L && !live[q - 1]) --q;
+        bool pr = true;
+        if (q > L) pr = ck[q - 1] < key;
+        const uint64_t nb = ~__ballot(pr);
+        const int j = nb ? __ffsll((unsigned long long)nb) - 1 : 64;
+        const int64_t pj = L + (width * (j + 1)) / 64;
+        const int64_t pj1 = L + (width * j) / 64;
+        if (j < 64) H = pj - 1;
+        L = pj1;
+    }
+    const int64_t p = L + 1 + lane;
+    bool viol = false;
+    if (p <= H && live[p - 1]) viol = ck[p - 1] >= key;
+    const uint64_t b = __ballot(viol);
+    const int64_t pstar = b ? L + __ffsll((unsigned long long)b) - 1 : H;
+    int64_t nxt = pstar + 1;
+    while (nxt <= len && !live[nxt - 1]) ++nxt;
+    if (nxt <= len && ck[nxt - 1] == key) return DFoundKey{nxt, key, true};
+    int64_t i = pstar;
     while (i > 0 && !live[i - 1]) --i;
     if (i > 0) return DFoundKey{i, ck[i - 1], true};
     return DFoundKey{0, 0, false};
@@ -366,7 +455,7 @@ __device__ int64_t d_insert_after(Seq& S, int64_t key, double val, int64_t pos) 
 // src/writes.jl:14-23,57-63 ; del_from is the (possibly wider) range of the delete path (src/pcsr.jl:302-307)
 __device__ int d_set_in_range(Seq& S, int64_t key, double val, int64_t from, int64_t to, int64_t del_from) {
     if (val != 0.0) {
-        const DFound f = d_find(S.keys, S.vals, S.occ, key, from, to);
+        const DFound f = d_find_fast(S.keys, S.vals, S.occ, key, from, to);     // [from, to] never holds a semaphore
         if (f.has && f.key == key && from <= f.pos && f.pos <= to) {
             __syncthreads();
             if (threadIdx.x == 0) S.vals[f.pos - 1] = val;
@@ -379,7 +468,11 @@ __device__ int d_set_in_range(Seq& S, int64_t key, double val, int64_t from, int
         S.nb_elements += 1;
         return d_after_count_change(S, ip);
     }
-    const DFound f = d_find(S.keys, S.vals, S.occ, key, del_from, to);
+    // the delete range of a partition starts AT its semaphore (key 0, src/pcsr.jl:307): the wave-parallel search is
+    // only equivalent for key > 0 there; otherwise replay the reference bisection probe for probe
+    const bool sorted_ok = (S.sems == nullptr) || key > SEM_KEY;
+    const DFound f = sorted_ok ? d_find_fast(S.keys, S.vals, S.occ, key, del_from, to)
+                               : d_find(S.keys, S.vals, S.occ, key, del_from, to);
     if (f.has && f.key == key) {
         __syncthreads();
         if (threadIdx.x == 0) occ_clear(S, f.pos);
@@ -506,7 +599,7 @@ __device__ int d_exec(Seq& S, const Op& op) {
         case OP_PCSC_SET:
             return d_pcsc_set(S, op.v, op.a, op.b);
         case OP_MPCSC_SET: {       // setindex!(mpcsc, value, row, col)  src/pcsr.jl:341-351
-            const DFoundKey f = d_find_table(S.col_keys, S.col_live, S.table_len, op.b);
+            const DFoundKey f = d_find_table_fast(S.col_keys, S.col_live, S.table_len, op.b);
             int64_t col_pos = f.pos;
             if (!(f.has && f.key == op.b)) {
                 if (f.pos == S.table_len) {
@@ -528,7 +621,7 @@ __device__ int d_exec(Seq& S, const Op& op) {
         case OP_DELETE_PARTITION:
             return d_deletepartition(S, op.b);
         case OP_MPCSC_DELETECOLUMN: {   // deletecolumn!(mpcsc, col)  src/pcsr.jl:206-212
-            const DFoundKey f = d_find_table(S.col_keys, S.col_live, S.table_len, op.b);
+            const DFoundKey f = d_find_table_fast(S.col_keys, S.col_live, S.table_len, op.b);
             if (!(f.has && f.key == op.b)) { S.err = E_ARG; return SEQ_ERROR; }
             __syncthreads();
             if (threadIdx.x == 0) S.col_live[f.pos - 1] = 0;
