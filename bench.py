@@ -179,8 +179,19 @@ def main():
         "build_s": round(build_s, 2),
     }
 
+    # HBM-side traffic per launch from the committed rocprofv3 PMC passes of the same kernel on the same workload
+    # (separate --pmc FETCH_SIZE / WRITE_SIZE runs, gfx950 x2 correction on the coalesced-stream part): profiles/
+    pmc = os.path.join(ROOT, "profiles", "r01_final_pmc_summary.json")
+    if os.path.exists(pmc) and m == 1_000_000 and ncl == 1_000_000 and per == 10:
+        with open(pmc) as f:
+            pm = json.load(f)
+        out["roofline"]["traffic"] = pm["k_spmv_gather_C3"]["corrected_traffic_total"]
+        out["roofline"]["traffic_source"] = "profiles/r01_final_pmc_summary.json (rocprofv3 --pmc, corrected)"
     if rank == 0 and not args.no_extras:
         out.update(extras(dsa, hip, torch, A, dev))
+        if os.path.exists(pmc) and "roofline_rebalance" in out:
+            out["roofline_rebalance"]["traffic"] = pm["k_move_root_2^24"]["corrected_traffic_total"] \
+                if out["roofline_rebalance"]["window_slots"] == 16777216 else None
     if rank == 0 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(dsa, m, per)
     if world > 1:
