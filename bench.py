@@ -182,6 +182,7 @@ def main():
     # HBM-side traffic per launch from the committed rocprofv3 PMC passes of the same kernel on the same workload
     # (separate --pmc FETCH_SIZE / WRITE_SIZE runs, gfx950 x2 correction on the coalesced-stream part): profiles/
     pmc = os.path.join(ROOT, "profiles", "r01_final_pmc_summary.json")
+    pm = None
     if os.path.exists(pmc) and m == 1_000_000 and ncl == 1_000_000 and per == 10:
         with open(pmc) as f:
             pm = json.load(f)
@@ -189,7 +190,7 @@ def main():
         out["roofline"]["traffic_source"] = "profiles/r01_final_pmc_summary.json (rocprofv3 --pmc, corrected)"
     if rank == 0 and not args.no_extras:
         out.update(extras(dsa, hip, torch, A, dev))
-        if os.path.exists(pmc) and "roofline_rebalance" in out:
+        if pm is not None and "roofline_rebalance" in out:
             out["roofline_rebalance"]["traffic"] = pm["k_move_root_2^24"]["corrected_traffic_total"] \
                 if out["roofline_rebalance"]["window_slots"] == 16777216 else None
     if rank == 0 and not args.no_cpu_baseline:
@@ -241,6 +242,38 @@ def extras(dsa, hip, torch, A, dev):
                             "config": "C2: 2^20-slot PMA (700k keys) + 100k batched inserts, whole dsa_vec_set_batch call incl. H2D",
                             "window_slots_per_insert_A": round(info["stat_window_slots"] / 100000, 1),
                             "extends": info["stat_extends"]}
+    # --- C5 (scaled 1/10): stream new columns element by element into an empty matrix (both orientations),
+    #     SpMV every 500 columns.  Full C5 is 50k columns x 16 rows over 100k rows; parity of this loop vs the
+    #     oracle is tests/test_hip_parity.py::test_matrix_from_empty_streaming_columns_c5_scaled
+    m5, ncols5, per5 = 10_000, 5_000, 16
+    B = dsa.dynamicsparse(fill_mode=False, binding=hip)
+    hip.call("mat_set_stream", B.h, C.c_void_p(stream.cuda_stream))
+    rows5 = 1 + (splitmix_array(11, ncols5 * per5 * 2) % np.uint64(m5)).astype(np.int64)
+    vals5 = unit12(12, ncols5 * per5)
+    x5 = torch.from_numpy(unit12(13, ncols5)).to(dev)
+    y5 = torch.zeros(m5, dtype=torch.float64, device=dev)
+    t_w, t_s, nw, nsp, pos = 0.0, 0.0, 0, 0, 0
+    for c0 in range(0, ncols5, 500):
+        I5, J5 = [], []
+        for j in range(c0 + 1, c0 + 501):
+            seen = set()
+            while len(seen) < per5:
+                seen.add(int(rows5[pos])); pos += 1
+            rr = sorted(seen)
+            I5 += rr; J5 += [j] * per5
+        V5 = vals5[nw:nw + len(I5)]
+        t = time.perf_counter()
+        B.set_batch(I5, J5, V5)
+        t_w += time.perf_counter() - t
+        nw += len(I5)
+        t = time.perf_counter()
+        hip.call("mat_spmv_dense_dev", B.h, 0, 0, C.c_void_p(x5.data_ptr()), c0 + 500, C.c_void_p(y5.data_ptr()), m5)
+        torch.cuda.synchronize()
+        t_s += time.perf_counter() - t
+        nsp += 1
+    res["c5_streaming_scaled"] = {"columns": ncols5, "rows": m5, "element_writes": nw, "columns_per_s": round(ncols5 / t_w, 1),
+                                  "element_writes_per_s": round(nw / t_w, 1), "spmv_ms_avg": round(t_s / nsp * 1e3, 4),
+                                  "note": "each element write updates both orientations (2 PCSR inserts) on the device sequencer"}
     return res
 
 

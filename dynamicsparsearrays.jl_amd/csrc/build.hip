@@ -1,0 +1,124 @@
+// csrc/build.hip — K-build: the bulk (fill-mode flush) constructor on the device.
+//
+// Reproduces _dynamicsparse (src/pcsr.jl:354-431) + the PackedCSC constructor's cell stream
+// (src/pcsr.jl:26-63) for one orientation: sort the (partition, key) pairs, combine duplicates, count the
+// cells per partition and emit the ordered stream  [sem(0, id), entries...]  per partition, plus the
+// partition keys.  The stream is written straight into the PMA's slot buffer; the full-array spread
+// (src/pma.jl:42-55) is then one k_move<true> launch (rebalance.hip).
+//
+//   sort      : two stable LSD radix sorts (rocPRIM device_radix_sort, 64-bit signed keys) — by key, then by
+//               partition — carrying the input index, so equal (partition, key) pairs stay in INPUT order.
+//               The reference sorts with an unstable QuickSort (src/pcsr.jl:360); input order is one of its
+//               legal outcomes and makes the Float64 fold of duplicates deterministic.
+//   flags     : new-partition / new-cell flags from neighbour compares (coalesced).
+//   scans     : two inclusive scans (rocPRIM device_scan) give the partition id and the cell rank.
+//   emit      : every first-of-run lane folds its duplicate run left to right (src/pcsr.jl:374-375) and
+//               writes its cell at  rank-1 + partition_id  ; every first-of-partition lane writes the
+//               semaphore cell (0, id) at  rank-1 + id-1  and the partition key.
+// Bound: HBM (sort passes dominate: 8 B key + 4 B index, 2 x 8 digit passes).
+#include "dsa_dev.h"
+
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+
+namespace dsa {
+
+__global__ void k_iota(uint32_t* idx, int64_t n) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i < n) idx[i] = (uint32_t)i;
+}
+__global__ void k_gather_i64(const int64_t* __restrict__ src, const uint32_t* __restrict__ idx, int64_t* __restrict__ dst, int64_t n) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[idx[i]];
+}
+__global__ void k_flags(const int64_t* __restrict__ part, const int64_t* __restrict__ key, uint32_t* __restrict__ fpart,
+                        uint32_t* __restrict__ fcell, int64_t n) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const bool np = (i == 0) || part[i] != part[i - 1];
+    fpart[i] = np ? 1u : 0u;
+    fcell[i] = (np || key[i] != key[i - 1]) ? 1u : 0u;
+}
+__global__ void k_emit(const int64_t* __restrict__ part, const int64_t* __restrict__ key, const uint32_t* __restrict__ idx,
+                       const double* __restrict__ val, const uint32_t* __restrict__ fpart, const uint32_t* __restrict__ fcell,
+                       const uint32_t* __restrict__ spart, const uint32_t* __restrict__ scell, int64_t n, int32_t combine,
+                       int64_t* __restrict__ out_keys, double* __restrict__ out_vals, int64_t* __restrict__ part_keys) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (!fcell[i]) return;
+    const int64_t pid = spart[i];            // 1-based partition id
+    const int64_t rank = scell[i];           // 1-based rank among the distinct cells
+    double acc = val[idx[i]];
+    for (int64_t j = i + 1; j < n && !fcell[j]; ++j) {     // left fold of the duplicates, input order
+        const double v = val[idx[j]];
+        acc = combine == 0 ? acc + v : (combine == 1 ? acc * v : v);
+    }
+    const int64_t pos = rank - 1 + pid;
+    out_keys[pos] = key[i];
+    out_vals[pos] = acc;
+    if (fpart[i]) {
+        out_keys[pos - 1] = SEM_KEY;
+        out_vals[pos - 1] = (double)pid;
+        part_keys[pid - 1] = part[i];
+    }
+}
+
+static void free_scratch(BuildScratch& s) {
+    void* ptrs[] = {s.idx0, s.idx1, s.idx2, s.fpart, s.fcell, s.spart, s.scell, s.k1, s.p1, s.p2, s.k2, s.temp};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    s = BuildScratch();
+}
+
+#define BCHK(e) do { hipError_t _e = (e); if (_e != hipSuccess) { free_scratch(s); return _e; } } while (0)
+
+// Phase 1: sort + flags + scans.  d_part / d_key / d_val: the nnz input triples in HBM.
+// Returns the number of distinct cells and of partitions through counts[0..1] (host).  The scratch stays alive
+// for phase 2 (build_emit), which writes n_cells + n_parts stream cells.
+hipError_t build_prepare(const int64_t* d_part, const int64_t* d_key, int64_t nnz, BuildScratch& s, int64_t counts[2],
+                         hipStream_t stream) {
+    s.n = nnz;
+    const size_t n = (size_t)nnz;
+    BCHK(hipMalloc(&s.idx0, n * 4)); BCHK(hipMalloc(&s.idx1, n * 4)); BCHK(hipMalloc(&s.idx2, n * 4));
+    BCHK(hipMalloc(&s.fpart, n * 4)); BCHK(hipMalloc(&s.fcell, n * 4)); BCHK(hipMalloc(&s.spart, n * 4)); BCHK(hipMalloc(&s.scell, n * 4));
+    BCHK(hipMalloc(&s.k1, n * 8)); BCHK(hipMalloc(&s.p1, n * 8)); BCHK(hipMalloc(&s.p2, n * 8)); BCHK(hipMalloc(&s.k2, n * 8));
+    size_t t1 = 0, t2 = 0;
+    BCHK(rocprim::radix_sort_pairs(nullptr, t1, d_key, s.k1, s.idx0, s.idx1, n, 0, 64, stream));
+    BCHK(rocprim::inclusive_scan(nullptr, t2, s.fpart, s.spart, n, rocprim::plus<uint32_t>(), stream));
+    s.temp_bytes = t1 > t2 ? t1 : t2;
+    BCHK(hipMalloc(&s.temp, s.temp_bytes));
+    const unsigned blocks = (unsigned)((nnz + 255) / 256);
+    hipLaunchKernelGGL(k_iota, dim3(blocks), dim3(256), 0, stream, s.idx0, nnz);
+    size_t tb = s.temp_bytes;
+    BCHK(rocprim::radix_sort_pairs(s.temp, tb, d_key, s.k1, s.idx0, s.idx1, n, 0, 64, stream));           // by key
+    hipLaunchKernelGGL(k_gather_i64, dim3(blocks), dim3(256), 0, stream, d_part, s.idx1, s.p1, nnz);
+    tb = s.temp_bytes;
+    BCHK(rocprim::radix_sort_pairs(s.temp, tb, s.p1, s.p2, s.idx1, s.idx2, n, 0, 64, stream));           // then by partition (stable)
+    hipLaunchKernelGGL(k_gather_i64, dim3(blocks), dim3(256), 0, stream, d_key, s.idx2, s.k2, nnz);
+    hipLaunchKernelGGL(k_flags, dim3(blocks), dim3(256), 0, stream, s.p2, s.k2, s.fpart, s.fcell, nnz);
+    tb = s.temp_bytes;
+    BCHK(rocprim::inclusive_scan(s.temp, tb, s.fpart, s.spart, n, rocprim::plus<uint32_t>(), stream));
+    tb = s.temp_bytes;
+    BCHK(rocprim::inclusive_scan(s.temp, tb, s.fcell, s.scell, n, rocprim::plus<uint32_t>(), stream));
+    uint32_t last[2] = {0, 0};
+    BCHK(hipMemcpyAsync(&last[0], s.scell + (n - 1), 4, hipMemcpyDeviceToHost, stream));
+    BCHK(hipMemcpyAsync(&last[1], s.spart + (n - 1), 4, hipMemcpyDeviceToHost, stream));
+    BCHK(hipStreamSynchronize(stream));
+    counts[0] = last[0]; counts[1] = last[1];
+    return hipGetLastError();
+}
+
+hipError_t build_emit(const double* d_val, int32_t combine, BuildScratch& s, int64_t* out_keys, double* out_vals,
+                      int64_t* part_keys, hipStream_t stream) {
+    const unsigned blocks = (unsigned)((s.n + 255) / 256);
+    hipLaunchKernelGGL(k_emit, dim3(blocks), dim3(256), 0, stream, s.p2, s.k2, s.idx2, d_val, s.fpart, s.fcell, s.spart, s.scell,
+                       s.n, combine, out_keys, out_vals, part_keys);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    free_scratch(s);
+    return e;
+}
+
+void build_abort(BuildScratch& s) { free_scratch(s); }
+
+}  // namespace dsa

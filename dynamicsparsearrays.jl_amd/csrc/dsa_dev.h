@@ -165,6 +165,21 @@ hipError_t launch_rebalance(const int64_t* src_keys, const double* src_vals, con
 // clears occupancy bits of slots [from, to] (1-based, inclusive); from/to word-aligned or inside one word
 hipError_t launch_clear_occ(uint64_t* occ, int64_t from, int64_t to, hipStream_t stream);
 
+// ---- K-build (build.hip): device bulk constructor of one orientation ---------------------------------------------
+struct BuildScratch {
+    int64_t n = 0;
+    uint32_t *idx0 = nullptr, *idx1 = nullptr, *idx2 = nullptr, *fpart = nullptr, *fcell = nullptr, *spart = nullptr, *scell = nullptr;
+    int64_t *k1 = nullptr, *p1 = nullptr, *p2 = nullptr, *k2 = nullptr;
+    void* temp = nullptr; size_t temp_bytes = 0;
+};
+// phase 1: sort by (partition, key, input order), flags, scans; counts[0] = distinct cells, counts[1] = partitions
+hipError_t build_prepare(const int64_t* d_part, const int64_t* d_key, int64_t nnz, BuildScratch& s, int64_t counts[2],
+                         hipStream_t stream);
+// phase 2: emit the ordered cell stream [sem(0,id), entries...] (counts[0]+counts[1] cells) and the partition keys
+hipError_t build_emit(const double* d_val, int32_t combine, BuildScratch& s, int64_t* out_keys, double* out_vals,
+                      int64_t* part_keys, hipStream_t stream);
+void build_abort(BuildScratch& s);
+
 hipError_t launch_sequencer(int64_t* keys, double* vals, uint64_t* occ, int64_t* sems, int64_t* col_keys,
                             uint8_t* col_live, Ctl* ctl, const Op* ops, int64_t n_ops, hipStream_t stream);
 

@@ -4,8 +4,8 @@
 // Everything that touches slots runs on the GPU (rebalance.hip, sequencer.hip, spmv.hip).  The host
 // keeps only: the control scalars of each PMA (mirrored from the device control block), the integer
 // density bounds derived from the reference's Float64 thresholds (src/pma.jl:58,70,87 and :120-121),
-// the fill-mode staging buffer (src/buffer.jl — a host Dict in the reference as well) and the sort of
-// the (col,row) pairs of the bulk builder (src/pcsr.jl:359-363; device sort is a SURVEY §8f item).
+// and the fill-mode staging buffer (src/buffer.jl — a host Dict in the reference as well).  The bulk builder
+// (sort by (col,row), combine, emit, spread) runs on the device (build.hip + rebalance.hip).
 // There is no CPU fallback for any slot operation.
 #include "../../include/dsa.h"
 #include "dsa_dev.h"
@@ -495,20 +495,34 @@ void build_cell_stream(const int64_t* part, const int64_t* key, const double* va
     }
 }
 
-// semaphores[] positions are written by the spread kernel; col_keys / live come from the host
-void mpcsc_build(Pma& P, const int64_t* part, const int64_t* key, const double* val, int64_t nnz, int32_t combine) {
-    std::vector<int64_t> ck, ks; std::vector<double> vs;
-    if (nnz > 0) build_cell_stream(part, key, val, nnz, combine, ck, ks, vs);
-    const int64_t np = (int64_t)ck.size();
-    P.h_ctl->nb_partitions = np; P.h_ctl->table_len = np;
-    ensure_tables(P, std::max<int64_t>(2 * np, 64));
-    if (np > 0 && P.has_cols) {
-        std::vector<uint8_t> live((size_t)np, 1);
-        HIPCHK(hipMemcpyAsync(P.col_keys, ck.data(), (size_t)np * sizeof(int64_t), hipMemcpyHostToDevice, P.stream));
-        HIPCHK(hipMemcpyAsync(P.col_live, live.data(), (size_t)np, hipMemcpyHostToDevice, P.stream));
-        HIPCHK(hipStreamSynchronize(P.stream));
+// K-build of one orientation from device-resident triples: sort / combine / emit on the device (build.hip), then the
+// full-array spread; semaphores[] positions are written by the spread kernel.
+void mpcsc_build_dev(Pma& P, const int64_t* d_part, const int64_t* d_key, const double* d_val, int64_t nnz, int32_t combine) {
+    if (nnz == 0) {
+        P.h_ctl->nb_partitions = 0; P.h_ctl->table_len = 0;
+        ensure_tables(P, 64);
+        build_from_packed(P, {}, {});
+        return;
     }
-    build_from_packed(P, ks, vs);
+    BuildScratch sc;
+    int64_t counts[2] = {0, 0};
+    hipError_t e = build_prepare(d_part, d_key, nnz, sc, counts, P.stream);
+    if (e != hipSuccess) fail(DSA_EHIP, std::string("K-build prepare: ") + hipGetErrorString(e));
+    const int64_t np = counts[1], n = counts[0] + counts[1];
+    try {
+        P.h_ctl->nb_partitions = np; P.h_ctl->table_len = np;
+        ensure_tables(P, std::max<int64_t>(2 * np, 64));
+        const int64_t capacity = capacity_for(n);
+        set_geometry_for_new(P, capacity, n);
+        ensure_capacity_alloc(P, 2 * capacity);
+        HIPCHK(hipMemsetAsync(P.col_live, 1, (size_t)np, P.stream));
+    } catch (...) { build_abort(sc); throw; }
+    e = build_emit(d_val, combine, sc, P.K(), P.V(), P.col_keys, P.stream);
+    if (e != hipSuccess) fail(DSA_EHIP, std::string("K-build emit: ") + hipGetErrorString(e));
+    P.h_ctl->stat_rebalances = 0; P.h_ctl->stat_window_slots = 0;
+    if (P.capacity() != P.h_ctl->segment_capacity) { P.h_ctl->stat_rebalances = 1; P.h_ctl->stat_window_slots = P.capacity(); }
+    root_rebalance(P, n, P.capacity(), n, true);
+    upload_ctl(P);
 }
 
 }  // namespace
@@ -539,8 +553,29 @@ namespace {
 void mat_build_major(dsa_mat* h, const int64_t* I, const int64_t* J, const double* V, int64_t nnz) {
     pma_init_common(h->col, true, true);
     pma_init_common(h->row, true, true);
-    mpcsc_build(h->col, J, I, V, nnz, DSA_COMBINE_ADD);      // dynamicsparsecolmajor(I, J, V)
-    mpcsc_build(h->row, I, J, V, nnz, DSA_COMBINE_ADD);      // dynamicsparsecolmajor(J, I, V)
+    int64_t *dI = nullptr, *dJ = nullptr; double* dV = nullptr;
+    try {
+        if (nnz > 0) {
+            hipStream_t s = h->col.stream;
+            HIPCHK(hipMalloc(&dI, (size_t)nnz * sizeof(int64_t)));
+            HIPCHK(hipMalloc(&dJ, (size_t)nnz * sizeof(int64_t)));
+            HIPCHK(hipMalloc(&dV, (size_t)nnz * sizeof(double)));
+            HIPCHK(hipMemcpyAsync(dI, I, (size_t)nnz * sizeof(int64_t), hipMemcpyHostToDevice, s));
+            HIPCHK(hipMemcpyAsync(dJ, J, (size_t)nnz * sizeof(int64_t), hipMemcpyHostToDevice, s));
+            HIPCHK(hipMemcpyAsync(dV, V, (size_t)nnz * sizeof(double), hipMemcpyHostToDevice, s));
+            HIPCHK(hipStreamSynchronize(s));
+        }
+        mpcsc_build_dev(h->col, dJ, dI, dV, nnz, DSA_COMBINE_ADD);      // dynamicsparsecolmajor(I, J, V): partitions = columns
+        mpcsc_build_dev(h->row, dI, dJ, dV, nnz, DSA_COMBINE_ADD);      // dynamicsparsecolmajor(J, I, V): partitions = rows
+    } catch (...) {
+        if (dI) hipFree(dI);
+        if (dJ) hipFree(dJ);
+        if (dV) hipFree(dV);
+        throw;
+    }
+    if (dI) hipFree(dI);
+    if (dJ) hipFree(dJ);
+    if (dV) hipFree(dV);
     h->has_major = true;
 }
 
