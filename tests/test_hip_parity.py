@@ -401,3 +401,108 @@ def test_c3_scale_build_and_spmv_properties(dsa, hip):
     import scipy.sparse as sp
     A = sp.csr_matrix((vals, (rows - 1, cols - 1)), shape=(m, n))
     np.testing.assert_allclose(y1, A @ x1, rtol=1e-12, atol=0)
+
+
+# ---------------------------------------------------------------- the reference's functional tests, our RNG, HIP vs oracle
+@pytest.mark.parametrize("n", [20, 1000, 20000])
+def test_vec_fill_then_empty_matches_oracle(dsa, hip, oracle, n):
+    """test/functional/sparsevector.jl:88-119: fill with n random keys then empty — every shrink level."""
+    g = SplitMix64(n)
+    keys = []
+    seen = set()
+    while len(keys) < n:
+        k = 1 + g.next() % 10 ** 10
+        if k not in seen:
+            seen.add(k); keys.append(k)
+    vals = [g.unit12() for _ in keys]
+    a = dsa.dynamicsparsevec([], [], binding=hip)
+    b = dsa.dynamicsparsevec([], [], binding=oracle)
+    for v in (a, b):
+        v.set_batch(keys, vals)
+    assert_vec_equal(a, b)
+    assert a.nnz() == n
+    half = keys[: n // 2]
+    for v in (a, b):
+        v.set_batch(half, np.zeros(len(half)))
+    assert_vec_equal(a, b)
+    rest = keys[n // 2:]
+    for v in (a, b):
+        v.set_batch(rest, np.zeros(len(rest)))
+    assert_vec_equal(a, b)
+    assert a.nnz() == 0 and a.info()["stat_shrinks"] == b.info()["stat_shrinks"]
+
+
+def test_pcsc_42_partitions_matches_oracle(dsa, hip, oracle):
+    """test/functional/sparsematrix.jl:123-156 through the PackedCSC entry points."""
+    g = SplitMix64(42)
+    parts = [{1 + g.next() % 10000: float(1 + g.next() % 99) for _ in range(20 + g.next() % 300)} for _ in range(42)]
+    rk, vv = [list(d) for d in parts], [list(d.values()) for d in parts]
+    a = dsa.packedcsc(rk, vv, binding=hip)
+    b = dsa.packedcsc(rk, vv, binding=oracle)
+    for _ in range(1500):
+        pid = 1 + g.next() % 42
+        key = 1 + g.next() % 10000
+        val = float(g.next() % 5)           # zeros delete
+        a[key, pid] = val
+        b[key, pid] = val
+    a[3, 45] = 1.0                          # auto-creates partitions 43..45 (src/pcsr.jl:295-297)
+    b[3, 45] = 1.0
+    a.deletepartition(7)
+    b.deletepartition(7)
+    la, lb = a.export_layout(), b.export_layout()
+    assert layouts_equal(la[:3], lb[:3]) and np.array_equal(la[3], lb[3])
+    assert a.nnz() == b.nnz() and a.nbpartitions() == b.nbpartitions() == 44
+    for _ in range(300):
+        pid = 1 + g.next() % 42
+        key = 1 + g.next() % 10000
+        if pid != 7:
+            assert a[key, pid] == b[key, pid]
+
+
+def test_matrix_append_thousands_of_columns_matches_oracle(dsa, hip, oracle):
+    """test/functional/sparsematrix.jl:369-382: `for col in nb_cols:5000; matrix[1,col] = 1`."""
+    I, J, V = rand_matrix_ops(77, 340, 1000, 17000, pzero=0.0)
+    a = dsa.dynamicsparse(I, J, V, binding=hip)
+    b = dsa.dynamicsparse(I, J, V, binding=oracle)
+    cols = np.arange(1000, 5001)
+    for m_ in (a, b):
+        m_.set_batch(np.ones(len(cols), dtype=np.int64), cols, np.ones(len(cols)))
+    assert_mat_equal(a, b)
+    assert np.all(a.get_batch(np.ones(len(cols), dtype=np.int64), cols) == 1.0)
+
+
+def test_fill_mode_flush_matches_oracle(dsa, hip, oracle):
+    """closefillmode! (src/matrix.jl:126-134) through the device K-build: duplicates fold in input order."""
+    g = SplitMix64(8)
+    row = [1 + g.next() % 1000 for _ in range(10000)]
+    col = [1 + g.next() % 1000 for _ in range(10000)]
+    val = [float(1 + g.next() % 100000) for _ in range(10000)]
+    mats = []
+    for bnd in (hip, oracle):
+        m_ = dsa.dynamicsparse(fill_mode=True, binding=bnd)
+        m_.addrow(2000, [5, 3, 9], [1.0, 2.0, 3.0])
+        m_.set_batch(row, col, val)
+        m_.closefillmode()
+        mats.append(m_)
+    assert_mat_equal(*mats)
+    # non-integer duplicates: the fold order (input order) must match bit for bit
+    I = [1, 1, 1, 2, 2]
+    J = [1, 1, 1, 3, 3]
+    V = [0.1, 0.2, 0.3, 1e16, 1.0]
+    assert_mat_equal(dsa.dynamicsparse(I, J, V, binding=hip), dsa.dynamicsparse(I, J, V, binding=oracle))
+
+
+def test_negative_and_huge_keys_match_oracle(dsa, hip, oracle):
+    res = []
+    for bnd in (hip, oracle):
+        v = dsa.dynamicsparsevec([-5, 10 ** 15, 3, -(10 ** 12)], [1.0, 2.0, 3.0, 4.0], binding=bnd)
+        v[-7] = 9.0
+        v[3] = 0
+        a = dsa.dynamicsparse([1, 2, 3], [5, -2, 10 ** 13], [1.0, 2.0, 3.0], binding=bnd)
+        a[7, -9] = 4.0
+        a[-4, 5] = 2.5                       # negative row key: lands in the rowmajor twin's tables
+        a[-4, 5] = 0.0                       # delete path on a range that starts at the semaphore, key < 0
+        res.append((v, a))
+    assert_vec_equal(res[0][0], res[1][0])
+    assert_mat_equal(res[0][1], res[1][1])
+    assert res[0][1].col_view(-9) == [(7, 4.0)]

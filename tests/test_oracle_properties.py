@@ -1,0 +1,125 @@
+"""CPU property tests of the oracle with our own RNG — the reference's functional tests that use its
+MersenneTwister stream (not reproducible outside Julia) re-run as value-parity checks against dict /
+scipy oracles plus the structural invariants of test/utils.jl:68-113."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from util import SplitMix64, check_key_order, check_semaphores
+
+
+@pytest.mark.parametrize("n", [20, 100, 1000, 10000])
+def test_vec_fill_then_empty_tracks_nnz(dsa, oracle, n):
+    """test/functional/sparsevector.jl:88-119 (dynsparsevec_fill_empty)."""
+    g = SplitMix64(n)
+    kv = {}
+    while len(kv) < n:
+        kv[1 + g.next() % 10 ** 10] = g.unit12()
+    v = dsa.dynamicsparsevec([], [], binding=oracle)
+    for i, (k, x) in enumerate(kv.items(), start=1):
+        v[k] = x
+        assert v.nnz() == i
+    assert all(v[k] == x for k, x in list(kv.items())[:200])
+    ks, vs = v.nonzeros()
+    assert np.all(np.diff(ks) > 0) and len(ks) == n
+    for i, k in enumerate(kv, start=1):
+        v[k] = 0.0
+        assert v.nnz() == n - i
+    assert v.info()["capacity"] >= 2
+
+
+def test_vec_build_then_million_style_inserts(dsa, oracle):
+    """test/functional/sparsevector.jl:121-161 scaled: bulk build, overwrite/insert merge, dense 1..N fill."""
+    g = SplitMix64(99)
+    kv1 = {1 + g.next() % 10 ** 10: g.unit12() for _ in range(20000)}
+    v = dsa.dynamicsparsevec(list(kv1), list(kv1.values()), binding=oracle)
+    kv2 = {1 + g.next() % 10 ** 10: g.unit12() for _ in range(20000)}
+    v.set_batch(list(kv2), list(kv2.values()))
+    kv1.update(kv2)
+    q = list(kv1)[:: 7]
+    assert np.array_equal(v.get_batch(q), np.array([kv1[k] for k in q]))
+    w = dsa.dynamicsparsevec([5, 77, 4000], [1.0, 2.0, 3.0], binding=oracle)
+    w.set_batch(np.arange(1, 5001), np.full(5000, 10.0))
+    assert np.all(w.get_batch(np.arange(1, 5001)) == 10.0) and w.nnz() == 5000
+
+
+def test_pcsc_42_partitions_random_accumulate(dsa, oracle):
+    """test/functional/sparsematrix.jl:123-156 (pcsc_insertions_and_gets)."""
+    g = SplitMix64(42)
+    parts = [{1 + g.next() % 10000: float(1 + g.next() % 99) for _ in range(20 + g.next() % 300)} for _ in range(42)]
+    p = dsa.packedcsc([list(d) for d in parts], [list(d.values()) for d in parts], binding=oracle)
+    for _ in range(3000):
+        pid = 1 + g.next() % 42
+        key = 1 + g.next() % 10000
+        assert p[key, pid] == parts[pid - 1].get(key, 0.0)
+    for _ in range(5000):
+        pid = 1 + g.next() % 42
+        key = 1 + g.next() % 10000
+        val = float(1 + g.next() % 99)
+        p[key, pid] = p[key, pid] + val
+        parts[pid - 1][key] = parts[pid - 1].get(key, 0.0) + val
+    for pid, d in enumerate(parts, start=1):
+        for key, val in list(d.items())[:100]:
+            assert p[key, pid] == val
+    k, v, o, s = p.export_layout()
+    assert check_semaphores(k, v, o, s) == 42
+    check_key_order(k, o)
+
+
+def test_matrix_value_parity_with_scipy_and_new_columns(dsa, oracle):
+    """test/functional/sparsematrix.jl:363-382: build, read back, then append thousands of new columns."""
+    g = SplitMix64(5)
+    nr, nc = 340, 1000
+    I, J, V = [], [], []
+    seen = set()
+    for _ in range(17000):
+        i, j = 1 + g.next() % nr, 1 + g.next() % nc
+        if (i, j) not in seen:
+            seen.add((i, j)); I.append(i); J.append(j); V.append(float(g.next() % 10 ** 6) / 1000.0)
+    a = dsa.dynamicsparse(I, J, V, binding=oracle)
+    assert np.array_equal(a.get_batch(I, J), np.array(V))
+    cols = np.arange(nc, 4001)
+    a.set_batch(np.ones(len(cols), dtype=np.int64), cols, np.ones(len(cols)))
+    assert np.all(a.get_batch(np.ones(len(cols), dtype=np.int64), cols) == 1.0)
+    for o in (0, 1):
+        L = a.export_layout(o)
+        check_semaphores(L["keys"], L["vals"], L["occ"], L["semaphores"])
+        check_key_order(L["keys"], L["occ"])
+    A = sp.csr_matrix((V, (np.array(I) - 1, np.array(J) - 1)), shape=(nr, 4001)).tolil()
+    A[0, nc - 1:4000] = 1.0
+    x = 1.0 + np.arange(4001) / 4001.0
+    np.testing.assert_allclose(a.mul(x), A.tocsr() @ x, rtol=1e-12)
+
+
+def test_fill_mode_random_flush_sums_duplicates(dsa, oracle):
+    """test/functional/sparsematrix.jl:469-488: 10k random writes in fill mode accumulate like sparse(I,J,V)."""
+    g = SplitMix64(8)
+    row = [1 + g.next() % 1000 for _ in range(10000)]
+    col = [1 + g.next() % 1000 for _ in range(10000)]
+    val = [float(1 + g.next() % 100000) for _ in range(10000)]
+    a = dsa.dynamicsparse(fill_mode=True, binding=oracle)
+    a.set_batch(row, col, val)
+    a.closefillmode()
+    ref = sp.coo_matrix((val, (np.array(row) - 1, np.array(col) - 1)), shape=(1000, 1000)).tocsr()
+    qi = np.repeat(np.arange(1, 101), 1000)
+    qj = np.tile(np.arange(1, 1001), 100)
+    assert np.array_equal(a.get_batch(qi, qj), np.asarray(ref[:100].todense()).ravel())
+    # non-fill mode overwrites instead (test :490-507)
+    b = dsa.dynamicsparse(fill_mode=False, binding=oracle)
+    b.set_batch(row, col, val)
+    last = {}
+    for r, c, x in zip(row, col, val):
+        last[(r, c)] = x
+    keys = list(last)[:3000]
+    assert np.array_equal(b.get_batch([k[0] for k in keys], [k[1] for k in keys]), np.array([last[k] for k in keys]))
+
+
+def test_negative_and_huge_keys(dsa, oracle):
+    v = dsa.dynamicsparsevec([-5, 10 ** 15, 3, -(10 ** 12)], [1.0, 2.0, 3.0, 4.0], binding=oracle)
+    assert [k for k, _ in v] == [-(10 ** 12), -5, 3, 10 ** 15]
+    v[-7] = 9.0
+    assert v[-7] == 9.0 and v[10 ** 15] == 2.0 and len(v) == 10 ** 15
+    a = dsa.dynamicsparse([1, 2, 3], [5, -2, 10 ** 13], [1.0, 2.0, 3.0], binding=oracle)
+    a[7, -9] = 4.0                                       # new column in front of everything (sparsematrix.jl:251)
+    assert a[2, -2] == 2.0 and a[7, -9] == 4.0 and a[3, 10 ** 13] == 3.0
+    assert a.col_view(-9) == [(7, 4.0)] and a.row_view(3) == [(10 ** 13, 3.0)]
