@@ -202,4 +202,11 @@ hipError_t launch_spmv_scatter(const int64_t* keys, const double* vals, const ui
                                const int64_t* sems, const int64_t* part_keys, const uint8_t* part_live, int64_t table_len,
                                const double* x, int64_t nx, double* y, int64_t ny, hipStream_t stream);
 
+// sparse x driven by its stored entries over the orientation whose partitions are x's index space (colmajor for mat*v):
+// y (dense, zeroed here) += x_j * column j ; touched[row] = 1 for every row that received a term
+hipError_t launch_spmv_xdriven(const int64_t* keys, const double* vals, const uint64_t* occ, int64_t capacity,
+                               const int64_t* sems, const int64_t* col_keys, const uint8_t* col_live, int64_t table_len,
+                               const int64_t* xi, const double* xv, int64_t nx, double* y, uint8_t* touched, int64_t ny,
+                               hipStream_t stream);
+
 }  // namespace dsa

@@ -1017,36 +1017,63 @@ int32_t dsa_mat_spmv_dense(dsa_mat_t* h, int32_t transpose, const double* x, int
     API_CATCH
 }
 
-// sparse x: densify x, run the gather kernel for the values and once more on the 0/1 pattern of x to
-// obtain the touched rows (the result shape of _mul_output, src/operations.jl:11-12)
+// sparse x (the shape Coluna uses): two device strategies, same result shape (_mul_output, src/operations.jl:11-12)
+//   nx small  : k_spmv_xdriven over the reference's own orientation (colmajor for mat*v) — work ~ matched cells
+//   nx large  : densify x, gather kernel over the twin for the values + once more on the 0/1 pattern of x
 int32_t dsa_mat_spmv_sparse(dsa_mat_t* h, int32_t transpose, const int64_t* xi, const double* xv, int64_t nx,
                             int64_t* yi, double* yv, int64_t cap, int64_t* n_out) {
     API_TRY
     if (!h->has_major) fail(DSA_EMODE, "matrix is in fill mode");
     const int64_t ny = transpose ? h->n : h->m;
+    const int64_t ncols = transpose ? h->m : h->n;
     int64_t nxd = 0;
     for (int64_t i = 0; i < nx; ++i) {
         if (i > 0 && xi[i] <= xi[i - 1]) fail(DSA_EARG, "indices of x must be strictly ascending");
         nxd = std::max(nxd, xi[i]);
     }
     *n_out = 0;
-    if (ny <= 0 || nxd <= 0) return DSA_OK;
-    std::vector<double> xd((size_t)nxd, 0.0), xf((size_t)nxd, 0.0);
-    for (int64_t i = 0; i < nx; ++i) if (xi[i] >= 1) { xd[(size_t)(xi[i] - 1)] = xv[i]; xf[(size_t)(xi[i] - 1)] = 1.0; }
-    ensure_xy(h, nxd, 2 * ny);
-    Pma& P = transpose ? h->col : h->row;
-    std::vector<double> y((size_t)ny), pat((size_t)ny);
-    HIPCHK(hipMemcpyAsync(h->d_x, xd.data(), (size_t)nxd * sizeof(double), hipMemcpyHostToDevice, P.stream));
-    spmv_dev(h, transpose, 0, h->d_x, nxd, h->d_y, ny, P.stream);
-    HIPCHK(hipMemcpyAsync(y.data(), h->d_y, (size_t)ny * sizeof(double), hipMemcpyDeviceToHost, P.stream));
-    HIPCHK(hipStreamSynchronize(P.stream));
-    HIPCHK(hipMemcpyAsync(h->d_x, xf.data(), (size_t)nxd * sizeof(double), hipMemcpyHostToDevice, P.stream));
-    // pattern pass: same kernel, every cell whose x entry is stored contributes 1 -> touched rows
-    spmv_dev(h, transpose, 0, h->d_x, nxd, h->d_y + ny, ny, P.stream, 1);
-    HIPCHK(hipMemcpyAsync(pat.data(), h->d_y + ny, (size_t)ny * sizeof(double), hipMemcpyDeviceToHost, P.stream));
-    HIPCHK(hipStreamSynchronize(P.stream));
+    if (ny <= 0 || nx <= 0) return DSA_OK;
+    std::vector<double> y((size_t)ny);
+    std::vector<uint8_t> flag((size_t)ny);
+    const bool xdriven = nx * 8 < std::max<int64_t>(ncols, 1) || nxd <= 0 || xi[0] < 1;
+    if (xdriven) {
+        Pma& P = transpose ? h->row : h->col;          // partitions indexed like x
+        // scratch: y (ny doubles) | touched (ny bytes) | xi | xv
+        const size_t bytes = (size_t)ny * 8 + (size_t)((ny + 7) / 8) * 8 + (size_t)nx * 16;
+        void* d = nullptr;
+        HIPCHK(hipMalloc(&d, bytes));
+        double* d_y = (double*)d;
+        uint8_t* d_t = (uint8_t*)(d_y + ny);
+        int64_t* d_xi = (int64_t*)(d_t + (size_t)((ny + 7) / 8) * 8);
+        double* d_xv = (double*)(d_xi + nx);
+        try {
+            HIPCHK(hipMemcpyAsync(d_xi, xi, (size_t)nx * 8, hipMemcpyHostToDevice, P.stream));
+            HIPCHK(hipMemcpyAsync(d_xv, xv, (size_t)nx * 8, hipMemcpyHostToDevice, P.stream));
+            hipError_t e = launch_spmv_xdriven(P.K(), P.V(), P.O(), P.capacity(), P.sems, P.col_keys, P.col_live, P.h_ctl->table_len,
+                                               d_xi, d_xv, nx, d_y, d_t, ny, P.stream);
+            if (e != hipSuccess) fail(DSA_EHIP, std::string("spmv launch: ") + hipGetErrorString(e));
+            HIPCHK(hipMemcpyAsync(y.data(), d_y, (size_t)ny * 8, hipMemcpyDeviceToHost, P.stream));
+            HIPCHK(hipMemcpyAsync(flag.data(), d_t, (size_t)ny, hipMemcpyDeviceToHost, P.stream));
+            HIPCHK(hipStreamSynchronize(P.stream));
+        } catch (...) { hipFree(d); throw; }
+        hipFree(d);
+    } else {
+        std::vector<double> xd((size_t)nxd, 0.0), xf((size_t)nxd, 0.0), pat((size_t)ny);
+        for (int64_t i = 0; i < nx; ++i) { xd[(size_t)(xi[i] - 1)] = xv[i]; xf[(size_t)(xi[i] - 1)] = 1.0; }
+        ensure_xy(h, nxd, 2 * ny);
+        Pma& P = transpose ? h->col : h->row;
+        HIPCHK(hipMemcpyAsync(h->d_x, xd.data(), (size_t)nxd * sizeof(double), hipMemcpyHostToDevice, P.stream));
+        spmv_dev(h, transpose, 0, h->d_x, nxd, h->d_y, ny, P.stream);
+        HIPCHK(hipMemcpyAsync(y.data(), h->d_y, (size_t)ny * sizeof(double), hipMemcpyDeviceToHost, P.stream));
+        HIPCHK(hipStreamSynchronize(P.stream));
+        HIPCHK(hipMemcpyAsync(h->d_x, xf.data(), (size_t)nxd * sizeof(double), hipMemcpyHostToDevice, P.stream));
+        spmv_dev(h, transpose, 0, h->d_x, nxd, h->d_y + ny, ny, P.stream, 1);     // pattern pass: touched rows
+        HIPCHK(hipMemcpyAsync(pat.data(), h->d_y + ny, (size_t)ny * sizeof(double), hipMemcpyDeviceToHost, P.stream));
+        HIPCHK(hipStreamSynchronize(P.stream));
+        for (int64_t r = 0; r < ny; ++r) flag[(size_t)r] = pat[(size_t)r] != 0.0;
+    }
     int64_t cnt = 0;
-    for (int64_t r = 0; r < ny; ++r) if (pat[(size_t)r] != 0.0) {
+    for (int64_t r = 0; r < ny; ++r) if (flag[(size_t)r]) {
         if (cnt >= cap) fail(DSA_ECAP, "output buffers too small");
         yi[cnt] = r + 1; yv[cnt] = y[(size_t)r]; ++cnt;
     }

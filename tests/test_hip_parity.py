@@ -323,6 +323,16 @@ def test_spmv_matches_oracle(dsa, hip, oracle, m, n, per_col, seed):
     ib, vb = b.mul((xi, xv))
     assert np.array_equal(ia, ib)
     np.testing.assert_allclose(va, vb, rtol=RTOL, atol=0)
+    # a few entries only (x-driven kernel) and nearly all of them (densify + pattern pass), both transposes
+    for cnt in (3, max(3, (7 * n) // 8)):
+        xi2 = np.unique(1 + (splitmix_array(seed + 5, cnt) % np.uint64(n)).astype(np.int64))
+        xv2 = unit12_array(seed + 6, len(xi2))
+        for tr in (False, True):
+            xi3 = xi2 if not tr else xi2[xi2 <= m]
+            ia, va = a.mul((xi3, xv2[: len(xi3)]), transpose=tr)
+            ib, vb = b.mul((xi3, xv2[: len(xi3)]), transpose=tr)
+            assert np.array_equal(ia, ib), (cnt, tr)
+            np.testing.assert_allclose(va, vb, rtol=RTOL, atol=0)
 
 
 def test_spmv_long_rows_and_tile_straddling(dsa, hip, oracle):
@@ -506,3 +516,7 @@ def test_negative_and_huge_keys_match_oracle(dsa, hip, oracle):
     assert_vec_equal(res[0][0], res[1][0])
     assert_mat_equal(res[0][1], res[1][1])
     assert res[0][1].col_view(-9) == [(7, 4.0)]
+    # sparse x with a negative column key: only the x-driven kernel can address it (like the reference's _mul)
+    ya = res[0][1].mul(([-9, 5], [2.0, 3.0]))
+    yb = res[1][1].mul(([-9, 5], [2.0, 3.0]))
+    assert np.array_equal(ya[0], yb[0]) and np.array_equal(ya[1], yb[1])
