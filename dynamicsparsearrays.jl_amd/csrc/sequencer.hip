@@ -38,6 +38,7 @@ struct Seq {
     int64_t* sK; double* sV;       // LDS staging for the small-window rebalance
     uint32_t* sWordOff;            // [SMALL_W/64 + 1]
     int64_t* sRed;                 // [SEQ_BLOCK/64] block-reduce scratch
+    const int64_t* lo; const int64_t* hi;   // integer density bounds per level (LDS copy of Ctl::lo / Ctl::hi)
 };
 
 // ---- bitmap scans (uniform, executed by every thread) -------------------------------------------
@@ -407,14 +408,14 @@ __device__ int d_after_count_change(Seq& S, int64_t pos) {
         left += blk_count(S, ws, prev_ws);
         right += blk_count(S, prev_we + 1, we + 1);
         const int64_t c = left + right;
-        if (S.ctl->lo[h] <= c && c <= S.ctl->hi[h]) { accepted = true; break; }
+        if (S.lo[h] <= c && c <= S.hi[h]) { accepted = true; break; }
         prev_ws = ws; prev_we = we;
     }
     const int64_t count = left + right;
     if (!accepted) {
         const int64_t H = S.height;
-        if (count > S.ctl->hi[H]) { S.y_m = count; return SEQ_Y_EXTEND; }
-        if (count < S.ctl->lo[H] && S.height > 1) { S.y_m = count; return SEQ_Y_SHRINK; }
+        if (count > S.hi[H]) { S.y_m = count; return SEQ_Y_EXTEND; }
+        if (count < S.lo[H] && S.height > 1) { S.y_m = count; return SEQ_Y_SHRINK; }
         ws = 1; we = S.capacity;
     }
     // _even_rebalance!  src/pma.jl:94-103 / src/pcsr.jl:88-97
@@ -431,6 +432,21 @@ __device__ int64_t d_insert_after(Seq& S, int64_t key, double val, int64_t pos) 
     const int64_t ne = d_next_empty(S.occ, pos, S.capacity);
     const int64_t pe = ne != 0 ? 0 : d_prev_empty(S.occ, pos);
     const bool last_occ = (ne == 0 && pe != 0) ? occ_test(S.occ, pos) : true;
+    if (ne != 0 && ne - (pos + 1) <= SEQ_BLOCK) {
+        // common case, fused: one chunk.  bitmap reads + cell loads | barrier | cell stores + new cell + bitmap | barrier
+        const int64_t p = ne - 1 - threadIdx.x;
+        const bool act = p >= pos + 1;
+        int64_t k = 0; double v = 0.0;
+        if (act) { k = S.keys[p - 1]; v = S.vals[p - 1]; }
+        __syncthreads();
+        if (act) {
+            S.keys[p] = k; S.vals[p] = v;
+            if (S.sems != nullptr && k == SEM_KEY) S.sems[(int64_t)v - 1] = p + 1;
+        }
+        if (threadIdx.x == 0) { S.keys[pos] = key; S.vals[pos] = val; occ_set(S, ne); }
+        __syncthreads();
+        return pos + 1;
+    }
     __syncthreads();                       // every thread has finished reading the bitmap
     if (ne != 0) {
         blk_shift_right(S, pos + 1, ne);
@@ -462,7 +478,6 @@ __device__ int d_set_in_range(Seq& S, int64_t key, double val, int64_t from, int
             __syncthreads();
             return 0;
         }
-        __syncthreads();
         const int64_t ip = d_insert_after(S, key, val, f.pos);
         if (ip == 0) return SEQ_ERROR;
         S.nb_elements += 1;
@@ -651,17 +666,23 @@ __global__ __launch_bounds__(SEQ_BLOCK) void k_sequencer(int64_t* keys, double* 
     S.sK = reinterpret_cast<int64_t*>(lds);
     S.sV = reinterpret_cast<double*>(lds + SMALL_W * sizeof(int64_t));
     S.sWordOff = sWordOff; S.sRed = sRed;
+    __shared__ int64_t sLo[MAX_LEVELS], sHi[MAX_LEVELS];
+    if (threadIdx.x < MAX_LEVELS) { sLo[threadIdx.x] = ctl->lo[threadIdx.x]; sHi[threadIdx.x] = ctl->hi[threadIdx.x]; }
+    S.lo = sLo; S.hi = sHi;
+    __syncthreads();
 
     int64_t i = ctl->next_op;
     int status = SEQ_DONE;
+    Op op = ops[i < n_ops ? i : 0];
     for (; i < n_ops; ++i) {
-        const Op op = ops[i];
+        const Op nxt = ops[i + 1 < n_ops ? i + 1 : i];          // prefetched under the current op's memory traffic
         const int r = d_exec(S, op);
         if (r != 0) {
             status = r & 0xff;
             if (!(r & RERUN) && status != SEQ_ERROR) ++i;      // the op itself is complete once the host has acted
             break;
         }
+        op = nxt;
     }
     __syncthreads();
     if (threadIdx.x == 0) {

@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""Sequencer cost breakdown (dev tool): find-only, overwrite, insert batches on the C2 vector."""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench, dsa_loader
+dsa = dsa_loader.load(); hip = dsa.product()
+n0 = 700000
+keys0 = np.arange(1, n0 + 1, dtype=np.int64) * 2
+v = dsa.dynamicsparsevec(keys0, bench.unit12(3, n0), binding=hip)
+rng = np.random.default_rng(1)
+def t(label, keys, vals):
+    v.set_batch(keys[:100], vals[:100])
+    t0 = time.perf_counter(); v.set_batch(keys, vals); dt = time.perf_counter() - t0
+    print("%-40s %7.2f us/op" % (label, dt / len(keys) * 1e6))
+ex = rng.choice(keys0, 100000)
+t("delete of missing keys (find only)", ex + 1 - 2 * (ex % 2 == 1), np.zeros(100000))   # odd keys: absent
+t("overwrite existing keys", ex, bench.unit12(9, 100000))
+t("1 op batches x200 (host round trip)", ex[:200], bench.unit12(9, 200)) if False else None
+t0 = time.perf_counter()
+for k in ex[:300]: v[int(k)] = 1.5
+print("%-40s %7.2f us/op" % ("single-op calls (host round trip each)", (time.perf_counter() - t0) / 300 * 1e6))
+odd = np.unique(1 + 2 * (bench.splitmix_array(4, 120000) % np.uint64(700000)).astype(np.int64))[:100000]
+rng.shuffle(odd)
+t("uniform inserts (new keys)", odd, bench.unit12(4, len(odd)))
+t("delete them again", odd, np.zeros(len(odd)))
