@@ -295,6 +295,16 @@ class DynamicSparseMatrix(_Handle):
     def row_view(self, row):                          # @view m[row, :]  src/matrix.jl:70-81
         return self._view("mat_row_view", row)
 
+    def col_slice(self, col):                         # m[:, col]  src/pcsr.jl:285-291
+        h = VP()
+        self.b.call("mat_col_slice", self.h, int(col), C.byref(h))
+        return DynamicSparseVector(self.b, h)
+
+    def row_slice(self, row):                         # m[row, :]  src/pcsr.jl:269-283
+        h = VP()
+        self.b.call("mat_row_slice", self.h, int(row), C.byref(h))
+        return DynamicSparseVector(self.b, h)
+
     def nnz(self):
         out = C.c_int64()
         self.b.call("mat_nnz", self.h, C.byref(out))

@@ -98,6 +98,8 @@ _SIGS = {
     "mat_deleterow": [VP, I64],
     "mat_col_view": [VP, I64, P_I64, P_F64, I64, P_I64],
     "mat_row_view": [VP, I64, P_I64, P_F64, I64, P_I64],
+    "mat_col_slice": [VP, I64, C.POINTER(VP)],
+    "mat_row_slice": [VP, I64, C.POINTER(VP)],
     "mat_nnz": [VP, P_I64],
     "mat_size": [VP, P_I64, P_I64],
     "mat_nbpartitions": [VP, I32, P_I64],

@@ -955,6 +955,8 @@ int32_t dsa_mat_deleterow(dsa_mat_t* h, int64_t row) {         // src/matrix.jl:
     API_CATCH
 }
 
+static void _check_status(int32_t rc) { if (rc != DSA_OK) fail(rc, g_err); }
+
 static int32_t view_impl(dsa_mat_t* h, int32_t o, int64_t key, int64_t* ks, double* vs, int64_t cap, int64_t* n_out) {
     API_TRY
     if (h->fillmode) fail(DSA_EMODE, "View not available in fill mode.");
@@ -971,6 +973,21 @@ int32_t dsa_mat_col_view(dsa_mat_t* h, int64_t col, int64_t* rows, double* vals,
 int32_t dsa_mat_row_view(dsa_mat_t* h, int64_t row, int64_t* cols, double* vals, int64_t cap, int64_t* n_out) {
     return view_impl(h, DSA_ROWMAJOR, row, cols, vals, cap, n_out);
 }
+// m[:, col] (src/pcsr.jl:285-291 -> :247-259) and m[row, :] (src/pcsr.jl:269-283; served from the rowmajor twin, whose
+// partition `row` holds exactly the (col, value) pairs the reference collects by scanning the colmajor array)
+static int32_t slice_impl(dsa_mat_t* h, int32_t o, int64_t key, dsa_vec_t** out) {
+    API_TRY
+    if (h->fillmode) fail(DSA_EMODE, "slices are not available in fill mode");
+    std::vector<int64_t> k; std::vector<double> v;
+    col_view_of(orient(h, o), key, k, v);
+    int64_t len = 0;
+    for (int64_t x : k) len = std::max(len, x);          // _guess_length(pma)  src/vector.jl:7-8
+    _check_status(dsa_vec_create(k.data(), v.data(), (int64_t)k.size(), DSA_COMBINE_ADD, len, out));
+    API_CATCH
+}
+int32_t dsa_mat_col_slice(dsa_mat_t* h, int64_t col, dsa_vec_t** out) { return slice_impl(h, DSA_COLMAJOR, col, out); }
+int32_t dsa_mat_row_slice(dsa_mat_t* h, int64_t row, dsa_vec_t** out) { return slice_impl(h, DSA_ROWMAJOR, row, out); }
+
 int32_t dsa_mat_nnz(dsa_mat_t* h, int64_t* out) {      // nnz(m) = nnz(m.rowmajor)  src/matrix.jl:91
     API_TRY Pma& P = orient(h, DSA_ROWMAJOR); *out = P.h_ctl->nb_elements - P.h_ctl->nb_partitions; API_CATCH
 }

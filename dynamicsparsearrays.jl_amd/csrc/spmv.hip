@@ -119,7 +119,7 @@ __global__ __launch_bounds__(SP_BLOCK) void k_spmv(const int64_t* __restrict__ k
             else if (k[j] >= 1 && k[j] <= nx) {
                 const double xv = x[k[j] - 1];
                 // pattern pass (touched rows of _mul, src/operations.jl:101): count the cells whose x entry is stored
-                p = pattern ? (xv != 0.0 ? 1.0 : 0.0) : v[j] * xv;
+                p = pattern == 1 ? (xv != 0.0 ? 1.0 : 0.0) : v[j] * xv;
             }
         }
         sP[ls] = p;
@@ -145,6 +145,7 @@ __global__ __launch_bounds__(SP_BLOCK) void k_spmv(const int64_t* __restrict__ k
         if (lane == 0) sCarry = c;
     }
 
+    if (pattern == 2) return;      // dev ablation (DSA_DBG_SPMV=2): stream + gather only, no segmented sums
     if (!SCATTER) {
         // ---- phase 2 (gather): one lane per semaphore sums its segment in slot order -------------
         for (int j = tid; j < total; j += SP_BLOCK) {
@@ -292,11 +293,13 @@ hipError_t launch_spmv_xdriven(const int64_t* keys, const double* vals, const ui
     return hipGetLastError();
 }
 
+#include <cstdlib>
 static hipError_t launch_spmv(bool scatter, int pattern, const int64_t* keys, const double* vals, const uint64_t* occ, int64_t capacity,
                               const int64_t* sems, const int64_t* part_keys, int64_t table_len, const double* x, int64_t nx,
                               double* y, int64_t ny, hipStream_t stream) {
     hipError_t e = hipMemsetAsync(y, 0, (size_t)ny * sizeof(double), stream);
     if (e != hipSuccess) return e;
+    { static const char* dbg = getenv("DSA_DBG_SPMV"); if (dbg && pattern == 0) pattern = atoi(dbg); }
     const int64_t ntiles = (capacity + SP_TILE - 1) / SP_TILE;
     if (scatter)
         hipLaunchKernelGGL(k_spmv<true>, dim3((unsigned)ntiles), dim3(SP_BLOCK), 0, stream, keys, vals, occ, capacity, sems,

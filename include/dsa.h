@@ -139,6 +139,10 @@ int32_t dsa_mat_deleterow(dsa_mat_t* h, int64_t row);
 /* @view m[:, col] / @view m[row, :] iteration  src/matrix.jl:70-93, src/views.jl:15-35 */
 int32_t dsa_mat_col_view(dsa_mat_t* h, int64_t col, int64_t* rows, double* vals, int64_t cap, int64_t* n_out);
 int32_t dsa_mat_row_view(dsa_mat_t* h, int64_t row, int64_t* cols, double* vals, int64_t cap, int64_t* n_out);
+/* m[:, col] / m[row, :] as a NEW dynamic sparse vector  (getindex(mpcsc, :, col) src/pcsr.jl:285-291 -> :247-259 ;
+ * getindex(mpcsc, row, :) src/pcsr.jl:269-283): the stored entries of the column / row, length = largest key */
+int32_t dsa_mat_col_slice(dsa_mat_t* h, int64_t col, dsa_vec_t** out);
+int32_t dsa_mat_row_slice(dsa_mat_t* h, int64_t row, dsa_vec_t** out);
 /* nnz(m) src/matrix.jl:91 ; size(m) :92 ; nbpartitions(orientation) src/pcsr.jl:21-22 */
 int32_t dsa_mat_nnz(dsa_mat_t* h, int64_t* out);
 int32_t dsa_mat_size(dsa_mat_t* h, int64_t* m, int64_t* n);

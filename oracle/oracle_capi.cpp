@@ -285,6 +285,28 @@ int32_t ora_mat_col_view(ora_mat* h, int64_t col, int64_t* rows, double* vals, i
 int32_t ora_mat_row_view(ora_mat* h, int64_t row, int64_t* cols, double* vals, int64_t cap, int64_t* n_out) {
     return view_impl(h, 1, row, cols, vals, cap, n_out);
 }
+// m[:, col] / m[row, :] as new vectors.  The row slice follows the reference literally: a scan of the COLMAJOR array
+// (mpcsc_row_slice, src/pcsr.jl:269-283) — the HIP library serves it from the rowmajor twin; both must agree.
+int32_t ora_mat_col_slice(ora_mat* h, int64_t col, ora_vec** out) {
+    ORA_TRY
+    if (h->a.fillmode) throw Err{EMODE, "slices are not available in fill mode"};
+    std::vector<int64_t> k; std::vector<double> v;
+    mpcsc_col_view(orient(h, 0), col, k, v);
+    auto* r = new ora_vec();
+    vec_init(r->v, k, v, COMBINE_ADD, -1);
+    *out = r;
+    ORA_CATCH
+}
+int32_t ora_mat_row_slice(ora_mat* h, int64_t row, ora_vec** out) {
+    ORA_TRY
+    if (h->a.fillmode) throw Err{EMODE, "slices are not available in fill mode"};
+    std::vector<int64_t> k; std::vector<double> v;
+    mpcsc_row_slice(orient(h, 0), row, k, v);
+    auto* r = new ora_vec();
+    vec_init(r->v, k, v, COMBINE_ADD, -1);
+    *out = r;
+    ORA_CATCH
+}
 int32_t ora_mat_nnz(ora_mat* h, int64_t* out) {   // nnz(m) = nnz(m.rowmajor)  src/matrix.jl:91
     ORA_TRY
     const MappedPackedCSC& r = orient(h, 1);

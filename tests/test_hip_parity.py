@@ -520,3 +520,14 @@ def test_negative_and_huge_keys_match_oracle(dsa, hip, oracle):
     ya = res[0][1].mul(([-9, 5], [2.0, 3.0]))
     yb = res[1][1].mul(([-9, 5], [2.0, 3.0]))
     assert np.array_equal(ya[0], yb[0]) and np.array_equal(ya[1], yb[1])
+
+
+def test_row_and_column_slices_match_oracle(dsa, hip, oracle):
+    """m[:, j] / m[i, :] as new dynamic sparse vectors (src/pcsr.jl:247-291); the HIP row slice comes from the
+    rowmajor twin, the oracle's from the reference's scan of the colmajor array — same entries, same layout."""
+    I, J, V = rand_matrix_ops(31, 60, 90, 2500, pzero=0.0)
+    a = dsa.dynamicsparse(I, J, V, binding=hip)
+    b = dsa.dynamicsparse(I, J, V, binding=oracle)
+    for key in (1, 7, 33, 60, 89, 1000):
+        assert_vec_equal(a.col_slice(key), b.col_slice(key))
+        assert_vec_equal(a.row_slice(key), b.row_slice(key))

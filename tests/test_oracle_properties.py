@@ -123,3 +123,17 @@ def test_negative_and_huge_keys(dsa, oracle):
     a[7, -9] = 4.0                                       # new column in front of everything (sparsematrix.jl:251)
     assert a[2, -2] == 2.0 and a[7, -9] == 4.0 and a[3, 10 ** 13] == 3.0
     assert a.col_view(-9) == [(7, 4.0)] and a.row_view(3) == [(10 ** 13, 3.0)]
+
+
+def test_row_and_column_slices(dsa, oracle):
+    """test/functional/sparsematrix.jl:212-245 (A.5): m[2, :] / m[:, 2] as dynamic sparse vectors."""
+    J = [1, 1, 1, 2, 2, 2, 3, 3, 3]
+    I = [1, 2, 3, 2, 6, 7, 1, 6, 8]
+    V = [2, 3, 4, 2, 4, 5, 3, 5, 7]
+    a = dsa.dynamicsparse(I, J, V, binding=oracle)
+    a[1, 1] = 4; a[1, 2] = 3; a[3, 1] = 0; a[4, 2] = 1
+    row = a.row_slice(2)
+    assert row.nnz() == 2 and [row[j] for j in (1, 2, 3)] == [3.0, 2.0, 0.0]
+    col = a.col_slice(2)
+    assert col.nnz() == 5 and [col[i] for i in range(1, 9)] == [3.0, 2.0, 0.0, 1.0, 0.0, 4.0, 5.0, 0.0]
+    assert a.col_slice(99).nnz() == 0 and a.row_slice(5).nnz() == 0
