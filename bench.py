@@ -246,8 +246,7 @@ def extras(dsa, hip, torch, A, dev):
     #     SpMV every 500 columns.  Full C5 is 50k columns x 16 rows over 100k rows; parity of this loop vs the
     #     oracle is tests/test_hip_parity.py::test_matrix_from_empty_streaming_columns_c5_scaled
     m5, ncols5, per5 = 10_000, 5_000, 16
-    B = dsa.dynamicsparse(fill_mode=False, binding=hip)
-    hip.call("mat_set_stream", B.h, C.c_void_p(stream.cuda_stream))
+    B = dsa.dynamicsparse(fill_mode=False, binding=hip)      # keeps its two own streams: the orientations update concurrently
     rows5 = 1 + (splitmix_array(11, ncols5 * per5 * 2) % np.uint64(m5)).astype(np.int64)
     vals5 = unit12(12, ncols5 * per5)
     x5 = torch.from_numpy(unit12(13, ncols5)).to(dev)

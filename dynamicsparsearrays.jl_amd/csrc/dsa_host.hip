@@ -300,55 +300,100 @@ const char* err_text(int32_t e) {
     }
 }
 
+// ---- the yield loop around the device sequencer, as a resumable state machine so that the two orientations of a
+// matrix can run their sequencers concurrently on their own streams ------------------------------------------------
+struct SeqRun {
+    Pma* P = nullptr;
+    const std::vector<Op>* ops = nullptr;
+    int64_t n = 0;
+    bool active = false;
+    int32_t err = 0;         // status of the failing op (0 if none)
+    int64_t applied = 0;     // ops fully applied
+    int64_t guard = 0;
+};
+
+void seq_launch(SeqRun& r) {
+    Pma& P = *r.P;
+    // pinned h_ctl: H2D, kernel and D2H are stream-ordered; the host does not touch h_ctl until the next synchronize
+    HIPCHK(hipMemcpyAsync(P.d_ctl, P.h_ctl, sizeof(Ctl), hipMemcpyHostToDevice, P.stream));
+    hipError_t e = launch_sequencer(P.K(), P.V(), P.O(), P.has_sems ? P.sems : nullptr, P.has_cols ? P.col_keys : nullptr,
+                                    P.has_cols ? P.col_live : nullptr, P.d_ctl, P.d_ops, r.n, P.stream);
+    if (e != hipSuccess) fail(DSA_EHIP, std::string("sequencer launch: ") + hipGetErrorString(e));
+    HIPCHK(hipMemcpyAsync(P.h_ctl, P.d_ctl, sizeof(Ctl), hipMemcpyDeviceToHost, P.stream));
+}
+
+void seq_start(SeqRun& r, Pma& P, const std::vector<Op>& ops) {
+    r = SeqRun();
+    r.P = &P; r.ops = &ops; r.n = (int64_t)ops.size();
+    if (r.n == 0) return;
+    ensure_ops(P, r.n);
+    HIPCHK(hipMemcpyAsync(P.d_ops, ops.data(), (size_t)r.n * sizeof(Op), hipMemcpyHostToDevice, P.stream));
+    P.h_ctl->next_op = 0; P.h_ctl->status = 0; P.h_ctl->err = 0;
+    r.active = true;
+    seq_launch(r);
+}
+
+// waits for the running kernel of `r`, services its yield and relaunches; returns false once the batch is finished
+bool seq_step(SeqRun& r) {
+    if (!r.active) return false;
+    Pma& P = *r.P;
+    HIPCHK(hipStreamSynchronize(P.stream));
+    Ctl& c = *P.h_ctl;
+    switch (c.status) {
+        case SEQ_DONE:
+            r.applied = r.n; r.active = false;
+            return false;
+        case SEQ_ERROR:
+            r.err = seq_err_to_status(c.err); r.applied = c.next_op; r.active = false;
+            return false;
+        case SEQ_Y_REBALANCE:
+            window_rebalance(P, c.y_ws, c.y_we, c.y_m);
+            break;
+        case SEQ_Y_EXTEND: {       // _extend!  src/pma.jl:143-151 then _even_rebalance!(1, capacity, count)
+            const int64_t old_cap = c.capacity;
+            c.capacity *= 2; c.nb_segments *= 2; c.height += 1;
+            compute_bounds(P);
+            c.stat_extends += 1; c.stat_rebalances += 1; c.stat_window_slots += c.capacity;
+            root_rebalance(P, old_cap, c.capacity, c.y_m, false);
+            break;
+        }
+        case SEQ_Y_SHRINK: {       // pack! + _shrink!  src/pma.jl:135-139,153-161 then _even_rebalance!
+            const int64_t old_cap = c.capacity;
+            c.capacity /= 2; c.nb_segments /= 2; c.height -= 1;
+            compute_bounds(P);
+            c.stat_shrinks += 1; c.stat_rebalances += 1; c.stat_window_slots += c.capacity;
+            root_rebalance(P, old_cap, c.capacity, c.y_m, false);
+            break;
+        }
+        case SEQ_Y_TABLE_GROW:
+            ensure_tables(P, c.table_len + 1);
+            break;
+        default:
+            fail(DSA_EASSERT, "unknown sequencer status");
+    }
+    if (++r.guard > 4 * r.n + 1000000) fail(DSA_EASSERT, "sequencer made no progress");
+    seq_launch(r);
+    return true;
+}
+
 // Runs `ops` in order on the device.  Returns the number of ops fully applied; *err receives the
 // status of the failing op (0 if all were applied).
 int64_t run_ops(Pma& P, const std::vector<Op>& ops, int32_t* err) {
-    *err = 0;
-    const int64_t n = (int64_t)ops.size();
-    if (n == 0) return 0;
-    ensure_ops(P, n);
-    HIPCHK(hipMemcpyAsync(P.d_ops, ops.data(), (size_t)n * sizeof(Op), hipMemcpyHostToDevice, P.stream));
-    P.h_ctl->next_op = 0; P.h_ctl->status = 0; P.h_ctl->err = 0;
-    upload_ctl(P);
-    for (int64_t guard = 0;; ++guard) {
-        hipError_t e = launch_sequencer(P.K(), P.V(), P.O(), P.has_sems ? P.sems : nullptr, P.has_cols ? P.col_keys : nullptr,
-                                        P.has_cols ? P.col_live : nullptr, P.d_ctl, P.d_ops, n, P.stream);
-        if (e != hipSuccess) fail(DSA_EHIP, std::string("sequencer launch: ") + hipGetErrorString(e));
-        download_ctl(P);
-        Ctl& c = *P.h_ctl;
-        switch (c.status) {
-            case SEQ_DONE:
-                return n;
-            case SEQ_ERROR:
-                *err = seq_err_to_status(c.err);
-                return c.next_op;
-            case SEQ_Y_REBALANCE:
-                window_rebalance(P, c.y_ws, c.y_we, c.y_m);
-                break;
-            case SEQ_Y_EXTEND: {       // _extend!  src/pma.jl:143-151 then _even_rebalance!(1, capacity, count)
-                const int64_t old_cap = c.capacity;
-                c.capacity *= 2; c.nb_segments *= 2; c.height += 1;
-                compute_bounds(P);
-                c.stat_extends += 1; c.stat_rebalances += 1; c.stat_window_slots += c.capacity;
-                root_rebalance(P, old_cap, c.capacity, c.y_m, false);
-                break;
-            }
-            case SEQ_Y_SHRINK: {       // pack! + _shrink!  src/pma.jl:135-139,153-161 then _even_rebalance!
-                const int64_t old_cap = c.capacity;
-                c.capacity /= 2; c.nb_segments /= 2; c.height -= 1;
-                compute_bounds(P);
-                c.stat_shrinks += 1; c.stat_rebalances += 1; c.stat_window_slots += c.capacity;
-                root_rebalance(P, old_cap, c.capacity, c.y_m, false);
-                break;
-            }
-            case SEQ_Y_TABLE_GROW:
-                ensure_tables(P, c.table_len + 1);
-                break;
-            default:
-                fail(DSA_EASSERT, "unknown sequencer status");
-        }
-        upload_ctl(P);
-        if (guard > 4 * n + 1000000) fail(DSA_EASSERT, "sequencer made no progress");
+    SeqRun r;
+    seq_start(r, P, ops);
+    while (seq_step(r)) {}
+    *err = r.err;
+    return r.applied;
+}
+
+// Two independent structures (the colmajor and rowmajor orientation): both sequencers run at the same time, each on
+// its own stream; the host alternates between their yield mailboxes.
+void run_ops_pair(Pma& A, const std::vector<Op>& opsA, Pma& B, const std::vector<Op>& opsB, SeqRun& ra, SeqRun& rb) {
+    seq_start(ra, A, opsA);
+    seq_start(rb, B, opsB);
+    while (ra.active || rb.active) {
+        if (ra.active) seq_step(ra);
+        if (rb.active) seq_step(rb);
     }
 }
 
@@ -595,6 +640,20 @@ void mat_apply_sets(dsa_mat* h, const int64_t* I, const int64_t* J, const double
     for (int64_t k = 0; k < n; ++k) {
         oc[(size_t)k] = make_op(OP_MPCSC_SET, I[k], J[k], V[k]);      // colmajor[row, col] = val
         orw[(size_t)k] = make_op(OP_MPCSC_SET, J[k], I[k], V[k]);     // rowmajor[col, row] = val
+    }
+    // Without tombstones an OP_MPCSC_SET cannot fail (the reference's assert / bounds paths of addpartition! need a
+    // deleted partition, App. A.6 (3)), so the two orientations can be updated concurrently; otherwise the colmajor
+    // batch runs first and the rowmajor batch is cut at the failing op, like the reference's statement order.
+    const bool no_tombstones = h->col.h_ctl->nb_partitions == h->col.h_ctl->table_len &&
+                               h->row.h_ctl->nb_partitions == h->row.h_ctl->table_len;
+    if (no_tombstones && h->col.stream != h->row.stream) {
+        SeqRun rc, rr;
+        run_ops_pair(h->col, oc, h->row, orw, rc, rr);
+        const int64_t done = std::min(rc.applied, rr.applied);
+        for (int64_t k = 0; k < std::min(done + 1, n); ++k) if (V[k] != 0.0) { h->m = std::max(h->m, I[k]); h->n = std::max(h->n, J[k]); }
+        if (rc.err) fail(rc.err, err_text(rc.err));
+        if (rr.err) fail(rr.err, err_text(rr.err));
+        return;
     }
     int32_t err = 0;
     const int64_t done = run_ops(h->col, oc, &err);
