@@ -531,3 +531,38 @@ def test_row_and_column_slices_match_oracle(dsa, hip, oracle):
     for key in (1, 7, 33, 60, 89, 1000):
         assert_vec_equal(a.col_slice(key), b.col_slice(key))
         assert_vec_equal(a.row_slice(key), b.row_slice(key))
+
+
+def test_c4_shard_scale_build_spmv_and_root_rebalance(dsa, hip):
+    """One shard of BASELINE config 4 at full size on the GPU alone: 1.25 M columns x 10 M rows, 12.5 M nnz ->
+    capacity 2^25 in both orientations (colmajor density 0.41, rowmajor 0.67).  Size-independent properties:
+    capacity rule, element counts, semaphore table, SpMV vs scipy (1e-12), rebalance idempotence (digest)."""
+    import scipy.sparse as sp
+    m, n, per = 10_000_000, 1_250_000, 10
+    rows = 1 + (splitmix_array(8, n * per) % np.uint64(m)).astype(np.int64)
+    cols = np.repeat(np.arange(1, n + 1, dtype=np.int64), per)
+    vals = unit12_array(9, n * per)
+    key = cols * np.int64(m + 1) + rows
+    _, first = np.unique(key, return_index=True)
+    rows, cols, vals = rows[first], cols[first], vals[first]
+    a = dsa.dynamicsparse(rows, cols, vals, m, n, binding=hip)
+    for o in (0, 1):
+        inf = a.info(o)
+        assert inf["capacity"] == 1 << 25, inf
+        assert inf["nb_elements"] == len(rows) + inf["nb_partitions"]
+    assert a.info(0)["nb_partitions"] == n
+    x = unit12_array(10, n)
+    y = a.mul(x)
+    A = sp.csr_matrix((vals, (rows - 1, cols - 1)), shape=(m, n))
+    np.testing.assert_allclose(y, A @ x, rtol=RTOL, atol=0)
+    xt = unit12_array(11, m)
+    np.testing.assert_allclose(a.mul(xt, transpose=True), A.T @ xt, rtol=RTOL, atol=0)
+    L0 = a.export_layout(0)
+    occ = L0["occ"].astype(bool)
+    pos = np.nonzero(occ)[0] + 1
+    sem = L0["keys"][occ] == 0
+    assert np.array_equal(pos[sem], L0["semaphores"])
+    a.rebalance_root(0)                      # full 2^25-slot window: layout-idempotent
+    L1 = a.export_layout(0)
+    assert np.array_equal(L0["occ"], L1["occ"]) and np.array_equal(L0["keys"], L1["keys"])
+    assert np.array_equal(L0["semaphores"], L1["semaphores"])
