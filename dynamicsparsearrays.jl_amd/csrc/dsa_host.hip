@@ -575,7 +575,10 @@ void mpcsc_build_dev(Pma& P, const int64_t* d_part, const int64_t* d_key, const 
 // ------------------------------------------------------------------------------------------------
 // handles
 // ------------------------------------------------------------------------------------------------
-struct dsa_vec { Pma P; int64_t n = 0; };
+// Single setindex! calls are write-combined on the host (the "buffered batched writes" of the path): they are queued and
+// applied, in order, by ONE sequencer launch at the latest before the next call that observes the structure.
+constexpr size_t PENDING_FLUSH = 1u << 16;
+struct dsa_vec { Pma P; int64_t n = 0; std::vector<int64_t> pk; std::vector<double> pv; };
 struct dsa_pcsc { Pma P; };
 struct FillBuffer {     // Buffer  src/buffer.jl:1-4 (host staging in the reference too)
     std::unordered_map<int64_t, size_t> index;
@@ -591,6 +594,7 @@ struct dsa_mat {
     bool has_major = false;
     Pma col, row;          // colmajor / rowmajor MappedPackedCSC
     double* d_x = nullptr; double* d_y = nullptr; int64_t x_cap = 0, y_cap = 0;
+    std::vector<int64_t> pi, pj; std::vector<double> pv;      // queued single writes (non-fill mode)
 };
 
 namespace {
@@ -748,13 +752,21 @@ int32_t dsa_vec_create(const int64_t* keys, const double* vals, int64_t n, int32
 int32_t dsa_vec_create_empty(dsa_vec_t** out) { return dsa_vec_create(nullptr, nullptr, 0, DSA_COMBINE_ADD, -1, out); }
 int32_t dsa_vec_destroy(dsa_vec_t* h) { if (h) { pma_destroy(h->P); delete h; } return DSA_OK; }
 
+static void vec_flush(dsa_vec_t* h);
+
 int32_t dsa_vec_get_batch(dsa_vec_t* h, const int64_t* keys, int64_t n, double* out) {
-    API_TRY get_batch(h->P, 0, keys, nullptr, n, out); API_CATCH
+    API_TRY vec_flush(h); get_batch(h->P, 0, keys, nullptr, n, out); API_CATCH
 }
 int32_t dsa_vec_get(dsa_vec_t* h, int64_t key, double* out) { return dsa_vec_get_batch(h, &key, 1, out); }
 
-int32_t dsa_vec_set_batch(dsa_vec_t* h, const int64_t* keys, const double* vals, int64_t n) {
-    API_TRY
+static void vec_apply(dsa_vec_t* h, const int64_t* keys, const double* vals, int64_t n);
+static void vec_flush(dsa_vec_t* h) {
+    if (h->pk.empty()) return;
+    std::vector<int64_t> k; std::vector<double> v;
+    k.swap(h->pk); v.swap(h->pv);                      // the queue is empty even if the apply fails
+    vec_apply(h, k.data(), v.data(), (int64_t)k.size());
+}
+static void vec_apply(dsa_vec_t* h, const int64_t* keys, const double* vals, int64_t n) {
     std::vector<Op> ops((size_t)n);
     for (int64_t i = 0; i < n; ++i) ops[(size_t)i] = make_op(OP_VEC_SET, keys[i], 0, vals[i]);
     int32_t err = 0;
@@ -762,14 +774,27 @@ int32_t dsa_vec_set_batch(dsa_vec_t* h, const int64_t* keys, const double* vals,
     const int64_t upto = err ? std::min(done + 1, n) : done;          // v.n is updated before the write (src/vector.jl:77-79)
     for (int64_t i = 0; i < upto; ++i) if (vals[i] != 0.0) h->n = std::max(h->n, keys[i]);
     if (err) fail(err, err_text(err));
+}
+
+int32_t dsa_vec_set_batch(dsa_vec_t* h, const int64_t* keys, const double* vals, int64_t n) {
+    API_TRY
+    vec_flush(h);
+    vec_apply(h, keys, vals, n);
     API_CATCH
 }
-int32_t dsa_vec_set(dsa_vec_t* h, int64_t key, double val) { return dsa_vec_set_batch(h, &key, &val, 1); }
-int32_t dsa_vec_nnz(dsa_vec_t* h, int64_t* out) { *out = h->P.h_ctl->nb_elements; return DSA_OK; }
+int32_t dsa_vec_set(dsa_vec_t* h, int64_t key, double val) {      // queued; see PENDING_FLUSH
+    API_TRY
+    if (val != 0.0) h->n = std::max(h->n, key);
+    h->pk.push_back(key); h->pv.push_back(val);
+    if (h->pk.size() >= PENDING_FLUSH) vec_flush(h);
+    API_CATCH
+}
+int32_t dsa_vec_nnz(dsa_vec_t* h, int64_t* out) { API_TRY vec_flush(h); *out = h->P.h_ctl->nb_elements; API_CATCH }
 int32_t dsa_vec_len(dsa_vec_t* h, int64_t* out) { *out = h->n; return DSA_OK; }
 
 int32_t dsa_vec_nonzeros(dsa_vec_t* h, int64_t* keys, double* vals, int64_t cap, int64_t* n_out) {
     API_TRY
+    vec_flush(h);
     std::vector<int64_t> ks; std::vector<double> vs;
     read_range(h->P, 1, h->P.capacity(), ks, vs);
     if ((int64_t)ks.size() > cap) fail(DSA_ECAP, "output buffers too small");
@@ -779,6 +804,7 @@ int32_t dsa_vec_nonzeros(dsa_vec_t* h, int64_t* keys, double* vals, int64_t cap,
 }
 int32_t dsa_vec_shrink_size(dsa_vec_t* h) {     // shrink_size!  src/vector.jl:64 (+ _guess_length :7-8)
     API_TRY
+    vec_flush(h);
     std::vector<int64_t> ks; std::vector<double> vs;
     read_range(h->P, 1, h->P.capacity(), ks, vs);
     int64_t n = 0;
@@ -786,12 +812,13 @@ int32_t dsa_vec_shrink_size(dsa_vec_t* h) {     // shrink_size!  src/vector.jl:6
     h->n = n;
     API_CATCH
 }
-int32_t dsa_vec_info(dsa_vec_t* h, int64_t* info) { pma_info(h->P, h->n, info); return DSA_OK; }
+int32_t dsa_vec_info(dsa_vec_t* h, int64_t* info) { API_TRY vec_flush(h); pma_info(h->P, h->n, info); API_CATCH }
 int32_t dsa_vec_export_layout(dsa_vec_t* h, int64_t* keys, double* vals, uint8_t* occ, int64_t cap) {
-    API_TRY export_slots(h->P, keys, vals, occ, cap); API_CATCH
+    API_TRY vec_flush(h); export_slots(h->P, keys, vals, occ, cap); API_CATCH
 }
 int32_t dsa_vec_rebalance_root(dsa_vec_t* h) {
     API_TRY
+    vec_flush(h);
     Pma& P = h->P;
     if (P.capacity() != P.h_ctl->segment_capacity) {
         P.h_ctl->stat_rebalances += 1; P.h_ctl->stat_window_slots += P.capacity();
@@ -801,12 +828,13 @@ int32_t dsa_vec_rebalance_root(dsa_vec_t* h) {
 }
 int32_t dsa_vec_set_stream(dsa_vec_t* h, void* s) {
     API_TRY
+    vec_flush(h);
     HIPCHK(hipStreamSynchronize(h->P.stream));
     if (h->P.own_stream) hipStreamDestroy(h->P.stream);
     h->P.stream = (hipStream_t)s; h->P.own_stream = false;
     API_CATCH
 }
-int32_t dsa_vec_sync(dsa_vec_t* h) { API_TRY HIPCHK(hipStreamSynchronize(h->P.stream)); API_CATCH }
+int32_t dsa_vec_sync(dsa_vec_t* h) { API_TRY vec_flush(h); HIPCHK(hipStreamSynchronize(h->P.stream)); API_CATCH }
 
 // ---------------- PackedCSC ----------------
 int32_t dsa_pcsc_create(const int64_t* colptr, int64_t nparts, const int64_t* row_keys, const double* vals,
@@ -923,9 +951,33 @@ static void fill_addelem(FillBuffer& b, int64_t row, int64_t col, double val) { 
     b.length += 1;
 }
 
+static void mat_flush(dsa_mat_t* h) {
+    if (h->pi.empty()) return;
+    std::vector<int64_t> i, j; std::vector<double> v;
+    i.swap(h->pi); j.swap(h->pj); v.swap(h->pv);       // the queue is empty even if the apply fails
+    mat_apply_sets(h, i.data(), j.data(), v.data(), (int64_t)i.size());
+}
+
+int32_t dsa_mat_set(dsa_mat_t* h, double val, int64_t row, int64_t col) {
+    API_TRY
+    check_key(row); check_key(col);
+    if (val != 0.0) { h->m = std::max(h->m, row); h->n = std::max(h->n, col); }      // src/matrix.jl:44-47
+    if (h->fillmode) {
+        fill_addelem(h->buf, row, col, val);
+    } else {
+        h->pi.push_back(row); h->pj.push_back(col); h->pv.push_back(val);
+        // with tombstones a write can hit the reference's assert / bounds paths: apply it now so the error surfaces here
+        const bool tombstones = h->col.h_ctl->nb_partitions != h->col.h_ctl->table_len ||
+                                h->row.h_ctl->nb_partitions != h->row.h_ctl->table_len;
+        if (tombstones || h->pi.size() >= PENDING_FLUSH) mat_flush(h);
+    }
+    API_CATCH
+}
+
 int32_t dsa_mat_set_batch(dsa_mat_t* h, const int64_t* I, const int64_t* J, const double* V, int64_t n) {
     API_TRY
     for (int64_t k = 0; k < n; ++k) { check_key(I[k]); check_key(J[k]); }
+    mat_flush(h);
     if (h->fillmode) {
         for (int64_t k = 0; k < n; ++k) {
             if (V[k] != 0.0) { h->m = std::max(h->m, I[k]); h->n = std::max(h->n, J[k]); }
@@ -936,10 +988,10 @@ int32_t dsa_mat_set_batch(dsa_mat_t* h, const int64_t* I, const int64_t* J, cons
     }
     API_CATCH
 }
-int32_t dsa_mat_set(dsa_mat_t* h, double val, int64_t row, int64_t col) { return dsa_mat_set_batch(h, &row, &col, &val, 1); }
 
 int32_t dsa_mat_get_batch(dsa_mat_t* h, const int64_t* I, const int64_t* J, int64_t n, double* out) {
     API_TRY
+    mat_flush(h);
     if (h->fillmode) fail(DSA_EMODE, "getindex(row, col) is not available in fill mode.");
     get_batch(h->col, 2, I, J, n, out);
     API_CATCH
@@ -948,6 +1000,7 @@ int32_t dsa_mat_get(dsa_mat_t* h, int64_t row, int64_t col, double* out) { retur
 
 int32_t dsa_mat_addrow(dsa_mat_t* h, int64_t row, const int64_t* colids, const double* vals, int64_t n) {
     API_TRY
+    mat_flush(h);
     check_key(row);
     for (int64_t k = 0; k < n; ++k) check_key(colids[k]);
     if (h->fillmode) {     // addrow!(buffer, ...)  src/buffer.jl:10-18
@@ -970,6 +1023,7 @@ int32_t dsa_mat_addrow(dsa_mat_t* h, int64_t row, const int64_t* colids, const d
 
 int32_t dsa_mat_closefillmode(dsa_mat_t* h) {     // closefillmode!  src/matrix.jl:126-134
     API_TRY
+    mat_flush(h);
     if (!h->fillmode) fail(DSA_EMODE, "Cannot close fill mode because matrix is not in fill mode.");
     std::vector<int64_t> I, J; std::vector<double> V;     // get_rowids_colids_vals  src/buffer.jl:33-50
     I.reserve((size_t)h->buf.length); J.reserve((size_t)h->buf.length); V.reserve((size_t)h->buf.length);
@@ -985,6 +1039,7 @@ int32_t dsa_mat_closefillmode(dsa_mat_t* h) {     // closefillmode!  src/matrix.
 
 int32_t dsa_mat_deletecolumn(dsa_mat_t* h, int64_t col) {      // src/matrix.jl:95-102
     API_TRY
+    mat_flush(h);
     if (h->fillmode) fail(DSA_EMODE, "Cannot delete a column in fill mode");
     std::vector<int64_t> rows; std::vector<double> vals;
     col_view_of(h->col, col, rows, vals);
@@ -1000,6 +1055,7 @@ int32_t dsa_mat_deletecolumn(dsa_mat_t* h, int64_t col) {      // src/matrix.jl:
 }
 int32_t dsa_mat_deleterow(dsa_mat_t* h, int64_t row) {         // src/matrix.jl:104-111
     API_TRY
+    mat_flush(h);
     if (h->fillmode) fail(DSA_EMODE, "Cannot delete a row in fill mode");
     std::vector<int64_t> cols; std::vector<double> vals;
     col_view_of(h->row, row, cols, vals);
@@ -1018,6 +1074,7 @@ static void _check_status(int32_t rc) { if (rc != DSA_OK) fail(rc, g_err); }
 
 static int32_t view_impl(dsa_mat_t* h, int32_t o, int64_t key, int64_t* ks, double* vs, int64_t cap, int64_t* n_out) {
     API_TRY
+    mat_flush(h);
     if (h->fillmode) fail(DSA_EMODE, "View not available in fill mode.");
     std::vector<int64_t> k; std::vector<double> v;
     col_view_of(orient(h, o), key, k, v);
@@ -1036,6 +1093,7 @@ int32_t dsa_mat_row_view(dsa_mat_t* h, int64_t row, int64_t* cols, double* vals,
 // partition `row` holds exactly the (col, value) pairs the reference collects by scanning the colmajor array)
 static int32_t slice_impl(dsa_mat_t* h, int32_t o, int64_t key, dsa_vec_t** out) {
     API_TRY
+    mat_flush(h);
     if (h->fillmode) fail(DSA_EMODE, "slices are not available in fill mode");
     std::vector<int64_t> k; std::vector<double> v;
     col_view_of(orient(h, o), key, k, v);
@@ -1048,14 +1106,15 @@ int32_t dsa_mat_col_slice(dsa_mat_t* h, int64_t col, dsa_vec_t** out) { return s
 int32_t dsa_mat_row_slice(dsa_mat_t* h, int64_t row, dsa_vec_t** out) { return slice_impl(h, DSA_ROWMAJOR, row, out); }
 
 int32_t dsa_mat_nnz(dsa_mat_t* h, int64_t* out) {      // nnz(m) = nnz(m.rowmajor)  src/matrix.jl:91
-    API_TRY Pma& P = orient(h, DSA_ROWMAJOR); *out = P.h_ctl->nb_elements - P.h_ctl->nb_partitions; API_CATCH
+    API_TRY mat_flush(h); Pma& P = orient(h, DSA_ROWMAJOR); *out = P.h_ctl->nb_elements - P.h_ctl->nb_partitions; API_CATCH
 }
 int32_t dsa_mat_size(dsa_mat_t* h, int64_t* m, int64_t* n) { *m = h->m; *n = h->n; return DSA_OK; }
-int32_t dsa_mat_nbpartitions(dsa_mat_t* h, int32_t o, int64_t* out) { API_TRY *out = orient(h, o).h_ctl->nb_partitions; API_CATCH }
-int32_t dsa_mat_info(dsa_mat_t* h, int32_t o, int64_t* info) { API_TRY Pma& P = orient(h, o); pma_info(P, P.h_ctl->nb_partitions, info); API_CATCH }
+int32_t dsa_mat_nbpartitions(dsa_mat_t* h, int32_t o, int64_t* out) { API_TRY mat_flush(h); *out = orient(h, o).h_ctl->nb_partitions; API_CATCH }
+int32_t dsa_mat_info(dsa_mat_t* h, int32_t o, int64_t* info) { API_TRY mat_flush(h); Pma& P = orient(h, o); pma_info(P, P.h_ctl->nb_partitions, info); API_CATCH }
 int32_t dsa_mat_export_layout(dsa_mat_t* h, int32_t o, int64_t* keys, double* vals, uint8_t* occ, int64_t cap,
                               int64_t* semaphores, int64_t* col_keys, uint8_t* col_live, int64_t table_cap) {
     API_TRY
+    mat_flush(h);
     Pma& P = orient(h, o);
     export_slots(P, keys, vals, occ, cap);
     export_tables(P, semaphores, col_keys, col_live, table_cap);
@@ -1063,6 +1122,7 @@ int32_t dsa_mat_export_layout(dsa_mat_t* h, int32_t o, int64_t* keys, double* va
 }
 int32_t dsa_mat_rebalance_root(dsa_mat_t* h, int32_t o) {
     API_TRY
+    mat_flush(h);
     Pma& P = orient(h, o);
     if (P.capacity() != P.h_ctl->segment_capacity) {
         P.h_ctl->stat_rebalances += 1; P.h_ctl->stat_window_slots += P.capacity();
@@ -1073,6 +1133,7 @@ int32_t dsa_mat_rebalance_root(dsa_mat_t* h, int32_t o) {
 
 int32_t dsa_mat_spmv_dense_dev(dsa_mat_t* h, int32_t transpose, int32_t algo, const double* d_x, int64_t nx, double* d_y, int64_t ny) {
     API_TRY
+    mat_flush(h);
     Pma& P = transpose ? h->col : h->row;
     spmv_dev(h, transpose, algo, d_x, nx, d_y, ny, P.stream);
     API_CATCH
@@ -1080,6 +1141,7 @@ int32_t dsa_mat_spmv_dense_dev(dsa_mat_t* h, int32_t transpose, int32_t algo, co
 
 int32_t dsa_mat_spmv_dense(dsa_mat_t* h, int32_t transpose, const double* x, int64_t nx, double* y, int64_t ny) {
     API_TRY
+    mat_flush(h);
     if (!h->has_major) fail(DSA_EMODE, "matrix is in fill mode");
     if (nx < 0 || ny < 0) fail(DSA_EARG, "negative length");
     ensure_xy(h, nx, ny);
@@ -1099,6 +1161,7 @@ int32_t dsa_mat_spmv_dense(dsa_mat_t* h, int32_t transpose, const double* x, int
 int32_t dsa_mat_spmv_sparse(dsa_mat_t* h, int32_t transpose, const int64_t* xi, const double* xv, int64_t nx,
                             int64_t* yi, double* yv, int64_t cap, int64_t* n_out) {
     API_TRY
+    mat_flush(h);
     if (!h->has_major) fail(DSA_EMODE, "matrix is in fill mode");
     const int64_t ny = transpose ? h->n : h->m;
     const int64_t ncols = transpose ? h->m : h->n;
@@ -1159,6 +1222,7 @@ int32_t dsa_mat_spmv_sparse(dsa_mat_t* h, int32_t transpose, const int64_t* xi, 
 
 int32_t dsa_mat_set_stream(dsa_mat_t* h, void* s) {
     API_TRY
+    mat_flush(h);
     if (!h->has_major) fail(DSA_EMODE, "matrix is in fill mode");
     for (Pma* P : {&h->col, &h->row}) {
         HIPCHK(hipStreamSynchronize(P->stream));
@@ -1169,6 +1233,7 @@ int32_t dsa_mat_set_stream(dsa_mat_t* h, void* s) {
 }
 int32_t dsa_mat_sync(dsa_mat_t* h) {
     API_TRY
+    mat_flush(h);
     if (h->has_major) { HIPCHK(hipStreamSynchronize(h->col.stream)); HIPCHK(hipStreamSynchronize(h->row.stream)); }
     API_CATCH
 }

@@ -80,7 +80,9 @@ int32_t dsa_vec_destroy(dsa_vec_t* h);
 /* getindex(v, key)  src/vector.jl:73 -> src/pma.jl:189-193 */
 int32_t dsa_vec_get(dsa_vec_t* h, int64_t key, double* out);
 int32_t dsa_vec_get_batch(dsa_vec_t* h, const int64_t* keys, int64_t n, double* out);
-/* setindex!(v, value, key)  src/vector.jl:76-81 -> src/pma.jl:196-213 */
+/* setindex!(v, value, key)  src/vector.jl:76-81 -> src/pma.jl:196-213.  WRITE-COMBINED: the call queues the write on the
+ * host; queued writes are applied in order by one device sequencer launch at the latest before the next call that observes
+ * the vector (get, nnz, info, iteration, export, ...) or when 65536 are pending.  length(v) is updated immediately. */
 int32_t dsa_vec_set(dsa_vec_t* h, int64_t key, double val);
 /* n sequential setindex! calls, applied in order (sequential-equivalent batch) */
 int32_t dsa_vec_set_batch(dsa_vec_t* h, const int64_t* keys, const double* vals, int64_t n);
@@ -122,7 +124,9 @@ int32_t dsa_mat_create_from_coo(const int64_t* I, const int64_t* J, const double
 /* dynamicsparse(K, L, T; fill_mode)  src/matrix.jl:31-41 */
 int32_t dsa_mat_create_empty(int32_t fill_mode, dsa_mat_t** out);
 int32_t dsa_mat_destroy(dsa_mat_t* h);
-/* setindex!(m, val, row, col)  src/matrix.jl:43-62 (fill mode: addelem! src/buffer.jl:20-31) */
+/* setindex!(m, val, row, col)  src/matrix.jl:43-62 (fill mode: addelem! src/buffer.jl:20-31).  WRITE-COMBINED like
+ * dsa_vec_set (size(m) is updated immediately); when the matrix holds deleted columns/rows — the only state in which a write
+ * can fail in the reference — the write is applied before the call returns so the error surfaces here. */
 int32_t dsa_mat_set(dsa_mat_t* h, double val, int64_t row, int64_t col);
 /* n sequential setindex! calls in order */
 int32_t dsa_mat_set_batch(dsa_mat_t* h, const int64_t* I, const int64_t* J, const double* V, int64_t n);

@@ -566,3 +566,33 @@ def test_c4_shard_scale_build_spmv_and_root_rebalance(dsa, hip):
     L1 = a.export_layout(0)
     assert np.array_equal(L0["occ"], L1["occ"]) and np.array_equal(L0["keys"], L1["keys"])
     assert np.array_equal(L0["semaphores"], L1["semaphores"])
+
+
+def test_write_combined_single_sets_match_oracle(dsa, hip, oracle):
+    """dsa_vec_set / dsa_mat_set queue their writes and flush them in order (65536 pending, or the next observing
+    call): 70k single-op calls must leave exactly the layout of 70k sequential setindex! calls."""
+    g = SplitMix64(123)
+    ks = [1 + g.next() % 200000 for _ in range(70000)]
+    vs = [0.0 if g.next() % 5 == 0 else g.unit12() for _ in ks]
+    a = dsa.dynamicsparsevec([], [], binding=hip)
+    b = dsa.dynamicsparsevec([], [], binding=oracle)
+    for k, v in zip(ks, vs):
+        a[k] = v
+    b.set_batch(ks, vs)
+    assert len(a) == len(b)                      # length is updated eagerly
+    assert_vec_equal(a, b)
+    I, J, V = rand_matrix_ops(55, 300, 400, 8000)
+    ma = dsa.dynamicsparse(fill_mode=False, binding=hip)
+    mb = dsa.dynamicsparse(fill_mode=False, binding=oracle)
+    for i, j, v in zip(I, J, V):
+        ma[i, j] = v
+    mb.set_batch(I, J, V)
+    assert ma.size() == mb.size()
+    assert ma[I[0], J[0]] == mb[I[0], J[0]]      # a read in the middle forces the flush
+    assert_mat_equal(ma, mb)
+    ma.deletecolumn(J[1]); mb.deletecolumn(J[1])  # tombstones: later single writes apply eagerly
+    for i, j, v in zip(I[:500], J[:500], V[:500]):
+        if j != J[1]:
+            ma[i, j + 1000] = v
+            mb[i, j + 1000] = v
+    assert_mat_equal(ma, mb)
