@@ -164,8 +164,14 @@ __global__ __launch_bounds__(SP_BLOCK) void k_spmv(const int64_t* __restrict__ k
                 const int e = atomicAdd(&sNLong, 1);
                 sLong[e] = LongSeg{a + 1, end, row, is_last};
             } else if (row >= 1 && row <= ny) {
+                // left-to-right sum of the segment (the reference's accumulation order); four LDS reads in flight
                 double sum = 0.0;
-                for (int s = a + 1; s < end; ++s) sum = sum + sP[s];
+                int s = a + 1;
+                for (; s + 3 < end; s += 4) {
+                    const double t0 = sP[s], t1 = sP[s + 1], t2 = sP[s + 2], t3 = sP[s + 3];
+                    sum = sum + t0; sum = sum + t1; sum = sum + t2; sum = sum + t3;
+                }
+                for (; s < end; ++s) sum = sum + sP[s];
                 if (is_last) atomicAdd(&y[row - 1], sum);    // the row may continue in the next tile
                 else y[row - 1] = sum;
             }
