@@ -36,18 +36,22 @@ __global__ void k_flags(const int64_t* __restrict__ part, const int64_t* __restr
                         uint32_t* __restrict__ fcell, int64_t n) {
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const bool np = (i == 0) || part[i] != part[i - 1];
+    // part == nullptr: a plain vector (one implicit partition, no semaphore cells)
+    const bool np = part == nullptr ? (i == 0) : ((i == 0) || part[i] != part[i - 1]);
     fpart[i] = np ? 1u : 0u;
     fcell[i] = (np || key[i] != key[i - 1]) ? 1u : 0u;
 }
 __global__ void k_emit(const int64_t* __restrict__ part, const int64_t* __restrict__ key, const uint32_t* __restrict__ idx,
                        const double* __restrict__ val, const uint32_t* __restrict__ fpart, const uint32_t* __restrict__ fcell,
                        const uint32_t* __restrict__ spart, const uint32_t* __restrict__ scell, int64_t n, int32_t combine,
-                       int64_t* __restrict__ out_keys, double* __restrict__ out_vals, int64_t* __restrict__ part_keys) {
+                       int64_t* __restrict__ out_keys, double* __restrict__ out_vals, int64_t* __restrict__ part_keys,
+                       int mode) {
+    // mode 0: mapped partitions (ids = rank of the distinct partition keys, semaphore emitted by the first cell)
+    // mode 1: plain vector (no semaphores)   mode 2: explicit partition ids 1..P in `part` (semaphores by k_emit_sems)
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (i >= n) return;
     if (!fcell[i]) return;
-    const int64_t pid = spart[i];            // 1-based partition id
+    const int64_t pid = mode == 0 ? (int64_t)spart[i] : (mode == 1 ? 0 : part[i]);   // semaphore cells in front of this cell
     const int64_t rank = scell[i];           // 1-based rank among the distinct cells
     double acc = val[idx[i]];
     for (int64_t j = i + 1; j < n && !fcell[j]; ++j) {     // left fold of the duplicates, input order
@@ -57,11 +61,28 @@ __global__ void k_emit(const int64_t* __restrict__ part, const int64_t* __restri
     const int64_t pos = rank - 1 + pid;
     out_keys[pos] = key[i];
     out_vals[pos] = acc;
-    if (fpart[i]) {
+    if (mode == 0 && fpart[i]) {
         out_keys[pos - 1] = SEM_KEY;
         out_vals[pos - 1] = (double)pid;
         part_keys[pid - 1] = part[i];
     }
+}
+
+// mode 2: semaphore cell of every partition p = 1..P (empty partitions included, src/pcsr.jl:36-41):
+// position = (#distinct cells of partitions < p) + p - 1
+__global__ void k_emit_sems(const int64_t* __restrict__ part_sorted, const uint32_t* __restrict__ scell, int64_t n, int64_t nparts,
+                            int64_t* __restrict__ out_keys, double* __restrict__ out_vals) {
+    const int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x + 1;
+    if (p > nparts) return;
+    int64_t lo = 0, hi = n;                     // first index with part >= p
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (part_sorted[mid] < p) lo = mid + 1; else hi = mid;
+    }
+    const int64_t cells_before = lo == 0 ? 0 : (int64_t)scell[lo - 1];
+    const int64_t pos = cells_before + p - 1;
+    out_keys[pos] = SEM_KEY;
+    out_vals[pos] = (double)p;
 }
 
 static void free_scratch(BuildScratch& s) {
@@ -91,11 +112,17 @@ hipError_t build_prepare(const int64_t* d_part, const int64_t* d_key, int64_t nn
     hipLaunchKernelGGL(k_iota, dim3(blocks), dim3(256), 0, stream, s.idx0, nnz);
     size_t tb = s.temp_bytes;
     BCHK(rocprim::radix_sort_pairs(s.temp, tb, d_key, s.k1, s.idx0, s.idx1, n, 0, 64, stream));           // by key
-    hipLaunchKernelGGL(k_gather_i64, dim3(blocks), dim3(256), 0, stream, d_part, s.idx1, s.p1, nnz);
-    tb = s.temp_bytes;
-    BCHK(rocprim::radix_sort_pairs(s.temp, tb, s.p1, s.p2, s.idx1, s.idx2, n, 0, 64, stream));           // then by partition (stable)
-    hipLaunchKernelGGL(k_gather_i64, dim3(blocks), dim3(256), 0, stream, d_key, s.idx2, s.k2, nnz);
-    hipLaunchKernelGGL(k_flags, dim3(blocks), dim3(256), 0, stream, s.p2, s.k2, s.fpart, s.fcell, nnz);
+    if (d_part != nullptr) {
+        hipLaunchKernelGGL(k_gather_i64, dim3(blocks), dim3(256), 0, stream, d_part, s.idx1, s.p1, nnz);
+        tb = s.temp_bytes;
+        BCHK(rocprim::radix_sort_pairs(s.temp, tb, s.p1, s.p2, s.idx1, s.idx2, n, 0, 64, stream));       // then by partition (stable)
+        hipLaunchKernelGGL(k_gather_i64, dim3(blocks), dim3(256), 0, stream, d_key, s.idx2, s.k2, nnz);
+        hipLaunchKernelGGL(k_flags, dim3(blocks), dim3(256), 0, stream, s.p2, s.k2, s.fpart, s.fcell, nnz);
+    } else {                                                                                               // vector: keys only
+        BCHK(hipMemcpyAsync(s.idx2, s.idx1, n * 4, hipMemcpyDeviceToDevice, stream));
+        BCHK(hipMemcpyAsync(s.k2, s.k1, n * 8, hipMemcpyDeviceToDevice, stream));
+        hipLaunchKernelGGL(k_flags, dim3(blocks), dim3(256), 0, stream, (const int64_t*)nullptr, s.k2, s.fpart, s.fcell, nnz);
+    }
     tb = s.temp_bytes;
     BCHK(rocprim::inclusive_scan(s.temp, tb, s.fpart, s.spart, n, rocprim::plus<uint32_t>(), stream));
     tb = s.temp_bytes;
@@ -109,10 +136,13 @@ hipError_t build_prepare(const int64_t* d_part, const int64_t* d_key, int64_t nn
 }
 
 hipError_t build_emit(const double* d_val, int32_t combine, BuildScratch& s, int64_t* out_keys, double* out_vals,
-                      int64_t* part_keys, hipStream_t stream) {
+                      int64_t* part_keys, int mode, int64_t nparts_explicit, hipStream_t stream) {
     const unsigned blocks = (unsigned)((s.n + 255) / 256);
-    hipLaunchKernelGGL(k_emit, dim3(blocks), dim3(256), 0, stream, s.p2, s.k2, s.idx2, d_val, s.fpart, s.fcell, s.spart, s.scell,
-                       s.n, combine, out_keys, out_vals, part_keys);
+    hipLaunchKernelGGL(k_emit, dim3(blocks), dim3(256), 0, stream, mode == 1 ? (const int64_t*)nullptr : s.p2, s.k2, s.idx2, d_val,
+                       s.fpart, s.fcell, s.spart, s.scell, s.n, combine, out_keys, out_vals, part_keys, mode);
+    if (mode == 2 && nparts_explicit > 0)
+        hipLaunchKernelGGL(k_emit_sems, dim3((unsigned)((nparts_explicit + 255) / 256)), dim3(256), 0, stream, s.p2, s.scell, s.n,
+                           nparts_explicit, out_keys, out_vals);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(stream);
     free_scratch(s);

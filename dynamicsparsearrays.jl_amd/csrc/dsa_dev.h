@@ -176,8 +176,10 @@ struct BuildScratch {
 hipError_t build_prepare(const int64_t* d_part, const int64_t* d_key, int64_t nnz, BuildScratch& s, int64_t counts[2],
                          hipStream_t stream);
 // phase 2: emit the ordered cell stream [sem(0,id), entries...] (counts[0]+counts[1] cells) and the partition keys
+// mode 0: mapped partitions (semaphores + partition keys) ; 1: plain vector (d_part was nullptr) ; 2: explicit partition
+// ids 1..nparts_explicit in d_part (PackedCSC: empty partitions keep their semaphore)
 hipError_t build_emit(const double* d_val, int32_t combine, BuildScratch& s, int64_t* out_keys, double* out_vals,
-                      int64_t* part_keys, hipStream_t stream);
+                      int64_t* part_keys, int mode, int64_t nparts_explicit, hipStream_t stream);
 void build_abort(BuildScratch& s);
 
 hipError_t launch_sequencer(int64_t* keys, double* vals, uint64_t* occ, int64_t* sems, int64_t* col_keys,

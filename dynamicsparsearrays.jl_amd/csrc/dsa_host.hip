@@ -486,88 +486,68 @@ void read_range(Pma& P, int64_t from, int64_t to, std::vector<int64_t>& ks, std:
 }
 
 // ------------------------------------------------------------------------------------------------
-// host-side preparation of the bulk builders
+// bulk builders (K-build): everything but the staging of the caller's arrays runs on the device
 // ------------------------------------------------------------------------------------------------
-double combine_apply(int32_t op, double a, double b) {
-    switch (op) {
-        case DSA_COMBINE_ADD: return a + b;
-        case DSA_COMBINE_MUL: return a * b;
-        default: return b;
-    }
-}
-
-// _prepare_keys_vals!  src/vector.jl:10-36 : stable sort by key, left fold of duplicates
-void prepare_keys_vals(std::vector<int64_t>& keys, std::vector<double>& vals, int32_t combine) {
-    const size_t n = keys.size();
-    if (n == 0) return;
-    std::vector<uint32_t> perm(n);
-    std::iota(perm.begin(), perm.end(), 0u);
-    std::stable_sort(perm.begin(), perm.end(), [&](uint32_t a, uint32_t b) { return keys[a] < keys[b]; });
-    std::vector<int64_t> k2; std::vector<double> v2;
-    k2.reserve(n); v2.reserve(n);
-    for (size_t i = 0; i < n; ++i) {
-        const int64_t k = keys[perm[i]]; const double v = vals[perm[i]];
-        if (!k2.empty() && k2.back() == k) v2.back() = combine_apply(combine, v2.back(), v);
-        else { k2.push_back(k); v2.push_back(v); }
-    }
-    keys.swap(k2); vals.swap(v2);
-}
-
-// _dynamicsparse  src/pcsr.jl:354-431 + PackedCSC ctor :26-63 : (part, key, val) triples -> the ordered
-// cell stream [sem(0,id), entries...] per partition, and the partition keys.  The reference's QuickSort
-// is unstable; duplicates are folded here in input order (one of its legal outcomes).
-void build_cell_stream(const int64_t* part, const int64_t* key, const double* val, int64_t nnz, int32_t combine,
-                       std::vector<int64_t>& ck, std::vector<int64_t>& out_keys, std::vector<double>& out_vals) {
-    struct T { int64_t p, k; uint32_t i; };
-    std::vector<T> t((size_t)nnz);
-    for (int64_t i = 0; i < nnz; ++i) t[(size_t)i] = T{part[i], key[i], (uint32_t)i};
-    std::sort(t.begin(), t.end(), [](const T& a, const T& b) {
-        if (a.p != b.p) return a.p < b.p;
-        if (a.k != b.k) return a.k < b.k;
-        return a.i < b.i;
-    });
-    ck.clear(); out_keys.clear(); out_vals.clear();
-    out_keys.reserve((size_t)nnz + (size_t)nnz / 4 + 16); out_vals.reserve((size_t)nnz + (size_t)nnz / 4 + 16);
-    for (size_t j = 0; j < t.size(); ++j) {
-        const bool new_part = (j == 0 || t[j].p != t[j - 1].p);
-        if (new_part) {
-            ck.push_back(t[j].p);
-            out_keys.push_back(SEM_KEY);
-            out_vals.push_back((double)ck.size());
-        }
-        if (!new_part && t[j].k == t[j - 1].k) out_vals.back() = combine_apply(combine, out_vals.back(), val[t[j].i]);
-        else { out_keys.push_back(t[j].k); out_vals.push_back(val[t[j].i]); }
-    }
-}
-
-// K-build of one orientation from device-resident triples: sort / combine / emit on the device (build.hip), then the
-// full-array spread; semaphores[] positions are written by the spread kernel.
-void mpcsc_build_dev(Pma& P, const int64_t* d_part, const int64_t* d_key, const double* d_val, int64_t nnz, int32_t combine) {
+// K-build from device-resident triples: sort / combine / emit on the device (build.hip), then the full-array spread;
+// semaphores[] positions are written by the spread kernel.
+//   mode 0: one orientation of a matrix (MappedPackedCSC: partitions = distinct values of d_part)
+//   mode 1: a vector (d_part == nullptr, no semaphores)         dynamicsparsevec  src/vector.jl:38-62
+//   mode 2: PackedCSC with explicit partition ids 1..nparts      PackedCSC ctor    src/pcsr.jl:26-63
+void pma_build_dev(Pma& P, const int64_t* d_part, const int64_t* d_key, const double* d_val, int64_t nnz, int32_t combine,
+                   int mode, int64_t nparts_explicit) {
     if (nnz == 0) {
-        P.h_ctl->nb_partitions = 0; P.h_ctl->table_len = 0;
-        ensure_tables(P, 64);
-        build_from_packed(P, {}, {});
+        std::vector<int64_t> ks; std::vector<double> vs;
+        const int64_t np = mode == 2 ? nparts_explicit : 0;
+        for (int64_t p = 1; p <= np; ++p) { ks.push_back(SEM_KEY); vs.push_back((double)p); }    // only semaphore cells
+        if (P.has_sems) { P.h_ctl->nb_partitions = np; P.h_ctl->table_len = np; ensure_tables(P, std::max<int64_t>(2 * np, 64)); }
+        build_from_packed(P, ks, vs);
         return;
     }
     BuildScratch sc;
     int64_t counts[2] = {0, 0};
     hipError_t e = build_prepare(d_part, d_key, nnz, sc, counts, P.stream);
     if (e != hipSuccess) fail(DSA_EHIP, std::string("K-build prepare: ") + hipGetErrorString(e));
-    const int64_t np = counts[1], n = counts[0] + counts[1];
+    const int64_t np = mode == 0 ? counts[1] : (mode == 2 ? nparts_explicit : 0);
+    const int64_t n = counts[0] + np;
     try {
-        P.h_ctl->nb_partitions = np; P.h_ctl->table_len = np;
-        ensure_tables(P, std::max<int64_t>(2 * np, 64));
+        if (P.has_sems) {
+            P.h_ctl->nb_partitions = np; P.h_ctl->table_len = np;
+            ensure_tables(P, std::max<int64_t>(2 * np, 64));
+        }
         const int64_t capacity = capacity_for(n);
         set_geometry_for_new(P, capacity, n);
         ensure_capacity_alloc(P, 2 * capacity);
-        HIPCHK(hipMemsetAsync(P.col_live, 1, (size_t)np, P.stream));
+        if (P.has_cols && np > 0) HIPCHK(hipMemsetAsync(P.col_live, 1, (size_t)np, P.stream));
     } catch (...) { build_abort(sc); throw; }
-    e = build_emit(d_val, combine, sc, P.K(), P.V(), P.col_keys, P.stream);
+    e = build_emit(d_val, combine, sc, P.K(), P.V(), P.has_cols ? P.col_keys : nullptr, mode, nparts_explicit, P.stream);
     if (e != hipSuccess) fail(DSA_EHIP, std::string("K-build emit: ") + hipGetErrorString(e));
     P.h_ctl->stat_rebalances = 0; P.h_ctl->stat_window_slots = 0;
     if (P.capacity() != P.h_ctl->segment_capacity) { P.h_ctl->stat_rebalances = 1; P.h_ctl->stat_window_slots = P.capacity(); }
     root_rebalance(P, n, P.capacity(), n, true);
     upload_ctl(P);
+}
+
+// uploads host arrays (any of them may be nullptr) and runs the device builder
+void pma_build_from_host(Pma& P, const int64_t* part, const int64_t* key, const double* val, int64_t nnz, int32_t combine,
+                         int mode, int64_t nparts_explicit) {
+    int64_t *dP = nullptr, *dK = nullptr; double* dV = nullptr;
+    try {
+        if (nnz > 0) {
+            if (part) { HIPCHK(hipMalloc(&dP, (size_t)nnz * 8)); HIPCHK(hipMemcpyAsync(dP, part, (size_t)nnz * 8, hipMemcpyHostToDevice, P.stream)); }
+            HIPCHK(hipMalloc(&dK, (size_t)nnz * 8)); HIPCHK(hipMemcpyAsync(dK, key, (size_t)nnz * 8, hipMemcpyHostToDevice, P.stream));
+            HIPCHK(hipMalloc(&dV, (size_t)nnz * 8)); HIPCHK(hipMemcpyAsync(dV, val, (size_t)nnz * 8, hipMemcpyHostToDevice, P.stream));
+            HIPCHK(hipStreamSynchronize(P.stream));
+        }
+        pma_build_dev(P, dP, dK, dV, nnz, combine, mode, nparts_explicit);
+    } catch (...) {
+        if (dP) hipFree(dP);
+        if (dK) hipFree(dK);
+        if (dV) hipFree(dV);
+        throw;
+    }
+    if (dP) hipFree(dP);
+    if (dK) hipFree(dK);
+    if (dV) hipFree(dV);
 }
 
 }  // namespace
@@ -614,8 +594,8 @@ void mat_build_major(dsa_mat* h, const int64_t* I, const int64_t* J, const doubl
             HIPCHK(hipMemcpyAsync(dV, V, (size_t)nnz * sizeof(double), hipMemcpyHostToDevice, s));
             HIPCHK(hipStreamSynchronize(s));
         }
-        mpcsc_build_dev(h->col, dJ, dI, dV, nnz, DSA_COMBINE_ADD);      // dynamicsparsecolmajor(I, J, V): partitions = columns
-        mpcsc_build_dev(h->row, dI, dJ, dV, nnz, DSA_COMBINE_ADD);      // dynamicsparsecolmajor(J, I, V): partitions = rows
+        pma_build_dev(h->col, dJ, dI, dV, nnz, DSA_COMBINE_ADD, 0, 0);      // dynamicsparsecolmajor(I, J, V): partitions = columns
+        pma_build_dev(h->row, dI, dJ, dV, nnz, DSA_COMBINE_ADD, 0, 0);      // dynamicsparsecolmajor(J, I, V): partitions = rows
     } catch (...) {
         if (dI) hipFree(dI);
         if (dJ) hipFree(dJ);
@@ -737,13 +717,13 @@ int32_t dsa_set_device(int32_t device) {
 int32_t dsa_vec_create(const int64_t* keys, const double* vals, int64_t n, int32_t combine_op, int64_t len, dsa_vec_t** out) {
     API_TRY
     if (n < 0) fail(DSA_EARG, "negative length");
-    std::vector<int64_t> k(keys, keys + n); std::vector<double> v(vals, vals + n);
-    if (len < 0) { len = 0; for (int64_t x : k) len = std::max(len, x); }      // _guess_length  src/vector.jl:6
-    prepare_keys_vals(k, v, combine_op);
+    if (len < 0) { len = 0; for (int64_t i = 0; i < n; ++i) len = std::max(len, keys[i]); }      // _guess_length  src/vector.jl:6
+    if (n > 0xffffffffll) fail(DSA_EARG, "more than 2^32-1 entries in one call");
     auto* h = new dsa_vec();
     try {
         pma_init_common(h->P, false, false);
-        build_from_packed(h->P, k, v);
+        // _prepare_keys_vals! (stable sort + left fold of duplicates, src/vector.jl:10-36) and the spread, on the device
+        pma_build_from_host(h->P, nullptr, keys, vals, n, combine_op, 1, 0);
     } catch (...) { pma_destroy(h->P); delete h; throw; }
     h->n = len;
     *out = h;
@@ -841,20 +821,15 @@ int32_t dsa_pcsc_create(const int64_t* colptr, int64_t nparts, const int64_t* ro
                         int32_t combine_op, dsa_pcsc_t** out) {
     API_TRY
     if (nparts <= 0) fail(DSA_EARG, "PackedCSC needs at least one partition");
-    std::vector<int64_t> ks; std::vector<double> vs;
-    for (int64_t p = 0; p < nparts; ++p) {        // src/pcsr.jl:36-51
-        ks.push_back(SEM_KEY); vs.push_back((double)(p + 1));
-        std::vector<int64_t> nk(row_keys + colptr[p], row_keys + colptr[p + 1]);
-        std::vector<double> nv(vals + colptr[p], vals + colptr[p + 1]);
-        prepare_keys_vals(nk, nv, combine_op);
-        ks.insert(ks.end(), nk.begin(), nk.end()); vs.insert(vs.end(), nv.begin(), nv.end());
-    }
+    const int64_t nnz = colptr[nparts] - colptr[0];
+    if (nnz > 0xffffffffll) fail(DSA_EARG, "more than 2^32-1 entries in one call");
+    std::vector<int64_t> part((size_t)nnz);      // partition id of every entry (index expansion only; the sort / combine
+    for (int64_t p = 0; p < nparts; ++p)          // of src/pcsr.jl:36-51 runs on the device)
+        for (int64_t e = colptr[p]; e < colptr[p + 1]; ++e) part[(size_t)(e - colptr[0])] = p + 1;
     auto* h = new dsa_pcsc();
     try {
         pma_init_common(h->P, true, false);
-        h->P.h_ctl->nb_partitions = nparts; h->P.h_ctl->table_len = nparts;
-        ensure_tables(h->P, std::max<int64_t>(2 * nparts, 64));
-        build_from_packed(h->P, ks, vs);
+        pma_build_from_host(h->P, part.data(), row_keys + colptr[0], vals + colptr[0], nnz, combine_op, 2, nparts);
     } catch (...) { pma_destroy(h->P); delete h; throw; }
     *out = h;
     API_CATCH
