@@ -162,6 +162,11 @@ hipError_t launch_rebalance(const int64_t* src_keys, const double* src_vals, con
                             int64_t* dst_keys, double* dst_vals, uint64_t* dst_occ,
                             int64_t dst_ws, int64_t dst_we, int64_t m, int64_t* sems,
                             RebalanceWork* work, hipStream_t stream);
+// K-pack: occupied cells of slots [from, to] (1-based, inclusive), in slot order, to dense device buffers of capacity out_cap;
+// *count (host) receives the number of cells.  Synchronises the stream once (count needed to size the copy-out).
+hipError_t launch_compact_range(const int64_t* keys, const double* vals, const uint64_t* occ, int64_t from, int64_t to,
+                                int64_t* out_keys, double* out_vals, int64_t out_cap, RebalanceWork* work, int64_t* count,
+                                hipStream_t stream);
 // clears occupancy bits of slots [from, to] (1-based, inclusive); from/to word-aligned or inside one word
 hipError_t launch_clear_occ(uint64_t* occ, int64_t from, int64_t to, hipStream_t stream);
 

@@ -468,21 +468,20 @@ void get_batch(Pma& P, int mode, const int64_t* qa, const int64_t* qb, int64_t n
     if (err) fail(err, err == DSA_EBOUNDS ? "partition index out of range" : "partition has no semaphore");
 }
 
-// stored cells of the slot range [from, to] in slot order
+// stored cells of the slot range [from, to] in slot order: K-pack on the device into the alternate buffer (free between
+// rebalances), then only the packed cells cross PCIe
 void read_range(Pma& P, int64_t from, int64_t to, std::vector<int64_t>& ks, std::vector<double>& vs) {
     ks.clear(); vs.clear();
     if (to < from) return;
-    const int64_t n = to - from + 1;
-    const int64_t w0 = (from - 1) >> 6, w1 = (to - 1) >> 6;
-    std::vector<int64_t> k((size_t)n); std::vector<double> v((size_t)n); std::vector<uint64_t> o((size_t)(w1 - w0 + 1));
-    HIPCHK(hipMemcpyAsync(k.data(), P.K() + (from - 1), (size_t)n * sizeof(int64_t), hipMemcpyDeviceToHost, P.stream));
-    HIPCHK(hipMemcpyAsync(v.data(), P.V() + (from - 1), (size_t)n * sizeof(double), hipMemcpyDeviceToHost, P.stream));
-    HIPCHK(hipMemcpyAsync(o.data(), P.O() + w0, o.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, P.stream));
+    const int alt = 1 - P.cur;
+    int64_t cnt = 0;
+    hipError_t e = launch_compact_range(P.K(), P.V(), P.O(), from, to, P.keys[alt], P.vals[alt], P.cap_alloc, &P.work, &cnt, P.stream);
+    if (e != hipSuccess) fail(DSA_EHIP, std::string("compact launch: ") + hipGetErrorString(e));
+    if (cnt == 0) return;
+    ks.resize((size_t)cnt); vs.resize((size_t)cnt);
+    HIPCHK(hipMemcpyAsync(ks.data(), P.keys[alt], (size_t)cnt * sizeof(int64_t), hipMemcpyDeviceToHost, P.stream));
+    HIPCHK(hipMemcpyAsync(vs.data(), P.vals[alt], (size_t)cnt * sizeof(double), hipMemcpyDeviceToHost, P.stream));
     HIPCHK(hipStreamSynchronize(P.stream));
-    for (int64_t i = 0; i < n; ++i) {
-        const int64_t s = from - 1 + i;
-        if ((o[(size_t)((s >> 6) - w0)] >> (s & 63)) & 1ull) { ks.push_back(k[(size_t)i]); vs.push_back(v[(size_t)i]); }
-    }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -236,6 +236,58 @@ __global__ __launch_bounds__(MOVE_BLOCK) void k_move(MoveArgs a) {
     }
 }
 
+// K-pack as a stand-alone kernel: the occupied cells of a slot range, in slot order, to a dense output (pack! of
+// src/moves.jl:94-110 into a separate buffer).  Serves per-column iteration (DynamicMatrixColView, src/views.jl:15-35)
+// and iteration over a vector (src/pma.jl:165-180): one wave per 4096-slot source tile, lane <-> occupancy word for the
+// prefix, then lane <-> slot with ballot-style popcount ranks; out[tile_off + rank] is a contiguous run per wave.
+__global__ __launch_bounds__(64) void k_compact(const int64_t* __restrict__ keys, const double* __restrict__ vals,
+                                                const uint64_t* __restrict__ occ, int64_t lo0, int64_t hi0, int64_t w0,
+                                                int64_t nwords, const uint32_t* __restrict__ tile_off,
+                                                int64_t* __restrict__ out_keys, double* __restrict__ out_vals) {
+    const int lane = threadIdx.x;
+    const int64_t t = blockIdx.x;
+    const int64_t wl = t * SRC_TILE_WORDS + lane;
+    uint64_t myword = 0;
+    if (wl < nwords) myword = occ[w0 + wl] & range_mask_for_word(w0 + wl, lo0, hi0);
+    const uint32_t myoff = wave_excl_scan((uint32_t)popc64(myword));
+    const int64_t base = tile_off[t];
+    for (int w = 0; w < SRC_TILE_WORDS; ++w) {
+        const uint64_t mask = __shfl(myword, w, 64);
+        const int64_t woff = base + (int64_t)__shfl(myoff, w, 64);  // cross-lane reads stay outside divergent code
+        if (mask == 0) continue;                                   // wave-uniform
+        if ((mask >> lane) & 1ull) {
+            const int64_t r = woff + popc64(mask & mask_lt(lane));
+            const int64_t s = ((w0 + t * SRC_TILE_WORDS + w) << 6) + lane;
+            out_keys[r] = keys[s];
+            out_vals[r] = vals[s];
+        }
+    }
+}
+
+hipError_t launch_compact_range(const int64_t* keys, const double* vals, const uint64_t* occ, int64_t from, int64_t to,
+                                int64_t* out_keys, double* out_vals, int64_t out_cap, RebalanceWork* work, int64_t* count,
+                                hipStream_t stream) {
+    *count = 0;
+    if (to < from) return hipSuccess;
+    const int64_t lo0 = from - 1, hi0 = to - 1, w0 = lo0 >> 6;
+    const int64_t nwords = (hi0 >> 6) - w0 + 1;
+    const int64_t ntiles = (nwords + SRC_TILE_WORDS - 1) / SRC_TILE_WORDS;
+    if (ntiles + 1 > work->tiles_cap) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_tile_count, dim3((unsigned)ntiles), dim3(64), 0, stream, occ, lo0, hi0, w0, nwords, work->tile_cnt);
+    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, stream, work->tile_cnt, work->tile_off, ntiles);
+    uint32_t total = 0;
+    hipError_t e = hipMemcpyAsync(&total, work->tile_off + ntiles, sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
+    if (e != hipSuccess) return e;
+    e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) return e;
+    *count = total;
+    if (total == 0) return hipSuccess;
+    if ((int64_t)total > out_cap) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_compact, dim3((unsigned)ntiles), dim3(64), 0, stream, keys, vals, occ, lo0, hi0, w0, nwords, work->tile_off,
+                       out_keys, out_vals);
+    return hipGetLastError();
+}
+
 __global__ void k_clear_occ(uint64_t* occ, int64_t lo0, int64_t hi0) {
     const int64_t w0 = lo0 >> 6, w1 = hi0 >> 6;
     for (int64_t w = w0 + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; w <= w1; w += (int64_t)gridDim.x * blockDim.x)
