@@ -115,6 +115,12 @@ class DynamicSparseVector(_Handle):
     def rebalance_root(self):
         self.b.call("vec_rebalance_root", self.h)
 
+    def check(self):
+        """device-side invariant checker (HIP library only): report[2..6] must be 0."""
+        r = np.zeros(8, dtype=np.int64)
+        self.b.call("vec_check", self.h, r.ctypes.data_as(P_I64))
+        return r
+
     def __eq__(self, other):                          # src/vector.jl:85-87, src/pma.jl:236-266
         if not isinstance(other, DynamicSparseVector):
             return NotImplemented
@@ -342,6 +348,12 @@ class DynamicSparseMatrix(_Handle):
 
     def rebalance_root(self, orientation):
         self.b.call("mat_rebalance_root", self.h, orientation)
+
+    def check(self, orientation):
+        """device-side invariant checker (HIP library only): report[2..6] must be 0."""
+        r = np.zeros(8, dtype=np.int64)
+        self.b.call("mat_check", self.h, orientation, r.ctypes.data_as(P_I64))
+        return r
 
     def transpose(self):
         return Transposed(self)

@@ -114,6 +114,8 @@ _DEVICE_SIGS = {
     "device_count": [P_I32],
     "set_device": [I32],
     "mat_spmv_dense_dev": [VP, I32, I32, VP, I64, VP, I64],
+    "vec_check": [VP, P_I64],
+    "mat_check": [VP, I32, P_I64],
     "mat_set_stream": [VP, VP],
     "vec_set_stream": [VP, VP],
     "mat_sync": [VP],

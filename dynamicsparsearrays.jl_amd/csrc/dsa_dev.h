@@ -196,6 +196,10 @@ hipError_t launch_get_batch(int mode, const int64_t* keys, const double* vals, c
                             const int64_t* sems, const int64_t* col_keys, const uint8_t* col_live, int64_t table_len,
                             const int64_t* qa, const int64_t* qb, int64_t n, double* out, int32_t* err_out,
                             hipStream_t stream);
+// device-side invariant checker; report[0..5] as documented at k_check_slots (8 x uint64 device scratch)
+hipError_t launch_check(const int64_t* keys, const double* vals, const uint64_t* occ, int64_t capacity, int64_t occ_words,
+                        const int64_t* sems, const int64_t* col_keys, const uint8_t* col_live, int64_t table_len,
+                        unsigned long long* report, hipStream_t stream);
 // partition slot range lookup for views: out[0] = from (first slot after the semaphore), out[1] = to, or 0,0 if missing
 hipError_t launch_partition_range(const int64_t* sems, const int64_t* col_keys, const uint8_t* col_live,
                                   int64_t table_len, int64_t capacity, int64_t col, int64_t* out, hipStream_t stream);

@@ -441,6 +441,21 @@ void export_tables(Pma& P, int64_t* semaphores, int64_t* col_keys, uint8_t* col_
     if (col_keys) for (int64_t i = 0; i < tl; ++i) if (!col_live[i]) col_keys[i] = 0;
 }
 
+void pma_check(Pma& P, int64_t* report) {
+    unsigned long long* d = nullptr;
+    HIPCHK(hipMalloc(&d, 8 * sizeof(unsigned long long)));
+    unsigned long long r[8] = {0};
+    hipError_t e = launch_check(P.K(), P.V(), P.O(), P.capacity(), P.occ_words, P.has_sems ? P.sems : nullptr,
+                                P.has_cols ? P.col_keys : nullptr, P.has_cols ? P.col_live : nullptr, P.h_ctl->table_len, d, P.stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(r, d, sizeof(r), hipMemcpyDeviceToHost, P.stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(P.stream);
+    hipFree(d);
+    if (e != hipSuccess) fail(DSA_EHIP, std::string("check: ") + hipGetErrorString(e));
+    for (int i = 0; i < 8; ++i) report[i] = (int64_t)r[i];
+    const int64_t live = P.has_sems ? P.h_ctl->nb_partitions : 0;
+    report[6] = (report[0] != P.h_ctl->nb_elements || report[1] != live) ? 1 : 0;
+}
+
 void ensure_q(Pma& P, int64_t n) {
     if (n <= P.q_cap) return;
     if (P.d_q) hipFree(P.d_q);
@@ -805,6 +820,7 @@ int32_t dsa_vec_rebalance_root(dsa_vec_t* h) {
     }
     API_CATCH
 }
+int32_t dsa_vec_check(dsa_vec_t* h, int64_t* report) { API_TRY vec_flush(h); pma_check(h->P, report); API_CATCH }
 int32_t dsa_vec_set_stream(dsa_vec_t* h, void* s) {
     API_TRY
     vec_flush(h);
@@ -1194,6 +1210,7 @@ int32_t dsa_mat_spmv_sparse(dsa_mat_t* h, int32_t transpose, const int64_t* xi, 
     API_CATCH
 }
 
+int32_t dsa_mat_check(dsa_mat_t* h, int32_t o, int64_t* report) { API_TRY mat_flush(h); pma_check(orient(h, o), report); API_CATCH }
 int32_t dsa_mat_set_stream(dsa_mat_t* h, void* s) {
     API_TRY
     mat_flush(h);

@@ -750,6 +750,78 @@ hipError_t launch_get_batch(int mode, const int64_t* keys, const double* vals, c
     return hipGetLastError();
 }
 
+// ---- device-side invariant checker (the structural checks of the reference's test/utils.jl:68-113, at full size) ------
+// report[0] = occupied cells, [1] = semaphore cells, [2] = semaphore cells whose table entry does not point back,
+// [3] = key-order violations inside a partition (or anywhere, for a plain vector), [4] = live table entries that do not
+// point at a semaphore cell holding their id, [5] = occupancy bits at or beyond the capacity
+__global__ void k_check_slots(const int64_t* keys, const double* vals, const uint64_t* occ, int64_t capacity, int64_t occ_words,
+                              const int64_t* sems, int64_t table_len, unsigned long long* report) {
+    const int64_t s0 = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;      // 0-based slot
+    unsigned long long n_occ = 0, n_sem = 0, bad_sem = 0, bad_order = 0;
+    if (s0 < capacity && ((occ[s0 >> 6] >> (s0 & 63)) & 1ull)) {
+        n_occ = 1;
+        const int64_t k = keys[s0];
+        if (sems != nullptr && k == SEM_KEY) {
+            n_sem = 1;
+            const int64_t id = (int64_t)vals[s0];
+            if (id < 1 || id > table_len || sems[id - 1] != s0 + 1) bad_sem = 1;
+        } else {
+            const int64_t p = d_prev_occupied(occ, s0, 1);                  // previous occupied position (1-based), 0 if none
+            if (p >= 1) {
+                const int64_t pk = keys[p - 1];
+                const bool prev_is_sem = sems != nullptr && pk == SEM_KEY;
+                if (!prev_is_sem && !(pk < k)) bad_order = 1;
+            }
+        }
+    }
+    unsigned long long beyond = 0;
+    const int64_t w = s0;                                                   // reuse the grid for the words past the capacity
+    if (w < occ_words && (w << 6) >= capacity) beyond = (unsigned long long)popc64(occ[w]);
+    else if (w < occ_words && ((w + 1) << 6) > capacity) beyond = (unsigned long long)popc64(occ[w] & ~mask_lt((int)(capacity & 63)));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        n_occ += __shfl_xor(n_occ, o, 64); n_sem += __shfl_xor(n_sem, o, 64); bad_sem += __shfl_xor(bad_sem, o, 64);
+        bad_order += __shfl_xor(bad_order, o, 64); beyond += __shfl_xor(beyond, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (n_occ) atomicAdd(&report[0], n_occ);
+        if (n_sem) atomicAdd(&report[1], n_sem);
+        if (bad_sem) atomicAdd(&report[2], bad_sem);
+        if (bad_order) atomicAdd(&report[3], bad_order);
+        if (beyond) atomicAdd(&report[5], beyond);
+    }
+}
+__global__ void k_check_table(const int64_t* keys, const double* vals, const uint64_t* occ, int64_t capacity, const int64_t* sems,
+                              const int64_t* col_keys, const uint8_t* col_live, int64_t table_len, unsigned long long* report) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= table_len) return;
+    const int64_t pos = sems[i];
+    bool bad = false;
+    if (pos != 0) {
+        if (pos < 1 || pos > capacity || !occ_test(occ, pos) || keys[pos - 1] != SEM_KEY || vals[pos - 1] != (double)(i + 1)) bad = true;
+        if (col_live != nullptr && !col_live[i]) bad = true;
+        if (col_live != nullptr && i > 0) {                                  // live column keys ascend with the id
+            int64_t j = i - 1;
+            while (j >= 0 && !col_live[j]) --j;
+            if (j >= 0 && !(col_keys[j] < col_keys[i])) bad = true;
+        }
+    } else if (col_live != nullptr && col_live[i]) bad = true;
+    if (bad) atomicAdd(&report[4], 1ull);
+}
+hipError_t launch_check(const int64_t* keys, const double* vals, const uint64_t* occ, int64_t capacity, int64_t occ_words,
+                        const int64_t* sems, const int64_t* col_keys, const uint8_t* col_live, int64_t table_len,
+                        unsigned long long* report, hipStream_t stream) {
+    hipError_t e = hipMemsetAsync(report, 0, 8 * sizeof(unsigned long long), stream);
+    if (e != hipSuccess) return e;
+    const int64_t n = capacity > occ_words ? capacity : occ_words;
+    hipLaunchKernelGGL(k_check_slots, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, keys, vals, occ, capacity, occ_words,
+                       sems, table_len, report);
+    if (sems != nullptr && table_len > 0)
+        hipLaunchKernelGGL(k_check_table, dim3((unsigned)((table_len + 255) / 256)), dim3(256), 0, stream, keys, vals, occ, capacity,
+                           sems, col_keys, col_live, table_len, report);
+    return hipGetLastError();
+}
+
 // view(mpcsc, :, col)  src/views.jl:15-35 : slot range of the column
 __global__ void k_partition_range(const int64_t* sems, const int64_t* col_keys, const uint8_t* col_live, int64_t table_len,
                                   int64_t capacity, int64_t col, int64_t* out) {

@@ -173,6 +173,12 @@ int32_t dsa_mat_spmv_sparse(dsa_mat_t* h, int32_t transpose, const int64_t* xi, 
  * orientation with fp64 atomics (the literal _mul loop nest) */
 int32_t dsa_mat_spmv_dense_dev(dsa_mat_t* h, int32_t transpose, int32_t algo, const double* d_x,
                                int64_t nx, double* d_y, int64_t ny);
+/* Device-side invariant checker (the structural checks of the reference's test/utils.jl:68-113, runnable at full size):
+ * report[0] occupied cells, [1] semaphore cells, [2] semaphore cells whose table entry does not point back, [3] key-order
+ * violations, [4] bad table entries (not pointing at their semaphore / dead key / unsorted column keys), [5] occupancy bits at or
+ * beyond the capacity, [6] 1 if report[0] != nb_elements or report[1] != live partitions.  A healthy structure has [2..6] == 0. */
+int32_t dsa_vec_check(dsa_vec_t* h, int64_t report[8]);
+int32_t dsa_mat_check(dsa_mat_t* h, int32_t orientation, int64_t report[8]);
 /* stream control for *_dev entry points (hipStream_t passed as void*; NULL = legacy default stream) */
 int32_t dsa_mat_set_stream(dsa_mat_t* h, void* hip_stream);
 int32_t dsa_vec_set_stream(dsa_vec_t* h, void* hip_stream);
