@@ -87,7 +87,18 @@ __global__ __launch_bounds__(SP_BLOCK) void k_spmv(const int64_t* __restrict__ k
     __shared__ uint64_t sSemBits[SP_TILE / 64];
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int64_t b0 = (int64_t)blockIdx.x * SP_TILE;
+    // XCD-aware tile mapping: workgroups are dealt round-robin to the 8 XCDs (blockIdx % 8 shares an XCD, speed only),
+    // so XCD g is given the g-th contiguous eighth of the slot array: rows that are neighbours stay on one L2, and a
+    // matrix with any band / block structure gathers x from a range that its XCD already holds.
+    const int64_t ntiles = (capacity + SP_TILE - 1) / SP_TILE;
+    int64_t tile = blockIdx.x;
+    if (ntiles >= 64 && !(pattern & 4)) {                 // (pattern bit 2: dev knob DSA_DBG_SPMV=4 keeps the identity map)
+                                                          // grid = 8 * ceil(ntiles / 8): (xcd, i) -> xcd * per + i is onto [0, ntiles)
+        const int64_t per = (ntiles + 7) / 8;
+        tile = (int64_t)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
+        if (tile >= ntiles) return;
+    }
+    const int64_t b0 = tile * SP_TILE;
     const int tile_end = (int)((capacity - b0) < SP_TILE ? (capacity - b0) : SP_TILE);
     if (tid == 0) sNLong = 0;
 
@@ -119,7 +130,7 @@ __global__ __launch_bounds__(SP_BLOCK) void k_spmv(const int64_t* __restrict__ k
             else if (k[j] >= 1 && k[j] <= nx) {
                 const double xv = x[k[j] - 1];
                 // pattern pass (touched rows of _mul, src/operations.jl:101): count the cells whose x entry is stored
-                p = pattern == 1 ? (xv != 0.0 ? 1.0 : 0.0) : v[j] * xv;
+                p = (pattern & 3) == 1 ? (xv != 0.0 ? 1.0 : 0.0) : v[j] * xv;
             }
         }
         sP[ls] = p;
@@ -145,7 +156,7 @@ __global__ __launch_bounds__(SP_BLOCK) void k_spmv(const int64_t* __restrict__ k
         if (lane == 0) sCarry = c;
     }
 
-    if (pattern == 2) return;      // dev ablation (DSA_DBG_SPMV=2): stream + gather only, no segmented sums
+    if ((pattern & 3) == 2) return;      // dev ablation (DSA_DBG_SPMV=2): stream + gather only, no segmented sums
     if (!SCATTER) {
         // ---- phase 2 (gather): one lane per semaphore sums its segment in slot order -------------
         for (int j = tid; j < total; j += SP_BLOCK) {
@@ -307,11 +318,12 @@ static hipError_t launch_spmv(bool scatter, int pattern, const int64_t* keys, co
     if (e != hipSuccess) return e;
     { static const char* dbg = getenv("DSA_DBG_SPMV"); if (dbg && pattern == 0) pattern = atoi(dbg); }
     const int64_t ntiles = (capacity + SP_TILE - 1) / SP_TILE;
+    const int64_t grid = ntiles >= 64 ? 8 * ((ntiles + 7) / 8) : ntiles;     // see the XCD-aware mapping in k_spmv
     if (scatter)
-        hipLaunchKernelGGL(k_spmv<true>, dim3((unsigned)ntiles), dim3(SP_BLOCK), 0, stream, keys, vals, occ, capacity, sems,
+        hipLaunchKernelGGL(k_spmv<true>, dim3((unsigned)grid), dim3(SP_BLOCK), 0, stream, keys, vals, occ, capacity, sems,
                            part_keys, table_len, x, nx, y, ny, 0);
     else
-        hipLaunchKernelGGL(k_spmv<false>, dim3((unsigned)ntiles), dim3(SP_BLOCK), 0, stream, keys, vals, occ, capacity, sems,
+        hipLaunchKernelGGL(k_spmv<false>, dim3((unsigned)grid), dim3(SP_BLOCK), 0, stream, keys, vals, occ, capacity, sems,
                            part_keys, table_len, x, nx, y, ny, pattern);
     return hipGetLastError();
 }

@@ -72,3 +72,18 @@ for nx_, label in ((1_000_000, "8 MB"), (500_000, "4 MB"), (250_000, "2 MB"), (1
     idx = torch.randint(0, nx_, (11_000_000,), device=dev, dtype=torch.int64)
     us = timeit(lambda: torch.index_select(xt, 0, idx))
     print("torch gather 11M x f64 from %s table: %.1f us -> %.1f G gathers/s" % (label, us, 11e6 / us / 1e3))
+
+# banded matrix (|row - col| < 4096): the XCD-aware tile map keeps each XCD's x range L2-resident
+import numpy as np
+nb = 1_000_000
+colsb = np.repeat(np.arange(1, nb + 1, dtype=np.int64), 10)
+offs = (bench.splitmix_array(21, nb * 10) % np.uint64(8192)).astype(np.int64) - 4096
+rowsb = np.clip(colsb + offs, 1, nb)
+keyb = colsb * np.int64(nb + 1) + rowsb
+_, fb = np.unique(keyb, return_index=True)
+Bm = dsa.dynamicsparse(rowsb[fb], colsb[fb], bench.unit12(22, len(fb)), nb, nb, binding=hip)
+hip.call("mat_set_stream", Bm.h, C.c_void_p(stream.cuda_stream))
+capb = Bm.info(1)["capacity"]
+us = timeit(lambda: hip.call("mat_spmv_dense_dev", Bm.h, 0, 0, C.c_void_p(x.data_ptr()), nb, C.c_void_p(y.data_ptr()), nb))
+bb = 16 * capb + 16 * nb
+print("banded 1M x 1M, ~10M nnz: gather A*x   %8.1f us  %7.1f GB/s (%.1f%%)" % (us, bb / us / 1e3, bb / us / 1e3 / 80))
