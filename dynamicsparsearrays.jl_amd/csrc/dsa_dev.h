@@ -190,6 +190,20 @@ void build_abort(BuildScratch& s);
 hipError_t launch_sequencer(int64_t* keys, double* vals, uint64_t* occ, int64_t* sems, int64_t* col_keys,
                             uint8_t* col_live, Ctl* ctl, const Op* ops, int64_t n_ops, hipStream_t stream);
 
+// ---- batch-parallel writes of a vector's PMA (parbatch.hip) ------------------------------------------------------------
+struct Plan {
+    int64_t lo, hi;        // footprint: slots the op reads for its decisions or modifies (lo > hi: empty)
+    int64_t pos, aux;      // predecessor / found position ; shift target (next / previous empty slot)
+    int64_t ws, we;        // window accepted by the density scan after the op
+    int32_t count;         // cells of that window after the op
+    int32_t action;
+};
+// plans ops [i0, i0+G) on the current state and writes to *d_out the length of the prefix that can be applied in parallel
+hipError_t launch_plan_resolve(const int64_t* keys, const double* vals, const uint64_t* occ, const Ctl* ctl, const Op* ops,
+                               int64_t i0, int G, Plan* plans, int32_t* d_out, hipStream_t stream);
+hipError_t launch_apply(int64_t* keys, double* vals, uint64_t* occ, Ctl* ctl, const Op* ops, int64_t i0, int d, const Plan* plans,
+                        hipStream_t stream);
+
 // batched read-only lookups.  mode 0: getindex(pma, key) ; 1: getindex(pcsc, key, partition) ;
 // 2: getindex(mpcsc, row, col).  err_out: first error code (0 if none)
 hipError_t launch_get_batch(int mode, const int64_t* keys, const double* vals, const uint64_t* occ, int64_t capacity,

@@ -12,6 +12,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 #include <string>
@@ -70,6 +71,7 @@ struct Pma {
     Op* d_ops = nullptr; int64_t ops_cap = 0;
     double* d_q = nullptr; int64_t q_cap = 0;      // scratch for lookups (3 arrays of q_cap)
     int32_t* d_err = nullptr;
+    Plan* d_plans = nullptr; int32_t* d_prefix = nullptr; int32_t* h_prefix = nullptr;     // batch-parallel writes
     int64_t* d_small = nullptr;                     // 8 x int64 scratch
     // thresholds  src/pma.jl:58,70,87
     double t_h = 0.7, t_0 = 0.92, p_h = 0.3, p_0 = 0.08, t_d = 0.0, p_d = 0.0;
@@ -103,6 +105,9 @@ void pma_destroy(Pma& P) {
     if (P.d_ops) hipFree(P.d_ops);
     if (P.d_q) hipFree(P.d_q);
     if (P.d_err) hipFree(P.d_err);
+    if (P.d_plans) hipFree(P.d_plans);
+    if (P.d_prefix) hipFree(P.d_prefix);
+    if (P.h_prefix) hipHostFree(P.h_prefix);
     if (P.d_small) hipFree(P.d_small);
     if (P.own_stream && P.stream) hipStreamDestroy(P.stream);
     P = Pma();
@@ -384,6 +389,58 @@ int64_t run_ops(Pma& P, const std::vector<Op>& ops, int32_t* err) {
     while (seq_step(r)) {}
     *err = r.err;
     return r.applied;
+}
+
+// Batch-parallel execution of vector writes (parbatch.hip): rounds of plan / resolve / apply for the prefix of ops whose
+// footprints are pairwise disjoint; the op that cuts a short prefix (and a growing chunk after it while prefixes stay
+// short: ascending appends, hammering one key) goes through the sequential sequencer.  Same final state as run_ops.
+int64_t run_vec_ops_parallel(Pma& P, const std::vector<Op>& ops, int32_t* err) {
+    *err = 0;
+    const int64_t n = (int64_t)ops.size();
+    if (n == 0) return 0;
+    constexpr int GMAX = 1024, MIN_PREFIX = 12;
+    ensure_ops(P, n);
+    HIPCHK(hipMemcpyAsync(P.d_ops, ops.data(), (size_t)n * sizeof(Op), hipMemcpyHostToDevice, P.stream));
+    if (!P.d_plans) {
+        HIPCHK(hipMalloc(&P.d_plans, (size_t)GMAX * sizeof(Plan)));
+        HIPCHK(hipMalloc(&P.d_prefix, sizeof(int32_t)));
+        HIPCHK(hipHostMalloc(&P.h_prefix, sizeof(int32_t), hipHostMallocDefault));
+    }
+    P.h_ctl->next_op = 0; P.h_ctl->status = 0; P.h_ctl->err = 0;
+    upload_ctl(P);
+    int64_t i = 0, seq_chunk = 64;
+    int G = 256;
+    bool host_ctl_stale = false;
+    while (i < n) {
+        const int g = (int)std::min<int64_t>(G, n - i);
+        hipError_t e = launch_plan_resolve(P.K(), P.V(), P.O(), P.d_ctl, P.d_ops, i, g, P.d_plans, P.d_prefix, P.stream);
+        if (e != hipSuccess) fail(DSA_EHIP, std::string("plan launch: ") + hipGetErrorString(e));
+        HIPCHK(hipMemcpyAsync(P.h_prefix, P.d_prefix, sizeof(int32_t), hipMemcpyDeviceToHost, P.stream));
+        HIPCHK(hipStreamSynchronize(P.stream));
+        const int d = *P.h_prefix;
+        if (d >= MIN_PREFIX || (d == g && d > 0)) {
+            e = launch_apply(P.K(), P.V(), P.O(), P.d_ctl, P.d_ops, i, d, P.d_plans, P.stream);
+            if (e != hipSuccess) fail(DSA_EHIP, std::string("apply launch: ") + hipGetErrorString(e));
+            i += d;
+            host_ctl_stale = true;
+            seq_chunk = 64;
+            G = std::min(GMAX, std::max(64, 2 * d));
+            continue;
+        }
+        // short prefix: sequential sequencer for ops [i, i + seq_chunk)
+        if (host_ctl_stale) { download_ctl(P); host_ctl_stale = false; }
+        SeqRun r;
+        r.P = &P; r.ops = &ops; r.n = std::min<int64_t>(n, i + seq_chunk); r.active = true;
+        P.h_ctl->next_op = i; P.h_ctl->status = 0; P.h_ctl->err = 0;
+        seq_launch(r);
+        while (seq_step(r)) {}
+        if (r.err) { *err = r.err; return r.applied; }
+        i = r.applied;
+        seq_chunk = std::min<int64_t>(seq_chunk * 2, 8192);
+        G = 64;
+    }
+    if (host_ctl_stale) download_ctl(P);
+    return n;
 }
 
 // Two independent structures (the colmajor and rowmajor orientation): both sequencers run at the same time, each on
@@ -764,7 +821,8 @@ static void vec_apply(dsa_vec_t* h, const int64_t* keys, const double* vals, int
     std::vector<Op> ops((size_t)n);
     for (int64_t i = 0; i < n; ++i) ops[(size_t)i] = make_op(OP_VEC_SET, keys[i], 0, vals[i]);
     int32_t err = 0;
-    const int64_t done = run_ops(h->P, ops, &err);
+    static const bool par = [] { const char* e = getenv("DSA_PARBATCH"); return !(e && e[0] == '0'); }();
+    const int64_t done = (par && n >= 128) ? run_vec_ops_parallel(h->P, ops, &err) : run_ops(h->P, ops, &err);
     const int64_t upto = err ? std::min(done + 1, n) : done;          // v.n is updated before the write (src/vector.jl:77-79)
     for (int64_t i = 0; i < upto; ++i) if (vals[i] != 0.0) h->n = std::max(h->n, keys[i]);
     if (err) fail(err, err_text(err));

@@ -1,0 +1,318 @@
+// csrc/parbatch.hip — batch-parallel writes for a vector's PMA: plan / resolve / apply.
+//
+// A batch is DEFINED as the reference's setindex! applied in order (src/pma.jl:196-213).  Two writes commute when the
+// slots one of them reads to take its decisions or modifies are untouched by the other.  Per round, for the next G ops:
+//
+//   k_plan    (one wave per op, read-only): K-find (wave-parallel form), the shift target (_nextemptypos /
+//             _previousemptypos, src/utils.jl:3-28) and the density-threshold scan of src/pma.jl:105-141 evaluated on the
+//             PRE-round state, corrected by the op's own occupancy change.  The result is a Plan with the op's FOOTPRINT:
+//             the hull of { predecessor slot and the slot after it (what find depends on), the shifted run, the accepted
+//             window (every window whose count was consulted lies inside it) }.  Ops whose scan is not accepted within
+//             PB_MAX_W slots (big rebalance, _extend!, _shrink!), or that are not vector writes, are BARRIERs.
+//   k_resolve (one workgroup): an op conflicts if its footprint overlaps another op's.  Every overlapping pair (i < j)
+//             has j >= the second-smallest conflicting index c1, so ops [0, d), d = min(c1, first BARRIER), are pairwise
+//             disjoint: each of them sees, when executed alone in order, exactly the state it was planned on.
+//   k_apply   (one wave per op): shift, write, occupancy update (atomics: footprints are disjoint in slots, not in 64-slot
+//             bitmap words), then the small-window pack + spread through the wave's LDS slice.
+//
+// The host (dsa_host.hip) applies the prefix in parallel and hands the op at d (and a growing chunk after it when the
+// prefixes stay short, e.g. ascending appends) to the sequential sequencer.  Result: bit-identical to the sequential order.
+#include "dsa_dev.h"
+#include "find_dev.h"
+
+namespace dsa {
+
+constexpr int PB_BLOCK = 256;                 // 4 waves = 4 ops per workgroup
+constexpr int PB_MAX_W = 1024;                // largest window a single wave rebalances (16 KB of LDS per wave)
+
+enum : int32_t { PB_NOOP = 0, PB_OVERWRITE = 1, PB_INS_R = 2, PB_INS_L = 3, PB_DELETE = 4, PB_BARRIER = 5 };
+
+__device__ __forceinline__ int64_t pb_wave_sum(int64_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ uint64_t pb_occ_load(const uint64_t* occ, int64_t w) {
+    // L2-served load: other waves of the same launch update neighbouring bits of shared words with device-scope atomics
+    return __hip_atomic_load(occ + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// occupied cells of [ws, we] (1-based, inclusive), whole wave
+__device__ int64_t pb_wave_count(const uint64_t* occ, int64_t ws, int64_t we, bool coherent) {
+    const int64_t lo0 = ws - 1, hi0 = we - 1, w0 = lo0 >> 6, w1 = hi0 >> 6;
+    int64_t c = 0;
+    for (int64_t w = w0 + lane_id(); w <= w1; w += 64)
+        c += popc64((coherent ? pb_occ_load(occ, w) : occ[w]) & word_range_mask(w, lo0, hi0));
+    return pb_wave_sum(c);
+}
+
+__global__ __launch_bounds__(PB_BLOCK) void k_plan(const int64_t* keys, const double* vals, const uint64_t* occ, const Ctl* ctl,
+                                                   const Op* ops, int64_t i0, int G, Plan* plans) {
+    const int w = blockIdx.x * (PB_BLOCK / 64) + (threadIdx.x >> 6);
+    if (w >= G) return;
+    const int64_t capacity = ctl->capacity, seg = ctl->segment_capacity, height = ctl->height;
+    const Op op = ops[i0 + w];
+    Plan pl;
+    pl.lo = 1; pl.hi = 0; pl.pos = 0; pl.aux = 0; pl.ws = 0; pl.we = 0; pl.count = 0; pl.action = PB_BARRIER;
+    if (op.kind == OP_VEC_SET) {
+        const DFound f = d_find_fast(keys, vals, occ, op.a, 1, capacity);
+        const bool exists = f.has && f.key == op.a;
+        int64_t ip = 0, changed = 0, delta = 0, wlo = 1, whi = 0, rlo = 1, rhi = 0;
+        bool scan = false;
+        if (op.v != 0.0) {
+            if (exists) {                                   // overwrite  src/writes.jl:16-19
+                pl.action = PB_OVERWRITE; pl.pos = f.pos; pl.lo = f.pos; pl.hi = f.pos;
+            } else {
+                const int64_t p = f.pos;
+                const int64_t ne = d_next_empty(occ, p, capacity);
+                rlo = p >= 1 ? p : 1; rhi = p + 1 <= capacity ? p + 1 : capacity;
+                if (ne != 0) { pl.action = PB_INS_R; ip = p + 1; changed = ne; wlo = p + 1; whi = ne; pl.aux = ne; scan = true; }
+                else {
+                    const int64_t pe = d_prev_empty(occ, p);
+                    if (pe != 0) { pl.action = PB_INS_L; ip = p; changed = pe; wlo = pe; whi = p; pl.aux = pe; scan = true; }
+                }
+                pl.pos = p; delta = 1;
+            }
+        } else {
+            if (!exists) {                                  // delete of a missing key: nothing happens, but only as long as
+                const int64_t p = f.pos;                    // nobody inserts that key first -> depends on slots p, p+1
+                pl.action = PB_NOOP;
+                pl.lo = p >= 1 ? p : 1; pl.hi = p + 1 <= capacity ? p + 1 : capacity;
+            } else {
+                pl.action = PB_DELETE; pl.pos = f.pos; ip = f.pos; changed = f.pos; delta = -1;
+                wlo = whi = f.pos; rlo = rhi = f.pos; scan = true;
+            }
+        }
+        if (scan) {
+            bool accepted = false;
+            int64_t ws = 1, we = 0, c = 0;
+            for (int64_t h = 0; h <= height; ++h) {
+                const int64_t W = seg << h;
+                if (W > PB_MAX_W && h > 0) break;
+                ws = ((ip - 1) / W) * W + 1;
+                we = ws + W - 1;
+                c = pb_wave_count(occ, ws, we, false) + ((changed >= ws && changed <= we) ? delta : 0);
+                if (ctl->lo[h] <= c && c <= ctl->hi[h]) { accepted = true; break; }
+            }
+            if (!accepted) {
+                pl.action = PB_BARRIER;
+            } else {
+                pl.ws = ws; pl.we = we; pl.count = (int32_t)c;
+                int64_t lo = ws < wlo ? ws : wlo, hi = we > whi ? we : whi;
+                if (rlo < lo) lo = rlo;
+                if (rhi > hi) hi = rhi;
+                pl.lo = lo; pl.hi = hi;
+            }
+        }
+    }
+    if (lane_id() == 0) plans[w] = pl;
+}
+
+__global__ __launch_bounds__(1024) void k_resolve(const Plan* plans, int G, int32_t* out) {
+    __shared__ int64_t sLo[1024], sHi[1024];
+    __shared__ int sC0, sC1, sB;
+    const int i = threadIdx.x;
+    int act = PB_NOOP;
+    int64_t lo = 1, hi = 0;
+    if (i < G) { const Plan p = plans[i]; lo = p.lo; hi = p.hi; act = p.action; }
+    sLo[i] = lo; sHi[i] = hi;
+    if (i == 0) { sC0 = G; sC1 = G; sB = G; }
+    __syncthreads();
+    bool conflict = false;
+    if (i < G && lo <= hi) {
+        for (int j = 0; j < G; ++j) {
+            const int64_t l2 = sLo[j], h2 = sHi[j];
+            if (j != i && l2 <= h2 && l2 <= hi && lo <= h2) { conflict = true; break; }
+        }
+    }
+    if (conflict) atomicMin(&sC0, i);
+    if (i < G && act == PB_BARRIER) atomicMin(&sB, i);
+    __syncthreads();
+    if (conflict && i > sC0) atomicMin(&sC1, i);
+    __syncthreads();
+    if (i == 0) { const int d = sC1 < sB ? sC1 : sB; out[0] = d < G ? d : G; }
+}
+
+// ---- apply ----------------------------------------------------------------------------------------------------------
+__device__ void pb_shift_right(int64_t* keys, double* vals, int64_t a, int64_t b) {      // cells [a, b-1] -> +1
+    const int lane = lane_id();
+    for (int64_t hi = b - 1; hi >= a; hi -= 64) {
+        const int64_t p = hi - lane;
+        const bool act = p >= a;
+        int64_t k = 0; double v = 0.0;
+        if (act) { k = keys[p - 1]; v = vals[p - 1]; }
+        if (act) { keys[p] = k; vals[p] = v; }
+    }
+}
+__device__ void pb_shift_left(int64_t* keys, double* vals, int64_t a, int64_t b, bool last_occ) {   // cells [a+1, b] -> -1
+    const int lane = lane_id();
+    for (int64_t lo = a + 1; lo <= b; lo += 64) {
+        const int64_t p = lo + lane;
+        const bool act = p <= b && (p < b || last_occ);
+        int64_t k = 0; double v = 0.0;
+        if (act) { k = keys[p - 1]; v = vals[p - 1]; }
+        if (act) { keys[p - 2] = k; vals[p - 2] = v; }
+    }
+}
+__device__ __forceinline__ void pb_bit_set(uint64_t* occ, int64_t pos) {
+    atomicOr((unsigned long long*)(occ + ((pos - 1) >> 6)), 1ull << ((pos - 1) & 63));
+}
+__device__ __forceinline__ void pb_bit_clear(uint64_t* occ, int64_t pos) {
+    atomicAnd((unsigned long long*)(occ + ((pos - 1) >> 6)), ~(1ull << ((pos - 1) & 63)));
+}
+__device__ __forceinline__ uint32_t pb_wave_excl_scan(uint32_t v) {
+    const int lane = lane_id();
+    uint32_t x = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t y = __shfl_up(x, o, 64);
+        if (lane >= o) x += y;
+    }
+    return x - v;
+}
+
+// pack! + spread! of [ws, we] (W <= PB_MAX_W) holding m cells, by one wave  (src/moves.jl:94-140)
+__device__ void pb_wave_rebalance(int64_t* keys, double* vals, uint64_t* occ, int64_t ws, int64_t we, int64_t m,
+                                  int64_t* sK, double* sV) {
+    const int lane = lane_id();
+    const int64_t W = we - ws + 1, lo0 = ws - 1, w0 = lo0 >> 6;
+    const SpreadGeom g = make_geom(W, m);
+    if (W >= 64) {
+        const int nwords = (int)(W >> 6);                          // <= 16
+        const uint64_t myword = lane < nwords ? pb_occ_load(occ, w0 + lane) : 0ull;
+        const uint32_t myoff = pb_wave_excl_scan((uint32_t)popc64(myword));
+        for (int w = 0; w < nwords; ++w) {
+            const uint64_t mask = __shfl(myword, w, 64);
+            const uint32_t off = __shfl(myoff, w, 64);
+            if ((mask >> lane) & 1ull) {
+                const uint32_t r = off + (uint32_t)popc64(mask & mask_lt(lane));
+                const int64_t s = ((w0 + w) << 6) + lane;
+                // L2-served loads: some of these cells were just written by this wave's own shift
+                sK[r] = __hip_atomic_load(keys + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                sV[r] = __hip_atomic_load(vals + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_s_waitcnt(0xc07f);                        // lgkmcnt(0): the wave's LDS writes have landed
+        for (int64_t base = 0; base < W; base += 64) {
+            const int q = (int)base + lane + 1;
+            bool occd = false;
+            int rank;
+            if (!slot_is_gap(g, q, &rank)) {
+                occd = true;
+                keys[lo0 + q - 1] = sK[rank - 1];
+                vals[lo0 + q - 1] = sV[rank - 1];
+            }
+            const uint64_t b = __ballot(occd);
+            if (lane == 0) __hip_atomic_store(occ + w0 + (base >> 6), b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    } else {
+        const int bit0 = (int)(lo0 & 63);
+        const uint64_t wmask = ((1ull << W) - 1ull) << bit0;
+        const uint64_t word = pb_occ_load(occ, w0);
+        const uint64_t mask = (word & wmask) >> bit0;
+        if (lane < W && ((mask >> lane) & 1ull)) {
+            const int r = popc64(mask & mask_lt(lane));
+            sK[r] = __hip_atomic_load(keys + lo0 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sV[r] = __hip_atomic_load(vals + lo0 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        bool occd = false;
+        const int q = lane + 1;
+        if (q <= W) {
+            int rank;
+            if (!slot_is_gap(g, q, &rank)) {
+                occd = true;
+                keys[lo0 + q - 1] = sK[rank - 1];
+                vals[lo0 + q - 1] = sV[rank - 1];
+            }
+        }
+        const uint64_t b = __ballot(occd);
+        if (lane == 0) {                                           // only this op's bits of the shared word change
+            atomicAnd((unsigned long long*)(occ + w0), ~wmask);
+            atomicOr((unsigned long long*)(occ + w0), (b << bit0) & wmask);
+        }
+    }
+}
+
+__global__ __launch_bounds__(PB_BLOCK) void k_apply(int64_t* keys, double* vals, uint64_t* occ, Ctl* ctl, const Op* ops,
+                                                    int64_t i0, int d, const Plan* plans) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char pb_lds[];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int w = blockIdx.x * (PB_BLOCK / 64) + wv;
+    if (w >= d) return;
+    int64_t* sK = reinterpret_cast<int64_t*>(pb_lds) + (size_t)wv * PB_MAX_W;
+    double* sV = reinterpret_cast<double*>(pb_lds + (size_t)(PB_BLOCK / 64) * PB_MAX_W * sizeof(int64_t)) + (size_t)wv * PB_MAX_W;
+    const Plan pl = plans[w];
+    const Op op = ops[i0 + w];
+    const int64_t seg = ctl->segment_capacity;
+    int64_t delta = 0;
+    switch (pl.action) {
+        case PB_OVERWRITE:
+            if (lane == 0) vals[pl.pos - 1] = op.v;
+            break;
+        case PB_INS_R: {                                           // _insert!, right branch  src/writes.jl:29-32
+            const int64_t p = pl.pos, ne = pl.aux;
+            pb_shift_right(keys, vals, p + 1, ne);
+            if (lane == 0) { keys[p] = op.a; vals[p] = op.v; pb_bit_set(occ, ne); }
+            delta = 1;
+            break;
+        }
+        case PB_INS_L: {                                           // _insert!, left branch  src/writes.jl:34-37
+            const int64_t p = pl.pos, pe = pl.aux;
+            const bool last_occ = (pb_occ_load(occ, (p - 1) >> 6) >> ((p - 1) & 63)) & 1ull;
+            pb_shift_left(keys, vals, pe, p, last_occ);
+            if (lane == 0) {
+                keys[p - 1] = op.a; vals[p - 1] = op.v;
+                if (pe < p - 1) { pb_bit_set(occ, pe); if (!last_occ) pb_bit_clear(occ, p - 1); }
+                else if (last_occ) pb_bit_set(occ, pe);
+                pb_bit_set(occ, p);
+            }
+            delta = 1;
+            break;
+        }
+        case PB_DELETE:
+            if (lane == 0) pb_bit_clear(occ, pl.pos);
+            delta = -1;
+            break;
+        default:
+            break;
+    }
+    if (delta != 0) {
+        if (lane == 0) atomicAdd((unsigned long long*)&ctl->nb_elements, (unsigned long long)delta);
+        const int64_t W = pl.we - pl.ws + 1;
+        if (W != seg) {                                            // _even_rebalance!  src/pma.jl:94-103
+            __builtin_amdgcn_s_waitcnt(0);                         // the op's own stores / atomics are complete
+            pb_wave_rebalance(keys, vals, occ, pl.ws, pl.we, pl.count, sK, sV);
+            if (lane == 0) {
+                atomicAdd((unsigned long long*)&ctl->stat_rebalances, 1ull);
+                atomicAdd((unsigned long long*)&ctl->stat_window_slots, (unsigned long long)W);
+                atomicAdd((unsigned long long*)&ctl->stat_small_rebalances, 1ull);
+            }
+        }
+    }
+}
+
+hipError_t launch_plan_resolve(const int64_t* keys, const double* vals, const uint64_t* occ, const Ctl* ctl, const Op* ops,
+                               int64_t i0, int G, Plan* plans, int32_t* d_out, hipStream_t stream) {
+    hipLaunchKernelGGL(k_plan, dim3((unsigned)((G + 3) / 4)), dim3(PB_BLOCK), 0, stream, keys, vals, occ, ctl, ops, i0, G, plans);
+    hipLaunchKernelGGL(k_resolve, dim3(1), dim3(1024), 0, stream, plans, G, d_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_apply(int64_t* keys, double* vals, uint64_t* occ, Ctl* ctl, const Op* ops, int64_t i0, int d, const Plan* plans,
+                        hipStream_t stream) {
+    static bool configured = false;
+    const size_t lds = (size_t)(PB_BLOCK / 64) * PB_MAX_W * (sizeof(int64_t) + sizeof(double));
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_apply), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        configured = true;
+    }
+    hipLaunchKernelGGL(k_apply, dim3((unsigned)((d + 3) / 4)), dim3(PB_BLOCK), lds, stream, keys, vals, occ, ctl, ops, i0, d, plans);
+    return hipGetLastError();
+}
+
+}  // namespace dsa
