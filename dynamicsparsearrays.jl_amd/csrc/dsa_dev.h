@@ -199,10 +199,11 @@ struct Plan {
     int32_t action;
 };
 // plans ops [i0, i0+G) on the current state and writes to *d_out the length of the prefix that can be applied in parallel
-hipError_t launch_plan_resolve(const int64_t* keys, const double* vals, const uint64_t* occ, const Ctl* ctl, const Op* ops,
+hipError_t launch_plan_resolve(const int64_t* keys, const double* vals, const uint64_t* occ, const int64_t* sems,
+                               const int64_t* col_keys, const uint8_t* col_live, const Ctl* ctl, const Op* ops,
                                int64_t i0, int G, Plan* plans, int32_t* d_out, hipStream_t stream);
-hipError_t launch_apply(int64_t* keys, double* vals, uint64_t* occ, Ctl* ctl, const Op* ops, int64_t i0, int d, const Plan* plans,
-                        hipStream_t stream);
+hipError_t launch_apply(int64_t* keys, double* vals, uint64_t* occ, int64_t* sems, Ctl* ctl, const Op* ops, int64_t i0, int d,
+                        const Plan* plans, hipStream_t stream);
 
 // batched read-only lookups.  mode 0: getindex(pma, key) ; 1: getindex(pcsc, key, partition) ;
 // 2: getindex(mpcsc, row, col).  err_out: first error code (0 if none)

@@ -394,7 +394,7 @@ int64_t run_ops(Pma& P, const std::vector<Op>& ops, int32_t* err) {
 // Batch-parallel execution of vector writes (parbatch.hip): rounds of plan / resolve / apply for the prefix of ops whose
 // footprints are pairwise disjoint; the op that cuts a short prefix (and a growing chunk after it while prefixes stay
 // short: ascending appends, hammering one key) goes through the sequential sequencer.  Same final state as run_ops.
-int64_t run_vec_ops_parallel(Pma& P, const std::vector<Op>& ops, int32_t* err) {
+int64_t run_ops_parallel(Pma& P, const std::vector<Op>& ops, int32_t* err) {
     *err = 0;
     const int64_t n = (int64_t)ops.size();
     if (n == 0) return 0;
@@ -413,13 +413,14 @@ int64_t run_vec_ops_parallel(Pma& P, const std::vector<Op>& ops, int32_t* err) {
     bool host_ctl_stale = false;
     while (i < n) {
         const int g = (int)std::min<int64_t>(G, n - i);
-        hipError_t e = launch_plan_resolve(P.K(), P.V(), P.O(), P.d_ctl, P.d_ops, i, g, P.d_plans, P.d_prefix, P.stream);
+        hipError_t e = launch_plan_resolve(P.K(), P.V(), P.O(), P.has_sems ? P.sems : nullptr, P.has_cols ? P.col_keys : nullptr,
+                                           P.has_cols ? P.col_live : nullptr, P.d_ctl, P.d_ops, i, g, P.d_plans, P.d_prefix, P.stream);
         if (e != hipSuccess) fail(DSA_EHIP, std::string("plan launch: ") + hipGetErrorString(e));
         HIPCHK(hipMemcpyAsync(P.h_prefix, P.d_prefix, sizeof(int32_t), hipMemcpyDeviceToHost, P.stream));
         HIPCHK(hipStreamSynchronize(P.stream));
         const int d = *P.h_prefix;
         if (d >= MIN_PREFIX || (d == g && d > 0)) {
-            e = launch_apply(P.K(), P.V(), P.O(), P.d_ctl, P.d_ops, i, d, P.d_plans, P.stream);
+            e = launch_apply(P.K(), P.V(), P.O(), P.has_sems ? P.sems : nullptr, P.d_ctl, P.d_ops, i, d, P.d_plans, P.stream);
             if (e != hipSuccess) fail(DSA_EHIP, std::string("apply launch: ") + hipGetErrorString(e));
             i += d;
             host_ctl_stale = true;
@@ -701,6 +702,19 @@ void mat_apply_sets(dsa_mat* h, const int64_t* I, const int64_t* J, const double
     // batch runs first and the rowmajor batch is cut at the failing op, like the reference's statement order.
     const bool no_tombstones = h->col.h_ctl->nb_partitions == h->col.h_ctl->table_len &&
                                h->row.h_ctl->nb_partitions == h->row.h_ctl->table_len;
+    static const bool par = [] { const char* e = getenv("DSA_PARBATCH"); return !(e && e[0] == '0'); }();
+    if (par && no_tombstones && n >= 128) {
+        // batch-parallel rounds per orientation (writes to existing columns with disjoint footprints run concurrently; new
+        // columns and anything else fall back to the sequential sequencer inside run_ops_parallel)
+        int32_t ec = 0, er = 0;
+        const int64_t dc = run_ops_parallel(h->col, oc, &ec);
+        const int64_t dr = run_ops_parallel(h->row, orw, &er);
+        const int64_t done = std::min(dc, dr);
+        for (int64_t k = 0; k < std::min(done + 1, n); ++k) if (V[k] != 0.0) { h->m = std::max(h->m, I[k]); h->n = std::max(h->n, J[k]); }
+        if (ec) fail(ec, err_text(ec));
+        if (er) fail(er, err_text(er));
+        return;
+    }
     if (no_tombstones && h->col.stream != h->row.stream) {
         SeqRun rc, rr;
         run_ops_pair(h->col, oc, h->row, orw, rc, rr);
@@ -822,7 +836,7 @@ static void vec_apply(dsa_vec_t* h, const int64_t* keys, const double* vals, int
     for (int64_t i = 0; i < n; ++i) ops[(size_t)i] = make_op(OP_VEC_SET, keys[i], 0, vals[i]);
     int32_t err = 0;
     static const bool par = [] { const char* e = getenv("DSA_PARBATCH"); return !(e && e[0] == '0'); }();
-    const int64_t done = (par && n >= 128) ? run_vec_ops_parallel(h->P, ops, &err) : run_ops(h->P, ops, &err);
+    const int64_t done = (par && n >= 128) ? run_ops_parallel(h->P, ops, &err) : run_ops(h->P, ops, &err);
     const int64_t upto = err ? std::min(done + 1, n) : done;          // v.n is updated before the write (src/vector.jl:77-79)
     for (int64_t i = 0; i < upto; ++i) if (vals[i] != 0.0) h->n = std::max(h->n, keys[i]);
     if (err) fail(err, err_text(err));

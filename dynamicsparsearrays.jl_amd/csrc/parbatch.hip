@@ -45,17 +45,40 @@ __device__ int64_t pb_wave_count(const uint64_t* occ, int64_t ws, int64_t we, bo
     return pb_wave_sum(c);
 }
 
-__global__ __launch_bounds__(PB_BLOCK) void k_plan(const int64_t* keys, const double* vals, const uint64_t* occ, const Ctl* ctl,
-                                                   const Op* ops, int64_t i0, int G, Plan* plans) {
+__global__ __launch_bounds__(PB_BLOCK) void k_plan(const int64_t* keys, const double* vals, const uint64_t* occ,
+                                                   const int64_t* sems, const int64_t* col_keys, const uint8_t* col_live,
+                                                   const Ctl* ctl, const Op* ops, int64_t i0, int G, Plan* plans) {
     const int w = blockIdx.x * (PB_BLOCK / 64) + (threadIdx.x >> 6);
     if (w >= G) return;
     const int64_t capacity = ctl->capacity, seg = ctl->segment_capacity, height = ctl->height;
     const Op op = ops[i0 + w];
     Plan pl;
     pl.lo = 1; pl.hi = 0; pl.pos = 0; pl.aux = 0; pl.ws = 0; pl.we = 0; pl.count = 0; pl.action = PB_BARRIER;
+    // search range of the write: the whole array for a vector (src/pma.jl:196-213); for setindex!(mpcsc, v, row, col) on an
+    // EXISTING live column, semaphore+1 .. end of partition for the insert path and semaphore .. end for the delete path
+    // (src/pcsr.jl:294-310).  Anything else (new column, deleted partition, delete of a key <= 0 whose bisection is
+    // path-dependent) is left to the sequential sequencer.
+    bool plannable = false;
+    int64_t from = 1, to = capacity, del_from = 1;
     if (op.kind == OP_VEC_SET) {
-        const DFound f = d_find_fast(keys, vals, occ, op.a, 1, capacity);
-        const bool exists = f.has && f.key == op.a;
+        plannable = true;
+    } else if (op.kind == OP_MPCSC_SET && sems != nullptr && col_keys != nullptr) {
+        const int64_t table_len = ctl->table_len;
+        const DFoundKey tf = d_find_table_fast(col_keys, col_live, table_len, op.b);
+        if (tf.has && tf.key == op.b) {
+            const int64_t sp = sems[tf.pos - 1];
+            if (sp != 0 && (op.v != 0.0 || op.a > SEM_KEY)) {
+                const int64_t nxt = d_next_live_sem(sems, tf.pos, table_len);
+                from = sp + 1; del_from = sp;
+                to = nxt != 0 ? sems[nxt - 1] - 1 : capacity;
+                plannable = true;
+            }
+        }
+    }
+    if (plannable) {
+        const DFound f = op.v != 0.0 ? d_find_fast(keys, vals, occ, op.a, from, to) : d_find_fast(keys, vals, occ, op.a, del_from, to);
+        const bool exists = op.v != 0.0 ? (f.has && f.key == op.a && from <= f.pos && f.pos <= to)      // src/writes.jl:16
+                                        : (f.has && f.key == op.a);                                     // src/writes.jl:59
         int64_t ip = 0, changed = 0, delta = 0, wlo = 1, whi = 0, rlo = 1, rhi = 0;
         bool scan = false;
         if (op.v != 0.0) {
@@ -133,24 +156,30 @@ __global__ __launch_bounds__(1024) void k_resolve(const Plan* plans, int G, int3
 }
 
 // ---- apply ----------------------------------------------------------------------------------------------------------
-__device__ void pb_shift_right(int64_t* keys, double* vals, int64_t a, int64_t b) {      // cells [a, b-1] -> +1
+__device__ void pb_shift_right(int64_t* keys, double* vals, int64_t* sems, int64_t a, int64_t b) {      // cells [a, b-1] -> +1
     const int lane = lane_id();
     for (int64_t hi = b - 1; hi >= a; hi -= 64) {
         const int64_t p = hi - lane;
         const bool act = p >= a;
         int64_t k = 0; double v = 0.0;
         if (act) { k = keys[p - 1]; v = vals[p - 1]; }
-        if (act) { keys[p] = k; vals[p] = v; }
+        if (act) {
+            keys[p] = k; vals[p] = v;
+            if (sems != nullptr && k == SEM_KEY) sems[(int64_t)v - 1] = p + 1;       // _moverightloop!  src/moves.jl:32-36
+        }
     }
 }
-__device__ void pb_shift_left(int64_t* keys, double* vals, int64_t a, int64_t b, bool last_occ) {   // cells [a+1, b] -> -1
+__device__ void pb_shift_left(int64_t* keys, double* vals, int64_t* sems, int64_t a, int64_t b, bool last_occ) {   // cells [a+1, b] -> -1
     const int lane = lane_id();
     for (int64_t lo = a + 1; lo <= b; lo += 64) {
         const int64_t p = lo + lane;
         const bool act = p <= b && (p < b || last_occ);
         int64_t k = 0; double v = 0.0;
         if (act) { k = keys[p - 1]; v = vals[p - 1]; }
-        if (act) { keys[p - 2] = k; vals[p - 2] = v; }
+        if (act) {
+            keys[p - 2] = k; vals[p - 2] = v;
+            if (sems != nullptr && k == SEM_KEY) sems[(int64_t)v - 1] = p - 1;       // _moveleftloop!  src/moves.jl:75-79
+        }
     }
 }
 __device__ __forceinline__ void pb_bit_set(uint64_t* occ, int64_t pos) {
@@ -171,7 +200,7 @@ __device__ __forceinline__ uint32_t pb_wave_excl_scan(uint32_t v) {
 }
 
 // pack! + spread! of [ws, we] (W <= PB_MAX_W) holding m cells, by one wave  (src/moves.jl:94-140)
-__device__ void pb_wave_rebalance(int64_t* keys, double* vals, uint64_t* occ, int64_t ws, int64_t we, int64_t m,
+__device__ void pb_wave_rebalance(int64_t* keys, double* vals, uint64_t* occ, int64_t* sems, int64_t ws, int64_t we, int64_t m,
                                   int64_t* sK, double* sV) {
     const int lane = lane_id();
     const int64_t W = we - ws + 1, lo0 = ws - 1, w0 = lo0 >> 6;
@@ -200,8 +229,11 @@ __device__ void pb_wave_rebalance(int64_t* keys, double* vals, uint64_t* occ, in
             int rank;
             if (!slot_is_gap(g, q, &rank)) {
                 occd = true;
-                keys[lo0 + q - 1] = sK[rank - 1];
-                vals[lo0 + q - 1] = sV[rank - 1];
+                const int64_t k = sK[rank - 1];
+                const double v = sV[rank - 1];
+                keys[lo0 + q - 1] = k;
+                vals[lo0 + q - 1] = v;
+                if (sems != nullptr && k == SEM_KEY) sems[(int64_t)v - 1] = lo0 + q;       // spread! with semaphores  src/moves.jl:160-166
             }
             const uint64_t b = __ballot(occd);
             if (lane == 0) __hip_atomic_store(occ + w0 + (base >> 6), b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -225,8 +257,11 @@ __device__ void pb_wave_rebalance(int64_t* keys, double* vals, uint64_t* occ, in
             int rank;
             if (!slot_is_gap(g, q, &rank)) {
                 occd = true;
-                keys[lo0 + q - 1] = sK[rank - 1];
-                vals[lo0 + q - 1] = sV[rank - 1];
+                const int64_t k = sK[rank - 1];
+                const double v = sV[rank - 1];
+                keys[lo0 + q - 1] = k;
+                vals[lo0 + q - 1] = v;
+                if (sems != nullptr && k == SEM_KEY) sems[(int64_t)v - 1] = lo0 + q;
             }
         }
         const uint64_t b = __ballot(occd);
@@ -237,8 +272,8 @@ __device__ void pb_wave_rebalance(int64_t* keys, double* vals, uint64_t* occ, in
     }
 }
 
-__global__ __launch_bounds__(PB_BLOCK) void k_apply(int64_t* keys, double* vals, uint64_t* occ, Ctl* ctl, const Op* ops,
-                                                    int64_t i0, int d, const Plan* plans) {
+__global__ __launch_bounds__(PB_BLOCK) void k_apply(int64_t* keys, double* vals, uint64_t* occ, int64_t* sems, Ctl* ctl,
+                                                    const Op* ops, int64_t i0, int d, const Plan* plans) {
     extern __shared__ __attribute__((aligned(16))) unsigned char pb_lds[];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int w = blockIdx.x * (PB_BLOCK / 64) + wv;
@@ -255,7 +290,7 @@ __global__ __launch_bounds__(PB_BLOCK) void k_apply(int64_t* keys, double* vals,
             break;
         case PB_INS_R: {                                           // _insert!, right branch  src/writes.jl:29-32
             const int64_t p = pl.pos, ne = pl.aux;
-            pb_shift_right(keys, vals, p + 1, ne);
+            pb_shift_right(keys, vals, sems, p + 1, ne);
             if (lane == 0) { keys[p] = op.a; vals[p] = op.v; pb_bit_set(occ, ne); }
             delta = 1;
             break;
@@ -263,7 +298,7 @@ __global__ __launch_bounds__(PB_BLOCK) void k_apply(int64_t* keys, double* vals,
         case PB_INS_L: {                                           // _insert!, left branch  src/writes.jl:34-37
             const int64_t p = pl.pos, pe = pl.aux;
             const bool last_occ = (pb_occ_load(occ, (p - 1) >> 6) >> ((p - 1) & 63)) & 1ull;
-            pb_shift_left(keys, vals, pe, p, last_occ);
+            pb_shift_left(keys, vals, sems, pe, p, last_occ);
             if (lane == 0) {
                 keys[p - 1] = op.a; vals[p - 1] = op.v;
                 if (pe < p - 1) { pb_bit_set(occ, pe); if (!last_occ) pb_bit_clear(occ, p - 1); }
@@ -285,7 +320,7 @@ __global__ __launch_bounds__(PB_BLOCK) void k_apply(int64_t* keys, double* vals,
         const int64_t W = pl.we - pl.ws + 1;
         if (W != seg) {                                            // _even_rebalance!  src/pma.jl:94-103
             __builtin_amdgcn_s_waitcnt(0);                         // the op's own stores / atomics are complete
-            pb_wave_rebalance(keys, vals, occ, pl.ws, pl.we, pl.count, sK, sV);
+            pb_wave_rebalance(keys, vals, occ, sems, pl.ws, pl.we, pl.count, sK, sV);
             if (lane == 0) {
                 atomicAdd((unsigned long long*)&ctl->stat_rebalances, 1ull);
                 atomicAdd((unsigned long long*)&ctl->stat_window_slots, (unsigned long long)W);
@@ -295,15 +330,17 @@ __global__ __launch_bounds__(PB_BLOCK) void k_apply(int64_t* keys, double* vals,
     }
 }
 
-hipError_t launch_plan_resolve(const int64_t* keys, const double* vals, const uint64_t* occ, const Ctl* ctl, const Op* ops,
+hipError_t launch_plan_resolve(const int64_t* keys, const double* vals, const uint64_t* occ, const int64_t* sems,
+                               const int64_t* col_keys, const uint8_t* col_live, const Ctl* ctl, const Op* ops,
                                int64_t i0, int G, Plan* plans, int32_t* d_out, hipStream_t stream) {
-    hipLaunchKernelGGL(k_plan, dim3((unsigned)((G + 3) / 4)), dim3(PB_BLOCK), 0, stream, keys, vals, occ, ctl, ops, i0, G, plans);
+    hipLaunchKernelGGL(k_plan, dim3((unsigned)((G + 3) / 4)), dim3(PB_BLOCK), 0, stream, keys, vals, occ, sems, col_keys, col_live,
+                       ctl, ops, i0, G, plans);
     hipLaunchKernelGGL(k_resolve, dim3(1), dim3(1024), 0, stream, plans, G, d_out);
     return hipGetLastError();
 }
 
-hipError_t launch_apply(int64_t* keys, double* vals, uint64_t* occ, Ctl* ctl, const Op* ops, int64_t i0, int d, const Plan* plans,
-                        hipStream_t stream) {
+hipError_t launch_apply(int64_t* keys, double* vals, uint64_t* occ, int64_t* sems, Ctl* ctl, const Op* ops, int64_t i0, int d,
+                        const Plan* plans, hipStream_t stream) {
     static bool configured = false;
     const size_t lds = (size_t)(PB_BLOCK / 64) * PB_MAX_W * (sizeof(int64_t) + sizeof(double));
     if (!configured) {
@@ -311,7 +348,7 @@ hipError_t launch_apply(int64_t* keys, double* vals, uint64_t* occ, Ctl* ctl, co
         if (e != hipSuccess) return e;
         configured = true;
     }
-    hipLaunchKernelGGL(k_apply, dim3((unsigned)((d + 3) / 4)), dim3(PB_BLOCK), lds, stream, keys, vals, occ, ctl, ops, i0, d, plans);
+    hipLaunchKernelGGL(k_apply, dim3((unsigned)((d + 3) / 4)), dim3(PB_BLOCK), lds, stream, keys, vals, occ, sems, ctl, ops, i0, d, plans);
     return hipGetLastError();
 }
 

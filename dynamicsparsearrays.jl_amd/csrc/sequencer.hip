@@ -42,70 +42,6 @@ struct Seq {
     const int64_t* lo; const int64_t* hi;   // integer density bounds per level (LDS copy of Ctl::lo / Ctl::hi)
 };
 
-struct DFoundKey { int64_t pos; int64_t key; bool has; };
-// find(col_keys, key)  src/finds.jl:59-61 on a Vector{Union{Nothing,L}}
-__device__ DFoundKey d_find_table(const int64_t* ck, const uint8_t* live, int64_t len, int64_t key) {
-    int64_t from = 1, to = len;
-    while (from <= to) {
-        const int64_t mid = (from + to) >> 1;
-        int64_t i = mid;
-        while (i >= from && !live[i - 1]) --i;
-        if (i < from) {
-            from = mid + 1;
-        } else {
-            const int64_t c = ck[i - 1];
-            if (c > key) to = i - 1;
-            else if (c < key) from = mid + 1;
-            else return DFoundKey{i, c, true};
-        }
-    }
-    int64_t i = to;
-    while (i > 0 && !live[i - 1]) --i;
-    if (i > 0) return DFoundKey{i, ck[i - 1], true};
-    return DFoundKey{0, 0, false};
-}
-
-// wave-parallel form of d_find_table (live column keys are strictly ascending)
-__device__ DFoundKey d_find_table_fast(const int64_t* ck, const uint8_t* live, int64_t len, int64_t key) {
-    const int lane = lane_id();
-    int64_t L = 0, H = len;
-    while (H - L > 64) {
-        const int64_t width = H - L;
-        const int64_t p = L + (width * (lane + 1)) / 64;
-        int64_t q = p;
-        while (q > L && !live[q - 1]) --q;
-        bool pr = true;
-        if (q > L) pr = ck[q - 1] < key;
-        const uint64_t nb = ~__ballot(pr);
-        const int j = nb ? __ffsll((unsigned long long)nb) - 1 : 64;
-        const int64_t pj = L + (width * (j + 1)) / 64;
-        const int64_t pj1 = L + (width * j) / 64;
-        if (j < 64) H = pj - 1;
-        L = pj1;
-    }
-    const int64_t p = L + 1 + lane;
-    bool viol = false;
-    if (p <= H && live[p - 1]) viol = ck[p - 1] >= key;
-    const uint64_t b = __ballot(viol);
-    const int64_t pstar = b ? L + __ffsll((unsigned long long)b) - 1 : H;
-    int64_t nxt = pstar + 1;
-    while (nxt <= len && !live[nxt - 1]) ++nxt;
-    if (nxt <= len && ck[nxt - 1] == key) return DFoundKey{nxt, key, true};
-    int64_t i = pstar;
-    while (i > 0 && !live[i - 1]) --i;
-    if (i > 0) return DFoundKey{i, ck[i - 1], true};
-    return DFoundKey{0, 0, false};
-}
-
-// _nextnonemptypos(semaphores, from)  src/utils.jl:12-19
-__device__ int64_t d_next_live_sem(const int64_t* sems, int64_t from, int64_t len) {
-    int64_t pos = from + 1;
-    while (pos <= len) {
-        if (sems[pos - 1] != 0) return pos;
-        ++pos;
-    }
-    return 0;
-}
 
 // ---- workgroup-parallel primitives ------------------------------------------------------------------
 
