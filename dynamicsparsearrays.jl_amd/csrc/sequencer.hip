@@ -36,6 +36,7 @@ struct Seq {
     int64_t stat_window_slots, stat_rebalances, stat_small;
     int64_t y_ws, y_we, y_m;
     int32_t err;
+    bool tail_hint;                // the previous insert went behind the last cell of its range: try that first (append runs)
     int64_t* sK; double* sV;       // LDS staging for the small-window rebalance
     uint32_t* sWordOff;            // [SMALL_W/64 + 1]
     int64_t* sRed;                 // [SEQ_BLOCK/64] block-reduce scratch
@@ -273,7 +274,19 @@ __device__ int64_t d_insert_after(Seq& S, int64_t key, double val, int64_t pos) 
 // src/writes.jl:14-23,57-63 ; del_from is the (possibly wider) range of the delete path (src/pcsr.jl:302-307)
 __device__ int d_set_in_range(Seq& S, int64_t key, double val, int64_t from, int64_t to, int64_t del_from) {
     if (val != 0.0) {
-        const DFound f = d_find_fast(S.keys, S.vals, S.occ, key, from, to);     // [from, to] never holds a semaphore
+        // append runs (ascending keys: Coluna's column streaming, BASELINE config 2 batch A): when the previous insert landed
+        // behind the last cell of its range, look there first — find() returns that cell whenever its key is smaller
+        DFound f;
+        bool have = false;
+        if (S.tail_hint && to >= from) {
+            const int64_t lp = d_prev_occupied(S.occ, to, from);
+            if (lp >= from) {
+                const int64_t lk = S.keys[lp - 1];
+                if (lk < key) { f = DFound{lp, lk, 0.0, true}; have = true; }
+            }
+        }
+        if (!have) f = d_find_fast(S.keys, S.vals, S.occ, key, from, to);     // [from, to] never holds a semaphore
+        S.tail_hint = have || (f.has && f.pos >= from && f.key < key && d_next_occupied(S.occ, f.pos, to) == 0);
         if (f.has && f.key == key && from <= f.pos && f.pos <= to) {
             __syncthreads();
             if (threadIdx.x == 0) S.vals[f.pos - 1] = val;
@@ -464,7 +477,7 @@ __global__ __launch_bounds__(SEQ_BLOCK) void k_sequencer(int64_t* keys, double* 
     S.table_len = ctl->table_len; S.table_cap = ctl->table_cap;
     S.stat_window_slots = ctl->stat_window_slots; S.stat_rebalances = ctl->stat_rebalances;
     S.stat_small = ctl->stat_small_rebalances;
-    S.y_ws = S.y_we = S.y_m = 0; S.err = 0;
+    S.y_ws = S.y_we = S.y_m = 0; S.err = 0; S.tail_hint = false;
     S.sK = reinterpret_cast<int64_t*>(lds);
     S.sV = reinterpret_cast<double*>(lds + SMALL_W * sizeof(int64_t));
     S.sWordOff = sWordOff; S.sRed = sRed;

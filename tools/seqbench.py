@@ -25,3 +25,16 @@ odd = np.unique(1 + 2 * (bench.splitmix_array(4, 120000) % np.uint64(700000)).as
 rng.shuffle(odd)
 t("uniform inserts (new keys)", odd, bench.unit12(4, len(odd)))
 t("delete them again", odd, np.zeros(len(odd)))
+
+# matrix: random updates on an existing 20k x 30k structure (both orientations), batch-parallel vs sequential
+import subprocess
+m, n = 20000, 30000
+rows = 1 + (bench.splitmix_array(31, 600000) % np.uint64(m)).astype(np.int64)
+cols = 1 + (bench.splitmix_array(32, 600000) % np.uint64(n)).astype(np.int64)
+A = dsa.dynamicsparse(rows, cols, bench.unit12(33, 600000), m, n, binding=hip)
+ui = 1 + (bench.splitmix_array(34, 200000) % np.uint64(m)).astype(np.int64)
+uj = 1 + (bench.splitmix_array(35, 200000) % np.uint64(n)).astype(np.int64)
+uv = np.where(bench.splitmix_array(36, 200000) % np.uint64(4) == 0, 0.0, bench.unit12(37, 200000))
+A.set_batch(ui[:100], uj[:100], uv[:100])
+t0 = time.perf_counter(); A.set_batch(ui, uj, uv); dt = time.perf_counter() - t0
+print("%-40s %7.2f us/op (%s)" % ("matrix random A[i,j]=v (2 PCSR writes)", dt / len(ui) * 1e6, os.environ.get("DSA_PARBATCH", "1")))
