@@ -124,20 +124,22 @@ __device__ void blk_rebalance_small(Seq& S, int64_t ws, int64_t we, int64_t m) {
     const SpreadGeom g = make_geom(W, m);
     if (W >= 64) {
         const int nwords = (int)(W >> 6);              // <= 128
-        // exclusive prefix of the per-word popcounts (two wave scans)
-        if (wv < 2) {
-            const int w = wv * 64 + lane;
-            const uint32_t pc = w < nwords ? (uint32_t)popc64(S.occ[w0 + w]) : 0u;
-            const uint32_t ex = seq_wave_excl_scan(pc);
-            if (w < nwords) S.sWordOff[w] = ex;
-            if (lane == 63) S.sRed[wv] = ex + pc;
+        // exclusive prefix of the per-word popcounts: wave 0, 64 words per pass (any workgroup size)
+        if (wv == 0) {
+            uint32_t carry = 0;
+            for (int g0 = 0; g0 < nwords; g0 += 64) {
+                const int w = g0 + lane;
+                const uint32_t pc = w < nwords ? (uint32_t)popc64(S.occ[w0 + w]) : 0u;
+                const uint32_t ex = seq_wave_excl_scan(pc);
+                if (w < nwords) S.sWordOff[w] = carry + ex;
+                carry += __shfl(ex + pc, 63, 64);
+            }
         }
         __syncthreads();
-        const uint32_t add = (uint32_t)S.sRed[0];
         for (int w = wv; w < nwords; w += SEQ_BLOCK / 64) {
             const uint64_t mask = S.occ[w0 + w];
             if ((mask >> lane) & 1ull) {
-                const uint32_t r = S.sWordOff[w] + (w >= 64 ? add : 0u) + (uint32_t)popc64(mask & mask_lt(lane));
+                const uint32_t r = S.sWordOff[w] + (uint32_t)popc64(mask & mask_lt(lane));
                 const int64_t s = ((w0 + w) << 6) + lane;
                 S.sK[r] = S.keys[s];
                 S.sV[r] = S.vals[s];
