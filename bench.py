@@ -242,6 +242,20 @@ def extras(dsa, hip, torch, A, dev):
                             "config": "C2: 2^20-slot PMA (700k keys) + 100k batched inserts, whole dsa_vec_set_batch call incl. H2D",
                             "window_slots_per_insert_A": round(info["stat_window_slots"] / 100000, 1),
                             "extends": info["stat_extends"]}
+    # --- random A[i,j] = v updates on an existing 20k x 30k structure (each write = 2 PCSR writes, batch-parallel path)
+    mm, nn = 20000, 30000
+    ri = 1 + (splitmix_array(31, 600000) % np.uint64(mm)).astype(np.int64)
+    ci = 1 + (splitmix_array(32, 600000) % np.uint64(nn)).astype(np.int64)
+    M = dsa.dynamicsparse(ri, ci, unit12(33, 600000), mm, nn, binding=hip)
+    ui = 1 + (splitmix_array(34, 200000) % np.uint64(mm)).astype(np.int64)
+    uj = 1 + (splitmix_array(35, 200000) % np.uint64(nn)).astype(np.int64)
+    uv = np.where(splitmix_array(36, 200000) % np.uint64(4) == 0, 0.0, unit12(37, 200000))
+    M.set_batch(ui[:128], uj[:128], uv[:128])
+    t = time.perf_counter()
+    M.set_batch(ui, uj, uv)
+    res["inserts_per_s"]["matrix_random_updates_per_s"] = round(len(ui) / (time.perf_counter() - t), 1)
+    res["inserts_per_s"]["matrix_random_updates_config"] = "200k random A[i,j]=v (25% deletes) on a 20k x 30k matrix with 600k nnz"
+
     # --- C5 (scaled 1/10): stream new columns element by element into an empty matrix (both orientations),
     #     SpMV every 500 columns.  Full C5 is 50k columns x 16 rows over 100k rows; parity of this loop vs the
     #     oracle is tests/test_hip_parity.py::test_matrix_from_empty_streaming_columns_c5_scaled
@@ -306,7 +320,20 @@ def cpu_baseline(dsa, m, per):
     for _ in range(reps):
         lib.ora_mat_spmv_dense_fastacc(B.h, 0, xp, ncs, yy.ctypes.data_as(dsa.binding.P_F64), m)
     tf = (time.perf_counter() - t) / reps
+    # the same C2 insert batches on the oracle (single thread)
+    n0 = 700000
+    vo = dsa.dynamicsparsevec(np.arange(1, n0 + 1, dtype=np.int64) * 2, unit12(3, n0), binding=ora)
+    app = np.arange(1400001, 1500001, dtype=np.int64)
+    t = time.perf_counter()
+    vo.set_batch(app, unit12(3, 100000))
+    ta = time.perf_counter() - t
+    odd = np.unique(1 + 2 * (splitmix_array(4, 120000) % np.uint64(700000)).astype(np.int64))[:100000]
+    np.random.default_rng(4).shuffle(odd)
+    t = time.perf_counter()
+    vo.set_batch(odd, unit12(4, len(odd)))
+    tb2 = time.perf_counter() - t
     return {"value": round(bytes_ / 1e9 / ts, 4), "unit": "GB/s", "cores": 1, "kind": "port",
+            "inserts_per_s": {"batch_A_ascending_appends": round(100000 / ta, 1), "batch_B_uniform": round(len(odd) / tb2, 1)},
             "sample": "first 400k columns of the C3 matrix (1M x 400k, %d nnz, colmajor capacity %d): y = A*x with the "
                       "reference's Dict accumulator (src/operations.jl:101), 1 thread of %d host cores" % (len(I), cap, multiprocessing.cpu_count()),
             "nnz_per_s": round(len(I) / ts, 1),
