@@ -198,12 +198,19 @@ struct Plan {
     int32_t count;         // cells of that window after the op
     int32_t action;
 };
-// plans ops [i0, i0+G) on the current state and writes to *d_out the length of the prefix that can be applied in parallel
-hipError_t launch_plan_resolve(const int64_t* keys, const double* vals, const uint64_t* occ, const int64_t* sems,
-                               const int64_t* col_keys, const uint8_t* col_live, const Ctl* ctl, const Op* ops,
-                               int64_t i0, int G, Plan* plans, int32_t* d_out, hipStream_t stream);
-hipError_t launch_apply(int64_t* keys, double* vals, uint64_t* occ, int64_t* sems, Ctl* ctl, const Op* ops, int64_t i0, int d,
-                        const Plan* plans, hipStream_t stream);
+// device-resident driver state of the batch-parallel rounds: the host enqueues several rounds back to back and only then
+// synchronises to read it
+struct RoundState {
+    int64_t cursor;        // next op of the batch
+    int64_t limit;         // one past the last op
+    int32_t G;             // ops planned per round (adapted on the device to 2x the last prefix, 64..1024)
+    int32_t d;             // prefix length decided by k_resolve for the round in flight
+    int32_t stop;          // 0 running, 1 short prefix at `cursor` (sequencer must take over), 2 batch finished
+    int32_t min_prefix, g_used, pad;
+    int64_t rounds, par_ops;
+};
+hipError_t launch_round(int64_t* keys, double* vals, uint64_t* occ, int64_t* sems, const int64_t* col_keys, const uint8_t* col_live,
+                        Ctl* ctl, const Op* ops, RoundState* rs, Plan* plans, uint32_t* flags, hipStream_t stream);
 
 // batched read-only lookups.  mode 0: getindex(pma, key) ; 1: getindex(pcsc, key, partition) ;
 // 2: getindex(mpcsc, row, col).  err_out: first error code (0 if none)

@@ -71,7 +71,8 @@ struct Pma {
     Op* d_ops = nullptr; int64_t ops_cap = 0;
     double* d_q = nullptr; int64_t q_cap = 0;      // scratch for lookups (3 arrays of q_cap)
     int32_t* d_err = nullptr;
-    Plan* d_plans = nullptr; int32_t* d_prefix = nullptr; int32_t* h_prefix = nullptr;     // batch-parallel writes
+    int64_t stat_par_rounds = 0, stat_par_ops = 0, stat_seq_ops = 0;      // batch-parallel instrumentation
+    Plan* d_plans = nullptr; uint32_t* d_flags = nullptr; RoundState* d_rs = nullptr; RoundState* h_rs = nullptr;   // batch-parallel writes
     int64_t* d_small = nullptr;                     // 8 x int64 scratch
     // thresholds  src/pma.jl:58,70,87
     double t_h = 0.7, t_0 = 0.92, p_h = 0.3, p_0 = 0.08, t_d = 0.0, p_d = 0.0;
@@ -106,8 +107,9 @@ void pma_destroy(Pma& P) {
     if (P.d_q) hipFree(P.d_q);
     if (P.d_err) hipFree(P.d_err);
     if (P.d_plans) hipFree(P.d_plans);
-    if (P.d_prefix) hipFree(P.d_prefix);
-    if (P.h_prefix) hipHostFree(P.h_prefix);
+    if (P.d_flags) hipFree(P.d_flags);
+    if (P.d_rs) hipFree(P.d_rs);
+    if (P.h_rs) hipHostFree(P.h_rs);
     if (P.d_small) hipFree(P.d_small);
     if (P.own_stream && P.stream) hipStreamDestroy(P.stream);
     P = Pma();
@@ -398,13 +400,15 @@ int64_t run_ops_parallel(Pma& P, const std::vector<Op>& ops, int32_t* err) {
     *err = 0;
     const int64_t n = (int64_t)ops.size();
     if (n == 0) return 0;
-    constexpr int GMAX = 1024, MIN_PREFIX = 12;
+    constexpr int GMAX = 1024, MIN_PREFIX = 12, ROUNDS_PER_SYNC = 12;
     ensure_ops(P, n);
     HIPCHK(hipMemcpyAsync(P.d_ops, ops.data(), (size_t)n * sizeof(Op), hipMemcpyHostToDevice, P.stream));
     if (!P.d_plans) {
         HIPCHK(hipMalloc(&P.d_plans, (size_t)GMAX * sizeof(Plan)));
-        HIPCHK(hipMalloc(&P.d_prefix, sizeof(int32_t)));
-        HIPCHK(hipHostMalloc(&P.h_prefix, sizeof(int32_t), hipHostMallocDefault));
+        HIPCHK(hipMalloc(&P.d_flags, (size_t)GMAX * sizeof(uint32_t)));
+        HIPCHK(hipMemsetAsync(P.d_flags, 0, (size_t)GMAX * sizeof(uint32_t), P.stream));
+        HIPCHK(hipMalloc(&P.d_rs, sizeof(RoundState)));
+        HIPCHK(hipHostMalloc(&P.h_rs, sizeof(RoundState), hipHostMallocDefault));
     }
     P.h_ctl->next_op = 0; P.h_ctl->status = 0; P.h_ctl->err = 0;
     upload_ctl(P);
@@ -412,23 +416,24 @@ int64_t run_ops_parallel(Pma& P, const std::vector<Op>& ops, int32_t* err) {
     int G = 256;
     bool host_ctl_stale = false;
     while (i < n) {
-        const int g = (int)std::min<int64_t>(G, n - i);
-        hipError_t e = launch_plan_resolve(P.K(), P.V(), P.O(), P.has_sems ? P.sems : nullptr, P.has_cols ? P.col_keys : nullptr,
-                                           P.has_cols ? P.col_live : nullptr, P.d_ctl, P.d_ops, i, g, P.d_plans, P.d_prefix, P.stream);
-        if (e != hipSuccess) fail(DSA_EHIP, std::string("plan launch: ") + hipGetErrorString(e));
-        HIPCHK(hipMemcpyAsync(P.h_prefix, P.d_prefix, sizeof(int32_t), hipMemcpyDeviceToHost, P.stream));
-        HIPCHK(hipStreamSynchronize(P.stream));
-        const int d = *P.h_prefix;
-        if (d >= MIN_PREFIX || (d == g && d > 0)) {
-            e = launch_apply(P.K(), P.V(), P.O(), P.has_sems ? P.sems : nullptr, P.d_ctl, P.d_ops, i, d, P.d_plans, P.stream);
-            if (e != hipSuccess) fail(DSA_EHIP, std::string("apply launch: ") + hipGetErrorString(e));
-            i += d;
-            host_ctl_stale = true;
-            seq_chunk = 64;
-            G = std::min(GMAX, std::max(64, 2 * d));
-            continue;
+        // ---- a burst of rounds driven by the device-resident cursor; one host synchronisation per burst
+        RoundState& rs = *P.h_rs;
+        std::memset(&rs, 0, sizeof(rs));
+        rs.cursor = i; rs.limit = n; rs.G = G; rs.min_prefix = MIN_PREFIX;
+        HIPCHK(hipMemcpyAsync(P.d_rs, P.h_rs, sizeof(RoundState), hipMemcpyHostToDevice, P.stream));
+        for (int r = 0; r < ROUNDS_PER_SYNC; ++r) {
+            hipError_t e = launch_round(P.K(), P.V(), P.O(), P.has_sems ? P.sems : nullptr, P.has_cols ? P.col_keys : nullptr,
+                                        P.has_cols ? P.col_live : nullptr, P.d_ctl, P.d_ops, P.d_rs, P.d_plans, P.d_flags, P.stream);
+            if (e != hipSuccess) fail(DSA_EHIP, std::string("round launch: ") + hipGetErrorString(e));
         }
-        // short prefix: sequential sequencer for ops [i, i + seq_chunk)
+        HIPCHK(hipMemcpyAsync(P.h_rs, P.d_rs, sizeof(RoundState), hipMemcpyDeviceToHost, P.stream));
+        HIPCHK(hipStreamSynchronize(P.stream));
+        if (rs.cursor > i) { host_ctl_stale = true; seq_chunk = 64; }
+        P.stat_par_rounds += rs.rounds; P.stat_par_ops += rs.par_ops;
+        i = rs.cursor;
+        G = rs.G;
+        if (rs.stop != 1) continue;                       // burst used up (0) or batch finished (2)
+        // ---- short prefix at op i: sequential sequencer for ops [i, i + seq_chunk)
         if (host_ctl_stale) { download_ctl(P); host_ctl_stale = false; }
         SeqRun r;
         r.P = &P; r.ops = &ops; r.n = std::min<int64_t>(n, i + seq_chunk); r.active = true;
@@ -436,6 +441,7 @@ int64_t run_ops_parallel(Pma& P, const std::vector<Op>& ops, int32_t* err) {
         seq_launch(r);
         while (seq_step(r)) {}
         if (r.err) { *err = r.err; return r.applied; }
+        P.stat_seq_ops += r.applied - i;
         i = r.applied;
         seq_chunk = std::min<int64_t>(seq_chunk * 2, 8192);
         G = 64;
@@ -469,6 +475,7 @@ void pma_info(Pma& P, int64_t nb_partitions_or_len, int64_t* info) {
     info[DSA_INFO_STAT_REBALANCES] = c.stat_rebalances;
     info[DSA_INFO_STAT_EXTENDS] = c.stat_extends;
     info[DSA_INFO_STAT_SHRINKS] = c.stat_shrinks;
+    info[11] = P.stat_par_rounds; info[12] = P.stat_par_ops; info[13] = P.stat_seq_ops;
 }
 
 void export_slots(Pma& P, int64_t* keys, double* vals, uint8_t* occ, int64_t cap) {

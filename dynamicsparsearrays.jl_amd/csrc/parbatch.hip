@@ -47,7 +47,12 @@ __device__ int64_t pb_wave_count(const uint64_t* occ, int64_t ws, int64_t we, bo
 
 __global__ __launch_bounds__(PB_BLOCK) void k_plan(const int64_t* keys, const double* vals, const uint64_t* occ,
                                                    const int64_t* sems, const int64_t* col_keys, const uint8_t* col_live,
-                                                   const Ctl* ctl, const Op* ops, int64_t i0, int G, Plan* plans) {
+                                                   const Ctl* ctl, const Op* ops, const RoundState* rs, Plan* plans) {
+    // the round's window of ops comes from the device-resident cursor: rounds are enqueued back to back without host syncs
+    if (rs->stop) return;
+    const int64_t i0 = rs->cursor;
+    const int64_t left = rs->limit - i0;
+    const int G = (int)(left < rs->G ? left : rs->G);
     const int w = blockIdx.x * (PB_BLOCK / 64) + (threadIdx.x >> 6);
     if (w >= G) return;
     const int64_t capacity = ctl->capacity, seg = ctl->segment_capacity, height = ctl->height;
@@ -130,29 +135,73 @@ __global__ __launch_bounds__(PB_BLOCK) void k_plan(const int64_t* keys, const do
     if (lane_id() == 0) plans[w] = pl;
 }
 
-__global__ __launch_bounds__(1024) void k_resolve(const Plan* plans, int G, int32_t* out) {
-    __shared__ int64_t sLo[1024], sHi[1024];
+// pairwise overlap test, spread over the grid: block b owns 64 candidate partners j, thread i tests op i against them
+__global__ __launch_bounds__(1024) void k_conflicts(const Plan* plans, const RoundState* rs, uint32_t* flags) {
+    if (rs->stop) return;
+    const int64_t left = rs->limit - rs->cursor;
+    const int G = (int)(left < rs->G ? left : rs->G);
+    __shared__ int64_t sLo[64], sHi[64];
+    const int i = threadIdx.x, j0 = blockIdx.x * 64;
+    if (j0 >= G) return;
+    if (i < 64) {
+        int64_t lo = 1, hi = 0;
+        if (j0 + i < G) { lo = plans[j0 + i].lo; hi = plans[j0 + i].hi; }
+        sLo[i] = lo; sHi[i] = hi;
+    }
+    __syncthreads();
+    if (i >= G) return;
+    const int64_t lo = plans[i].lo, hi = plans[i].hi;
+    if (lo > hi) return;
+    bool conflict = false;
+#pragma unroll 8
+    for (int k = 0; k < 64; ++k) {
+        const int64_t l2 = sLo[k], h2 = sHi[k];
+        conflict = conflict || (j0 + k != i && l2 <= h2 && l2 <= hi && lo <= h2);
+    }
+    if (conflict) flags[i] = 1u;
+}
+
+// prefix length d = min(second-smallest conflicting op, first barrier); advances nothing (k_advance does, after k_apply)
+__global__ __launch_bounds__(1024) void k_resolve(const Plan* plans, RoundState* rs, uint32_t* flags) {
+    if (rs->stop) return;
     __shared__ int sC0, sC1, sB;
+    const int64_t left = rs->limit - rs->cursor;
+    const int G = (int)(left < rs->G ? left : rs->G);
     const int i = threadIdx.x;
-    int act = PB_NOOP;
-    int64_t lo = 1, hi = 0;
-    if (i < G) { const Plan p = plans[i]; lo = p.lo; hi = p.hi; act = p.action; }
-    sLo[i] = lo; sHi[i] = hi;
     if (i == 0) { sC0 = G; sC1 = G; sB = G; }
     __syncthreads();
     bool conflict = false;
-    if (i < G && lo <= hi) {
-        for (int j = 0; j < G; ++j) {
-            const int64_t l2 = sLo[j], h2 = sHi[j];
-            if (j != i && l2 <= h2 && l2 <= hi && lo <= h2) { conflict = true; break; }
-        }
+    if (i < G) {
+        conflict = flags[i] != 0u;
+        flags[i] = 0u;                                               // re-armed for the next round
+        if (conflict) atomicMin(&sC0, i);
+        if (plans[i].action == PB_BARRIER) atomicMin(&sB, i);
     }
-    if (conflict) atomicMin(&sC0, i);
-    if (i < G && act == PB_BARRIER) atomicMin(&sB, i);
     __syncthreads();
     if (conflict && i > sC0) atomicMin(&sC1, i);
     __syncthreads();
-    if (i == 0) { const int d = sC1 < sB ? sC1 : sB; out[0] = d < G ? d : G; }
+    if (i == 0) {
+        int d = sC1 < sB ? sC1 : sB;
+        if (d > G) d = G;
+        // a short prefix means the ops around the cursor collide (appends, one hot key): hand over to the sequencer
+        if (d < rs->min_prefix && d < G) { rs->stop = 1; rs->d = 0; }
+        else rs->d = d;
+        rs->g_used = G;
+    }
+}
+
+// after k_apply: move the cursor and adapt the group size to the observed prefix length
+__global__ void k_advance(RoundState* rs) {
+    if (threadIdx.x != 0 || blockIdx.x != 0 || rs->stop) return;
+    const int d = rs->d;
+    rs->cursor += d;
+    rs->rounds += 1; rs->par_ops += d;
+    int G = 2 * d;
+    if (G < 64) G = 64;
+    if (G > 1024) G = 1024;
+    rs->G = G;
+    rs->d = 0;
+    if (rs->cursor >= rs->limit) rs->stop = 2;                       // finished
 }
 
 // ---- apply ----------------------------------------------------------------------------------------------------------
@@ -273,8 +322,11 @@ __device__ void pb_wave_rebalance(int64_t* keys, double* vals, uint64_t* occ, in
 }
 
 __global__ __launch_bounds__(PB_BLOCK) void k_apply(int64_t* keys, double* vals, uint64_t* occ, int64_t* sems, Ctl* ctl,
-                                                    const Op* ops, int64_t i0, int d, const Plan* plans) {
+                                                    const Op* ops, const RoundState* rs, const Plan* plans) {
     extern __shared__ __attribute__((aligned(16))) unsigned char pb_lds[];
+    if (rs->stop) return;
+    const int64_t i0 = rs->cursor;
+    const int d = rs->d;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int w = blockIdx.x * (PB_BLOCK / 64) + wv;
     if (w >= d) return;
@@ -330,17 +382,9 @@ __global__ __launch_bounds__(PB_BLOCK) void k_apply(int64_t* keys, double* vals,
     }
 }
 
-hipError_t launch_plan_resolve(const int64_t* keys, const double* vals, const uint64_t* occ, const int64_t* sems,
-                               const int64_t* col_keys, const uint8_t* col_live, const Ctl* ctl, const Op* ops,
-                               int64_t i0, int G, Plan* plans, int32_t* d_out, hipStream_t stream) {
-    hipLaunchKernelGGL(k_plan, dim3((unsigned)((G + 3) / 4)), dim3(PB_BLOCK), 0, stream, keys, vals, occ, sems, col_keys, col_live,
-                       ctl, ops, i0, G, plans);
-    hipLaunchKernelGGL(k_resolve, dim3(1), dim3(1024), 0, stream, plans, G, d_out);
-    return hipGetLastError();
-}
-
-hipError_t launch_apply(int64_t* keys, double* vals, uint64_t* occ, int64_t* sems, Ctl* ctl, const Op* ops, int64_t i0, int d,
-                        const Plan* plans, hipStream_t stream) {
+// one round = plan -> conflicts -> resolve -> apply -> advance, all driven by the device-resident RoundState
+hipError_t launch_round(int64_t* keys, double* vals, uint64_t* occ, int64_t* sems, const int64_t* col_keys, const uint8_t* col_live,
+                        Ctl* ctl, const Op* ops, RoundState* rs, Plan* plans, uint32_t* flags, hipStream_t stream) {
     static bool configured = false;
     const size_t lds = (size_t)(PB_BLOCK / 64) * PB_MAX_W * (sizeof(int64_t) + sizeof(double));
     if (!configured) {
@@ -348,7 +392,12 @@ hipError_t launch_apply(int64_t* keys, double* vals, uint64_t* occ, int64_t* sem
         if (e != hipSuccess) return e;
         configured = true;
     }
-    hipLaunchKernelGGL(k_apply, dim3((unsigned)((d + 3) / 4)), dim3(PB_BLOCK), lds, stream, keys, vals, occ, sems, ctl, ops, i0, d, plans);
+    constexpr int GMAX = 1024;
+    hipLaunchKernelGGL(k_plan, dim3(GMAX / 4), dim3(PB_BLOCK), 0, stream, keys, vals, occ, sems, col_keys, col_live, ctl, ops, rs, plans);
+    hipLaunchKernelGGL(k_conflicts, dim3(GMAX / 64), dim3(1024), 0, stream, plans, rs, flags);
+    hipLaunchKernelGGL(k_resolve, dim3(1), dim3(1024), 0, stream, plans, rs, flags);
+    hipLaunchKernelGGL(k_apply, dim3(GMAX / 4), dim3(PB_BLOCK), lds, stream, keys, vals, occ, sems, ctl, ops, rs, plans);
+    hipLaunchKernelGGL(k_advance, dim3(1), dim3(64), 0, stream, rs);
     return hipGetLastError();
 }
 

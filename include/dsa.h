@@ -58,6 +58,9 @@ enum {
     DSA_INFO_STAT_REBALANCES = 8, /* instrumentation: number of pack/spread windows so far */
     DSA_INFO_STAT_EXTENDS = 9,
     DSA_INFO_STAT_SHRINKS = 10,
+    DSA_INFO_STAT_PAR_ROUNDS = 11, /* batch-parallel rounds / ops applied in parallel / ops applied by the sequencer */
+    DSA_INFO_STAT_PAR_OPS = 12,
+    DSA_INFO_STAT_SEQ_OPS = 13,
     DSA_INFO_COUNT = 16
 };
 

@@ -24,6 +24,7 @@ print("%-40s %7.2f us/op" % ("single-op calls (host round trip each)", (time.per
 odd = np.unique(1 + 2 * (bench.splitmix_array(4, 120000) % np.uint64(700000)).astype(np.int64))[:100000]
 rng.shuffle(odd)
 t("uniform inserts (new keys)", odd, bench.unit12(4, len(odd)))
+print({k: v.info()[k] for k in ("stat_par_rounds", "stat_par_ops", "stat_seq_ops")})
 t("delete them again", odd, np.zeros(len(odd)))
 
 # matrix: random updates on an existing 20k x 30k structure (both orientations), batch-parallel vs sequential
