@@ -206,7 +206,7 @@ struct RoundState {
     int32_t G;             // ops planned per round (adapted on the device to 2x the last prefix, 64..1024)
     int32_t d;             // prefix length decided by k_resolve for the round in flight
     int32_t stop;          // 0 running, 1 short prefix at `cursor` (sequencer must take over), 2 batch finished
-    int32_t min_prefix, g_used, pad;
+    int32_t min_prefix, G_next, pad;
     int64_t rounds, par_ops;
 };
 hipError_t launch_round(int64_t* keys, double* vals, uint64_t* occ, int64_t* sems, const int64_t* col_keys, const uint8_t* col_live,

@@ -428,9 +428,11 @@ int64_t run_ops_parallel(Pma& P, const std::vector<Op>& ops, int32_t* err) {
         }
         HIPCHK(hipMemcpyAsync(P.h_rs, P.d_rs, sizeof(RoundState), hipMemcpyDeviceToHost, P.stream));
         HIPCHK(hipStreamSynchronize(P.stream));
-        if (rs.cursor > i) { host_ctl_stale = true; seq_chunk = 64; }
-        P.stat_par_rounds += rs.rounds; P.stat_par_ops += rs.par_ops;
-        i = rs.cursor;
+        // the prefix of the last round of the burst has been applied but is folded into the cursor only by the next k_resolve
+        const int64_t reached = rs.cursor + rs.d;
+        if (reached > i) { host_ctl_stale = true; seq_chunk = 64; }
+        P.stat_par_rounds += rs.rounds + (rs.d > 0 ? 1 : 0); P.stat_par_ops += rs.par_ops + rs.d;
+        i = reached;
         G = rs.G;
         if (rs.stop != 1) continue;                       // burst used up (0) or batch finished (2)
         // ---- short prefix at op i: sequential sequencer for ops [i, i + seq_chunk)

@@ -50,7 +50,7 @@ __global__ __launch_bounds__(PB_BLOCK) void k_plan(const int64_t* keys, const do
                                                    const Ctl* ctl, const Op* ops, const RoundState* rs, Plan* plans) {
     // the round's window of ops comes from the device-resident cursor: rounds are enqueued back to back without host syncs
     if (rs->stop) return;
-    const int64_t i0 = rs->cursor;
+    const int64_t i0 = rs->cursor + rs->d;            // k_resolve of this round folds the previous prefix into the cursor
     const int64_t left = rs->limit - i0;
     const int G = (int)(left < rs->G ? left : rs->G);
     const int w = blockIdx.x * (PB_BLOCK / 64) + (threadIdx.x >> 6);
@@ -138,7 +138,7 @@ __global__ __launch_bounds__(PB_BLOCK) void k_plan(const int64_t* keys, const do
 // pairwise overlap test, spread over the grid: block b owns 64 candidate partners j, thread i tests op i against them
 __global__ __launch_bounds__(1024) void k_conflicts(const Plan* plans, const RoundState* rs, uint32_t* flags) {
     if (rs->stop) return;
-    const int64_t left = rs->limit - rs->cursor;
+    const int64_t left = rs->limit - (rs->cursor + rs->d);
     const int G = (int)(left < rs->G ? left : rs->G);
     __shared__ int64_t sLo[64], sHi[64];
     const int i = threadIdx.x, j0 = blockIdx.x * 64;
@@ -161,11 +161,14 @@ __global__ __launch_bounds__(1024) void k_conflicts(const Plan* plans, const Rou
     if (conflict) flags[i] = 1u;
 }
 
-// prefix length d = min(second-smallest conflicting op, first barrier); advances nothing (k_advance does, after k_apply)
+// single workgroup: (1) folds the previous round's prefix into the cursor, (2) decides this round's prefix
+// d = min(second-smallest conflicting op, first barrier) and the next group size.  k_apply then works on (cursor, d).
 __global__ __launch_bounds__(1024) void k_resolve(const Plan* plans, RoundState* rs, uint32_t* flags) {
     if (rs->stop) return;
     __shared__ int sC0, sC1, sB;
-    const int64_t left = rs->limit - rs->cursor;
+    const int d_prev = rs->d;
+    const int64_t i0 = rs->cursor + d_prev;
+    const int64_t left = rs->limit - i0;
     const int G = (int)(left < rs->G ? left : rs->G);
     const int i = threadIdx.x;
     if (i == 0) { sC0 = G; sC1 = G; sB = G; }
@@ -181,27 +184,19 @@ __global__ __launch_bounds__(1024) void k_resolve(const Plan* plans, RoundState*
     if (conflict && i > sC0) atomicMin(&sC1, i);
     __syncthreads();
     if (i == 0) {
+        rs->cursor = i0;
+        if (d_prev > 0) { rs->rounds += 1; rs->par_ops += d_prev; }
+        if (left <= 0) { rs->stop = 2; rs->d = 0; return; }          // finished
         int d = sC1 < sB ? sC1 : sB;
         if (d > G) d = G;
         // a short prefix means the ops around the cursor collide (appends, one hot key): hand over to the sequencer
-        if (d < rs->min_prefix && d < G) { rs->stop = 1; rs->d = 0; }
-        else rs->d = d;
-        rs->g_used = G;
+        if (d < rs->min_prefix && d < G) { rs->stop = 1; rs->d = 0; return; }
+        rs->d = d;
+        int Gn = 2 * d;
+        if (Gn < 64) Gn = 64;
+        if (Gn > 1024) Gn = 1024;
+        rs->G_next = Gn;
     }
-}
-
-// after k_apply: move the cursor and adapt the group size to the observed prefix length
-__global__ void k_advance(RoundState* rs) {
-    if (threadIdx.x != 0 || blockIdx.x != 0 || rs->stop) return;
-    const int d = rs->d;
-    rs->cursor += d;
-    rs->rounds += 1; rs->par_ops += d;
-    int G = 2 * d;
-    if (G < 64) G = 64;
-    if (G > 1024) G = 1024;
-    rs->G = G;
-    rs->d = 0;
-    if (rs->cursor >= rs->limit) rs->stop = 2;                       // finished
 }
 
 // ---- apply ----------------------------------------------------------------------------------------------------------
@@ -329,6 +324,7 @@ __global__ __launch_bounds__(PB_BLOCK) void k_apply(int64_t* keys, double* vals,
     const int d = rs->d;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int w = blockIdx.x * (PB_BLOCK / 64) + wv;
+    if (w == 0 && lane == 0) const_cast<RoundState*>(rs)->G = rs->G_next;     // group size of the NEXT round (G is not read any more)
     if (w >= d) return;
     int64_t* sK = reinterpret_cast<int64_t*>(pb_lds) + (size_t)wv * PB_MAX_W;
     double* sV = reinterpret_cast<double*>(pb_lds + (size_t)(PB_BLOCK / 64) * PB_MAX_W * sizeof(int64_t)) + (size_t)wv * PB_MAX_W;
@@ -382,7 +378,7 @@ __global__ __launch_bounds__(PB_BLOCK) void k_apply(int64_t* keys, double* vals,
     }
 }
 
-// one round = plan -> conflicts -> resolve -> apply -> advance, all driven by the device-resident RoundState
+// one round = plan -> conflicts -> resolve (+ cursor advance) -> apply, all driven by the device-resident RoundState
 hipError_t launch_round(int64_t* keys, double* vals, uint64_t* occ, int64_t* sems, const int64_t* col_keys, const uint8_t* col_live,
                         Ctl* ctl, const Op* ops, RoundState* rs, Plan* plans, uint32_t* flags, hipStream_t stream) {
     static bool configured = false;
@@ -397,7 +393,6 @@ hipError_t launch_round(int64_t* keys, double* vals, uint64_t* occ, int64_t* sem
     hipLaunchKernelGGL(k_conflicts, dim3(GMAX / 64), dim3(1024), 0, stream, plans, rs, flags);
     hipLaunchKernelGGL(k_resolve, dim3(1), dim3(1024), 0, stream, plans, rs, flags);
     hipLaunchKernelGGL(k_apply, dim3(GMAX / 4), dim3(PB_BLOCK), lds, stream, keys, vals, occ, sems, ctl, ops, rs, plans);
-    hipLaunchKernelGGL(k_advance, dim3(1), dim3(64), 0, stream, rs);
     return hipGetLastError();
 }
 
