@@ -209,8 +209,15 @@ struct RoundState {
     int32_t min_prefix, G_next, pad;
     int64_t rounds, par_ops;
 };
-hipError_t launch_round(int64_t* keys, double* vals, uint64_t* occ, int64_t* sems, const int64_t* col_keys, const uint8_t* col_live,
-                        Ctl* ctl, const Op* ops, RoundState* rs, Plan* plans, uint32_t* flags, hipStream_t stream);
+struct BurstGraph {        // cached hipGraph of one burst of rounds (host-side)
+    hipGraphExec_t exec = nullptr; hipGraph_t graph = nullptr; hipStream_t stream = nullptr;
+    const void* key[12] = {};
+    bool disabled = false;
+};
+hipError_t launch_burst(int64_t* keys, double* vals, uint64_t* occ, int64_t* sems, const int64_t* col_keys, const uint8_t* col_live,
+                        Ctl* ctl, const Op* ops, RoundState* rs, Plan* plans, uint32_t* flags, int rounds, BurstGraph* cache,
+                        hipStream_t stream);
+void burst_graph_destroy(BurstGraph* cache);
 
 // batched read-only lookups.  mode 0: getindex(pma, key) ; 1: getindex(pcsc, key, partition) ;
 // 2: getindex(mpcsc, row, col).  err_out: first error code (0 if none)

@@ -72,6 +72,7 @@ struct Pma {
     double* d_q = nullptr; int64_t q_cap = 0;      // scratch for lookups (3 arrays of q_cap)
     int32_t* d_err = nullptr;
     int64_t stat_par_rounds = 0, stat_par_ops = 0, stat_seq_ops = 0;      // batch-parallel instrumentation
+    BurstGraph burst;
     Plan* d_plans = nullptr; uint32_t* d_flags = nullptr; RoundState* d_rs = nullptr; RoundState* h_rs = nullptr;   // batch-parallel writes
     int64_t* d_small = nullptr;                     // 8 x int64 scratch
     // thresholds  src/pma.jl:58,70,87
@@ -106,6 +107,7 @@ void pma_destroy(Pma& P) {
     if (P.d_ops) hipFree(P.d_ops);
     if (P.d_q) hipFree(P.d_q);
     if (P.d_err) hipFree(P.d_err);
+    burst_graph_destroy(&P.burst);
     if (P.d_plans) hipFree(P.d_plans);
     if (P.d_flags) hipFree(P.d_flags);
     if (P.d_rs) hipFree(P.d_rs);
@@ -421,10 +423,11 @@ int64_t run_ops_parallel(Pma& P, const std::vector<Op>& ops, int32_t* err) {
         std::memset(&rs, 0, sizeof(rs));
         rs.cursor = i; rs.limit = n; rs.G = G; rs.min_prefix = MIN_PREFIX;
         HIPCHK(hipMemcpyAsync(P.d_rs, P.h_rs, sizeof(RoundState), hipMemcpyHostToDevice, P.stream));
-        for (int r = 0; r < ROUNDS_PER_SYNC; ++r) {
-            hipError_t e = launch_round(P.K(), P.V(), P.O(), P.has_sems ? P.sems : nullptr, P.has_cols ? P.col_keys : nullptr,
-                                        P.has_cols ? P.col_live : nullptr, P.d_ctl, P.d_ops, P.d_rs, P.d_plans, P.d_flags, P.stream);
-            if (e != hipSuccess) fail(DSA_EHIP, std::string("round launch: ") + hipGetErrorString(e));
+        {
+            hipError_t e = launch_burst(P.K(), P.V(), P.O(), P.has_sems ? P.sems : nullptr, P.has_cols ? P.col_keys : nullptr,
+                                        P.has_cols ? P.col_live : nullptr, P.d_ctl, P.d_ops, P.d_rs, P.d_plans, P.d_flags,
+                                        ROUNDS_PER_SYNC, &P.burst, P.stream);
+            if (e != hipSuccess) fail(DSA_EHIP, std::string("burst launch: ") + hipGetErrorString(e));
         }
         HIPCHK(hipMemcpyAsync(P.h_rs, P.d_rs, sizeof(RoundState), hipMemcpyDeviceToHost, P.stream));
         HIPCHK(hipStreamSynchronize(P.stream));

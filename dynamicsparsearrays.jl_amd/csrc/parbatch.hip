@@ -379,21 +379,73 @@ __global__ __launch_bounds__(PB_BLOCK) void k_apply(int64_t* keys, double* vals,
 }
 
 // one round = plan -> conflicts -> resolve (+ cursor advance) -> apply, all driven by the device-resident RoundState
-hipError_t launch_round(int64_t* keys, double* vals, uint64_t* occ, int64_t* sems, const int64_t* col_keys, const uint8_t* col_live,
-                        Ctl* ctl, const Op* ops, RoundState* rs, Plan* plans, uint32_t* flags, hipStream_t stream) {
+static hipError_t configure_apply() {
     static bool configured = false;
-    const size_t lds = (size_t)(PB_BLOCK / 64) * PB_MAX_W * (sizeof(int64_t) + sizeof(double));
     if (!configured) {
+        const size_t lds = (size_t)(PB_BLOCK / 64) * PB_MAX_W * (sizeof(int64_t) + sizeof(double));
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_apply), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         configured = true;
     }
+    return hipSuccess;
+}
+static hipError_t enqueue_round(int64_t* keys, double* vals, uint64_t* occ, int64_t* sems, const int64_t* col_keys,
+                                const uint8_t* col_live, Ctl* ctl, const Op* ops, RoundState* rs, Plan* plans, uint32_t* flags,
+                                hipStream_t stream) {
+    const size_t lds = (size_t)(PB_BLOCK / 64) * PB_MAX_W * (sizeof(int64_t) + sizeof(double));
     constexpr int GMAX = 1024;
     hipLaunchKernelGGL(k_plan, dim3(GMAX / 4), dim3(PB_BLOCK), 0, stream, keys, vals, occ, sems, col_keys, col_live, ctl, ops, rs, plans);
     hipLaunchKernelGGL(k_conflicts, dim3(GMAX / 64), dim3(1024), 0, stream, plans, rs, flags);
     hipLaunchKernelGGL(k_resolve, dim3(1), dim3(1024), 0, stream, plans, rs, flags);
     hipLaunchKernelGGL(k_apply, dim3(GMAX / 4), dim3(PB_BLOCK), lds, stream, keys, vals, occ, sems, ctl, ops, rs, plans);
     return hipGetLastError();
+}
+
+// A burst of `rounds` rounds.  The launch sequence depends only on pointers, so it is captured once into a hipGraph and
+// replayed (one graph launch instead of 4 x rounds kernel launches: the rounds are launch-bound); re-captured when a buffer
+// moves (root rebalance swaps the slot buffers, a bigger batch re-allocates the op array).  Falls back to eager launches
+// when the stream cannot be captured.
+hipError_t launch_burst(int64_t* keys, double* vals, uint64_t* occ, int64_t* sems, const int64_t* col_keys, const uint8_t* col_live,
+                        Ctl* ctl, const Op* ops, RoundState* rs, Plan* plans, uint32_t* flags, int rounds, BurstGraph* cache,
+                        hipStream_t stream) {
+    hipError_t e = configure_apply();
+    if (e != hipSuccess) return e;
+    const void* key[12] = {keys, vals, occ, sems, col_keys, col_live, ctl, ops, rs, plans, flags, (const void*)(intptr_t)rounds};
+    bool same = cache->exec != nullptr && cache->stream == stream;
+    for (int k = 0; k < 12 && same; ++k) same = cache->key[k] == key[k];
+    if (!same && !cache->disabled) {
+        if (cache->exec) { (void)hipGraphExecDestroy(cache->exec); cache->exec = nullptr; }
+        if (cache->graph) { (void)hipGraphDestroy(cache->graph); cache->graph = nullptr; }
+        if (hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+            for (int r = 0; r < rounds; ++r) (void)enqueue_round(keys, vals, occ, sems, col_keys, col_live, ctl, ops, rs, plans, flags, stream);
+            hipGraph_t g = nullptr;
+            e = hipStreamEndCapture(stream, &g);
+            if (e == hipSuccess && g != nullptr && hipGraphInstantiate(&cache->exec, g, nullptr, nullptr, 0) == hipSuccess) {
+                cache->graph = g;
+                for (int k = 0; k < 12; ++k) cache->key[k] = key[k];
+                cache->stream = stream;
+            } else {
+                if (g) (void)hipGraphDestroy(g);
+                cache->exec = nullptr; cache->disabled = true;
+                (void)hipGetLastError();
+            }
+        } else {
+            cache->disabled = true;
+            (void)hipGetLastError();
+        }
+    }
+    if (cache->exec != nullptr && !cache->disabled) return hipGraphLaunch(cache->exec, stream);
+    for (int r = 0; r < rounds; ++r) {
+        e = enqueue_round(keys, vals, occ, sems, col_keys, col_live, ctl, ops, rs, plans, flags, stream);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+void burst_graph_destroy(BurstGraph* cache) {
+    if (cache->exec) (void)hipGraphExecDestroy(cache->exec);
+    if (cache->graph) (void)hipGraphDestroy(cache->graph);
+    *cache = BurstGraph();
 }
 
 }  // namespace dsa
