@@ -84,11 +84,18 @@ def main():
     if world != args.gpus:
         if rank == 0:
             print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    # DSA_BENCH_SAME_GPU=1 + DSA_BENCH_BACKEND=gloo: dev-only way to exercise the multi-rank code path on a 1-GPU box
+    if os.environ.get("DSA_BENCH_SAME_GPU") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        backend = os.environ.get("DSA_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
 
     import dsa_loader
     dsa = dsa_loader.load()
