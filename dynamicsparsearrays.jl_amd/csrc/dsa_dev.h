@@ -26,7 +26,9 @@ enum SeqStatus : int32_t {
     SEQ_Y_EXTEND = 2,      // root density > t  -> _extend!  (src/pma.jl:143-151) then root rebalance
     SEQ_Y_SHRINK = 3,      // root density < p  -> pack + _shrink! (src/pma.jl:135-139,153-161)
     SEQ_Y_TABLE_GROW = 4,  // semaphore / col_keys tables are full; re-run the op after growing
-    SEQ_ERROR = 5
+    SEQ_ERROR = 5,
+    SEQ_Y_APPEND_RUN = 6   // ops [y_ws, y_ws+y_m) are ascending appends behind the y_we cells: the host saves the bitmap, runs
+                           // k_append_run (bitmap-only replay) and K-permute (one move per cell), then relaunches
 };
 
 struct Ctl {
@@ -45,6 +47,8 @@ struct Ctl {
     int64_t err_op;
     // instrumentation
     int64_t stat_window_slots, stat_rebalances, stat_extends, stat_shrinks, stat_small_rebalances;
+    int64_t no_run_at;     // op index that must take the normal path (an append run made no progress there), or -1
+    int64_t dbg[6];        // append-run profile of the last run: slow ops, ticks (100 MHz) in setup / fast loop / slow path, blocks loaded
     // vector length n (src/vector.jl:2) is host-only
 };
 
@@ -162,6 +166,11 @@ hipError_t launch_rebalance(const int64_t* src_keys, const double* src_vals, con
                             int64_t* dst_keys, double* dst_vals, uint64_t* dst_occ,
                             int64_t dst_ws, int64_t dst_we, int64_t m, int64_t* sems,
                             RebalanceWork* work, hipStream_t stream);
+// K-permute: order-preserving move of the n0 cells of (src, src_occ) followed by the cells of ops[i0..] to the set bits of
+// dst_occ (already final), writing dst keys / vals and, if sems != nullptr, the semaphore table
+hipError_t launch_permute(const int64_t* src_keys, const double* src_vals, const uint64_t* src_occ, int64_t src_cap,
+                          int64_t* dst_keys, double* dst_vals, const uint64_t* dst_occ, int64_t dst_cap, int64_t n0,
+                          const Op* ops, int64_t i0, int64_t* sems, RebalanceWork* wsrc, RebalanceWork* wdst, hipStream_t stream);
 // K-pack: occupied cells of slots [from, to] (1-based, inclusive), in slot order, to dense device buffers of capacity out_cap;
 // *count (host) receives the number of cells.  Synchronises the stream once (count needed to size the copy-out).
 hipError_t launch_compact_range(const int64_t* keys, const double* vals, const uint64_t* occ, int64_t from, int64_t to,
@@ -187,8 +196,15 @@ hipError_t build_emit(const double* d_val, int32_t combine, BuildScratch& s, int
                       int64_t* part_keys, int mode, int64_t nparts_explicit, hipStream_t stream);
 void build_abort(BuildScratch& s);
 
+// n_avail >= n_ops: ops resident behind the chunk (an append run may consume them); run_ok enables append-run detection
 hipError_t launch_sequencer(int64_t* keys, double* vals, uint64_t* occ, int64_t* sems, int64_t* col_keys,
-                            uint8_t* col_live, Ctl* ctl, const Op* ops, int64_t n_ops, hipStream_t stream);
+                            uint8_t* col_live, Ctl* ctl, const Op* ops, int64_t n_ops, int64_t n_avail, bool run_ok,
+                            hipStream_t stream);
+// flags / d_T: cell types and cell count written by k_run_expand (MappedPackedCSC runs), nullptr for a vector run
+hipError_t launch_append_run(uint64_t* occ, Ctl* ctl, int64_t i0, int64_t R, const uint64_t* flags, const int64_t* d_T,
+                             hipStream_t stream);
+hipError_t launch_run_expand(const Op* ops, int64_t i0, int64_t R, const Ctl* ctl, int64_t* col_keys, uint8_t* col_live, Op* cells,
+                             uint64_t* flags, int64_t* out, hipStream_t stream);
 
 // ---- batch-parallel writes of a vector's PMA (parbatch.hip) ------------------------------------------------------------
 struct Plan {

@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <numeric>
 #include <string>
@@ -42,6 +43,8 @@ struct Fail { int32_t code; std::string msg; };
     return DSA_OK;
 
 int g_device = 0;
+// dev knob: DSA_APPEND_RUNS=0 sends ascending append runs through the per-op sequencer path (A/B measurements)
+const bool g_append_runs = [] { const char* e = getenv("DSA_APPEND_RUNS"); return !(e && e[0] == '0'); }();
 
 // capacity = 2^ceil(Int, log2(ceil(n / t_h)))   src/pma.jl:64,81,88 (Float64 arithmetic, App. A.1)
 int64_t capacity_for(int64_t n) {
@@ -68,6 +71,9 @@ struct Pma {
     Ctl* d_ctl = nullptr;
     Ctl* h_ctl = nullptr;         // pinned host mirror
     RebalanceWork work{nullptr, nullptr, 0};
+    RebalanceWork work2{nullptr, nullptr, 0};   // second prefix table of K-permute (old and new bitmap)
+    uint64_t* occ_old = nullptr;                // bitmap saved by the sequencer at the start of an append run
+    Op* run_cells = nullptr; uint64_t* run_flags = nullptr; int64_t* run_out = nullptr; int64_t run_cap = 0;   // cell stream of a MappedPackedCSC append run
     Op* d_ops = nullptr; int64_t ops_cap = 0;
     double* d_q = nullptr; int64_t q_cap = 0;      // scratch for lookups (3 arrays of q_cap)
     int32_t* d_err = nullptr;
@@ -94,6 +100,11 @@ void pma_free_buffers(Pma& P) {
     if (P.work.tile_cnt) hipFree(P.work.tile_cnt);
     if (P.work.tile_off) hipFree(P.work.tile_off);
     P.work = RebalanceWork{nullptr, nullptr, 0};
+    if (P.work2.tile_cnt) hipFree(P.work2.tile_cnt);
+    if (P.work2.tile_off) hipFree(P.work2.tile_off);
+    P.work2 = RebalanceWork{nullptr, nullptr, 0};
+    if (P.occ_old) hipFree(P.occ_old);
+    P.occ_old = nullptr;
 }
 
 void pma_destroy(Pma& P) {
@@ -113,6 +124,9 @@ void pma_destroy(Pma& P) {
     if (P.d_rs) hipFree(P.d_rs);
     if (P.h_rs) hipHostFree(P.h_rs);
     if (P.d_small) hipFree(P.d_small);
+    if (P.run_cells) hipFree(P.run_cells);
+    if (P.run_flags) hipFree(P.run_flags);
+    if (P.run_out) hipFree(P.run_out);
     if (P.own_stream && P.stream) hipStreamDestroy(P.stream);
     P = Pma();
 }
@@ -135,6 +149,12 @@ void alloc_work(Pma& P, int64_t slots) {
     P.work.tiles_cap = slots / 4096 + 8;
     HIPCHK(hipMalloc(&P.work.tile_cnt, (size_t)P.work.tiles_cap * sizeof(uint32_t)));
     HIPCHK(hipMalloc(&P.work.tile_off, (size_t)P.work.tiles_cap * sizeof(uint32_t)));
+    if (P.work2.tile_cnt) { hipFree(P.work2.tile_cnt); hipFree(P.work2.tile_off); }
+    P.work2.tiles_cap = P.work.tiles_cap;
+    HIPCHK(hipMalloc(&P.work2.tile_cnt, (size_t)P.work2.tiles_cap * sizeof(uint32_t)));
+    HIPCHK(hipMalloc(&P.work2.tile_off, (size_t)P.work2.tiles_cap * sizeof(uint32_t)));
+    if (P.occ_old) hipFree(P.occ_old);
+    HIPCHK(hipMalloc(&P.occ_old, (size_t)occ_words_for(slots) * sizeof(uint64_t)));
 }
 
 void pma_init_common(Pma& P, bool sems, bool cols) {
@@ -289,6 +309,23 @@ void build_from_packed(Pma& P, const std::vector<int64_t>& keys, const std::vect
     upload_ctl(P);
 }
 
+// An append run was simulated on the bitmap of the current buffer (sequencer.hip): the y_we cells that existed before the
+// run (positions: saved bitmap occ_old) followed by the cells cells[i0..] move to the set bits of the current bitmap,
+// written into the alternate buffer, which becomes current.
+void permute_run(Pma& P, const Op* cells, int64_t i0, int64_t n0) {
+    const int alt = 1 - P.cur;
+    const int64_t cap = P.capacity();
+    hipError_t e = launch_permute(P.K(), P.V(), P.occ_old, cap, P.keys[alt], P.vals[alt], P.O(), cap, n0, cells, i0,
+                                  P.has_sems ? P.sems : nullptr, &P.work, &P.work2, P.stream);
+    if (e != hipSuccess) fail(DSA_EHIP, std::string("permute launch: ") + hipGetErrorString(e));
+    const int64_t words = (cap + 63) / 64;
+    HIPCHK(hipMemcpyAsync(P.occ[alt], P.O(), (size_t)words * sizeof(uint64_t), hipMemcpyDeviceToDevice, P.stream));
+    if (words < P.occ_dirty[alt])
+        HIPCHK(hipMemsetAsync(P.occ[alt] + words, 0, (size_t)(P.occ_dirty[alt] - words) * sizeof(uint64_t), P.stream));
+    P.occ_dirty[alt] = words;
+    P.cur = alt;
+}
+
 void ensure_ops(Pma& P, int64_t n) {
     if (n <= P.ops_cap) return;
     if (P.d_ops) hipFree(P.d_ops);
@@ -315,18 +352,20 @@ struct SeqRun {
     Pma* P = nullptr;
     const std::vector<Op>* ops = nullptr;
     int64_t n = 0;
+    int64_t n_avail = 0;     // ops resident in d_ops (>= n): an append run may consume ops beyond the chunk
     bool active = false;
     int32_t err = 0;         // status of the failing op (0 if none)
     int64_t applied = 0;     // ops fully applied
     int64_t guard = 0;
 };
 
-void seq_launch(SeqRun& r) {
+void seq_launch(SeqRun& r, bool upload = true) {
     Pma& P = *r.P;
     // pinned h_ctl: H2D, kernel and D2H are stream-ordered; the host does not touch h_ctl until the next synchronize
-    HIPCHK(hipMemcpyAsync(P.d_ctl, P.h_ctl, sizeof(Ctl), hipMemcpyHostToDevice, P.stream));
+    if (upload) HIPCHK(hipMemcpyAsync(P.d_ctl, P.h_ctl, sizeof(Ctl), hipMemcpyHostToDevice, P.stream));
     hipError_t e = launch_sequencer(P.K(), P.V(), P.O(), P.has_sems ? P.sems : nullptr, P.has_cols ? P.col_keys : nullptr,
-                                    P.has_cols ? P.col_live : nullptr, P.d_ctl, P.d_ops, r.n, P.stream);
+                                    P.has_cols ? P.col_live : nullptr, P.d_ctl, P.d_ops, r.n, std::max(r.n, r.n_avail),
+                                    g_append_runs && P.occ_old != nullptr, P.stream);
     if (e != hipSuccess) fail(DSA_EHIP, std::string("sequencer launch: ") + hipGetErrorString(e));
     HIPCHK(hipMemcpyAsync(P.h_ctl, P.d_ctl, sizeof(Ctl), hipMemcpyDeviceToHost, P.stream));
 }
@@ -337,7 +376,7 @@ void seq_start(SeqRun& r, Pma& P, const std::vector<Op>& ops) {
     if (r.n == 0) return;
     ensure_ops(P, r.n);
     HIPCHK(hipMemcpyAsync(P.d_ops, ops.data(), (size_t)r.n * sizeof(Op), hipMemcpyHostToDevice, P.stream));
-    P.h_ctl->next_op = 0; P.h_ctl->status = 0; P.h_ctl->err = 0;
+    P.h_ctl->next_op = 0; P.h_ctl->status = 0; P.h_ctl->err = 0; P.h_ctl->no_run_at = -1;
     r.active = true;
     seq_launch(r);
 }
@@ -350,7 +389,7 @@ bool seq_step(SeqRun& r) {
     Ctl& c = *P.h_ctl;
     switch (c.status) {
         case SEQ_DONE:
-            r.applied = r.n; r.active = false;
+            r.applied = std::max(r.n, c.next_op); r.active = false;
             return false;
         case SEQ_ERROR:
             r.err = seq_err_to_status(c.err); r.applied = c.next_op; r.active = false;
@@ -377,6 +416,38 @@ bool seq_step(SeqRun& r) {
         case SEQ_Y_TABLE_GROW:
             ensure_tables(P, c.table_len + 1);
             break;
+        case SEQ_Y_APPEND_RUN: {
+            if (getenv("DSA_DBG_RUN") && c.dbg[4])
+                fprintf(stderr, "[previous append run] ops=%lld slow=%lld fast=%.1fus slow=%.1fus shader clock %.0f MHz\n", (long long)c.dbg[4],
+                        (long long)c.dbg[0], c.dbg[2] / 100.0, c.dbg[3] / 100.0, c.dbg[5] ? 100.0 * c.dbg[1] / c.dbg[5] : 0.0);
+            // save the bitmap, replay the run on the live bitmap, move the cells; all stream-ordered, no host wait.  The
+            // device control block is authoritative afterwards (next_op, nb_elements, tables, statistics): no upload on relaunch.
+            const int64_t words = (c.capacity + 63) / 64;
+            const int64_t i0 = c.y_ws, R = c.y_m, n0 = c.y_we;
+            hipError_t e;
+            if (P.has_cols) {
+                // MappedPackedCSC run: at most R new columns; expand the ops into the cell stream (semaphore cells included)
+                ensure_tables(P, c.table_len + R + 1);
+                if (2 * R + 1024 > P.run_cap) {
+                    if (P.run_cells) hipFree(P.run_cells);
+                    if (P.run_flags) hipFree(P.run_flags);
+                    P.run_cap = std::max<int64_t>(2 * R + 1024, 1 << 16);
+                    HIPCHK(hipMalloc(&P.run_cells, (size_t)P.run_cap * sizeof(Op)));
+                    HIPCHK(hipMalloc(&P.run_flags, (size_t)(P.run_cap / 64 + 32) * sizeof(uint64_t)));
+                }
+                if (!P.run_out) HIPCHK(hipMalloc(&P.run_out, 2 * sizeof(int64_t)));
+                HIPCHK(hipMemcpyAsync(P.d_ctl, P.h_ctl, sizeof(Ctl), hipMemcpyHostToDevice, P.stream));     // table_cap may have grown
+                e = launch_run_expand(P.d_ops, i0, R, P.d_ctl, P.col_keys, P.col_live, P.run_cells, P.run_flags, P.run_out, P.stream);
+                if (e != hipSuccess) fail(DSA_EHIP, std::string("run expand launch: ") + hipGetErrorString(e));
+            }
+            HIPCHK(hipMemcpyAsync(P.occ_old, P.O(), (size_t)words * sizeof(uint64_t), hipMemcpyDeviceToDevice, P.stream));
+            e = launch_append_run(P.O(), P.d_ctl, i0, R, P.has_cols ? P.run_flags : nullptr, P.has_cols ? P.run_out : nullptr, P.stream);
+            if (e != hipSuccess) fail(DSA_EHIP, std::string("append run launch: ") + hipGetErrorString(e));
+            permute_run(P, P.has_cols ? P.run_cells : P.d_ops, P.has_cols ? 0 : i0, n0);
+            if (++r.guard > 4 * r.n + 1000000) fail(DSA_EASSERT, "sequencer made no progress");
+            seq_launch(r, false);
+            return true;
+        }
         default:
             fail(DSA_EASSERT, "unknown sequencer status");
     }
@@ -412,7 +483,7 @@ int64_t run_ops_parallel(Pma& P, const std::vector<Op>& ops, int32_t* err) {
         HIPCHK(hipMalloc(&P.d_rs, sizeof(RoundState)));
         HIPCHK(hipHostMalloc(&P.h_rs, sizeof(RoundState), hipHostMallocDefault));
     }
-    P.h_ctl->next_op = 0; P.h_ctl->status = 0; P.h_ctl->err = 0;
+    P.h_ctl->next_op = 0; P.h_ctl->status = 0; P.h_ctl->err = 0; P.h_ctl->no_run_at = -1;
     upload_ctl(P);
     int64_t i = 0, seq_chunk = 64;
     int G = 256;
@@ -441,8 +512,8 @@ int64_t run_ops_parallel(Pma& P, const std::vector<Op>& ops, int32_t* err) {
         // ---- short prefix at op i: sequential sequencer for ops [i, i + seq_chunk)
         if (host_ctl_stale) { download_ctl(P); host_ctl_stale = false; }
         SeqRun r;
-        r.P = &P; r.ops = &ops; r.n = std::min<int64_t>(n, i + seq_chunk); r.active = true;
-        P.h_ctl->next_op = i; P.h_ctl->status = 0; P.h_ctl->err = 0;
+        r.P = &P; r.ops = &ops; r.n = std::min<int64_t>(n, i + seq_chunk); r.n_avail = n; r.active = true;
+        P.h_ctl->next_op = i; P.h_ctl->status = 0; P.h_ctl->err = 0; P.h_ctl->no_run_at = -1;
         seq_launch(r);
         while (seq_step(r)) {}
         if (r.err) { *err = r.err; return r.applied; }
@@ -719,8 +790,16 @@ void mat_apply_sets(dsa_mat* h, const int64_t* I, const int64_t* J, const double
         // batch-parallel rounds per orientation (writes to existing columns with disjoint footprints run concurrently; new
         // columns and anything else fall back to the sequential sequencer inside run_ops_parallel)
         int32_t ec = 0, er = 0;
+        static const bool dbg_time = getenv("DSA_DBG_TIME") != nullptr;
+        const auto t0 = std::chrono::steady_clock::now();
         const int64_t dc = run_ops_parallel(h->col, oc, &ec);
+        const auto t1 = std::chrono::steady_clock::now();
         const int64_t dr = run_ops_parallel(h->row, orw, &er);
+        if (dbg_time)
+            fprintf(stderr, "[mat_apply_sets] n=%lld colmajor %.2f ms (par %lld seq %lld)  rowmajor %.2f ms (par %lld seq %lld)\n", (long long)n,
+                    std::chrono::duration<double, std::milli>(t1 - t0).count(), (long long)h->col.stat_par_ops, (long long)h->col.stat_seq_ops,
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count(), (long long)h->row.stat_par_ops,
+                    (long long)h->row.stat_seq_ops);
         const int64_t done = std::min(dc, dr);
         for (int64_t k = 0; k < std::min(done + 1, n); ++k) if (V[k] != 0.0) { h->m = std::max(h->m, I[k]); h->n = std::max(h->n, J[k]); }
         if (ec) fail(ec, err_text(ec));

@@ -288,6 +288,112 @@ hipError_t launch_compact_range(const int64_t* keys, const double* vals, const u
     return hipGetLastError();
 }
 
+// ---- K-permute: order-preserving move between two occupancy bitmaps ---------------------------------------------------
+// The cells of a PMA always keep their relative order, so the layout after ANY sequence of inserts is fully determined by
+// the final occupancy bitmap: the r-th cell (old bitmap order, followed by the appended cells in op order) sits at the r-th
+// set bit of the new bitmap.  The append fast path of the sequencer simulates pack! / spread! on the BITMAP only (no cell
+// moves) and this kernel then moves every cell exactly once.  One workgroup per 4096-slot destination tile; ranks <= n0
+// come from the source array (compaction through LDS as in k_move), ranks > n0 from the batch's op records.
+constexpr int PERM_TILE = 4096;
+struct PermArgs {
+    const int64_t* src_keys; const double* src_vals; const uint64_t* src_occ; int64_t src_words;
+    int64_t* dst_keys; double* dst_vals; const uint64_t* dst_occ; int64_t dst_words;
+    const uint32_t* src_off; int64_t src_tiles;        // exclusive prefix per 4096-slot source tile (k_tile_scan)
+    const uint32_t* dst_off; int64_t dst_tiles;
+    int64_t n0;                                         // cells that existed before the run
+    const Op* ops; int64_t i0;                          // appended cell r (1-based beyond n0) = ops[i0 + r - 1]
+    int64_t* sems;
+};
+__global__ __launch_bounds__(256) void k_permute(PermArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char perm_lds[];
+    int64_t* sK = reinterpret_cast<int64_t*>(perm_lds);
+    double* sV = reinterpret_cast<double*>(perm_lds + PERM_TILE * sizeof(int64_t));
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int64_t d = blockIdx.x;
+    const int64_t R0 = a.dst_off[d];
+    const int64_t cnt = (int64_t)a.dst_off[d + 1] - R0;            // cells landing in this tile: ranks R0+1 .. R0+cnt
+    if (cnt == 0) return;
+    // ---- stage: ranks from the source array
+    const int64_t from_src = R0 < a.n0 ? ((R0 + cnt <= a.n0 ? cnt : a.n0 - R0)) : 0;
+    if (from_src > 0) {
+        int64_t lo = 0, hi = a.src_tiles - 1;                      // largest t with src_off[t] <= R0
+        while (lo < hi) {
+            const int64_t mid = (lo + hi + 1) >> 1;
+            if ((int64_t)a.src_off[mid] <= R0) lo = mid; else hi = mid - 1;
+        }
+        for (int64_t t = lo; t < a.src_tiles && (int64_t)a.src_off[t] < R0 + from_src; ++t) {
+            const int64_t base = a.src_off[t];
+            const int64_t wl = t * SRC_TILE_WORDS + lane;
+            const uint64_t myword = wl < a.src_words ? a.src_occ[wl] : 0ull;
+            const uint32_t myoff = wave_excl_scan((uint32_t)popc64(myword));
+            for (int w = wv; w < SRC_TILE_WORDS; w += 4) {
+                const uint64_t mask = __shfl(myword, w, 64);
+                const int64_t off = base + (int64_t)__shfl(myoff, w, 64);
+                if ((mask >> lane) & 1ull) {
+                    const int64_t rank = off + popc64(mask & mask_lt(lane)) + 1;
+                    if (rank > R0 && rank <= R0 + from_src) {
+                        const int64_t s = ((t * SRC_TILE_WORDS + w) << 6) + lane;
+                        sK[rank - R0 - 1] = a.src_keys[s];
+                        sV[rank - R0 - 1] = a.src_vals[s];
+                    }
+                }
+            }
+        }
+    }
+    // ---- stage: appended cells
+    for (int64_t r = from_src + tid; r < cnt; r += 256) {
+        const Op op = a.ops[a.i0 + (R0 + r - a.n0)];
+        sK[r] = op.a; sV[r] = op.v;
+    }
+    __syncthreads();
+    // ---- write: lane <-> slot, one destination word per wave iteration
+    const int64_t wbase = d * SRC_TILE_WORDS;
+    const int64_t wl = wbase + lane;
+    const uint64_t dword = wl < a.dst_words ? a.dst_occ[wl] : 0ull;
+    const uint32_t doff = wave_excl_scan((uint32_t)popc64(dword));
+    for (int w = wv; w < SRC_TILE_WORDS; w += 4) {
+        const uint64_t mask = __shfl(dword, w, 64);
+        const uint32_t off = __shfl(doff, w, 64);
+        if ((mask >> lane) & 1ull) {
+            const uint32_t r = off + (uint32_t)popc64(mask & mask_lt(lane));
+            const int64_t pos0 = ((wbase + w) << 6) + lane;
+            const int64_t k = sK[r];
+            const double v = sV[r];
+            a.dst_keys[pos0] = k;
+            a.dst_vals[pos0] = v;
+            if (a.sems != nullptr && k == SEM_KEY) a.sems[(int64_t)v - 1] = pos0 + 1;
+        }
+    }
+}
+
+hipError_t launch_permute(const int64_t* src_keys, const double* src_vals, const uint64_t* src_occ, int64_t src_cap,
+                          int64_t* dst_keys, double* dst_vals, const uint64_t* dst_occ, int64_t dst_cap, int64_t n0,
+                          const Op* ops, int64_t i0, int64_t* sems, RebalanceWork* wsrc, RebalanceWork* wdst, hipStream_t stream) {
+    PermArgs a;
+    a.src_keys = src_keys; a.src_vals = src_vals; a.src_occ = src_occ; a.src_words = (src_cap + 63) / 64;
+    a.dst_keys = dst_keys; a.dst_vals = dst_vals; a.dst_occ = dst_occ; a.dst_words = (dst_cap + 63) / 64;
+    a.src_tiles = (a.src_words + SRC_TILE_WORDS - 1) / SRC_TILE_WORDS;
+    a.dst_tiles = (a.dst_words + SRC_TILE_WORDS - 1) / SRC_TILE_WORDS;
+    if (a.src_tiles + 1 > wsrc->tiles_cap || a.dst_tiles + 1 > wdst->tiles_cap) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_tile_count, dim3((unsigned)a.src_tiles), dim3(64), 0, stream, src_occ, (int64_t)0, src_cap - 1, (int64_t)0,
+                       a.src_words, wsrc->tile_cnt);
+    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, stream, wsrc->tile_cnt, wsrc->tile_off, a.src_tiles);
+    hipLaunchKernelGGL(k_tile_count, dim3((unsigned)a.dst_tiles), dim3(64), 0, stream, dst_occ, (int64_t)0, dst_cap - 1, (int64_t)0,
+                       a.dst_words, wdst->tile_cnt);
+    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, stream, wdst->tile_cnt, wdst->tile_off, a.dst_tiles);
+    a.src_off = wsrc->tile_off; a.dst_off = wdst->tile_off;
+    a.n0 = n0; a.ops = ops; a.i0 = i0; a.sems = sems;
+    static bool configured = false;
+    const size_t lds = (size_t)PERM_TILE * 16;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_permute), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        configured = true;
+    }
+    hipLaunchKernelGGL(k_permute, dim3((unsigned)a.dst_tiles), dim3(256), lds, stream, a);
+    return hipGetLastError();
+}
+
 __global__ void k_clear_occ(uint64_t* occ, int64_t lo0, int64_t hi0) {
     const int64_t w0 = lo0 >> 6, w1 = hi0 >> 6;
     for (int64_t w = w0 + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; w <= w1; w += (int64_t)gridDim.x * blockDim.x)

@@ -232,6 +232,501 @@ __device__ int d_after_count_change(Seq& S, int64_t pos) {
     return SEQ_Y_REBALANCE;
 }
 
+// ---- append runs: pack! / spread! simulated on the occupancy bitmap only ------------------------------------------------
+// A run of setindex! calls with strictly ascending keys above the current last key (Coluna's column streaming, BASELINE
+// config 2 batch A) always inserts behind the last cell, and the density scan / even rebalance that follows only needs
+// cell COUNTS and produces cell POSITIONS — the keys and values never influence control flow.  Cells keep their relative
+// order, so the final layout is a function of the final bitmap alone.  The run is therefore executed on the bitmap:
+// wave 0 keeps the 4096-slot block around the tail in registers (one 64-bit word per lane, per-level counts as butterfly
+// partial sums) and replays insert + _look_for_rebalance! + spread! per op without touching memory; windows wider than the
+// block go through the workgroup-wide bitmap path.  The host then moves every cell exactly once (k_permute, rebalance.hip).
+constexpr int64_t RUN_MIN = 64;
+constexpr int64_t RUN_BLOCK = 4096;
+
+struct RunComm { int64_t idx, L, reb, slots, small; int32_t need, pad; };
+
+// occupancy of window offsets 64t+1 .. 64t+64 after spread! (bit b <-> offset 64t+1+b)
+__device__ __forceinline__ uint64_t spread_word_bits(const SpreadGeom& g, int t) {
+    uint64_t bits = ~0ull;
+    const int E = (int)g.E;
+    const int lo = 64 * t, hi = lo + 64;
+    int k = gaps_le(g, lo);
+#pragma clang loop vectorize(disable) unroll(disable)
+    for (++k; k <= E; ++k) {
+        const int d = gap_D(g, k);
+        if (d > hi) break;
+        bits &= ~(1ull << (d - lo - 1));
+    }
+    return bits;
+}
+// 1-based offset of the last cell after spread! of m >= 1 cells over W slots
+__device__ __forceinline__ int64_t spread_last_cell(const SpreadGeom& g) {
+    int q = (int)g.W, k = (int)g.E;
+    while (k > 0 && gap_D(g, k) == q) { --q; --k; }
+    return q;
+}
+
+// number of leading ops of ops[i..n) that continue an append run.
+//   mode 0 (vector):           OP_VEC_SET, non-zero value, key above the previous key (pa0 for the first op)
+//   mode 1 (MappedPackedCSC):  OP_MPCSC_SET, non-zero value, row >= 1, (col, row) lexicographically above the previous
+//                              (col, row) ((pb0, pa0) for the first op; any column when first_any)
+__device__ int64_t blk_run_length(Seq& S, const Op* ops, int64_t i, int64_t n, int mode, int64_t pa0, int64_t pb0, bool first_any) {
+    int64_t R = 0;
+    for (int64_t base = i; base < n; base += SEQ_BLOCK) {
+        const int64_t j = base + threadIdx.x;
+        bool bad = false;
+        if (j < n) {
+            const Op o = ops[j];
+            int64_t pa = pa0, pb = pb0;
+            bool any = first_any;
+            if (j != i) { const Op q = ops[j - 1]; pa = q.a; pb = q.b; any = false; }
+            if (mode == 0) bad = !(o.kind == OP_VEC_SET && o.v != 0.0 && o.a > pa);
+            else bad = !(o.kind == OP_MPCSC_SET && o.v != 0.0 && o.a >= 1 && (any || o.b > pb || (o.b == pb && o.a > pa)));
+        }
+        const uint64_t b = __ballot(bad);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0)
+            S.sRed[threadIdx.x >> 6] = b ? (int64_t)((threadIdx.x & ~63) + __ffsll((unsigned long long)b) - 1) : (int64_t)SEQ_BLOCK;
+        __syncthreads();
+        int64_t first = SEQ_BLOCK;
+#pragma unroll
+        for (int k = 0; k < SEQ_BLOCK / 64; ++k) first = S.sRed[k] < first ? S.sRed[k] : first;
+        const int64_t lim = (n - base) < SEQ_BLOCK ? (n - base) : (int64_t)SEQ_BLOCK;
+        if (first < lim) return R + first;
+        R += lim;
+    }
+    return R;
+}
+
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const uint32_t y = __shfl_xor(v, o, 64); v = y > v ? y : v; }
+    return v;
+}
+
+__device__ __forceinline__ uint32_t rdlane(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
+__device__ __forceinline__ uint64_t rdlane64(uint64_t v, int l) {
+    return ((uint64_t)rdlane((uint32_t)(v >> 32), l) << 32) | (uint64_t)rdlane((uint32_t)v, l);
+}
+
+// memo of spread! patterns for windows of up to 256 slots: the pattern depends on (W, c) only and an append run keeps
+// hitting the same few (level, count) pairs.  Filled on first use by wave 0.
+constexpr int MEMO_ENTRIES = 640, MEMO_WORDS = 1664;
+struct RunMemo { uint64_t words[MEMO_WORDS]; uint8_t valid[MEMO_ENTRIES]; };
+
+// wave 0: replays appends rc->idx .. end-1 on the register-resident block until one needs the workgroup path (need = 1).
+// Everything per op is wave-uniform register work: lane <-> occupancy word of the block for the bitmap, lane <-> level
+// for the density scan (the levels inside one word are tested first, from the word alone; wider in-block levels from a
+// butterfly of word popcounts), lane <-> window offset when a spread! pattern is computed (one ballot per word).
+__device__ void wave_fast_appends(Seq& S, RunComm* rc, RunMemo* memo, const uint64_t* flags, int64_t end) {
+    const int lane = lane_id();
+    int64_t idx = rc->idx, L = rc->L;
+    int64_t reb = 0, slots = 0;
+    const int64_t cap = S.capacity, seg = S.seg;
+    const int64_t nwords = (cap + 63) >> 6;
+    const int64_t blkslots = cap < RUN_BLOCK ? cap : RUN_BLOCK;
+    const int lseg = 63 - __clzll((long long)seg);
+    // level h = lane: window size and integer density bounds; levels wider than the block cannot be decided here
+    const bool lvl_valid = lane <= (int)S.height;
+    const int64_t Wl = lvl_valid ? (seg << lane) : 0;
+    const bool lvl_in_block = lvl_valid && Wl <= blkslots;
+    const bool lvl_low = lvl_in_block && Wl <= 64;
+    const bool lvl_mid = lvl_in_block && Wl > 64;
+    const uint32_t my_lo = lvl_in_block ? (uint32_t)S.lo[lane] : 1u;
+    const uint32_t my_hi = lvl_in_block ? (uint32_t)S.hi[lane] : 0u;
+    const int my_j = lvl_mid ? (lseg + lane - 6) : 0;                           // log2(W / 64)
+    const uint64_t my_low_mask = lvl_low ? (Wl == 64 ? ~0ull : ((1ull << Wl) - 1ull)) : 0ull;
+    const int my_low_align = lvl_low ? ~((int)Wl - 1) & 63 : 0;
+    const bool any_mid = __ballot(lvl_mid) != 0;
+    // memo bases of level h = lane (W <= 256): entry index and first word of entry c = 0
+    int my_ent = 0, my_wb = 0;
+    {
+        int e = 0, wb = 0;
+        for (int h = 0; h < 64; ++h) {
+            const int64_t Wh = seg << h;
+            if (h > (int)S.height || Wh > 256) break;
+            if (h == lane) { my_ent = e; my_wb = wb; }
+            e += (int)Wh + 1;
+            wb += ((int)Wh + 1) * (Wh <= 64 ? 1 : (int)(Wh >> 6));
+        }
+    }
+    const int last_lane = (int)((nwords - 1) & 63);
+    const uint64_t cap_bit = 1ull << ((cap - 1) & 63);
+    int need = 0;
+    // cell types of the run (MappedPackedCSC: bit set = semaphore cell of a new column); one word per 64 cells
+    int64_t fw_idx = -1;
+    uint64_t fw = 0;
+    while (idx < end && need == 0) {
+        if (flags != nullptr && (idx >> 6) != fw_idx) { fw_idx = idx >> 6; fw = flags[fw_idx]; }
+        const bool sem0 = (fw >> (idx & 63)) & 1ull;
+        const int64_t tgt = (L < cap && !sem0) ? L + 1 : cap;
+        const int64_t blk = (tgt - 1) / RUN_BLOCK;
+        const int64_t w = blk * 64 + lane;
+        uint64_t word = w < nwords ? S.occ[w] : 0ull;
+        while (idx < end) {
+            if (flags != nullptr && (idx >> 6) != fw_idx) { fw_idx = idx >> 6; fw = flags[fw_idx]; }
+            const bool is_sem = (fw >> (idx & 63)) & 1ull;
+            const uint64_t word_saved = word;
+            int64_t ip;
+            if (L < cap && !is_sem) {
+                // _insert! behind the last cell  src/writes.jl:26-43
+                ip = L + 1;
+                if ((ip - 1) / RUN_BLOCK != blk) break;                       // the tail moves into the next block: reload
+                if (lane == (int)(((ip - 1) >> 6) & 63)) word |= 1ull << ((ip - 1) & 63);
+            } else {
+                // insert at the end of the array: a cell behind a tail that sits on the last slot, or a new partition's
+                // semaphore (always inserted "after position capacity", src/pcsr.jl:99-112).  The nearest empty slot left
+                // of the last slot takes the shift; almost always it is in the last word.
+                if ((cap - 1) / RUN_BLOCK != blk) break;
+                const uint64_t wl = rdlane64(word, last_lane);
+                uint64_t zl = ~wl & ~cap_bit;
+                if (cap < 64) zl &= (1ull << cap) - 1ull;
+                uint32_t best;
+                if (zl) best = (uint32_t)((last_lane << 6) + 64 - __clzll((long long)zl));
+                else {
+                    uint64_t z = w < nwords ? ~word : 0ull;
+                    if (lane == last_lane) z &= ~cap_bit;
+                    const uint32_t rel = z ? (uint32_t)((lane << 6) + 64 - __clzll((long long)z)) : 0u;
+                    best = wave_max_u32(rel);
+                    if (best == 0) { need = 1; break; }
+                }
+                const int64_t pe = blk * RUN_BLOCK + best;
+                ip = cap;
+                if (wl & cap_bit) {                                           // tail on the last slot: cells (pe, cap] shift left
+                    if (lane == (int)(((pe - 1) >> 6) & 63)) word |= 1ull << ((pe - 1) & 63);
+                } else if (pe == cap - 1) {                                   // last slot and its neighbour empty
+                    if (lane == last_lane) word |= cap_bit;
+                } else {                                                      // last slot empty, cells (pe, cap-1] shift left
+                    if (lane == (int)(((pe - 1) >> 6) & 63)) word |= 1ull << ((pe - 1) & 63);
+                    if (lane == (int)(((cap - 2) >> 6) & 63)) word &= ~(1ull << ((cap - 2) & 63));
+                    if (lane == last_lane) word |= cap_bit;
+                }
+            }
+            const int lane_ip = __builtin_amdgcn_readfirstlane((int)(((ip - 1) >> 6) & 63));
+            const int bit_ip = (int)((ip - 1) & 63);
+            // _look_for_rebalance!  src/pma.jl:105-141: lane h evaluates level h
+            const uint64_t word_ip = rdlane64(word, lane_ip);
+            uint32_t c_l = (uint32_t)popc64(word_ip & (my_low_mask << (bit_ip & my_low_align)));
+            uint64_t acc = __ballot(lvl_low && my_lo <= c_l && c_l <= my_hi);
+            if (acc == 0 && any_mid) {
+                uint32_t s[7];
+                s[0] = (uint32_t)popc64(word);
+#pragma unroll
+                for (int j = 1; j < 7; ++j) s[j] = s[j - 1] + __shfl_xor(s[j - 1], 1 << (j - 1), 64);
+                const uint32_t s1 = rdlane(s[1], lane_ip), s2 = rdlane(s[2], lane_ip), s3 = rdlane(s[3], lane_ip),
+                               s4 = rdlane(s[4], lane_ip), s5 = rdlane(s[5], lane_ip), s6 = rdlane(s[6], lane_ip);
+                c_l = my_j == 1 ? s1 : my_j == 2 ? s2 : my_j == 3 ? s3 : my_j == 4 ? s4 : my_j == 5 ? s5 : s6;
+                acc = __ballot(lvl_mid && my_lo <= c_l && c_l <= my_hi);
+            }
+            if (acc == 0) {
+                // a wider window (or _extend!) decides: undo, hand the op to the workgroup path
+                word = word_saved;
+                need = 1;
+                break;
+            }
+            const int h = __ffsll((unsigned long long)acc) - 1;
+            if (h == 0) { L = ip; ++idx; continue; }
+            // _even_rebalance!: spread! of c cells over the window, bits only
+            const int W = (int)seg << h;                                      // <= 4096
+            const int c = (int)rdlane(c_l, h);
+            reb += 1; slots += W;
+            const int64_t ws = ((ip - 1) & ~((int64_t)W - 1)) + 1;
+            const int lw0 = (int)(((ws - 1) >> 6) & 63);
+            if (W <= 256) {
+                const int nw = W < 64 ? 1 : (W >> 6);
+                const int ent = (int)rdlane((uint32_t)my_ent, h) + c;
+                const int wb = (int)rdlane((uint32_t)my_wb, h) + c * nw;
+                if (!memo->valid[ent]) {
+                    SpreadGeom g;                                             // make_geom(W, c) with 32-bit conversions
+                    g.W = W; g.E = W - c;
+                    g.f = (double)W / (double)(W - c);
+                    g.inv_f = (double)(W - c) / (double)W;
+                    for (int t = 0; t < nw; ++t) {
+                        const int q = 64 * t + lane + 1;
+                        int rank;
+                        const bool cell = q <= W && !slot_is_gap(g, q, &rank);
+                        const uint64_t nb = __ballot(cell);
+                        if (lane == 0) memo->words[wb + t] = nb;
+                    }
+                    if (lane == 0) memo->valid[ent] = 1;
+                }
+                const uint64_t lastw = memo->words[wb + nw - 1];
+                if (W < 64) {
+                    const int sh = (int)((ws - 1) & 63);
+                    const uint64_t m = ((1ull << W) - 1ull) << sh;
+                    if (lane == lane_ip) word = (word & ~m) | (lastw << sh);
+                } else {
+                    const int t = lane - lw0;
+                    if (t >= 0 && t < nw) word = memo->words[wb + t];
+                }
+                L = ws - 1 + 64 * (nw - 1) + (64 - __clzll((long long)lastw));
+            } else {
+                SpreadGeom g;
+                g.W = W; g.E = W - c;
+                g.f = (double)W / (double)(W - c);
+                g.inv_f = (double)(W - c) / (double)W;
+                const int t = lane - lw0;
+                if (t >= 0 && t < (W >> 6)) word = spread_word_bits(g, t);
+                L = ws - 1 + spread_last_cell(g);
+            }
+            ++idx;
+        }
+        if (w < nwords) S.occ[w] = word;
+    }
+    if (lane == 0) { rc->idx = idx; rc->L = L; rc->reb = reb; rc->slots = slots; rc->small = reb; rc->need = need; }
+}
+
+// spread! of m cells over [ws, we], occupancy words only (workgroup-wide)
+__device__ void blk_rewrite_bits(Seq& S, int64_t ws, int64_t we, int64_t m) {
+    const int64_t W = we - ws + 1;
+    const SpreadGeom g = make_geom(W, m);
+    const int64_t w0 = (ws - 1) >> 6;
+    __syncthreads();
+    if (W >= 64) {
+        for (int64_t t = threadIdx.x; t < (W >> 6); t += SEQ_BLOCK) S.occ[w0 + t] = spread_word_bits(g, (int)t);
+    } else if (threadIdx.x == 0) {
+        const int sh = (int)((ws - 1) & 63);
+        const uint64_t msk = ((1ull << W) - 1ull) << sh;
+        S.occ[w0] = (S.occ[w0] & ~msk) | ((spread_word_bits(g, 0) << sh) & msk);
+    }
+    __syncthreads();
+}
+
+// one append on the global bitmap (all threads, uniform): insert behind the tail (or, for a semaphore / a tail on the
+// last slot, at the end of the array) + density scan + spread! of the bits.  Returns false (bitmap unchanged) when the op
+// needs _extend! / _shrink! or cannot be placed: the run ends before it.
+__device__ bool blk_slow_append(Seq& S, int64_t& L, bool is_sem) {
+    const int64_t cap = S.capacity;
+    int64_t ip, pe = 0;
+    int how;                      // 0: set ip ; 1: set pe ; 2: set cap ; 3: set pe, clear cap-1, set cap
+    if (L < cap && !is_sem) { ip = L + 1; how = 0; }
+    else {
+        pe = d_prev_empty(S.occ, cap);
+        if (pe == 0) return false;
+        ip = cap;
+        how = occ_test(S.occ, cap) ? 1 : (pe == cap - 1 ? 2 : 3);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (how == 0) occ_set(S, ip);
+        else if (how == 1) occ_set(S, pe);
+        else if (how == 2) occ_set(S, cap);
+        else { occ_set(S, pe); occ_clear(S, cap - 1); occ_set(S, cap); }
+    }
+    __syncthreads();
+    int64_t prev_ws = ip, prev_we = ip - 1, left = 0, right = 0, ws = 1, we = cap;
+    bool accepted = false;
+    for (int64_t h = 0; h <= S.height; ++h) {
+        const int64_t W = S.seg << h;
+        ws = ((ip - 1) & ~(W - 1)) + 1;
+        we = ws + W - 1;
+        left += blk_count(S, ws, prev_ws);
+        right += blk_count(S, prev_we + 1, we + 1);
+        const int64_t c = left + right;
+        if (S.lo[h] <= c && c <= S.hi[h]) { accepted = true; break; }
+        prev_ws = ws; prev_we = we;
+    }
+    const int64_t count = left + right;
+    if (!accepted) {
+        const int64_t H = S.height;
+        if (count > S.hi[H] || (count < S.lo[H] && S.height > 1)) {
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                if (how == 0) occ_clear(S, ip);
+                else if (how == 1) occ_clear(S, pe);
+                else if (how == 2) occ_clear(S, cap);
+                else { occ_clear(S, pe); occ_set(S, cap - 1); occ_clear(S, cap); }
+            }
+            __syncthreads();
+            return false;
+        }
+        ws = 1; we = cap;
+    }
+    S.nb_elements += 1;
+    const int64_t W = we - ws + 1;
+    if (W == S.seg) { L = ip; return true; }
+    S.stat_rebalances += 1; S.stat_window_slots += W;
+    if (W <= SMALL_W) S.stat_small += 1;
+    blk_rewrite_bits(S, ws, we, count);
+    L = ws - 1 + spread_last_cell(make_geom(W, count));
+    return true;
+}
+
+// Run detection (inside the sequencer): number of ops of ops[i..] that form an append run, or 0.
+__device__ int64_t d_detect_append_run(Seq& S, const Op* ops, int64_t i, int64_t n_avail) {
+    if (S.nb_elements < 1) return 0;
+    const int64_t L0 = d_prev_occupied(S.occ, S.capacity, 1);
+    if (L0 < 1) return 0;
+    const int64_t lk = S.keys[L0 - 1];
+    const int64_t R = blk_run_length(S, ops, i, n_avail, 0, lk, 0, false);
+    return R >= RUN_MIN ? R : 0;
+}
+// MappedPackedCSC: (col, row) ascending above the last cell of the last partition — new columns are appended partitions
+// (addpartition!(pcsc) src/pcsr.jl:99-112 via setindex! src/pcsr.jl:341-351), rows go behind the last cell.
+__device__ int64_t d_detect_pcsc_run(Seq& S, const Op* ops, int64_t i, int64_t n_avail) {
+    const int64_t tl = S.table_len;
+    int64_t pa0 = 0, pb0 = 0;
+    bool any = false;
+    if (tl == 0) {
+        if (S.nb_elements != 0) return 0;
+        any = true;
+    } else {
+        if (!S.col_live[tl - 1]) return 0;                 // tombstones at the end of the table: addpartition!(pcsc, prev) paths
+        const int64_t sp = S.sems[tl - 1];
+        if (sp == 0) return 0;
+        pb0 = S.col_keys[tl - 1];
+        const int64_t L0 = d_prev_occupied(S.occ, S.capacity, 1);
+        if (L0 < sp) return 0;
+        const int64_t lk = L0 == sp ? 0 : S.keys[L0 - 1];
+        pa0 = lk > 0 ? lk : 0;
+    }
+    const int64_t R = blk_run_length(S, ops, i, n_avail, 1, pa0, pb0, any);
+    return R >= RUN_MIN ? R : 0;
+}
+
+// Expands the ops of a MappedPackedCSC run into its cell stream (a semaphore cell (0, id) in front of the first row of every
+// new column), appends the new columns to col_keys / col_live and writes one type bit per cell.  One workgroup.
+__global__ __launch_bounds__(1024) void k_run_expand(const Op* ops, int64_t i0, int64_t R, const Ctl* ctl, int64_t* col_keys,
+                                                     uint8_t* col_live, Op* cells, uint64_t* flags, int64_t* out) {
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t carry_s;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int64_t tl0 = ctl->table_len;
+    const int64_t lastcol = tl0 > 0 ? col_keys[tl0 - 1] : 0;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < R; base += 1024) {
+        const int64_t j = base + tid;
+        Op o; o.a = 0; o.b = 0; o.v = 0.0; o.kind = 0; o.pad = 0;
+        uint32_t newc = 0;
+        if (j < R) {
+            o = ops[i0 + j];
+            newc = (j == 0) ? ((tl0 == 0 || o.b != lastcol) ? 1u : 0u) : (o.b != ops[i0 + j - 1].b ? 1u : 0u);
+        }
+        const uint32_t ex = seq_wave_excl_scan(newc);
+        if (lane == 63) wsum[wv] = ex + newc;
+        __syncthreads();
+        uint32_t woff = 0;
+        for (int k = 0; k < wv; ++k) woff += wsum[k];
+        const uint32_t carry = carry_s;
+        const int64_t before = (int64_t)carry + woff + ex;          // new columns in front of op j
+        if (j < R) {
+            const int64_t c0 = j + before;
+            Op cell; cell.b = 0; cell.kind = 0; cell.pad = 0;
+            if (newc) {
+                cell.a = SEM_KEY; cell.v = (double)(tl0 + before + 1);
+                cells[c0] = cell;
+                col_keys[tl0 + before] = o.b; col_live[tl0 + before] = 1;
+            }
+            cell.a = o.a; cell.v = o.v;
+            cells[c0 + newc] = cell;
+        }
+        __syncthreads();
+        if (tid == 1023) carry_s = carry + woff + ex + newc;
+        __syncthreads();
+    }
+    const int64_t T = R + (int64_t)carry_s;
+    __threadfence_block();
+    __syncthreads();
+    for (int64_t base = 0; base < T; base += 1024) {
+        const int64_t c = base + tid;
+        const bool sem = c < T && cells[c].a == SEM_KEY;
+        const uint64_t b = __ballot(sem);
+        if (lane == 0) flags[(base >> 6) + wv] = b;
+    }
+    if (tid == 0) { out[0] = T; out[1] = (int64_t)carry_s; }
+}
+
+hipError_t launch_run_expand(const Op* ops, int64_t i0, int64_t R, const Ctl* ctl, int64_t* col_keys, uint8_t* col_live, Op* cells,
+                             uint64_t* flags, int64_t* out, hipStream_t stream) {
+    hipLaunchKernelGGL(k_run_expand, dim3(1), dim3(1024), 0, stream, ops, i0, R, ctl, col_keys, col_live, cells, flags, out);
+    return hipGetLastError();
+}
+
+// The run itself is its own single-workgroup kernel (own register allocation: the per-op loop of wave 0 must stay
+// spill-free).  Replays ops [i0, i0+R) on the bitmap `occ` (the saved copy for K-permute was made by the host) and
+// updates the control block: next_op, nb_elements, statistics.  A run ends early at an op that needs _extend! /
+// _shrink!; when that is the very first op, no_run_at tells the sequencer to execute it on the normal path.
+__global__ __launch_bounds__(SEQ_BLOCK) void k_append_run(uint64_t* occ, Ctl* ctl, int64_t i0, int64_t R, const uint64_t* flags,
+                                                          const int64_t* d_T) {
+    __shared__ int64_t sRed[SEQ_BLOCK / 64];
+    __shared__ RunComm sRun;
+    __shared__ RunMemo sMemo;
+    __shared__ int64_t sLo[MAX_LEVELS], sHi[MAX_LEVELS];
+    for (int k = threadIdx.x; k < MEMO_ENTRIES; k += SEQ_BLOCK) sMemo.valid[k] = 0;
+    Seq S;
+    S.keys = nullptr; S.vals = nullptr; S.occ = occ; S.sems = nullptr; S.col_keys = nullptr; S.col_live = nullptr; S.ctl = ctl;
+    S.capacity = ctl->capacity; S.seg = ctl->segment_capacity; S.height = ctl->height;
+    S.nb_elements = ctl->nb_elements; S.nb_partitions = 0; S.table_len = 0; S.table_cap = 0;
+    S.stat_window_slots = ctl->stat_window_slots; S.stat_rebalances = ctl->stat_rebalances;
+    S.stat_small = ctl->stat_small_rebalances;
+    S.y_ws = S.y_we = S.y_m = 0; S.err = 0; S.tail_hint = false;
+    S.sK = nullptr; S.sV = nullptr; S.sWordOff = nullptr; S.sRed = sRed;
+    if (threadIdx.x < MAX_LEVELS) { sLo[threadIdx.x] = ctl->lo[threadIdx.x]; sHi[threadIdx.x] = ctl->hi[threadIdx.x]; }
+    S.lo = sLo; S.hi = sHi;
+    __syncthreads();
+    RunComm* rc = &sRun;
+    // cells of the run: the ops themselves (vector), or the expanded cell stream of k_run_expand (flags != nullptr)
+    int64_t idx = 0, L = d_prev_occupied(occ, S.capacity, 1);
+    const int64_t end = flags != nullptr ? d_T[0] : R;
+    int64_t t_fast = 0, t_slow = 0, n_slow = 0;
+    const int64_t c_begin = clock64(), w_begin = wall_clock64();
+    while (idx < end) {
+        if (threadIdx.x == 0) { rc->idx = idx; rc->L = L; }
+        __syncthreads();
+        const int64_t t0 = wall_clock64();
+        if (threadIdx.x < 64) wave_fast_appends(S, rc, &sMemo, flags, end);
+        __syncthreads();
+        const int64_t t1 = wall_clock64();
+        t_fast += t1 - t0;
+        const int64_t nidx = rc->idx;
+        L = rc->L;
+        S.nb_elements += nidx - idx;
+        S.stat_rebalances += rc->reb; S.stat_window_slots += rc->slots; S.stat_small += rc->small;
+        idx = nidx;
+        const int need = rc->need;
+        __syncthreads();
+        if (!need) continue;
+        const bool ok = blk_slow_append(S, L, flags != nullptr && ((flags[idx >> 6] >> (idx & 63)) & 1ull));
+        t_slow += wall_clock64() - t1; ++n_slow;
+        if (!ok) break;
+        ++idx;
+    }
+    // semaphore cells among the idx cells that were placed: new partitions; the others are completed ops
+    int64_t nsem = 0;
+    if (flags != nullptr) {
+        for (int64_t wd = threadIdx.x; (wd << 6) < idx; wd += SEQ_BLOCK) {
+            uint64_t f = flags[wd];
+            if (((wd + 1) << 6) > idx) f &= mask_lt((int)(idx - (wd << 6)));
+            nsem += popc64(f);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) nsem += __shfl_xor(nsem, o, 64);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) sRed[threadIdx.x >> 6] = nsem;
+        __syncthreads();
+        nsem = 0;
+        for (int k = 0; k < SEQ_BLOCK / 64; ++k) nsem += sRed[k];
+    }
+    if (threadIdx.x == 0) {
+        const int64_t next = i0 + idx - nsem;
+        ctl->next_op = next;
+        ctl->no_run_at = idx < end ? next : -1;
+        ctl->nb_partitions += nsem; ctl->table_len += nsem;
+        ctl->nb_elements = S.nb_elements;
+        ctl->stat_window_slots = S.stat_window_slots; ctl->stat_rebalances = S.stat_rebalances;
+        ctl->stat_small_rebalances = S.stat_small;
+        ctl->dbg[0] = n_slow; ctl->dbg[2] = t_fast; ctl->dbg[3] = t_slow; ctl->dbg[4] = idx;
+        ctl->dbg[1] = clock64() - c_begin; ctl->dbg[5] = wall_clock64() - w_begin;
+    }
+}
+
+hipError_t launch_append_run(uint64_t* occ, Ctl* ctl, int64_t i0, int64_t R, const uint64_t* flags, const int64_t* d_T,
+                             hipStream_t stream) {
+    hipLaunchKernelGGL(k_append_run, dim3(1), dim3(SEQ_BLOCK), 0, stream, occ, ctl, i0, R, flags, d_T);
+    return hipGetLastError();
+}
+
 // _insert!(array, key, value, pos, semaphores)  src/writes.jl:26-43 ; returns the insertion position or 0 (EFULL)
 __device__ int64_t d_insert_after(Seq& S, int64_t key, double val, int64_t pos) {
     const int64_t ne = d_next_empty(S.occ, pos, S.capacity);
@@ -468,7 +963,7 @@ __device__ int d_exec(Seq& S, const Op& op) {
 
 __global__ __launch_bounds__(SEQ_BLOCK) void k_sequencer(int64_t* keys, double* vals, uint64_t* occ, int64_t* sems,
                                                          int64_t* col_keys, uint8_t* col_live, Ctl* ctl,
-                                                         const Op* ops, int64_t n_ops) {
+                                                         const Op* ops, int64_t n_ops, int64_t n_avail, int run_ok) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     __shared__ int64_t sRed[SEQ_BLOCK / 64];
     __shared__ uint32_t sWordOff[SMALL_W / 64 + 1];
@@ -491,8 +986,22 @@ __global__ __launch_bounds__(SEQ_BLOCK) void k_sequencer(int64_t* keys, double* 
     int64_t i = ctl->next_op;
     int status = SEQ_DONE;
     Op op = ops[i < n_ops ? i : 0];
+    int64_t run_cooldown = 0;
+    const int64_t no_run_at = ctl->no_run_at;
     for (; i < n_ops; ++i) {
         const Op nxt = ops[i + 1 < n_ops ? i + 1 : i];          // prefetched under the current op's memory traffic
+        const bool vec_cand = sems == nullptr && op.kind == OP_VEC_SET && nxt.kind == OP_VEC_SET && nxt.a > op.a;
+        const bool csc_cand = col_keys != nullptr && op.kind == OP_MPCSC_SET && nxt.kind == OP_MPCSC_SET &&
+                              (nxt.b > op.b || (nxt.b == op.b && nxt.a > op.a));
+        if (run_ok && (vec_cand || csc_cand) && op.v != 0.0 && i + RUN_MIN <= n_avail && i != no_run_at && --run_cooldown < 0) {
+            const int64_t R = vec_cand ? d_detect_append_run(S, ops, i, n_avail) : d_detect_pcsc_run(S, ops, i, n_avail);
+            if (R > 0) {
+                S.y_ws = i; S.y_we = S.nb_elements; S.y_m = R;
+                status = SEQ_Y_APPEND_RUN;
+                break;
+            }
+            run_cooldown = 32;
+        }
         const int r = d_exec(S, op);
         if (r != 0) {
             status = r & 0xff;
@@ -515,7 +1024,8 @@ __global__ __launch_bounds__(SEQ_BLOCK) void k_sequencer(int64_t* keys, double* 
 }
 
 hipError_t launch_sequencer(int64_t* keys, double* vals, uint64_t* occ, int64_t* sems, int64_t* col_keys,
-                            uint8_t* col_live, Ctl* ctl, const Op* ops, int64_t n_ops, hipStream_t stream) {
+                            uint8_t* col_live, Ctl* ctl, const Op* ops, int64_t n_ops, int64_t n_avail, bool run_ok,
+                            hipStream_t stream) {
     static bool configured = false;
     const size_t lds_bytes = (size_t)SMALL_W * (sizeof(int64_t) + sizeof(double));
     if (!configured) {
@@ -525,7 +1035,7 @@ hipError_t launch_sequencer(int64_t* keys, double* vals, uint64_t* occ, int64_t*
         configured = true;
     }
     hipLaunchKernelGGL(k_sequencer, dim3(1), dim3(SEQ_BLOCK), lds_bytes, stream, keys, vals, occ, sems, col_keys, col_live,
-                       ctl, ops, n_ops);
+                       ctl, ops, n_ops, n_avail, run_ok ? 1 : 0);
     return hipGetLastError();
 }
 

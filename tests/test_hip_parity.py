@@ -188,6 +188,42 @@ def test_ascending_appends_trigger_big_windows_and_extend(dsa, hip, oracle, n0, 
     assert_vec_equal(a, b)
 
 
+@pytest.mark.parametrize("n0,runs,seed", [(1, [64, 65, 200], 1), (3, [5000], 2), (100, [63, 64, 1000, 70, 3000], 3),
+                                           (5000, [20000, 100, 64], 4), (70000, [150000], 5), (20, [70] * 12, 6)])
+def test_append_runs_simulated_on_the_bitmap_match_oracle(dsa, hip, oracle, n0, runs, seed):
+    """Ascending append runs (>= 64 ops) take the bitmap-only path of the sequencer (insert + density scan + spread!
+    replayed on occupancy words, cells moved once by K-permute).  Runs of many lengths, from tiny capacities (leaf-only
+    arrays, segment < 64 slots) through several _extend!s, separated by ops that break a run: an update of an existing key,
+    a delete, an insert in the middle, a descending key, an explicit zero."""
+    rng = np.random.default_rng(seed)
+    keys0 = np.arange(1, n0 + 1, dtype=np.int64) * 3
+    a = dsa.dynamicsparsevec(keys0, unit12_array(seed, n0), binding=hip)
+    b = dsa.dynamicsparsevec(keys0, unit12_array(seed, n0), binding=oracle)
+    top = int(keys0[-1])
+    for r_i, r in enumerate(runs):
+        steps = rng.integers(1, 4, size=r).astype(np.int64)
+        app = top + np.cumsum(steps)
+        top = int(app[-1])
+        vals = unit12_array(seed * 100 + r_i, r)
+        # one batch = breaker ops + the run + breaker ops, so that the run is detected in the middle of a batch
+        pre_k = np.array([keys0[0], app[0] - 1 if steps[0] > 1 else keys0[-1], keys0[n0 // 2]], dtype=np.int64)
+        pre_v = np.array([1.5, 0.0, 0.0 if r_i % 2 else 2.5])
+        post_k = np.array([app[-1], app[r // 2], app[-1] + 5, app[-1] + 2], dtype=np.int64)   # update, update, append, descending
+        post_v = np.array([9.0, 0.0, 1.0, 2.0])
+        top += 5
+        ks = np.concatenate([pre_k, app, post_k]); vs = np.concatenate([pre_v, vals, post_v])
+        a.set_batch(ks, vs)
+        b.set_batch(ks, vs)
+        assert_vec_equal(a, b)
+        ia, ib = a.info(), b.info()
+        for k in ("stat_extends", "stat_shrinks", "stat_rebalances", "stat_window_slots"):
+            assert ia[k] == ib[k], (k, r_i, ia, ib)
+    rep = a.check()
+    assert rep[0] == a.nnz() and not rep[2:7].any(), rep
+    q = np.concatenate([keys0[:50], np.arange(top - 200, top + 3, dtype=np.int64)])
+    assert np.array_equal(a.get_batch(q), b.get_batch(q))
+
+
 def test_c2_full_scale_batches(dsa, hip, oracle):
     """BASELINE config 2 at full size: 2^20-slot PMA (700k keys), batch A = 100k ascending appends
     (one 2^20-slot root rebalance + one extend to 2^21), batch B = 100k uniform odd keys."""

@@ -1,0 +1,16 @@
+#!/usr/bin/env python3
+"""Append-run cost breakdown (dev tool): BASELINE config 2 batch A on the C2 vector.  DSA_DBG_RUN=1 prints the in-kernel profile."""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench, dsa_loader
+dsa = dsa_loader.load(); hip = dsa.product()
+n0 = 700000
+keys0 = np.arange(1, n0 + 1, dtype=np.int64) * 2
+for rep in range(2):
+    v = dsa.dynamicsparsevec(keys0, bench.unit12(3, n0), binding=hip)
+    app = np.arange(1400001, 1500001, dtype=np.int64)
+    va = bench.unit12(3, 100000)
+    t0 = time.perf_counter(); v.set_batch(app, va); dt = time.perf_counter() - t0
+    print("batch A: %.2f ms  %.0f appends/s" % (dt * 1e3, len(app) / dt), v.info()["capacity"])
