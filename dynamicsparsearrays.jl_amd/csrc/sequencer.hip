@@ -834,11 +834,14 @@ __device__ int d_addpartition_middle(Seq& S, int64_t prev, bool with_col, int64_
     const int64_t target = S.sems[prev];
     int64_t sem_pos = 0;
     if (target == 0) {
+        // addcolumn! stores the column key in the tombstoned slot BEFORE addpartition! looks for the next semaphore
+        // (src/pcsr.jl:155-156,165): the key stays there when that lookup throws
+        __syncthreads();
+        if (with_col && threadIdx.x == 0) { S.col_keys[prev] = col; S.col_live[prev] = 1; }
+        __syncthreads();
         const int64_t next = d_next_live_sem(S.sems, prev + 1, S.table_len);
         if (next == 0) { S.err = E_BOUNDS; return SEQ_ERROR; }      // semaphores[0] in the reference (App. A.6 (3))
         sem_pos = S.sems[next - 1] - 1;
-        __syncthreads();
-        if (with_col && threadIdx.x == 0) { S.col_keys[prev] = col; S.col_live[prev] = 1; }
     } else {
         if (S.table_len + 1 > S.table_cap) return SEQ_Y_TABLE_GROW | RERUN;
         // reference @assert !isnothing(moved_sem_pos) (src/pcsr.jl:132): no tombstone may be shifted

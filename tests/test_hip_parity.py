@@ -325,6 +325,89 @@ def test_matrix_from_empty_streaming_columns_c5_scaled(dsa, hip, oracle):
         np.testing.assert_allclose(ya, yb, rtol=RTOL, atol=0)
 
 
+def _column_run(g, gv, cols, m_rows, per_lo, per_hi):
+    """(I, J, V) for the given new columns: rows ascending inside each column (an append run of the colmajor orientation)."""
+    I, J, V = [], [], []
+    for j in cols:
+        per = per_lo + g.next() % (per_hi - per_lo + 1)
+        rows = set()
+        while len(rows) < per:
+            rows.add(1 + g.next() % m_rows)
+        for r in sorted(rows):
+            I.append(r); J.append(j); V.append(gv.unit12())
+    return I, J, V
+
+
+@pytest.mark.parametrize("seed,m_rows,per_lo,per_hi,batches", [(21, 300, 1, 1, [70, 200, 64, 500]), (22, 50, 1, 12, [100, 400, 30, 1500]),
+                                                              (23, 5000, 16, 16, [500, 500, 2000]), (24, 40, 3, 30, [10, 90, 90, 700])])
+def test_matrix_column_append_runs_match_oracle(dsa, hip, oracle, seed, m_rows, per_lo, per_hi, batches):
+    """Column streaming (Coluna pattern): every batch appends new columns in (col, row) order -> the colmajor orientation takes
+    the bitmap-only append-run path including the semaphore cells of the new partitions; the rowmajor orientation takes the
+    general path.  Starts from an empty matrix, runs through several _extend!s and table growths; between the runs, ops that
+    must not be swallowed by a run: a write into an older column, an update of an existing cell, a delete, a repeated row."""
+    a = dsa.dynamicsparse(fill_mode=False, binding=hip)
+    b = dsa.dynamicsparse(fill_mode=False, binding=oracle)
+    g, gv = SplitMix64(seed), SplitMix64(seed + 100)
+    nxt = 1
+    for bi, nb in enumerate(batches):
+        I, J, V = _column_run(g, gv, range(nxt, nxt + nb), m_rows, per_lo, per_hi)
+        nxt += nb
+        if bi >= 1:
+            # breakers in the middle of the batch: older column, update, delete, duplicate row in the current column
+            k = len(I) // 2
+            I[k:k] = [1 + g.next() % m_rows, I[0], I[1], I[k - 1]]
+            J[k:k] = [1, J[0], J[1], J[k - 1]]
+            V[k:k] = [4.25, 7.5, 0.0, 8.125]
+        a.set_batch(I, J, V)
+        b.set_batch(I, J, V)
+        assert_mat_equal(a, b)
+        for o in (0, 1):
+            ia, ib = a.info(o), b.info(o)
+            for key in ("stat_extends", "stat_rebalances", "stat_window_slots"):
+                assert ia[key] == ib[key], (o, key, bi)
+    # the batch continues the last existing column before opening new ones
+    last_rows = [m_rows + 1, m_rows + 2, m_rows + 5]
+    I, J, V = _column_run(g, gv, range(nxt, nxt + 80), m_rows, per_lo, per_hi)
+    I = last_rows + I; J = [nxt - 1] * 3 + J; V = [1.0, 2.0, 3.0] + V
+    a.set_batch(I, J, V); b.set_batch(I, J, V)
+    assert_mat_equal(a, b)
+    nxt += 80
+    rep = a.check(0)
+    assert not rep[2:7].any(), rep
+    x = unit12_array(seed, a.size()[1])
+    np.testing.assert_allclose(a.mul(x), b.mul(x), rtol=RTOL, atol=0)
+    # a tombstone at the end of the table: no run; the reference's addcolumn! stores the key in the tombstoned slot and
+    # addpartition! then throws (no semaphore follows, src/pcsr.jl:121-123) — same error, same state afterwards
+    a.deletecolumn(nxt - 1); b.deletecolumn(nxt - 1)
+    I, J, V = _column_run(g, gv, range(nxt, nxt + 70), m_rows, per_lo, per_hi)
+    errs = []
+    for m_ in (a, b):
+        try:
+            m_.set_batch(I, J, V)
+            errs.append(None)
+        except dsa.DsaError as e:
+            errs.append(e.code)
+    assert errs[0] == errs[1]
+    assert_mat_equal(a, b)
+
+
+def test_matrix_row_append_runs_and_negative_rows_match_oracle(dsa, hip, oracle):
+    """Rows streamed in (row, col) order make the ROWMAJOR orientation the append run; rows <= 0 never enter a run
+    (the semaphore key is 0) but must still match."""
+    a = dsa.dynamicsparse(fill_mode=False, binding=hip)
+    b = dsa.dynamicsparse(fill_mode=False, binding=oracle)
+    g, gv = SplitMix64(31), SplitMix64(32)
+    J, I, V = _column_run(g, gv, range(1, 301), 200, 2, 9)          # transposed roles: "columns" are rows here
+    a.set_batch(I, J, V); b.set_batch(I, J, V)
+    assert_mat_equal(a, b)
+    I2, J2, V2 = [], [], []
+    for j in range(400, 500):
+        for r in (-5, -2, 3, 9):
+            I2.append(r); J2.append(j); V2.append(gv.unit12())
+    a.set_batch(I2, J2, V2); b.set_batch(I2, J2, V2)
+    assert_mat_equal(a, b)
+
+
 def test_error_codes_match_reference_sites(dsa, hip):
     a = dsa.dynamicsparse([1, 2], [1, 2], [1.0, 2.0], binding=hip)
     with pytest.raises(dsa.DsaArgumentError):
