@@ -4,22 +4,16 @@
 // (src/operations.jl:14-60) for a dense x (every index stored).  Two forms over ONE orientation
 // P of the matrix (a MappedPackedCSC: slot array + semaphores + partition keys):
 //
-//   gather  : y[part_key(p)] = sum_{slots of partition p} val * x[key]      (no atomics inside a row)
+//   gather  : y[part_key(p)] = sum_{slots of partition p} val * x[key]      (k_spmv_gather; no atomics inside a row)
 //             used on the TWIN orientation: mat*v walks rowmajor, transpose(mat)*v walks colmajor.
 //             Per output row the terms are added left to right in ascending key order — exactly
-//             the reference's accumulation order — except for rows that straddle a tile boundary
-//             (two or more partial sums joined by fp64 atomics; within the 1e-12 tolerance).
+//             the reference's accumulation order — except for rows longer than a wave's span
+//             (partial sums joined by fp64 atomics; within the 1e-12 tolerance).
 //   scatter : y[key] += x[part_key(p)] * val with fp64 atomics — the literal loop nest of the
-//             reference on its own orientation (mat*v walks colmajor).
+//             reference on its own orientation (mat*v walks colmajor)                       (k_spmv_scatter).
 //
-// Bound: HBM.  Algorithmic bytes per launch = 16*capacity + 8*nx + 8*ny: the flat
+// Bound: HBM / fabric.  Algorithmic bytes per launch = 16*capacity + 8*nx + 8*ny: the flat
 // scan streams every slot (gaps included — they are part of the bit-identical layout) once.
-//
-// Kernel shape: one 256-thread workgroup per 2048-slot tile; wave w owns 8 occupancy words, lane <->
-// slot (one ballot-shaped word per iteration, coalesced 8-byte key/value streams).  Products are
-// staged in LDS; semaphore slots are compacted per wave with ballot + popcount; each semaphore's
-// owner lane then sums its segment from LDS in slot order.  The partition active at the tile start
-// is found by a short backward ballot scan (fallback: bisection of the semaphore table).
 #include "dsa_dev.h"
 
 namespace dsa {
@@ -29,8 +23,6 @@ constexpr int SP_BLOCK = 256;
 constexpr int SP_WAVES = SP_BLOCK / 64;
 constexpr int SP_PER_WAVE = SP_TILE / SP_WAVES;     // 512 slots = 8 words
 constexpr int SP_WORDS_PER_WAVE = SP_PER_WAVE / 64;
-constexpr int SP_LONG = 48;                          // segments longer than this are summed by a whole wave
-constexpr int SP_MAXLONG = 64;
 constexpr int SP_BACK_WORDS = 32;                    // backward ballot scan limit before the table bisection
 
 __device__ __forceinline__ double wave_reduce_add_f64(double v) {
@@ -69,10 +61,9 @@ __device__ int64_t carry_in_partition(const int64_t* __restrict__ keys, const do
     return best + 1;
 }
 
-struct LongSeg { int start, end; int64_t row; int atomic; };
-
-template <bool SCATTER>
-__global__ __launch_bounds__(SP_BLOCK) void k_spmv(const int64_t* __restrict__ keys, const double* __restrict__ vals,
+// scatter form: one 256-thread workgroup per 2048-slot tile; wave w owns 8 occupancy words, lane <-> slot; values and
+// semaphore ids are staged in LDS, every cell finds the semaphore in front of it from the per-word semaphore ballots.
+__global__ __launch_bounds__(SP_BLOCK) void k_spmv_scatter(const int64_t* __restrict__ keys, const double* __restrict__ vals,
                                                    const uint64_t* __restrict__ occ, int64_t capacity,
                                                    const int64_t* __restrict__ sems,
                                                    const int64_t* __restrict__ part_keys, int64_t table_len,
@@ -82,8 +73,6 @@ __global__ __launch_bounds__(SP_BLOCK) void k_spmv(const int64_t* __restrict__ k
     __shared__ uint16_t sSemList[SP_WAVES][SP_PER_WAVE];
     __shared__ int sSemCnt[SP_WAVES];
     __shared__ int64_t sCarry;
-    __shared__ LongSeg sLong[SP_MAXLONG];
-    __shared__ int sNLong;
     __shared__ uint64_t sSemBits[SP_TILE / 64];
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -100,9 +89,8 @@ __global__ __launch_bounds__(SP_BLOCK) void k_spmv(const int64_t* __restrict__ k
     }
     const int64_t b0 = tile * SP_TILE;
     const int tile_end = (int)((capacity - b0) < SP_TILE ? (capacity - b0) : SP_TILE);
-    if (tid == 0) sNLong = 0;
 
-    // ---- phase 1: stream the tile, products (gather) or raw values (scatter) -> LDS -----------------
+    // ---- phase 1: stream the tile, values -> LDS ---------------------------------------------------------
     int64_t k[SP_WORDS_PER_WAVE];
     double v[SP_WORDS_PER_WAVE];
     bool bit[SP_WORDS_PER_WAVE];
@@ -123,21 +111,11 @@ __global__ __launch_bounds__(SP_BLOCK) void k_spmv(const int64_t* __restrict__ k
     for (int j = 0; j < SP_WORDS_PER_WAVE; ++j) {
         const int ls = wv * SP_PER_WAVE + j * 64 + lane;
         const bool issem = bit[j] && k[j] == SEM_KEY;
-        double p = 0.0;
-        if (issem) p = v[j];
-        else if (bit[j]) {
-            if (SCATTER) p = v[j];
-            else if (k[j] >= 1 && k[j] <= nx) {
-                const double xv = x[k[j] - 1];
-                // pattern pass (touched rows of _mul, src/operations.jl:101): count the cells whose x entry is stored
-                p = (pattern & 3) == 1 ? (xv != 0.0 ? 1.0 : 0.0) : v[j] * xv;
-            }
-        }
-        sP[ls] = p;
+        sP[ls] = bit[j] ? v[j] : 0.0;
         const uint64_t sb = __ballot(issem);
         if (issem) sSemList[wv][nsem + popc64(sb & mask_lt(lane))] = (uint16_t)ls;
         nsem += popc64(sb);
-        if (SCATTER && lane == 0) sSemBits[wv * SP_WORDS_PER_WAVE + j] = sb;
+        if (lane == 0) sSemBits[wv * SP_WORDS_PER_WAVE + j] = sb;
     }
     if (lane == 0) sSemCnt[wv] = nsem;
     __syncthreads();
@@ -156,63 +134,8 @@ __global__ __launch_bounds__(SP_BLOCK) void k_spmv(const int64_t* __restrict__ k
         if (lane == 0) sCarry = c;
     }
 
-    if ((pattern & 3) == 2) return;      // dev ablation (DSA_DBG_SPMV=2): stream + gather only, no segmented sums
-    if (!SCATTER) {
-        // ---- phase 2 (gather): one lane per semaphore sums its segment in slot order -------------
-        for (int j = tid; j < total; j += SP_BLOCK) {
-            int w = 0, idx = j;
-            while (idx >= cnt[w]) { idx -= cnt[w]; ++w; }
-            const int a = sSemList[w][idx];
-            int end = tile_end;
-            if (idx + 1 < cnt[w]) end = sSemList[w][idx + 1];
-            else {
-                for (int w2 = w + 1; w2 < SP_WAVES; ++w2) if (cnt[w2] > 0) { end = sSemList[w2][0]; break; }
-            }
-            const int64_t id = (int64_t)sP[a];
-            const int64_t row = part_keys[id - 1];
-            const int is_last = (j == total - 1);
-            if (end - a - 1 > SP_LONG) {
-                const int e = atomicAdd(&sNLong, 1);
-                sLong[e] = LongSeg{a + 1, end, row, is_last};
-            } else if (row >= 1 && row <= ny) {
-                // left-to-right sum of the segment (the reference's accumulation order); four LDS reads in flight
-                double sum = 0.0;
-                int s = a + 1;
-                for (; s + 3 < end; s += 4) {
-                    const double t0 = sP[s], t1 = sP[s + 1], t2 = sP[s + 2], t3 = sP[s + 3];
-                    sum = sum + t0; sum = sum + t1; sum = sum + t2; sum = sum + t3;
-                }
-                for (; s < end; ++s) sum = sum + sP[s];
-                if (is_last) atomicAdd(&y[row - 1], sum);    // the row may continue in the next tile
-                else y[row - 1] = sum;
-            }
-        }
-        __syncthreads();
-        // head: slots in front of the first semaphore belong to the carried-in partition
-        if (wv == 0 && first_sem > 0) {
-            const int64_t c = sCarry;
-            if (c > 0) {
-                double sum = 0.0;
-                for (int s = lane; s < first_sem; s += 64) sum += sP[s];
-                sum = wave_reduce_add_f64(sum);
-                const int64_t row = part_keys[c - 1];
-                if (lane == 0 && row >= 1 && row <= ny) atomicAdd(&y[row - 1], sum);
-            }
-        }
-        // long segments: a whole wave each
-        const int nlong = sNLong;
-        for (int e = wv; e < nlong; e += SP_WAVES) {
-            const LongSeg L = sLong[e];
-            double sum = 0.0;
-            for (int s = L.start + lane; s < L.end; s += 64) sum += sP[s];
-            sum = wave_reduce_add_f64(sum);
-            if (lane == 0 && L.row >= 1 && L.row <= ny) {
-                if (L.atomic) atomicAdd(&y[L.row - 1], sum);
-                else y[L.row - 1] = sum;
-            }
-        }
-    } else {
-        // ---- phase 2 (scatter): every cell finds the semaphore that precedes it -------------------
+    {
+        // ---- phase 2: every cell finds the semaphore that precedes it -------------------------------
         __shared__ int sLastBefore[SP_TILE / 64];
         __syncthreads();
         if (tid < SP_TILE / 64) {
@@ -236,6 +159,196 @@ __global__ __launch_bounds__(SP_BLOCK) void k_spmv(const int64_t* __restrict__ k
                     const int64_t col = part_keys[id - 1];
                     if (col >= 1 && col <= nx && k[j] >= 1 && k[j] <= ny) atomicAdd(&y[k[j] - 1], x[col - 1] * v[j]);
                 }
+            }
+        }
+    }
+}
+
+// ---- gather form, wave-level ---------------------------------------------------------------------------------------
+// One wave per 512 contiguous slots (8 occupancy words); no workgroup barrier.  The cost of this kernel is the number of
+// cache-line requests a CU can keep in flight (tools/gatherbench.hip: the slot streams and the x gathers queue for the
+// same miss slots of the CU and their times add), so everything a wave will need is requested up front in ONE round of
+// straight-line code: 9 words of (key, value) — its own 8 plus the word behind them —, the keys of the word in front,
+// then one gather per lane and word: x[key] for a cell, part_keys[id] for a semaphore (its output row).  The products go
+// to the wave's own LDS slice; the semaphores of the span are compacted (ballot + popcount) and one lane per semaphore
+// sums its row from LDS left to right — the reference's accumulation order (src/operations.jl:101), so a row comes
+// out bit-identical to the reference unless it is longer than a span.  Who writes a row is decided by where its semaphore is:
+//   * a wave writes every row whose semaphore lies in its 512 slots, running past its end (at most one more span,
+//     SW_WORDS words) until the next semaphore: plain store, each y entry written once;
+//   * the cells in front of a wave's first semaphore belong to an earlier wave — covered by that wave's overrun iff the
+//     previous span contains a semaphore; otherwise (rows longer than a span) the wave adds its share with an fp64
+//     atomic to the row found by the backward search, and the owner, whose overrun hit the limit, adds with an atomic too.
+constexpr int SW_WORDS = 8;
+constexpr int SW_SLOTS = (SW_WORDS + 1) * 64;     // products kept per wave: own span + the word behind it
+constexpr int SW_COOP = 4;                        // spans with at most this many semaphores: a whole wave per row
+
+__device__ __forceinline__ double product_of(double v, double xv, bool count_pass) {
+    // count pass (touched rows of _mul, src/operations.jl:101): 1 for every cell whose x entry is stored (non-zero)
+    return count_pass ? (xv != 0.0 ? 1.0 : 0.0) : v * xv;
+}
+
+__global__ __launch_bounds__(SP_BLOCK) void k_spmv_gather(const int64_t* __restrict__ keys, const double* __restrict__ vals,
+                                                          const uint64_t* __restrict__ occ, int64_t capacity,
+                                                          const int64_t* __restrict__ sems,
+                                                          const int64_t* __restrict__ part_keys, int64_t table_len,
+                                                          const double* __restrict__ x, int64_t nx,
+                                                          double* __restrict__ y, int64_t ny, int pattern) {
+    __shared__ double sPw[SP_WAVES][SW_SLOTS];
+    __shared__ uint16_t sListw[SP_WAVES][SW_SLOTS];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    double* sP = sPw[wv];
+    uint16_t* sList = sListw[wv];
+    // XCD-aware tile mapping (see k_spmv): XCD g streams the g-th contiguous eighth of the slot array
+    const int64_t ntiles = (capacity + SP_TILE - 1) / SP_TILE;
+    int64_t tile = blockIdx.x;
+    if (ntiles >= 64 && !(pattern & 4)) {
+        const int64_t per = (ntiles + 7) / 8;
+        tile = (int64_t)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
+        if (tile >= ntiles) return;
+    }
+    const int64_t nwords = (capacity + 63) >> 6;      // slot buffers are allocated in whole words (cap_alloc >= 4096)
+    const int64_t w0 = tile * (SP_TILE / 64) + (int64_t)wv * SW_WORDS;
+    if (w0 >= nwords) return;
+    const bool count_pass = (pattern & 3) == 1;
+    const int64_t* other = table_len > 0 ? part_keys : (const int64_t*)occ;     // what idle lanes and semaphores read
+
+    // ---- one round of requests (straight-line: word indices are clamped, not predicated) ---------------------------------
+    int64_t k[SW_WORDS + 1];
+    double v[SW_WORDS + 1];
+#pragma unroll
+    for (int j = 0; j <= SW_WORDS; ++j) {
+        const int64_t w = w0 + j < nwords ? w0 + j : nwords - 1;
+        k[j] = __builtin_nontemporal_load(keys + (w << 6) + lane);
+        v[j] = __builtin_nontemporal_load(vals + (w << 6) + lane);
+    }
+    // the word in front: does the previous span own the cells before our first semaphore?
+    const int64_t pw = w0 > 0 ? w0 - 1 : 0;
+    const uint64_t pword = w0 > 0 ? occ[pw] : 0ull;
+    const int64_t pk = keys[(pw << 6) + lane];
+
+    // ---- semaphore ballots, one gather per lane and word -----------------------------------------------------------------
+    uint64_t sb[SW_WORDS + 1], cm[SW_WORDS + 1];
+    int64_t q[SW_WORDS + 1];       // cell: bits of x[key] ; semaphore: row key of its partition
+    const uint32_t tlen = table_len < 0x7fffffff ? (uint32_t)table_len : 0x7fffffffu;
+#pragma unroll
+    for (int j = 0; j <= SW_WORDS; ++j) {
+        const uint64_t word = w0 + j < nwords ? occ[w0 + j] : 0ull;
+        const bool bit = (word >> lane) & 1ull;
+        const bool issem = bit && k[j] == SEM_KEY;
+        sb[j] = __ballot(issem);
+        bool cell = bit && (uint64_t)(k[j] - 1) < (uint64_t)nx;           // 1 <= key <= nx (a semaphore wraps to 2^64-1)
+        // the word behind the span: only the cells in front of its first semaphore matter
+        if (j == SW_WORDS) cell = cell && lane < (sb[j] ? __ffsll((unsigned long long)sb[j]) - 1 : 64);
+        cm[j] = __ballot(cell);
+        const uint32_t id1 = (uint32_t)((int)v[j] - 1);                     // partition ids are stored as Float64 (src/pcsr.jl:104)
+        const bool semrow = issem && id1 < tlen;
+        const int64_t* base = cell ? (const int64_t*)x : other;
+        const int64_t idx = cell ? k[j] - 1 : (semrow ? (int64_t)id1 : 0);
+        q[j] = base[idx];
+        if (issem && !semrow) q[j] = 0;
+    }
+    // ---- products and semaphore rows -> LDS ; compact the semaphores of the span ---------------------------------------
+    int nsem = 0;
+#pragma unroll
+    for (int j = 0; j <= SW_WORDS; ++j) {
+        const bool cell = (cm[j] >> lane) & 1ull;
+        const bool issem = (sb[j] >> lane) & 1ull;
+        const double p = product_of(v[j], __longlong_as_double(q[j]), count_pass);
+        sP[j * 64 + lane] = issem ? __longlong_as_double(q[j]) : (cell ? p : 0.0);
+        if (j < SW_WORDS) {
+            if (issem) sList[nsem + popc64(sb[j] & mask_lt(lane))] = (uint16_t)(j * 64 + lane);
+            nsem += popc64(sb[j]);
+        }
+    }
+    const int own_words = (int)(nwords - w0 < SW_WORDS ? nwords - w0 : SW_WORDS);
+    // end of the row that is open at the end of the span, as far as the 9 words show it
+    const bool behind_valid = w0 + SW_WORDS < nwords;
+    const int endpos = !behind_valid ? own_words * 64 : (sb[SW_WORDS] ? SW_WORDS * 64 + __ffsll((unsigned long long)sb[SW_WORDS]) - 1 : SW_SLOTS);
+    bool closed = !behind_valid || sb[SW_WORDS] != 0;
+    __builtin_amdgcn_wave_barrier();
+
+    double open_sum = 0.0;         // last row of the span (wave-uniform after the walk)
+    int64_t open_row = 0;
+    if (nsem > SW_COOP) {
+        // one lane per semaphore, left to right
+        for (int e = lane; e < nsem; e += 64) {
+            const int a = sList[e];
+            const bool is_last = e == nsem - 1;
+            const int end = is_last ? endpos : (int)sList[e + 1];
+            const int64_t row = __double_as_longlong(sP[a]);
+            double sum = 0.0;
+            int t = a + 1;
+            for (; t + 3 < end; t += 4) {
+                const double t0 = sP[t], t1 = sP[t + 1], t2 = sP[t + 2], t3 = sP[t + 3];
+                sum = sum + t0; sum = sum + t1; sum = sum + t2; sum = sum + t3;
+            }
+            for (; t < end; ++t) sum = sum + sP[t];
+            if (!is_last || closed) { if (row >= 1 && row <= ny) y[row - 1] = sum; }
+        }
+        if (!closed) {        // re-sum the open row cooperatively for the slow path below
+            const int a = sList[nsem - 1];
+            open_row = __double_as_longlong(sP[a]);
+            double sum = 0.0;
+            for (int t = a + 1 + lane; t < endpos; t += 64) sum += sP[t];
+            open_sum = wave_reduce_add_f64(sum);
+        }
+    } else {
+        // few, long rows: the whole wave sums each of them
+        for (int e = 0; e < nsem; ++e) {
+            const int a = sList[e];
+            const bool is_last = e == nsem - 1;
+            const int end = is_last ? endpos : (int)sList[e + 1];
+            const int64_t row = __double_as_longlong(sP[a]);
+            double sum = 0.0;
+            for (int t = a + 1 + lane; t < end; t += 64) sum += sP[t];
+            sum = wave_reduce_add_f64(sum);
+            if (!is_last || closed) { if (lane == 0 && row >= 1 && row <= ny) y[row - 1] = sum; }
+            else { open_row = row; open_sum = sum; }
+        }
+    }
+
+    if (nsem > 0 && !closed) {
+        // ---- rows longer than a word behind the span: keep going, at most to the end of the next span ---------------
+        for (int64_t w = w0 + SW_WORDS + 1; !closed && w < w0 + 2 * SW_WORDS; ++w) {
+            if (w >= nwords) { closed = true; break; }
+            const uint64_t wd = occ[w];
+            const bool bit = (wd >> lane) & 1ull;
+            int64_t kk = -1; double vv = 0.0;
+            if (bit) { kk = keys[(w << 6) + lane]; vv = vals[(w << 6) + lane]; }
+            const uint64_t sbw = __ballot(bit && kk == SEM_KEY);
+            const int lim = sbw ? __ffsll((unsigned long long)sbw) - 1 : 64;
+            double pp = 0.0;
+            if (bit && lane < lim && kk >= 1 && kk <= nx) pp = product_of(vv, x[kk - 1], count_pass);
+            open_sum += wave_reduce_add_f64(pp);
+            closed = sbw != 0;
+        }
+        if (w0 + 2 * SW_WORDS >= nwords) closed = true;       // nothing behind the next span: nobody else adds to this row
+        if (lane == 0 && open_row >= 1 && open_row <= ny) {
+            if (closed) y[open_row - 1] = open_sum;
+            else atomicAdd(&y[open_row - 1], open_sum);       // the row continues: later waves add their share
+        }
+    }
+
+    // ---- cells in front of our first semaphore ---------------------------------------------------------------------------
+    if (w0 > 0) {
+        const bool pbit = (pword >> lane) & 1ull;
+        bool covered = __ballot(pbit && pk == SEM_KEY) != 0;
+        for (int64_t w = w0 - 2; !covered && w >= 0 && w >= w0 - SW_WORDS; --w) {
+            const uint64_t wd = occ[w];
+            bool issem = false;
+            if ((wd >> lane) & 1ull) issem = keys[(w << 6) + lane] == SEM_KEY;
+            covered = __ballot(issem) != 0;
+        }
+        if (!covered) {
+            const int head_end = nsem > 0 ? (int)sList[0] : own_words * 64;
+            double sum = 0.0;
+            for (int t = lane; t < head_end; t += 64) sum += sP[t];
+            sum = wave_reduce_add_f64(sum);
+            const int64_t c = carry_in_partition(keys, vals, occ, sems, table_len, (w0 - SW_WORDS > 0 ? w0 - SW_WORDS : 0) << 6);
+            if (c >= 1 && c <= table_len) {
+                const int64_t row = part_keys[c - 1];
+                if (lane == 0 && row >= 1 && row <= ny) atomicAdd(&y[row - 1], sum);
             }
         }
     }
@@ -320,10 +433,10 @@ static hipError_t launch_spmv(bool scatter, int pattern, const int64_t* keys, co
     const int64_t ntiles = (capacity + SP_TILE - 1) / SP_TILE;
     const int64_t grid = ntiles >= 64 ? 8 * ((ntiles + 7) / 8) : ntiles;     // see the XCD-aware mapping in k_spmv
     if (scatter)
-        hipLaunchKernelGGL(k_spmv<true>, dim3((unsigned)grid), dim3(SP_BLOCK), 0, stream, keys, vals, occ, capacity, sems,
+        hipLaunchKernelGGL(k_spmv_scatter, dim3((unsigned)grid), dim3(SP_BLOCK), 0, stream, keys, vals, occ, capacity, sems,
                            part_keys, table_len, x, nx, y, ny, 0);
     else
-        hipLaunchKernelGGL(k_spmv<false>, dim3((unsigned)grid), dim3(SP_BLOCK), 0, stream, keys, vals, occ, capacity, sems,
+        hipLaunchKernelGGL(k_spmv_gather, dim3((unsigned)grid), dim3(SP_BLOCK), 0, stream, keys, vals, occ, capacity, sems,
                            part_keys, table_len, x, nx, y, ny, pattern);
     return hipGetLastError();
 }
