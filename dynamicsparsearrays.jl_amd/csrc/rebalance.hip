@@ -9,7 +9,7 @@
 // Bound: HBM.  Algorithmic bytes per W-slot window = 2 * 16 * W (read + write every slot);
 // the occupancy bitmap (W/8 B each way) and the tile counters are not counted.
 //
-//   k_tile_count : one wave per 4096-slot source tile, lane <-> occupancy word, popcount + wave reduce
+//   k_tile_count : cells per 4096-slot source tile, lane <-> occupancy word, popcount + wave reduce (16 tiles per workgroup)
 //   k_tile_scan  : one workgroup, exclusive prefix of the tile counts
 //   k_move       : one workgroup per 2048-slot DESTINATION tile.  Source cells whose rank falls in
 //                  the tile are compacted into LDS with wave64 ballot-style prefix popcounts (only
@@ -54,37 +54,50 @@ __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v) {
     return x - v;
 }
 
-__global__ __launch_bounds__(64) void k_tile_count(const uint64_t* __restrict__ occ, int64_t lo0, int64_t hi0,
-                                                   int64_t w0, int64_t nwords, uint32_t* __restrict__ tile_cnt) {
-    const int64_t t = blockIdx.x;
-    const int64_t w = t * SRC_TILE_WORDS + threadIdx.x;
-    uint32_t pc = 0;
-    if (w < nwords) pc = popc64(occ[w0 + w] & range_mask_for_word(w0 + w, lo0, hi0));
-    pc = wave_reduce_add(pc);
-    if (threadIdx.x == 0) tile_cnt[t] = pc;
+// 256-thread workgroups, 16 tiles each (wave w: tiles 16b+4w .. +3): the four occupancy loads of a lane are in flight together
+constexpr int CNT_TILES = 16;
+__global__ __launch_bounds__(256) void k_tile_count(const uint64_t* __restrict__ occ, int64_t lo0, int64_t hi0,
+                                                    int64_t w0, int64_t nwords, int64_t ntiles, uint32_t* __restrict__ tile_cnt) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t pc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t t = (int64_t)blockIdx.x * CNT_TILES + wv * 4 + i;
+        const int64_t w = t * SRC_TILE_WORDS + lane;
+        pc[i] = 0;
+        if (t < ntiles && w < nwords) pc[i] = popc64(occ[w0 + w] & range_mask_for_word(w0 + w, lo0, hi0));
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t t = (int64_t)blockIdx.x * CNT_TILES + wv * 4 + i;
+        const uint32_t r = wave_reduce_add(pc[i]);
+        if (lane == 0 && t < ntiles) tile_cnt[t] = r;
+    }
 }
 
+// one workgroup: exclusive prefix of n counts, 4096 per round (4 consecutive counts per thread, one barrier pair per round)
 __global__ __launch_bounds__(1024) void k_tile_scan(const uint32_t* __restrict__ cnt, uint32_t* __restrict__ off, int64_t n) {
     __shared__ uint32_t wsum[16];
-    __shared__ uint32_t carry_s;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    if (tid == 0) carry_s = 0;
-    __syncthreads();
-    for (int64_t base = 0; base < n; base += 1024) {
-        const int64_t i = base + tid;
-        const uint32_t v = i < n ? cnt[i] : 0u;
-        const uint32_t ex = wave_excl_scan(v);
-        if (lane == 63) wsum[wv] = ex + v;
+    uint32_t carry = 0;
+    for (int64_t base = 0; base < n; base += 4096) {
+        const int64_t i0 = base + (int64_t)tid * 4;
+        uint32_t c[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) c[i] = i0 + i < n ? cnt[i0 + i] : 0u;
+        const uint32_t local = c[0] + c[1] + c[2] + c[3];
+        const uint32_t ex = wave_excl_scan(local);
+        if (lane == 63) wsum[wv] = ex + local;
         __syncthreads();
-        uint32_t woff = 0;
-        for (int k = 0; k < wv; ++k) woff += wsum[k];
-        const uint32_t carry = carry_s;
-        if (i < n) off[i] = carry + woff + ex;
-        __syncthreads();
-        if (tid == 1023) carry_s = carry + woff + ex + v;
+        uint32_t run = carry + ex, total = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { const uint32_t wsk = wsum[k]; if (k < wv) run += wsk; total += wsk; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { if (i0 + i < n) off[i0 + i] = run; run += c[i]; }
+        carry += total;
         __syncthreads();
     }
-    if (tid == 0) off[n] = carry_s;
+    if (tid == 0) off[n] = carry;
 }
 
 struct MoveArgs {
@@ -273,7 +286,7 @@ hipError_t launch_compact_range(const int64_t* keys, const double* vals, const u
     const int64_t nwords = (hi0 >> 6) - w0 + 1;
     const int64_t ntiles = (nwords + SRC_TILE_WORDS - 1) / SRC_TILE_WORDS;
     if (ntiles + 1 > work->tiles_cap) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_tile_count, dim3((unsigned)ntiles), dim3(64), 0, stream, occ, lo0, hi0, w0, nwords, work->tile_cnt);
+    hipLaunchKernelGGL(k_tile_count, dim3((unsigned)((ntiles + CNT_TILES - 1) / CNT_TILES)), dim3(256), 0, stream, occ, lo0, hi0, w0, nwords, ntiles, work->tile_cnt);
     hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, stream, work->tile_cnt, work->tile_off, ntiles);
     uint32_t total = 0;
     hipError_t e = hipMemcpyAsync(&total, work->tile_off + ntiles, sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
@@ -375,11 +388,11 @@ hipError_t launch_permute(const int64_t* src_keys, const double* src_vals, const
     a.src_tiles = (a.src_words + SRC_TILE_WORDS - 1) / SRC_TILE_WORDS;
     a.dst_tiles = (a.dst_words + SRC_TILE_WORDS - 1) / SRC_TILE_WORDS;
     if (a.src_tiles + 1 > wsrc->tiles_cap || a.dst_tiles + 1 > wdst->tiles_cap) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_tile_count, dim3((unsigned)a.src_tiles), dim3(64), 0, stream, src_occ, (int64_t)0, src_cap - 1, (int64_t)0,
-                       a.src_words, wsrc->tile_cnt);
+    hipLaunchKernelGGL(k_tile_count, dim3((unsigned)((a.src_tiles + CNT_TILES - 1) / CNT_TILES)), dim3(256), 0, stream, src_occ, (int64_t)0,
+                       src_cap - 1, (int64_t)0, a.src_words, a.src_tiles, wsrc->tile_cnt);
     hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, stream, wsrc->tile_cnt, wsrc->tile_off, a.src_tiles);
-    hipLaunchKernelGGL(k_tile_count, dim3((unsigned)a.dst_tiles), dim3(64), 0, stream, dst_occ, (int64_t)0, dst_cap - 1, (int64_t)0,
-                       a.dst_words, wdst->tile_cnt);
+    hipLaunchKernelGGL(k_tile_count, dim3((unsigned)((a.dst_tiles + CNT_TILES - 1) / CNT_TILES)), dim3(256), 0, stream, dst_occ, (int64_t)0,
+                       dst_cap - 1, (int64_t)0, a.dst_words, a.dst_tiles, wdst->tile_cnt);
     hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, stream, wdst->tile_cnt, wdst->tile_off, a.dst_tiles);
     a.src_off = wsrc->tile_off; a.dst_off = wdst->tile_off;
     a.n0 = n0; a.ops = ops; a.i0 = i0; a.sems = sems;
@@ -432,8 +445,8 @@ hipError_t launch_rebalance(const int64_t* src_keys, const double* src_vals, con
     const int64_t ntiles = (nwords + SRC_TILE_WORDS - 1) / SRC_TILE_WORDS;
     if (ntiles + 1 > work->tiles_cap) return hipErrorInvalidValue;
     // the occupancy array is allocated in whole 64-word tiles (see Pma::alloc), so lane <-> word reads stay in bounds
-    hipLaunchKernelGGL(k_tile_count, dim3((unsigned)ntiles), dim3(64), 0, stream, src_occ, a.src_lo0, a.src_hi0,
-                       a.src_w0, nwords, work->tile_cnt);
+    hipLaunchKernelGGL(k_tile_count, dim3((unsigned)((ntiles + CNT_TILES - 1) / CNT_TILES)), dim3(256), 0, stream, src_occ, a.src_lo0,
+                       a.src_hi0, a.src_w0, nwords, ntiles, work->tile_cnt);
     hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, stream, work->tile_cnt, work->tile_off, ntiles);
     a.tile_off = work->tile_off; a.ntiles = ntiles;
     a.tiles_per_cell = m > 0 ? (double)ntiles / (double)m : 0.0;

@@ -41,7 +41,13 @@ struct Seq {
     uint32_t* sWordOff;            // [SMALL_W/64 + 1]
     int64_t* sRed;                 // [SEQ_BLOCK/64] block-reduce scratch
     const int64_t* lo; const int64_t* hi;   // integer density bounds per level (LDS copy of Ctl::lo / Ctl::hi)
+    // pending partitions (see "deferred column-table inserts" below): table entries [n_sorted, table_len) were created
+    // in this launch at the END of the tables, in arrival order; pKey / pIdx (LDS) list them sorted by key
+    int64_t n_sorted;
+    int n_pend;
+    int64_t* pKey; uint32_t* pIdx;
 };
+constexpr int PEND_MAX = 1024;
 
 
 // ---- workgroup-parallel primitives ------------------------------------------------------------------
@@ -878,8 +884,119 @@ __device__ int d_addpartition_middle(Seq& S, int64_t prev, bool with_col, int64_
     return r ? (r | RERUN) : 0;
 }
 
+// ---- deferred column-table inserts ----------------------------------------------------------------------------------
+// addpartition!(pcsc, prev) in the middle of the tables (src/pcsr.jl:114-146) shifts semaphores[] / col_keys[] one entry to
+// the right and rewrites the id stored in EVERY later semaphore cell: O(#partitions) per new column — the cost of streaming
+// new rows into the rowmajor twin in random key order (BASELINE config 5: 100k rows -> 5e9 id rewrites).  Ids are only
+// labels: the slot layout depends on WHERE the new semaphore cell is inserted (in front of the semaphore of its successor in
+// key order), not on its number.  So inside one launch a new partition is appended at the END of the tables with the next
+// free id (cells and tables stay consistent with each other: shifts, rebalances and spreads keep working on ids), its key
+// is kept in a small sorted list in LDS, lookups consult the sorted table part + that list, and the tables are brought
+// back to key order — ONE merge pass with ONE renumbering of the cells — when the list is full, before any op that is not a
+// plain MappedPackedCSC write, and always before the kernel exits (the host, the batch-parallel kernels and the big
+// rebalance never see pending entries).  Only used while no tombstone exists (nb_partitions == table_len); the
+// tombstone-reuse and @assert paths of the reference run on the literal code below.
+__device__ int pend_lower_bound(const Seq& S, int64_t key) {          // first j with pKey[j] >= key
+    int lo = 0, hi = S.n_pend;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (S.pKey[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+__device__ void pend_insert(Seq& S, int64_t key, int64_t idx, int p) {
+    __syncthreads();
+    int64_t kk[PEND_MAX / SEQ_BLOCK]; uint32_t ii[PEND_MAX / SEQ_BLOCK];
+#pragma unroll
+    for (int u = 0; u < PEND_MAX / SEQ_BLOCK; ++u) {
+        const int j = p + threadIdx.x + SEQ_BLOCK * u;
+        if (j < S.n_pend) { kk[u] = S.pKey[j]; ii[u] = S.pIdx[j]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < PEND_MAX / SEQ_BLOCK; ++u) {
+        const int j = p + threadIdx.x + SEQ_BLOCK * u;
+        if (j < S.n_pend) { S.pKey[j + 1] = kk[u]; S.pIdx[j + 1] = ii[u]; }
+    }
+    if (threadIdx.x == 0) { S.pKey[p] = key; S.pIdx[p] = (uint32_t)idx; }
+    __syncthreads();
+    S.n_pend += 1;
+}
+// successor in key order of `key` (which is in neither set, or is the key of partition `self`): 0-based table index, -1 if none.
+// sorted_succ = 0-based index of the first sorted entry with a larger key (>= n_sorted: none)
+__device__ int64_t succ_index(const Seq& S, int64_t sorted_succ, int64_t key) {
+    const int pj = pend_lower_bound(S, key + 1);
+    const bool has_s = sorted_succ < S.n_sorted, has_p = pj < S.n_pend;
+    if (has_s && has_p) return S.col_keys[sorted_succ] < S.pKey[pj] ? sorted_succ : (int64_t)S.pIdx[pj];
+    if (has_s) return sorted_succ;
+    if (has_p) return (int64_t)S.pIdx[pj];
+    return -1;
+}
+// tables back to key order: sorted entry i moves up by the number of pending keys below it, pending rank r goes to
+// (#sorted keys below it) + r; every cell whose id changed is rewritten once
+__device__ void d_merge_pending(Seq& S) {
+    const int K = S.n_pend;
+    if (K == 0) return;
+    __syncthreads();
+    const int64_t ns = S.n_sorted;
+    int64_t* dst = S.sK;                                      // dynamic LDS is free between ops
+    int64_t* spos = reinterpret_cast<int64_t*>(S.sV);
+    for (int r = threadIdx.x; r < K; r += SEQ_BLOCK) {
+        const int64_t key = S.pKey[r];
+        int64_t lo = 0, hi = ns;
+        while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (S.col_keys[mid] < key) lo = mid + 1; else hi = mid; }
+        dst[r] = lo + r;
+        spos[r] = S.sems[S.pIdx[r]];
+    }
+    __syncthreads();
+    const int64_t i_min = dst[0];                              // sorted entries below the smallest pending key stay
+    constexpr int U = 4;
+    for (int64_t hi = ns - 1; hi >= i_min; hi -= SEQ_BLOCK * U) {
+        int64_t sp[U], ck[U]; int sh[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t i = hi - threadIdx.x - SEQ_BLOCK * u;
+            if (i >= i_min) { sp[u] = S.sems[i]; ck[u] = S.col_keys[i]; }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t i = hi - threadIdx.x - SEQ_BLOCK * u;
+            sh[u] = i >= i_min ? pend_lower_bound(S, ck[u]) : 0;
+        }
+        __syncthreads();               // all loads of the chunk before its stores; stores never reach below the chunk
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t i = hi - threadIdx.x - SEQ_BLOCK * u;
+            if (i >= i_min && sh[u] > 0) {
+                const int64_t d = i + sh[u];
+                S.sems[d] = sp[u]; S.col_keys[d] = ck[u]; S.col_live[d] = 1;
+                S.vals[sp[u] - 1] = (double)(d + 1);
+            }
+        }
+    }
+    __syncthreads();
+    for (int r = threadIdx.x; r < K; r += SEQ_BLOCK) {
+        const int64_t d = dst[r];
+        S.sems[d] = spos[r]; S.col_keys[d] = S.pKey[r]; S.col_live[d] = 1;
+        S.vals[spos[r] - 1] = (double)(d + 1);
+    }
+    __syncthreads();
+    S.n_sorted = S.table_len;
+    S.n_pend = 0;
+}
+
 // _pos_of_partition_end  src/pcsr.jl:177-186
 __device__ int64_t d_partition_end(Seq& S, int64_t partition) {
+    if (S.n_pend > 0) {            // no tombstones in this mode: the successor in key order, sorted part or pending list
+        const int64_t kp = S.col_keys[partition - 1];
+        int64_t sorted_succ = partition;                        // 0-based index of the next sorted entry
+        if (partition > S.n_sorted) {
+            const DFoundKey f = d_find_table_fast(S.col_keys, S.col_live, S.n_sorted, kp);
+            sorted_succ = f.has ? f.pos : 0;                    // number of sorted keys < kp
+        }
+        const int64_t sidx = succ_index(S, sorted_succ, kp);
+        return sidx >= 0 ? S.sems[sidx] - 1 : S.capacity;
+    }
     const int64_t next = d_next_live_sem(S.sems, partition, S.table_len);
     return next != 0 ? S.sems[next - 1] - 1 : S.capacity;
 }
@@ -923,27 +1040,62 @@ __device__ int d_deletepartition(Seq& S, int64_t partition) {
 }
 
 __device__ int d_exec(Seq& S, const Op& op) {
+    if (op.kind != OP_MPCSC_SET && S.n_pend > 0) d_merge_pending(S);
     switch (op.kind) {
         case OP_VEC_SET:
             return d_set_in_range(S, op.a, op.v, 1, S.capacity, 1);
         case OP_PCSC_SET:
             return d_pcsc_set(S, op.v, op.a, op.b);
         case OP_MPCSC_SET: {       // setindex!(mpcsc, value, row, col)  src/pcsr.jl:341-351
-            const DFoundKey f = d_find_table_fast(S.col_keys, S.col_live, S.table_len, op.b);
+            if (S.n_pend == PEND_MAX) d_merge_pending(S);
+            if (S.n_pend == 0) S.n_sorted = S.table_len;
+            const DFoundKey f = d_find_table_fast(S.col_keys, S.col_live, S.n_sorted, op.b);
             int64_t col_pos = f.pos;
-            if (!(f.has && f.key == op.b)) {
-                if (f.pos == S.table_len) {
-                    if (S.table_len + 1 > S.table_cap) return SEQ_Y_TABLE_GROW | RERUN;
-                    __syncthreads();
-                    if (threadIdx.x == 0) { S.col_keys[S.table_len] = op.b; S.col_live[S.table_len] = 1; }
-                    __syncthreads();
-                    const int r = d_addpartition_append(S);
-                    if (r) return r;
-                    col_pos = S.table_len;
+            bool found = f.has && f.key == op.b;
+            int pj = 0;
+            if (!found && S.n_pend > 0) {
+                pj = pend_lower_bound(S, op.b);
+                if (pj < S.n_pend && S.pKey[pj] == op.b) { found = true; col_pos = (int64_t)S.pIdx[pj] + 1; }
+            }
+            if (!found) {
+                const bool no_tombstone = S.nb_partitions == S.table_len;
+                if (S.n_pend == 0 && (f.pos == S.table_len || !no_tombstone)) {
+                    // the literal paths of the reference: append behind the last column, or middle insert with tombstones around
+                    if (f.pos == S.table_len) {
+                        if (S.table_len + 1 > S.table_cap) return SEQ_Y_TABLE_GROW | RERUN;
+                        __syncthreads();
+                        if (threadIdx.x == 0) { S.col_keys[S.table_len] = op.b; S.col_live[S.table_len] = 1; }
+                        __syncthreads();
+                        const int r = d_addpartition_append(S);
+                        S.n_sorted = S.table_len;
+                        if (r) return r;
+                        col_pos = S.table_len;
+                    } else {
+                        const int r = d_addpartition_middle(S, f.pos, true, op.b);
+                        S.n_sorted = S.table_len;
+                        if (r) return r;
+                        col_pos = f.pos + 1;
+                    }
                 } else {
-                    const int r = d_addpartition_middle(S, f.pos, true, op.b);
-                    if (r) return r;
-                    col_pos = f.pos + 1;
+                    // deferred middle insert: same semaphore cell at the same place, table entry at the end (see above)
+                    if (S.table_len + 1 > S.table_cap) return SEQ_Y_TABLE_GROW | RERUN;
+                    const int64_t sidx = succ_index(S, f.has ? f.pos : 0, op.b);
+                    const int64_t sem_pos = sidx >= 0 ? S.sems[sidx] - 1 : S.capacity;
+                    const int64_t idx = S.table_len;
+                    __syncthreads();
+                    if (threadIdx.x == 0) { S.col_keys[idx] = op.b; S.col_live[idx] = 1; S.sems[idx] = sem_pos; }
+                    __syncthreads();
+                    S.table_len += 1;
+                    S.nb_partitions += 1;
+                    pend_insert(S, op.b, idx, pj);
+                    const int64_t ip = d_insert_after(S, SEM_KEY, (double)(idx + 1), sem_pos);
+                    if (ip == 0) return SEQ_ERROR;
+                    if (threadIdx.x == 0) S.sems[idx] = ip;
+                    __syncthreads();
+                    S.nb_elements += 1;
+                    const int r = d_after_count_change(S, ip);
+                    if (r) return r | RERUN;
+                    col_pos = idx + 1;
                 }
             }
             return d_pcsc_set(S, op.v, op.a, col_pos);
@@ -978,6 +1130,9 @@ __global__ __launch_bounds__(SEQ_BLOCK) void k_sequencer(int64_t* keys, double* 
     S.stat_window_slots = ctl->stat_window_slots; S.stat_rebalances = ctl->stat_rebalances;
     S.stat_small = ctl->stat_small_rebalances;
     S.y_ws = S.y_we = S.y_m = 0; S.err = 0; S.tail_hint = false;
+    __shared__ int64_t sPKey[PEND_MAX];
+    __shared__ uint32_t sPIdx[PEND_MAX];
+    S.n_sorted = S.table_len; S.n_pend = 0; S.pKey = sPKey; S.pIdx = sPIdx;
     S.sK = reinterpret_cast<int64_t*>(lds);
     S.sV = reinterpret_cast<double*>(lds + SMALL_W * sizeof(int64_t));
     S.sWordOff = sWordOff; S.sRed = sRed;
@@ -997,6 +1152,7 @@ __global__ __launch_bounds__(SEQ_BLOCK) void k_sequencer(int64_t* keys, double* 
         const bool csc_cand = col_keys != nullptr && op.kind == OP_MPCSC_SET && nxt.kind == OP_MPCSC_SET &&
                               (nxt.b > op.b || (nxt.b == op.b && nxt.a > op.a));
         if (run_ok && (vec_cand || csc_cand) && op.v != 0.0 && i + RUN_MIN <= n_avail && i != no_run_at && --run_cooldown < 0) {
+            d_merge_pending(S);
             const int64_t R = vec_cand ? d_detect_append_run(S, ops, i, n_avail) : d_detect_pcsc_run(S, ops, i, n_avail);
             if (R > 0) {
                 S.y_ws = i; S.y_we = S.nb_elements; S.y_m = R;
@@ -1013,6 +1169,7 @@ __global__ __launch_bounds__(SEQ_BLOCK) void k_sequencer(int64_t* keys, double* 
         }
         op = nxt;
     }
+    d_merge_pending(S);            // the tables leave the kernel in key order
     __syncthreads();
     if (threadIdx.x == 0) {
         ctl->next_op = i;

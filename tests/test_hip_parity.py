@@ -325,6 +325,73 @@ def test_matrix_from_empty_streaming_columns_c5_scaled(dsa, hip, oracle):
         np.testing.assert_allclose(ya, yb, rtol=RTOL, atol=0)
 
 
+@pytest.mark.parametrize("seed,nkeys,batch,span", [(31, 3000, 3000, 10**6), (32, 2500, 700, 5000), (33, 400, 90, 600)])
+def test_new_columns_in_random_key_order_deferred_table_inserts(dsa, hip, oracle, seed, nkeys, batch, span):
+    """Writes that create rows AND columns in random key order (middle inserts of addpartition!, src/pcsr.jl:114-146): the
+    device keeps new partitions at the end of the tables inside a launch and merges them once (more than 1024 new keys
+    in a batch: several merges); negative keys, overwrites, deletes of entries, and a deletecolumn! / deleterow! in the
+    middle (tombstones: the literal reference path).  Tables, semaphore ids and slot layout must equal the oracle's."""
+    g = SplitMix64(seed)
+    gv = SplitMix64(seed + 100)
+    a = dsa.dynamicsparse(fill_mode=False, binding=hip)
+    b = dsa.dynamicsparse(fill_mode=False, binding=oracle)
+    done = 0
+    while done < nkeys:
+        I, J, V = [], [], []
+        for _ in range(min(batch, nkeys - done)):
+            i = int(g.next() % (2 * span)) - span
+            j = int(g.next() % (2 * span)) - span
+            if i == 0 or j == 0:
+                continue
+            v = 0.0 if g.next() % 11 == 0 else gv.unit12()
+            I.append(i); J.append(j); V.append(v)
+            if g.next() % 3 == 0:                       # a second entry in the same row / column
+                I.append(i); J.append(int(g.next() % (2 * span)) - span or 7); V.append(gv.unit12())
+        a.set_batch(I, J, V)
+        b.set_batch(I, J, V)
+        assert_mat_equal(a, b)
+        done += batch
+    # tombstones: afterwards new keys take the reference's own middle-insert path (reuse of the tombstoned id, or the
+    # @assert of src/pcsr.jl:132 — then both sides must fail at the same op with the same code and the same state)
+    jdel = next(j for j, v in zip(J, V) if v != 0.0)
+    idel = next(i for i, v in zip(I[::-1], V[::-1]) if v != 0.0)
+    for m_ in (a, b):
+        m_.deletecolumn(jdel)
+        m_.deleterow(idel)
+    assert_mat_equal(a, b)
+    # re-create the deleted column and row (the tombstoned ids are reused, src/pcsr.jl:121-126) and append behind the last keys
+    live = [(i, j) for i, j, v in zip(I, J, V) if v != 0.0 and j != jdel and i != idel]
+    iex, jex = live[0]
+    I = [idel, idel, 5 * span, 5 * span + 1, iex]
+    J = [jex, jdel, jdel, 6 * span, jdel]
+    V = [gv.unit12() for _ in I]
+    for m_ in (a, b):
+        m_.set_batch(I, J, V)
+    assert_mat_equal(a, b)
+    # a new key in front of a tombstone that is not adjacent: the reference's @assert (src/pcsr.jl:132) — same error on both
+    # sides (the table state after that crash is a documented divergence, DESIGN.md §4: not compared)
+    for m_ in (a, b):
+        m_.deletecolumn(jdel)
+    I = [int(g.next() % (2 * span)) - span or 3 for _ in range(40)]
+    J = [int(g.next() % (2 * span)) - span or 5 for _ in range(40)]
+    V = [gv.unit12() for _ in range(40)]
+    codes = []
+    for m_ in (a, b):
+        try:
+            m_.set_batch(I, J, V)
+            codes.append(0)
+        except dsa.DsaError as e:
+            codes.append(e.code)
+    assert codes[0] == codes[1], codes
+    if codes[0] != 0:
+        return
+    assert_mat_equal(a, b)
+    n = a.size()[1]
+    if n >= 1:
+        x = unit12_array(seed + 5, n)
+        np.testing.assert_allclose(a.mul(x), b.mul(x), rtol=RTOL, atol=0)
+
+
 def _column_run(g, gv, cols, m_rows, per_lo, per_hi):
     """(I, J, V) for the given new columns: rows ascending inside each column (an append run of the colmajor orientation)."""
     I, J, V = [], [], []

@@ -6,14 +6,16 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench, dsa_loader
 dsa = dsa_loader.load(); hip = dsa.product()
-m5, ncols5, per5 = 10_000, 5_000, 16
+full = '--full' in sys.argv
+m5, ncols5, per5 = (100_000, 50_000, 16) if full else (10_000, 5_000, 16)
+step = 1000 if full else 500
 B = dsa.dynamicsparse(fill_mode=False, binding=hip)
 rows5 = 1 + (bench.splitmix_array(11, ncols5 * per5 * 2) % np.uint64(m5)).astype(np.int64)
 vals5 = bench.unit12(12, ncols5 * per5)
 pos = 0; nw = 0; t_w = 0.0
-for c0 in range(0, ncols5, 500):
+for c0 in range(0, ncols5, step):
     I5, J5 = [], []
-    for j in range(c0 + 1, c0 + 501):
+    for j in range(c0 + 1, c0 + step + 1):
         seen = set()
         while len(seen) < per5:
             seen.add(int(rows5[pos])); pos += 1
@@ -22,4 +24,4 @@ for c0 in range(0, ncols5, 500):
     V5 = vals5[nw:nw + len(I5)]
     t = time.perf_counter(); B.set_batch(I5, J5, V5); t_w += time.perf_counter() - t
     nw += len(I5)
-print("C5 scaled: %d element writes in %.1f ms -> %.0f writes/s" % (nw, t_w * 1e3, nw / t_w))
+print("C5 %s:" % ("full" if full else "scaled") + " %d element writes in %.1f ms -> %.0f writes/s" % (nw, t_w * 1e3, nw / t_w))
