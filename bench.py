@@ -117,33 +117,52 @@ def main():
     stream = torch.cuda.current_stream()
     hip.call("mat_set_stream", A.h, C.c_void_p(stream.cuda_stream))
     x = torch.from_numpy(unit12(7, ncl, start=col0)).to(dev)
-    y = torch.zeros(m, dtype=torch.float64, device=dev)
-    xp, yp = C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr())
+    # two output vectors: the RCCL all-reduce of step k (its own stream) overlaps the SpMV of step k+1
+    ys = [torch.zeros(m, dtype=torch.float64, device=dev) for _ in range(2 if world > 1 else 1)]
+    y = ys[0]
+    xp = C.c_void_p(x.data_ptr())
+    yps = [C.c_void_p(t.data_ptr()) for t in ys]
+    pending = [None] * len(ys)
 
-    def spmv():
-        hip.call("mat_spmv_dense_dev", A.h, 0, 0, xp, ncl, yp, m)
+    def spmv(k=0):
+        hip.call("mat_spmv_dense_dev", A.h, 0, 0, xp, ncl, yps[k % len(ys)], m)
 
-    def step():
-        spmv()
+    def step(k):
+        b = k % len(ys)
+        if pending[b] is not None:
+            pending[b].wait()                     # the collective that last used this buffer (two steps ago)
+            pending[b] = None
+        spmv(k)
         if world > 1:
-            dist.all_reduce(y, op=dist.ReduceOp.SUM)
+            pending[b] = dist.all_reduce(ys[b], op=dist.ReduceOp.SUM, async_op=True)
+
+    def drain():
+        for b in range(len(ys)):
+            if pending[b] is not None:
+                pending[b].wait()
+                pending[b] = None
 
     def barrier():
+        drain()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    for k in range(args.warmup):
+        step(k)
     barrier()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t1 = time.perf_counter()
     for k in range(args.steps):
+        b = k % len(ys)
+        if pending[b] is not None:
+            pending[b].wait()
+            pending[b] = None
         ev[k][0].record(stream)
-        spmv()
+        spmv(k)
         ev[k][1].record(stream)
         if world > 1:
-            dist.all_reduce(y, op=dist.ReduceOp.SUM)
+            pending[b] = dist.all_reduce(ys[b], op=dist.ReduceOp.SUM, async_op=True)
     barrier()
     elapsed = time.perf_counter() - t1
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
@@ -175,10 +194,10 @@ def main():
         "config": {"workload": "C3: PCSR %dx%d Float64, %d nnz per GPU, dense-x SpMV y=A*x (gather over the rowmajor twin)"
                                % (m, ncl * world, nnz),
                    "capacity_slots": cap, "density": round((nnz + m) / cap, 4), "sharding": "column-range x%d" % world,
-                   "collective": "RCCL all_reduce(y, %d f64)" % m if world > 1 else "none"},
+                   "collective": ("RCCL all_reduce(y, %d f64) on its own stream, overlapped with the next step's SpMV (two y buffers)" % m) if world > 1 else "none"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                     "kernel": "dsa::k_spmv<false> (+ 8 MB y memset)", "algorithmic_bytes": bytes_launch,
+                     "kernel": "dsa::k_spmv_gather (+ 8 MB y memset)", "algorithmic_bytes": bytes_launch,
                      "kernel_ms": round(kern_ms, 5),
                      "useful_bytes_no_gaps": useful_bytes,
                      "useful_gbps": round(useful_bytes / 1e9 / (kern_ms / 1e3), 2)},
@@ -263,38 +282,55 @@ def extras(dsa, hip, torch, A, dev):
     res["inserts_per_s"]["matrix_random_updates_per_s"] = round(len(ui) / (time.perf_counter() - t), 1)
     res["inserts_per_s"]["matrix_random_updates_config"] = "200k random A[i,j]=v (25% deletes) on a 20k x 30k matrix with 600k nnz"
 
-    # --- C5 (scaled 1/10): stream new columns element by element into an empty matrix (both orientations),
-    #     SpMV every 500 columns.  Full C5 is 50k columns x 16 rows over 100k rows; parity of this loop vs the
-    #     oracle is tests/test_hip_parity.py::test_matrix_from_empty_streaming_columns_c5_scaled
-    m5, ncols5, per5 = 10_000, 5_000, 16
-    B = dsa.dynamicsparse(fill_mode=False, binding=hip)      # keeps its two own streams: the orientations update concurrently
-    rows5 = 1 + (splitmix_array(11, ncols5 * per5 * 2) % np.uint64(m5)).astype(np.int64)
-    vals5 = unit12(12, ncols5 * per5)
-    x5 = torch.from_numpy(unit12(13, ncols5)).to(dev)
-    y5 = torch.zeros(m5, dtype=torch.float64, device=dev)
-    t_w, t_s, nw, nsp, pos = 0.0, 0.0, 0, 0, 0
-    for c0 in range(0, ncols5, 500):
-        I5, J5 = [], []
-        for j in range(c0 + 1, c0 + 501):
-            seen = set()
-            while len(seen) < per5:
-                seen.add(int(rows5[pos])); pos += 1
-            rr = sorted(seen)
-            I5 += rr; J5 += [j] * per5
-        V5 = vals5[nw:nw + len(I5)]
+    # --- C5 (BASELINE config 5, full size): stream 50k new columns (16 distinct rows each, ascending inside a column, 100k rows)
+    #     element by element into an empty matrix — both orientations —, SpMV every 1000 columns.  Parity of this loop vs the
+    #     oracle: tests/test_hip_parity.py::test_matrix_from_empty_streaming_columns_c5_scaled
+    res["c5_streaming"] = c5_streaming(dsa, hip, torch, dev, *C5_FULL)
+    return res
+
+
+C5_FULL = (100_000, 50_000, 16, 1000)
+
+
+def c5_columns(m5, ncols5, per5):
+    """(I, J, V) of the C5 stream: column j = 1..ncols5 in order, its rows ascending (seeds 11 / 12)."""
+    I, J, V = c3_triplets(m5, ncols5, per5, 0, seed_rows=11, seed_vals=12)
+    order = np.lexsort((I, J))
+    return I[order], J[order], V
+
+
+def c5_streaming(dsa, hip, torch, dev, m5, ncols5, per5, every, binding=None, stop_after=None):
+    B = dsa.dynamicsparse(fill_mode=False, binding=binding or hip)     # keeps its two own streams: the orientations update concurrently
+    I5, J5, V5 = c5_columns(m5, ncols5, per5)
+    x5 = unit12(13, ncols5)
+    if binding is None:
+        xd = torch.from_numpy(x5).to(dev)
+        yd = torch.zeros(m5, dtype=torch.float64, device=dev)
+    t_w, t_s, nsp, t_first = 0.0, 0.0, 0, None
+    for c0 in range(0, ncols5, every):
+        sl = slice(c0 * per5, (c0 + every) * per5)
         t = time.perf_counter()
-        B.set_batch(I5, J5, V5)
+        B.set_batch(I5[sl], J5[sl], V5[sl])
         t_w += time.perf_counter() - t
-        nw += len(I5)
         t = time.perf_counter()
-        hip.call("mat_spmv_dense_dev", B.h, 0, 0, C.c_void_p(x5.data_ptr()), c0 + 500, C.c_void_p(y5.data_ptr()), m5)
-        torch.cuda.synchronize()
+        if binding is None:
+            hip.call("mat_spmv_dense_dev", B.h, 0, 0, C.c_void_p(xd.data_ptr()), c0 + every, C.c_void_p(yd.data_ptr()), m5)
+            torch.cuda.synchronize()
+        else:
+            B.mul(x5[: c0 + every])
         t_s += time.perf_counter() - t
         nsp += 1
-    res["c5_streaming_scaled"] = {"columns": ncols5, "rows": m5, "element_writes": nw, "columns_per_s": round(ncols5 / t_w, 1),
-                                  "element_writes_per_s": round(nw / t_w, 1), "spmv_ms_avg": round(t_s / nsp * 1e3, 4),
-                                  "note": "each element write updates both orientations (2 PCSR inserts) on the device sequencer"}
-    return res
+        if c0 + every == 10_000:
+            t_first = t_w
+        if stop_after is not None and c0 + every >= stop_after:
+            break
+    ncols_done = min(ncols5, (nsp * every))
+    nw = ncols_done * per5
+    return {"columns": ncols_done, "rows": m5, "element_writes": nw, "columns_per_s": round(ncols_done / t_w, 1),
+            "element_writes_per_s": round(nw / t_w, 1), "write_s": round(t_w, 3), "first_10k_columns_write_s": None if t_first is None else round(t_first, 3),
+            "spmv_ms_avg": round(t_s / nsp * 1e3, 4), "spmv_every_columns": every,
+            "note": "each element write updates both orientations (2 PCSR inserts); new rows arrive in random key order "
+                    "(middle inserts of addpartition!, src/pcsr.jl:114-146)"}
 
 
 def cpu_baseline(dsa, m, per):
@@ -339,7 +375,9 @@ def cpu_baseline(dsa, m, per):
     t = time.perf_counter()
     vo.set_batch(odd, unit12(4, len(odd)))
     tb2 = time.perf_counter() - t
+    c5 = c5_streaming(dsa, None, None, None, *C5_FULL, binding=ora, stop_after=10_000)
     return {"value": round(bytes_ / 1e9 / ts, 4), "unit": "GB/s", "cores": 1, "kind": "port",
+            "c5_first_10k_columns": {k: c5[k] for k in ("columns", "element_writes", "write_s", "element_writes_per_s", "spmv_ms_avg")},
             "inserts_per_s": {"batch_A_ascending_appends": round(100000 / ta, 1), "batch_B_uniform": round(len(odd) / tb2, 1)},
             "sample": "first 400k columns of the C3 matrix (1M x 400k, %d nnz, colmajor capacity %d): y = A*x with the "
                       "reference's Dict accumulator (src/operations.jl:101), 1 thread of %d host cores" % (len(I), cap, multiprocessing.cpu_count()),

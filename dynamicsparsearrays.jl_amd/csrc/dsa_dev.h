@@ -48,6 +48,7 @@ struct Ctl {
     // instrumentation
     int64_t stat_window_slots, stat_rebalances, stat_extends, stat_shrinks, stat_small_rebalances;
     int64_t no_run_at;     // op index that must take the normal path (an append run made no progress there), or -1
+    int64_t prof[16];      // dev profile of the sequencer (shader cycles): table lookup, new partition, element write, merges; counts
     int64_t dbg[6];        // append-run profile of the last run: slow ops, ticks (100 MHz) in setup / fast loop / slow path, blocks loaded
     // vector length n (src/vector.jl:2) is host-only
 };

@@ -794,7 +794,15 @@ void mat_apply_sets(dsa_mat* h, const int64_t* I, const int64_t* J, const double
         const auto t0 = std::chrono::steady_clock::now();
         const int64_t dc = run_ops_parallel(h->col, oc, &ec);
         const auto t1 = std::chrono::steady_clock::now();
+        if (dbg_time) { std::memset(h->row.h_ctl->prof, 0, sizeof(h->row.h_ctl->prof)); }
         const int64_t dr = run_ops_parallel(h->row, orw, &er);
+        if (dbg_time) {
+            const int64_t* q = h->row.h_ctl->prof;
+            fprintf(stderr, "  [rowmajor sequencer cycles] lookup %lld (%lld ops)  newpart %lld (%lld)  elem %lld  merge %lld (%lld)  kernel total %lld\n",
+                    (long long)q[0], (long long)q[4], (long long)q[1], (long long)q[5], (long long)q[2], (long long)q[3], (long long)q[6], (long long)q[7]);
+            fprintf(stderr, "    find %lld  insert %lld  density-scan+rebalance %lld (small rebalances %lld cycles, %lld of them, %lld slots)  partition_end %lld\n",
+                    (long long)q[8], (long long)q[9], (long long)q[10], (long long)q[12], (long long)q[13], (long long)q[14], (long long)q[11]);
+        }
         if (dbg_time)
             fprintf(stderr, "[mat_apply_sets] n=%lld colmajor %.2f ms (par %lld seq %lld)  rowmajor %.2f ms (par %lld seq %lld)\n", (long long)n,
                     std::chrono::duration<double, std::milli>(t1 - t0).count(), (long long)h->col.stat_par_ops, (long long)h->col.stat_seq_ops,

@@ -166,14 +166,15 @@ static __device__ DFoundKey d_find_table(const int64_t* ck, const uint8_t* live,
 }
 
 // wave-parallel form of d_find_table (live column keys are strictly ascending)
-static __device__ DFoundKey d_find_table_fast(const int64_t* ck, const uint8_t* live, int64_t len, int64_t key) {
+// dense = true: the caller knows that no entry of [0, len) is tombstoned (nb_partitions == table_len): live[] is not read
+static __device__ DFoundKey d_find_table_fast(const int64_t* ck, const uint8_t* live, int64_t len, int64_t key, bool dense = false) {
     const int lane = lane_id();
     int64_t L = 0, H = len;
     while (H - L > 64) {
         const int64_t width = H - L;
         const int64_t p = L + (width * (lane + 1)) / 64;
         int64_t q = p;
-        while (q > L && !live[q - 1]) --q;
+        if (!dense) while (q > L && !live[q - 1]) --q;
         bool pr = true;
         if (q > L) pr = ck[q - 1] < key;
         const uint64_t nb = ~__ballot(pr);
@@ -185,14 +186,14 @@ static __device__ DFoundKey d_find_table_fast(const int64_t* ck, const uint8_t* 
     }
     const int64_t p = L + 1 + lane;
     bool viol = false;
-    if (p <= H && live[p - 1]) viol = ck[p - 1] >= key;
+    if (p <= H && (dense || live[p - 1])) viol = ck[p - 1] >= key;
     const uint64_t b = __ballot(viol);
     const int64_t pstar = b ? L + __ffsll((unsigned long long)b) - 1 : H;
     int64_t nxt = pstar + 1;
-    while (nxt <= len && !live[nxt - 1]) ++nxt;
+    if (!dense) while (nxt <= len && !live[nxt - 1]) ++nxt;
     if (nxt <= len && ck[nxt - 1] == key) return DFoundKey{nxt, key, true};
     int64_t i = pstar;
-    while (i > 0 && !live[i - 1]) --i;
+    if (!dense) while (i > 0 && !live[i - 1]) --i;
     if (i > 0) return DFoundKey{i, ck[i - 1], true};
     return DFoundKey{0, 0, false};
 }

@@ -69,7 +69,7 @@ __global__ __launch_bounds__(PB_BLOCK) void k_plan(const int64_t* keys, const do
         plannable = true;
     } else if (op.kind == OP_MPCSC_SET && sems != nullptr && col_keys != nullptr) {
         const int64_t table_len = ctl->table_len;
-        const DFoundKey tf = d_find_table_fast(col_keys, col_live, table_len, op.b);
+        const DFoundKey tf = d_find_table_fast(col_keys, col_live, table_len, op.b, ctl->nb_partitions == table_len);
         if (tf.has && tf.key == op.b) {
             const int64_t sp = sems[tf.pos - 1];
             if (sp != 0 && (op.v != 0.0 || op.a > SEM_KEY)) {

@@ -45,7 +45,8 @@ struct Seq {
     // in this launch at the END of the tables, in arrival order; pKey / pIdx (LDS) list them sorted by key
     int64_t n_sorted;
     int n_pend;
-    int64_t* pKey; uint32_t* pIdx;
+    int64_t prof[16];
+    int64_t* pKey; uint32_t* pIdx; uint32_t* pLb;      // pLb: number of SORTED keys below the pending key
 };
 constexpr int PEND_MAX = 1024;
 
@@ -212,7 +213,24 @@ __device__ int d_after_count_change(Seq& S, int64_t pos) {
     int64_t left = 0, right = 0;
     int64_t ws = 1, we = S.capacity;
     bool accepted = false;
-    for (int64_t h = 0; h <= S.height; ++h) {
+    int64_t h0 = 0;
+    if (S.seg <= 64) {
+        // the levels whose window fits the occupancy word of `pos` (windows are aligned powers of two): one load, popcounts of
+        // sub-masks.  Only left + right is ever used, so the last window's count seeds `left` for the wider levels.
+        const uint64_t word = S.occ[(pos - 1) >> 6];
+        for (; h0 <= S.height; ++h0) {
+            const int64_t W = S.seg << h0;
+            if (W > 64) break;
+            const int64_t ws0 = ((pos - 1) / W) * W;                          // 0-based first slot of the window
+            const uint64_t mask = (W == 64 ? ~0ull : ((1ull << W) - 1ull)) << (ws0 & 63);
+            const int64_t c = popc64(word & mask);
+            ws = ws0 + 1; we = ws0 + W;
+            left = c; right = 0;
+            if (S.lo[h0] <= c && c <= S.hi[h0]) { accepted = true; break; }
+            prev_ws = ws; prev_we = we;
+        }
+    }
+    for (int64_t h = h0; !accepted && h <= S.height; ++h) {
         const int64_t W = S.seg << h;
         ws = ((pos - 1) / W) * W + 1;
         we = ws + W - 1;
@@ -233,7 +251,7 @@ __device__ int d_after_count_change(Seq& S, int64_t pos) {
     const int64_t W = we - ws + 1;
     if (W == S.seg) return 0;
     S.stat_rebalances += 1; S.stat_window_slots += W;
-    if (W <= SMALL_W) { blk_rebalance_small(S, ws, we, count); return 0; }
+    if (W <= SMALL_W) { const int64_t tr0 = (int64_t)__builtin_readcyclecounter(); blk_rebalance_small(S, ws, we, count); S.prof[12] += (int64_t)__builtin_readcyclecounter() - tr0; S.prof[13] += 1; S.prof[14] += W; return 0; }
     S.y_ws = ws; S.y_we = we; S.y_m = count;
     return SEQ_Y_REBALANCE;
 }
@@ -788,7 +806,9 @@ __device__ int d_set_in_range(Seq& S, int64_t key, double val, int64_t from, int
                 if (lk < key) { f = DFound{lp, lk, 0.0, true}; have = true; }
             }
         }
+        const int64_t ts0 = (int64_t)__builtin_readcyclecounter();
         if (!have) f = d_find_fast(S.keys, S.vals, S.occ, key, from, to);     // [from, to] never holds a semaphore
+        S.prof[8] += (int64_t)__builtin_readcyclecounter() - ts0;
         S.tail_hint = have || (f.has && f.pos >= from && f.key < key && d_next_occupied(S.occ, f.pos, to) == 0);
         if (f.has && f.key == key && from <= f.pos && f.pos <= to) {
             __syncthreads();
@@ -796,10 +816,14 @@ __device__ int d_set_in_range(Seq& S, int64_t key, double val, int64_t from, int
             __syncthreads();
             return 0;
         }
+        const int64_t ts1 = (int64_t)__builtin_readcyclecounter();
         const int64_t ip = d_insert_after(S, key, val, f.pos);
         if (ip == 0) return SEQ_ERROR;
         S.nb_elements += 1;
-        return d_after_count_change(S, ip);
+        const int64_t ts2 = (int64_t)__builtin_readcyclecounter();
+        const int rr = d_after_count_change(S, ip);
+        S.prof[9] += ts2 - ts1; S.prof[10] += (int64_t)__builtin_readcyclecounter() - ts2;
+        return rr;
     }
     // the delete range of a partition starts AT its semaphore (key 0, src/pcsr.jl:307): the wave-parallel search is
     // only equivalent for key > 0 there; otherwise replay the reference bisection probe for probe
@@ -904,21 +928,21 @@ __device__ int pend_lower_bound(const Seq& S, int64_t key) {          // first j
     }
     return lo;
 }
-__device__ void pend_insert(Seq& S, int64_t key, int64_t idx, int p) {
+__device__ void pend_insert(Seq& S, int64_t key, int64_t idx, int64_t lb, int p) {
     __syncthreads();
-    int64_t kk[PEND_MAX / SEQ_BLOCK]; uint32_t ii[PEND_MAX / SEQ_BLOCK];
+    int64_t kk[PEND_MAX / SEQ_BLOCK]; uint32_t ii[PEND_MAX / SEQ_BLOCK], ll[PEND_MAX / SEQ_BLOCK];
 #pragma unroll
     for (int u = 0; u < PEND_MAX / SEQ_BLOCK; ++u) {
         const int j = p + threadIdx.x + SEQ_BLOCK * u;
-        if (j < S.n_pend) { kk[u] = S.pKey[j]; ii[u] = S.pIdx[j]; }
+        if (j < S.n_pend) { kk[u] = S.pKey[j]; ii[u] = S.pIdx[j]; ll[u] = S.pLb[j]; }
     }
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < PEND_MAX / SEQ_BLOCK; ++u) {
         const int j = p + threadIdx.x + SEQ_BLOCK * u;
-        if (j < S.n_pend) { S.pKey[j + 1] = kk[u]; S.pIdx[j + 1] = ii[u]; }
+        if (j < S.n_pend) { S.pKey[j + 1] = kk[u]; S.pIdx[j + 1] = ii[u]; S.pLb[j + 1] = ll[u]; }
     }
-    if (threadIdx.x == 0) { S.pKey[p] = key; S.pIdx[p] = (uint32_t)idx; }
+    if (threadIdx.x == 0) { S.pKey[p] = key; S.pIdx[p] = (uint32_t)idx; S.pLb[p] = (uint32_t)lb; }
     __syncthreads();
     S.n_pend += 1;
 }
@@ -937,15 +961,13 @@ __device__ int64_t succ_index(const Seq& S, int64_t sorted_succ, int64_t key) {
 __device__ void d_merge_pending(Seq& S) {
     const int K = S.n_pend;
     if (K == 0) return;
+    const int64_t tm0 = (int64_t)__builtin_readcyclecounter();
     __syncthreads();
     const int64_t ns = S.n_sorted;
     int64_t* dst = S.sK;                                      // dynamic LDS is free between ops
     int64_t* spos = reinterpret_cast<int64_t*>(S.sV);
     for (int r = threadIdx.x; r < K; r += SEQ_BLOCK) {
-        const int64_t key = S.pKey[r];
-        int64_t lo = 0, hi = ns;
-        while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (S.col_keys[mid] < key) lo = mid + 1; else hi = mid; }
-        dst[r] = lo + r;
+        dst[r] = (int64_t)S.pLb[r] + r;                       // (#sorted keys below it) + (#pending keys below it)
         spos[r] = S.sems[S.pIdx[r]];
     }
     __syncthreads();
@@ -983,6 +1005,7 @@ __device__ void d_merge_pending(Seq& S) {
     __syncthreads();
     S.n_sorted = S.table_len;
     S.n_pend = 0;
+    S.prof[3] += (int64_t)__builtin_readcyclecounter() - tm0; S.prof[6] += 1;
 }
 
 // _pos_of_partition_end  src/pcsr.jl:177-186
@@ -1010,7 +1033,9 @@ __device__ int d_pcsc_set(Seq& S, double val, int64_t key, int64_t partition) {
     }
     const int64_t from = S.sems[partition - 1];
     if (from == 0) { S.err = E_DELETED; return SEQ_ERROR; }
+    const int64_t te0 = (int64_t)__builtin_readcyclecounter();
     const int64_t to = d_partition_end(S, partition);
+    S.prof[11] += (int64_t)__builtin_readcyclecounter() - te0;
     return d_set_in_range(S, key, val, from + 1, to, from);
 }
 
@@ -1049,16 +1074,25 @@ __device__ int d_exec(Seq& S, const Op& op) {
         case OP_MPCSC_SET: {       // setindex!(mpcsc, value, row, col)  src/pcsr.jl:341-351
             if (S.n_pend == PEND_MAX) d_merge_pending(S);
             if (S.n_pend == 0) S.n_sorted = S.table_len;
-            const DFoundKey f = d_find_table_fast(S.col_keys, S.col_live, S.n_sorted, op.b);
+            const int64_t tp0 = (int64_t)__builtin_readcyclecounter();
+            const bool no_tombstone = S.nb_partitions == S.table_len;
+            const DFoundKey f = d_find_table_fast(S.col_keys, S.col_live, S.n_sorted, op.b, no_tombstone);
             int64_t col_pos = f.pos;
             bool found = f.has && f.key == op.b;
             int pj = 0;
+            // successor of the column in key order (0-based table index, -1: none, -2: not known yet) — bounds its slot range
+            int64_t sidx = -2;
+            if (found && S.n_pend > 0) sidx = succ_index(S, col_pos, op.b);
             if (!found && S.n_pend > 0) {
                 pj = pend_lower_bound(S, op.b);
-                if (pj < S.n_pend && S.pKey[pj] == op.b) { found = true; col_pos = (int64_t)S.pIdx[pj] + 1; }
+                if (pj < S.n_pend && S.pKey[pj] == op.b) {
+                    found = true; col_pos = (int64_t)S.pIdx[pj] + 1;
+                    sidx = succ_index(S, (int64_t)S.pLb[pj], op.b);
+                }
             }
+            const int64_t tp1 = (int64_t)__builtin_readcyclecounter();
+            S.prof[0] += tp1 - tp0; S.prof[4] += 1;
             if (!found) {
-                const bool no_tombstone = S.nb_partitions == S.table_len;
                 if (S.n_pend == 0 && (f.pos == S.table_len || !no_tombstone)) {
                     // the literal paths of the reference: append behind the last column, or middle insert with tombstones around
                     if (f.pos == S.table_len) {
@@ -1079,7 +1113,8 @@ __device__ int d_exec(Seq& S, const Op& op) {
                 } else {
                     // deferred middle insert: same semaphore cell at the same place, table entry at the end (see above)
                     if (S.table_len + 1 > S.table_cap) return SEQ_Y_TABLE_GROW | RERUN;
-                    const int64_t sidx = succ_index(S, f.has ? f.pos : 0, op.b);
+                    const int64_t lb = f.has ? f.pos : 0;
+                    sidx = succ_index(S, lb, op.b);
                     const int64_t sem_pos = sidx >= 0 ? S.sems[sidx] - 1 : S.capacity;
                     const int64_t idx = S.table_len;
                     __syncthreads();
@@ -1087,7 +1122,7 @@ __device__ int d_exec(Seq& S, const Op& op) {
                     __syncthreads();
                     S.table_len += 1;
                     S.nb_partitions += 1;
-                    pend_insert(S, op.b, idx, pj);
+                    pend_insert(S, op.b, idx, lb, pj);
                     const int64_t ip = d_insert_after(S, SEM_KEY, (double)(idx + 1), sem_pos);
                     if (ip == 0) return SEQ_ERROR;
                     if (threadIdx.x == 0) S.sems[idx] = ip;
@@ -1097,8 +1132,19 @@ __device__ int d_exec(Seq& S, const Op& op) {
                     if (r) return r | RERUN;
                     col_pos = idx + 1;
                 }
+                S.prof[1] += (int64_t)__builtin_readcyclecounter() - tp1; S.prof[5] += 1;
             }
-            return d_pcsc_set(S, op.v, op.a, col_pos);
+            const int64_t tp2 = (int64_t)__builtin_readcyclecounter();
+            int rr;
+            if (sidx == -2) rr = d_pcsc_set(S, op.v, op.a, col_pos);
+            else {
+                // setindex!(pcsc, value, key, partition) with the range end already known  src/pcsr.jl:294-310
+                const int64_t from = S.sems[col_pos - 1];
+                const int64_t to = sidx >= 0 ? S.sems[sidx] - 1 : S.capacity;
+                rr = d_set_in_range(S, op.a, op.v, from + 1, to, from);
+            }
+            S.prof[2] += (int64_t)__builtin_readcyclecounter() - tp2;
+            return rr;
         }
         case OP_DELETE_PARTITION:
             return d_deletepartition(S, op.b);
@@ -1132,7 +1178,10 @@ __global__ __launch_bounds__(SEQ_BLOCK) void k_sequencer(int64_t* keys, double* 
     S.y_ws = S.y_we = S.y_m = 0; S.err = 0; S.tail_hint = false;
     __shared__ int64_t sPKey[PEND_MAX];
     __shared__ uint32_t sPIdx[PEND_MAX];
-    S.n_sorted = S.table_len; S.n_pend = 0; S.pKey = sPKey; S.pIdx = sPIdx;
+    __shared__ uint32_t sPLb[PEND_MAX];
+    S.n_sorted = S.table_len; S.n_pend = 0; S.pKey = sPKey; S.pIdx = sPIdx; S.pLb = sPLb;
+    for (int q = 0; q < 16; ++q) S.prof[q] = 0;
+    const int64_t tk0 = (int64_t)__builtin_readcyclecounter();
     S.sK = reinterpret_cast<int64_t*>(lds);
     S.sV = reinterpret_cast<double*>(lds + SMALL_W * sizeof(int64_t));
     S.sWordOff = sWordOff; S.sRed = sRed;
@@ -1151,8 +1200,8 @@ __global__ __launch_bounds__(SEQ_BLOCK) void k_sequencer(int64_t* keys, double* 
         const bool vec_cand = sems == nullptr && op.kind == OP_VEC_SET && nxt.kind == OP_VEC_SET && nxt.a > op.a;
         const bool csc_cand = col_keys != nullptr && op.kind == OP_MPCSC_SET && nxt.kind == OP_MPCSC_SET &&
                               (nxt.b > op.b || (nxt.b == op.b && nxt.a > op.a));
-        if (run_ok && (vec_cand || csc_cand) && op.v != 0.0 && i + RUN_MIN <= n_avail && i != no_run_at && --run_cooldown < 0) {
-            d_merge_pending(S);
+        // (no detection while middle inserts are pending: an append run needs its columns behind the last key)
+        if (run_ok && (vec_cand || csc_cand) && op.v != 0.0 && i + RUN_MIN <= n_avail && i != no_run_at && S.n_pend == 0 && --run_cooldown < 0) {
             const int64_t R = vec_cand ? d_detect_append_run(S, ops, i, n_avail) : d_detect_pcsc_run(S, ops, i, n_avail);
             if (R > 0) {
                 S.y_ws = i; S.y_we = S.nb_elements; S.y_m = R;
@@ -1180,6 +1229,8 @@ __global__ __launch_bounds__(SEQ_BLOCK) void k_sequencer(int64_t* keys, double* 
         ctl->y_ws = S.y_ws; ctl->y_we = S.y_we; ctl->y_m = S.y_m;
         ctl->stat_window_slots = S.stat_window_slots; ctl->stat_rebalances = S.stat_rebalances;
         ctl->stat_small_rebalances = S.stat_small;
+        S.prof[7] = (int64_t)__builtin_readcyclecounter() - tk0;
+        for (int q = 0; q < 16; ++q) ctl->prof[q] += S.prof[q];
     }
 }
 

@@ -32,8 +32,8 @@ F, W = per_kernel(fetch), per_kernel(write)
 KB = 1024.0
 res = {"_units": "bytes per dispatch; rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KB",
        "_correction": "gfx950: FETCH_SIZE counts 64 B per 128-B request of a coalesced stream -> x2 on the stream part "
-                      "(MI355X_MICROARCH.md §HBM); calibrated here on k_spmv with nx=0 (streams only) and on k_move"}
-sp = [k for k in F if "k_spmv<false>" in k]
+                      "(MI355X_MICROARCH.md §HBM); calibrated here on k_spmv_gather with nx=0 (streams only) and on k_move"}
+sp = [k for k in F if "k_spmv_gather" in k]
 if sp:
     f = F[sp[0]]
     w = W[sp[0]]
