@@ -48,6 +48,8 @@ struct Ctl {
     // instrumentation
     int64_t stat_window_slots, stat_rebalances, stat_extends, stat_shrinks, stat_small_rebalances;
     int64_t no_run_at;     // op index that must take the normal path (an append run made no progress there), or -1
+    int64_t n_pending;     // table entries [table_len - n_pending, table_len) were created by batch-parallel rounds at the END of the
+                           // tables (arrival order, not key order); the sequencer merges them (sequencer.hip); 0 at every API boundary
     int64_t prof[16];      // dev profile of the sequencer (shader cycles): table lookup, new partition, element write, merges; counts
     int64_t dbg[6];        // append-run profile of the last run: slow ops, ticks (100 MHz) in setup / fast loop / slow path, blocks loaded
     // vector length n (src/vector.jl:2) is host-only
@@ -225,13 +227,14 @@ struct RoundState {
     int32_t stop;          // 0 running, 1 short prefix at `cursor` (sequencer must take over), 2 batch finished
     int32_t min_prefix, G_next, pad;
     int64_t rounds, par_ops;
+    int64_t why[8];        // dev: what cut the prefixes (index = Plan::count of the first BARRIER op; 7 = a conflict)
 };
 struct BurstGraph {        // cached hipGraph of one burst of rounds (host-side)
     hipGraphExec_t exec = nullptr; hipGraph_t graph = nullptr; hipStream_t stream = nullptr;
     const void* key[12] = {};
     bool disabled = false;
 };
-hipError_t launch_burst(int64_t* keys, double* vals, uint64_t* occ, int64_t* sems, const int64_t* col_keys, const uint8_t* col_live,
+hipError_t launch_burst(int64_t* keys, double* vals, uint64_t* occ, int64_t* sems, int64_t* col_keys, uint8_t* col_live,
                         Ctl* ctl, const Op* ops, RoundState* rs, Plan* plans, uint32_t* flags, int rounds, BurstGraph* cache,
                         hipStream_t stream);
 void burst_graph_destroy(BurstGraph* cache);

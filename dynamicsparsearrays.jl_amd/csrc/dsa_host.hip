@@ -63,6 +63,7 @@ struct Pma {
     double* vals[2] = {nullptr, nullptr};
     uint64_t* occ[2] = {nullptr, nullptr};
     int cur = 0;
+    int64_t stat_why[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int64_t cap_alloc = 0;        // slots allocated per buffer
     int64_t occ_words = 0;        // words allocated per bitmap (whole 64-word tiles)
     int64_t occ_dirty[2] = {0, 0}; // high-water mark: words >= occ_dirty[b] of bitmap b are known to be zero
@@ -506,6 +507,7 @@ int64_t run_ops_parallel(Pma& P, const std::vector<Op>& ops, int32_t* err) {
         const int64_t reached = rs.cursor + rs.d;
         if (reached > i) { host_ctl_stale = true; seq_chunk = 64; }
         P.stat_par_rounds += rs.rounds + (rs.d > 0 ? 1 : 0); P.stat_par_ops += rs.par_ops + rs.d;
+        for (int q = 0; q < 8; ++q) P.stat_why[q] += rs.why[q];
         i = reached;
         G = rs.G;
         if (rs.stop != 1) continue;                       // burst used up (0) or batch finished (2)
@@ -523,6 +525,14 @@ int64_t run_ops_parallel(Pma& P, const std::vector<Op>& ops, int32_t* err) {
         G = 64;
     }
     if (host_ctl_stale) download_ctl(P);
+    if (P.h_ctl->n_pending > 0) {
+        // columns created by the last rounds still sit at the end of the tables: an empty sequencer run merges them
+        SeqRun r;
+        r.P = &P; r.ops = &ops; r.n = n; r.n_avail = n; r.active = true;
+        P.h_ctl->next_op = n; P.h_ctl->status = 0; P.h_ctl->err = 0; P.h_ctl->no_run_at = -1;
+        seq_launch(r);
+        while (seq_step(r)) {}
+    }
     return n;
 }
 
@@ -800,6 +810,9 @@ void mat_apply_sets(dsa_mat* h, const int64_t* I, const int64_t* J, const double
             const int64_t* q = h->row.h_ctl->prof;
             fprintf(stderr, "  [rowmajor sequencer cycles] lookup %lld (%lld ops)  newpart %lld (%lld)  elem %lld  merge %lld (%lld)  kernel total %lld\n",
                     (long long)q[0], (long long)q[4], (long long)q[1], (long long)q[5], (long long)q[2], (long long)q[3], (long long)q[6], (long long)q[7]);
+            fprintf(stderr, "    prefix cuts (stop): notplannable %lld  newcol-nosucc %lld  limits %lld  shifts %lld  semleaf %lld  window %lld  scan %lld  conflict %lld ; rounds %lld\n",
+                    (long long)h->row.stat_why[0], (long long)h->row.stat_why[1], (long long)h->row.stat_why[2], (long long)h->row.stat_why[3], (long long)h->row.stat_why[4],
+                    (long long)h->row.stat_why[5], (long long)h->row.stat_why[6], (long long)h->row.stat_why[7], (long long)h->row.stat_par_rounds);
             fprintf(stderr, "    find %lld  insert %lld  density-scan+rebalance %lld (small rebalances %lld cycles, %lld of them, %lld slots)  partition_end %lld\n",
                     (long long)q[8], (long long)q[9], (long long)q[10], (long long)q[12], (long long)q[13], (long long)q[14], (long long)q[11]);
         }

@@ -25,7 +25,8 @@ namespace dsa {
 constexpr int PB_BLOCK = 256;                 // 4 waves = 4 ops per workgroup
 constexpr int PB_MAX_W = 1024;                // largest window a single wave rebalances (16 KB of LDS per wave)
 
-enum : int32_t { PB_NOOP = 0, PB_OVERWRITE = 1, PB_INS_R = 2, PB_INS_L = 3, PB_DELETE = 4, PB_BARRIER = 5 };
+enum : int32_t { PB_NOOP = 0, PB_OVERWRITE = 1, PB_INS_R = 2, PB_INS_L = 3, PB_DELETE = 4, PB_BARRIER = 5, PB_NEWCOL = 6 };
+constexpr int64_t PB_PEND_MAX = 1024;         // = PEND_MAX of the sequencer, which imports and merges the pending table entries
 
 __device__ __forceinline__ int64_t pb_wave_sum(int64_t v) {
 #pragma unroll
@@ -59,6 +60,7 @@ __global__ __launch_bounds__(PB_BLOCK) void k_plan(const int64_t* keys, const do
     const Op op = ops[i0 + w];
     Plan pl;
     pl.lo = 1; pl.hi = 0; pl.pos = 0; pl.aux = 0; pl.ws = 0; pl.we = 0; pl.count = 0; pl.action = PB_BARRIER;
+    int why = 0;           // dev: reason of a BARRIER (kept in pl.count): 0 not plannable, 1 new column w/o successor or v == 0, 2 limits, 3 shifts, 4 sem leaf, 5 window, 6 scan
     // search range of the write: the whole array for a vector (src/pma.jl:196-213); for setindex!(mpcsc, v, row, col) on an
     // EXISTING live column, semaphore+1 .. end of partition for the insert path and semaphore .. end for the delete path
     // (src/pcsr.jl:294-310).  Anything else (new column, deleted partition, delete of a key <= 0 whose bisection is
@@ -68,15 +70,78 @@ __global__ __launch_bounds__(PB_BLOCK) void k_plan(const int64_t* keys, const do
     if (op.kind == OP_VEC_SET) {
         plannable = true;
     } else if (op.kind == OP_MPCSC_SET && sems != nullptr && col_keys != nullptr) {
-        const int64_t table_len = ctl->table_len;
-        const DFoundKey tf = d_find_table_fast(col_keys, col_live, table_len, op.b, ctl->nb_partitions == table_len);
-        if (tf.has && tf.key == op.b) {
-            const int64_t sp = sems[tf.pos - 1];
+        const int64_t table_len = ctl->table_len, npend = ctl->n_pending, ns = table_len - npend;
+        const bool dense = ctl->nb_partitions == table_len;          // no tombstone (always true while entries are pending)
+        const DFoundKey tf = d_find_table_fast(col_keys, col_live, ns, op.b, dense);
+        bool found = tf.has && tf.key == op.b;
+        int64_t part = tf.pos;                                       // 1-based partition id
+        // successor of op.b in key order (0-based table index, -1: none): first sorted entry with a larger key ...
+        int64_t sidx = -1, skey = 0;
+        if (dense) {
+            const int64_t sorted_succ = tf.has ? tf.pos : 0;         // found: the next entry ; not found: #keys below
+            if (sorted_succ < ns) { sidx = sorted_succ; skey = col_keys[sorted_succ]; }
+            // ... or a pending entry (created by earlier rounds at the end of the tables, arrival order): wave-wide scan
+            if (npend > 0) {
+                int64_t bk = INT64_MAX, bi = -1, hit = -1;
+                for (int64_t j = lane_id(); j < npend; j += 64) {
+                    const int64_t k = col_keys[ns + j];
+                    if (k == op.b) hit = ns + j;
+                    if (k > op.b && k < bk) { bk = k; bi = ns + j; }
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    const int64_t k2 = __shfl_xor(bk, o, 64), i2 = __shfl_xor(bi, o, 64), h2 = __shfl_xor(hit, o, 64);
+                    if (k2 < bk) { bk = k2; bi = i2; }
+                    if (h2 > hit) hit = h2;
+                }
+                if (!found && hit >= 0) { found = true; part = hit + 1; }
+                if (bi >= 0 && (sidx < 0 || bk < skey)) { sidx = bi; skey = bk; }
+            }
+        }
+        if (found) {
+            const int64_t sp = sems[part - 1];
             if (sp != 0 && (op.v != 0.0 || op.a > SEM_KEY)) {
-                const int64_t nxt = d_next_live_sem(sems, tf.pos, table_len);
                 from = sp + 1; del_from = sp;
-                to = nxt != 0 ? sems[nxt - 1] - 1 : capacity;
+                if (dense) to = sidx >= 0 ? sems[sidx] - 1 : capacity;
+                else {
+                    const int64_t nxt = d_next_live_sem(sems, part, table_len);
+                    to = nxt != 0 ? sems[nxt - 1] - 1 : capacity;
+                }
                 plannable = true;
+            }
+        } else if (!(dense && sidx >= 0 && op.v != 0.0)) { why = 1;
+        } else if (!(npend + w + 1 <= PB_PEND_MAX && table_len + w + 1 <= ctl->table_cap)) { why = 2;
+        } else {
+            // NEW column in front of an existing one (addcolumn! + addpartition!(pcsc, prev), src/pcsr.jl:114-169, then the write):
+            // its semaphore cell goes right in front of the successor's semaphore, the element right behind it — two
+            // dependent inserts, each with its own density scan and possibly its own rebalance.  k_apply EXECUTES them in
+            // order on the live state; the plan only proves that everything they can touch lies in one aligned window
+            // [A, B] of level H (the footprint): both inserts shift to the right inside it, and the level-H window accepts
+            // the count after one and after two new cells, so either scan stops at a level <= H, and the semaphore is not on
+            // the window's last slot.  Then the element's insert stays inside too: the successor's semaphore follows the new
+            // one in [A, B], so after a rebalance of a window W1 that holds both it is not the last cell of W1 and spread!
+            // (src/moves.jl:120-140, last gap on one of the last two slots) leaves a gap behind it; if W1 ends ON the new
+            // semaphore, or nothing was rebalanced, the second empty slot of the pre-round state (ne2 <= B) is still free.
+            const int64_t p1 = sems[sidx] - 1;                        // _insert! after p1: the new semaphore lands on p1 + 1
+            const int64_t ip1 = p1 + 1;
+            const int64_t ne1 = d_next_empty(occ, p1, capacity);
+            const int64_t ne2 = ne1 != 0 ? d_next_empty(occ, ne1, capacity) : 0;
+            why = 3;
+            if (p1 >= 1 && ne1 != 0 && ne2 != 0) {
+                why = 5;
+                for (int64_t h = 0; h <= height; ++h) {
+                    const int64_t W = seg << h;
+                    if (W > PB_MAX_W) break;
+                    const int64_t A = ((ip1 - 1) / W) * W + 1, B = A + W - 1;
+                    if (ne2 > B || ip1 >= B) continue;
+                    const int64_t cnt = pb_wave_count(occ, A, B, false);
+                    if (ctl->lo[h] <= cnt + 1 && cnt + 2 <= ctl->hi[h]) {
+                        pl.action = PB_NEWCOL; pl.pos = p1; pl.aux = ne1;
+                        pl.ws = A; pl.we = B; pl.count = (int32_t)h;
+                        pl.lo = p1 < A ? p1 : A; pl.hi = B;
+                        break;
+                    }
+                }
             }
         }
     }
@@ -122,7 +187,7 @@ __global__ __launch_bounds__(PB_BLOCK) void k_plan(const int64_t* keys, const do
                 if (ctl->lo[h] <= c && c <= ctl->hi[h]) { accepted = true; break; }
             }
             if (!accepted) {
-                pl.action = PB_BARRIER;
+                pl.action = PB_BARRIER; why = 6;
             } else {
                 pl.ws = ws; pl.we = we; pl.count = (int32_t)c;
                 int64_t lo = ws < wlo ? ws : wlo, hi = we > whi ? we : whi;
@@ -132,6 +197,7 @@ __global__ __launch_bounds__(PB_BLOCK) void k_plan(const int64_t* keys, const do
             }
         }
     }
+    if (pl.action == PB_BARRIER) pl.count = why;
     if (lane_id() == 0) plans[w] = pl;
 }
 
@@ -190,7 +256,7 @@ __global__ __launch_bounds__(1024) void k_resolve(const Plan* plans, RoundState*
         int d = sC1 < sB ? sC1 : sB;
         if (d > G) d = G;
         // a short prefix means the ops around the cursor collide (appends, one hot key): hand over to the sequencer
-        if (d < rs->min_prefix && d < G) { rs->stop = 1; rs->d = 0; return; }
+        if (d < rs->min_prefix && d < G) { rs->why[sB <= sC1 ? (plans[sB < G ? sB : 0].count & 7) : 7] += 1; rs->stop = 1; rs->d = 0; return; }
         rs->d = d;
         int Gn = 2 * d;
         if (Gn < 64) Gn = 64;
@@ -210,6 +276,20 @@ __device__ void pb_shift_right(int64_t* keys, double* vals, int64_t* sems, int64
         if (act) {
             keys[p] = k; vals[p] = v;
             if (sems != nullptr && k == SEM_KEY) sems[(int64_t)v - 1] = p + 1;       // _moverightloop!  src/moves.jl:32-36
+        }
+    }
+}
+// cells [a, b-1] -> +dist, highest chunk first (a chunk's stores land above every cell that is still to be read)
+__device__ void pb_shift_right_by(int64_t* keys, double* vals, int64_t* sems, int64_t a, int64_t b, int dist) {
+    const int lane = lane_id();
+    for (int64_t hi = b - 1; hi >= a; hi -= 64) {
+        const int64_t p = hi - lane;
+        const bool act = p >= a;
+        int64_t k = 0; double v = 0.0;
+        if (act) { k = keys[p - 1]; v = vals[p - 1]; }
+        if (act) {
+            keys[p - 1 + dist] = k; vals[p - 1 + dist] = v;
+            if (sems != nullptr && k == SEM_KEY) sems[(int64_t)v - 1] = p + dist;
         }
     }
 }
@@ -316,8 +396,60 @@ __device__ void pb_wave_rebalance(int64_t* keys, double* vals, uint64_t* occ, in
     }
 }
 
-__global__ __launch_bounds__(PB_BLOCK) void k_apply(int64_t* keys, double* vals, uint64_t* occ, int64_t* sems, Ctl* ctl,
-                                                    const Op* ops, const RoundState* rs, const Plan* plans) {
+// ---- pieces of k_apply that run on the LIVE state of the op's footprint (cells and bits this wave has just written):
+// L2-served loads, after the wave's own stores have been acknowledged
+__device__ int64_t pb_next_empty_live(const uint64_t* occ, int64_t from, int64_t capacity) {          // _nextemptypos  src/utils.jl:3-10
+    if (from + 1 > capacity) return 0;
+    int64_t w = from >> 6;
+    uint64_t word = ~pb_occ_load(occ, w) & ~mask_lt((int)(from & 63));
+    const int64_t lastw = (capacity - 1) >> 6;
+    while (true) {
+        if (word) { const int64_t p = (w << 6) + __ffsll((unsigned long long)word); return p <= capacity ? p : 0; }
+        if (++w > lastw) return 0;
+        word = ~pb_occ_load(occ, w);
+    }
+}
+__device__ void pb_shift_right_live(int64_t* keys, double* vals, int64_t* sems, int64_t a, int64_t b) {      // cells [a, b-1] -> +1
+    const int lane = lane_id();
+    for (int64_t hi = b - 1; hi >= a; hi -= 64) {
+        const int64_t p = hi - lane;
+        const bool act = p >= a;
+        int64_t k = 0; double v = 0.0;
+        if (act) {
+            k = __hip_atomic_load(keys + p - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            v = __hip_atomic_load(vals + p - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (act) {
+            keys[p] = k; vals[p] = v;
+            if (sems != nullptr && k == SEM_KEY) sems[(int64_t)v - 1] = p + 1;
+        }
+    }
+}
+// _look_for_rebalance! + _even_rebalance! (src/pma.jl:94-141) around `ip` on the live bitmap; the plan guarantees acceptance
+// at a level whose window fits one wave.  Returns true when cells were moved.
+__device__ bool pb_scan_and_rebalance_live(int64_t* keys, double* vals, uint64_t* occ, int64_t* sems, Ctl* ctl, int64_t ip, int64_t hmax,
+                                           int64_t* sK, double* sV) {
+    const int64_t seg = ctl->segment_capacity;
+    int64_t ws = 1, we = 0, c = 0, W = seg;
+    for (int64_t h = 0; h <= hmax; ++h) {
+        W = seg << h;
+        ws = ((ip - 1) / W) * W + 1;
+        we = ws + W - 1;
+        c = pb_wave_count(occ, ws, we, true);
+        if (ctl->lo[h] <= c && c <= ctl->hi[h]) break;
+    }
+    if (W == seg) return false;
+    pb_wave_rebalance(keys, vals, occ, sems, ws, we, c, sK, sV);
+    if (lane_id() == 0) {
+        atomicAdd((unsigned long long*)&ctl->stat_rebalances, 1ull);
+        atomicAdd((unsigned long long*)&ctl->stat_window_slots, (unsigned long long)W);
+        atomicAdd((unsigned long long*)&ctl->stat_small_rebalances, 1ull);
+    }
+    return true;
+}
+
+__global__ __launch_bounds__(PB_BLOCK) void k_apply(int64_t* keys, double* vals, uint64_t* occ, int64_t* sems, int64_t* col_keys,
+                                                    uint8_t* col_live, Ctl* ctl, const Op* ops, const RoundState* rs, const Plan* plans) {
     extern __shared__ __attribute__((aligned(16))) unsigned char pb_lds[];
     if (rs->stop) return;
     const int64_t i0 = rs->cursor;
@@ -360,6 +492,36 @@ __global__ __launch_bounds__(PB_BLOCK) void k_apply(int64_t* keys, double* vals,
             if (lane == 0) pb_bit_clear(occ, pl.pos);
             delta = -1;
             break;
+        case PB_NEWCOL: {                                          // new column + its first element: two inserts in order (see k_plan)
+            const int64_t p1 = pl.pos, ne1 = pl.aux, hmax = pl.count, capacity = ctl->capacity;
+            // ids are labels: the next free table entry, whatever the key order (merged by the sequencer: Ctl::n_pending)
+            int64_t idx = 0;
+            if (lane == 0) {
+                idx = (int64_t)atomicAdd((unsigned long long*)&ctl->table_len, 1ull);
+                atomicAdd((unsigned long long*)&ctl->n_pending, 1ull);
+                atomicAdd((unsigned long long*)&ctl->nb_partitions, 1ull);
+                atomicAdd((unsigned long long*)&ctl->nb_elements, 2ull);
+            }
+            idx = __shfl(idx, 0, 64);
+            // addpartition!: the semaphore cell (0, id) in front of the successor's semaphore  src/pcsr.jl:136-144
+            pb_shift_right(keys, vals, sems, p1 + 1, ne1);
+            if (lane == 0) {
+                keys[p1] = SEM_KEY; vals[p1] = (double)(idx + 1);
+                sems[idx] = p1 + 1; col_keys[idx] = op.b; col_live[idx] = 1;
+                pb_bit_set(occ, ne1);
+            }
+            __builtin_amdgcn_s_waitcnt(0);
+            const bool moved = pb_scan_and_rebalance_live(keys, vals, occ, sems, ctl, p1 + 1, hmax, sK, sV);
+            __builtin_amdgcn_s_waitcnt(0);
+            const int64_t s1 = moved ? __hip_atomic_load(sems + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : p1 + 1;
+            // setindex!(pcsc, value, key, partition) into the empty partition: find() returns the semaphore, insert behind it
+            const int64_t ne2 = pb_next_empty_live(occ, s1, capacity);
+            pb_shift_right_live(keys, vals, sems, s1 + 1, ne2);
+            if (lane == 0) { keys[s1] = op.a; vals[s1] = op.v; pb_bit_set(occ, ne2); }
+            __builtin_amdgcn_s_waitcnt(0);
+            pb_scan_and_rebalance_live(keys, vals, occ, sems, ctl, s1 + 1, hmax, sK, sV);
+            break;
+        }
         default:
             break;
     }
@@ -389,15 +551,15 @@ static hipError_t configure_apply() {
     }
     return hipSuccess;
 }
-static hipError_t enqueue_round(int64_t* keys, double* vals, uint64_t* occ, int64_t* sems, const int64_t* col_keys,
-                                const uint8_t* col_live, Ctl* ctl, const Op* ops, RoundState* rs, Plan* plans, uint32_t* flags,
+static hipError_t enqueue_round(int64_t* keys, double* vals, uint64_t* occ, int64_t* sems, int64_t* col_keys,
+                                uint8_t* col_live, Ctl* ctl, const Op* ops, RoundState* rs, Plan* plans, uint32_t* flags,
                                 hipStream_t stream) {
     const size_t lds = (size_t)(PB_BLOCK / 64) * PB_MAX_W * (sizeof(int64_t) + sizeof(double));
     constexpr int GMAX = 1024;
     hipLaunchKernelGGL(k_plan, dim3(GMAX / 4), dim3(PB_BLOCK), 0, stream, keys, vals, occ, sems, col_keys, col_live, ctl, ops, rs, plans);
     hipLaunchKernelGGL(k_conflicts, dim3(GMAX / 64), dim3(1024), 0, stream, plans, rs, flags);
     hipLaunchKernelGGL(k_resolve, dim3(1), dim3(1024), 0, stream, plans, rs, flags);
-    hipLaunchKernelGGL(k_apply, dim3(GMAX / 4), dim3(PB_BLOCK), lds, stream, keys, vals, occ, sems, ctl, ops, rs, plans);
+    hipLaunchKernelGGL(k_apply, dim3(GMAX / 4), dim3(PB_BLOCK), lds, stream, keys, vals, occ, sems, col_keys, col_live, ctl, ops, rs, plans);
     return hipGetLastError();
 }
 
@@ -405,7 +567,7 @@ static hipError_t enqueue_round(int64_t* keys, double* vals, uint64_t* occ, int6
 // replayed (one graph launch instead of 4 x rounds kernel launches: the rounds are launch-bound); re-captured when a buffer
 // moves (root rebalance swaps the slot buffers, a bigger batch re-allocates the op array).  Falls back to eager launches
 // when the stream cannot be captured.
-hipError_t launch_burst(int64_t* keys, double* vals, uint64_t* occ, int64_t* sems, const int64_t* col_keys, const uint8_t* col_live,
+hipError_t launch_burst(int64_t* keys, double* vals, uint64_t* occ, int64_t* sems, int64_t* col_keys, uint8_t* col_live,
                         Ctl* ctl, const Op* ops, RoundState* rs, Plan* plans, uint32_t* flags, int rounds, BurstGraph* cache,
                         hipStream_t stream) {
     hipError_t e = configure_apply();

@@ -1008,6 +1008,27 @@ __device__ void d_merge_pending(Seq& S) {
     S.prof[3] += (int64_t)__builtin_readcyclecounter() - tm0; S.prof[6] += 1;
 }
 
+// entries appended by the batch-parallel rounds (Ctl::n_pending, arrival order): build the sorted list and merge at once
+__device__ void d_import_pending(Seq& S, int64_t K) {
+    if (K <= 0) return;
+    const int64_t ns = S.table_len - K;
+    S.n_sorted = ns;
+    int64_t* tmp = S.sK;                                       // dynamic LDS is free between ops
+    for (int64_t r = threadIdx.x; r < K; r += SEQ_BLOCK) tmp[r] = S.col_keys[ns + r];
+    __syncthreads();
+    for (int64_t r = threadIdx.x; r < K; r += SEQ_BLOCK) {
+        const int64_t key = tmp[r];
+        int rank = 0;
+        for (int64_t j = 0; j < K; ++j) rank += tmp[j] < key ? 1 : 0;          // keys are distinct
+        int64_t lo = 0, hi = ns;
+        while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (S.col_keys[mid] < key) lo = mid + 1; else hi = mid; }
+        S.pKey[rank] = key; S.pIdx[rank] = (uint32_t)(ns + r); S.pLb[rank] = (uint32_t)lo;
+    }
+    __syncthreads();
+    S.n_pend = (int)K;
+    d_merge_pending(S);
+}
+
 // _pos_of_partition_end  src/pcsr.jl:177-186
 __device__ int64_t d_partition_end(Seq& S, int64_t partition) {
     if (S.n_pend > 0) {            // no tombstones in this mode: the successor in key order, sorted part or pending list
@@ -1189,6 +1210,7 @@ __global__ __launch_bounds__(SEQ_BLOCK) void k_sequencer(int64_t* keys, double* 
     if (threadIdx.x < MAX_LEVELS) { sLo[threadIdx.x] = ctl->lo[threadIdx.x]; sHi[threadIdx.x] = ctl->hi[threadIdx.x]; }
     S.lo = sLo; S.hi = sHi;
     __syncthreads();
+    if (col_keys != nullptr && ctl->n_pending > 0) d_import_pending(S, ctl->n_pending);
 
     int64_t i = ctl->next_op;
     int status = SEQ_DONE;
@@ -1226,6 +1248,7 @@ __global__ __launch_bounds__(SEQ_BLOCK) void k_sequencer(int64_t* keys, double* 
         ctl->err = S.err;
         ctl->err_op = (status == SEQ_ERROR) ? i : -1;
         ctl->nb_elements = S.nb_elements; ctl->nb_partitions = S.nb_partitions; ctl->table_len = S.table_len;
+        ctl->n_pending = 0;
         ctl->y_ws = S.y_ws; ctl->y_we = S.y_we; ctl->y_m = S.y_m;
         ctl->stat_window_slots = S.stat_window_slots; ctl->stat_rebalances = S.stat_rebalances;
         ctl->stat_small_rebalances = S.stat_small;

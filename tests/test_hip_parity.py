@@ -392,6 +392,27 @@ def test_new_columns_in_random_key_order_deferred_table_inserts(dsa, hip, oracle
         np.testing.assert_allclose(a.mul(x), b.mul(x), rtol=RTOL, atol=0)
 
 
+def test_c5_mid_scale_parallel_column_creation_matches_oracle(dsa, hip, oracle):
+    """BASELINE config 5 at 1/5 of full size (20k rows, 6k columns x 16, 96k element writes) in batches of 1000 columns: most
+    new rows are created by the batch-parallel rounds (k_plan / k_apply PB_NEWCOL, table entries pending until the sequencer
+    merges them), the rest by the sequencer's deferred inserts.  Tables, ids, slot layout and SpMV vs the oracle after every batch."""
+    import bench
+    m_rows, ncols, per, every = 20_000, 6_000, 16, 1000
+    I, J, V = bench.c5_columns(m_rows, ncols, per)
+    a = dsa.dynamicsparse(fill_mode=False, binding=hip)
+    b = dsa.dynamicsparse(fill_mode=False, binding=oracle)
+    x = unit12_array(13, ncols)
+    for c0 in range(0, ncols, every):
+        sl = slice(c0 * per, (c0 + every) * per)
+        a.set_batch(I[sl], J[sl], V[sl])
+        b.set_batch(I[sl], J[sl], V[sl])
+        assert_mat_equal(a, b)
+    st = a.info(dsa.ROWMAJOR)
+    assert st["stat_par_ops"] > 20_000, st            # the parallel path really created rows
+    np.testing.assert_allclose(a.mul(x), b.mul(x), rtol=RTOL, atol=0)
+    np.testing.assert_allclose(a.mul(unit12_array(14, m_rows), transpose=True), b.mul(unit12_array(14, m_rows), transpose=True), rtol=RTOL, atol=0)
+
+
 def _column_run(g, gv, cols, m_rows, per_lo, per_hi):
     """(I, J, V) for the given new columns: rows ascending inside each column (an append run of the colmajor orientation)."""
     I, J, V = [], [], []
