@@ -16,7 +16,9 @@
 #include <chrono>
 #include <cstring>
 #include <numeric>
+#include <exception>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -474,7 +476,7 @@ int64_t run_ops_parallel(Pma& P, const std::vector<Op>& ops, int32_t* err) {
     *err = 0;
     const int64_t n = (int64_t)ops.size();
     if (n == 0) return 0;
-    constexpr int GMAX = 1024, MIN_PREFIX = 12, ROUNDS_PER_SYNC = 12;
+    constexpr int GMAX = 1024, MIN_PREFIX = 4, ROUNDS_PER_SYNC = 12;
     ensure_ops(P, n);
     HIPCHK(hipMemcpyAsync(P.d_ops, ops.data(), (size_t)n * sizeof(Op), hipMemcpyHostToDevice, P.stream));
     if (!P.d_plans) {
@@ -801,26 +803,26 @@ void mat_apply_sets(dsa_mat* h, const int64_t* I, const int64_t* J, const double
         // columns and anything else fall back to the sequential sequencer inside run_ops_parallel)
         int32_t ec = 0, er = 0;
         static const bool dbg_time = getenv("DSA_DBG_TIME") != nullptr;
+        // the two orientations are independent structures on their own streams: their round / sequencer loops (host-driven)
+        // run side by side, the rowmajor one on a helper thread
         const auto t0 = std::chrono::steady_clock::now();
-        const int64_t dc = run_ops_parallel(h->col, oc, &ec);
-        const auto t1 = std::chrono::steady_clock::now();
-        if (dbg_time) { std::memset(h->row.h_ctl->prof, 0, sizeof(h->row.h_ctl->prof)); }
-        const int64_t dr = run_ops_parallel(h->row, orw, &er);
-        if (dbg_time) {
-            const int64_t* q = h->row.h_ctl->prof;
-            fprintf(stderr, "  [rowmajor sequencer cycles] lookup %lld (%lld ops)  newpart %lld (%lld)  elem %lld  merge %lld (%lld)  kernel total %lld\n",
-                    (long long)q[0], (long long)q[4], (long long)q[1], (long long)q[5], (long long)q[2], (long long)q[3], (long long)q[6], (long long)q[7]);
-            fprintf(stderr, "    prefix cuts (stop): notplannable %lld  newcol-nosucc %lld  limits %lld  shifts %lld  semleaf %lld  window %lld  scan %lld  conflict %lld ; rounds %lld\n",
-                    (long long)h->row.stat_why[0], (long long)h->row.stat_why[1], (long long)h->row.stat_why[2], (long long)h->row.stat_why[3], (long long)h->row.stat_why[4],
-                    (long long)h->row.stat_why[5], (long long)h->row.stat_why[6], (long long)h->row.stat_why[7], (long long)h->row.stat_par_rounds);
-            fprintf(stderr, "    find %lld  insert %lld  density-scan+rebalance %lld (small rebalances %lld cycles, %lld of them, %lld slots)  partition_end %lld\n",
-                    (long long)q[8], (long long)q[9], (long long)q[10], (long long)q[12], (long long)q[13], (long long)q[14], (long long)q[11]);
-        }
+        int64_t dc = 0, dr = 0;
+        std::exception_ptr row_exc;
+        const bool side_by_side = h->col.stream != h->row.stream;
+        std::thread row_thread;
+        if (side_by_side)
+            row_thread = std::thread([&] {
+                try { if (hipSetDevice(g_device) != hipSuccess) fail(DSA_EHIP, "hipSetDevice"); dr = run_ops_parallel(h->row, orw, &er); }
+                catch (...) { row_exc = std::current_exception(); }
+            });
+        try { dc = run_ops_parallel(h->col, oc, &ec); }
+        catch (...) { if (row_thread.joinable()) row_thread.join(); throw; }
+        if (side_by_side) { row_thread.join(); if (row_exc) std::rethrow_exception(row_exc); }
+        else dr = run_ops_parallel(h->row, orw, &er);
         if (dbg_time)
-            fprintf(stderr, "[mat_apply_sets] n=%lld colmajor %.2f ms (par %lld seq %lld)  rowmajor %.2f ms (par %lld seq %lld)\n", (long long)n,
-                    std::chrono::duration<double, std::milli>(t1 - t0).count(), (long long)h->col.stat_par_ops, (long long)h->col.stat_seq_ops,
-                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count(), (long long)h->row.stat_par_ops,
-                    (long long)h->row.stat_seq_ops);
+            fprintf(stderr, "[mat_apply_sets] n=%lld both orientations %.2f ms  colmajor (par %lld seq %lld)  rowmajor (par %lld seq %lld)\n", (long long)n,
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), (long long)h->col.stat_par_ops,
+                    (long long)h->col.stat_seq_ops, (long long)h->row.stat_par_ops, (long long)h->row.stat_seq_ops);
         const int64_t done = std::min(dc, dr);
         for (int64_t k = 0; k < std::min(done + 1, n); ++k) if (V[k] != 0.0) { h->m = std::max(h->m, I[k]); h->n = std::max(h->n, J[k]); }
         if (ec) fail(ec, err_text(ec));
