@@ -527,6 +527,7 @@ int64_t run_ops_parallel(Pma& P, const std::vector<Op>& ops, int32_t* err) {
         G = 64;
     }
     if (host_ctl_stale) download_ctl(P);
+    if (P.h_ctl->err == DSA_EASSERT && P.h_ctl->status != SEQ_ERROR) fail(DSA_EASSERT, "batch-parallel column creation left its footprint (internal invariant)");
     if (P.h_ctl->n_pending > 0) {
         // columns created by the last rounds still sit at the end of the tables: an empty sequencer run merges them
         SeqRun r;

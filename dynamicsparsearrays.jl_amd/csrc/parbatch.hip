@@ -516,6 +516,11 @@ __global__ __launch_bounds__(PB_BLOCK) void k_apply(int64_t* keys, double* vals,
             const int64_t s1 = moved ? __hip_atomic_load(sems + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : p1 + 1;
             // setindex!(pcsc, value, key, partition) into the empty partition: find() returns the semaphore, insert behind it
             const int64_t ne2 = pb_next_empty_live(occ, s1, capacity);
+            if (ne2 == 0 || ne2 > pl.hi || s1 < pl.lo || s1 >= pl.hi) {
+                // cannot happen (see k_plan); if it ever does, fail loudly instead of writing outside the footprint
+                if (lane == 0) atomicExch(&ctl->err, (int32_t)E_ASSERT);
+                break;
+            }
             pb_shift_right_live(keys, vals, sems, s1 + 1, ne2);
             if (lane == 0) { keys[s1] = op.a; vals[s1] = op.v; pb_bit_set(occ, ne2); }
             __builtin_amdgcn_s_waitcnt(0);

@@ -413,6 +413,42 @@ def test_c5_mid_scale_parallel_column_creation_matches_oracle(dsa, hip, oracle):
     np.testing.assert_allclose(a.mul(unit12_array(14, m_rows), transpose=True), b.mul(unit12_array(14, m_rows), transpose=True), rtol=RTOL, atol=0)
 
 
+@pytest.mark.parametrize("seed", [41, 42, 43, 44, 45, 46])
+def test_parallel_column_creation_stress(dsa, hip, oracle, seed):
+    """Randomised mixes around the batch-parallel creation of rows / columns: batches of random (i, j, v) over a key space that
+    keeps producing new keys, a varying share of deletes (sparser windows -> other rebalance levels), dense rows, and batches
+    small enough for the plain sequencer in between.  Layout and tables vs the oracle after every batch."""
+    g = SplitMix64(seed)
+    gv = SplitMix64(seed + 500)
+    a = dsa.dynamicsparse(fill_mode=False, binding=hip)
+    b = dsa.dynamicsparse(fill_mode=False, binding=oracle)
+    span_i = [400, 3000, 20000][seed % 3]
+    span_j = [5000, 700, 20000][seed % 3]
+    live = []
+    for step in range(14):
+        nb = [900, 60, 2500, 300, 1500][step % 5]
+        del_share = [0, 5, 2, 9, 3][(step + seed) % 5]
+        I, J, V = [], [], []
+        for _ in range(nb):
+            r = g.next() % 10
+            if r < del_share and live:
+                i, j = live[g.next() % len(live)]
+                I.append(i); J.append(j); V.append(0.0)
+            elif r == 9 and live:                          # grow one row into a long one
+                i, _ = live[g.next() % len(live)]
+                j = 1 + int(g.next() % span_j)
+                I.append(i); J.append(j); V.append(gv.unit12()); live.append((i, j))
+            else:
+                i = 1 + int(g.next() % span_i); j = 1 + int(g.next() % span_j)
+                I.append(i); J.append(j); V.append(gv.unit12()); live.append((i, j))
+        a.set_batch(I, J, V)
+        b.set_batch(I, J, V)
+        assert_mat_equal(a, b)
+    n = a.size()[1]
+    x = unit12_array(seed + 7, n)
+    np.testing.assert_allclose(a.mul(x), b.mul(x), rtol=RTOL, atol=0)
+
+
 def _column_run(g, gv, cols, m_rows, per_lo, per_hi):
     """(I, J, V) for the given new columns: rows ascending inside each column (an append run of the colmajor orientation)."""
     I, J, V = [], [], []
