@@ -250,6 +250,60 @@ def extras(dsa, hip, torch, A, dev):
                                  "unit": "GB/s", "frac": round(b / 1e9 / (ms / 1e3) / HBM_PEAK_GBS, 4),
                                  "window_slots": cap, "algorithmic_bytes": b, "ms": round(ms, 5),
                                  "kernels": "k_tile_count + k_tile_scan + k_move<false>"}
+    # --- the isolated rebalance on full windows of 2^20 / 2^21 / 2^24 slots at densities 0.35 / 0.70:
+    #     a vector's PMA built from n = density * capacity keys, root pack + spread timed back to back
+    sweep = []
+    for lg in (20, 21, 24):
+        for dens in (0.35, 0.70):
+            capv = 1 << lg
+            n = int(dens * capv) + (2 if dens < 0.5 else 0)          # n / 0.7 just above capv / 2 keeps the capacity rule at capv
+            n = min(n, int(0.7 * capv))
+            vv = dsa.dynamicsparsevec(np.arange(1, n + 1, dtype=np.int64) * 3, unit12(40 + lg, n), binding=hip)
+            if vv.info()["capacity"] != capv:
+                continue
+            hip.call("vec_set_stream", vv.h, C.c_void_p(stream.cuda_stream))
+            for _ in range(3):
+                vv.rebalance_root()
+            torch.cuda.synchronize()
+            r0, r1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            nrep = 50 if lg < 24 else 20
+            r0.record(stream)
+            for _ in range(nrep):
+                vv.rebalance_root()
+            r1.record(stream)
+            torch.cuda.synchronize()
+            us = r0.elapsed_time(r1) / nrep * 1e3
+            sweep.append({"window_slots": capv, "density": round(n / capv, 3), "us": round(us, 2),
+                          "gbps": round(32 * capv / us / 1e3, 1), "frac": round(32 * capv / us / 1e3 / HBM_PEAK_GBS, 4)})
+            del vv
+    res["rebalance_sweep"] = sweep
+    # --- one C4 shard (BASELINE config 4 per GPU: 10M rows, 1.25M columns, 12.5M nnz, capacity 2^25, y = 10M doubles)
+    try:
+        m4, n4 = 10_000_000, 1_250_000
+        I4, J4, V4 = c3_triplets(m4, n4, 10, 0, seed_rows=8, seed_vals=9)
+        A4 = dsa.dynamicsparse(I4, J4, V4, m4, n4, binding=hip)
+        hip.call("mat_set_stream", A4.h, C.c_void_p(stream.cuda_stream))
+        cap4 = A4.info(dsa.ROWMAJOR)["capacity"]
+        x4 = torch.from_numpy(unit12(10, n4)).to(dev)
+        y4 = torch.zeros(m4, dtype=torch.float64, device=dev)
+        for _ in range(3):
+            hip.call("mat_spmv_dense_dev", A4.h, 0, 0, C.c_void_p(x4.data_ptr()), n4, C.c_void_p(y4.data_ptr()), m4)
+        torch.cuda.synchronize()
+        r0, r1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        r0.record(stream)
+        for _ in range(20):
+            hip.call("mat_spmv_dense_dev", A4.h, 0, 0, C.c_void_p(x4.data_ptr()), n4, C.c_void_p(y4.data_ptr()), m4)
+        r1.record(stream)
+        torch.cuda.synchronize()
+        ms4 = r0.elapsed_time(r1) / 20
+        b4 = 16 * cap4 + 8 * n4 + 8 * m4
+        res["c4_shard_spmv"] = {"rows": m4, "columns": n4, "nnz": len(I4), "capacity_slots": cap4, "ms": round(ms4, 5),
+                                "algorithmic_bytes": b4, "gbps": round(b4 / 1e9 / (ms4 / 1e3), 1),
+                                "frac": round(b4 / 1e9 / (ms4 / 1e3) / HBM_PEAK_GBS, 4),
+                                "note": "local SpMV of one of the 8 column-range shards of BASELINE config 4 (the 80 MB all-reduce of y is not included)"}
+        del A4, x4, y4
+    except Exception as e:           # an extra must never cost the headline line
+        res["c4_shard_spmv"] = {"error": str(e)[:200]}
     # --- C2: 2^20-slot PMA, 100k ascending appends (batch A) and 100k uniform odd keys (batch B)
     n0 = 700000
     keys0 = np.arange(1, n0 + 1, dtype=np.int64) * 2
