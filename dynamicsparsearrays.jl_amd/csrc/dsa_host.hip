@@ -488,7 +488,8 @@ int64_t run_ops_parallel(Pma& P, const std::vector<Op>& ops, int32_t* err) {
     }
     P.h_ctl->next_op = 0; P.h_ctl->status = 0; P.h_ctl->err = 0; P.h_ctl->no_run_at = -1;
     upload_ctl(P);
-    int64_t i = 0, seq_chunk = 64;
+    static const int64_t SEQ_CHUNK0 = [] { const char* e = getenv("DSA_SEQ_CHUNK"); return e ? (int64_t)atoi(e) : (int64_t)8; }();
+    int64_t i = 0, seq_chunk = SEQ_CHUNK0;
     int G = 256;
     bool host_ctl_stale = false;
     while (i < n) {
@@ -507,7 +508,7 @@ int64_t run_ops_parallel(Pma& P, const std::vector<Op>& ops, int32_t* err) {
         HIPCHK(hipStreamSynchronize(P.stream));
         // the prefix of the last round of the burst has been applied but is folded into the cursor only by the next k_resolve
         const int64_t reached = rs.cursor + rs.d;
-        if (reached > i) { host_ctl_stale = true; seq_chunk = 64; }
+        if (reached > i) { host_ctl_stale = true; seq_chunk = SEQ_CHUNK0; }
         P.stat_par_rounds += rs.rounds + (rs.d > 0 ? 1 : 0); P.stat_par_ops += rs.par_ops + rs.d;
         for (int q = 0; q < 8; ++q) P.stat_why[q] += rs.why[q];
         i = reached;
