@@ -840,18 +840,22 @@ void mat_apply_sets(dsa_mat* h, const int64_t* I, const int64_t* J, const double
         if (rr.err) fail(rr.err, err_text(rr.err));
         return;
     }
+    // tombstones present: a write that creates a column can fail (src/pcsr.jl:124,132), so the colmajor batch runs first and the
+    // rowmajor batch is cut at the failing op, like the reference's statement order — still through the batch-parallel
+    // rounds for everything that is plannable (writes to existing columns); new columns take the sequencer's literal path
+    const bool par_seq = par && n >= 128;
     int32_t err = 0;
-    const int64_t done = run_ops(h->col, oc, &err);
+    const int64_t done = par_seq ? run_ops_parallel(h->col, oc, &err) : run_ops(h->col, oc, &err);
     for (int64_t k = 0; k < done; ++k) if (V[k] != 0.0) { h->m = std::max(h->m, I[k]); h->n = std::max(h->n, J[k]); }
     if (err) {
         // the failing write had already updated size(m) in the reference (src/matrix.jl:44-47)
         if (V[done] != 0.0) { h->m = std::max(h->m, I[done]); h->n = std::max(h->n, J[done]); }
         orw.resize((size_t)done);
         int32_t e2 = 0;
-        run_ops(h->row, orw, &e2);
+        if (par_seq) run_ops_parallel(h->row, orw, &e2); else run_ops(h->row, orw, &e2);
         fail(err, err_text(err));
     }
-    run_ops(h->row, orw, &err);
+    if (par_seq) run_ops_parallel(h->row, orw, &err); else run_ops(h->row, orw, &err);
     if (err) fail(err, err_text(err));
 }
 

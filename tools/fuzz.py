@@ -14,6 +14,7 @@ import dsa_loader  # noqa: E402
 from util import SplitMix64  # noqa: E402
 
 dsa = dsa_loader.load()
+BIG = os.environ.get("FUZZ_BIG") == "1"       # larger key spaces and batches: big-window yields, extends, > 1024 pending columns
 hip = None if os.environ.get("FUZZ_SELF") == "1" else dsa.product()
 ora = dsa.Binding(os.path.join(ROOT, "oracle", "liboracle.so"), "ora", device_api=False)
 if hip is None:
@@ -37,15 +38,16 @@ def mat_equal(a, b, ctx):
 
 def run_matrix(seed):
     g = SplitMix64(seed)
-    span_i = [50, 400, 3000, 40000][g.next() % 4]
-    span_j = [50, 400, 3000, 40000][g.next() % 4]
+    spans = [3000, 40000, 300000, 2000000] if BIG else [50, 400, 3000, 40000]
+    span_i = spans[g.next() % 4]
+    span_j = spans[g.next() % 4]
     neg = g.next() % 4 == 0
     a = dsa.dynamicsparse(fill_mode=False, binding=hip)
     b = dsa.dynamicsparse(fill_mode=False, binding=ora)
     live = []
     steps = 4 + g.next() % 10
     for step in range(steps):
-        nb = [5, 40, 130, 600, 2500, 9000][g.next() % 6]
+        nb = ([130, 2500, 9000, 30000, 60000, 120000] if BIG else [5, 40, 130, 600, 2500, 9000])[g.next() % 6]
         mode = g.next() % 5          # 0 random, 1 column stream (ascending), 2 row stream, 3 delete-heavy, 4 overwrite-heavy
         I, J, V = [], [], []
         if mode == 1 or mode == 2:
