@@ -12,7 +12,8 @@ step = 1000 if full else 500
 B = dsa.dynamicsparse(fill_mode=False, binding=hip)
 rows5 = 1 + (bench.splitmix_array(11, ncols5 * per5 * 2) % np.uint64(m5)).astype(np.int64)
 vals5 = bench.unit12(12, ncols5 * per5)
-pos = 0; nw = 0; t_w = 0.0
+pos = 0; nw = 0; t_w = 0.0; t_d = 0.0; nd = 0
+deletes = '--deletes' in sys.argv      # delete 5 % of the streamed columns after every batch (tombstones in the colmajor tables)
 for c0 in range(0, ncols5, step):
     I5, J5 = [], []
     for j in range(c0 + 1, c0 + step + 1):
@@ -24,4 +25,10 @@ for c0 in range(0, ncols5, step):
     V5 = vals5[nw:nw + len(I5)]
     t = time.perf_counter(); B.set_batch(I5, J5, V5); t_w += time.perf_counter() - t
     nw += len(I5)
+    if deletes:
+        t = time.perf_counter()
+        for j in range(c0 + 1, c0 + step + 1, 20):
+            B.deletecolumn(j); nd += 1
+        t_d += time.perf_counter() - t
+if deletes: print('deletecolumn: %d calls, %.1f ms (%.1f us each)' % (nd, t_d * 1e3, t_d / max(nd, 1) * 1e6))
 print("C5 %s:" % ("full" if full else "scaled") + " %d element writes in %.1f ms -> %.0f writes/s" % (nw, t_w * 1e3, nw / t_w))
