@@ -674,7 +674,10 @@ void pma_build_dev(Pma& P, const int64_t* d_part, const int64_t* d_key, const do
     }
     BuildScratch sc;
     int64_t counts[2] = {0, 0};
+    static const bool dbg_time = getenv("DSA_DBG_TIME") != nullptr;
+    const auto tp0 = std::chrono::steady_clock::now();
     hipError_t e = build_prepare(d_part, d_key, nnz, sc, counts, P.stream);
+    const auto tp1 = std::chrono::steady_clock::now();
     if (e != hipSuccess) fail(DSA_EHIP, std::string("K-build prepare: ") + hipGetErrorString(e));
     const int64_t np = mode == 0 ? counts[1] : (mode == 2 ? nparts_explicit : 0);
     const int64_t n = counts[0] + np;
@@ -688,12 +691,19 @@ void pma_build_dev(Pma& P, const int64_t* d_part, const int64_t* d_key, const do
         ensure_capacity_alloc(P, 2 * capacity);
         if (P.has_cols && np > 0) HIPCHK(hipMemsetAsync(P.col_live, 1, (size_t)np, P.stream));
     } catch (...) { build_abort(sc); throw; }
+    const auto tp2 = std::chrono::steady_clock::now();
     e = build_emit(d_val, combine, sc, P.K(), P.V(), P.has_cols ? P.col_keys : nullptr, mode, nparts_explicit, P.stream);
     if (e != hipSuccess) fail(DSA_EHIP, std::string("K-build emit: ") + hipGetErrorString(e));
+    const auto tp3 = std::chrono::steady_clock::now();
     P.h_ctl->stat_rebalances = 0; P.h_ctl->stat_window_slots = 0;
     if (P.capacity() != P.h_ctl->segment_capacity) { P.h_ctl->stat_rebalances = 1; P.h_ctl->stat_window_slots = P.capacity(); }
     root_rebalance(P, n, P.capacity(), n, true);
     upload_ctl(P);
+    if (dbg_time) {
+        auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        fprintf(stderr, "  [pma_build_dev] prepare (alloc + sorts + scans) %.1f ms  tables/slot alloc %.1f ms  emit (+ free) %.1f ms  spread + ctl %.1f ms\n",
+                ms(tp0, tp1), ms(tp1, tp2), ms(tp2, tp3), ms(tp3, std::chrono::steady_clock::now()));
+    }
 }
 
 // uploads host arrays (any of them may be nullptr) and runs the device builder
@@ -752,6 +762,7 @@ void mat_build_major(dsa_mat* h, const int64_t* I, const int64_t* J, const doubl
     pma_init_common(h->col, true, true);
     pma_init_common(h->row, true, true);
     int64_t *dI = nullptr, *dJ = nullptr; double* dV = nullptr;
+    const auto tup0 = std::chrono::steady_clock::now();
     try {
         if (nnz > 0) {
             hipStream_t s = h->col.stream;
@@ -763,8 +774,15 @@ void mat_build_major(dsa_mat* h, const int64_t* I, const int64_t* J, const doubl
             HIPCHK(hipMemcpyAsync(dV, V, (size_t)nnz * sizeof(double), hipMemcpyHostToDevice, s));
             HIPCHK(hipStreamSynchronize(s));
         }
+        static const bool dbg_time = getenv("DSA_DBG_TIME") != nullptr;
+        const auto tb0 = std::chrono::steady_clock::now();
         pma_build_dev(h->col, dJ, dI, dV, nnz, DSA_COMBINE_ADD, 0, 0);      // dynamicsparsecolmajor(I, J, V): partitions = columns
+        const auto tb1 = std::chrono::steady_clock::now();
         pma_build_dev(h->row, dI, dJ, dV, nnz, DSA_COMBINE_ADD, 0, 0);      // dynamicsparsecolmajor(J, I, V): partitions = rows
+        if (dbg_time)
+            fprintf(stderr, "[mat_build_major] nnz=%lld upload %.1f ms  colmajor %.1f ms  rowmajor %.1f ms\n", (long long)nnz,
+                    std::chrono::duration<double, std::milli>(tb0 - tup0).count(), std::chrono::duration<double, std::milli>(tb1 - tb0).count(),
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tb1).count());
     } catch (...) {
         if (dI) hipFree(dI);
         if (dJ) hipFree(dJ);
