@@ -305,6 +305,20 @@ def extras(dsa, hip, torch, A, dev):
         del A4, x4, y4
     except Exception as e:           # an extra must never cost the headline line
         res["c4_shard_spmv"] = {"error": str(e)[:200]}
+    # --- sparse x through the host-pointer entry point (the _mul shape Coluna calls, src/operations.jl:107-135): result = touched
+    #     rows in ascending order; few stored entries -> x-driven kernel, many -> densify + gather + pattern pass.  Times include
+    #     the PCIe copies of x and of the result.
+    sp = []
+    m3, n3 = A.size()
+    for nxs in (100, 10_000, 500_000):
+        xi = np.unique(1 + (splitmix_array(50 + nxs, nxs) % np.uint64(n3)).astype(np.int64))
+        xv = unit12(51, len(xi))
+        A.mul((xi, xv))
+        t = time.perf_counter()
+        for _ in range(5):
+            yi, yv = A.mul((xi, xv))
+        sp.append({"stored_x_entries": int(len(xi)), "touched_rows": int(len(yi)), "ms": round((time.perf_counter() - t) / 5 * 1e3, 3)})
+    res["spmv_sparse_x"] = sp
     # --- C2: 2^20-slot PMA, 100k ascending appends (batch A) and 100k uniform odd keys (batch B)
     n0 = 700000
     keys0 = np.arange(1, n0 + 1, dtype=np.int64) * 2

@@ -179,6 +179,10 @@ hipError_t launch_permute(const int64_t* src_keys, const double* src_vals, const
 hipError_t launch_compact_range(const int64_t* keys, const double* vals, const uint64_t* occ, int64_t from, int64_t to,
                                 int64_t* out_keys, double* out_vals, int64_t out_cap, RebalanceWork* work, int64_t* count,
                                 hipStream_t stream);
+// sparse-x SpMV result: touched flags (bytes, or the doubles of a pattern pass) -> (row, y[row]) pairs in ascending row order
+hipError_t launch_touched_compact(const uint8_t* bytes, const double* pattern, const double* y, int64_t ny, uint64_t* bm,
+                                  int64_t* out_i, double* out_v, RebalanceWork* work, int64_t* count, hipStream_t stream);
+hipError_t launch_scatter_x(const int64_t* xi, const double* xv, int64_t nx, double* xd, double* xf, int64_t nxd, hipStream_t stream);
 // clears occupancy bits of slots [from, to] (1-based, inclusive); from/to word-aligned or inside one word
 hipError_t launch_clear_occ(uint64_t* occ, int64_t from, int64_t to, hipStream_t stream);
 

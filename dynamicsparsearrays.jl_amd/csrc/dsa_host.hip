@@ -753,6 +753,8 @@ struct dsa_mat {
     bool has_major = false;
     Pma col, row;          // colmajor / rowmajor MappedPackedCSC
     double* d_x = nullptr; double* d_y = nullptr; int64_t x_cap = 0, y_cap = 0;
+    void* sp_base = nullptr; size_t sp_bytes = 0;             // scratch of the sparse-x SpMV (grown, never shrunk)
+    RebalanceWork sp_work{nullptr, nullptr, 0};
     std::vector<int64_t> pi, pj; std::vector<double> pv;      // queued single writes (non-fill mode)
 };
 
@@ -1134,6 +1136,8 @@ int32_t dsa_mat_destroy(dsa_mat_t* h) {
         if (h->has_major) { pma_destroy(h->col); pma_destroy(h->row); }
         if (h->d_x) hipFree(h->d_x);
         if (h->d_y) hipFree(h->d_y);
+        if (h->sp_base) hipFree(h->sp_base);
+        if (h->sp_work.tile_cnt) { hipFree(h->sp_work.tile_cnt); hipFree(h->sp_work.tile_off); }
         delete h;
     }
     return DSA_OK;
@@ -1372,50 +1376,59 @@ int32_t dsa_mat_spmv_sparse(dsa_mat_t* h, int32_t transpose, const int64_t* xi, 
     }
     *n_out = 0;
     if (ny <= 0 || nx <= 0) return DSA_OK;
-    std::vector<double> y((size_t)ny);
-    std::vector<uint8_t> flag((size_t)ny);
     const bool xdriven = nx * 8 < std::max<int64_t>(ncols, 1) || nxd <= 0 || xi[0] < 1;
-    if (xdriven) {
-        Pma& P = transpose ? h->row : h->col;          // partitions indexed like x
-        // scratch: y (ny doubles) | touched (ny bytes) | xi | xv
-        const size_t bytes = (size_t)ny * 8 + (size_t)((ny + 7) / 8) * 8 + (size_t)nx * 16;
-        void* d = nullptr;
-        HIPCHK(hipMalloc(&d, bytes));
-        double* d_y = (double*)d;
-        uint8_t* d_t = (uint8_t*)(d_y + ny);
-        int64_t* d_xi = (int64_t*)(d_t + (size_t)((ny + 7) / 8) * 8);
-        double* d_xv = (double*)(d_xi + nx);
-        try {
-            HIPCHK(hipMemcpyAsync(d_xi, xi, (size_t)nx * 8, hipMemcpyHostToDevice, P.stream));
-            HIPCHK(hipMemcpyAsync(d_xv, xv, (size_t)nx * 8, hipMemcpyHostToDevice, P.stream));
-            hipError_t e = launch_spmv_xdriven(P.K(), P.V(), P.O(), P.capacity(), P.sems, P.col_keys, P.col_live, P.h_ctl->table_len,
-                                               d_xi, d_xv, nx, d_y, d_t, ny, P.stream);
-            if (e != hipSuccess) fail(DSA_EHIP, std::string("spmv launch: ") + hipGetErrorString(e));
-            HIPCHK(hipMemcpyAsync(y.data(), d_y, (size_t)ny * 8, hipMemcpyDeviceToHost, P.stream));
-            HIPCHK(hipMemcpyAsync(flag.data(), d_t, (size_t)ny, hipMemcpyDeviceToHost, P.stream));
-            HIPCHK(hipStreamSynchronize(P.stream));
-        } catch (...) { hipFree(d); throw; }
-        hipFree(d);
-    } else {
-        std::vector<double> xd((size_t)nxd, 0.0), xf((size_t)nxd, 0.0), pat((size_t)ny);
-        for (int64_t i = 0; i < nx; ++i) { xd[(size_t)(xi[i] - 1)] = xv[i]; xf[(size_t)(xi[i] - 1)] = 1.0; }
-        ensure_xy(h, nxd, 2 * ny);
-        Pma& P = transpose ? h->col : h->row;
-        HIPCHK(hipMemcpyAsync(h->d_x, xd.data(), (size_t)nxd * sizeof(double), hipMemcpyHostToDevice, P.stream));
-        spmv_dev(h, transpose, 0, h->d_x, nxd, h->d_y, ny, P.stream);
-        HIPCHK(hipMemcpyAsync(y.data(), h->d_y, (size_t)ny * sizeof(double), hipMemcpyDeviceToHost, P.stream));
-        HIPCHK(hipStreamSynchronize(P.stream));
-        HIPCHK(hipMemcpyAsync(h->d_x, xf.data(), (size_t)nxd * sizeof(double), hipMemcpyHostToDevice, P.stream));
-        spmv_dev(h, transpose, 0, h->d_x, nxd, h->d_y + ny, ny, P.stream, 1);     // pattern pass: touched rows
-        HIPCHK(hipMemcpyAsync(pat.data(), h->d_y + ny, (size_t)ny * sizeof(double), hipMemcpyDeviceToHost, P.stream));
-        HIPCHK(hipStreamSynchronize(P.stream));
-        for (int64_t r = 0; r < ny; ++r) flag[(size_t)r] = pat[(size_t)r] != 0.0;
+    // Everything stays on the device until the compacted result: x is uploaded in its sparse form, the touched rows are
+    // packed on the device (bitmap + K-pack) and only the (row, value) pairs come back.
+    // scratch: xi | xv | xf (dense 0/1 pattern of x) | touched bytes | bitmap | out rows | out values
+    const int64_t nxdd = xdriven ? 0 : nxd;
+    const int64_t nwords = (ny + 63) >> 6, ntiles = (nwords + 63) / 64, nwp = ntiles * 64;
+    const size_t off_xv = (size_t)nx * 8, off_xf = off_xv + (size_t)nx * 8, off_t = off_xf + (size_t)nxdd * 8,
+                 off_bm = off_t + (size_t)((ny + 7) / 8) * 8, off_oi = off_bm + (size_t)nwp * 8, off_ov = off_oi + (size_t)ny * 8,
+                 bytes = off_ov + (size_t)ny * 8;
+    if (bytes > h->sp_bytes) {
+        if (h->sp_base) hipFree(h->sp_base);
+        h->sp_base = nullptr; h->sp_bytes = 0;
+        const size_t want = bytes + bytes / 2;
+        HIPCHK(hipMalloc(&h->sp_base, want));
+        h->sp_bytes = want;
     }
+    if (ntiles + 1 > h->sp_work.tiles_cap) {
+        if (h->sp_work.tile_cnt) { hipFree(h->sp_work.tile_cnt); hipFree(h->sp_work.tile_off); h->sp_work = RebalanceWork{nullptr, nullptr, 0}; }
+        const int64_t tc = 2 * ntiles + 8;
+        HIPCHK(hipMalloc(&h->sp_work.tile_cnt, (size_t)tc * sizeof(uint32_t)));
+        HIPCHK(hipMalloc(&h->sp_work.tile_off, (size_t)tc * sizeof(uint32_t)));
+        h->sp_work.tiles_cap = tc;
+    }
+    char* base = (char*)h->sp_base;
+    int64_t* d_xi = (int64_t*)base; double* d_xv = (double*)(base + off_xv); double* d_xf = (double*)(base + off_xf);
+    uint8_t* d_t = (uint8_t*)(base + off_t); uint64_t* d_bm = (uint64_t*)(base + off_bm);
+    int64_t* d_oi = (int64_t*)(base + off_oi); double* d_ov = (double*)(base + off_ov);
+    ensure_xy(h, std::max<int64_t>(nxdd, 1), 2 * ny);
+    Pma& P = xdriven ? (transpose ? h->row : h->col) : (transpose ? h->col : h->row);      // the structure that is walked
+    hipStream_t s = P.stream;
+    HIPCHK(hipMemcpyAsync(d_xi, xi, (size_t)nx * 8, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(d_xv, xv, (size_t)nx * 8, hipMemcpyHostToDevice, s));
+    hipError_t e;
     int64_t cnt = 0;
-    for (int64_t r = 0; r < ny; ++r) if (flag[(size_t)r]) {
-        if (cnt >= cap) fail(DSA_ECAP, "output buffers too small");
-        yi[cnt] = r + 1; yv[cnt] = y[(size_t)r]; ++cnt;
+    if (xdriven) {
+        e = launch_spmv_xdriven(P.K(), P.V(), P.O(), P.capacity(), P.sems, P.col_keys, P.col_live, P.h_ctl->table_len,
+                                d_xi, d_xv, nx, h->d_y, d_t, ny, s);
+        if (e != hipSuccess) fail(DSA_EHIP, std::string("spmv launch: ") + hipGetErrorString(e));
+        e = launch_touched_compact(d_t, nullptr, h->d_y, ny, d_bm, d_oi, d_ov, &h->sp_work, &cnt, s);
+    } else {
+        e = launch_scatter_x(d_xi, d_xv, nx, h->d_x, d_xf, nxd, s);
+        if (e != hipSuccess) fail(DSA_EHIP, std::string("scatter launch: ") + hipGetErrorString(e));
+        spmv_dev(h, transpose, 0, h->d_x, nxd, h->d_y, ny, s);
+        spmv_dev(h, transpose, 0, d_xf, nxd, h->d_y + ny, ny, s, 1);                      // pattern pass: touched rows
+        e = launch_touched_compact(nullptr, h->d_y + ny, h->d_y, ny, d_bm, d_oi, d_ov, &h->sp_work, &cnt, s);
     }
+    if (e != hipSuccess) fail(DSA_EHIP, std::string("touched-row compaction: ") + hipGetErrorString(e));
+    if (cnt > cap) { HIPCHK(hipStreamSynchronize(s)); fail(DSA_ECAP, "output buffers too small"); }
+    if (cnt > 0) {
+        HIPCHK(hipMemcpyAsync(yi, d_oi, (size_t)cnt * 8, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(yv, d_ov, (size_t)cnt * 8, hipMemcpyDeviceToHost, s));
+    }
+    HIPCHK(hipStreamSynchronize(s));
     *n_out = cnt;
     API_CATCH
 }

@@ -121,9 +121,8 @@ __global__ __launch_bounds__(SP_BLOCK) void k_spmv_scatter(const int64_t* __rest
     __syncthreads();
 
     int cnt[SP_WAVES];
-    int total = 0;
 #pragma unroll
-    for (int w = 0; w < SP_WAVES; ++w) { cnt[w] = sSemCnt[w]; total += cnt[w]; }
+    for (int w = 0; w < SP_WAVES; ++w) cnt[w] = sSemCnt[w];
     int first_sem = tile_end;
 #pragma unroll
     for (int w = SP_WAVES - 1; w >= 0; --w) if (cnt[w] > 0) first_sem = sSemList[w][0];
@@ -420,6 +419,24 @@ hipError_t launch_spmv_xdriven(const int64_t* keys, const double* vals, const ui
     if (nx > 0)
         hipLaunchKernelGGL(k_spmv_xdriven, dim3((unsigned)((nx + 3) / 4)), dim3(256), 0, stream, keys, vals, occ, capacity, sems,
                            col_keys, col_live, table_len, xi, xv, nx, y, touched, ny);
+    return hipGetLastError();
+}
+
+// dense form of a sparse x on the device: xd[j] = x_j, xf[j] = 1 for every STORED entry (explicit zeros included: the
+// touched-row pattern of _mul counts stored entries, src/operations.jl:101); both vectors zeroed first
+__global__ void k_scatter_x(const int64_t* __restrict__ xi, const double* __restrict__ xv, int64_t nx, double* __restrict__ xd,
+                            double* __restrict__ xf, int64_t nxd) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nx) return;
+    const int64_t j = xi[i];
+    if (j >= 1 && j <= nxd) { xd[j - 1] = xv[i]; xf[j - 1] = 1.0; }
+}
+hipError_t launch_scatter_x(const int64_t* xi, const double* xv, int64_t nx, double* xd, double* xf, int64_t nxd, hipStream_t stream) {
+    hipError_t e = hipMemsetAsync(xd, 0, (size_t)nxd * sizeof(double), stream);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(xf, 0, (size_t)nxd * sizeof(double), stream);
+    if (e != hipSuccess) return e;
+    if (nx > 0) hipLaunchKernelGGL(k_scatter_x, dim3((unsigned)((nx + 255) / 256)), dim3(256), 0, stream, xi, xv, nx, xd, xf, nxd);
     return hipGetLastError();
 }
 
