@@ -253,6 +253,10 @@ hipError_t launch_get_batch(int mode, const int64_t* keys, const double* vals, c
 hipError_t launch_check(const int64_t* keys, const double* vals, const uint64_t* occ, int64_t capacity, int64_t occ_words,
                         const int64_t* sems, const int64_t* col_keys, const uint8_t* col_live, int64_t table_len,
                         unsigned long long* report, hipStream_t stream);
+// view of one partition in one launch (ranges up to 16384 slots): meta = {from, to, err, partition id, cells or -1 = use the general path}
+hipError_t launch_view_small(const int64_t* keys, const double* vals, const uint64_t* occ, const int64_t* sems, const int64_t* col_keys,
+                             const uint8_t* col_live, int64_t table_len, int64_t capacity, int64_t col, int64_t* out_k, double* out_v,
+                             int64_t out_cap, int64_t* meta, hipStream_t stream);
 // partition slot range lookup for views: out[0] = from (first slot after the semaphore), out[1] = to, or 0,0 if missing
 hipError_t launch_partition_range(const int64_t* sems, const int64_t* col_keys, const uint8_t* col_live,
                                   int64_t table_len, int64_t capacity, int64_t col, int64_t* out, hipStream_t stream);

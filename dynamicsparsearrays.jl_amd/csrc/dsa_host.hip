@@ -880,15 +880,32 @@ void mat_apply_sets(dsa_mat* h, const int64_t* I, const int64_t* J, const double
 }
 
 void col_view_of(Pma& P, int64_t col, std::vector<int64_t>& ks, std::vector<double>& vs) {
+    // one launch (partition lookup + K-pack of its slot range into the idle alternate buffer) and one host round trip for
+    // partitions of up to 16384 slots; the first SPEC cells travel with the meta words, longer views fetch the rest
+    constexpr int64_t SPEC = 512;
     ks.clear(); vs.clear();
-    hipError_t e = launch_partition_range(P.sems, P.col_keys, P.col_live, P.h_ctl->table_len, P.capacity(), col, P.d_small, P.stream);
-    if (e != hipSuccess) fail(DSA_EHIP, std::string("range launch: ") + hipGetErrorString(e));
-    int64_t r[4] = {0, 0, 0, 0};
+    const int alt = 1 - P.cur;
+    const int64_t out_cap = std::min<int64_t>(P.cap_alloc, 16384);
+    hipError_t e = launch_view_small(P.K(), P.V(), P.O(), P.sems, P.col_keys, P.col_live, P.h_ctl->table_len, P.capacity(), col,
+                                     P.keys[alt], P.vals[alt], out_cap, P.d_small, P.stream);
+    if (e != hipSuccess) fail(DSA_EHIP, std::string("view launch: ") + hipGetErrorString(e));
+    int64_t r[5] = {0, 0, 0, 0, 0};
+    const int64_t spec = std::min<int64_t>(SPEC, out_cap);
+    ks.resize((size_t)spec); vs.resize((size_t)spec);
     HIPCHK(hipMemcpyAsync(r, P.d_small, sizeof(r), hipMemcpyDeviceToHost, P.stream));
+    HIPCHK(hipMemcpyAsync(ks.data(), P.keys[alt], (size_t)spec * sizeof(int64_t), hipMemcpyDeviceToHost, P.stream));
+    HIPCHK(hipMemcpyAsync(vs.data(), P.vals[alt], (size_t)spec * sizeof(double), hipMemcpyDeviceToHost, P.stream));
     HIPCHK(hipStreamSynchronize(P.stream));
-    if (r[2] != 0) fail((int32_t)r[2], "partition has no semaphore");
-    if (r[0] == 0) return;       // empty view: the column does not exist (src/views.jl:17,24)
-    read_range(P, r[0], r[1], ks, vs);
+    if (r[2] != 0) { ks.clear(); vs.clear(); fail((int32_t)r[2], "partition has no semaphore"); }
+    if (r[0] == 0) { ks.clear(); vs.clear(); return; }       // empty view: the column does not exist (src/views.jl:17,24)
+    const int64_t cnt = r[4];
+    if (cnt < 0) { read_range(P, r[0], r[1], ks, vs); return; }   // a long partition: general K-pack path
+    ks.resize((size_t)cnt); vs.resize((size_t)cnt);
+    if (cnt > spec) {
+        HIPCHK(hipMemcpyAsync(ks.data() + spec, P.keys[alt] + spec, (size_t)(cnt - spec) * sizeof(int64_t), hipMemcpyDeviceToHost, P.stream));
+        HIPCHK(hipMemcpyAsync(vs.data() + spec, P.vals[alt] + spec, (size_t)(cnt - spec) * sizeof(double), hipMemcpyDeviceToHost, P.stream));
+        HIPCHK(hipStreamSynchronize(P.stream));
+    }
 }
 
 void ensure_xy(dsa_mat* h, int64_t nx, int64_t ny) {
@@ -1249,12 +1266,20 @@ int32_t dsa_mat_deletecolumn(dsa_mat_t* h, int64_t col) {      // src/matrix.jl:
     col_view_of(h->col, col, rows, vals);
     std::vector<Op> ops;
     for (int64_t r : rows) ops.push_back(make_op(OP_MPCSC_SET, col, r, 0.0));     // rowmajor[col, row] = 0
-    int32_t err = 0;
-    run_ops(h->row, ops, &err);
-    if (err) fail(err, err_text(err));
     std::vector<Op> del{make_op(OP_MPCSC_DELETECOLUMN, 0, col, 0.0)};
-    run_ops(h->col, del, &err);
-    if (err) fail(err, err_text(err));
+    // the element deletes of the twin cannot fail and touch the other structure: both sequencers run side by side
+    if (h->col.stream != h->row.stream) {
+        SeqRun rr, rc;
+        run_ops_pair(h->row, ops, h->col, del, rr, rc);
+        if (rr.err) fail(rr.err, err_text(rr.err));
+        if (rc.err) fail(rc.err, err_text(rc.err));
+    } else {
+        int32_t err = 0;
+        run_ops(h->row, ops, &err);
+        if (err) fail(err, err_text(err));
+        run_ops(h->col, del, &err);
+        if (err) fail(err, err_text(err));
+    }
     API_CATCH
 }
 int32_t dsa_mat_deleterow(dsa_mat_t* h, int64_t row) {         // src/matrix.jl:104-111
@@ -1265,12 +1290,19 @@ int32_t dsa_mat_deleterow(dsa_mat_t* h, int64_t row) {         // src/matrix.jl:
     col_view_of(h->row, row, cols, vals);
     std::vector<Op> ops;
     for (int64_t c : cols) ops.push_back(make_op(OP_MPCSC_SET, row, c, 0.0));     // colmajor[row, col] = 0
-    int32_t err = 0;
-    run_ops(h->col, ops, &err);
-    if (err) fail(err, err_text(err));
     std::vector<Op> del{make_op(OP_MPCSC_DELETECOLUMN, 0, row, 0.0)};
-    run_ops(h->row, del, &err);
-    if (err) fail(err, err_text(err));
+    if (h->col.stream != h->row.stream) {
+        SeqRun rc, rr;
+        run_ops_pair(h->col, ops, h->row, del, rc, rr);
+        if (rc.err) fail(rc.err, err_text(rc.err));
+        if (rr.err) fail(rr.err, err_text(rr.err));
+    } else {
+        int32_t err = 0;
+        run_ops(h->col, ops, &err);
+        if (err) fail(err, err_text(err));
+        run_ops(h->row, del, &err);
+        if (err) fail(err, err_text(err));
+    }
     API_CATCH
 }
 

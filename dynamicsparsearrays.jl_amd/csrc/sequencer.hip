@@ -1398,6 +1398,54 @@ __global__ void k_partition_range(const int64_t* sems, const int64_t* col_keys, 
     out[2] = 0;
     out[3] = f.pos;
 }
+// view(mpcsc, :, col) (src/views.jl:15-35) in ONE launch for partitions of up to VIEW_SMALL_SLOTS slots: partition lookup, then the
+// occupied cells of its slot range packed in slot order into out_k / out_v (one wave, ballot-style ranks).  meta[0] = from,
+// meta[1] = to, meta[2] = error code, meta[3] = partition id, meta[4] = number of cells or -1 when the range is longer (the
+// caller then takes the general K-pack path).  Column views and deletecolumn! / deleterow! need one host round trip this way.
+constexpr int64_t VIEW_SMALL_SLOTS = 16384;
+__global__ __launch_bounds__(64) void k_view_small(const int64_t* __restrict__ keys, const double* __restrict__ vals,
+                                                   const uint64_t* __restrict__ occ, const int64_t* sems, const int64_t* col_keys,
+                                                   const uint8_t* col_live, int64_t table_len, int64_t capacity, int64_t col,
+                                                   int64_t* __restrict__ out_k, double* __restrict__ out_v, int64_t out_cap, int64_t* meta) {
+    const int lane = threadIdx.x;
+    int64_t from = 0, to = 0, err = 0, pid = 0;
+    const DFoundKey f = d_find_table(col_keys, col_live, table_len, col);
+    if (f.has && f.key == col) {
+        const int64_t sp = sems[f.pos - 1];
+        if (sp == 0) err = E_ASSERT;
+        else {
+            const int64_t next = d_next_live_sem(sems, f.pos, table_len);
+            from = sp + 1;
+            to = next != 0 ? sems[next - 1] - 1 : capacity;
+            pid = f.pos;
+        }
+    }
+    int64_t cnt = 0;
+    if (from != 0 && to >= from) {
+        if (to - from + 1 > VIEW_SMALL_SLOTS) cnt = -1;
+        else {
+            const int64_t lo0 = from - 1, hi0 = to - 1;
+            for (int64_t w = lo0 >> 6; w <= (hi0 >> 6); ++w) {
+                const uint64_t mask = occ[w] & word_range_mask(w, lo0, hi0);
+                if ((mask >> lane) & 1ull) {
+                    const int64_t r = cnt + popc64(mask & mask_lt(lane));
+                    if (r < out_cap) { out_k[r] = keys[(w << 6) + lane]; out_v[r] = vals[(w << 6) + lane]; }
+                }
+                cnt += popc64(mask);
+            }
+            if (cnt > out_cap) cnt = -1;
+        }
+    }
+    if (lane == 0) { meta[0] = from; meta[1] = to; meta[2] = err; meta[3] = pid; meta[4] = cnt; }
+}
+hipError_t launch_view_small(const int64_t* keys, const double* vals, const uint64_t* occ, const int64_t* sems, const int64_t* col_keys,
+                             const uint8_t* col_live, int64_t table_len, int64_t capacity, int64_t col, int64_t* out_k, double* out_v,
+                             int64_t out_cap, int64_t* meta, hipStream_t stream) {
+    hipLaunchKernelGGL(k_view_small, dim3(1), dim3(64), 0, stream, keys, vals, occ, sems, col_keys, col_live, table_len, capacity, col, out_k,
+                       out_v, out_cap, meta);
+    return hipGetLastError();
+}
+
 hipError_t launch_partition_range(const int64_t* sems, const int64_t* col_keys, const uint8_t* col_live,
                                   int64_t table_len, int64_t capacity, int64_t col, int64_t* out, hipStream_t stream) {
     hipLaunchKernelGGL(k_partition_range, dim3(1), dim3(64), 0, stream, sems, col_keys, col_live, table_len, capacity, col, out);
