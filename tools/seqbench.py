@@ -39,3 +39,13 @@ uv = np.where(bench.splitmix_array(36, 200000) % np.uint64(4) == 0, 0.0, bench.u
 A.set_batch(ui[:100], uj[:100], uv[:100])
 t0 = time.perf_counter(); A.set_batch(ui, uj, uv); dt = time.perf_counter() - t0
 print("%-40s %7.2f us/op (%s)" % ("matrix random A[i,j]=v (2 PCSR writes)", dt / len(ui) * 1e6, os.environ.get("DSA_PARBATCH", "1")))
+# small batches on the same matrix: latency of one set_batch call by batch size
+for nb in (16, 130, 500, 2000, 8000):
+    reps = 20
+    off = 1000
+    t0 = time.perf_counter()
+    for r in range(reps):
+        sl = slice(off + r * nb, off + (r + 1) * nb)
+        A.set_batch(ui[sl], uj[sl], uv[sl])
+    dt = (time.perf_counter() - t0) / reps
+    print("matrix set_batch of %5d writes: %8.1f us per call  %6.2f us/op" % (nb, dt * 1e6, dt / nb * 1e6))
