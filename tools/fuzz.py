@@ -95,6 +95,19 @@ def run_matrix(seed):
         if ea is not None:
             return "err%d" % ea          # state after a reference crash path is a documented divergence
         mat_equal(a, b, (seed, step, mode, nb))
+        if live:                              # views, lookups and the sparse-x product on the fresh state
+            i0, j0 = live[g.next() % len(live)]
+            for name, key in (("col_view", j0), ("row_view", i0)):
+                assert getattr(a, name)(key) == getattr(b, name)(key), (seed, step, name, key)
+            qi = [live[g.next() % len(live)][0] for _ in range(8)] + [1 + int(g.next() % span_i)]
+            qj = [live[g.next() % len(live)][1] for _ in range(8)] + [1 + int(g.next() % span_j)]
+            assert np.array_equal(a.get_batch(qi, qj), b.get_batch(qi, qj)), (seed, step, "get_batch")
+            if not neg and g.next() % 3 == 0:      # (negative row keys: the reference's sparsevec throws — documented divergence)
+                cols = sorted({j for _, j in live if j >= 1})
+                xi = np.array(cols[:: max(1, len(cols) // (1 + g.next() % 40))], dtype=np.int64)
+                xv = 1.0 + (np.arange(len(xi)) % 5) / 4.0
+                ia, va2 = a.mul((xi, xv)); ib, vb2 = b.mul((xi, xv))
+                assert np.array_equal(ia, ib) and np.allclose(va2, vb2, rtol=1e-12, atol=0), (seed, step, "sparse-x mul")
         if g.next() % 7 == 0 and live:       # tombstones now and then
             i, j = live[g.next() % len(live)]
             try:
