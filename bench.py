@@ -216,12 +216,18 @@ def main():
         out["roofline"]["traffic"] = pm["k_spmv_gather_C3"]["corrected_traffic_total"]
         out["roofline"]["traffic_source"] = "profiles/r01_final_pmc_summary.json (rocprofv3 --pmc, corrected)"
     if rank == 0 and world == 1 and not args.no_extras:          # the extra legs and the CPU baseline belong to the N = 1 line
-        out.update(extras(dsa, hip, torch, A, dev))
+        try:
+            out.update(extras(dsa, hip, torch, A, dev))
+        except Exception as e:               # an extra leg must never cost the headline line
+            out["extras_error"] = "%s: %s" % (type(e).__name__, str(e)[:300])
         if pm is not None and "roofline_rebalance" in out:
             out["roofline_rebalance"]["traffic"] = pm["k_move_root_2^24"]["corrected_traffic_total"] \
                 if out["roofline_rebalance"]["window_slots"] == 16777216 else None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(dsa, m, per)
+        try:
+            out["cpu_baseline"] = cpu_baseline(dsa, m, per)
+        except Exception as e:
+            out["cpu_baseline"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
