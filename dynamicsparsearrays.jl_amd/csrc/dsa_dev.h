@@ -229,7 +229,7 @@ struct RoundState {
     int32_t G;             // ops planned per round (adapted on the device to 2x the last prefix, 64..1024)
     int32_t d;             // prefix length decided by k_resolve for the round in flight
     int32_t stop;          // 0 running, 1 short prefix at `cursor` (sequencer must take over), 2 batch finished
-    int32_t min_prefix, G_next, pad;
+    int32_t min_prefix, G_next, pad;   // pad: fault flag raised by k_apply (an op left its planned footprint: cannot happen, checked by the host)
     int64_t rounds, par_ops;
     int64_t why[8];        // dev: what cut the prefixes (index = Plan::count of the first BARRIER op; 7 = a conflict)
 };

@@ -507,6 +507,7 @@ int64_t run_ops_parallel(Pma& P, const std::vector<Op>& ops, int32_t* err) {
         HIPCHK(hipMemcpyAsync(P.h_rs, P.d_rs, sizeof(RoundState), hipMemcpyDeviceToHost, P.stream));
         HIPCHK(hipStreamSynchronize(P.stream));
         // the prefix of the last round of the burst has been applied but is folded into the cursor only by the next k_resolve
+        if (rs.pad != 0) fail(DSA_EASSERT, "batch-parallel column creation left its footprint (internal invariant)");
         const int64_t reached = rs.cursor + rs.d;
         if (reached > i) { host_ctl_stale = true; seq_chunk = SEQ_CHUNK0; }
         P.stat_par_rounds += rs.rounds + (rs.d > 0 ? 1 : 0); P.stat_par_ops += rs.par_ops + rs.d;
@@ -528,7 +529,6 @@ int64_t run_ops_parallel(Pma& P, const std::vector<Op>& ops, int32_t* err) {
         G = 64;
     }
     if (host_ctl_stale) download_ctl(P);
-    if (P.h_ctl->err == DSA_EASSERT && P.h_ctl->status != SEQ_ERROR) fail(DSA_EASSERT, "batch-parallel column creation left its footprint (internal invariant)");
     if (P.h_ctl->n_pending > 0) {
         // columns created by the last rounds still sit at the end of the tables: an empty sequencer run merges them
         SeqRun r;

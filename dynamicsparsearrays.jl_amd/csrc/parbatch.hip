@@ -518,7 +518,7 @@ __global__ __launch_bounds__(PB_BLOCK) void k_apply(int64_t* keys, double* vals,
             const int64_t ne2 = pb_next_empty_live(occ, s1, capacity);
             if (ne2 == 0 || ne2 > pl.hi || s1 < pl.lo || s1 >= pl.hi) {
                 // cannot happen (see k_plan); if it ever does, fail loudly instead of writing outside the footprint
-                if (lane == 0) atomicExch(&ctl->err, (int32_t)E_ASSERT);
+                if (lane == 0) atomicExch(&const_cast<RoundState*>(rs)->pad, 1);      // RoundState::pad = fault flag, read by the host after every burst
                 break;
             }
             pb_shift_right_live(keys, vals, sems, s1 + 1, ne2);

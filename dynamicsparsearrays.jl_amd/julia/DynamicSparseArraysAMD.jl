@@ -9,8 +9,8 @@ module DynamicSparseArraysAMD
 
 using SparseArrays
 
-export DynamicSparseVector, DynamicSparseMatrix, dynamicsparsevec, dynamicsparse, nbpartitions,
-       deletecolumn!, deleterow!, addrow!, closefillmode!, shrink_size!
+export DynamicSparseVector, DynamicSparseMatrix, PackedCSC, dynamicsparsevec, dynamicsparse, nbpartitions,
+       deletecolumn!, deleterow!, deletepartition!, addrow!, closefillmode!, shrink_size!, set_device!
 
 const libdsa = get(ENV, "DSA_HIP_LIB", joinpath(@__DIR__, "..", "csrc", "libdsa_hip.so"))
 
@@ -26,6 +26,10 @@ function _check(rc::Int32)
 end
 
 const COMBINE = IdDict{Function,Int32}(+ => Int32(0), * => Int32(1))
+
+"one process per GPU: select the device before creating handles (dsa_set_device)"
+set_device!(dev::Integer) = _check(ccall((:dsa_set_device, libdsa), Int32, (Int32,), dev))
+device_count() = ccall((:dsa_device_count, libdsa), Int32, ())
 
 # ------------------------------------------------------------------ vector  (reference src/vector.jl)
 mutable struct DynamicSparseVector <: AbstractSparseVector{Float64,Int64}
@@ -68,6 +72,15 @@ end
 function Base.setindex!(v::DynamicSparseVector, value, key::Integer)
     _check(ccall((:dsa_vec_set, libdsa), Int32, (Ptr{Cvoid}, Int64, Float64), v.h, key, Float64(value)))
     return v
+end
+dynamicsparsevec(::Type{Int64}, ::Type{Float64}) = (out = Ref{Ptr{Cvoid}}(C_NULL);
+    _check(ccall((:dsa_vec_create_empty, libdsa), Int32, (Ref{Ptr{Cvoid}},), out)); DynamicSparseVector(out[]))
+"n getindex calls in one ccall"
+function getindex_batch(v::DynamicSparseVector, keys::Vector{Int64})
+    out = Vector{Float64}(undef, length(keys))
+    GC.@preserve keys out _check(ccall((:dsa_vec_get_batch, libdsa), Int32,
+        (Ptr{Cvoid}, Ptr{Int64}, Int64, Ptr{Float64}), v.h, keys, length(keys), out))
+    return out
 end
 "n sequential setindex! calls in one ccall (sequential-equivalent batch)"
 function setindex_batch!(v::DynamicSparseVector, keys::Vector{Int64}, vals::Vector{Float64})
@@ -165,6 +178,63 @@ function _view(sym::Symbol, a::DynamicSparseMatrix, key::Int64)
 end
 Base.view(a::DynamicSparseMatrix, ::Colon, col::Int64) = _view(:dsa_mat_col_view, a, col)   # src/matrix.jl:83-88
 Base.view(a::DynamicSparseMatrix, row::Int64, ::Colon) = _view(:dsa_mat_row_view, a, row)   # src/matrix.jl:70-81
+# m[:, col] / m[row, :]: new device-resident vectors (src/pcsr.jl:269-291)
+function _slice(sym::Symbol, a::DynamicSparseMatrix, key::Int64)
+    out = Ref{Ptr{Cvoid}}(C_NULL)
+    _check(ccall((sym, libdsa), Int32, (Ptr{Cvoid}, Int64, Ref{Ptr{Cvoid}}), a.h, key, out))
+    return DynamicSparseVector(out[])
+end
+Base.getindex(a::DynamicSparseMatrix, ::Colon, col::Int64) = _slice(:dsa_mat_col_slice, a, col)
+Base.getindex(a::DynamicSparseMatrix, row::Int64, ::Colon) = _slice(:dsa_mat_row_slice, a, row)
+"n getindex calls in one ccall"
+function getindex_batch(a::DynamicSparseMatrix, I::Vector{Int64}, J::Vector{Int64})
+    out = Vector{Float64}(undef, length(I))
+    GC.@preserve I J out _check(ccall((:dsa_mat_get_batch, libdsa), Int32,
+        (Ptr{Cvoid}, Ptr{Int64}, Ptr{Int64}, Int64, Ptr{Float64}), a.h, I, J, length(I), out))
+    return out
+end
+
+# ------------------------------------------------------------------ PackedCSC  (reference src/pcsr.jl:4-339)
+mutable struct PackedCSC
+    h::Ptr{Cvoid}
+    function PackedCSC(h::Ptr{Cvoid})
+        p = new(h)
+        finalizer(x -> ccall((:dsa_pcsc_destroy, libdsa), Int32, (Ptr{Cvoid},), x.h), p)
+        return p
+    end
+end
+"PackedCSC(row_keys, values, combine): one vector of keys / values per partition (src/pcsr.jl:26-63)"
+function PackedCSC(row_keys::Vector{Vector{Int64}}, values::Vector{Vector{Float64}}, combine::Function = +)
+    length(row_keys) == length(values) || throw(ArgumentError("Must have same number of partitions."))
+    colptr = Int64[0]; keys = Int64[]; vals = Float64[]          # CSC-style offsets (0-based, nparts + 1 entries)
+    for (p, (ks, vs)) in enumerate(zip(row_keys, values))
+        length(ks) == length(vs) || throw(ArgumentError("Partition $p: keys & values must have same length."))
+        append!(keys, ks); append!(vals, vs); push!(colptr, length(keys))
+    end
+    out = Ref{Ptr{Cvoid}}(C_NULL)
+    GC.@preserve colptr keys vals _check(ccall((:dsa_pcsc_create, libdsa), Int32,
+        (Ptr{Int64}, Int64, Ptr{Int64}, Ptr{Float64}, Int32, Ref{Ptr{Cvoid}}),
+        colptr, length(row_keys), keys, vals, get(COMBINE, combine, Int32(0)), out))
+    return PackedCSC(out[])
+end
+PackedCSC() = (out = Ref{Ptr{Cvoid}}(C_NULL); _check(ccall((:dsa_pcsc_create_empty, libdsa), Int32, (Ref{Ptr{Cvoid}},), out)); PackedCSC(out[]))
+function Base.getindex(p::PackedCSC, key::Int64, partition::Int64)          # src/pcsr.jl:228-232
+    out = Ref{Float64}(0.0)
+    _check(ccall((:dsa_pcsc_get, libdsa), Int32, (Ptr{Cvoid}, Int64, Int64, Ref{Float64}), p.h, key, partition, out))
+    return out[]
+end
+function Base.setindex!(p::PackedCSC, value, key::Int64, partition::Int64)  # src/pcsr.jl:294-310
+    _check(ccall((:dsa_pcsc_set, libdsa), Int32, (Ptr{Cvoid}, Float64, Int64, Int64), p.h, Float64(value), key, partition))
+    return p
+end
+deletepartition!(p::PackedCSC, partition::Int64) =                           # src/pcsr.jl:188-204
+    (_check(ccall((:dsa_pcsc_deletepartition, libdsa), Int32, (Ptr{Cvoid}, Int64), p.h, partition)); nothing)
+function SparseArrays.nnz(p::PackedCSC)
+    out = Ref{Int64}(0); _check(ccall((:dsa_pcsc_nnz, libdsa), Int32, (Ptr{Cvoid}, Ref{Int64}), p.h, out)); out[]
+end
+function nbpartitions(p::PackedCSC)
+    out = Ref{Int64}(0); _check(ccall((:dsa_pcsc_nbpartitions, libdsa), Int32, (Ptr{Cvoid}, Ref{Int64}), p.h, out)); out[]
+end
 
 # ------------------------------------------------------------------ SpMV  (reference src/operations.jl)
 struct Transposed{T}; array::T; end
