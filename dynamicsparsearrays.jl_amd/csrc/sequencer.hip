@@ -21,6 +21,13 @@
 
 namespace dsa {
 
+// dev profile of the sequencer (Ctl::prof, printed under DSA_DBG_TIME): compiled in with -DDSA_PROFILE only — the shader-clock
+// reads (s_memtime) cost a few percent of a sequential op
+#ifdef DSA_PROFILE
+#define DSA_TICK() ((int64_t)__builtin_readcyclecounter())
+#else
+#define DSA_TICK() ((int64_t)0)
+#endif
 constexpr int SEQ_BLOCK = 256;
 constexpr int64_t SMALL_W = 8192;
 
@@ -251,7 +258,7 @@ __device__ int d_after_count_change(Seq& S, int64_t pos) {
     const int64_t W = we - ws + 1;
     if (W == S.seg) return 0;
     S.stat_rebalances += 1; S.stat_window_slots += W;
-    if (W <= SMALL_W) { const int64_t tr0 = (int64_t)__builtin_readcyclecounter(); blk_rebalance_small(S, ws, we, count); S.prof[12] += (int64_t)__builtin_readcyclecounter() - tr0; S.prof[13] += 1; S.prof[14] += W; return 0; }
+    if (W <= SMALL_W) { const int64_t tr0 = DSA_TICK(); blk_rebalance_small(S, ws, we, count); S.prof[12] += DSA_TICK() - tr0; S.prof[13] += 1; S.prof[14] += W; return 0; }
     S.y_ws = ws; S.y_we = we; S.y_m = count;
     return SEQ_Y_REBALANCE;
 }
@@ -806,9 +813,9 @@ __device__ int d_set_in_range(Seq& S, int64_t key, double val, int64_t from, int
                 if (lk < key) { f = DFound{lp, lk, 0.0, true}; have = true; }
             }
         }
-        const int64_t ts0 = (int64_t)__builtin_readcyclecounter();
+        const int64_t ts0 = DSA_TICK();
         if (!have) f = d_find_fast(S.keys, S.vals, S.occ, key, from, to);     // [from, to] never holds a semaphore
-        S.prof[8] += (int64_t)__builtin_readcyclecounter() - ts0;
+        S.prof[8] += DSA_TICK() - ts0;
         S.tail_hint = have || (f.has && f.pos >= from && f.key < key && d_next_occupied(S.occ, f.pos, to) == 0);
         if (f.has && f.key == key && from <= f.pos && f.pos <= to) {
             __syncthreads();
@@ -816,13 +823,13 @@ __device__ int d_set_in_range(Seq& S, int64_t key, double val, int64_t from, int
             __syncthreads();
             return 0;
         }
-        const int64_t ts1 = (int64_t)__builtin_readcyclecounter();
+        const int64_t ts1 = DSA_TICK();
         const int64_t ip = d_insert_after(S, key, val, f.pos);
         if (ip == 0) return SEQ_ERROR;
         S.nb_elements += 1;
-        const int64_t ts2 = (int64_t)__builtin_readcyclecounter();
+        const int64_t ts2 = DSA_TICK();
         const int rr = d_after_count_change(S, ip);
-        S.prof[9] += ts2 - ts1; S.prof[10] += (int64_t)__builtin_readcyclecounter() - ts2;
+        S.prof[9] += ts2 - ts1; S.prof[10] += DSA_TICK() - ts2;
         return rr;
     }
     // the delete range of a partition starts AT its semaphore (key 0, src/pcsr.jl:307): the wave-parallel search is
@@ -961,7 +968,7 @@ __device__ int64_t succ_index(const Seq& S, int64_t sorted_succ, int64_t key) {
 __device__ void d_merge_pending(Seq& S) {
     const int K = S.n_pend;
     if (K == 0) return;
-    const int64_t tm0 = (int64_t)__builtin_readcyclecounter();
+    const int64_t tm0 = DSA_TICK();
     __syncthreads();
     const int64_t ns = S.n_sorted;
     int64_t* dst = S.sK;                                      // dynamic LDS is free between ops
@@ -1005,7 +1012,7 @@ __device__ void d_merge_pending(Seq& S) {
     __syncthreads();
     S.n_sorted = S.table_len;
     S.n_pend = 0;
-    S.prof[3] += (int64_t)__builtin_readcyclecounter() - tm0; S.prof[6] += 1;
+    S.prof[3] += DSA_TICK() - tm0; S.prof[6] += 1;
 }
 
 // entries appended by the batch-parallel rounds (Ctl::n_pending, arrival order): build the sorted list and merge at once
@@ -1054,9 +1061,9 @@ __device__ int d_pcsc_set(Seq& S, double val, int64_t key, int64_t partition) {
     }
     const int64_t from = S.sems[partition - 1];
     if (from == 0) { S.err = E_DELETED; return SEQ_ERROR; }
-    const int64_t te0 = (int64_t)__builtin_readcyclecounter();
+    const int64_t te0 = DSA_TICK();
     const int64_t to = d_partition_end(S, partition);
-    S.prof[11] += (int64_t)__builtin_readcyclecounter() - te0;
+    S.prof[11] += DSA_TICK() - te0;
     return d_set_in_range(S, key, val, from + 1, to, from);
 }
 
@@ -1095,7 +1102,7 @@ __device__ int d_exec(Seq& S, const Op& op) {
         case OP_MPCSC_SET: {       // setindex!(mpcsc, value, row, col)  src/pcsr.jl:341-351
             if (S.n_pend == PEND_MAX) d_merge_pending(S);
             if (S.n_pend == 0) S.n_sorted = S.table_len;
-            const int64_t tp0 = (int64_t)__builtin_readcyclecounter();
+            const int64_t tp0 = DSA_TICK();
             const bool no_tombstone = S.nb_partitions == S.table_len;
             const DFoundKey f = d_find_table_fast(S.col_keys, S.col_live, S.n_sorted, op.b, no_tombstone);
             int64_t col_pos = f.pos;
@@ -1111,7 +1118,7 @@ __device__ int d_exec(Seq& S, const Op& op) {
                     sidx = succ_index(S, (int64_t)S.pLb[pj], op.b);
                 }
             }
-            const int64_t tp1 = (int64_t)__builtin_readcyclecounter();
+            const int64_t tp1 = DSA_TICK();
             S.prof[0] += tp1 - tp0; S.prof[4] += 1;
             if (!found) {
                 if (S.n_pend == 0 && (f.pos == S.table_len || !no_tombstone)) {
@@ -1153,9 +1160,9 @@ __device__ int d_exec(Seq& S, const Op& op) {
                     if (r) return r | RERUN;
                     col_pos = idx + 1;
                 }
-                S.prof[1] += (int64_t)__builtin_readcyclecounter() - tp1; S.prof[5] += 1;
+                S.prof[1] += DSA_TICK() - tp1; S.prof[5] += 1;
             }
-            const int64_t tp2 = (int64_t)__builtin_readcyclecounter();
+            const int64_t tp2 = DSA_TICK();
             int rr;
             if (sidx == -2) rr = d_pcsc_set(S, op.v, op.a, col_pos);
             else {
@@ -1164,7 +1171,7 @@ __device__ int d_exec(Seq& S, const Op& op) {
                 const int64_t to = sidx >= 0 ? S.sems[sidx] - 1 : S.capacity;
                 rr = d_set_in_range(S, op.a, op.v, from + 1, to, from);
             }
-            S.prof[2] += (int64_t)__builtin_readcyclecounter() - tp2;
+            S.prof[2] += DSA_TICK() - tp2;
             return rr;
         }
         case OP_DELETE_PARTITION:
@@ -1202,7 +1209,7 @@ __global__ __launch_bounds__(SEQ_BLOCK) void k_sequencer(int64_t* keys, double* 
     __shared__ uint32_t sPLb[PEND_MAX];
     S.n_sorted = S.table_len; S.n_pend = 0; S.pKey = sPKey; S.pIdx = sPIdx; S.pLb = sPLb;
     for (int q = 0; q < 16; ++q) S.prof[q] = 0;
-    const int64_t tk0 = (int64_t)__builtin_readcyclecounter();
+    const int64_t tk0 = DSA_TICK();
     S.sK = reinterpret_cast<int64_t*>(lds);
     S.sV = reinterpret_cast<double*>(lds + SMALL_W * sizeof(int64_t));
     S.sWordOff = sWordOff; S.sRed = sRed;
@@ -1252,7 +1259,7 @@ __global__ __launch_bounds__(SEQ_BLOCK) void k_sequencer(int64_t* keys, double* 
         ctl->y_ws = S.y_ws; ctl->y_we = S.y_we; ctl->y_m = S.y_m;
         ctl->stat_window_slots = S.stat_window_slots; ctl->stat_rebalances = S.stat_rebalances;
         ctl->stat_small_rebalances = S.stat_small;
-        S.prof[7] = (int64_t)__builtin_readcyclecounter() - tk0;
+        S.prof[7] = DSA_TICK() - tk0;
         for (int q = 0; q < 16; ++q) ctl->prof[q] += S.prof[q];
     }
 }

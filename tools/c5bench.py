@@ -32,3 +32,7 @@ for c0 in range(0, ncols5, step):
         t_d += time.perf_counter() - t
 if deletes: print('deletecolumn: %d calls, %.1f ms (%.1f us each)' % (nd, t_d * 1e3, t_d / max(nd, 1) * 1e6))
 print("C5 %s:" % ("full" if full else "scaled") + " %d element writes in %.1f ms -> %.0f writes/s" % (nw, t_w * 1e3, nw / t_w))
+
+for o, name in ((0, "colmajor"), (1, "rowmajor")):
+    inf = B.info(o)
+    print("final info %s:" % name, {k: inf[k] for k in ("capacity", "nb_elements", "stat_rebalances", "stat_window_slots", "stat_extends", "stat_par_rounds", "stat_par_ops", "stat_seq_ops")})
