@@ -343,7 +343,7 @@ __device__ __forceinline__ uint64_t rdlane64(uint64_t v, int l) {
 // memo of spread! patterns for windows of up to 256 slots: the pattern depends on (W, c) only and an append run keeps
 // hitting the same few (level, count) pairs.  Filled on first use by wave 0.
 constexpr int MEMO_ENTRIES = 640, MEMO_WORDS = 1664;
-struct RunMemo { uint64_t words[MEMO_WORDS]; uint8_t valid[MEMO_ENTRIES]; };
+struct RunMemo { uint64_t words[MEMO_WORDS]; uint8_t valid[MEMO_ENTRIES]; unsigned long long gapw[64]; };   // gapw: scratch of the cooperative spread
 
 // wave 0: replays appends rc->idx .. end-1 on the register-resident block until one needs the workgroup path (need = 1).
 // Everything per op is wave-uniform register work: lane <-> occupancy word of the block for the bitmap, lane <-> level
@@ -497,7 +497,21 @@ __device__ void wave_fast_appends(Seq& S, RunComm* rc, RunMemo* memo, const uint
                 g.f = (double)W / (double)(W - c);
                 g.inv_f = (double)(W - c) / (double)W;
                 const int t = lane - lw0;
-                if (t >= 0 && t < (W >> 6)) word = spread_word_bits(g, t);
+                const int nww = W >> 6, E = W - c;
+                if (E <= 16 * nww) {
+                    // few gaps per word (dense window): the whole wave generates the E gap offsets D(k) — lane <-> k — and clears
+                    // their bits in an LDS image of the window, instead of every lane looping over the gaps of its own word
+                    if (lane < nww) memo->gapw[lane] = ~0ull;
+                    __builtin_amdgcn_wave_barrier();
+                    for (int k = lane + 1; k <= E; k += 64) {
+                        const int d = gap_D(g, k);                             // 1-based offset in the window
+                        atomicAnd(&memo->gapw[(d - 1) >> 6], ~(1ull << ((d - 1) & 63)));
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_s_waitcnt(0xc07f);                        // lgkmcnt(0): the wave's LDS atomics have landed
+                    if (t >= 0 && t < nww) word = memo->gapw[t];
+                    __builtin_amdgcn_wave_barrier();
+                } else if (t >= 0 && t < nww) word = spread_word_bits(g, t);
                 L = ws - 1 + spread_last_cell(g);
             }
             ++idx;
