@@ -343,7 +343,7 @@ __device__ __forceinline__ uint64_t rdlane64(uint64_t v, int l) {
 // memo of spread! patterns for windows of up to 256 slots: the pattern depends on (W, c) only and an append run keeps
 // hitting the same few (level, count) pairs.  Filled on first use by wave 0.
 constexpr int MEMO_ENTRIES = 640, MEMO_WORDS = 1664;
-struct RunMemo { uint64_t words[MEMO_WORDS]; uint8_t valid[MEMO_ENTRIES]; unsigned long long gapw[64]; };   // gapw: scratch of the cooperative spread
+struct RunMemo { uint64_t words[MEMO_WORDS]; unsigned long long gapw[64]; };   // gapw: scratch of the cooperative spread
 
 // wave 0: replays appends rc->idx .. end-1 on the register-resident block until one needs the workgroup path (need = 1).
 // Everything per op is wave-uniform register work: lane <-> occupancy word of the block for the bitmap, lane <-> level
@@ -369,15 +369,14 @@ __device__ void wave_fast_appends(Seq& S, RunComm* rc, RunMemo* memo, const uint
     const uint64_t my_low_mask = lvl_low ? (Wl == 64 ? ~0ull : ((1ull << Wl) - 1ull)) : 0ull;
     const int my_low_align = lvl_low ? ~((int)Wl - 1) & 63 : 0;
     const bool any_mid = __ballot(lvl_mid) != 0;
-    // memo bases of level h = lane (W <= 256): entry index and first word of entry c = 0
-    int my_ent = 0, my_wb = 0;
+    // memo base of level h = lane (W <= 256): first word of entry c = 0
+    int my_wb = 0;
     {
-        int e = 0, wb = 0;
+        int wb = 0;
         for (int h = 0; h < 64; ++h) {
             const int64_t Wh = seg << h;
             if (h > (int)S.height || Wh > 256) break;
-            if (h == lane) { my_ent = e; my_wb = wb; }
-            e += (int)Wh + 1;
+            if (h == lane) my_wb = wb;
             wb += ((int)Wh + 1) * (Wh <= 64 ? 1 : (int)(Wh >> 6));
         }
     }
@@ -465,9 +464,11 @@ __device__ void wave_fast_appends(Seq& S, RunComm* rc, RunMemo* memo, const uint
             const int lw0 = (int)(((ws - 1) >> 6) & 63);
             if (W <= 256) {
                 const int nw = W < 64 ? 1 : (W >> 6);
-                const int ent = (int)rdlane((uint32_t)my_ent, h) + c;
                 const int wb = (int)rdlane((uint32_t)my_wb, h) + c * nw;
-                if (!memo->valid[ent]) {
+                // a filled entry never ends with an empty word (c >= lo[h] cells spread evenly): 0 = not computed yet — one LDS
+                // round trip instead of a separate valid flag
+                uint64_t lastw = memo->words[wb + nw - 1];
+                if (lastw == 0) {
                     SpreadGeom g;                                             // make_geom(W, c) with 32-bit conversions
                     g.W = W; g.E = W - c;
                     g.f = (double)W / (double)(W - c);
@@ -478,10 +479,11 @@ __device__ void wave_fast_appends(Seq& S, RunComm* rc, RunMemo* memo, const uint
                         const bool cell = q <= W && !slot_is_gap(g, q, &rank);
                         const uint64_t nb = __ballot(cell);
                         if (lane == 0) memo->words[wb + t] = nb;
+                        lastw = nb;
                     }
-                    if (lane == 0) memo->valid[ent] = 1;
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_s_waitcnt(0xc07f);                        // the other lanes read the entry below
                 }
-                const uint64_t lastw = memo->words[wb + nw - 1];
                 if (W < 64) {
                     const int sh = (int)((ws - 1) & 63);
                     const uint64_t m = ((1ull << W) - 1ull) << sh;
@@ -698,7 +700,7 @@ __global__ __launch_bounds__(SEQ_BLOCK) void k_append_run(uint64_t* occ, Ctl* ct
     __shared__ RunComm sRun;
     __shared__ RunMemo sMemo;
     __shared__ int64_t sLo[MAX_LEVELS], sHi[MAX_LEVELS];
-    for (int k = threadIdx.x; k < MEMO_ENTRIES; k += SEQ_BLOCK) sMemo.valid[k] = 0;
+    for (int k = threadIdx.x; k < MEMO_WORDS; k += SEQ_BLOCK) sMemo.words[k] = 0ull;      // 0 = entry not computed yet
     Seq S;
     S.keys = nullptr; S.vals = nullptr; S.occ = occ; S.sems = nullptr; S.col_keys = nullptr; S.col_live = nullptr; S.ctl = ctl;
     S.capacity = ctl->capacity; S.seg = ctl->segment_capacity; S.height = ctl->height;
