@@ -101,10 +101,10 @@ __global__ __launch_bounds__(1024) void k_tile_scan(const uint32_t* __restrict__
 }
 
 struct MoveArgs {
-    const int64_t* src_keys; const double* src_vals; const uint64_t* src_occ;
+    KeyArr src_keys; const double* src_vals; const uint64_t* src_occ;
     int64_t src_lo0, src_hi0;      // 0-based inclusive source slot range
     int64_t src_w0;                // first source occupancy word
-    int64_t* dst_keys; double* dst_vals; uint64_t* dst_occ;
+    KeyArr dst_keys; double* dst_vals; uint64_t* dst_occ;
     int64_t dst_lo0;               // 0-based first destination slot (multiple of the window size)
     int64_t Wd, m;
     int64_t* sems;
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(MOVE_BLOCK) void k_move(MoveArgs a) {
                     // unconditional loads (inactive lanes read the word's first slot, inside the allocation)
                     const int64_t s = (word_index << 6) + (act[u] ? lane : 0);
                     const int64_t s_safe = in ? s : a.src_lo0;
-                    kk[u] = __builtin_nontemporal_load(a.src_keys + s_safe);
+                    kk[u] = a.src_keys.ld_nt(s_safe);
                     vv[u] = __builtin_nontemporal_load(a.src_vals + s_safe);
                 }
 #pragma unroll
@@ -231,11 +231,9 @@ __global__ __launch_bounds__(MOVE_BLOCK) void k_move(MoveArgs a) {
                 }
             }
             const int64_t d = a.dst_lo0 + qa - 1;
-            typedef long long ll2v __attribute__((ext_vector_type(2)));
             typedef double d2v __attribute__((ext_vector_type(2)));
-            ll2v kv; kv.x = k2[0]; kv.y = k2[1];
             d2v vv2; vv2.x = v2[0]; vv2.y = v2[1];
-            __builtin_nontemporal_store(kv, reinterpret_cast<ll2v*>(a.dst_keys + d));
+            a.dst_keys.st2_nt(d, k2[0], k2[1]);
             __builtin_nontemporal_store(vv2, reinterpret_cast<d2v*>(a.dst_vals + d));
         }
         const uint64_t be = __ballot(o2[0]);
@@ -253,10 +251,10 @@ __global__ __launch_bounds__(MOVE_BLOCK) void k_move(MoveArgs a) {
 // src/moves.jl:94-110 into a separate buffer).  Serves per-column iteration (DynamicMatrixColView, src/views.jl:15-35)
 // and iteration over a vector (src/pma.jl:165-180): one wave per 4096-slot source tile, lane <-> occupancy word for the
 // prefix, then lane <-> slot with ballot-style popcount ranks; out[tile_off + rank] is a contiguous run per wave.
-__global__ __launch_bounds__(64) void k_compact(const int64_t* __restrict__ keys, const double* __restrict__ vals,
+__global__ __launch_bounds__(64) void k_compact(KeyArr keys, const double* __restrict__ vals,
                                                 const uint64_t* __restrict__ occ, int64_t lo0, int64_t hi0, int64_t w0,
                                                 int64_t nwords, const uint32_t* __restrict__ tile_off,
-                                                int64_t* __restrict__ out_keys, double* __restrict__ out_vals) {
+                                                KeyArr out_keys, double* __restrict__ out_vals) {
     const int lane = threadIdx.x;
     const int64_t t = blockIdx.x;
     const int64_t wl = t * SRC_TILE_WORDS + lane;
@@ -277,8 +275,8 @@ __global__ __launch_bounds__(64) void k_compact(const int64_t* __restrict__ keys
     }
 }
 
-hipError_t launch_compact_range(const int64_t* keys, const double* vals, const uint64_t* occ, int64_t from, int64_t to,
-                                int64_t* out_keys, double* out_vals, int64_t out_cap, RebalanceWork* work, int64_t* count,
+hipError_t launch_compact_range(KeyArr keys, const double* vals, const uint64_t* occ, int64_t from, int64_t to,
+                                KeyArr out_keys, double* out_vals, int64_t out_cap, RebalanceWork* work, int64_t* count,
                                 hipStream_t stream) {
     *count = 0;
     if (to < from) return hipSuccess;
@@ -367,8 +365,8 @@ hipError_t launch_touched_compact(const uint8_t* bytes, const double* pattern, c
 // come from the source array (compaction through LDS as in k_move), ranks > n0 from the batch's op records.
 constexpr int PERM_TILE = 4096;
 struct PermArgs {
-    const int64_t* src_keys; const double* src_vals; const uint64_t* src_occ; int64_t src_words;
-    int64_t* dst_keys; double* dst_vals; const uint64_t* dst_occ; int64_t dst_words;
+    KeyArr src_keys; const double* src_vals; const uint64_t* src_occ; int64_t src_words;
+    KeyArr dst_keys; double* dst_vals; const uint64_t* dst_occ; int64_t dst_words;
     const uint32_t* src_off; int64_t src_tiles;        // exclusive prefix per 4096-slot source tile (k_tile_scan)
     const uint32_t* dst_off; int64_t dst_tiles;
     int64_t n0;                                         // cells that existed before the run
@@ -437,8 +435,8 @@ __global__ __launch_bounds__(256) void k_permute(PermArgs a) {
     }
 }
 
-hipError_t launch_permute(const int64_t* src_keys, const double* src_vals, const uint64_t* src_occ, int64_t src_cap,
-                          int64_t* dst_keys, double* dst_vals, const uint64_t* dst_occ, int64_t dst_cap, int64_t n0,
+hipError_t launch_permute(KeyArr src_keys, const double* src_vals, const uint64_t* src_occ, int64_t src_cap,
+                          KeyArr dst_keys, double* dst_vals, const uint64_t* dst_occ, int64_t dst_cap, int64_t n0,
                           const Op* ops, int64_t i0, int64_t* sems, RebalanceWork* wsrc, RebalanceWork* wdst, hipStream_t stream) {
     PermArgs a;
     a.src_keys = src_keys; a.src_vals = src_vals; a.src_occ = src_occ; a.src_words = (src_cap + 63) / 64;
@@ -479,9 +477,9 @@ hipError_t launch_clear_occ(uint64_t* occ, int64_t from, int64_t to, hipStream_t
     return hipGetLastError();
 }
 
-hipError_t launch_rebalance(const int64_t* src_keys, const double* src_vals, const uint64_t* src_occ,
+hipError_t launch_rebalance(KeyArr src_keys, const double* src_vals, const uint64_t* src_occ,
                             int64_t src_ws, int64_t src_we, bool src_packed,
-                            int64_t* dst_keys, double* dst_vals, uint64_t* dst_occ,
+                            KeyArr dst_keys, double* dst_vals, uint64_t* dst_occ,
                             int64_t dst_ws, int64_t dst_we, int64_t m, int64_t* sems,
                             RebalanceWork* work, hipStream_t stream) {
     MoveArgs a;
