@@ -62,7 +62,7 @@ struct Pma {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     void* keys[2] = {nullptr, nullptr};      // physical key arrays: int32_t unless `wide` (KeyArr, dsa_dev.h)
-    bool wide = true;
+    bool wide = false;
     double* vals[2] = {nullptr, nullptr};
     uint64_t* occ[2] = {nullptr, nullptr};
     int cur = 0;
@@ -153,6 +153,11 @@ void download_keys(Pma& P, int64_t* dst, const void* src, int64_t n) {      // s
     HIPCHK(hipMemcpyAsync(tmp.data(), src, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, P.stream));
     HIPCHK(hipStreamSynchronize(P.stream));
     for (int64_t i = 0; i < n; ++i) dst[i] = (int64_t)tmp[(size_t)i];
+}
+
+bool keys_fit32(const int64_t* k, int64_t n) {
+    for (int64_t i = 0; i < n; ++i) if (!key_fits32(k[i])) return false;
+    return true;
 }
 
 int64_t occ_words_for(int64_t slots) {
@@ -320,6 +325,7 @@ void window_rebalance(Pma& P, int64_t ws, int64_t we, int64_t m) {
 // cell stream; n == 0 -> PackedMemoryArray(K, T) (capacity for 100 expected cells)  src/pma.jl:86-91
 void build_from_packed(Pma& P, const std::vector<int64_t>& keys, const std::vector<double>& vals) {
     const int64_t n = (int64_t)keys.size();
+    if (P.cap_alloc == 0) P.wide = !keys_fit32(keys.data(), n);
     const int64_t capacity = capacity_for(n == 0 ? 100 : n);
     set_geometry_for_new(P, capacity, n);
     ensure_capacity_alloc(P, 2 * capacity);
@@ -371,6 +377,27 @@ const char* err_text(int32_t e) {
     }
 }
 
+// First key outside Int32: both slot buffers are re-allocated with 64-bit keys, the current one converted on the device.
+// (The alternate buffer holds no live data between operations.)
+void widen_keys(Pma& P) {
+    if (P.wide) return;
+    HIPCHK(hipStreamSynchronize(P.stream));
+    void* old[2] = {P.keys[0], P.keys[1]};
+    for (int b = 0; b < 2; ++b) { P.keys[b] = nullptr; if (P.cap_alloc > 0) HIPCHK(hipMalloc(&P.keys[b], (size_t)P.cap_alloc * sizeof(int64_t))); }
+    if (P.cap_alloc > 0 && old[P.cur] != nullptr) {
+        hipError_t e = launch_widen_keys(old[P.cur], P.keys[P.cur], P.cap_alloc, P.stream);
+        if (e != hipSuccess) fail(DSA_EHIP, std::string("widen launch: ") + hipGetErrorString(e));
+        HIPCHK(hipStreamSynchronize(P.stream));
+    }
+    for (int b = 0; b < 2; ++b) if (old[b]) hipFree(old[b]);
+    P.wide = true;
+}
+void ensure_key_width(Pma& P, const std::vector<Op>& ops) {
+    if (P.wide) return;
+    for (const Op& o : ops)
+        if ((o.kind == OP_VEC_SET || o.kind == OP_PCSC_SET || o.kind == OP_MPCSC_SET) && !key_fits32(o.a)) { widen_keys(P); return; }
+}
+
 // ---- the yield loop around the device sequencer, as a resumable state machine so that the two orientations of a
 // matrix can run their sequencers concurrently on their own streams ------------------------------------------------
 struct SeqRun {
@@ -399,6 +426,7 @@ void seq_start(SeqRun& r, Pma& P, const std::vector<Op>& ops) {
     r = SeqRun();
     r.P = &P; r.ops = &ops; r.n = (int64_t)ops.size();
     if (r.n == 0) return;
+    ensure_key_width(P, ops);
     ensure_ops(P, r.n);
     HIPCHK(hipMemcpyAsync(P.d_ops, ops.data(), (size_t)r.n * sizeof(Op), hipMemcpyHostToDevice, P.stream));
     P.h_ctl->next_op = 0; P.h_ctl->status = 0; P.h_ctl->err = 0; P.h_ctl->no_run_at = -1;
@@ -499,6 +527,7 @@ int64_t run_ops_parallel(Pma& P, const std::vector<Op>& ops, int32_t* err) {
     const int64_t n = (int64_t)ops.size();
     if (n == 0) return 0;
     constexpr int GMAX = 1024, MIN_PREFIX = 4, ROUNDS_PER_SYNC = 12;
+    ensure_key_width(P, ops);
     ensure_ops(P, n);
     HIPCHK(hipMemcpyAsync(P.d_ops, ops.data(), (size_t)n * sizeof(Op), hipMemcpyHostToDevice, P.stream));
     if (!P.d_plans) {
@@ -684,7 +713,8 @@ void read_range(Pma& P, int64_t from, int64_t to, std::vector<int64_t>& ks, std:
 //   mode 1: a vector (d_part == nullptr, no semaphores)         dynamicsparsevec  src/vector.jl:38-62
 //   mode 2: PackedCSC with explicit partition ids 1..nparts      PackedCSC ctor    src/pcsr.jl:26-63
 void pma_build_dev(Pma& P, const int64_t* d_part, const int64_t* d_key, const double* d_val, int64_t nnz, int32_t combine,
-                   int mode, int64_t nparts_explicit) {
+                   int mode, int64_t nparts_explicit, bool wide) {
+    P.wide = wide;                     // decided by the caller from the host copy of the keys, before anything is allocated
     if (nnz == 0) {
         std::vector<int64_t> ks; std::vector<double> vs;
         const int64_t np = mode == 2 ? nparts_explicit : 0;
@@ -738,7 +768,7 @@ void pma_build_from_host(Pma& P, const int64_t* part, const int64_t* key, const 
             HIPCHK(hipMalloc(&dV, (size_t)nnz * 8)); HIPCHK(hipMemcpyAsync(dV, val, (size_t)nnz * 8, hipMemcpyHostToDevice, P.stream));
             HIPCHK(hipStreamSynchronize(P.stream));
         }
-        pma_build_dev(P, dP, dK, dV, nnz, combine, mode, nparts_explicit);
+        pma_build_dev(P, dP, dK, dV, nnz, combine, mode, nparts_explicit, !keys_fit32(key, nnz));
     } catch (...) {
         if (dP) hipFree(dP);
         if (dK) hipFree(dK);
@@ -799,9 +829,9 @@ void mat_build_major(dsa_mat* h, const int64_t* I, const int64_t* J, const doubl
         }
         static const bool dbg_time = getenv("DSA_DBG_TIME") != nullptr;
         const auto tb0 = std::chrono::steady_clock::now();
-        pma_build_dev(h->col, dJ, dI, dV, nnz, DSA_COMBINE_ADD, 0, 0);      // dynamicsparsecolmajor(I, J, V): partitions = columns
+        pma_build_dev(h->col, dJ, dI, dV, nnz, DSA_COMBINE_ADD, 0, 0, !keys_fit32(I, nnz));      // dynamicsparsecolmajor(I, J, V): partitions = columns
         const auto tb1 = std::chrono::steady_clock::now();
-        pma_build_dev(h->row, dI, dJ, dV, nnz, DSA_COMBINE_ADD, 0, 0);      // dynamicsparsecolmajor(J, I, V): partitions = rows
+        pma_build_dev(h->row, dI, dJ, dV, nnz, DSA_COMBINE_ADD, 0, 0, !keys_fit32(J, nnz));      // dynamicsparsecolmajor(J, I, V): partitions = rows
         if (dbg_time)
             fprintf(stderr, "[mat_build_major] nnz=%lld upload %.1f ms  colmajor %.1f ms  rowmajor %.1f ms\n", (long long)nnz,
                     std::chrono::duration<double, std::milli>(tb0 - tup0).count(), std::chrono::duration<double, std::milli>(tb1 - tb0).count(),

@@ -18,6 +18,7 @@
 //                  whole — is stored as 16-byte key / value pairs, the occupancy words are rebuilt
 //                  from two ballots, and semaphore positions are scattered to the table.
 #include "dsa_dev.h"
+#include <algorithm>
 #include <cstdlib>
 
 namespace dsa {
@@ -460,6 +461,17 @@ hipError_t launch_permute(KeyArr src_keys, const double* src_vals, const uint64_
         configured = true;
     }
     hipLaunchKernelGGL(k_permute, dim3((unsigned)a.dst_tiles), dim3(256), lds, stream, a);
+    return hipGetLastError();
+}
+
+// int32 -> int64 key array (the structure receives its first key outside Int32)
+__global__ void k_widen_keys(const int32_t* __restrict__ src, int64_t* __restrict__ dst, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = (int64_t)src[i];
+}
+hipError_t launch_widen_keys(const void* src32, void* dst64, int64_t n, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    const int blocks = (int)std::min<int64_t>((n + 255) / 256, 4096);
+    hipLaunchKernelGGL(k_widen_keys, dim3(blocks), dim3(256), 0, stream, (const int32_t*)src32, (int64_t*)dst64, n);
     return hipGetLastError();
 }
 
