@@ -20,6 +20,7 @@
 #include "dsa_dev.h"
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 namespace dsa {
 
@@ -114,9 +115,12 @@ struct MoveArgs {
     int dbg;   // DSA_DBG_MOVE ablation knob (dev only): 1 = skip staging, 2 = skip the write phase
 };
 
-template <bool PACKED>
+template <bool PACKED, bool WIDE>
 __global__ __launch_bounds__(MOVE_BLOCK) void k_move(MoveArgs a) {
-    __shared__ int64_t sK[DST_TILE];
+    typedef typename std::conditional<WIDE, int64_t, int32_t>::type key_t;
+    const key_t* __restrict__ srck = static_cast<const key_t*>(a.src_keys.p);
+    key_t* __restrict__ dstk = static_cast<key_t*>(a.dst_keys.p);
+    __shared__ key_t sK[DST_TILE];
     __shared__ double sV[DST_TILE];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const SpreadGeom g = make_geom(a.Wd, a.m);
@@ -175,7 +179,7 @@ __global__ __launch_bounds__(MOVE_BLOCK) void k_move(MoveArgs a) {
             // empty words in front of the range are counted in `before`; words [before, notafter) may intersect
 #pragma unroll 1
             for (int jb = before + wv * 4; jb < notafter; jb += MOVE_BLOCK / 64 * 4) {
-                int64_t kk[4]; double vv[4]; int rk[4]; bool act[4];
+                key_t kk[4]; double vv[4]; int rk[4]; bool act[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int j = jb + u;
@@ -188,7 +192,7 @@ __global__ __launch_bounds__(MOVE_BLOCK) void k_move(MoveArgs a) {
                     // unconditional loads (inactive lanes read the word's first slot, inside the allocation)
                     const int64_t s = (word_index << 6) + (act[u] ? lane : 0);
                     const int64_t s_safe = in ? s : a.src_lo0;
-                    kk[u] = a.src_keys.ld_nt(s_safe);
+                    kk[u] = __builtin_nontemporal_load(srck + s_safe);
                     vv[u] = __builtin_nontemporal_load(a.src_vals + s_safe);
                 }
 #pragma unroll
@@ -208,7 +212,7 @@ __global__ __launch_bounds__(MOVE_BLOCK) void k_move(MoveArgs a) {
         const int64_t gq = q0 + (int64_t)wv * PER_WAVE + it * 128;   // 0-based offset of the 128-slot group
         if (gq >= a.Wd) break;                                        // wave-uniform
         const int64_t qa = gq + 2 * lane + 1;                         // 1-based offsets qa, qa+1
-        int64_t k2[2] = {0, 0};
+        key_t k2[2] = {0, 0};
         double v2[2] = {0.0, 0.0};
         bool o2[2] = {false, false};
         if (qa <= a.Wd) {
@@ -222,7 +226,7 @@ __global__ __launch_bounds__(MOVE_BLOCK) void k_move(MoveArgs a) {
                 if (!gap) {
                     o2[j] = true;
                     if (PACKED) {
-                        k2[j] = a.src_keys[a.src_lo0 + rank - 1];
+                        k2[j] = srck[a.src_lo0 + rank - 1];
                         v2[j] = a.src_vals[a.src_lo0 + rank - 1];
                     } else {
                         k2[j] = sK[rank - R0 - 1];
@@ -234,7 +238,9 @@ __global__ __launch_bounds__(MOVE_BLOCK) void k_move(MoveArgs a) {
             const int64_t d = a.dst_lo0 + qa - 1;
             typedef double d2v __attribute__((ext_vector_type(2)));
             d2v vv2; vv2.x = v2[0]; vv2.y = v2[1];
-            a.dst_keys.st2_nt(d, k2[0], k2[1]);
+            typedef key_t k2v __attribute__((ext_vector_type(2)));
+            k2v kv; kv.x = k2[0]; kv.y = k2[1];
+            __builtin_nontemporal_store(kv, reinterpret_cast<k2v*>(dstk + d));
             __builtin_nontemporal_store(vv2, reinterpret_cast<d2v*>(a.dst_vals + d));
         }
         const uint64_t be = __ballot(o2[0]);
@@ -506,7 +512,8 @@ hipError_t launch_rebalance(KeyArr src_keys, const double* src_vals, const uint6
     { static const char* e = getenv("DSA_DBG_MOVE"); a.dbg = e ? atoi(e) : 0; }
     const int64_t ndst = (a.Wd + DST_TILE - 1) / DST_TILE;
     if (src_packed) {
-        hipLaunchKernelGGL(k_move<true>, dim3((unsigned)ndst), dim3(MOVE_BLOCK), 0, stream, a);
+        if (a.src_keys.wide) hipLaunchKernelGGL((k_move<true, true>), dim3((unsigned)ndst), dim3(MOVE_BLOCK), 0, stream, a);
+        else hipLaunchKernelGGL((k_move<true, false>), dim3((unsigned)ndst), dim3(MOVE_BLOCK), 0, stream, a);
         return hipGetLastError();
     }
     const int64_t nwords = (a.src_hi0 >> 6) - a.src_w0 + 1;
@@ -518,7 +525,8 @@ hipError_t launch_rebalance(KeyArr src_keys, const double* src_vals, const uint6
     hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, stream, work->tile_cnt, work->tile_off, ntiles);
     a.tile_off = work->tile_off; a.ntiles = ntiles;
     a.tiles_per_cell = m > 0 ? (double)ntiles / (double)m : 0.0;
-    hipLaunchKernelGGL(k_move<false>, dim3((unsigned)ndst), dim3(MOVE_BLOCK), 0, stream, a);
+    if (a.src_keys.wide) hipLaunchKernelGGL((k_move<false, true>), dim3((unsigned)ndst), dim3(MOVE_BLOCK), 0, stream, a);
+    else hipLaunchKernelGGL((k_move<false, false>), dim3((unsigned)ndst), dim3(MOVE_BLOCK), 0, stream, a);
     return hipGetLastError();
 }
 

@@ -15,6 +15,7 @@
 // Bound: HBM / fabric.  Algorithmic bytes per launch = 16*capacity + 8*nx + 8*ny: the flat
 // scan streams every slot (gaps included — they are part of the bit-identical layout) once.
 #include "dsa_dev.h"
+#include <type_traits>
 
 namespace dsa {
 
@@ -186,12 +187,15 @@ __device__ __forceinline__ double product_of(double v, double xv, bool count_pas
     return count_pass ? (xv != 0.0 ? 1.0 : 0.0) : v * xv;
 }
 
+template <bool WIDE>
 __global__ __launch_bounds__(SP_BLOCK) void k_spmv_gather(KeyArr keys, const double* __restrict__ vals,
                                                           const uint64_t* __restrict__ occ, int64_t capacity,
                                                           const int64_t* __restrict__ sems,
                                                           const int64_t* __restrict__ part_keys, int64_t table_len,
                                                           const double* __restrict__ x, int64_t nx,
                                                           double* __restrict__ y, int64_t ny, int pattern) {
+    typedef typename std::conditional<WIDE, int64_t, int32_t>::type key_t;      // physical key width, fixed at compile time for the streams
+    const key_t* __restrict__ kp = static_cast<const key_t*>(keys.p);
     __shared__ double sPw[SP_WAVES][SW_SLOTS];
     __shared__ uint16_t sListw[SP_WAVES][SW_SLOTS];
     const int lane = threadIdx.x & 63;
@@ -218,13 +222,13 @@ __global__ __launch_bounds__(SP_BLOCK) void k_spmv_gather(KeyArr keys, const dou
 #pragma unroll
     for (int j = 0; j <= SW_WORDS; ++j) {
         const int64_t w = w0 + j < nwords ? w0 + j : nwords - 1;
-        k[j] = keys.ld_nt((w << 6) + lane);
+        k[j] = (int64_t)__builtin_nontemporal_load(kp + (w << 6) + lane);
         v[j] = __builtin_nontemporal_load(vals + (w << 6) + lane);
     }
     // the word in front: does the previous span own the cells before our first semaphore?
     const int64_t pw = w0 > 0 ? w0 - 1 : 0;
     const uint64_t pword = w0 > 0 ? occ[pw] : 0ull;
-    const int64_t pk = keys[(pw << 6) + lane];
+    const int64_t pk = (int64_t)kp[(pw << 6) + lane];
 
     // ---- semaphore ballots, one gather per lane and word -----------------------------------------------------------------
     uint64_t sb[SW_WORDS + 1], cm[SW_WORDS + 1];
@@ -452,8 +456,11 @@ static hipError_t launch_spmv(bool scatter, int pattern, KeyArr keys, const doub
     if (scatter)
         hipLaunchKernelGGL(k_spmv_scatter, dim3((unsigned)grid), dim3(SP_BLOCK), 0, stream, keys, vals, occ, capacity, sems,
                            part_keys, table_len, x, nx, y, ny, 0);
+    else if (keys.wide)
+        hipLaunchKernelGGL(k_spmv_gather<true>, dim3((unsigned)grid), dim3(SP_BLOCK), 0, stream, keys, vals, occ, capacity, sems,
+                           part_keys, table_len, x, nx, y, ny, pattern);
     else
-        hipLaunchKernelGGL(k_spmv_gather, dim3((unsigned)grid), dim3(SP_BLOCK), 0, stream, keys, vals, occ, capacity, sems,
+        hipLaunchKernelGGL(k_spmv_gather<false>, dim3((unsigned)grid), dim3(SP_BLOCK), 0, stream, keys, vals, occ, capacity, sems,
                            part_keys, table_len, x, nx, y, ny, pattern);
     return hipGetLastError();
 }
