@@ -155,7 +155,10 @@ void download_keys(Pma& P, int64_t* dst, const void* src, int64_t n) {      // s
     for (int64_t i = 0; i < n; ++i) dst[i] = (int64_t)tmp[(size_t)i];
 }
 
+// dev knob: DSA_KEYS_WIDE=1 keeps every structure in 64-bit keys (A/B measurements, coverage of the wide kernels)
+const bool g_force_wide = [] { const char* e = getenv("DSA_KEYS_WIDE"); return e && e[0] == '1'; }();
 bool keys_fit32(const int64_t* k, int64_t n) {
+    if (g_force_wide) return false;
     for (int64_t i = 0; i < n; ++i) if (!key_fits32(k[i])) return false;
     return true;
 }
