@@ -44,7 +44,7 @@ __global__ void k_flags(const int64_t* __restrict__ part, const int64_t* __restr
 __global__ void k_emit(const int64_t* __restrict__ part, const int64_t* __restrict__ key, const uint32_t* __restrict__ idx,
                        const double* __restrict__ val, const uint32_t* __restrict__ fpart, const uint32_t* __restrict__ fcell,
                        const uint32_t* __restrict__ spart, const uint32_t* __restrict__ scell, int64_t n, int32_t combine,
-                       int64_t* __restrict__ out_keys, double* __restrict__ out_vals, int64_t* __restrict__ part_keys,
+                       KeyArr out_keys, double* __restrict__ out_vals, int64_t* __restrict__ part_keys,
                        int mode) {
     // mode 0: mapped partitions (ids = rank of the distinct partition keys, semaphore emitted by the first cell)
     // mode 1: plain vector (no semaphores)   mode 2: explicit partition ids 1..P in `part` (semaphores by k_emit_sems)
@@ -71,7 +71,7 @@ __global__ void k_emit(const int64_t* __restrict__ part, const int64_t* __restri
 // mode 2: semaphore cell of every partition p = 1..P (empty partitions included, src/pcsr.jl:36-41):
 // position = (#distinct cells of partitions < p) + p - 1
 __global__ void k_emit_sems(const int64_t* __restrict__ part_sorted, const uint32_t* __restrict__ scell, int64_t n, int64_t nparts,
-                            int64_t* __restrict__ out_keys, double* __restrict__ out_vals) {
+                            KeyArr out_keys, double* __restrict__ out_vals) {
     const int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x + 1;
     if (p > nparts) return;
     int64_t lo = 0, hi = n;                     // first index with part >= p
@@ -135,7 +135,7 @@ hipError_t build_prepare(const int64_t* d_part, const int64_t* d_key, int64_t nn
     return hipGetLastError();
 }
 
-hipError_t build_emit(const double* d_val, int32_t combine, BuildScratch& s, int64_t* out_keys, double* out_vals,
+hipError_t build_emit(const double* d_val, int32_t combine, BuildScratch& s, KeyArr out_keys, double* out_vals,
                       int64_t* part_keys, int mode, int64_t nparts_explicit, hipStream_t stream) {
     const unsigned blocks = (unsigned)((s.n + 255) / 256);
     hipLaunchKernelGGL(k_emit, dim3(blocks), dim3(256), 0, stream, mode == 1 ? (const int64_t*)nullptr : s.p2, s.k2, s.idx2, d_val,

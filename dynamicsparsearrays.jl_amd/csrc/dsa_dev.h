@@ -19,6 +19,52 @@ constexpr int WAVE = 64;
 constexpr int64_t SEM_KEY = 0;            // semaphore_key(::Type{<:Integer})  src/pcsr.jl:23
 constexpr int MAX_LEVELS = 48;
 
+// ---- physical key storage ---------------------------------------------------------------------------
+// K = Int64 at the API; in HBM a slot array keeps its keys in 32 bits as long as every key ever written fits Int32
+// (row / column indices practically always do) and is widened once, by the host, before the first key that does not
+// (`wide`).  25 % fewer bytes for every kernel that streams slots (rebalance, SpMV, K-permute, K-build).  Kernels
+// receive the array by value; keys[i] reads / writes through a proxy, the streaming kernels use the typed loads below.
+struct KeyArr {
+    void* p;
+    int32_t wide;          // 0: int32_t keys, 1: int64_t keys
+    int32_t pad_;
+#if defined(__HIPCC__)
+    struct Ref {
+        void* p; int32_t wide; int64_t i;
+        __device__ __forceinline__ operator int64_t() const {
+            return wide ? static_cast<const int64_t*>(p)[i] : (int64_t) static_cast<const int32_t*>(p)[i];
+        }
+        __device__ __forceinline__ void operator=(int64_t k) const {
+            if (wide) static_cast<int64_t*>(p)[i] = k; else static_cast<int32_t*>(p)[i] = (int32_t)k;
+        }
+        __device__ __forceinline__ void operator=(const Ref& o) const { *this = (int64_t)o; }
+    };
+    __device__ __forceinline__ Ref operator[](int64_t i) const { return Ref{p, wide, i}; }
+    __device__ __forceinline__ int64_t ld(int64_t i) const { return (int64_t)(*this)[i]; }
+    __device__ __forceinline__ int64_t ld_nt(int64_t i) const {            // streamed once
+        return wide ? __builtin_nontemporal_load(static_cast<const int64_t*>(p) + i)
+                    : (int64_t)__builtin_nontemporal_load(static_cast<const int32_t*>(p) + i);
+    }
+    __device__ __forceinline__ int64_t ld_agent(int64_t i) const {         // L2-served (cells just written by this launch)
+        return wide ? __hip_atomic_load(static_cast<const int64_t*>(p) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                    : (int64_t)__hip_atomic_load(static_cast<const int32_t*>(p) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // two adjacent keys (i even), non-temporal: one 16-byte / 8-byte store
+    __device__ __forceinline__ void st2_nt(int64_t i, int64_t k0, int64_t k1) const {
+        if (wide) {
+            typedef long long ll2v __attribute__((ext_vector_type(2)));
+            ll2v kv; kv.x = k0; kv.y = k1;
+            __builtin_nontemporal_store(kv, reinterpret_cast<ll2v*>(static_cast<int64_t*>(p) + i));
+        } else {
+            typedef int i2v __attribute__((ext_vector_type(2)));
+            i2v kv; kv.x = (int)k0; kv.y = (int)k1;
+            __builtin_nontemporal_store(kv, reinterpret_cast<i2v*>(static_cast<int32_t*>(p) + i));
+        }
+    }
+#endif
+};
+static inline bool key_fits32(int64_t k) { return k >= INT32_MIN && k <= INT32_MAX; }
+
 // ---- control block shared by host and the sequencer kernel (one per PMA) ----------------------
 enum SeqStatus : int32_t {
     SEQ_DONE = 0,
@@ -164,25 +210,26 @@ struct RebalanceWork {   // scratch owned by a PMA for the big pack+spread
 // gathers the m occupied cells of src[src_ws..src_we] (in order) and spreads them over
 // dst[dst_ws..dst_we]; writes every dst slot, the dst occupancy words and, if sems != nullptr,
 // semaphores[id] for every cell with key == 0.  src_packed: the cells are src slots src_ws..src_ws+m-1.
-hipError_t launch_rebalance(const int64_t* src_keys, const double* src_vals, const uint64_t* src_occ,
+hipError_t launch_rebalance(KeyArr src_keys, const double* src_vals, const uint64_t* src_occ,
                             int64_t src_ws, int64_t src_we, bool src_packed,
-                            int64_t* dst_keys, double* dst_vals, uint64_t* dst_occ,
+                            KeyArr dst_keys, double* dst_vals, uint64_t* dst_occ,
                             int64_t dst_ws, int64_t dst_we, int64_t m, int64_t* sems,
                             RebalanceWork* work, hipStream_t stream);
 // K-permute: order-preserving move of the n0 cells of (src, src_occ) followed by the cells of ops[i0..] to the set bits of
 // dst_occ (already final), writing dst keys / vals and, if sems != nullptr, the semaphore table
-hipError_t launch_permute(const int64_t* src_keys, const double* src_vals, const uint64_t* src_occ, int64_t src_cap,
-                          int64_t* dst_keys, double* dst_vals, const uint64_t* dst_occ, int64_t dst_cap, int64_t n0,
+hipError_t launch_permute(KeyArr src_keys, const double* src_vals, const uint64_t* src_occ, int64_t src_cap,
+                          KeyArr dst_keys, double* dst_vals, const uint64_t* dst_occ, int64_t dst_cap, int64_t n0,
                           const Op* ops, int64_t i0, int64_t* sems, RebalanceWork* wsrc, RebalanceWork* wdst, hipStream_t stream);
 // K-pack: occupied cells of slots [from, to] (1-based, inclusive), in slot order, to dense device buffers of capacity out_cap;
 // *count (host) receives the number of cells.  Synchronises the stream once (count needed to size the copy-out).
-hipError_t launch_compact_range(const int64_t* keys, const double* vals, const uint64_t* occ, int64_t from, int64_t to,
-                                int64_t* out_keys, double* out_vals, int64_t out_cap, RebalanceWork* work, int64_t* count,
+hipError_t launch_compact_range(KeyArr keys, const double* vals, const uint64_t* occ, int64_t from, int64_t to,
+                                KeyArr out_keys, double* out_vals, int64_t out_cap, RebalanceWork* work, int64_t* count,
                                 hipStream_t stream);
 // sparse-x SpMV result: touched flags (bytes, or the doubles of a pattern pass) -> (row, y[row]) pairs in ascending row order
 hipError_t launch_touched_compact(const uint8_t* bytes, const double* pattern, const double* y, int64_t ny, uint64_t* bm,
                                   int64_t* out_i, double* out_v, RebalanceWork* work, int64_t* count, hipStream_t stream);
 hipError_t launch_scatter_x(const int64_t* xi, const double* xv, int64_t nx, double* xd, double* xf, int64_t nxd, hipStream_t stream);
+hipError_t launch_widen_keys(const void* src32, void* dst64, int64_t n, hipStream_t stream);
 // clears occupancy bits of slots [from, to] (1-based, inclusive); from/to word-aligned or inside one word
 hipError_t launch_clear_occ(uint64_t* occ, int64_t from, int64_t to, hipStream_t stream);
 
@@ -199,12 +246,12 @@ hipError_t build_prepare(const int64_t* d_part, const int64_t* d_key, int64_t nn
 // phase 2: emit the ordered cell stream [sem(0,id), entries...] (counts[0]+counts[1] cells) and the partition keys
 // mode 0: mapped partitions (semaphores + partition keys) ; 1: plain vector (d_part was nullptr) ; 2: explicit partition
 // ids 1..nparts_explicit in d_part (PackedCSC: empty partitions keep their semaphore)
-hipError_t build_emit(const double* d_val, int32_t combine, BuildScratch& s, int64_t* out_keys, double* out_vals,
+hipError_t build_emit(const double* d_val, int32_t combine, BuildScratch& s, KeyArr out_keys, double* out_vals,
                       int64_t* part_keys, int mode, int64_t nparts_explicit, hipStream_t stream);
 void build_abort(BuildScratch& s);
 
 // n_avail >= n_ops: ops resident behind the chunk (an append run may consume them); run_ok enables append-run detection
-hipError_t launch_sequencer(int64_t* keys, double* vals, uint64_t* occ, int64_t* sems, int64_t* col_keys,
+hipError_t launch_sequencer(KeyArr keys, double* vals, uint64_t* occ, int64_t* sems, int64_t* col_keys,
                             uint8_t* col_live, Ctl* ctl, const Op* ops, int64_t n_ops, int64_t n_avail, bool run_ok,
                             hipStream_t stream);
 // flags / d_T: cell types and cell count written by k_run_expand (MappedPackedCSC runs), nullptr for a vector run
@@ -238,41 +285,41 @@ struct BurstGraph {        // cached hipGraph of one burst of rounds (host-side)
     const void* key[12] = {};
     bool disabled = false;
 };
-hipError_t launch_burst(int64_t* keys, double* vals, uint64_t* occ, int64_t* sems, int64_t* col_keys, uint8_t* col_live,
+hipError_t launch_burst(KeyArr keys, double* vals, uint64_t* occ, int64_t* sems, int64_t* col_keys, uint8_t* col_live,
                         Ctl* ctl, const Op* ops, RoundState* rs, Plan* plans, uint32_t* flags, int rounds, BurstGraph* cache,
                         hipStream_t stream);
 void burst_graph_destroy(BurstGraph* cache);
 
 // batched read-only lookups.  mode 0: getindex(pma, key) ; 1: getindex(pcsc, key, partition) ;
 // 2: getindex(mpcsc, row, col).  err_out: first error code (0 if none)
-hipError_t launch_get_batch(int mode, const int64_t* keys, const double* vals, const uint64_t* occ, int64_t capacity,
+hipError_t launch_get_batch(int mode, KeyArr keys, const double* vals, const uint64_t* occ, int64_t capacity,
                             const int64_t* sems, const int64_t* col_keys, const uint8_t* col_live, int64_t table_len,
                             const int64_t* qa, const int64_t* qb, int64_t n, double* out, int32_t* err_out,
                             hipStream_t stream);
 // device-side invariant checker; report[0..5] as documented at k_check_slots (8 x uint64 device scratch)
-hipError_t launch_check(const int64_t* keys, const double* vals, const uint64_t* occ, int64_t capacity, int64_t occ_words,
+hipError_t launch_check(KeyArr keys, const double* vals, const uint64_t* occ, int64_t capacity, int64_t occ_words,
                         const int64_t* sems, const int64_t* col_keys, const uint8_t* col_live, int64_t table_len,
                         unsigned long long* report, hipStream_t stream);
 // view of one partition in one launch (ranges up to 16384 slots): meta = {from, to, err, partition id, cells or -1 = use the general path}
-hipError_t launch_view_small(const int64_t* keys, const double* vals, const uint64_t* occ, const int64_t* sems, const int64_t* col_keys,
-                             const uint8_t* col_live, int64_t table_len, int64_t capacity, int64_t col, int64_t* out_k, double* out_v,
+hipError_t launch_view_small(KeyArr keys, const double* vals, const uint64_t* occ, const int64_t* sems, const int64_t* col_keys,
+                             const uint8_t* col_live, int64_t table_len, int64_t capacity, int64_t col, KeyArr out_k, double* out_v,
                              int64_t out_cap, int64_t* meta, hipStream_t stream);
 // partition slot range lookup for views: out[0] = from (first slot after the semaphore), out[1] = to, or 0,0 if missing
 hipError_t launch_partition_range(const int64_t* sems, const int64_t* col_keys, const uint8_t* col_live,
                                   int64_t table_len, int64_t capacity, int64_t col, int64_t* out, hipStream_t stream);
 
 // y = P x over one orientation P, gather form: y[part_key[p]] = sum over partition p of val * x[key]
-hipError_t launch_spmv_gather(const int64_t* keys, const double* vals, const uint64_t* occ, int64_t capacity,
+hipError_t launch_spmv_gather(KeyArr keys, const double* vals, const uint64_t* occ, int64_t capacity,
                               const int64_t* sems, const int64_t* part_keys, const uint8_t* part_live, int64_t table_len,
                               const double* x, int64_t nx, double* y, int64_t ny, int pattern, hipStream_t stream);
 // y[key] += x[part_key[p]] * val, scatter form with fp64 atomics (the literal _mul loop nest)
-hipError_t launch_spmv_scatter(const int64_t* keys, const double* vals, const uint64_t* occ, int64_t capacity,
+hipError_t launch_spmv_scatter(KeyArr keys, const double* vals, const uint64_t* occ, int64_t capacity,
                                const int64_t* sems, const int64_t* part_keys, const uint8_t* part_live, int64_t table_len,
                                const double* x, int64_t nx, double* y, int64_t ny, hipStream_t stream);
 
 // sparse x driven by its stored entries over the orientation whose partitions are x's index space (colmajor for mat*v):
 // y (dense, zeroed here) += x_j * column j ; touched[row] = 1 for every row that received a term
-hipError_t launch_spmv_xdriven(const int64_t* keys, const double* vals, const uint64_t* occ, int64_t capacity,
+hipError_t launch_spmv_xdriven(KeyArr keys, const double* vals, const uint64_t* occ, int64_t capacity,
                                const int64_t* sems, const int64_t* col_keys, const uint8_t* col_live, int64_t table_len,
                                const int64_t* xi, const double* xv, int64_t nx, double* y, uint8_t* touched, int64_t ny,
                                hipStream_t stream);

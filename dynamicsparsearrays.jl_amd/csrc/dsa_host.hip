@@ -61,7 +61,8 @@ int64_t capacity_for(int64_t n) {
 struct Pma {
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    int64_t* keys[2] = {nullptr, nullptr};
+    void* keys[2] = {nullptr, nullptr};      // physical key arrays: int32_t unless `wide` (KeyArr, dsa_dev.h)
+    bool wide = false;
     double* vals[2] = {nullptr, nullptr};
     uint64_t* occ[2] = {nullptr, nullptr};
     int cur = 0;
@@ -88,7 +89,9 @@ struct Pma {
     double t_h = 0.7, t_0 = 0.92, p_h = 0.3, p_0 = 0.08, t_d = 0.0, p_d = 0.0;
 
     int64_t capacity() const { return h_ctl->capacity; }
-    int64_t* K() const { return keys[cur]; }
+    KeyArr K() const { return KeyArr{keys[cur], wide ? 1 : 0, 0}; }
+    KeyArr KA(int b) const { return KeyArr{keys[b], wide ? 1 : 0, 0}; }
+    size_t kb() const { return wide ? sizeof(int64_t) : sizeof(int32_t); }
     double* V() const { return vals[cur]; }
     uint64_t* O() const { return occ[cur]; }
 };
@@ -134,13 +137,39 @@ void pma_destroy(Pma& P) {
     P = Pma();
 }
 
+// keys cross the host boundary as int64_t; the device array is int32_t unless the structure is wide
+void upload_keys(Pma& P, void* dst, const int64_t* src, int64_t n) {
+    if (n <= 0) return;
+    if (P.wide) { HIPCHK(hipMemcpyAsync(dst, src, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, P.stream)); HIPCHK(hipStreamSynchronize(P.stream)); return; }
+    std::vector<int32_t> tmp((size_t)n);
+    for (int64_t i = 0; i < n; ++i) tmp[(size_t)i] = (int32_t)src[i];
+    HIPCHK(hipMemcpyAsync(dst, tmp.data(), (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, P.stream));
+    HIPCHK(hipStreamSynchronize(P.stream));
+}
+void download_keys(Pma& P, int64_t* dst, const void* src, int64_t n) {      // synchronises the stream
+    if (n <= 0) { HIPCHK(hipStreamSynchronize(P.stream)); return; }
+    if (P.wide) { HIPCHK(hipMemcpyAsync(dst, src, (size_t)n * sizeof(int64_t), hipMemcpyDeviceToHost, P.stream)); HIPCHK(hipStreamSynchronize(P.stream)); return; }
+    std::vector<int32_t> tmp((size_t)n);
+    HIPCHK(hipMemcpyAsync(tmp.data(), src, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, P.stream));
+    HIPCHK(hipStreamSynchronize(P.stream));
+    for (int64_t i = 0; i < n; ++i) dst[i] = (int64_t)tmp[(size_t)i];
+}
+
+// dev knob: DSA_KEYS_WIDE=1 keeps every structure in 64-bit keys (A/B measurements, coverage of the wide kernels)
+const bool g_force_wide = [] { const char* e = getenv("DSA_KEYS_WIDE"); return e && e[0] == '1'; }();
+bool keys_fit32(const int64_t* k, int64_t n) {
+    if (g_force_wide) return false;
+    for (int64_t i = 0; i < n; ++i) if (!key_fits32(k[i])) return false;
+    return true;
+}
+
 int64_t occ_words_for(int64_t slots) {
     const int64_t w = (slots + 63) / 64;
     return ((w + 63) / 64) * 64;      // whole 64-word tiles (k_tile_count / k_move read lane <-> word)
 }
 
 void alloc_one_buffer(Pma& P, int b, int64_t slots) {
-    HIPCHK(hipMalloc(&P.keys[b], (size_t)slots * sizeof(int64_t)));
+    HIPCHK(hipMalloc(&P.keys[b], (size_t)slots * P.kb()));
     HIPCHK(hipMalloc(&P.vals[b], (size_t)slots * sizeof(double)));
     const int64_t words = occ_words_for(slots);
     HIPCHK(hipMalloc(&P.occ[b], (size_t)words * sizeof(uint64_t)));
@@ -244,12 +273,12 @@ void ensure_capacity_alloc(Pma& P, int64_t slots) {
     if (slots <= P.cap_alloc) return;
     int64_t n = std::max<int64_t>(P.cap_alloc, 4096);
     while (n < slots) n *= 2;
-    int64_t* ok[2] = {P.keys[0], P.keys[1]}; double* ov[2] = {P.vals[0], P.vals[1]}; uint64_t* oo[2] = {P.occ[0], P.occ[1]};
+    void* ok[2] = {P.keys[0], P.keys[1]}; double* ov[2] = {P.vals[0], P.vals[1]}; uint64_t* oo[2] = {P.occ[0], P.occ[1]};
     const int64_t old_words = P.occ_words, old_slots = P.cap_alloc;
     for (int b = 0; b < 2; ++b) { P.keys[b] = nullptr; P.vals[b] = nullptr; P.occ[b] = nullptr; }
     for (int b = 0; b < 2; ++b) alloc_one_buffer(P, b, n);
     if (ok[P.cur] != nullptr && old_slots > 0) {
-        HIPCHK(hipMemcpyAsync(P.keys[P.cur], ok[P.cur], (size_t)old_slots * sizeof(int64_t), hipMemcpyDeviceToDevice, P.stream));
+        HIPCHK(hipMemcpyAsync(P.keys[P.cur], ok[P.cur], (size_t)old_slots * P.kb(), hipMemcpyDeviceToDevice, P.stream));
         HIPCHK(hipMemcpyAsync(P.vals[P.cur], ov[P.cur], (size_t)old_slots * sizeof(double), hipMemcpyDeviceToDevice, P.stream));
         HIPCHK(hipMemcpyAsync(P.occ[P.cur], oo[P.cur], (size_t)old_words * sizeof(uint64_t), hipMemcpyDeviceToDevice, P.stream));
     }
@@ -266,8 +295,8 @@ void ensure_capacity_alloc(Pma& P, int64_t slots) {
 void root_rebalance(Pma& P, int64_t src_cap, int64_t new_cap, int64_t m, bool src_packed) {
     ensure_capacity_alloc(P, std::max(src_cap, new_cap));
     const int alt = 1 - P.cur;
-    hipError_t e = launch_rebalance(P.keys[P.cur], P.vals[P.cur], P.occ[P.cur], 1, src_cap, src_packed,
-                                    P.keys[alt], P.vals[alt], P.occ[alt], 1, new_cap, m,
+    hipError_t e = launch_rebalance(P.KA(P.cur), P.vals[P.cur], P.occ[P.cur], 1, src_cap, src_packed,
+                                    P.KA(alt), P.vals[alt], P.occ[alt], 1, new_cap, m,
                                     P.has_sems ? P.sems : nullptr, &P.work, P.stream);
     if (e != hipSuccess) fail(DSA_EHIP, std::string("rebalance launch: ") + hipGetErrorString(e));
     // bits beyond the new capacity must be zero in the buffer that becomes current; only the words that
@@ -283,12 +312,13 @@ void root_rebalance(Pma& P, int64_t src_cap, int64_t new_cap, int64_t m, bool sr
 void window_rebalance(Pma& P, int64_t ws, int64_t we, int64_t m) {
     if (ws == 1 && we == P.capacity()) { root_rebalance(P, P.capacity(), P.capacity(), m, false); return; }
     const int alt = 1 - P.cur;
-    hipError_t e = launch_rebalance(P.K(), P.V(), P.O(), ws, we, false, P.keys[alt], P.vals[alt], P.occ[alt], ws, we, m,
+    hipError_t e = launch_rebalance(P.K(), P.V(), P.O(), ws, we, false, P.KA(alt), P.vals[alt], P.occ[alt], ws, we, m,
                                     P.has_sems ? P.sems : nullptr, &P.work, P.stream);
     if (e != hipSuccess) fail(DSA_EHIP, std::string("rebalance launch: ") + hipGetErrorString(e));
     const int64_t W = we - ws + 1;
     P.occ_dirty[alt] = std::max<int64_t>(P.occ_dirty[alt], (we + 63) / 64);
-    HIPCHK(hipMemcpyAsync(P.K() + (ws - 1), P.keys[alt] + (ws - 1), (size_t)W * sizeof(int64_t), hipMemcpyDeviceToDevice, P.stream));
+    HIPCHK(hipMemcpyAsync((char*)P.keys[P.cur] + (size_t)(ws - 1) * P.kb(), (char*)P.keys[alt] + (size_t)(ws - 1) * P.kb(), (size_t)W * P.kb(),
+                          hipMemcpyDeviceToDevice, P.stream));
     HIPCHK(hipMemcpyAsync(P.V() + (ws - 1), P.vals[alt] + (ws - 1), (size_t)W * sizeof(double), hipMemcpyDeviceToDevice, P.stream));
     HIPCHK(hipMemcpyAsync(P.O() + ((ws - 1) >> 6), P.occ[alt] + ((ws - 1) >> 6), (size_t)(W >> 6) * sizeof(uint64_t),
                           hipMemcpyDeviceToDevice, P.stream));
@@ -298,11 +328,12 @@ void window_rebalance(Pma& P, int64_t ws, int64_t we, int64_t m) {
 // cell stream; n == 0 -> PackedMemoryArray(K, T) (capacity for 100 expected cells)  src/pma.jl:86-91
 void build_from_packed(Pma& P, const std::vector<int64_t>& keys, const std::vector<double>& vals) {
     const int64_t n = (int64_t)keys.size();
+    if (P.cap_alloc == 0) P.wide = !keys_fit32(keys.data(), n);
     const int64_t capacity = capacity_for(n == 0 ? 100 : n);
     set_geometry_for_new(P, capacity, n);
     ensure_capacity_alloc(P, 2 * capacity);
     if (n > 0) {
-        HIPCHK(hipMemcpyAsync(P.K(), keys.data(), (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, P.stream));
+        upload_keys(P, P.keys[P.cur], keys.data(), n);
         HIPCHK(hipMemcpyAsync(P.V(), vals.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice, P.stream));
     }
     // _even_rebalance!(pma, 1, capacity, n): a no-op when the array is exactly one leaf (src/pma.jl:96-99)
@@ -318,7 +349,7 @@ void build_from_packed(Pma& P, const std::vector<int64_t>& keys, const std::vect
 void permute_run(Pma& P, const Op* cells, int64_t i0, int64_t n0) {
     const int alt = 1 - P.cur;
     const int64_t cap = P.capacity();
-    hipError_t e = launch_permute(P.K(), P.V(), P.occ_old, cap, P.keys[alt], P.vals[alt], P.O(), cap, n0, cells, i0,
+    hipError_t e = launch_permute(P.K(), P.V(), P.occ_old, cap, P.KA(alt), P.vals[alt], P.O(), cap, n0, cells, i0,
                                   P.has_sems ? P.sems : nullptr, &P.work, &P.work2, P.stream);
     if (e != hipSuccess) fail(DSA_EHIP, std::string("permute launch: ") + hipGetErrorString(e));
     const int64_t words = (cap + 63) / 64;
@@ -349,6 +380,27 @@ const char* err_text(int32_t e) {
     }
 }
 
+// First key outside Int32: both slot buffers are re-allocated with 64-bit keys, the current one converted on the device.
+// (The alternate buffer holds no live data between operations.)
+void widen_keys(Pma& P) {
+    if (P.wide) return;
+    HIPCHK(hipStreamSynchronize(P.stream));
+    void* old[2] = {P.keys[0], P.keys[1]};
+    for (int b = 0; b < 2; ++b) { P.keys[b] = nullptr; if (P.cap_alloc > 0) HIPCHK(hipMalloc(&P.keys[b], (size_t)P.cap_alloc * sizeof(int64_t))); }
+    if (P.cap_alloc > 0 && old[P.cur] != nullptr) {
+        hipError_t e = launch_widen_keys(old[P.cur], P.keys[P.cur], P.cap_alloc, P.stream);
+        if (e != hipSuccess) fail(DSA_EHIP, std::string("widen launch: ") + hipGetErrorString(e));
+        HIPCHK(hipStreamSynchronize(P.stream));
+    }
+    for (int b = 0; b < 2; ++b) if (old[b]) hipFree(old[b]);
+    P.wide = true;
+}
+void ensure_key_width(Pma& P, const std::vector<Op>& ops) {
+    if (P.wide) return;
+    for (const Op& o : ops)
+        if ((o.kind == OP_VEC_SET || o.kind == OP_PCSC_SET || o.kind == OP_MPCSC_SET) && !key_fits32(o.a)) { widen_keys(P); return; }
+}
+
 // ---- the yield loop around the device sequencer, as a resumable state machine so that the two orientations of a
 // matrix can run their sequencers concurrently on their own streams ------------------------------------------------
 struct SeqRun {
@@ -377,6 +429,7 @@ void seq_start(SeqRun& r, Pma& P, const std::vector<Op>& ops) {
     r = SeqRun();
     r.P = &P; r.ops = &ops; r.n = (int64_t)ops.size();
     if (r.n == 0) return;
+    ensure_key_width(P, ops);
     ensure_ops(P, r.n);
     HIPCHK(hipMemcpyAsync(P.d_ops, ops.data(), (size_t)r.n * sizeof(Op), hipMemcpyHostToDevice, P.stream));
     P.h_ctl->next_op = 0; P.h_ctl->status = 0; P.h_ctl->err = 0; P.h_ctl->no_run_at = -1;
@@ -477,6 +530,7 @@ int64_t run_ops_parallel(Pma& P, const std::vector<Op>& ops, int32_t* err) {
     const int64_t n = (int64_t)ops.size();
     if (n == 0) return 0;
     constexpr int GMAX = 1024, MIN_PREFIX = 4, ROUNDS_PER_SYNC = 12;
+    ensure_key_width(P, ops);
     ensure_ops(P, n);
     HIPCHK(hipMemcpyAsync(P.d_ops, ops.data(), (size_t)n * sizeof(Op), hipMemcpyHostToDevice, P.stream));
     if (!P.d_plans) {
@@ -572,7 +626,7 @@ void export_slots(Pma& P, int64_t* keys, double* vals, uint8_t* occ, int64_t cap
     const int64_t c = P.capacity();
     if (cap < c) fail(DSA_ECAP, "output buffers smaller than capacity");
     std::vector<uint64_t> words((size_t)((c + 63) / 64));
-    HIPCHK(hipMemcpyAsync(keys, P.K(), (size_t)c * sizeof(int64_t), hipMemcpyDeviceToHost, P.stream));
+    download_keys(P, keys, P.keys[P.cur], c);
     HIPCHK(hipMemcpyAsync(vals, P.V(), (size_t)c * sizeof(double), hipMemcpyDeviceToHost, P.stream));
     HIPCHK(hipMemcpyAsync(words.data(), P.O(), words.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, P.stream));
     HIPCHK(hipStreamSynchronize(P.stream));
@@ -645,13 +699,12 @@ void read_range(Pma& P, int64_t from, int64_t to, std::vector<int64_t>& ks, std:
     if (to < from) return;
     const int alt = 1 - P.cur;
     int64_t cnt = 0;
-    hipError_t e = launch_compact_range(P.K(), P.V(), P.O(), from, to, P.keys[alt], P.vals[alt], P.cap_alloc, &P.work, &cnt, P.stream);
+    hipError_t e = launch_compact_range(P.K(), P.V(), P.O(), from, to, P.KA(alt), P.vals[alt], P.cap_alloc, &P.work, &cnt, P.stream);
     if (e != hipSuccess) fail(DSA_EHIP, std::string("compact launch: ") + hipGetErrorString(e));
     if (cnt == 0) return;
     ks.resize((size_t)cnt); vs.resize((size_t)cnt);
-    HIPCHK(hipMemcpyAsync(ks.data(), P.keys[alt], (size_t)cnt * sizeof(int64_t), hipMemcpyDeviceToHost, P.stream));
     HIPCHK(hipMemcpyAsync(vs.data(), P.vals[alt], (size_t)cnt * sizeof(double), hipMemcpyDeviceToHost, P.stream));
-    HIPCHK(hipStreamSynchronize(P.stream));
+    download_keys(P, ks.data(), P.keys[alt], cnt);        // synchronises
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -663,7 +716,8 @@ void read_range(Pma& P, int64_t from, int64_t to, std::vector<int64_t>& ks, std:
 //   mode 1: a vector (d_part == nullptr, no semaphores)         dynamicsparsevec  src/vector.jl:38-62
 //   mode 2: PackedCSC with explicit partition ids 1..nparts      PackedCSC ctor    src/pcsr.jl:26-63
 void pma_build_dev(Pma& P, const int64_t* d_part, const int64_t* d_key, const double* d_val, int64_t nnz, int32_t combine,
-                   int mode, int64_t nparts_explicit) {
+                   int mode, int64_t nparts_explicit, bool wide) {
+    P.wide = wide;                     // decided by the caller from the host copy of the keys, before anything is allocated
     if (nnz == 0) {
         std::vector<int64_t> ks; std::vector<double> vs;
         const int64_t np = mode == 2 ? nparts_explicit : 0;
@@ -717,7 +771,7 @@ void pma_build_from_host(Pma& P, const int64_t* part, const int64_t* key, const 
             HIPCHK(hipMalloc(&dV, (size_t)nnz * 8)); HIPCHK(hipMemcpyAsync(dV, val, (size_t)nnz * 8, hipMemcpyHostToDevice, P.stream));
             HIPCHK(hipStreamSynchronize(P.stream));
         }
-        pma_build_dev(P, dP, dK, dV, nnz, combine, mode, nparts_explicit);
+        pma_build_dev(P, dP, dK, dV, nnz, combine, mode, nparts_explicit, !keys_fit32(key, nnz));
     } catch (...) {
         if (dP) hipFree(dP);
         if (dK) hipFree(dK);
@@ -778,9 +832,9 @@ void mat_build_major(dsa_mat* h, const int64_t* I, const int64_t* J, const doubl
         }
         static const bool dbg_time = getenv("DSA_DBG_TIME") != nullptr;
         const auto tb0 = std::chrono::steady_clock::now();
-        pma_build_dev(h->col, dJ, dI, dV, nnz, DSA_COMBINE_ADD, 0, 0);      // dynamicsparsecolmajor(I, J, V): partitions = columns
+        pma_build_dev(h->col, dJ, dI, dV, nnz, DSA_COMBINE_ADD, 0, 0, !keys_fit32(I, nnz));      // dynamicsparsecolmajor(I, J, V): partitions = columns
         const auto tb1 = std::chrono::steady_clock::now();
-        pma_build_dev(h->row, dI, dJ, dV, nnz, DSA_COMBINE_ADD, 0, 0);      // dynamicsparsecolmajor(J, I, V): partitions = rows
+        pma_build_dev(h->row, dI, dJ, dV, nnz, DSA_COMBINE_ADD, 0, 0, !keys_fit32(J, nnz));      // dynamicsparsecolmajor(J, I, V): partitions = rows
         if (dbg_time)
             fprintf(stderr, "[mat_build_major] nnz=%lld upload %.1f ms  colmajor %.1f ms  rowmajor %.1f ms\n", (long long)nnz,
                     std::chrono::duration<double, std::milli>(tb0 - tup0).count(), std::chrono::duration<double, std::milli>(tb1 - tb0).count(),
@@ -887,24 +941,22 @@ void col_view_of(Pma& P, int64_t col, std::vector<int64_t>& ks, std::vector<doub
     const int alt = 1 - P.cur;
     const int64_t out_cap = std::min<int64_t>(P.cap_alloc, 16384);
     hipError_t e = launch_view_small(P.K(), P.V(), P.O(), P.sems, P.col_keys, P.col_live, P.h_ctl->table_len, P.capacity(), col,
-                                     P.keys[alt], P.vals[alt], out_cap, P.d_small, P.stream);
+                                     P.KA(alt), P.vals[alt], out_cap, P.d_small, P.stream);
     if (e != hipSuccess) fail(DSA_EHIP, std::string("view launch: ") + hipGetErrorString(e));
     int64_t r[5] = {0, 0, 0, 0, 0};
     const int64_t spec = std::min<int64_t>(SPEC, out_cap);
     ks.resize((size_t)spec); vs.resize((size_t)spec);
     HIPCHK(hipMemcpyAsync(r, P.d_small, sizeof(r), hipMemcpyDeviceToHost, P.stream));
-    HIPCHK(hipMemcpyAsync(ks.data(), P.keys[alt], (size_t)spec * sizeof(int64_t), hipMemcpyDeviceToHost, P.stream));
     HIPCHK(hipMemcpyAsync(vs.data(), P.vals[alt], (size_t)spec * sizeof(double), hipMemcpyDeviceToHost, P.stream));
-    HIPCHK(hipStreamSynchronize(P.stream));
+    download_keys(P, ks.data(), P.keys[alt], spec);       // synchronises
     if (r[2] != 0) { ks.clear(); vs.clear(); fail((int32_t)r[2], "partition has no semaphore"); }
     if (r[0] == 0) { ks.clear(); vs.clear(); return; }       // empty view: the column does not exist (src/views.jl:17,24)
     const int64_t cnt = r[4];
     if (cnt < 0) { read_range(P, r[0], r[1], ks, vs); return; }   // a long partition: general K-pack path
     ks.resize((size_t)cnt); vs.resize((size_t)cnt);
     if (cnt > spec) {
-        HIPCHK(hipMemcpyAsync(ks.data() + spec, P.keys[alt] + spec, (size_t)(cnt - spec) * sizeof(int64_t), hipMemcpyDeviceToHost, P.stream));
         HIPCHK(hipMemcpyAsync(vs.data() + spec, P.vals[alt] + spec, (size_t)(cnt - spec) * sizeof(double), hipMemcpyDeviceToHost, P.stream));
-        HIPCHK(hipStreamSynchronize(P.stream));
+        download_keys(P, ks.data() + spec, (char*)P.keys[alt] + (size_t)spec * P.kb(), cnt - spec);
     }
 }
 

@@ -66,7 +66,7 @@ static __device__ int64_t d_prev_occupied(const uint64_t* occ, int64_t pos, int6
 struct DFound { int64_t pos; int64_t key; double val; bool has; };
 
 // find(array, key, from, to)  src/finds.jl:29-57 — same probes, same answers
-static __device__ DFound d_find(const int64_t* keys, const double* vals, const uint64_t* occ, int64_t key, int64_t from, int64_t to) {
+static __device__ DFound d_find(KeyArr keys, const double* vals, const uint64_t* occ, int64_t key, int64_t from, int64_t to) {
     while (from <= to) {
         const int64_t mid = (from + to) >> 1;
         const int64_t i = d_prev_occupied(occ, mid, from);
@@ -108,7 +108,7 @@ static __device__ int64_t d_next_occupied(const uint64_t* occ, int64_t pos, int6
 // nearest occupied cell left of `from`; else (0, nothing)  (src/finds.jl:29-57).  A 64-ary search on slot
 // positions: each round every lane probes one position (nearest occupied cell at or before it, via the
 // bitmap), one ballot narrows the interval 64-fold: ~log64(range) dependent round trips instead of log2.
-static __device__ DFound d_find_fast(const int64_t* keys, const double* vals, const uint64_t* occ, int64_t key, int64_t from, int64_t to) {
+static __device__ DFound d_find_fast(KeyArr keys, const double* vals, const uint64_t* occ, int64_t key, int64_t from, int64_t to) {
     const int lane = lane_id();
     int64_t pstar;
     if (to < from) {

@@ -46,7 +46,7 @@ __device__ int64_t pb_wave_count(const uint64_t* occ, int64_t ws, int64_t we, bo
     return pb_wave_sum(c);
 }
 
-__global__ __launch_bounds__(PB_BLOCK) void k_plan(const int64_t* keys, const double* vals, const uint64_t* occ,
+__global__ __launch_bounds__(PB_BLOCK) void k_plan(KeyArr keys, const double* vals, const uint64_t* occ,
                                                    const int64_t* sems, const int64_t* col_keys, const uint8_t* col_live,
                                                    const Ctl* ctl, const Op* ops, const RoundState* rs, Plan* plans) {
     // the round's window of ops comes from the device-resident cursor: rounds are enqueued back to back without host syncs
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(1024) void k_resolve(const Plan* plans, RoundState*
 }
 
 // ---- apply ----------------------------------------------------------------------------------------------------------
-__device__ void pb_shift_right(int64_t* keys, double* vals, int64_t* sems, int64_t a, int64_t b) {      // cells [a, b-1] -> +1
+__device__ void pb_shift_right(KeyArr keys, double* vals, int64_t* sems, int64_t a, int64_t b) {      // cells [a, b-1] -> +1
     const int lane = lane_id();
     for (int64_t hi = b - 1; hi >= a; hi -= 64) {
         const int64_t p = hi - lane;
@@ -280,7 +280,7 @@ __device__ void pb_shift_right(int64_t* keys, double* vals, int64_t* sems, int64
     }
 }
 // cells [a, b-1] -> +dist, highest chunk first (a chunk's stores land above every cell that is still to be read)
-__device__ void pb_shift_right_by(int64_t* keys, double* vals, int64_t* sems, int64_t a, int64_t b, int dist) {
+__device__ void pb_shift_right_by(KeyArr keys, double* vals, int64_t* sems, int64_t a, int64_t b, int dist) {
     const int lane = lane_id();
     for (int64_t hi = b - 1; hi >= a; hi -= 64) {
         const int64_t p = hi - lane;
@@ -293,7 +293,7 @@ __device__ void pb_shift_right_by(int64_t* keys, double* vals, int64_t* sems, in
         }
     }
 }
-__device__ void pb_shift_left(int64_t* keys, double* vals, int64_t* sems, int64_t a, int64_t b, bool last_occ) {   // cells [a+1, b] -> -1
+__device__ void pb_shift_left(KeyArr keys, double* vals, int64_t* sems, int64_t a, int64_t b, bool last_occ) {   // cells [a+1, b] -> -1
     const int lane = lane_id();
     for (int64_t lo = a + 1; lo <= b; lo += 64) {
         const int64_t p = lo + lane;
@@ -324,7 +324,7 @@ __device__ __forceinline__ uint32_t pb_wave_excl_scan(uint32_t v) {
 }
 
 // pack! + spread! of [ws, we] (W <= PB_MAX_W) holding m cells, by one wave  (src/moves.jl:94-140)
-__device__ void pb_wave_rebalance(int64_t* keys, double* vals, uint64_t* occ, int64_t* sems, int64_t ws, int64_t we, int64_t m,
+__device__ void pb_wave_rebalance(KeyArr keys, double* vals, uint64_t* occ, int64_t* sems, int64_t ws, int64_t we, int64_t m,
                                   int64_t* sK, double* sV) {
     const int lane = lane_id();
     const int64_t W = we - ws + 1, lo0 = ws - 1, w0 = lo0 >> 6;
@@ -340,7 +340,7 @@ __device__ void pb_wave_rebalance(int64_t* keys, double* vals, uint64_t* occ, in
                 const uint32_t r = off + (uint32_t)popc64(mask & mask_lt(lane));
                 const int64_t s = ((w0 + w) << 6) + lane;
                 // L2-served loads: some of these cells were just written by this wave's own shift
-                sK[r] = __hip_atomic_load(keys + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                sK[r] = keys.ld_agent(s);
                 sV[r] = __hip_atomic_load(vals + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
@@ -369,7 +369,7 @@ __device__ void pb_wave_rebalance(int64_t* keys, double* vals, uint64_t* occ, in
         const uint64_t mask = (word & wmask) >> bit0;
         if (lane < W && ((mask >> lane) & 1ull)) {
             const int r = popc64(mask & mask_lt(lane));
-            sK[r] = __hip_atomic_load(keys + lo0 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sK[r] = keys.ld_agent(lo0 + lane);
             sV[r] = __hip_atomic_load(vals + lo0 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __builtin_amdgcn_wave_barrier();
@@ -409,14 +409,14 @@ __device__ int64_t pb_next_empty_live(const uint64_t* occ, int64_t from, int64_t
         word = ~pb_occ_load(occ, w);
     }
 }
-__device__ void pb_shift_right_live(int64_t* keys, double* vals, int64_t* sems, int64_t a, int64_t b) {      // cells [a, b-1] -> +1
+__device__ void pb_shift_right_live(KeyArr keys, double* vals, int64_t* sems, int64_t a, int64_t b) {      // cells [a, b-1] -> +1
     const int lane = lane_id();
     for (int64_t hi = b - 1; hi >= a; hi -= 64) {
         const int64_t p = hi - lane;
         const bool act = p >= a;
         int64_t k = 0; double v = 0.0;
         if (act) {
-            k = __hip_atomic_load(keys + p - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            k = keys.ld_agent(p - 1);
             v = __hip_atomic_load(vals + p - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (act) {
@@ -427,7 +427,7 @@ __device__ void pb_shift_right_live(int64_t* keys, double* vals, int64_t* sems, 
 }
 // _look_for_rebalance! + _even_rebalance! (src/pma.jl:94-141) around `ip` on the live bitmap; the plan guarantees acceptance
 // at a level whose window fits one wave.  Returns true when cells were moved.
-__device__ bool pb_scan_and_rebalance_live(int64_t* keys, double* vals, uint64_t* occ, int64_t* sems, Ctl* ctl, int64_t ip, int64_t hmax,
+__device__ bool pb_scan_and_rebalance_live(KeyArr keys, double* vals, uint64_t* occ, int64_t* sems, Ctl* ctl, int64_t ip, int64_t hmax,
                                            int64_t* sK, double* sV) {
     const int64_t seg = ctl->segment_capacity;
     int64_t ws = 1, we = 0, c = 0, W = seg;
@@ -448,7 +448,7 @@ __device__ bool pb_scan_and_rebalance_live(int64_t* keys, double* vals, uint64_t
     return true;
 }
 
-__global__ __launch_bounds__(PB_BLOCK) void k_apply(int64_t* keys, double* vals, uint64_t* occ, int64_t* sems, int64_t* col_keys,
+__global__ __launch_bounds__(PB_BLOCK) void k_apply(KeyArr keys, double* vals, uint64_t* occ, int64_t* sems, int64_t* col_keys,
                                                     uint8_t* col_live, Ctl* ctl, const Op* ops, const RoundState* rs, const Plan* plans) {
     extern __shared__ __attribute__((aligned(16))) unsigned char pb_lds[];
     if (rs->stop) return;
@@ -556,7 +556,7 @@ static hipError_t configure_apply() {
     }
     return hipSuccess;
 }
-static hipError_t enqueue_round(int64_t* keys, double* vals, uint64_t* occ, int64_t* sems, int64_t* col_keys,
+static hipError_t enqueue_round(KeyArr keys, double* vals, uint64_t* occ, int64_t* sems, int64_t* col_keys,
                                 uint8_t* col_live, Ctl* ctl, const Op* ops, RoundState* rs, Plan* plans, uint32_t* flags,
                                 hipStream_t stream) {
     const size_t lds = (size_t)(PB_BLOCK / 64) * PB_MAX_W * (sizeof(int64_t) + sizeof(double));
@@ -572,12 +572,12 @@ static hipError_t enqueue_round(int64_t* keys, double* vals, uint64_t* occ, int6
 // replayed (one graph launch instead of 4 x rounds kernel launches: the rounds are launch-bound); re-captured when a buffer
 // moves (root rebalance swaps the slot buffers, a bigger batch re-allocates the op array).  Falls back to eager launches
 // when the stream cannot be captured.
-hipError_t launch_burst(int64_t* keys, double* vals, uint64_t* occ, int64_t* sems, int64_t* col_keys, uint8_t* col_live,
+hipError_t launch_burst(KeyArr keys, double* vals, uint64_t* occ, int64_t* sems, int64_t* col_keys, uint8_t* col_live,
                         Ctl* ctl, const Op* ops, RoundState* rs, Plan* plans, uint32_t* flags, int rounds, BurstGraph* cache,
                         hipStream_t stream) {
     hipError_t e = configure_apply();
     if (e != hipSuccess) return e;
-    const void* key[12] = {keys, vals, occ, sems, col_keys, col_live, ctl, ops, rs, plans, flags, (const void*)(intptr_t)rounds};
+    const void* key[12] = {keys.p, vals, occ, sems, col_keys, col_live, ctl, ops, rs, plans, flags, (const void*)(intptr_t)(rounds * 2 + keys.wide)};
     bool same = cache->exec != nullptr && cache->stream == stream;
     for (int k = 0; k < 12 && same; ++k) same = cache->key[k] == key[k];
     if (!same && !cache->disabled) {

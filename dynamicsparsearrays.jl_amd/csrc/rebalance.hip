@@ -18,7 +18,9 @@
 //                  whole — is stored as 16-byte key / value pairs, the occupancy words are rebuilt
 //                  from two ballots, and semaphore positions are scattered to the table.
 #include "dsa_dev.h"
+#include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 namespace dsa {
 
@@ -101,10 +103,10 @@ __global__ __launch_bounds__(1024) void k_tile_scan(const uint32_t* __restrict__
 }
 
 struct MoveArgs {
-    const int64_t* src_keys; const double* src_vals; const uint64_t* src_occ;
+    KeyArr src_keys; const double* src_vals; const uint64_t* src_occ;
     int64_t src_lo0, src_hi0;      // 0-based inclusive source slot range
     int64_t src_w0;                // first source occupancy word
-    int64_t* dst_keys; double* dst_vals; uint64_t* dst_occ;
+    KeyArr dst_keys; double* dst_vals; uint64_t* dst_occ;
     int64_t dst_lo0;               // 0-based first destination slot (multiple of the window size)
     int64_t Wd, m;
     int64_t* sems;
@@ -113,9 +115,12 @@ struct MoveArgs {
     int dbg;   // DSA_DBG_MOVE ablation knob (dev only): 1 = skip staging, 2 = skip the write phase
 };
 
-template <bool PACKED>
+template <bool PACKED, bool WIDE>
 __global__ __launch_bounds__(MOVE_BLOCK) void k_move(MoveArgs a) {
-    __shared__ int64_t sK[DST_TILE];
+    typedef typename std::conditional<WIDE, int64_t, int32_t>::type key_t;
+    const key_t* __restrict__ srck = static_cast<const key_t*>(a.src_keys.p);
+    key_t* __restrict__ dstk = static_cast<key_t*>(a.dst_keys.p);
+    __shared__ key_t sK[DST_TILE];
     __shared__ double sV[DST_TILE];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const SpreadGeom g = make_geom(a.Wd, a.m);
@@ -174,7 +179,7 @@ __global__ __launch_bounds__(MOVE_BLOCK) void k_move(MoveArgs a) {
             // empty words in front of the range are counted in `before`; words [before, notafter) may intersect
 #pragma unroll 1
             for (int jb = before + wv * 4; jb < notafter; jb += MOVE_BLOCK / 64 * 4) {
-                int64_t kk[4]; double vv[4]; int rk[4]; bool act[4];
+                key_t kk[4]; double vv[4]; int rk[4]; bool act[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int j = jb + u;
@@ -187,7 +192,7 @@ __global__ __launch_bounds__(MOVE_BLOCK) void k_move(MoveArgs a) {
                     // unconditional loads (inactive lanes read the word's first slot, inside the allocation)
                     const int64_t s = (word_index << 6) + (act[u] ? lane : 0);
                     const int64_t s_safe = in ? s : a.src_lo0;
-                    kk[u] = __builtin_nontemporal_load(a.src_keys + s_safe);
+                    kk[u] = __builtin_nontemporal_load(srck + s_safe);
                     vv[u] = __builtin_nontemporal_load(a.src_vals + s_safe);
                 }
 #pragma unroll
@@ -207,7 +212,7 @@ __global__ __launch_bounds__(MOVE_BLOCK) void k_move(MoveArgs a) {
         const int64_t gq = q0 + (int64_t)wv * PER_WAVE + it * 128;   // 0-based offset of the 128-slot group
         if (gq >= a.Wd) break;                                        // wave-uniform
         const int64_t qa = gq + 2 * lane + 1;                         // 1-based offsets qa, qa+1
-        int64_t k2[2] = {0, 0};
+        key_t k2[2] = {0, 0};
         double v2[2] = {0.0, 0.0};
         bool o2[2] = {false, false};
         if (qa <= a.Wd) {
@@ -221,7 +226,7 @@ __global__ __launch_bounds__(MOVE_BLOCK) void k_move(MoveArgs a) {
                 if (!gap) {
                     o2[j] = true;
                     if (PACKED) {
-                        k2[j] = a.src_keys[a.src_lo0 + rank - 1];
+                        k2[j] = srck[a.src_lo0 + rank - 1];
                         v2[j] = a.src_vals[a.src_lo0 + rank - 1];
                     } else {
                         k2[j] = sK[rank - R0 - 1];
@@ -231,11 +236,11 @@ __global__ __launch_bounds__(MOVE_BLOCK) void k_move(MoveArgs a) {
                 }
             }
             const int64_t d = a.dst_lo0 + qa - 1;
-            typedef long long ll2v __attribute__((ext_vector_type(2)));
             typedef double d2v __attribute__((ext_vector_type(2)));
-            ll2v kv; kv.x = k2[0]; kv.y = k2[1];
             d2v vv2; vv2.x = v2[0]; vv2.y = v2[1];
-            __builtin_nontemporal_store(kv, reinterpret_cast<ll2v*>(a.dst_keys + d));
+            typedef key_t k2v __attribute__((ext_vector_type(2)));
+            k2v kv; kv.x = k2[0]; kv.y = k2[1];
+            __builtin_nontemporal_store(kv, reinterpret_cast<k2v*>(dstk + d));
             __builtin_nontemporal_store(vv2, reinterpret_cast<d2v*>(a.dst_vals + d));
         }
         const uint64_t be = __ballot(o2[0]);
@@ -253,10 +258,10 @@ __global__ __launch_bounds__(MOVE_BLOCK) void k_move(MoveArgs a) {
 // src/moves.jl:94-110 into a separate buffer).  Serves per-column iteration (DynamicMatrixColView, src/views.jl:15-35)
 // and iteration over a vector (src/pma.jl:165-180): one wave per 4096-slot source tile, lane <-> occupancy word for the
 // prefix, then lane <-> slot with ballot-style popcount ranks; out[tile_off + rank] is a contiguous run per wave.
-__global__ __launch_bounds__(64) void k_compact(const int64_t* __restrict__ keys, const double* __restrict__ vals,
+__global__ __launch_bounds__(64) void k_compact(KeyArr keys, const double* __restrict__ vals,
                                                 const uint64_t* __restrict__ occ, int64_t lo0, int64_t hi0, int64_t w0,
                                                 int64_t nwords, const uint32_t* __restrict__ tile_off,
-                                                int64_t* __restrict__ out_keys, double* __restrict__ out_vals) {
+                                                KeyArr out_keys, double* __restrict__ out_vals) {
     const int lane = threadIdx.x;
     const int64_t t = blockIdx.x;
     const int64_t wl = t * SRC_TILE_WORDS + lane;
@@ -277,8 +282,8 @@ __global__ __launch_bounds__(64) void k_compact(const int64_t* __restrict__ keys
     }
 }
 
-hipError_t launch_compact_range(const int64_t* keys, const double* vals, const uint64_t* occ, int64_t from, int64_t to,
-                                int64_t* out_keys, double* out_vals, int64_t out_cap, RebalanceWork* work, int64_t* count,
+hipError_t launch_compact_range(KeyArr keys, const double* vals, const uint64_t* occ, int64_t from, int64_t to,
+                                KeyArr out_keys, double* out_vals, int64_t out_cap, RebalanceWork* work, int64_t* count,
                                 hipStream_t stream) {
     *count = 0;
     if (to < from) return hipSuccess;
@@ -367,8 +372,8 @@ hipError_t launch_touched_compact(const uint8_t* bytes, const double* pattern, c
 // come from the source array (compaction through LDS as in k_move), ranks > n0 from the batch's op records.
 constexpr int PERM_TILE = 4096;
 struct PermArgs {
-    const int64_t* src_keys; const double* src_vals; const uint64_t* src_occ; int64_t src_words;
-    int64_t* dst_keys; double* dst_vals; const uint64_t* dst_occ; int64_t dst_words;
+    KeyArr src_keys; const double* src_vals; const uint64_t* src_occ; int64_t src_words;
+    KeyArr dst_keys; double* dst_vals; const uint64_t* dst_occ; int64_t dst_words;
     const uint32_t* src_off; int64_t src_tiles;        // exclusive prefix per 4096-slot source tile (k_tile_scan)
     const uint32_t* dst_off; int64_t dst_tiles;
     int64_t n0;                                         // cells that existed before the run
@@ -437,8 +442,8 @@ __global__ __launch_bounds__(256) void k_permute(PermArgs a) {
     }
 }
 
-hipError_t launch_permute(const int64_t* src_keys, const double* src_vals, const uint64_t* src_occ, int64_t src_cap,
-                          int64_t* dst_keys, double* dst_vals, const uint64_t* dst_occ, int64_t dst_cap, int64_t n0,
+hipError_t launch_permute(KeyArr src_keys, const double* src_vals, const uint64_t* src_occ, int64_t src_cap,
+                          KeyArr dst_keys, double* dst_vals, const uint64_t* dst_occ, int64_t dst_cap, int64_t n0,
                           const Op* ops, int64_t i0, int64_t* sems, RebalanceWork* wsrc, RebalanceWork* wdst, hipStream_t stream) {
     PermArgs a;
     a.src_keys = src_keys; a.src_vals = src_vals; a.src_occ = src_occ; a.src_words = (src_cap + 63) / 64;
@@ -465,6 +470,17 @@ hipError_t launch_permute(const int64_t* src_keys, const double* src_vals, const
     return hipGetLastError();
 }
 
+// int32 -> int64 key array (the structure receives its first key outside Int32)
+__global__ void k_widen_keys(const int32_t* __restrict__ src, int64_t* __restrict__ dst, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = (int64_t)src[i];
+}
+hipError_t launch_widen_keys(const void* src32, void* dst64, int64_t n, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    const int blocks = (int)std::min<int64_t>((n + 255) / 256, 4096);
+    hipLaunchKernelGGL(k_widen_keys, dim3(blocks), dim3(256), 0, stream, (const int32_t*)src32, (int64_t*)dst64, n);
+    return hipGetLastError();
+}
+
 __global__ void k_clear_occ(uint64_t* occ, int64_t lo0, int64_t hi0) {
     const int64_t w0 = lo0 >> 6, w1 = hi0 >> 6;
     for (int64_t w = w0 + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; w <= w1; w += (int64_t)gridDim.x * blockDim.x)
@@ -479,9 +495,9 @@ hipError_t launch_clear_occ(uint64_t* occ, int64_t from, int64_t to, hipStream_t
     return hipGetLastError();
 }
 
-hipError_t launch_rebalance(const int64_t* src_keys, const double* src_vals, const uint64_t* src_occ,
+hipError_t launch_rebalance(KeyArr src_keys, const double* src_vals, const uint64_t* src_occ,
                             int64_t src_ws, int64_t src_we, bool src_packed,
-                            int64_t* dst_keys, double* dst_vals, uint64_t* dst_occ,
+                            KeyArr dst_keys, double* dst_vals, uint64_t* dst_occ,
                             int64_t dst_ws, int64_t dst_we, int64_t m, int64_t* sems,
                             RebalanceWork* work, hipStream_t stream) {
     MoveArgs a;
@@ -496,7 +512,8 @@ hipError_t launch_rebalance(const int64_t* src_keys, const double* src_vals, con
     { static const char* e = getenv("DSA_DBG_MOVE"); a.dbg = e ? atoi(e) : 0; }
     const int64_t ndst = (a.Wd + DST_TILE - 1) / DST_TILE;
     if (src_packed) {
-        hipLaunchKernelGGL(k_move<true>, dim3((unsigned)ndst), dim3(MOVE_BLOCK), 0, stream, a);
+        if (a.src_keys.wide) hipLaunchKernelGGL((k_move<true, true>), dim3((unsigned)ndst), dim3(MOVE_BLOCK), 0, stream, a);
+        else hipLaunchKernelGGL((k_move<true, false>), dim3((unsigned)ndst), dim3(MOVE_BLOCK), 0, stream, a);
         return hipGetLastError();
     }
     const int64_t nwords = (a.src_hi0 >> 6) - a.src_w0 + 1;
@@ -508,7 +525,8 @@ hipError_t launch_rebalance(const int64_t* src_keys, const double* src_vals, con
     hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, stream, work->tile_cnt, work->tile_off, ntiles);
     a.tile_off = work->tile_off; a.ntiles = ntiles;
     a.tiles_per_cell = m > 0 ? (double)ntiles / (double)m : 0.0;
-    hipLaunchKernelGGL(k_move<false>, dim3((unsigned)ndst), dim3(MOVE_BLOCK), 0, stream, a);
+    if (a.src_keys.wide) hipLaunchKernelGGL((k_move<false, true>), dim3((unsigned)ndst), dim3(MOVE_BLOCK), 0, stream, a);
+    else hipLaunchKernelGGL((k_move<false, false>), dim3((unsigned)ndst), dim3(MOVE_BLOCK), 0, stream, a);
     return hipGetLastError();
 }
 

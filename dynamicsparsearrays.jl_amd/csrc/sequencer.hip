@@ -36,7 +36,7 @@ constexpr int64_t SMALL_W = 8192;
 constexpr int RERUN = 0x100;
 
 struct Seq {
-    int64_t* keys; double* vals; uint64_t* occ;
+    KeyArr keys; double* vals; uint64_t* occ;
     int64_t* sems; int64_t* col_keys; uint8_t* col_live;
     Ctl* ctl;
     int64_t capacity, seg, height, nb_elements, nb_partitions, table_len, table_cap;
@@ -702,7 +702,7 @@ __global__ __launch_bounds__(SEQ_BLOCK) void k_append_run(uint64_t* occ, Ctl* ct
     __shared__ int64_t sLo[MAX_LEVELS], sHi[MAX_LEVELS];
     for (int k = threadIdx.x; k < MEMO_WORDS; k += SEQ_BLOCK) sMemo.words[k] = 0ull;      // 0 = entry not computed yet
     Seq S;
-    S.keys = nullptr; S.vals = nullptr; S.occ = occ; S.sems = nullptr; S.col_keys = nullptr; S.col_live = nullptr; S.ctl = ctl;
+    S.keys = KeyArr{nullptr, 1, 0}; S.vals = nullptr; S.occ = occ; S.sems = nullptr; S.col_keys = nullptr; S.col_live = nullptr; S.ctl = ctl;
     S.capacity = ctl->capacity; S.seg = ctl->segment_capacity; S.height = ctl->height;
     S.nb_elements = ctl->nb_elements; S.nb_partitions = 0; S.table_len = 0; S.table_cap = 0;
     S.stat_window_slots = ctl->stat_window_slots; S.stat_rebalances = ctl->stat_rebalances;
@@ -1206,7 +1206,7 @@ __device__ int d_exec(Seq& S, const Op& op) {
     }
 }
 
-__global__ __launch_bounds__(SEQ_BLOCK) void k_sequencer(int64_t* keys, double* vals, uint64_t* occ, int64_t* sems,
+__global__ __launch_bounds__(SEQ_BLOCK) void k_sequencer(KeyArr keys, double* vals, uint64_t* occ, int64_t* sems,
                                                          int64_t* col_keys, uint8_t* col_live, Ctl* ctl,
                                                          const Op* ops, int64_t n_ops, int64_t n_avail, int run_ok) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -1280,7 +1280,7 @@ __global__ __launch_bounds__(SEQ_BLOCK) void k_sequencer(int64_t* keys, double* 
     }
 }
 
-hipError_t launch_sequencer(int64_t* keys, double* vals, uint64_t* occ, int64_t* sems, int64_t* col_keys,
+hipError_t launch_sequencer(KeyArr keys, double* vals, uint64_t* occ, int64_t* sems, int64_t* col_keys,
                             uint8_t* col_live, Ctl* ctl, const Op* ops, int64_t n_ops, int64_t n_avail, bool run_ok,
                             hipStream_t stream) {
     static bool configured = false;
@@ -1299,7 +1299,7 @@ hipError_t launch_sequencer(int64_t* keys, double* vals, uint64_t* occ, int64_t*
 // ---- batched read-only lookups -----------------------------------------------------------------------
 // getindex(pma,key) src/pma.jl:189-193 ; getindex(pcsc,key,partition) src/pcsr.jl:222-232 ;
 // getindex(mpcsc,row,col) src/pcsr.jl:261-267.  One lane per query; each lane replays the reference's bisection.
-__global__ void k_get_batch(int mode, const int64_t* keys, const double* vals, const uint64_t* occ, int64_t capacity,
+__global__ void k_get_batch(int mode, KeyArr keys, const double* vals, const uint64_t* occ, int64_t capacity,
                             const int64_t* sems, const int64_t* col_keys, const uint8_t* col_live, int64_t table_len,
                             const int64_t* qa, const int64_t* qb, int64_t n, double* out, int32_t* err_out) {
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -1323,7 +1323,7 @@ __global__ void k_get_batch(int mode, const int64_t* keys, const double* vals, c
     out[i] = (f.has && f.key == key) ? f.val : 0.0;
 }
 
-hipError_t launch_get_batch(int mode, const int64_t* keys, const double* vals, const uint64_t* occ, int64_t capacity,
+hipError_t launch_get_batch(int mode, KeyArr keys, const double* vals, const uint64_t* occ, int64_t capacity,
                             const int64_t* sems, const int64_t* col_keys, const uint8_t* col_live, int64_t table_len,
                             const int64_t* qa, const int64_t* qb, int64_t n, double* out, int32_t* err_out,
                             hipStream_t stream) {
@@ -1338,7 +1338,7 @@ hipError_t launch_get_batch(int mode, const int64_t* keys, const double* vals, c
 // report[0] = occupied cells, [1] = semaphore cells, [2] = semaphore cells whose table entry does not point back,
 // [3] = key-order violations inside a partition (or anywhere, for a plain vector), [4] = live table entries that do not
 // point at a semaphore cell holding their id, [5] = occupancy bits at or beyond the capacity
-__global__ void k_check_slots(const int64_t* keys, const double* vals, const uint64_t* occ, int64_t capacity, int64_t occ_words,
+__global__ void k_check_slots(KeyArr keys, const double* vals, const uint64_t* occ, int64_t capacity, int64_t occ_words,
                               const int64_t* sems, int64_t table_len, unsigned long long* report) {
     const int64_t s0 = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;      // 0-based slot
     unsigned long long n_occ = 0, n_sem = 0, bad_sem = 0, bad_order = 0;
@@ -1375,7 +1375,7 @@ __global__ void k_check_slots(const int64_t* keys, const double* vals, const uin
         if (beyond) atomicAdd(&report[5], beyond);
     }
 }
-__global__ void k_check_table(const int64_t* keys, const double* vals, const uint64_t* occ, int64_t capacity, const int64_t* sems,
+__global__ void k_check_table(KeyArr keys, const double* vals, const uint64_t* occ, int64_t capacity, const int64_t* sems,
                               const int64_t* col_keys, const uint8_t* col_live, int64_t table_len, unsigned long long* report) {
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (i >= table_len) return;
@@ -1392,7 +1392,7 @@ __global__ void k_check_table(const int64_t* keys, const double* vals, const uin
     } else if (col_live != nullptr && col_live[i]) bad = true;
     if (bad) atomicAdd(&report[4], 1ull);
 }
-hipError_t launch_check(const int64_t* keys, const double* vals, const uint64_t* occ, int64_t capacity, int64_t occ_words,
+hipError_t launch_check(KeyArr keys, const double* vals, const uint64_t* occ, int64_t capacity, int64_t occ_words,
                         const int64_t* sems, const int64_t* col_keys, const uint8_t* col_live, int64_t table_len,
                         unsigned long long* report, hipStream_t stream) {
     hipError_t e = hipMemsetAsync(report, 0, 8 * sizeof(unsigned long long), stream);
@@ -1426,10 +1426,10 @@ __global__ void k_partition_range(const int64_t* sems, const int64_t* col_keys, 
 // meta[1] = to, meta[2] = error code, meta[3] = partition id, meta[4] = number of cells or -1 when the range is longer (the
 // caller then takes the general K-pack path).  Column views and deletecolumn! / deleterow! need one host round trip this way.
 constexpr int64_t VIEW_SMALL_SLOTS = 16384;
-__global__ __launch_bounds__(64) void k_view_small(const int64_t* __restrict__ keys, const double* __restrict__ vals,
+__global__ __launch_bounds__(64) void k_view_small(KeyArr keys, const double* __restrict__ vals,
                                                    const uint64_t* __restrict__ occ, const int64_t* sems, const int64_t* col_keys,
                                                    const uint8_t* col_live, int64_t table_len, int64_t capacity, int64_t col,
-                                                   int64_t* __restrict__ out_k, double* __restrict__ out_v, int64_t out_cap, int64_t* meta) {
+                                                   KeyArr out_k, double* __restrict__ out_v, int64_t out_cap, int64_t* meta) {
     const int lane = threadIdx.x;
     int64_t from = 0, to = 0, err = 0, pid = 0;
     const DFoundKey f = d_find_table(col_keys, col_live, table_len, col);
@@ -1461,8 +1461,8 @@ __global__ __launch_bounds__(64) void k_view_small(const int64_t* __restrict__ k
     }
     if (lane == 0) { meta[0] = from; meta[1] = to; meta[2] = err; meta[3] = pid; meta[4] = cnt; }
 }
-hipError_t launch_view_small(const int64_t* keys, const double* vals, const uint64_t* occ, const int64_t* sems, const int64_t* col_keys,
-                             const uint8_t* col_live, int64_t table_len, int64_t capacity, int64_t col, int64_t* out_k, double* out_v,
+hipError_t launch_view_small(KeyArr keys, const double* vals, const uint64_t* occ, const int64_t* sems, const int64_t* col_keys,
+                             const uint8_t* col_live, int64_t table_len, int64_t capacity, int64_t col, KeyArr out_k, double* out_v,
                              int64_t out_cap, int64_t* meta, hipStream_t stream) {
     hipLaunchKernelGGL(k_view_small, dim3(1), dim3(64), 0, stream, keys, vals, occ, sems, col_keys, col_live, table_len, capacity, col, out_k,
                        out_v, out_cap, meta);

@@ -15,6 +15,7 @@
 // Bound: HBM / fabric.  Algorithmic bytes per launch = 16*capacity + 8*nx + 8*ny: the flat
 // scan streams every slot (gaps included — they are part of the bit-identical layout) once.
 #include "dsa_dev.h"
+#include <type_traits>
 
 namespace dsa {
 
@@ -33,7 +34,7 @@ __device__ __forceinline__ double wave_reduce_add_f64(double v) {
 
 // partition id (1-based) whose semaphore is the last one located at a 0-based slot < b0, or 0.
 // Executed by one full wave.
-__device__ int64_t carry_in_partition(const int64_t* __restrict__ keys, const double* __restrict__ vals,
+__device__ int64_t carry_in_partition(KeyArr keys, const double* __restrict__ vals,
                                       const uint64_t* __restrict__ occ, const int64_t* __restrict__ sems,
                                       int64_t table_len, int64_t b0) {
     const int lane = lane_id();
@@ -63,7 +64,7 @@ __device__ int64_t carry_in_partition(const int64_t* __restrict__ keys, const do
 
 // scatter form: one 256-thread workgroup per 2048-slot tile; wave w owns 8 occupancy words, lane <-> slot; values and
 // semaphore ids are staged in LDS, every cell finds the semaphore in front of it from the per-word semaphore ballots.
-__global__ __launch_bounds__(SP_BLOCK) void k_spmv_scatter(const int64_t* __restrict__ keys, const double* __restrict__ vals,
+__global__ __launch_bounds__(SP_BLOCK) void k_spmv_scatter(KeyArr keys, const double* __restrict__ vals,
                                                    const uint64_t* __restrict__ occ, int64_t capacity,
                                                    const int64_t* __restrict__ sems,
                                                    const int64_t* __restrict__ part_keys, int64_t table_len,
@@ -103,7 +104,7 @@ __global__ __launch_bounds__(SP_BLOCK) void k_spmv_scatter(const int64_t* __rest
             // streamed once: non-temporal, so that the slot streams do not evict x from the XCD's L2
             const uint64_t word = __builtin_nontemporal_load(occ + (s >> 6));
             bit[j] = (word >> lane) & 1ull;
-            if (bit[j]) { k[j] = __builtin_nontemporal_load(keys + s); v[j] = __builtin_nontemporal_load(vals + s); }
+            if (bit[j]) { k[j] = keys.ld_nt(s); v[j] = __builtin_nontemporal_load(vals + s); }
         }
     }
     int nsem = 0;
@@ -186,12 +187,15 @@ __device__ __forceinline__ double product_of(double v, double xv, bool count_pas
     return count_pass ? (xv != 0.0 ? 1.0 : 0.0) : v * xv;
 }
 
-__global__ __launch_bounds__(SP_BLOCK) void k_spmv_gather(const int64_t* __restrict__ keys, const double* __restrict__ vals,
+template <bool WIDE>
+__global__ __launch_bounds__(SP_BLOCK) void k_spmv_gather(KeyArr keys, const double* __restrict__ vals,
                                                           const uint64_t* __restrict__ occ, int64_t capacity,
                                                           const int64_t* __restrict__ sems,
                                                           const int64_t* __restrict__ part_keys, int64_t table_len,
                                                           const double* __restrict__ x, int64_t nx,
                                                           double* __restrict__ y, int64_t ny, int pattern) {
+    typedef typename std::conditional<WIDE, int64_t, int32_t>::type key_t;      // physical key width, fixed at compile time for the streams
+    const key_t* __restrict__ kp = static_cast<const key_t*>(keys.p);
     __shared__ double sPw[SP_WAVES][SW_SLOTS];
     __shared__ uint16_t sListw[SP_WAVES][SW_SLOTS];
     const int lane = threadIdx.x & 63;
@@ -218,13 +222,13 @@ __global__ __launch_bounds__(SP_BLOCK) void k_spmv_gather(const int64_t* __restr
 #pragma unroll
     for (int j = 0; j <= SW_WORDS; ++j) {
         const int64_t w = w0 + j < nwords ? w0 + j : nwords - 1;
-        k[j] = __builtin_nontemporal_load(keys + (w << 6) + lane);
+        k[j] = (int64_t)__builtin_nontemporal_load(kp + (w << 6) + lane);
         v[j] = __builtin_nontemporal_load(vals + (w << 6) + lane);
     }
     // the word in front: does the previous span own the cells before our first semaphore?
     const int64_t pw = w0 > 0 ? w0 - 1 : 0;
     const uint64_t pword = w0 > 0 ? occ[pw] : 0ull;
-    const int64_t pk = keys[(pw << 6) + lane];
+    const int64_t pk = (int64_t)kp[(pw << 6) + lane];
 
     // ---- semaphore ballots, one gather per lane and word -----------------------------------------------------------------
     uint64_t sb[SW_WORDS + 1], cm[SW_WORDS + 1];
@@ -359,7 +363,7 @@ __global__ __launch_bounds__(SP_BLOCK) void k_spmv_gather(const int64_t* __restr
 // semaphore-1 (src/operations.jl:81-95) — and accumulate x_j * coeff into y[row] with fp64 atomics; every touched
 // row is flagged (a row whose products cancel or are zero still belongs to the result, src/operations.jl:101).
 // Work is proportional to the cells of the matched columns, not to the capacity.
-__global__ __launch_bounds__(256) void k_spmv_xdriven(const int64_t* __restrict__ keys, const double* __restrict__ vals,
+__global__ __launch_bounds__(256) void k_spmv_xdriven(KeyArr keys, const double* __restrict__ vals,
                                                       const uint64_t* __restrict__ occ, int64_t capacity,
                                                       const int64_t* __restrict__ sems, const int64_t* __restrict__ col_keys,
                                                       const uint8_t* __restrict__ col_live, int64_t table_len,
@@ -408,7 +412,7 @@ __global__ __launch_bounds__(256) void k_spmv_xdriven(const int64_t* __restrict_
     }
 }
 
-hipError_t launch_spmv_xdriven(const int64_t* keys, const double* vals, const uint64_t* occ, int64_t capacity,
+hipError_t launch_spmv_xdriven(KeyArr keys, const double* vals, const uint64_t* occ, int64_t capacity,
                                const int64_t* sems, const int64_t* col_keys, const uint8_t* col_live, int64_t table_len,
                                const int64_t* xi, const double* xv, int64_t nx, double* y, uint8_t* touched, int64_t ny,
                                hipStream_t stream) {
@@ -441,7 +445,7 @@ hipError_t launch_scatter_x(const int64_t* xi, const double* xv, int64_t nx, dou
 }
 
 #include <cstdlib>
-static hipError_t launch_spmv(bool scatter, int pattern, const int64_t* keys, const double* vals, const uint64_t* occ, int64_t capacity,
+static hipError_t launch_spmv(bool scatter, int pattern, KeyArr keys, const double* vals, const uint64_t* occ, int64_t capacity,
                               const int64_t* sems, const int64_t* part_keys, int64_t table_len, const double* x, int64_t nx,
                               double* y, int64_t ny, hipStream_t stream) {
     hipError_t e = hipMemsetAsync(y, 0, (size_t)ny * sizeof(double), stream);
@@ -452,18 +456,21 @@ static hipError_t launch_spmv(bool scatter, int pattern, const int64_t* keys, co
     if (scatter)
         hipLaunchKernelGGL(k_spmv_scatter, dim3((unsigned)grid), dim3(SP_BLOCK), 0, stream, keys, vals, occ, capacity, sems,
                            part_keys, table_len, x, nx, y, ny, 0);
+    else if (keys.wide)
+        hipLaunchKernelGGL(k_spmv_gather<true>, dim3((unsigned)grid), dim3(SP_BLOCK), 0, stream, keys, vals, occ, capacity, sems,
+                           part_keys, table_len, x, nx, y, ny, pattern);
     else
-        hipLaunchKernelGGL(k_spmv_gather, dim3((unsigned)grid), dim3(SP_BLOCK), 0, stream, keys, vals, occ, capacity, sems,
+        hipLaunchKernelGGL(k_spmv_gather<false>, dim3((unsigned)grid), dim3(SP_BLOCK), 0, stream, keys, vals, occ, capacity, sems,
                            part_keys, table_len, x, nx, y, ny, pattern);
     return hipGetLastError();
 }
 
-hipError_t launch_spmv_gather(const int64_t* keys, const double* vals, const uint64_t* occ, int64_t capacity,
+hipError_t launch_spmv_gather(KeyArr keys, const double* vals, const uint64_t* occ, int64_t capacity,
                               const int64_t* sems, const int64_t* part_keys, const uint8_t*, int64_t table_len,
                               const double* x, int64_t nx, double* y, int64_t ny, int pattern, hipStream_t stream) {
     return launch_spmv(false, pattern, keys, vals, occ, capacity, sems, part_keys, table_len, x, nx, y, ny, stream);
 }
-hipError_t launch_spmv_scatter(const int64_t* keys, const double* vals, const uint64_t* occ, int64_t capacity,
+hipError_t launch_spmv_scatter(KeyArr keys, const double* vals, const uint64_t* occ, int64_t capacity,
                                const int64_t* sems, const int64_t* part_keys, const uint8_t*, int64_t table_len,
                                const double* x, int64_t nx, double* y, int64_t ny, hipStream_t stream) {
     return launch_spmv(true, 0, keys, vals, occ, capacity, sems, part_keys, table_len, x, nx, y, ny, stream);

@@ -859,6 +859,50 @@ def test_device_checker_counts_on_small_structures(dsa, hip):
     assert r[0] == 3 and not r[2:7].any()
 
 
+def test_wide_keys_and_widening(dsa, hip, oracle):
+    """Keys are kept in 32 bits in HBM until the first key outside Int32 (KeyArr, csrc/dsa_dev.h): structures built wide, structures
+    widened by a later write (vector keys, matrix row keys, matrix column keys separately), values straddling +-2^31, and the usual
+    observers (layout export, views, lookups) on both sides of the switch."""
+    big = [2**31 - 1, 2**31, 2**31 + 5, 2**40 + 3, -(2**31), -(2**31) - 1, -(2**45)]
+    # vector: narrow -> widened by a batch, then more writes
+    ks = np.arange(1, 5001, dtype=np.int64) * 7
+    va = [dsa.dynamicsparsevec(ks, ks.astype(np.float64), binding=b) for b in (hip, oracle)]
+    for v in va:
+        v.set_batch(np.array(big, dtype=np.int64), np.arange(1, len(big) + 1, dtype=np.float64))
+        v.set_batch(ks[:300] + 1, np.ones(300))
+        v[2**33] = 4.5
+        v[2**33] = 0.0
+    ka, kb = va[0].export_layout(), va[1].export_layout()
+    assert np.array_equal(ka[2], kb[2])
+    occ = ka[2].astype(bool)
+    assert np.array_equal(ka[0][occ], kb[0][occ]) and np.array_equal(ka[1][occ], kb[1][occ])
+    assert va[0][2**40 + 3] == va[1][2**40 + 3] == 4.0
+    # vector built wide from the start
+    wa = [dsa.dynamicsparsevec(np.array(sorted(big) + [5, 6]), np.arange(9, dtype=np.float64) + 1, binding=b) for b in (hip, oracle)]
+    assert np.array_equal(wa[0].export_layout()[0][wa[0].export_layout()[2].astype(bool)], wa[1].export_layout()[0][wa[1].export_layout()[2].astype(bool)])
+    # matrix: first narrow, then a huge ROW key (colmajor keys widen), then a huge COLUMN key (rowmajor keys widen)
+    I = 1 + (splitmix_array(71, 4000) % np.uint64(900)).astype(np.int64)
+    J = 1 + (splitmix_array(72, 4000) % np.uint64(700)).astype(np.int64)
+    V = (1 + splitmix_array(73, 4000) % np.uint64(9)).astype(np.float64)
+    ms = [dsa.dynamicsparse(I, J, V, binding=b) for b in (hip, oracle)]
+    assert_mat_equal(*ms)
+    for step, (ii, jj) in enumerate([([2**35, 3, 4], [5, 5, 6]), ([7, 8], [2**34 + 1, 9]), ([2**35, 2**35 + 1], [2**34 + 1, 2**34 + 2])]):
+        for m_ in ms:
+            m_.set_batch(ii, jj, [1.5 + step] * len(ii))
+        assert_mat_equal(*ms)
+    big_batch_i = np.concatenate([I[:500] + 1, np.array([2**36, 2**36 + 1])])
+    big_batch_j = np.concatenate([J[:500], np.array([3, 2**37])])
+    for m_ in ms:
+        m_.set_batch(big_batch_i, big_batch_j, np.ones(len(big_batch_i)))          # batch-parallel path with wide keys
+    assert_mat_equal(*ms)
+    assert ms[0].col_view(5) == ms[1].col_view(5) and ms[0].row_view(2**35) == ms[1].row_view(2**35)
+    assert np.array_equal(ms[0].get_batch([2**35, 7, 1], [5, 2**34 + 1, 1]), ms[1].get_batch([2**35, 7, 1], [5, 2**34 + 1, 1]))
+    # (no SpMV here: with indices beyond 2^31 the dense result vector of the product would not fit any memory)
+    # matrix built wide from the start
+    mw = [dsa.dynamicsparse(np.array([1, 2**33, 5]), np.array([2**32 + 7, 2, 2]), np.array([1.0, 2.0, 3.0]), binding=b) for b in (hip, oracle)]
+    assert_mat_equal(*mw)
+
+
 def test_differential_fuzz_short(dsa, hip, oracle):
     """60 scenarios of tools/fuzz.py (random write batches: column / row streams, delete- and overwrite-heavy mixes, negative keys,
     tombstones, vectors) — HIP vs oracle after every batch.  The long run is `python tools/fuzz.py 240` (1540 scenarios clean in round 1)."""
