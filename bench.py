@@ -195,6 +195,7 @@ def main():
         "config": {"workload": "C3: PCSR %dx%d Float64, %d nnz per GPU, dense-x SpMV y=A*x (gather over the rowmajor twin)"
                                % (m, ncl * world, nnz),
                    "capacity_slots": cap, "density": round((nnz + m) / cap, 4), "sharding": "column-range x%d" % world,
+                   "physical_slot_bytes": 16 if os.environ.get("DSA_KEYS_WIDE") == "1" else 12,      # int32 keys in HBM while every key fits Int32 (KeyArr)
                    "collective": ("RCCL all_reduce(y, %d f64) on its own stream, overlapped with the next step's SpMV (two y buffers)" % m) if world > 1 else "none"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
@@ -213,7 +214,7 @@ def main():
     if os.path.exists(pmc) and m == 1_000_000 and ncl == 1_000_000 and per == 10:
         with open(pmc) as f:
             pm = json.load(f)
-        out["roofline"]["traffic"] = pm["k_spmv_gather_C3"]["corrected_traffic_total"]
+        out["roofline"]["traffic"] = pm.get("k_spmv_gather_C3", {}).get("corrected_traffic_total")
         out["roofline"]["traffic_source"] = "profiles/r01_final_pmc_summary.json (rocprofv3 --pmc, corrected)"
     if rank == 0 and world == 1 and not args.no_extras:          # the extra legs and the CPU baseline belong to the N = 1 line
         try:
@@ -221,7 +222,7 @@ def main():
         except Exception as e:               # an extra leg must never cost the headline line
             out["extras_error"] = "%s: %s" % (type(e).__name__, str(e)[:300])
         if pm is not None and "roofline_rebalance" in out:
-            out["roofline_rebalance"]["traffic"] = pm["k_move_root_2^24"]["corrected_traffic_total"] \
+            out["roofline_rebalance"]["traffic"] = pm.get("k_move_root_2^24", {}).get("corrected_traffic_total") \
                 if out["roofline_rebalance"]["window_slots"] == 16777216 else None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
@@ -256,7 +257,7 @@ def extras(dsa, hip, torch, A, dev):
     res["roofline_rebalance"] = {"bound": "hbm", "achieved": round(b / 1e9 / (ms / 1e3), 2), "peak": HBM_PEAK_GBS,
                                  "unit": "GB/s", "frac": round(b / 1e9 / (ms / 1e3) / HBM_PEAK_GBS, 4),
                                  "window_slots": cap, "algorithmic_bytes": b, "ms": round(ms, 5),
-                                 "kernels": "k_tile_count + k_tile_scan + k_move<false>"}
+                                 "kernels": "k_tile_count + k_tile_scan + k_move<false, WIDE=false>"}
     # --- the isolated rebalance on full windows of 2^20 / 2^21 / 2^24 slots at densities 0.35 / 0.70:
     #     a vector's PMA built from n = density * capacity keys, root pack + spread timed back to back
     sweep = []
