@@ -916,3 +916,16 @@ def test_differential_fuzz_short(dsa, hip, oracle):
         r = fz.run_matrix(seed) if seed % 4 else fz.run_vector(seed)
         res[r] = res.get(r, 0) + 1
     assert res.get("ok", 0) >= 30, res
+
+
+def test_forced_64bit_keys_build_in_a_subprocess(dsa, hip, oracle):
+    """DSA_KEYS_WIDE=1 (read when the library is loaded) keeps every structure in 64-bit keys: the wide instantiations of the
+    streaming kernels and the wide side of the key proxy stay covered — 12 s of the differential fuzzer in a child process."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DSA_KEYS_WIDE="1")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz.py"), "12", "12345"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "fuzz done" in r.stdout
