@@ -257,7 +257,7 @@ def extras(dsa, hip, torch, A, dev):
     res["roofline_rebalance"] = {"bound": "hbm", "achieved": round(b / 1e9 / (ms / 1e3), 2), "peak": HBM_PEAK_GBS,
                                  "unit": "GB/s", "frac": round(b / 1e9 / (ms / 1e3) / HBM_PEAK_GBS, 4),
                                  "window_slots": cap, "algorithmic_bytes": b, "ms": round(ms, 5),
-                                 "kernels": "k_tile_count + k_tile_scan + k_move<false, WIDE=false>"}
+                                 "kernels": "k_tile_count2 + k_move<false, WIDE=false>"}
     # --- the isolated rebalance on full windows of 2^20 / 2^21 / 2^24 slots at densities 0.35 / 0.70:
     #     a vector's PMA built from n = density * capacity keys, root pack + spread timed back to back
     sweep = []

@@ -9,8 +9,10 @@
 // Bound: HBM.  Algorithmic bytes per W-slot window = 2 * 16 * W (read + write every slot);
 // the occupancy bitmap (W/8 B each way) and the tile counters are not counted.
 //
-//   k_tile_count : cells per 4096-slot source tile, lane <-> occupancy word, popcount + wave reduce (16 tiles per workgroup)
-//   k_tile_scan  : one workgroup, exclusive prefix of the tile counts
+//   k_tile_count2: cells per 4096-slot source tile (lane <-> occupancy word, popcount + wave reduce), written as a
+//                  two-level prefix: exclusive prefix inside each group of 64 tiles + one total per group.  No scan
+//                  kernel: k_move adds the totals of the groups in front itself (one wave-wide load + reduce).
+//   k_tile_count / k_tile_scan : flat prefix (count, then a one-workgroup scan) for k_compact / k_permute / views
 //   k_move       : one workgroup per 2048-slot DESTINATION tile.  Source cells whose rank falls in
 //                  the tile are compacted into LDS with wave64 ballot-style prefix popcounts (only
 //                  occupancy words that intersect the rank range are touched, so each source line is
@@ -102,6 +104,39 @@ __global__ __launch_bounds__(1024) void k_tile_scan(const uint32_t* __restrict__
     if (tid == 0) off[n] = carry;
 }
 
+// k_tile_count2: the prefix source of k_move in ONE launch, no scan kernel.  Workgroup g counts the occupied slots of the 64
+// source tiles of group g (16 waves; wave w: tiles 64g+4w .. +3, lane <-> occupancy word), writes their exclusive prefix INSIDE the group
+// (local_off) and the group total (coarse); k_move adds the totals of the groups in front — one wave-wide load + reduce, issued
+// together with the local_off load, so a lookup costs one memory round trip like a read of a global prefix table would.
+constexpr int CNT2_SHIFT = 6, CNT2_TILES = 1 << CNT2_SHIFT, CNT2_THREADS = CNT2_TILES / 4 * 64;
+__global__ __launch_bounds__(CNT2_THREADS) void k_tile_count2(const uint64_t* __restrict__ occ, int64_t lo0, int64_t hi0, int64_t w0,
+                                                     int64_t nwords, int64_t ntiles, uint32_t* __restrict__ local_off,
+                                                     uint32_t* __restrict__ coarse) {
+    __shared__ uint32_t sT[CNT2_TILES];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    uint32_t pc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t t = (int64_t)blockIdx.x * CNT2_TILES + wv * 4 + i;
+        const int64_t w = t * SRC_TILE_WORDS + lane;
+        pc[i] = 0;
+        if (t < ntiles && w < nwords) pc[i] = popc64(occ[w0 + w] & range_mask_for_word(w0 + w, lo0, hi0));
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t r = wave_reduce_add(pc[i]);
+        if (lane == 0) sT[wv * 4 + i] = r;
+    }
+    __syncthreads();
+    if (wv == 0) {
+        const uint32_t v = lane < CNT2_TILES ? sT[lane] : 0u;
+        const uint32_t ex = wave_excl_scan(v);
+        const int64_t t = (int64_t)blockIdx.x * CNT2_TILES + lane;
+        if (lane < CNT2_TILES && t < ntiles) local_off[t] = ex;
+        if (lane == CNT2_TILES - 1) coarse[blockIdx.x] = ex + v;
+    }
+}
+
 struct MoveArgs {
     KeyArr src_keys; const double* src_vals; const uint64_t* src_occ;
     int64_t src_lo0, src_hi0;      // 0-based inclusive source slot range
@@ -111,9 +146,19 @@ struct MoveArgs {
     int64_t Wd, m;
     int64_t* sems;
     const uint32_t* tile_off; int64_t ntiles;
+    const uint32_t* coarse;         // cells per group of 64 source tiles; tile_off then holds the prefix INSIDE the group (k_tile_count2)
     double tiles_per_cell;          // ntiles / m: interpolation guess for the source tile of a rank
     int dbg;   // DSA_DBG_MOVE ablation knob (dev only): 1 = skip staging, 2 = skip the write phase
 };
+
+
+// prefix lookups over the two-level table of k_tile_count2 (wave-uniform arguments).
+// group_prefix(g): cells in the groups in front of group g — one wave-wide load + reduce per 64 groups (one for <= 2^24 slots).
+static __device__ __forceinline__ int64_t group_prefix(const uint32_t* __restrict__ coarse, int64_t g, int lane) {
+    uint32_t sum = 0;
+    for (int64_t b = lane; b < g; b += 64) sum += coarse[b];     // 32-bit: a PMA holds < 2^32 cells (tile_off is 32-bit too)
+    return wave_reduce_add(sum);
+}
 
 template <bool PACKED, bool WIDE>
 __global__ __launch_bounds__(MOVE_BLOCK) void k_move(MoveArgs a) {
@@ -136,39 +181,43 @@ __global__ __launch_bounds__(MOVE_BLOCK) void k_move(MoveArgs a) {
     if (!PACKED && a.dbg != 1) {
         // ---- locate the first source tile holding rank R0+1: the largest t with tile_off[t] <= R0.
         // Interpolated guess + short walk (cell density is near-uniform after a spread); bisection fallback.
+        // Each probe issues its loads together (the two in-group prefixes, the group totals): one memory round trip.
         int64_t lo = 0;
+        int64_t cg = -1, cP = 0;                 // cached group prefix
         if (cnt > 0) {
             lo = (int64_t)((double)R0 * a.tiles_per_cell);
             if (lo > a.ntiles - 1) lo = a.ntiles - 1;
+            int64_t l = 0, h = a.ntiles - 1;     // the answer lies in [l, h]
             int steps = 0;
-            while (steps < 6) {
-                const int64_t o0 = a.tile_off[lo], o1 = a.tile_off[lo + 1];
-                if (o0 > R0) { if (lo == 0) break; --lo; }
-                else if (o1 <= R0 && lo < a.ntiles - 1) ++lo;
+            while (true) {
+                const int64_t gl = lo >> CNT2_SHIFT;
+                const bool edge = (lo + 1 >= a.ntiles) || ((lo + 1) >> CNT2_SHIFT) != gl;     // lo is the last tile of its group
+                const uint32_t l0 = a.tile_off[lo];
+                const uint32_t l1 = edge ? a.coarse[gl] : a.tile_off[lo + 1];
+                if (gl != cg) { cP = group_prefix(a.coarse, gl, lane); cg = gl; }
+                const int64_t o0 = cP + l0, o1 = cP + l1;
+                if (o0 > R0) h = lo - 1;
+                else if (o1 <= R0 && lo < a.ntiles - 1) l = lo + 1;
                 else break;
+                if (l >= h) { lo = l; break; }
                 ++steps;
-            }
-            if (steps >= 6) {
-                int64_t l = 0, h = a.ntiles - 1;
-                while (l < h) {
-                    const int64_t mid = (l + h + 1) >> 1;
-                    if ((int64_t)a.tile_off[mid] <= R0) l = mid; else h = mid - 1;
-                }
-                lo = l;
+                lo = steps < 6 ? (o0 > R0 ? lo - 1 : lo + 1) : ((l + h + 1) >> 1);   // short walk, then bisection
             }
         }
         // ---- passes of MOVE_BLOCK/64 source tiles: wave w describes tile tb+w (word masks + rank bases) in LDS,
         //      then the intersecting words are dealt round-robin to the waves, 4 words (8 loads) per step.
         __shared__ uint64_t sWM[MOVE_BLOCK];
         __shared__ int32_t sWB[MOVE_BLOCK];        // rank base of the word relative to R0 (clamped)
-        for (int64_t tb = lo; cnt > 0 && tb < a.ntiles && (int64_t)a.tile_off[tb] < R0 + cnt; tb += MOVE_BLOCK / 64) {
+        for (int64_t tb = lo; cnt > 0 && tb < a.ntiles; tb += MOVE_BLOCK / 64) {
             const int64_t t = tb + wv;
             uint64_t myword = 0;
             int64_t base = (int64_t)1 << 40;
             if (t < a.ntiles) {
                 const int64_t wl = a.src_w0 + t * SRC_TILE_WORDS + lane;       // lane <-> word of the tile
                 myword = a.src_occ[wl] & range_mask_for_word(wl, a.src_lo0, a.src_hi0);
-                base = a.tile_off[t];
+                const uint32_t lt = a.tile_off[t];
+                if ((t >> CNT2_SHIFT) != cg) { cg = t >> CNT2_SHIFT; cP = group_prefix(a.coarse, cg, lane); }
+                base = cP + lt;
             }
             const uint32_t mypc = popc64(myword);
             const int64_t wbase = base + wave_excl_scan(mypc) - R0;            // cells of earlier words, relative to R0
@@ -200,6 +249,7 @@ __global__ __launch_bounds__(MOVE_BLOCK) void k_move(MoveArgs a) {
                     if (act[u]) { sK[rk[u]] = kk[u]; sV[rk[u]] = vv[u]; }
             }
             __syncthreads();
+            if (notafter < MOVE_BLOCK) break;      // a word of this pass starts behind the last rank: so does every later one
         }
     }
     __syncthreads();
@@ -508,7 +558,7 @@ hipError_t launch_rebalance(KeyArr src_keys, const double* src_vals, const uint6
     a.dst_lo0 = dst_ws - 1;
     a.Wd = dst_we - dst_ws + 1; a.m = m;
     a.sems = sems;
-    a.tile_off = nullptr; a.ntiles = 0; a.tiles_per_cell = 0.0;
+    a.tile_off = nullptr; a.coarse = nullptr; a.ntiles = 0; a.tiles_per_cell = 0.0;
     { static const char* e = getenv("DSA_DBG_MOVE"); a.dbg = e ? atoi(e) : 0; }
     const int64_t ndst = (a.Wd + DST_TILE - 1) / DST_TILE;
     if (src_packed) {
@@ -520,10 +570,9 @@ hipError_t launch_rebalance(KeyArr src_keys, const double* src_vals, const uint6
     const int64_t ntiles = (nwords + SRC_TILE_WORDS - 1) / SRC_TILE_WORDS;
     if (ntiles + 1 > work->tiles_cap) return hipErrorInvalidValue;
     // the occupancy array is allocated in whole 64-word tiles (see Pma::alloc), so lane <-> word reads stay in bounds
-    hipLaunchKernelGGL(k_tile_count, dim3((unsigned)((ntiles + CNT_TILES - 1) / CNT_TILES)), dim3(256), 0, stream, src_occ, a.src_lo0,
-                       a.src_hi0, a.src_w0, nwords, ntiles, work->tile_cnt);
-    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, stream, work->tile_cnt, work->tile_off, ntiles);
-    a.tile_off = work->tile_off; a.ntiles = ntiles;
+    hipLaunchKernelGGL(k_tile_count2, dim3((unsigned)((ntiles + CNT2_TILES - 1) / CNT2_TILES)), dim3(CNT2_THREADS), 0, stream, src_occ, a.src_lo0,
+                       a.src_hi0, a.src_w0, nwords, ntiles, work->tile_off, work->tile_cnt);
+    a.tile_off = work->tile_off; a.coarse = work->tile_cnt; a.ntiles = ntiles;
     a.tiles_per_cell = m > 0 ? (double)ntiles / (double)m : 0.0;
     if (a.src_keys.wide) hipLaunchKernelGGL((k_move<false, true>), dim3((unsigned)ndst), dim3(MOVE_BLOCK), 0, stream, a);
     else hipLaunchKernelGGL((k_move<false, false>), dim3((unsigned)ndst), dim3(MOVE_BLOCK), 0, stream, a);
