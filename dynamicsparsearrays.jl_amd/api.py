@@ -124,11 +124,40 @@ class DynamicSparseVector(_Handle):
     def __eq__(self, other):                          # src/vector.jl:85-87, src/pma.jl:236-266
         if not isinstance(other, DynamicSparseVector):
             return NotImplemented
-        if len(self) != len(other) or self.nnz() != other.nnz():
-            return False
-        k1, v1 = self.nonzeros()
-        k2, v2 = other.nonzeros()
-        return bool(np.array_equal(k1, k2) and np.array_equal(v1, v2))
+        if other.b is not self.b:
+            raise B.DsaArgumentError(B.EARG, "vectors of two different libraries")
+        out = C.c_int32()
+        self.b.call("vec_equal", self.h, other.h, C.byref(out))
+        return bool(out.value)
+
+    def axpby(self, alpha, other, beta):
+        """alpha*self + beta*other as ascending (keys, values): the SparseVector of v1 + v2 / v1 - v2 / -v
+        (AbstractSparseVector fallbacks over src/vector.jl:93-109; test/functional/math.jl:53-94)."""
+        if other.b is not self.b:
+            raise B.DsaArgumentError(B.EARG, "vectors of two different libraries")
+        cap = max(self.nnz() + other.nnz(), 1)
+        k = np.empty(cap, dtype=np.int64)
+        v = np.empty(cap, dtype=np.float64)
+        out = C.c_int64()
+        self.b.call("vec_axpby", self.h, float(alpha), other.h, float(beta), k.ctypes.data_as(P_I64), v.ctypes.data_as(P_F64),
+                    cap, C.byref(out))
+        return k[:out.value], v[:out.value]
+
+    def __add__(self, other):
+        return self.axpby(1.0, other, 1.0)
+
+    def __sub__(self, other):
+        return self.axpby(1.0, other, -1.0)
+
+    def __neg__(self):
+        k, v = self.nonzeros()
+        return k, -v
+
+    def filter(self, f):
+        """filter(f, v)  src/vector.jl:83 -> src/pma.jl:224-234: a NEW dynamic vector of the stored (key, value) pairs e with f(e)."""
+        k, v = self.nonzeros()
+        sel = np.fromiter((bool(f((int(a), float(b)))) for a, b in zip(k, v)), dtype=bool, count=len(k))
+        return dynamicsparsevec(k[sel], v[sel], binding=self.b)
 
     __hash__ = None
 

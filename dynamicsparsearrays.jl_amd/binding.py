@@ -72,6 +72,8 @@ _SIGS = {
     "vec_len": [VP, P_I64],
     "vec_shrink_size": [VP],
     "vec_nonzeros": [VP, P_I64, P_F64, I64, P_I64],
+    "vec_equal": [VP, VP, P_I32],
+    "vec_axpby": [VP, F64, VP, F64, P_I64, P_F64, I64, P_I64],
     "vec_info": [VP, P_I64],
     "vec_export_layout": [VP, P_I64, P_F64, P_U8, I64],
     "vec_rebalance_root": [VP],

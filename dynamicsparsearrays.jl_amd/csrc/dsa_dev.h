@@ -229,6 +229,10 @@ hipError_t launch_compact_range(KeyArr keys, const double* vals, const uint64_t*
 hipError_t launch_touched_compact(const uint8_t* bytes, const double* pattern, const double* y, int64_t ny, uint64_t* bm,
                                   int64_t* out_i, double* out_v, RebalanceWork* work, int64_t* count, hipStream_t stream);
 hipError_t launch_scatter_x(const int64_t* xi, const double* xv, int64_t nx, double* xd, double* xf, int64_t nxd, hipStream_t stream);
+// whole-vector operations on packed streams (rebalance.hip)
+hipError_t launch_packed_equal(KeyArr ka, const double* va, KeyArr kb, const double* vb, int64_t n, int32_t* differ, hipStream_t stream);
+hipError_t launch_merge_axpby(KeyArr ka, const double* va, int64_t na, double alpha, KeyArr kb, const double* vb, int64_t nb,
+                              double beta, int64_t* mk, double* mv, uint64_t* keep, hipStream_t stream);
 hipError_t launch_widen_keys(const void* src32, void* dst64, int64_t n, hipStream_t stream);
 // clears occupancy bits of slots [from, to] (1-based, inclusive); from/to word-aligned or inside one word
 hipError_t launch_clear_occ(uint64_t* occ, int64_t from, int64_t to, hipStream_t stream);

@@ -1077,6 +1077,81 @@ int32_t dsa_vec_nonzeros(dsa_vec_t* h, int64_t* keys, double* vals, int64_t cap,
     *n_out = (int64_t)ks.size();
     API_CATCH
 }
+// K-pack of the whole vector into its alternate slot buffer (free between rebalances); returns the number of stored cells.
+// Synchronises the vector's stream.
+static int64_t vec_pack_alt(dsa_vec_t* h) {
+    Pma& P = h->P;
+    int64_t cnt = 0;
+    const int alt = 1 - P.cur;
+    hipError_t e = launch_compact_range(P.K(), P.V(), P.O(), 1, P.capacity(), P.KA(alt), P.vals[alt], P.cap_alloc, &P.work, &cnt, P.stream);
+    if (e != hipSuccess) fail(DSA_EHIP, std::string("compact launch: ") + hipGetErrorString(e));
+    return cnt;
+}
+// v1 == v2  src/vector.jl:85-87 (lengths, then src/pma.jl:262-266: nb_elements, then the stored tuples pairwise in slot order,
+// _arrays_equal src/pma.jl:236-260); compared on the device, only the verdict crosses PCIe
+int32_t dsa_vec_equal(dsa_vec_t* a, dsa_vec_t* b, int32_t* out) {
+    API_TRY
+    vec_flush(a);
+    if (a == b) { *out = 1; return DSA_OK; }
+    vec_flush(b);
+    *out = 0;
+    if (a->n != b->n || a->P.h_ctl->nb_elements != b->P.h_ctl->nb_elements) return DSA_OK;
+    const int64_t n = a->P.h_ctl->nb_elements;
+    if (n == 0) { *out = 1; return DSA_OK; }
+    if (vec_pack_alt(a) != n || vec_pack_alt(b) != n) fail(DSA_EASSERT, "stored-cell count differs from nb_elements");
+    Pma &A = a->P, &B = b->P;
+    HIPCHK(hipMemsetAsync(A.d_err, 0, sizeof(int32_t), A.stream));
+    hipError_t e = launch_packed_equal(A.KA(1 - A.cur), A.vals[1 - A.cur], B.KA(1 - B.cur), B.vals[1 - B.cur], n, A.d_err, A.stream);
+    if (e != hipSuccess) fail(DSA_EHIP, std::string("compare launch: ") + hipGetErrorString(e));
+    int32_t differ = 0;
+    HIPCHK(hipMemcpyAsync(&differ, A.d_err, sizeof(int32_t), hipMemcpyDeviceToHost, A.stream));
+    HIPCHK(hipStreamSynchronize(A.stream));
+    *out = differ ? 0 : 1;
+    API_CATCH
+}
+// alpha * a + beta * b as ascending (key, value) pairs — the SparseVector the reference's v1 + v2 / v1 - v2 / -v evaluate to
+// through the AbstractSparseVector fallbacks over nonzeroinds / nonzeros (src/vector.jl:93-109; test/functional/math.jl:53-94).
+// Both operands are packed and merged on the device; a key stored in both keeps one entry unless its value is zero.
+int32_t dsa_vec_axpby(dsa_vec_t* a, double alpha, dsa_vec_t* b, double beta, int64_t* keys, double* vals, int64_t cap, int64_t* n_out) {
+    API_TRY
+    vec_flush(a);
+    if (b != a) vec_flush(b);
+    *n_out = 0;
+    const int64_t na = vec_pack_alt(a);
+    const int64_t nb = b != a ? vec_pack_alt(b) : na;
+    const int64_t total = na + nb;
+    if (total == 0) return DSA_OK;
+    Pma &A = a->P, &B = b->P;
+    const int64_t nwords = (total + 63) >> 6, ntiles = (nwords + 63) / 64;
+    char* scratch = nullptr;
+    const size_t off_mv = (size_t)total * 8, off_ok = 2 * off_mv, off_ov = 3 * off_mv, off_keep = 4 * off_mv,
+                 off_cnt = off_keep + (size_t)nwords * 8, off_off = off_cnt + (size_t)(ntiles + 8) * 4, bytes = off_off + (size_t)(ntiles + 8) * 4;
+    HIPCHK(hipMalloc(&scratch, bytes));
+    try {
+        int64_t* mk = reinterpret_cast<int64_t*>(scratch);
+        double* mv = reinterpret_cast<double*>(scratch + off_mv);
+        int64_t* ok = reinterpret_cast<int64_t*>(scratch + off_ok);
+        double* ov = reinterpret_cast<double*>(scratch + off_ov);
+        uint64_t* keep = reinterpret_cast<uint64_t*>(scratch + off_keep);
+        RebalanceWork work{reinterpret_cast<uint32_t*>(scratch + off_cnt), reinterpret_cast<uint32_t*>(scratch + off_off), ntiles + 8};
+        HIPCHK(hipMemsetAsync(keep, 0, (size_t)nwords * 8, A.stream));
+        hipError_t e = launch_merge_axpby(A.KA(1 - A.cur), A.vals[1 - A.cur], na, alpha, B.KA(1 - B.cur), B.vals[1 - B.cur], nb, beta,
+                                          mk, mv, keep, A.stream);
+        if (e != hipSuccess) fail(DSA_EHIP, std::string("merge launch: ") + hipGetErrorString(e));
+        int64_t cnt = 0;
+        e = launch_compact_range(KeyArr{mk, 1, 0}, mv, keep, 1, total, KeyArr{ok, 1, 0}, ov, total, &work, &cnt, A.stream);
+        if (e != hipSuccess) fail(DSA_EHIP, std::string("compact launch: ") + hipGetErrorString(e));
+        if (cnt > cap) fail(DSA_ECAP, "output buffers too small");
+        if (cnt > 0) {
+            HIPCHK(hipMemcpyAsync(keys, ok, (size_t)cnt * 8, hipMemcpyDeviceToHost, A.stream));
+            HIPCHK(hipMemcpyAsync(vals, ov, (size_t)cnt * 8, hipMemcpyDeviceToHost, A.stream));
+            HIPCHK(hipStreamSynchronize(A.stream));
+        }
+        *n_out = cnt;
+    } catch (...) { hipFree(scratch); throw; }
+    hipFree(scratch);
+    API_CATCH
+}
 int32_t dsa_vec_shrink_size(dsa_vec_t* h) {     // shrink_size!  src/vector.jl:64 (+ _guess_length :7-8)
     API_TRY
     vec_flush(h);

@@ -356,6 +356,65 @@ hipError_t launch_compact_range(KeyArr keys, const double* vals, const uint64_t*
     return hipGetLastError();
 }
 
+// ---- whole-vector operations on two packed (key, value) streams (the output of K-pack): == and a*x + b*y ----
+// v1 == v2 on the stored entries  (src/vector.jl:85-87 -> src/pma.jl:262-266 -> _arrays_equal src/pma.jl:236-260): the i-th
+// stored tuples must compare equal as Julia tuples: Int keys ==, Float64 values == (IEEE: NaN differs from itself, -0.0 == 0.0).
+__global__ __launch_bounds__(256) void k_packed_equal(KeyArr ka, const double* __restrict__ va, KeyArr kb,
+                                                      const double* __restrict__ vb, int64_t n, int32_t* __restrict__ differ) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    bool d = false;
+    if (i < n) d = (ka[i] != kb[i]) || !(va[i] == vb[i]);
+    if (__ballot(d) != 0ull && (threadIdx.x & 63) == 0) atomicOr(differ, 1);
+}
+hipError_t launch_packed_equal(KeyArr ka, const double* va, KeyArr kb, const double* vb, int64_t n, int32_t* differ, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_packed_equal, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, ka, va, kb, vb, n, differ);
+    return hipGetLastError();
+}
+
+// merge of two ascending key streams into one array of na + nb cells, equal keys adjacent (x's cell first): thread i places
+// x[i] at i + lower_bound(y, key) and y[j] at j + upper_bound(x, key).  A key stored in both operands keeps ONE cell (x's slot,
+// value alpha*x + beta*y, dropped when that is zero — the both-stored rule of the sparse-vector +/- the reference falls back
+// to, test/functional/math.jl:53-94); one-sided cells carry alpha*x or beta*y.  `keep` is the occupancy bitmap K-pack consumes.
+static __device__ __forceinline__ int64_t packed_bound(KeyArr k, int64_t n, int64_t key, bool upper) {
+    int64_t lo = 0, hi = n;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        const int64_t c = k[mid];
+        if (c < key || (upper && c == key)) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+__global__ __launch_bounds__(256) void k_merge_axpby(KeyArr ka, const double* __restrict__ va, int64_t na, double alpha,
+                                                     KeyArr kb, const double* __restrict__ vb, int64_t nb, double beta,
+                                                     int64_t* __restrict__ mk, double* __restrict__ mv, uint64_t* __restrict__ keep) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t < na) {
+        const int64_t key = ka[t];
+        const int64_t lb = packed_bound(kb, nb, key, false);
+        const bool both = lb < nb && kb[lb] == key;
+        const double v = both ? __dadd_rn(__dmul_rn(alpha, va[t]), __dmul_rn(beta, vb[lb])) : __dmul_rn(alpha, va[t]);
+        const int64_t p = t + lb;
+        mk[p] = key; mv[p] = v;
+        if (!both || v != 0.0) atomicOr(reinterpret_cast<unsigned long long*>(keep + (p >> 6)), 1ull << (p & 63));
+    } else if (t < na + nb) {
+        const int64_t j = t - na;
+        const int64_t key = kb[j];
+        const int64_t ub = packed_bound(ka, na, key, true);
+        const bool both = ub > 0 && ka[ub - 1] == key;
+        const int64_t p = j + ub;
+        mk[p] = key; mv[p] = __dmul_rn(beta, vb[j]);
+        if (!both) atomicOr(reinterpret_cast<unsigned long long*>(keep + (p >> 6)), 1ull << (p & 63));
+    }
+}
+hipError_t launch_merge_axpby(KeyArr ka, const double* va, int64_t na, double alpha, KeyArr kb, const double* vb, int64_t nb,
+                              double beta, int64_t* mk, double* mv, uint64_t* keep, hipStream_t stream) {
+    if (na + nb <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_merge_axpby, dim3((unsigned)((na + nb + 255) / 256)), dim3(256), 0, stream, ka, va, na, alpha, kb, vb, nb, beta,
+                       mk, mv, keep);
+    return hipGetLastError();
+}
+
 // ---- result of a sparse-x SpMV: (row, value) of the touched rows in ascending row order (the sparsevec of _mul_output,
 // src/operations.jl:11-12,127-134) — K-pack over a bitmap of touched rows instead of the occupancy bitmap
 __global__ __launch_bounds__(256) void k_touched_bitmap(const uint8_t* __restrict__ bytes, const double* __restrict__ pattern,

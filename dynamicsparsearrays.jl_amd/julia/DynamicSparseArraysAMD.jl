@@ -107,6 +107,31 @@ SparseArrays.nonzeros(v::DynamicSparseVector) = _stored(v)[2]
 Base.iterate(v::DynamicSparseVector, st = (zip(_stored(v)...), nothing)) =
     (r = st[2] === nothing ? iterate(st[1]) : iterate(st[1], st[2]); r === nothing ? nothing : (r[1], (st[1], r[2])))
 
+# v1 == v2  (src/vector.jl:85-87): compared on the device, only the verdict comes back
+function Base.:(==)(a::DynamicSparseVector, b::DynamicSparseVector)
+    out = Ref{Int32}(0)
+    _check(ccall((:dsa_vec_equal, libdsa), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ref{Int32}), a.h, b.h, out))
+    return out[] == 1
+end
+# v1 + v2, v1 - v2: the SparseVector the AbstractSparseVector fallbacks of the reference produce (test/functional/math.jl:53-94),
+# merged on the device.  Mixed operands (SparseVector with DynamicSparseVector) and -v keep using the stdlib fallbacks over
+# nonzeroinds / nonzeros above.
+function _axpby(a::DynamicSparseVector, alpha::Float64, b::DynamicSparseVector, beta::Float64)
+    length(a) == length(b) || throw(DimensionMismatch("dimensions must match"))
+    cap = max(nnz(a) + nnz(b), 1); ks = Vector{Int64}(undef, cap); vs = Vector{Float64}(undef, cap); m = Ref{Int64}(0)
+    GC.@preserve ks vs _check(ccall((:dsa_vec_axpby, libdsa), Int32,
+        (Ptr{Cvoid}, Float64, Ptr{Cvoid}, Float64, Ptr{Int64}, Ptr{Float64}, Int64, Ref{Int64}), a.h, alpha, b.h, beta, ks, vs, cap, m))
+    return SparseVector(length(a), resize!(ks, m[]), resize!(vs, m[]))
+end
+Base.:(+)(a::DynamicSparseVector, b::DynamicSparseVector) = _axpby(a, 1.0, b, 1.0)
+Base.:(-)(a::DynamicSparseVector, b::DynamicSparseVector) = _axpby(a, 1.0, b, -1.0)
+# filter(f, v)  (src/vector.jl:83 -> src/pma.jl:224-234): the predicate runs in Julia on the packed entries, the result is a new vector
+function Base.filter(f, v::DynamicSparseVector)
+    ks, vs = _stored(v)
+    keep = [f((ks[i], vs[i])) for i in eachindex(ks)]
+    return dynamicsparsevec(ks[keep], vs[keep])
+end
+
 # ------------------------------------------------------------------ matrix  (reference src/matrix.jl)
 mutable struct DynamicSparseMatrix
     h::Ptr{Cvoid}

@@ -95,6 +95,15 @@ int32_t dsa_vec_len(dsa_vec_t* h, int64_t* out);
 int32_t dsa_vec_shrink_size(dsa_vec_t* h);
 /* iterate(v) src/vector.jl:71 / nonzeroinds+nonzeros :93-109 : stored entries in slot order */
 int32_t dsa_vec_nonzeros(dsa_vec_t* h, int64_t* keys, double* vals, int64_t cap, int64_t* n_out);
+/* v1 == v2  src/vector.jl:85-87 -> src/pma.jl:262-266 -> _arrays_equal src/pma.jl:236-260: equal length(v), equal nb_elements and
+ * pairwise equal stored (key, value) tuples in slot order (layouts may differ).  *out = 1 / 0.  Both vectors are packed and
+ * compared on the device; only the verdict crosses PCIe. */
+int32_t dsa_vec_equal(dsa_vec_t* a, dsa_vec_t* b, int32_t* out);
+/* alpha * a + beta * b as ascending (key, value) pairs: the SparseVector the reference's  v1 + v2  (1, 1),  v1 - v2  (1, -1) and
+ * -v  (-1, 0, b = a) evaluate to through the AbstractSparseVector fallbacks over nonzeroinds / nonzeros
+ * (src/vector.jl:93-109; test/functional/math.jl:53-94).  A key stored in both operands keeps one entry, dropped when its value
+ * is zero; DSA_ECAP when cap < number of result entries (nnz(a) + nnz(b) always suffices).  Merge + compaction on the device. */
+int32_t dsa_vec_axpby(dsa_vec_t* a, double alpha, dsa_vec_t* b, double beta, int64_t* keys, double* vals, int64_t cap, int64_t* n_out);
 int32_t dsa_vec_info(dsa_vec_t* h, int64_t info[DSA_INFO_COUNT]);
 /* parity probe / snapshot: slot array (keys, vals, occ[i] in {0,1}), cap >= capacity */
 int32_t dsa_vec_export_layout(dsa_vec_t* h, int64_t* keys, double* vals, uint8_t* occ, int64_t cap);

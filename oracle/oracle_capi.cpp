@@ -187,6 +187,48 @@ int32_t ora_vec_nonzeros(ora_vec* h, int64_t* keys, double* vals, int64_t cap, i
     *n_out = n;
     ORA_CATCH
 }
+// _arrays_equal(array1, array2)  src/pma.jl:236-260: both slot arrays are walked skipping `nothing`; the i-th stored tuples
+// must be == (Int key ==, Float64 value ==), and neither side may have a stored tuple left over.
+static bool arrays_equal(const Elements& a1, const Elements& a2) {
+    int64_t i = 0, j = 0;
+    const int64_t n1 = a1.len(), n2 = a2.len();
+    while (true) {
+        while (i < n1 && !a1.tag[i]) ++i;
+        while (j < n2 && !a2.tag[j]) ++j;
+        if (i >= n1 || j >= n2) return i >= n1 && j >= n2;
+        if (a1.cell[i].key != a2.cell[j].key || !(a1.cell[i].val == a2.cell[j].val)) return false;
+        ++i; ++j;
+    }
+}
+// v1 == v2  src/vector.jl:85-87 ; pma1 == pma2  src/pma.jl:262-266
+int32_t ora_vec_equal(ora_vec* a, ora_vec* b, int32_t* out) {
+    ORA_TRY
+    *out = 0;
+    if (a->v.n != b->v.n) return OK;
+    if (a == b) { *out = 1; return OK; }
+    if (a->v.pma.nb_elements != b->v.pma.nb_elements) return OK;
+    *out = arrays_equal(a->v.pma.array, b->v.pma.array) ? 1 : 0;
+    ORA_CATCH
+}
+// alpha*a + beta*b as ascending (key, value) pairs: what v1 + v2, v1 - v2 and -v evaluate to in the reference through the
+// AbstractSparseVector fallbacks over nonzeroinds / nonzeros (src/vector.jl:93-109; exercised by test/functional/math.jl:53-94).
+// The merge itself is SparseArrays stdlib code (not under /root/reference): union of the stored keys, a key stored in both
+// operands is dropped when the combined value is zero; restated here as a two-pointer merge.
+int32_t ora_vec_axpby(ora_vec* a, double alpha, ora_vec* b, double beta, int64_t* keys, double* vals, int64_t cap, int64_t* n_out) {
+    ORA_TRY
+    std::vector<Cell> x, y;
+    { const Elements& e = a->v.pma.array; for (int64_t i = 0; i < e.len(); ++i) if (e.tag[i]) x.push_back(e.cell[i]); }
+    { const Elements& e = b->v.pma.array; for (int64_t i = 0; i < e.len(); ++i) if (e.tag[i]) y.push_back(e.cell[i]); }
+    size_t i = 0, j = 0; int64_t n = 0;
+    auto put = [&](int64_t k, double v) { if (n >= cap) throw Err{ECAP, "output buffers too small"}; keys[n] = k; vals[n] = v; ++n; };
+    while (i < x.size() || j < y.size()) {
+        if (j >= y.size() || (i < x.size() && x[i].key < y[j].key)) { put(x[i].key, alpha * x[i].val); ++i; }
+        else if (i >= x.size() || y[j].key < x[i].key) { put(y[j].key, beta * y[j].val); ++j; }
+        else { const double v = alpha * x[i].val + beta * y[j].val; if (v != 0.0) put(x[i].key, v); ++i; ++j; }
+    }
+    *n_out = n;
+    ORA_CATCH
+}
 int32_t ora_vec_info(ora_vec* h, int64_t* info) { fill_info(h->v.pma, h->v.n, 0, info); return OK; }
 int32_t ora_vec_export_layout(ora_vec* h, int64_t* keys, double* vals, uint8_t* occ, int64_t cap) {
     ORA_TRY export_elements(h->v.pma.array, keys, vals, occ, cap); ORA_CATCH

@@ -929,3 +929,55 @@ def test_forced_64bit_keys_build_in_a_subprocess(dsa, hip, oracle):
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz.py"), "12", "12345"], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "fuzz done" in r.stdout
+
+
+@pytest.mark.gpu
+def test_vector_equality_axpby_filter_match_oracle(dsa, hip, oracle):
+    """== (src/vector.jl:85-87, src/pma.jl:236-266), + / - / unary - (AbstractSparseVector fallbacks, test/functional/math.jl:53-94)
+    and filter (src/pma.jl:224-234) on device vectors: verdicts and result pairs identical to the oracle's, over small, large,
+    32-bit and 64-bit-key vectors."""
+    def build(b, k, v, **kw):
+        return dsa.dynamicsparsevec(k, v, binding=b, **kw)
+
+    for seed, n, keyspace in [(1, 25, 100), (2, 25, 100), (3, 3000, 5000), (4, 200000, 400000), (5, 1, 10), (6, 0, 10)]:
+        k1 = 1 + (splitmix_array(100 + seed, n) % np.uint64(keyspace)).astype(np.int64)
+        v1 = (1 + splitmix_array(200 + seed, n) % np.uint64(10)).astype(np.float64)
+        k2 = 1 + (splitmix_array(300 + seed, n) % np.uint64(keyspace)).astype(np.int64)
+        v2 = (1 + splitmix_array(400 + seed, n) % np.uint64(10)).astype(np.float64)
+        res = []
+        for b in (hip, oracle):
+            x, y = build(b, k1, v1, n=keyspace), build(b, k2, v2, n=keyspace)
+            r = [x + y, x - y, y - x, -x, x - x, x.axpby(2.5, y, -0.75), x == y, x == x]
+            z = build(b, k1[: n // 2], v1[: n // 2], n=keyspace)
+            z.set_batch(k1[n // 2:], np.zeros(n - n // 2))              # deletes of absent keys / of first-half duplicates
+            z2 = build(b, *z.nonzeros(), n=keyspace)
+            r += [z == z2, z2 == z, z == x]
+            f = x.filter(lambda e: e[0] % 3 == 1)
+            r += [f.nonzeros(), len(f), f.export_layout()]
+            res.append(r)
+        for got, want in zip(*res):
+            if isinstance(got, tuple):
+                assert len(got) == len(want) and all(np.array_equal(g, w) for g, w in zip(got, want))
+            else:
+                assert got == want
+        assert len(res[0][4][0]) == 0 and res[0][7] is True and res[0][8] is True
+    # same content behind 32-bit and 64-bit physical keys; NaN; different lengths
+    k = np.arange(1, 3001, dtype=np.int64) * 5
+    v = np.arange(1, 3001, dtype=np.float64)
+    for b in (hip, oracle):
+        a, w = build(b, k, v), build(b, k, v)
+        w[2**40] = 1.0
+        assert not (a == w) and not (w == a)
+        w[2**40] = 0.0                                    # w keeps 64-bit keys in the HIP library
+        w.shrink_size()
+        assert a == w and w == a
+        s = a + w
+        assert np.array_equal(s[0], k) and np.array_equal(s[1], 2 * v)
+        w[5] = float("nan")
+        c = build(b, *w.nonzeros())
+        assert w == w and not (w == c) and not (a == w)
+        big = build(b, np.array([2**35, 7, -(2**33)]), np.array([1.0, 2.0, 3.0]))
+        ks, vs = big - a
+        want_k = np.concatenate([[-(2**33)], k, [2**35]]).astype(np.int64)
+        want_k = np.unique(np.concatenate([want_k, [7]]))
+        assert np.array_equal(ks, want_k)

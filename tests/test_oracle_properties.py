@@ -137,3 +137,62 @@ def test_row_and_column_slices(dsa, oracle):
     col = a.col_slice(2)
     assert col.nnz() == 5 and [col[i] for i in range(1, 9)] == [3.0, 2.0, 0.0, 1.0, 0.0, 4.0, 5.0, 0.0]
     assert a.col_slice(99).nnz() == 0 and a.row_slice(5).nnz() == 0
+
+
+def _vec_math_case(seed, n=25, keyspace=100):
+    """the shape of addition() / subtraction() of test/functional/math.jl:53-94: 25 random keys in 1:100 (duplicates combined by +),
+    integer values 1:10 — drawn from our splitmix64"""
+    from util import splitmix_array
+    k = 1 + (splitmix_array(seed, n) % np.uint64(keyspace)).astype(np.int64)
+    v = (1 + splitmix_array(seed + 1000, n) % np.uint64(10)).astype(np.float64)
+    return k, v
+
+
+def _dense(k, v, n):
+    d = np.zeros(n + 1)
+    np.add.at(d, np.asarray(k, dtype=np.int64), v)
+    return d
+
+
+@pytest.mark.parametrize("seed", range(5))
+def test_vector_addition_subtraction_negation(dsa, oracle, seed):
+    """test/functional/math.jl:53-94: dyn_vec1 + dyn_vec2 == sparsevec sum, dyn_vec1 - dyn_vec2, -dyn_vec (value comparison)."""
+    k1, v1 = _vec_math_case(10 + seed)
+    k2, v2 = _vec_math_case(20 + seed)
+    a = dsa.dynamicsparsevec(k1, v1, n=100, binding=oracle)
+    b = dsa.dynamicsparsevec(k2, v2, n=100, binding=oracle)
+    d1, d2 = _dense(k1, v1, 100), _dense(k2, v2, 100)
+    for (ks, vs), want in (((a + b), d1 + d2), ((a - b), d1 - d2), ((-a), -d1), ((a - a), d1 * 0)):
+        assert np.all(np.diff(ks) > 0)
+        assert np.array_equal(_dense(ks, vs, 100), want)
+    ks, vs = a - a                                    # entries stored on both sides cancel: dropped
+    assert len(ks) == 0
+
+
+def test_vector_equality_and_filter(dsa, oracle):
+    """v1 == v2 compares length, stored count and the stored tuples in order — not the slot layout (src/vector.jl:85-87,
+    src/pma.jl:236-266; test/functional/sparsevector.jl:64-77); filter builds a new vector (src/pma.jl:224-234, sparsevector.jl:81-86)."""
+    k = np.arange(1, 401, dtype=np.int64) * 3
+    v = np.arange(1, 401, dtype=np.float64)
+    a = dsa.dynamicsparsevec(k, v, binding=oracle)
+    b = dsa.dynamicsparsevec(k[:100], v[:100], binding=oracle)
+    assert not (a == b)
+    b.set_batch(k[100:], v[100:])                     # same content, other history -> other layout
+    assert not np.array_equal(a.export_layout()[2], b.export_layout()[2])
+    assert a == b and a == a
+    b[7] = 1.0
+    assert not (a == b)
+    b[7] = 0.0
+    assert a == b
+    b[2000] = 1.0
+    b[2000] = 0.0                                     # length(b) grew: no longer equal until shrink_size!
+    assert not (a == b)
+    b.shrink_size()
+    assert a == b
+    b[3] = float("nan")
+    c = dsa.dynamicsparsevec(*b.nonzeros(), binding=oracle)
+    assert b == b and not (b == c)                    # === short cut; NaN != NaN element-wise
+    f = a.filter(lambda e: e[0] % 2 == 0 and e[1] > 10)
+    fk, fv = f.nonzeros()
+    sel = (k % 2 == 0) & (v > 10)
+    assert np.array_equal(fk, k[sel]) and np.array_equal(fv, v[sel]) and len(f) == int(k[sel].max())
