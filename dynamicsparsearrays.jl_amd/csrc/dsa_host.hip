@@ -1263,6 +1263,36 @@ int32_t dsa_mat_create_from_coo(const int64_t* I, const int64_t* J, const double
     *out = h;
     API_CATCH
 }
+// ---------------- column-range shards (the reference is single-process) ----------------
+// shard g of G owns the global column keys (col0, col0 + ncols]: n / G columns each, the first n % G shards one more
+int32_t dsa_shard_range(int64_t n, int32_t nshards, int32_t shard, int64_t* col0, int64_t* ncols) {
+    API_TRY
+    if (n < 0 || nshards <= 0 || shard < 0 || shard >= nshards) fail(DSA_EARG, "shard index / count out of range");
+    const int64_t base = n / nshards, rem = n % nshards;
+    *col0 = shard * base + std::min<int64_t>(shard, rem);
+    *ncols = base + (shard < rem ? 1 : 0);
+    API_CATCH
+}
+// the shard's sub-matrix as an independent reference-layout matrix: the triples whose column lies in the shard's range, with
+// LOCAL column keys 1..ncols (so x is the shard's slice of the global x); size m x ncols
+int32_t dsa_shard_create_from_coo(const int64_t* I, const int64_t* J, const double* V, int64_t nnz, int64_t m, int64_t n,
+                                  int32_t nshards, int32_t shard, dsa_mat_t** out) {
+    int64_t col0 = 0, ncols = 0;
+    if (n < 0) { g_err = "a sharded matrix needs its global column count"; return DSA_EARG; }
+    const int32_t rc = dsa_shard_range(n, nshards, shard, &col0, &ncols);
+    if (rc != DSA_OK) return rc;
+    std::vector<int64_t> li, lj; std::vector<double> lv;
+    try {
+        for (int64_t k = 0; k < nnz; ++k)
+            if (J[k] > col0 && J[k] <= col0 + ncols) { li.push_back(I[k]); lj.push_back(J[k] - col0); lv.push_back(V[k]); }
+    } catch (const std::bad_alloc&) { g_err = "host allocation failed"; return DSA_EHIP; }
+    return dsa_mat_create_from_coo(li.data(), lj.data(), lv.data(), (int64_t)li.size(), m, ncols, out);
+}
+// partial y (length m) of one shard: y_g = A[:, range_g] * x[range_g], x and y resident in HBM, asynchronous on the handle's
+// stream; the all-reduce over the shards belongs to the host layer (RCCL through torch.distributed, one process per GPU)
+int32_t dsa_shard_spmv_dev(dsa_mat_t* h, const double* d_x_local, int64_t nx, double* d_y_partial, int64_t ny) {
+    return dsa_mat_spmv_dense_dev(h, 0, 0, d_x_local, nx, d_y_partial, ny);
+}
 int32_t dsa_mat_create_empty(int32_t fill_mode, dsa_mat_t** out) {
     API_TRY
     auto* h = new dsa_mat();

@@ -10,7 +10,7 @@ module DynamicSparseArraysAMD
 using SparseArrays
 
 export DynamicSparseVector, DynamicSparseMatrix, PackedCSC, dynamicsparsevec, dynamicsparse, nbpartitions,
-       deletecolumn!, deleterow!, deletepartition!, addrow!, closefillmode!, shrink_size!, set_device!
+       deletecolumn!, deleterow!, deletepartition!, addrow!, closefillmode!, shrink_size!, set_device!, shard_range, dynamicsparse_shard
 
 const libdsa = get(ENV, "DSA_HIP_LIB", joinpath(@__DIR__, "..", "csrc", "libdsa_hip.so"))
 
@@ -30,6 +30,13 @@ const COMBINE = IdDict{Function,Int32}(+ => Int32(0), * => Int32(1))
 "one process per GPU: select the device before creating handles (dsa_set_device)"
 set_device!(dev::Integer) = _check(ccall((:dsa_set_device, libdsa), Int32, (Int32,), dev))
 device_count() = ccall((:dsa_device_count, libdsa), Int32, ())
+
+"column keys (col0, col0 + ncols] owned by shard `shard` (0-based) of `nshards` — dsa_shard_range"
+function shard_range(n::Integer, nshards::Integer, shard::Integer)
+    c0 = Ref{Int64}(0); nc = Ref{Int64}(0)
+    _check(ccall((:dsa_shard_range, libdsa), Int32, (Int64, Int32, Int32, Ref{Int64}, Ref{Int64}), n, nshards, shard, c0, nc))
+    return c0[], nc[]
+end
 
 # ------------------------------------------------------------------ vector  (reference src/vector.jl)
 mutable struct DynamicSparseVector <: AbstractSparseVector{Float64,Int64}
@@ -217,6 +224,14 @@ function getindex_batch(a::DynamicSparseMatrix, I::Vector{Int64}, J::Vector{Int6
     GC.@preserve I J out _check(ccall((:dsa_mat_get_batch, libdsa), Int32,
         (Ptr{Cvoid}, Ptr{Int64}, Ptr{Int64}, Int64, Ptr{Float64}), a.h, I, J, length(I), out))
     return out
+end
+
+"the column-range shard `shard` of `nshards` of the matrix given by its triples (local column keys 1..ncols) — one process per GPU"
+function dynamicsparse_shard(I::Vector{Int64}, J::Vector{Int64}, V::Vector{Float64}, m::Int64, n::Int64, nshards::Integer, shard::Integer)
+    out = Ref{Ptr{Cvoid}}(C_NULL)
+    GC.@preserve I J V _check(ccall((:dsa_shard_create_from_coo, libdsa), Int32,
+        (Ptr{Int64}, Ptr{Int64}, Ptr{Float64}, Int64, Int64, Int64, Int32, Int32, Ref{Ptr{Cvoid}}), I, J, V, length(I), m, n, nshards, shard, out))
+    return DynamicSparseMatrix(out[])
 end
 
 # ------------------------------------------------------------------ PackedCSC  (reference src/pcsr.jl:4-339)

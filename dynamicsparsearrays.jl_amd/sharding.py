@@ -37,9 +37,18 @@ class ColumnShard:
         I = np.asarray(I, dtype=np.int64)
         J = np.asarray(J_global, dtype=np.int64)
         V = np.asarray(V, dtype=np.float64)
-        mine = (J > self.col0) & (J <= self.col0 + self.ncols)
-        # local column keys 1..ncols: the shard is the reference layout of its own sub-matrix
-        self.A = api.dynamicsparse(I[mine], J[mine] - self.col0, V[mine], m, self.ncols, binding=binding)
+        b = binding if binding is not None else api.product()
+        if b.device_api:
+            # the C-ABI shard constructor (include/dsa.h: dsa_shard_create_from_coo) — same split, done inside the library
+            import ctypes as C
+            h = C.c_void_p()
+            b.call("shard_create_from_coo", I.ctypes.data_as(C.POINTER(C.c_int64)), J.ctypes.data_as(C.POINTER(C.c_int64)),
+                   V.ctypes.data_as(C.POINTER(C.c_double)), len(I), m, n_total, world, rank, C.byref(h))
+            self.A = api.DynamicSparseMatrix(b, h)
+        else:
+            mine = (J > self.col0) & (J <= self.col0 + self.ncols)
+            # local column keys 1..ncols: the shard is the reference layout of its own sub-matrix
+            self.A = api.dynamicsparse(I[mine], J[mine] - self.col0, V[mine], m, self.ncols, binding=b)
 
     def x_slice(self, x_global):
         return np.ascontiguousarray(x_global[self.col0:self.col0 + self.ncols])

@@ -185,6 +185,19 @@ int32_t dsa_mat_spmv_sparse(dsa_mat_t* h, int32_t transpose, const int64_t* xi, 
  * orientation with fp64 atomics (the literal _mul loop nest) */
 int32_t dsa_mat_spmv_dense_dev(dsa_mat_t* h, int32_t transpose, int32_t algo, const double* d_x,
                                int64_t nx, double* d_y, int64_t ny);
+/* ---- column-range shards.  No reference counterpart: the reference is single-process.  One PROCESS per GPU:
+ * each process selects its device (dsa_set_device), builds ITS shard and runs the local SpMV; the single data-path collective —
+ * the all-reduce (sum) of the partial y — is issued by the host layer (RCCL through torch.distributed in bench.py / sharding.py;
+ * MPI.jl or NCCL.jl from Julia), so no communicator crosses this ABI.
+ * dsa_shard_range: shard g of G owns the global column keys (col0, col0 + ncols].
+ * dsa_shard_create_from_coo: the triples of the shard's range as an independent reference-layout matrix (own capacity, height,
+ *   semaphores, column table; both orientations) with LOCAL column keys 1..ncols; size m x ncols.  n = global column count.
+ * dsa_shard_spmv_dev: y_partial = A[:, range] * x[range]; d_x_local = the shard's slice of x (ncols doubles), d_y_partial = m
+ *   doubles, both in HBM; asynchronous on the handle's stream (dsa_mat_set_stream / dsa_mat_sync). */
+int32_t dsa_shard_range(int64_t n, int32_t nshards, int32_t shard, int64_t* col0, int64_t* ncols);
+int32_t dsa_shard_create_from_coo(const int64_t* I, const int64_t* J, const double* V, int64_t nnz, int64_t m, int64_t n,
+                                  int32_t nshards, int32_t shard, dsa_mat_t** out);
+int32_t dsa_shard_spmv_dev(dsa_mat_t* shard, const double* d_x_local, int64_t nx, double* d_y_partial, int64_t ny);
 /* Device-side invariant checker (the structural checks of the reference's test/utils.jl:68-113, runnable at full size):
  * report[0] occupied cells, [1] semaphore cells, [2] semaphore cells whose table entry does not point back, [3] key-order
  * violations, [4] bad table entries (not pointing at their semaphore / dead key / unsorted column keys), [5] occupancy bits at or

@@ -981,3 +981,35 @@ def test_vector_equality_axpby_filter_match_oracle(dsa, hip, oracle):
         want_k = np.concatenate([[-(2**33)], k, [2**35]]).astype(np.int64)
         want_k = np.unique(np.concatenate([want_k, [7]]))
         assert np.array_equal(ks, want_k)
+
+
+@pytest.mark.gpu
+def test_shard_entry_points_split_spmv_exactly(dsa, hip, oracle):
+    """dsa_shard_create_from_coo / dsa_shard_spmv_dev (include/dsa.h): every shard is the reference layout of ITS
+    sub-matrix (slot-for-slot equal to the oracle's build of the filtered triples) and the partial products sum to A*x."""
+    import ctypes as C
+    import torch
+    from dsa_amd import sharding
+    m, n, nnz, G = 5000, 3001, 40000, 3
+    I = 1 + (splitmix_array(501, nnz) % np.uint64(m)).astype(np.int64)
+    J = 1 + (splitmix_array(502, nnz) % np.uint64(n)).astype(np.int64)
+    V = unit12_array(503, nnz)
+    x = unit12_array(504, n)
+    full = dsa.dynamicsparse(I, J, V, m, n, binding=oracle)
+    y_ref = full.mul(x, dense_out=m)
+    y = np.zeros(m)
+    for g in range(G):
+        sh = sharding.ColumnShard(dsa, I, J, V, m, n, g, G, binding=hip)
+        ref = sharding.ColumnShard(dsa, I, J, V, m, n, g, G, binding=oracle)
+        assert_mat_equal(sh.A, ref.A)
+        assert sh.A.size() == (m, sh.ncols)
+        dx = torch.from_numpy(sh.x_slice(x)).cuda()
+        dy = torch.empty(m, dtype=torch.float64, device="cuda")
+        hip.call("mat_set_stream", sh.A.h, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        hip.call("shard_spmv_dev", sh.A.h, C.c_void_p(dx.data_ptr()), sh.ncols, C.c_void_p(dy.data_ptr()), m)
+        torch.cuda.synchronize()
+        part = dy.cpu().numpy()
+        assert np.array_equal(part, sh.spmv_partial(sh.x_slice(x)))
+        np.testing.assert_allclose(part, ref.spmv_partial(ref.x_slice(x)), rtol=RTOL, atol=0)
+        y += part
+    np.testing.assert_allclose(y, y_ref, rtol=RTOL, atol=0)

@@ -44,3 +44,25 @@ def test_product_does_not_reference_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp", ".jl")) or f == "Makefile":
                 txt = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "liboracle" not in txt and "oracle.hpp" not in txt and "ora_" not in txt.replace("ora_`", ""), (dirpath, f)
+
+
+
+def test_shard_range_matches_the_host_layer(dsa):
+    """dsa_shard_range (pure host arithmetic, callable without a GPU) and sharding.column_range split n columns the same way;
+    the ranges tile 1..n without gaps or overlaps."""
+    import ctypes as C
+    from dsa_amd import sharding
+    b = dsa.product()
+    for n, G in [(10, 1), (10, 3), (1_000_000, 8), (7, 8), (0, 2), (10_000_000, 8)]:
+        end = 0
+        for g in range(G):
+            c0, nc = C.c_int64(), C.c_int64()
+            b.call("shard_range", n, G, g, C.byref(c0), C.byref(nc))
+            assert (c0.value, nc.value) == sharding.column_range(g, G, n)
+            assert c0.value == end
+            end += nc.value
+        assert end == n
+    c0, nc = C.c_int64(), C.c_int64()
+    import pytest
+    with pytest.raises(dsa.DsaArgumentError):
+        b.call("shard_range", 10, 2, 2, C.byref(c0), C.byref(nc))
