@@ -146,6 +146,17 @@ def run_vector(seed):
         occ = ka[2].astype(bool)
         assert np.array_equal(ka[0][occ], kb[0][occ]) and np.array_equal(ka[1][occ], kb[1][occ]), (seed, step, "cells")
         assert a.info() ["capacity"] == b.info()["capacity"]
+        if step % 2 == 1:                     # whole-vector operations against a second vector built another way
+            k2, v2 = b.nonzeros()
+            sel = np.array([g.next() % 4 != 0 for _ in range(len(k2))], dtype=bool)
+            bump = np.where(np.array([g.next() % 5 == 0 for _ in range(len(k2))]), -1.0, 1.0)
+            a2 = dsa.dynamicsparsevec(k2[sel], (v2 * bump)[sel], binding=hip)
+            b2 = dsa.dynamicsparsevec(k2[sel], (v2 * bump)[sel], binding=ora)
+            for x, y in ((a + a2, b + b2), (a - a2, b - b2), (a2 - a, b2 - b), (a.axpby(0.5, a2, 2.0), b.axpby(0.5, b2, 2.0))):
+                assert np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1]), (seed, step, "axpby")
+            assert (a == a2) == (b == b2) and (a == a) and ((a2 == a) == (b2 == b)), (seed, step, "==")
+            a3 = dsa.dynamicsparsevec(*a.nonzeros(), n=len(a), binding=hip)
+            assert a3 == a and a == a3, (seed, step, "== rebuilt")
     return "ok"
 
 
