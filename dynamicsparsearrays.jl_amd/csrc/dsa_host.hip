@@ -81,7 +81,7 @@ struct Pma {
     Op* d_ops = nullptr; int64_t ops_cap = 0;
     double* d_q = nullptr; int64_t q_cap = 0;      // scratch for lookups (3 arrays of q_cap)
     int32_t* d_err = nullptr;
-    int64_t stat_par_rounds = 0, stat_par_ops = 0, stat_seq_ops = 0;      // batch-parallel instrumentation
+    int64_t stat_par_rounds = 0, stat_par_ops = 0, stat_seq_ops = 0, stat_seq_launches = 0;      // batch-parallel instrumentation
     BurstGraph burst;
     Plan* d_plans = nullptr; uint32_t* d_flags = nullptr; RoundState* d_rs = nullptr; RoundState* h_rs = nullptr;   // batch-parallel writes
     int64_t* d_small = nullptr;                     // 8 x int64 scratch
@@ -577,7 +577,7 @@ int64_t run_ops_parallel(Pma& P, const std::vector<Op>& ops, int32_t* err) {
         seq_launch(r);
         while (seq_step(r)) {}
         if (r.err) { *err = r.err; return r.applied; }
-        P.stat_seq_ops += r.applied - i;
+        P.stat_seq_ops += r.applied - i; P.stat_seq_launches += 1;
         i = r.applied;
         seq_chunk = std::min<int64_t>(seq_chunk * 2, 8192);
         G = 64;
@@ -891,14 +891,24 @@ void mat_apply_sets(dsa_mat* h, const int64_t* I, const int64_t* J, const double
                 try { if (hipSetDevice(g_device) != hipSuccess) fail(DSA_EHIP, "hipSetDevice"); dr = run_ops_parallel(h->row, orw, &er); }
                 catch (...) { row_exc = std::current_exception(); }
             });
+        const int64_t rounds0 = h->row.stat_par_rounds;
         try { dc = run_ops_parallel(h->col, oc, &ec); }
         catch (...) { if (row_thread.joinable()) row_thread.join(); throw; }
+        const auto t1 = std::chrono::steady_clock::now();
         if (side_by_side) { row_thread.join(); if (row_exc) std::rethrow_exception(row_exc); }
         else dr = run_ops_parallel(h->row, orw, &er);
         if (dbg_time)
-            fprintf(stderr, "[mat_apply_sets] n=%lld both orientations %.2f ms  colmajor (par %lld seq %lld)  rowmajor (par %lld seq %lld)\n", (long long)n,
-                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), (long long)h->col.stat_par_ops,
-                    (long long)h->col.stat_seq_ops, (long long)h->row.stat_par_ops, (long long)h->row.stat_seq_ops);
+            fprintf(stderr, "[mat_apply_sets] n=%lld both orientations %.2f ms (colmajor done after %.2f ms)  colmajor (par %lld seq %lld ext %lld)  "
+                    "rowmajor (par %lld seq %lld ext %lld rounds +%lld)\n", (long long)n,
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(),
+                    std::chrono::duration<double, std::milli>(t1 - t0).count(), (long long)h->col.stat_par_ops,
+                    (long long)h->col.stat_seq_ops, (long long)h->col.h_ctl->stat_extends, (long long)h->row.stat_par_ops, (long long)h->row.stat_seq_ops,
+                    (long long)h->row.h_ctl->stat_extends, (long long)(h->row.stat_par_rounds - rounds0));
+        if (dbg_time)
+            fprintf(stderr, "    rowmajor: sequencer launches %lld  stops by reason [0 unplannable %lld, 1 newcol %lld, 2 limits %lld, 3 shifts %lld, 4 semleaf %lld, "
+                    "5 window %lld, 6 scan %lld, 7 conflict %lld]\n", (long long)h->row.stat_seq_launches, (long long)h->row.stat_why[0], (long long)h->row.stat_why[1],
+                    (long long)h->row.stat_why[2], (long long)h->row.stat_why[3], (long long)h->row.stat_why[4], (long long)h->row.stat_why[5],
+                    (long long)h->row.stat_why[6], (long long)h->row.stat_why[7]);
         const int64_t done = std::min(dc, dr);
         for (int64_t k = 0; k < std::min(done + 1, n); ++k) if (V[k] != 0.0) { h->m = std::max(h->m, I[k]); h->n = std::max(h->n, J[k]); }
         if (ec) fail(ec, err_text(ec));
