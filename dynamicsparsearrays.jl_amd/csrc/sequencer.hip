@@ -273,6 +273,7 @@ __device__ int d_after_count_change(Seq& S, int64_t pos) {
 // block go through the workgroup-wide bitmap path.  The host then moves every cell exactly once (k_permute, rebalance.hip).
 constexpr int64_t RUN_MIN = 64;
 constexpr int64_t RUN_BLOCK = 4096;
+constexpr int RUN_BLOCK_LOG2 = 12;
 
 struct RunComm { int64_t idx, L, reb, slots, small; int32_t need, pad; };
 
@@ -349,17 +350,22 @@ struct RunMemo { uint64_t words[MEMO_WORDS]; unsigned long long gapw[64]; };   /
 // Everything per op is wave-uniform register work: lane <-> occupancy word of the block for the bitmap, lane <-> level
 // for the density scan (the levels inside one word are tested first, from the word alone; wider in-block levels from a
 // butterfly of word popcounts), lane <-> window offset when a spread! pattern is computed (one ballot per word).
-__device__ void wave_fast_appends(Seq& S, RunComm* rc, RunMemo* memo, const uint64_t* flags, int64_t end) {
+// P = int32_t while capacity and run length fit 30 bits (positions, op indices and word indices are then single-register values:
+// a lone wave issues ~1 instruction per 4 cycles, so halving the 64-bit arithmetic is what shortens an op), int64_t otherwise.
+template <typename P>
+__device__ void wave_fast_appends(Seq& S, RunComm* rc, RunMemo* memo, const uint64_t* flags, int64_t end64) {
+    const P end = (P)end64;
     const int lane = lane_id();
-    int64_t idx = rc->idx, L = rc->L;
+    P idx = (P)rc->idx, L = (P)rc->L;
     int64_t reb = 0, slots = 0;
-    const int64_t cap = S.capacity, seg = S.seg;
-    const int64_t nwords = (cap + 63) >> 6;
-    const int64_t blkslots = cap < RUN_BLOCK ? cap : RUN_BLOCK;
+    const P cap = (P)S.capacity, seg = (P)S.seg;
+    const int height = (int)S.height;
+    const P nwords = (cap + 63) >> 6;
+    const P blkslots = cap < (P)RUN_BLOCK ? cap : (P)RUN_BLOCK;
     const int lseg = 63 - __clzll((long long)seg);
     // level h = lane: window size and integer density bounds; levels wider than the block cannot be decided here
-    const bool lvl_valid = lane <= (int)S.height;
-    const int64_t Wl = lvl_valid ? (seg << lane) : 0;
+    const bool lvl_valid = lane <= height;
+    const int64_t Wl = lvl_valid ? ((int64_t)seg << lane) : 0;
     const bool lvl_in_block = lvl_valid && Wl <= blkslots;
     const bool lvl_low = lvl_in_block && Wl <= 64;
     const bool lvl_mid = lvl_in_block && Wl > 64;
@@ -374,8 +380,8 @@ __device__ void wave_fast_appends(Seq& S, RunComm* rc, RunMemo* memo, const uint
     {
         int wb = 0;
         for (int h = 0; h < 64; ++h) {
-            const int64_t Wh = seg << h;
-            if (h > (int)S.height || Wh > 256) break;
+            const int64_t Wh = (int64_t)seg << h;
+            if (h > height || Wh > 256) break;
             if (h == lane) my_wb = wb;
             wb += ((int)Wh + 1) * (Wh <= 64 ? 1 : (int)(Wh >> 6));
         }
@@ -384,30 +390,30 @@ __device__ void wave_fast_appends(Seq& S, RunComm* rc, RunMemo* memo, const uint
     const uint64_t cap_bit = 1ull << ((cap - 1) & 63);
     int need = 0;
     // cell types of the run (MappedPackedCSC: bit set = semaphore cell of a new column); one word per 64 cells
-    int64_t fw_idx = -1;
+    P fw_idx = -1;
     uint64_t fw = 0;
     while (idx < end && need == 0) {
         if (flags != nullptr && (idx >> 6) != fw_idx) { fw_idx = idx >> 6; fw = flags[fw_idx]; }
         const bool sem0 = (fw >> (idx & 63)) & 1ull;
-        const int64_t tgt = (L < cap && !sem0) ? L + 1 : cap;
-        const int64_t blk = (tgt - 1) / RUN_BLOCK;
-        const int64_t w = blk * 64 + lane;
+        const P tgt = (L < cap && !sem0) ? L + 1 : cap;
+        const P blk = (tgt - 1) >> RUN_BLOCK_LOG2;
+        const P w = blk * 64 + lane;
         uint64_t word = w < nwords ? S.occ[w] : 0ull;
         while (idx < end) {
             if (flags != nullptr && (idx >> 6) != fw_idx) { fw_idx = idx >> 6; fw = flags[fw_idx]; }
             const bool is_sem = (fw >> (idx & 63)) & 1ull;
             const uint64_t word_saved = word;
-            int64_t ip;
+            P ip;
             if (L < cap && !is_sem) {
                 // _insert! behind the last cell  src/writes.jl:26-43
                 ip = L + 1;
-                if ((ip - 1) / RUN_BLOCK != blk) break;                       // the tail moves into the next block: reload
+                if (((ip - 1) >> RUN_BLOCK_LOG2) != blk) break;                       // the tail moves into the next block: reload
                 if (lane == (int)(((ip - 1) >> 6) & 63)) word |= 1ull << ((ip - 1) & 63);
             } else {
                 // insert at the end of the array: a cell behind a tail that sits on the last slot, or a new partition's
                 // semaphore (always inserted "after position capacity", src/pcsr.jl:99-112).  The nearest empty slot left
                 // of the last slot takes the shift; almost always it is in the last word.
-                if ((cap - 1) / RUN_BLOCK != blk) break;
+                if (((cap - 1) >> RUN_BLOCK_LOG2) != blk) break;
                 const uint64_t wl = rdlane64(word, last_lane);
                 uint64_t zl = ~wl & ~cap_bit;
                 if (cap < 64) zl &= (1ull << cap) - 1ull;
@@ -420,7 +426,7 @@ __device__ void wave_fast_appends(Seq& S, RunComm* rc, RunMemo* memo, const uint
                     best = wave_max_u32(rel);
                     if (best == 0) { need = 1; break; }
                 }
-                const int64_t pe = blk * RUN_BLOCK + best;
+                const P pe = blk * (P)RUN_BLOCK + (P)best;
                 ip = cap;
                 if (wl & cap_bit) {                                           // tail on the last slot: cells (pe, cap] shift left
                     if (lane == (int)(((pe - 1) >> 6) & 63)) word |= 1ull << ((pe - 1) & 63);
@@ -460,7 +466,7 @@ __device__ void wave_fast_appends(Seq& S, RunComm* rc, RunMemo* memo, const uint
             const int W = (int)seg << h;                                      // <= 4096
             const int c = (int)rdlane(c_l, h);
             reb += 1; slots += W;
-            const int64_t ws = ((ip - 1) & ~((int64_t)W - 1)) + 1;
+            const P ws = ((ip - 1) & ~((P)W - 1)) + 1;
             const int lw0 = (int)(((ws - 1) >> 6) & 63);
             if (W <= 256) {
                 const int nw = W < 64 ? 1 : (W >> 6);
@@ -514,13 +520,13 @@ __device__ void wave_fast_appends(Seq& S, RunComm* rc, RunMemo* memo, const uint
                     if (t >= 0 && t < nww) word = memo->gapw[t];
                     __builtin_amdgcn_wave_barrier();
                 } else if (t >= 0 && t < nww) word = spread_word_bits(g, t);
-                L = ws - 1 + spread_last_cell(g);
+                L = ws - 1 + (P)spread_last_cell(g);
             }
             ++idx;
         }
         if (w < nwords) S.occ[w] = word;
     }
-    if (lane == 0) { rc->idx = idx; rc->L = L; rc->reb = reb; rc->slots = slots; rc->small = reb; rc->need = need; }
+    if (lane == 0) { rc->idx = (int64_t)idx; rc->L = (int64_t)L; rc->reb = reb; rc->slots = slots; rc->small = reb; rc->need = need; }
 }
 
 // spread! of m cells over [ws, we], occupancy words only (workgroup-wide)
@@ -695,7 +701,7 @@ hipError_t launch_run_expand(const Op* ops, int64_t i0, int64_t R, const Ctl* ct
 // updates the control block: next_op, nb_elements, statistics.  A run ends early at an op that needs _extend! /
 // _shrink!; when that is the very first op, no_run_at tells the sequencer to execute it on the normal path.
 __global__ __launch_bounds__(SEQ_BLOCK) void k_append_run(uint64_t* occ, Ctl* ctl, int64_t i0, int64_t R, const uint64_t* flags,
-                                                          const int64_t* d_T) {
+                                                          const int64_t* d_T, int wide_pos) {
     __shared__ int64_t sRed[SEQ_BLOCK / 64];
     __shared__ RunComm sRun;
     __shared__ RunMemo sMemo;
@@ -717,12 +723,16 @@ __global__ __launch_bounds__(SEQ_BLOCK) void k_append_run(uint64_t* occ, Ctl* ct
     int64_t idx = 0, L = d_prev_occupied(occ, S.capacity, 1);
     const int64_t end = flags != nullptr ? d_T[0] : R;
     int64_t t_fast = 0, t_slow = 0, n_slow = 0;
+    const bool narrow_pos = !wide_pos && S.capacity <= (1ll << 30) && end <= (1ll << 30);
     const int64_t c_begin = clock64(), w_begin = wall_clock64();
     while (idx < end) {
         if (threadIdx.x == 0) { rc->idx = idx; rc->L = L; }
         __syncthreads();
         const int64_t t0 = wall_clock64();
-        if (threadIdx.x < 64) wave_fast_appends(S, rc, &sMemo, flags, end);
+        if (threadIdx.x < 64) {
+            if (narrow_pos) wave_fast_appends<int32_t>(S, rc, &sMemo, flags, end);
+            else wave_fast_appends<int64_t>(S, rc, &sMemo, flags, end);
+        }
         __syncthreads();
         const int64_t t1 = wall_clock64();
         t_fast += t1 - t0;
@@ -770,7 +780,8 @@ __global__ __launch_bounds__(SEQ_BLOCK) void k_append_run(uint64_t* occ, Ctl* ct
 
 hipError_t launch_append_run(uint64_t* occ, Ctl* ctl, int64_t i0, int64_t R, const uint64_t* flags, const int64_t* d_T,
                              hipStream_t stream) {
-    hipLaunchKernelGGL(k_append_run, dim3(1), dim3(SEQ_BLOCK), 0, stream, occ, ctl, i0, R, flags, d_T);
+    static const int wide_pos = [] { const char* e = getenv("DSA_POS_WIDE"); return (e && e[0] == '1') ? 1 : 0; }();   // dev knob: 64-bit positions
+    hipLaunchKernelGGL(k_append_run, dim3(1), dim3(SEQ_BLOCK), 0, stream, occ, ctl, i0, R, flags, d_T, wide_pos);
     return hipGetLastError();
 }
 

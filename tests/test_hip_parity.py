@@ -925,10 +925,13 @@ def test_forced_64bit_keys_build_in_a_subprocess(dsa, hip, oracle):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, DSA_KEYS_WIDE="1")
+    # DSA_POS_WIDE=1 additionally selects the 64-bit-position instantiation of the append-run replay (used for capacities > 2^30)
+    env = dict(os.environ, DSA_KEYS_WIDE="1", DSA_POS_WIDE="1")
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz.py"), "12", "12345"], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "fuzz done" in r.stdout
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "appendbench.py"), "--check"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "append parity ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 @pytest.mark.gpu

@@ -14,3 +14,14 @@ for rep in range(2):
     va = bench.unit12(3, 100000)
     t0 = time.perf_counter(); v.set_batch(app, va); dt = time.perf_counter() - t0
     print("batch A: %.2f ms  %.0f appends/s" % (dt * 1e3, len(app) / dt), v.info()["capacity"])
+
+if "--check" in sys.argv:      # parity of the batch against the CPU oracle (used by the test-suite under DSA_POS_WIDE=1)
+    ora = dsa.Binding(os.path.join(ROOT, "oracle", "liboracle.so"), "ora", device_api=False)
+    o = dsa.dynamicsparsevec(keys0, bench.unit12(3, n0), binding=ora)
+    o.set_batch(app, va)
+    a, b = v.export_layout(), o.export_layout()
+    assert np.array_equal(a[2], b[2])
+    occ = a[2].astype(bool)
+    assert np.array_equal(a[0][occ], b[0][occ]) and np.array_equal(a[1][occ], b[1][occ])
+    assert v.info()["stat_window_slots"] == o.info()["stat_window_slots"], (v.info(), o.info())
+    print("append parity ok")
