@@ -344,12 +344,76 @@ __device__ __forceinline__ uint64_t rdlane64(uint64_t v, int l) {
 // memo of spread! patterns for windows of up to 256 slots: the pattern depends on (W, c) only and an append run keeps
 // hitting the same few (level, count) pairs.  Filled on first use by wave 0.
 constexpr int MEMO_ENTRIES = 640, MEMO_WORDS = 1664;
-struct RunMemo { uint64_t words[MEMO_WORDS]; unsigned long long gapw[64]; };   // gapw: scratch of the cooperative spread
+constexpr int EV_WORDS = 512;
+struct RunMemo {
+    uint64_t words[MEMO_WORDS]; unsigned long long gapw[64];
+    uint64_t ev[EV_WORDS];   // count model: outcome of a rebalance of level h <= 4 (W <= 256) with c cells: suffix counts of levels 0..3 (16 bits each), bit 63 = one trailing gap
+};   // gapw: scratch of the cooperative spread
 
 // wave 0: replays appends rc->idx .. end-1 on the register-resident block until one needs the workgroup path (need = 1).
 // Everything per op is wave-uniform register work: lane <-> occupancy word of the block for the bitmap, lane <-> level
 // for the density scan (the levels inside one word are tested first, from the word alone; wider in-block levels from a
 // butterfly of word popcounts), lane <-> window offset when a spread! pattern is computed (one ballot per word).
+// spread! of c cells over the W-slot window starting at slot ws, bits only, on the register-resident block (lane <-> occupancy
+// word; lw0 = lane of the window's first word; wb_level = memo base of the level, used when W <= 256).  Returns the position of
+// the window's last cell.
+template <typename P>
+__device__ __forceinline__ P wave_spread_bits(uint64_t& word, RunMemo* memo, int lane, int W, int c, int wb_level, P ws, int lw0) {
+    if (W <= 256) {
+        const int nw = W < 64 ? 1 : (W >> 6);
+        const int wb = wb_level + c * nw;
+        // a filled entry never ends with an empty word (c >= lo[h] cells spread evenly): 0 = not computed yet — one LDS
+        // round trip instead of a separate valid flag
+        uint64_t lastw = memo->words[wb + nw - 1];
+        if (lastw == 0) {
+            SpreadGeom g;                                             // make_geom(W, c) with 32-bit conversions
+            g.W = W; g.E = W - c;
+            g.f = (double)W / (double)(W - c);
+            g.inv_f = (double)(W - c) / (double)W;
+            for (int t = 0; t < nw; ++t) {
+                const int q = 64 * t + lane + 1;
+                int rank;
+                const bool cell = q <= W && !slot_is_gap(g, q, &rank);
+                const uint64_t nb = __ballot(cell);
+                if (lane == 0) memo->words[wb + t] = nb;
+                lastw = nb;
+            }
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_s_waitcnt(0xc07f);                        // the other lanes read the entry below
+        }
+        if (W < 64) {
+            const int sh = (int)((ws - 1) & 63);
+            const uint64_t m = ((1ull << W) - 1ull) << sh;
+            if (lane == lw0) word = (word & ~m) | (lastw << sh);
+        } else {
+            const int t = lane - lw0;
+            if (t >= 0 && t < nw) word = memo->words[wb + t];
+        }
+        return ws - 1 + 64 * (nw - 1) + (64 - __clzll((long long)lastw));
+    }
+    SpreadGeom g;
+    g.W = W; g.E = W - c;
+    g.f = (double)W / (double)(W - c);
+    g.inv_f = (double)(W - c) / (double)W;
+    const int t = lane - lw0;
+    const int nww = W >> 6, E = W - c;
+    if (E <= 16 * nww) {
+        // few gaps per word (dense window): the whole wave generates the E gap offsets D(k) — lane <-> k — and clears
+        // their bits in an LDS image of the window, instead of every lane looping over the gaps of its own word
+        if (lane < nww) memo->gapw[lane] = ~0ull;
+        __builtin_amdgcn_wave_barrier();
+        for (int k = lane + 1; k <= E; k += 64) {
+            const int d = gap_D(g, k);                             // 1-based offset in the window
+            atomicAnd(&memo->gapw[(d - 1) >> 6], ~(1ull << ((d - 1) & 63)));
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xc07f);                        // lgkmcnt(0): the wave's LDS atomics have landed
+        if (t >= 0 && t < nww) word = memo->gapw[t];
+        __builtin_amdgcn_wave_barrier();
+    } else if (t >= 0 && t < nww) word = spread_word_bits(g, t);
+    return ws - 1 + (P)spread_last_cell(g);
+}
+
 // P = int32_t while capacity and run length fit 30 bits (positions, op indices and word indices are then single-register values:
 // a lone wave issues ~1 instruction per 4 cycles, so halving the 64-bit arithmetic is what shortens an op), int64_t otherwise.
 template <typename P>
@@ -389,6 +453,18 @@ __device__ void wave_fast_appends(Seq& S, RunComm* rc, RunMemo* memo, const uint
     const int last_lane = (int)((nwords - 1) & 63);
     const uint64_t cap_bit = 1ull << ((cap - 1) & 63);
     int need = 0;
+    int my_eb = -1;                                       // lane h: first word of level h in memo->ev, or -1 (level not memoised)
+    {
+        int eb = 0;
+        for (int h = 1; h <= 4; ++h) {
+            const int64_t Wh = (int64_t)seg << h;
+            if (h > height || Wh > 256) break;
+            if (h == lane) my_eb = eb;
+            eb += (int)Wh + 1;
+        }
+    }
+    const bool model_ok = cap >= (P)RUN_BLOCK && rc->pad == 0;      // whole 4096-slot block in front of the end: last_lane == 63
+    const P last_blk = (cap - 1) >> RUN_BLOCK_LOG2;
     // cell types of the run (MappedPackedCSC: bit set = semaphore cell of a new column); one word per 64 cells
     P fw_idx = -1;
     uint64_t fw = 0;
@@ -402,6 +478,86 @@ __device__ void wave_fast_appends(Seq& S, RunComm* rc, RunMemo* memo, const uint
         while (idx < end) {
             if (flags != nullptr && (idx >> 6) != fw_idx) { fw_idx = idx >> 6; fw = flags[fw_idx]; }
             const bool is_sem = (fw >> (idx & 63)) & 1ull;
+            // ---- count model: the tail sits on the last slot of the array.  Every append — cell or semaphore —
+            //      then takes the nearest gap left of the last slot and the windows of the density scan are the SUFFIXES of the array,
+            //      so the replay only needs the suffix count of every level (lane <-> level): an append adds 1 to every level
+            //      whose suffix still has a gap; a rebalance of level h with c cells leaves level j < h with W_j - G_j cells, G_j =
+            //      gaps of the closed-form spread pattern that fall into the last W_j offsets.  The bitmap is not touched per op:
+            //      when the model is left, the LAST rebalance of every level (each still valid outside the suffix of the next lower
+            //      one) is written once and the gaps consumed since — all in the last leaf — are filled from the right.
+            if (model_ok && L == cap && blk == last_blk) {
+                uint32_t cnt;
+                {
+                    const uint64_t wl_ = rdlane64(word, 63);
+                    const uint32_t c_low = (uint32_t)popc64(wl_ & (my_low_mask << (63 & my_low_align)));
+                    uint32_t sb[7];
+                    sb[0] = (uint32_t)popc64(word);
+#pragma unroll
+                    for (int j = 1; j < 7; ++j) sb[j] = sb[j - 1] + __shfl_xor(sb[j - 1], 1 << (j - 1), 64);
+                    const uint32_t s1 = rdlane(sb[1], 63), s2 = rdlane(sb[2], 63), s3 = rdlane(sb[3], 63), s4 = rdlane(sb[4], 63),
+                                   s5 = rdlane(sb[5], 63), s6 = rdlane(sb[6], 63);
+                    const uint32_t c_mid = my_j == 1 ? s1 : my_j == 2 ? s2 : my_j == 3 ? s3 : my_j == 4 ? s4 : my_j == 5 ? s5 : s6;
+                    cnt = lvl_low ? c_low : (lvl_mid ? c_mid : 0u);
+                }
+                const uint32_t my_W = lvl_in_block ? (uint32_t)Wl : 0u;
+                uint32_t ev_c = 0;                      // lane <-> level: cell count of the level's last rebalance ...
+                bool ev_valid = false;                  // ... if no wider rebalance came after it
+                int t_since = 0;                        // appends since the last rebalance (level-0 accepts: gaps of the last leaf)
+                bool last_empty = false;                // right after a rebalance the last slot is a gap
+                P L_ev = L;
+                while (idx < end) {
+                    if (__builtin_expect(flags != nullptr && (idx >> 6) != fw_idx, 0)) { fw_idx = idx >> 6; fw = flags[fw_idx]; }
+                    if (__builtin_expect(last_empty && ((fw >> (idx & 63)) & 1ull), 0)) break;       // a semaphore while the last slot is empty: general path
+                    const uint32_t cnt2 = cnt + (cnt < my_W ? 1u : 0u);
+                    const uint64_t acc = __ballot(lvl_in_block && my_lo <= cnt2 && cnt2 <= my_hi);
+                    if (__builtin_expect(acc == 0, 0)) { need = 1; break; }      // a window wider than the block (or _extend!) decides
+                    cnt = cnt2;
+                    ++idx;
+                    const int h = __ffsll((unsigned long long)acc) - 1;
+                    if (__builtin_expect(h == 0, 0)) { ++t_since; last_empty = false; continue; }
+                    const int W = (int)seg << h;
+                    const int c = (int)rdlane(cnt, h);
+                    reb += 1; slots += W;
+                    if (lane == h) { ev_c = (uint32_t)c; ev_valid = true; }
+                    else if (lane < h) ev_valid = false;
+                    t_since = 0; last_empty = true;
+                    const int eb = (int)rdlane((uint32_t)my_eb, h);
+                    uint64_t e = eb >= 0 ? memo->ev[eb + c] : 0ull;           // same address in every lane
+                    if (__builtin_expect(e == 0, 0)) {
+                        SpreadGeom g;
+                        g.W = W; g.E = W - c;
+                        g.f = (double)W / (double)(W - c);
+                        g.inv_f = (double)(W - c) / (double)W;
+                        if (lane < h) cnt = my_W - (uint32_t)((W - c) - gaps_le(g, W - (int)my_W));
+                        L_ev = cap - W + (P)spread_last_cell(g);
+                        if (eb >= 0) {
+                            e = (uint64_t)rdlane(cnt, 0) | ((uint64_t)(h > 1 ? rdlane(cnt, 1) : 0u) << 16) | ((uint64_t)(h > 2 ? rdlane(cnt, 2) : 0u) << 32) |
+                                ((uint64_t)(h > 3 ? rdlane(cnt, 3) : 0u) << 48) | (L_ev == cap - 1 ? 1ull << 63 : 0ull);
+                            if (lane == 0) memo->ev[eb + c] = e;
+                        }
+                    } else {
+                        if (lane < h) cnt = (uint32_t)(e >> (16 * lane)) & 0x7fffu;
+                        L_ev = (e >> 63) ? cap - 1 : cap - 2;             // the exact position is recomputed when the model is left
+                    }
+                    if (__builtin_expect(L_ev != cap - 1, 0)) break;          // several trailing gaps: the next appends fill them left to right (general path)
+                }
+                // ---- leave the model: write the surviving rebalances, widest first, then the consumed gaps
+                uint64_t vm = __ballot(ev_valid);
+                while (vm != 0) {
+                    const int j = 63 - __clzll((long long)vm);
+                    vm &= ~(1ull << j);
+                    const int Wj = (int)seg << j;
+                    const P wsj = cap - Wj + 1;
+                    L = wave_spread_bits<P>(word, memo, lane, Wj, (int)rdlane(ev_c, j), (int)rdlane((uint32_t)my_wb, j), wsj, (int)(((wsj - 1) >> 6) & 63));
+                }
+                if (t_since > 0) {
+                    if (lane == 63)
+                        for (int q = 0; q < t_since; ++q) word |= 1ull << (63 - __clzll((long long)~word));
+                    L = cap;
+                }
+                if (need) break;
+                continue;
+            }
             const uint64_t word_saved = word;
             P ip;
             if (L < cap && !is_sem) {
@@ -468,60 +624,7 @@ __device__ void wave_fast_appends(Seq& S, RunComm* rc, RunMemo* memo, const uint
             reb += 1; slots += W;
             const P ws = ((ip - 1) & ~((P)W - 1)) + 1;
             const int lw0 = (int)(((ws - 1) >> 6) & 63);
-            if (W <= 256) {
-                const int nw = W < 64 ? 1 : (W >> 6);
-                const int wb = (int)rdlane((uint32_t)my_wb, h) + c * nw;
-                // a filled entry never ends with an empty word (c >= lo[h] cells spread evenly): 0 = not computed yet — one LDS
-                // round trip instead of a separate valid flag
-                uint64_t lastw = memo->words[wb + nw - 1];
-                if (lastw == 0) {
-                    SpreadGeom g;                                             // make_geom(W, c) with 32-bit conversions
-                    g.W = W; g.E = W - c;
-                    g.f = (double)W / (double)(W - c);
-                    g.inv_f = (double)(W - c) / (double)W;
-                    for (int t = 0; t < nw; ++t) {
-                        const int q = 64 * t + lane + 1;
-                        int rank;
-                        const bool cell = q <= W && !slot_is_gap(g, q, &rank);
-                        const uint64_t nb = __ballot(cell);
-                        if (lane == 0) memo->words[wb + t] = nb;
-                        lastw = nb;
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_s_waitcnt(0xc07f);                        // the other lanes read the entry below
-                }
-                if (W < 64) {
-                    const int sh = (int)((ws - 1) & 63);
-                    const uint64_t m = ((1ull << W) - 1ull) << sh;
-                    if (lane == lane_ip) word = (word & ~m) | (lastw << sh);
-                } else {
-                    const int t = lane - lw0;
-                    if (t >= 0 && t < nw) word = memo->words[wb + t];
-                }
-                L = ws - 1 + 64 * (nw - 1) + (64 - __clzll((long long)lastw));
-            } else {
-                SpreadGeom g;
-                g.W = W; g.E = W - c;
-                g.f = (double)W / (double)(W - c);
-                g.inv_f = (double)(W - c) / (double)W;
-                const int t = lane - lw0;
-                const int nww = W >> 6, E = W - c;
-                if (E <= 16 * nww) {
-                    // few gaps per word (dense window): the whole wave generates the E gap offsets D(k) — lane <-> k — and clears
-                    // their bits in an LDS image of the window, instead of every lane looping over the gaps of its own word
-                    if (lane < nww) memo->gapw[lane] = ~0ull;
-                    __builtin_amdgcn_wave_barrier();
-                    for (int k = lane + 1; k <= E; k += 64) {
-                        const int d = gap_D(g, k);                             // 1-based offset in the window
-                        atomicAnd(&memo->gapw[(d - 1) >> 6], ~(1ull << ((d - 1) & 63)));
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_s_waitcnt(0xc07f);                        // lgkmcnt(0): the wave's LDS atomics have landed
-                    if (t >= 0 && t < nww) word = memo->gapw[t];
-                    __builtin_amdgcn_wave_barrier();
-                } else if (t >= 0 && t < nww) word = spread_word_bits(g, t);
-                L = ws - 1 + (P)spread_last_cell(g);
-            }
+            L = wave_spread_bits<P>(word, memo, lane, W, c, (int)rdlane((uint32_t)my_wb, h), ws, lw0);
             ++idx;
         }
         if (w < nwords) S.occ[w] = word;
@@ -701,12 +804,13 @@ hipError_t launch_run_expand(const Op* ops, int64_t i0, int64_t R, const Ctl* ct
 // updates the control block: next_op, nb_elements, statistics.  A run ends early at an op that needs _extend! /
 // _shrink!; when that is the very first op, no_run_at tells the sequencer to execute it on the normal path.
 __global__ __launch_bounds__(SEQ_BLOCK) void k_append_run(uint64_t* occ, Ctl* ctl, int64_t i0, int64_t R, const uint64_t* flags,
-                                                          const int64_t* d_T, int wide_pos) {
+                                                          const int64_t* d_T, int wide_pos, int no_model) {
     __shared__ int64_t sRed[SEQ_BLOCK / 64];
     __shared__ RunComm sRun;
     __shared__ RunMemo sMemo;
     __shared__ int64_t sLo[MAX_LEVELS], sHi[MAX_LEVELS];
     for (int k = threadIdx.x; k < MEMO_WORDS; k += SEQ_BLOCK) sMemo.words[k] = 0ull;      // 0 = entry not computed yet
+    for (int k = threadIdx.x; k < EV_WORDS; k += SEQ_BLOCK) sMemo.ev[k] = 0ull;
     Seq S;
     S.keys = KeyArr{nullptr, 1, 0}; S.vals = nullptr; S.occ = occ; S.sems = nullptr; S.col_keys = nullptr; S.col_live = nullptr; S.ctl = ctl;
     S.capacity = ctl->capacity; S.seg = ctl->segment_capacity; S.height = ctl->height;
@@ -726,7 +830,7 @@ __global__ __launch_bounds__(SEQ_BLOCK) void k_append_run(uint64_t* occ, Ctl* ct
     const bool narrow_pos = !wide_pos && S.capacity <= (1ll << 30) && end <= (1ll << 30);
     const int64_t c_begin = clock64(), w_begin = wall_clock64();
     while (idx < end) {
-        if (threadIdx.x == 0) { rc->idx = idx; rc->L = L; }
+        if (threadIdx.x == 0) { rc->idx = idx; rc->L = L; rc->pad = no_model; }
         __syncthreads();
         const int64_t t0 = wall_clock64();
         if (threadIdx.x < 64) {
@@ -781,7 +885,8 @@ __global__ __launch_bounds__(SEQ_BLOCK) void k_append_run(uint64_t* occ, Ctl* ct
 hipError_t launch_append_run(uint64_t* occ, Ctl* ctl, int64_t i0, int64_t R, const uint64_t* flags, const int64_t* d_T,
                              hipStream_t stream) {
     static const int wide_pos = [] { const char* e = getenv("DSA_POS_WIDE"); return (e && e[0] == '1') ? 1 : 0; }();   // dev knob: 64-bit positions
-    hipLaunchKernelGGL(k_append_run, dim3(1), dim3(SEQ_BLOCK), 0, stream, occ, ctl, i0, R, flags, d_T, wide_pos);
+    static const int no_model = [] { const char* e = getenv("DSA_COUNT_MODEL"); return (e && e[0] == '0') ? 1 : 0; }();   // dev knob: bitmap replay only
+    hipLaunchKernelGGL(k_append_run, dim3(1), dim3(SEQ_BLOCK), 0, stream, occ, ctl, i0, R, flags, d_T, wide_pos, no_model);
     return hipGetLastError();
 }
 

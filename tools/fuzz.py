@@ -132,6 +132,8 @@ def run_vector(seed):
     for step in range(3 + g.next() % 8):
         nb = [10, 200, 3000, 20000][g.next() % 4]
         mode = g.next() % 3
+        if BIG and mode == 1:
+            nb = [20000, 60000, 150000][g.next() % 3]      # long ascending runs: the count model of the append replay, with extends
         if mode == 0:
             keys = 1 + (np.array([g.next() for _ in range(nb)], dtype=np.uint64) % np.uint64(span)).astype(np.int64)
         elif mode == 1:
