@@ -672,7 +672,42 @@ __device__ bool blk_slow_append(Seq& S, int64_t& L, bool is_sem) {
     __syncthreads();
     int64_t prev_ws = ip, prev_we = ip - 1, left = 0, right = 0, ws = 1, we = cap;
     bool accepted = false;
-    for (int64_t h = 0; h <= S.height; ++h) {
+    int64_t h0 = 0;
+    if (cap >= 4096) {
+        // Levels up to 65536 slots in ONE pass instead of two block-wide counts (four barriers) per level: every word of the
+        // aligned 65536-slot window around ip adds its popcount to the bucket of the smallest whole-word window that holds both
+        // it and ip's word; the count of a level is a prefix sum over the buckets (levels inside one word: masks of ip's word).
+        __shared__ unsigned int sBk[12];
+        const int64_t PW = cap < 65536 ? cap : 65536;
+        const int64_t wsP = ((ip - 1) & ~(PW - 1)) + 1;
+        const int64_t w0 = (wsP - 1) >> 6, nw = PW >> 6, ipw = (ip - 1) >> 6;
+        if (threadIdx.x < 12) sBk[threadIdx.x] = 0u;
+        __syncthreads();
+        for (int64_t k = threadIdx.x; k < nw; k += SEQ_BLOCK) {
+            const int64_t w = w0 + k;
+            const uint64_t x = (uint64_t)(w ^ ipw);
+            atomicAdd(&sBk[x ? 64 - __clzll((long long)x) : 0], (unsigned int)popc64(S.occ[w]));
+        }
+        __syncthreads();
+        const uint64_t wip = S.occ[ipw];
+        const int bip = (int)((ip - 1) & 63);
+        int64_t c = 0, h = 0;
+        for (; h <= S.height && (S.seg << h) <= PW; ++h) {
+            const int64_t W = S.seg << h;
+            if (W < 64) c = popc64(wip & ((((uint64_t)1 << W) - 1ull) << (bip & ~((int)W - 1))));
+            else {
+                const int lw = 63 - __clzll((long long)(W >> 6));          // window of 2^lw words
+                c = 0;
+                for (int k = 0; k <= lw; ++k) c += sBk[k];
+            }
+            if (S.lo[h] <= c && c <= S.hi[h]) { accepted = true; ws = ((ip - 1) & ~(W - 1)) + 1; we = ws + W - 1; break; }
+        }
+        left = c; right = 0;
+        h0 = h;                                   // the loop below continues above the window counted here
+        prev_ws = wsP; prev_we = wsP + PW - 1;
+        __syncthreads();                          // sBk is reused by the next call
+    }
+    for (int64_t h = h0; !accepted && h <= S.height; ++h) {
         const int64_t W = S.seg << h;
         ws = ((ip - 1) & ~(W - 1)) + 1;
         we = ws + W - 1;
