@@ -918,7 +918,7 @@ def test_differential_fuzz_short(dsa, hip, oracle):
     assert res.get("ok", 0) >= 30, res
 
 
-def test_forced_64bit_keys_build_in_a_subprocess(dsa, hip, oracle):
+def test_forced_64bit_keys_and_replay_variants_in_subprocesses(dsa, hip, oracle):
     """DSA_KEYS_WIDE=1 (read when the library is loaded) keeps every structure in 64-bit keys: the wide instantiations of the
     streaming kernels and the wide side of the key proxy stay covered — 12 s of the differential fuzzer in a child process."""
     import os
@@ -932,6 +932,12 @@ def test_forced_64bit_keys_build_in_a_subprocess(dsa, hip, oracle):
     assert "fuzz done" in r.stdout
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "appendbench.py"), "--check"], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "append parity ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    # DSA_COUNT_MODEL=0: the bitmap-only append replay (the path every op takes outside the count model's regime) on a whole batch
+    env = dict(os.environ, DSA_COUNT_MODEL="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "appendbench.py"), "--check"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "append parity ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz.py"), "8", "777"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "fuzz done" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 @pytest.mark.gpu
