@@ -82,7 +82,7 @@ struct Pma {
     double* d_q = nullptr; int64_t q_cap = 0;      // scratch for lookups (3 arrays of q_cap)
     int32_t* d_err = nullptr;
     int64_t stat_par_rounds = 0, stat_par_ops = 0, stat_seq_ops = 0, stat_seq_launches = 0;      // batch-parallel instrumentation
-    BurstGraph burst;
+    BurstGraph burst, burst_short;      // cached graphs of a full burst of rounds and of a short one (conflict-heavy phases)
     Plan* d_plans = nullptr; uint32_t* d_flags = nullptr; RoundState* d_rs = nullptr; RoundState* h_rs = nullptr;   // batch-parallel writes
     int64_t* d_small = nullptr;                     // 8 x int64 scratch
     // thresholds  src/pma.jl:58,70,87
@@ -125,6 +125,7 @@ void pma_destroy(Pma& P) {
     if (P.d_q) hipFree(P.d_q);
     if (P.d_err) hipFree(P.d_err);
     burst_graph_destroy(&P.burst);
+    burst_graph_destroy(&P.burst_short);
     if (P.d_plans) hipFree(P.d_plans);
     if (P.d_flags) hipFree(P.d_flags);
     if (P.d_rs) hipFree(P.d_rs);
@@ -529,7 +530,7 @@ int64_t run_ops_parallel(Pma& P, const std::vector<Op>& ops, int32_t* err) {
     *err = 0;
     const int64_t n = (int64_t)ops.size();
     if (n == 0) return 0;
-    constexpr int GMAX = 1024, MIN_PREFIX = 4, ROUNDS_PER_SYNC = 12;
+    constexpr int GMAX = 1024, MIN_PREFIX = 4, ROUNDS_PER_SYNC = 12, ROUNDS_SHORT = 3;
     ensure_key_width(P, ops);
     ensure_ops(P, n);
     HIPCHK(hipMemcpyAsync(P.d_ops, ops.data(), (size_t)n * sizeof(Op), hipMemcpyHostToDevice, P.stream));
@@ -545,6 +546,9 @@ int64_t run_ops_parallel(Pma& P, const std::vector<Op>& ops, int32_t* err) {
     static const int64_t SEQ_CHUNK0 = [] { const char* e = getenv("DSA_SEQ_CHUNK"); return e ? (int64_t)atoi(e) : (int64_t)8; }();
     int64_t i = 0, seq_chunk = SEQ_CHUNK0;
     int G = 256;
+    // a burst that stops in its first rounds (short conflict-free prefix, barrier op) leaves the rest of its graph as no-op
+    // launches (~2.5 us each, four per round): after such a stop the next burst is a short one, until one runs to its end
+    int burst_rounds = ROUNDS_PER_SYNC;
     bool host_ctl_stale = false;
     while (i < n) {
         // ---- a burst of rounds driven by the device-resident cursor; one host synchronisation per burst
@@ -555,7 +559,7 @@ int64_t run_ops_parallel(Pma& P, const std::vector<Op>& ops, int32_t* err) {
         {
             hipError_t e = launch_burst(P.K(), P.V(), P.O(), P.has_sems ? P.sems : nullptr, P.has_cols ? P.col_keys : nullptr,
                                         P.has_cols ? P.col_live : nullptr, P.d_ctl, P.d_ops, P.d_rs, P.d_plans, P.d_flags,
-                                        ROUNDS_PER_SYNC, &P.burst, P.stream);
+                                        burst_rounds, burst_rounds == ROUNDS_PER_SYNC ? &P.burst : &P.burst_short, P.stream);
             if (e != hipSuccess) fail(DSA_EHIP, std::string("burst launch: ") + hipGetErrorString(e));
         }
         HIPCHK(hipMemcpyAsync(P.h_rs, P.d_rs, sizeof(RoundState), hipMemcpyDeviceToHost, P.stream));
@@ -568,6 +572,7 @@ int64_t run_ops_parallel(Pma& P, const std::vector<Op>& ops, int32_t* err) {
         for (int q = 0; q < 8; ++q) P.stat_why[q] += rs.why[q];
         i = reached;
         G = rs.G;
+        burst_rounds = (rs.stop == 1 && rs.rounds <= ROUNDS_SHORT) ? ROUNDS_SHORT : ROUNDS_PER_SYNC;
         if (rs.stop != 1) continue;                       // burst used up (0) or batch finished (2)
         // ---- short prefix at op i: sequential sequencer for ops [i, i + seq_chunk)
         if (host_ctl_stale) { download_ctl(P); host_ctl_stale = false; }
