@@ -29,7 +29,11 @@ const COMBINE = IdDict{Function,Int32}(+ => Int32(0), * => Int32(1))
 
 "one process per GPU: select the device before creating handles (dsa_set_device)"
 set_device!(dev::Integer) = _check(ccall((:dsa_set_device, libdsa), Int32, (Int32,), dev))
-device_count() = ccall((:dsa_device_count, libdsa), Int32, ())
+function device_count()
+    n = Ref{Int32}(0)
+    _check(ccall((:dsa_device_count, libdsa), Int32, (Ref{Int32},), n))
+    return n[]
+end
 
 "column keys (col0, col0 + ncols] owned by shard `shard` (0-based) of `nshards` — dsa_shard_range"
 function shard_range(n::Integer, nshards::Integer, shard::Integer)
@@ -197,27 +201,32 @@ function nbpartitions(a::DynamicSparseMatrix, orientation::Integer)     # 0 = co
     out = Ref{Int64}(0); _check(ccall((:dsa_mat_nbpartitions, libdsa), Int32, (Ptr{Cvoid}, Int32, Ref{Int64}), a.h, orientation, out)); out[]
 end
 
-function _view(sym::Symbol, a::DynamicSparseMatrix, key::Int64)
-    cap = 64
-    while true
-        ks = Vector{Int64}(undef, cap); vs = Vector{Float64}(undef, cap); n = Ref{Int64}(0)
-        rc = GC.@preserve ks vs ccall((sym, libdsa), Int32,
-            (Ptr{Cvoid}, Int64, Ptr{Int64}, Ptr{Float64}, Int64, Ref{Int64}), a.h, key, ks, vs, cap, n)
-        rc == 8 && (cap *= 8; continue)          # DSA_ECAP
-        _check(rc)
-        return collect(zip(resize!(ks, n[]), resize!(vs, n[])))
+# ccall needs a literal (symbol, library) pair: the four entry points are stamped out with @eval
+for (fname, sym) in ((:_col_view, :dsa_mat_col_view), (:_row_view, :dsa_mat_row_view))
+    @eval function $fname(a::DynamicSparseMatrix, key::Int64)
+        cap = 64
+        while true
+            ks = Vector{Int64}(undef, cap); vs = Vector{Float64}(undef, cap); n = Ref{Int64}(0)
+            rc = GC.@preserve ks vs ccall(($(QuoteNode(sym)), libdsa), Int32,
+                (Ptr{Cvoid}, Int64, Ptr{Int64}, Ptr{Float64}, Int64, Ref{Int64}), a.h, key, ks, vs, cap, n)
+            rc == 8 && (cap *= 8; continue)          # DSA_ECAP
+            _check(rc)
+            return collect(zip(resize!(ks, n[]), resize!(vs, n[])))
+        end
     end
 end
-Base.view(a::DynamicSparseMatrix, ::Colon, col::Int64) = _view(:dsa_mat_col_view, a, col)   # src/matrix.jl:83-88
-Base.view(a::DynamicSparseMatrix, row::Int64, ::Colon) = _view(:dsa_mat_row_view, a, row)   # src/matrix.jl:70-81
-# m[:, col] / m[row, :]: new device-resident vectors (src/pcsr.jl:269-291)
-function _slice(sym::Symbol, a::DynamicSparseMatrix, key::Int64)
-    out = Ref{Ptr{Cvoid}}(C_NULL)
-    _check(ccall((sym, libdsa), Int32, (Ptr{Cvoid}, Int64, Ref{Ptr{Cvoid}}), a.h, key, out))
-    return DynamicSparseVector(out[])
+Base.view(a::DynamicSparseMatrix, ::Colon, col::Int64) = _col_view(a, col)   # src/matrix.jl:83-88
+Base.view(a::DynamicSparseMatrix, row::Int64, ::Colon) = _row_view(a, row)   # src/matrix.jl:70-81
+
+for (fname, sym) in ((:_col_slice, :dsa_mat_col_slice), (:_row_slice, :dsa_mat_row_slice))
+    @eval function $fname(a::DynamicSparseMatrix, key::Int64)
+        out = Ref{Ptr{Cvoid}}(C_NULL)
+        _check(ccall(($(QuoteNode(sym)), libdsa), Int32, (Ptr{Cvoid}, Int64, Ref{Ptr{Cvoid}}), a.h, key, out))
+        return DynamicSparseVector(out[])
+    end
 end
-Base.getindex(a::DynamicSparseMatrix, ::Colon, col::Int64) = _slice(:dsa_mat_col_slice, a, col)
-Base.getindex(a::DynamicSparseMatrix, row::Int64, ::Colon) = _slice(:dsa_mat_row_slice, a, row)
+Base.getindex(a::DynamicSparseMatrix, ::Colon, col::Int64) = _col_slice(a, col)
+Base.getindex(a::DynamicSparseMatrix, row::Int64, ::Colon) = _row_slice(a, row)
 "n getindex calls in one ccall"
 function getindex_batch(a::DynamicSparseMatrix, I::Vector{Int64}, J::Vector{Int64})
     out = Vector{Float64}(undef, length(I))

@@ -66,3 +66,48 @@ def test_shard_range_matches_the_host_layer(dsa):
     import pytest
     with pytest.raises(dsa.DsaArgumentError):
         b.call("shard_range", 10, 2, 2, C.byref(c0), C.byref(nc))
+
+
+def test_julia_wrapper_binds_only_declared_symbols():
+    """The Julia wrapper cannot be executed here (no Julia toolchain): at least every symbol it `ccall`s must be declared in
+    include/dsa.h, and the argument count of each ccall must match the C prototype."""
+    jl = open(os.path.join(ROOT, "dynamicsparsearrays.jl_amd", "julia", "DynamicSparseArraysAMD.jl")).read()
+    hdr = open(os.path.join(ROOT, "include", "dsa.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    def c_class(a):
+        a = a.strip()
+        if "*" in a or "[" in a:
+            return "ptr"
+        for t, k in (("int64_t", "i64"), ("int32_t", "i32"), ("double", "f64")):
+            if re.search(r"\b" + t + r"\b", a):
+                return k
+        raise AssertionError(a)
+
+    def jl_class(a):
+        a = a.strip()
+        if a.startswith(("Ptr{", "Ref{")):
+            return "ptr"
+        return {"Int64": "i64", "Int32": "i32", "Float64": "f64", "Cdouble": "f64"}[a]
+
+    protos = {}
+    for m in re.finditer(r"\b(dsa_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", hdr, flags=re.S):
+        args = m.group(2).strip()
+        protos[m.group(1)] = [] if args in ("", "void") else [c_class(a) for a in args.split(",") if a.strip()]
+    used = re.findall(r"ccall\(\(:(dsa_[a-z0-9_]+),\s*libdsa\),\s*\w+,\s*\(((?:[^()]|\([^()]*\))*)\)", jl)
+    assert len(used) >= 30
+    for name, argt in used:
+        assert name in protos, name
+        got = [jl_class(a) for a in re.split(r",\s*(?![^{}]*\})", argt) if a.strip()]
+        assert got == protos[name], (name, got, protos[name])
+    # entry points stamped out with @eval: the symbol list of the `for` and the argument tuple of the ccall inside it
+    stamped = re.findall(r"for \(fname, sym\) in \(([^\n]*)\)\n(.*?)\nend\n", jl, flags=re.S)
+    assert len(stamped) == 2
+    for syms, body in stamped:
+        argt = re.search(r"ccall\(\(\$\(QuoteNode\(sym\)\), libdsa\), Int32,\s*\(((?:[^()]|\([^()]*\))*)\)", body).group(1)
+        got = [jl_class(a) for a in re.split(r",\s*(?![^{}]*\})", argt) if a.strip()]
+        for name in re.findall(r":(dsa_[a-z0-9_]+)", syms):
+            assert got == protos[name], (name, got, protos[name])
+    assert "ccall((sym" not in jl          # ccall needs a literal (symbol, library) pair
+    # symbols passed indirectly (the view / slice helpers take the symbol as an argument)
+    for name in re.findall(r":(dsa_[a-z0-9_]+)", jl):
+        assert name in protos, name
