@@ -315,7 +315,12 @@ hipError_t launch_partition_range(const int64_t* sems, const int64_t* col_keys, 
 // y = P x over one orientation P, gather form: y[part_key[p]] = sum over partition p of val * x[key]
 hipError_t launch_spmv_gather(KeyArr keys, const double* vals, const uint64_t* occ, int64_t capacity,
                               const int64_t* sems, const int64_t* part_keys, const uint8_t* part_live, int64_t table_len,
-                              const double* x, int64_t nx, double* y, int64_t ny, int pattern, hipStream_t stream);
+                              const double* x, int64_t nx, double* y, int64_t ny, int pattern, int mode, hipStream_t stream);
+constexpr int SPMV_ZFILL = 1;          // launch_spmv_gather mode bits (spmv.hip)
+constexpr int SPMV_PLAIN_STREAM = 2;
+constexpr int64_t SPMV_SPAN_SLOTS = 512;      // slots one wave of k_spmv_gather owns
+hipError_t launch_spmv_meta(const int64_t* sems, const int64_t* part_keys, int64_t table_len, int64_t capacity,
+                            unsigned long long* out5, hipStream_t stream);
 // y[key] += x[part_key[p]] * val, scatter form with fp64 atomics (the literal _mul loop nest)
 hipError_t launch_spmv_scatter(KeyArr keys, const double* vals, const uint64_t* occ, int64_t capacity,
                                const int64_t* sems, const int64_t* part_keys, const uint8_t* part_live, int64_t table_len,

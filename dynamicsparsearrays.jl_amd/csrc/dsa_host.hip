@@ -85,6 +85,10 @@ struct Pma {
     BurstGraph burst, burst_short;      // cached graphs of a full burst of rounds and of a short one (conflict-heavy phases)
     Plan* d_plans = nullptr; uint32_t* d_flags = nullptr; RoundState* d_rs = nullptr; RoundState* h_rs = nullptr;   // batch-parallel writes
     int64_t* d_small = nullptr;                     // 8 x int64 scratch
+    // bumped by every launch that can move cells or change the tables; SpmvMeta is recomputed when it differs
+    int64_t layout_epoch = 0;
+    int64_t stat_spmv_nomemset = 0;
+    struct SpmvMeta { int64_t epoch = -1; bool ordered = false; int64_t max_extent = 0, max_gap = 0, first_key = 0, last_key = 0; } spmv_meta;
     // thresholds  src/pma.jl:58,70,87
     double t_h = 0.7, t_0 = 0.92, p_h = 0.3, p_0 = 0.08, t_d = 0.0, p_d = 0.0;
 
@@ -295,6 +299,7 @@ void ensure_capacity_alloc(Pma& P, int64_t slots) {
 // (root _even_rebalance!, _extend!, pack! + _shrink!)  src/pma.jl:94-103,135-161
 void root_rebalance(Pma& P, int64_t src_cap, int64_t new_cap, int64_t m, bool src_packed) {
     ensure_capacity_alloc(P, std::max(src_cap, new_cap));
+    ++P.layout_epoch;
     const int alt = 1 - P.cur;
     hipError_t e = launch_rebalance(P.KA(P.cur), P.vals[P.cur], P.occ[P.cur], 1, src_cap, src_packed,
                                     P.KA(alt), P.vals[alt], P.occ[alt], 1, new_cap, m,
@@ -313,6 +318,7 @@ void root_rebalance(Pma& P, int64_t src_cap, int64_t new_cap, int64_t m, bool sr
 void window_rebalance(Pma& P, int64_t ws, int64_t we, int64_t m) {
     if (ws == 1 && we == P.capacity()) { root_rebalance(P, P.capacity(), P.capacity(), m, false); return; }
     const int alt = 1 - P.cur;
+    ++P.layout_epoch;
     hipError_t e = launch_rebalance(P.K(), P.V(), P.O(), ws, we, false, P.KA(alt), P.vals[alt], P.occ[alt], ws, we, m,
                                     P.has_sems ? P.sems : nullptr, &P.work, P.stream);
     if (e != hipSuccess) fail(DSA_EHIP, std::string("rebalance launch: ") + hipGetErrorString(e));
@@ -350,6 +356,7 @@ void build_from_packed(Pma& P, const std::vector<int64_t>& keys, const std::vect
 void permute_run(Pma& P, const Op* cells, int64_t i0, int64_t n0) {
     const int alt = 1 - P.cur;
     const int64_t cap = P.capacity();
+    ++P.layout_epoch;
     hipError_t e = launch_permute(P.K(), P.V(), P.occ_old, cap, P.KA(alt), P.vals[alt], P.O(), cap, n0, cells, i0,
                                   P.has_sems ? P.sems : nullptr, &P.work, &P.work2, P.stream);
     if (e != hipSuccess) fail(DSA_EHIP, std::string("permute launch: ") + hipGetErrorString(e));
@@ -419,6 +426,7 @@ void seq_launch(SeqRun& r, bool upload = true) {
     Pma& P = *r.P;
     // pinned h_ctl: H2D, kernel and D2H are stream-ordered; the host does not touch h_ctl until the next synchronize
     if (upload) HIPCHK(hipMemcpyAsync(P.d_ctl, P.h_ctl, sizeof(Ctl), hipMemcpyHostToDevice, P.stream));
+    ++P.layout_epoch;
     hipError_t e = launch_sequencer(P.K(), P.V(), P.O(), P.has_sems ? P.sems : nullptr, P.has_cols ? P.col_keys : nullptr,
                                     P.has_cols ? P.col_live : nullptr, P.d_ctl, P.d_ops, r.n, std::max(r.n, r.n_avail),
                                     g_append_runs && P.occ_old != nullptr, P.stream);
@@ -557,6 +565,7 @@ int64_t run_ops_parallel(Pma& P, const std::vector<Op>& ops, int32_t* err) {
         rs.cursor = i; rs.limit = n; rs.G = G; rs.min_prefix = MIN_PREFIX;
         HIPCHK(hipMemcpyAsync(P.d_rs, P.h_rs, sizeof(RoundState), hipMemcpyHostToDevice, P.stream));
         {
+            ++P.layout_epoch;
             hipError_t e = launch_burst(P.K(), P.V(), P.O(), P.has_sems ? P.sems : nullptr, P.has_cols ? P.col_keys : nullptr,
                                         P.has_cols ? P.col_live : nullptr, P.d_ctl, P.d_ops, P.d_rs, P.d_plans, P.d_flags,
                                         burst_rounds, burst_rounds == ROUNDS_PER_SYNC ? &P.burst : &P.burst_short, P.stream);
@@ -625,6 +634,7 @@ void pma_info(Pma& P, int64_t nb_partitions_or_len, int64_t* info) {
     info[DSA_INFO_STAT_EXTENDS] = c.stat_extends;
     info[DSA_INFO_STAT_SHRINKS] = c.stat_shrinks;
     info[11] = P.stat_par_rounds; info[12] = P.stat_par_ops; info[13] = P.stat_seq_ops;
+    info[DSA_INFO_STAT_SPMV_NOMEMSET] = P.stat_spmv_nomemset;
 }
 
 void export_slots(Pma& P, int64_t* keys, double* vals, uint8_t* occ, int64_t cap) {
@@ -751,6 +761,7 @@ void pma_build_dev(Pma& P, const int64_t* d_part, const int64_t* d_key, const do
         if (P.has_cols && np > 0) HIPCHK(hipMemsetAsync(P.col_live, 1, (size_t)np, P.stream));
     } catch (...) { build_abort(sc); throw; }
     const auto tp2 = std::chrono::steady_clock::now();
+    ++P.layout_epoch;
     e = build_emit(d_val, combine, sc, P.K(), P.V(), P.has_cols ? P.col_keys : nullptr, mode, nparts_explicit, P.stream);
     if (e != hipSuccess) fail(DSA_EHIP, std::string("K-build emit: ") + hipGetErrorString(e));
     const auto tp3 = std::chrono::steady_clock::now();
@@ -982,13 +993,51 @@ void ensure_xy(dsa_mat* h, int64_t nx, int64_t ny) {
 
 // mat * v walks the colmajor orientation in the reference (src/operations.jl:14-24), transpose(mat) * v the
 // rowmajor one (:26-36).  Gather form: the twin orientation, whose partitions are the OUTPUT index.
+// What the gather launch may assume about an orientation (recomputed after every launch that can change the layout or
+// the tables: one small kernel + an 8-byte round trip, amortised over the SpMV calls between two write batches).
+const Pma::SpmvMeta& spmv_meta(Pma& P) {
+    Pma::SpmvMeta& M = P.spmv_meta;
+    if (M.epoch == P.layout_epoch) return M;
+    M = Pma::SpmvMeta();
+    M.epoch = P.layout_epoch;
+    const Ctl& c = *P.h_ctl;
+    if (!P.has_cols || c.table_len <= 0 || c.nb_partitions != c.table_len || c.n_pending != 0) {     // tombstones: memset path
+        static const char* dbg = getenv("DSA_DBG_SPMV_META");
+        if (dbg) fprintf(stderr, "spmv_meta: has_cols %d table_len %lld nb_partitions %lld n_pending %lld\n", (int)P.has_cols, (long long)c.table_len,
+                         (long long)c.nb_partitions, (long long)c.n_pending);
+        return M;
+    }
+    hipError_t e = launch_spmv_meta(P.sems, P.col_keys, c.table_len, c.capacity, (unsigned long long*)P.d_small, P.stream);
+    if (e != hipSuccess) fail(DSA_EHIP, std::string("spmv meta launch: ") + hipGetErrorString(e));
+    int64_t r[5];
+    HIPCHK(hipMemcpyAsync(r, P.d_small, sizeof(r), hipMemcpyDeviceToHost, P.stream));
+    HIPCHK(hipStreamSynchronize(P.stream));
+    M.ordered = r[4] == 0;
+    M.max_extent = r[0]; M.max_gap = r[1]; M.first_key = r[2]; M.last_key = r[3];
+    { static const char* dbg = getenv("DSA_DBG_SPMV_META");
+      if (dbg) fprintf(stderr, "spmv_meta: table_len %lld ordered %d max_extent %lld max_gap %lld first %lld last %lld\n", (long long)c.table_len,
+                       (int)M.ordered, (long long)M.max_extent, (long long)M.max_gap, (long long)M.first_key, (long long)M.last_key); }
+    return M;
+}
+
+// mat * v walks the colmajor orientation in the reference (src/operations.jl:14-24), transpose(mat) * v the
+// rowmajor one (:26-36).  Gather form: the twin orientation, whose partitions are the OUTPUT index.
 void spmv_dev(dsa_mat* h, int32_t transpose, int32_t algo, const double* d_x, int64_t nx, double* d_y, int64_t ny, hipStream_t s,
               int pattern = 0) {
     if (!h->has_major) fail(DSA_EMODE, "matrix is in fill mode");
     hipError_t e;
     if (algo == 0) {
         Pma& P = transpose ? h->col : h->row;
-        e = launch_spmv_gather(P.K(), P.V(), P.O(), P.capacity(), P.sems, P.col_keys, P.col_live, P.h_ctl->table_len, d_x, nx, d_y, ny, pattern, s);
+        int mode = 0;
+        // no memset of y when every row is written exactly once by the kernel: no partition longer than a span (no atomics)
+        // and the rows without a partition are few (the owner of the next partition zeroes them)
+        constexpr int64_t MAX_FILL = 4096;
+        const Pma::SpmvMeta& M = spmv_meta(P);
+        if (M.ordered && M.max_extent <= SPMV_SPAN_SLOTS && M.max_gap <= MAX_FILL && M.first_key >= 1 && M.first_key <= MAX_FILL &&
+            ny - M.last_key <= MAX_FILL)
+            { mode |= SPMV_ZFILL; ++P.stat_spmv_nomemset; }
+        if (nx * (int64_t)sizeof(double) <= (3 << 20)) mode |= SPMV_PLAIN_STREAM;      // x stays in an XCD's 4 MB L2 beside the stream
+        e = launch_spmv_gather(P.K(), P.V(), P.O(), P.capacity(), P.sems, P.col_keys, P.col_live, P.h_ctl->table_len, d_x, nx, d_y, ny, pattern, mode, s);
     } else if (algo == 1) {
         Pma& P = transpose ? h->row : h->col;
         e = launch_spmv_scatter(P.K(), P.V(), P.O(), P.capacity(), P.sems, P.col_keys, P.col_live, P.h_ctl->table_len, d_x, nx, d_y, ny, s);

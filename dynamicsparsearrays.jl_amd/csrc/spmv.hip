@@ -187,7 +187,21 @@ __device__ __forceinline__ double product_of(double v, double xv, bool count_pas
     return count_pass ? (xv != 0.0 ? 1.0 : 0.0) : v * xv;
 }
 
-template <bool WIDE>
+// NT: the slot streams are loaded non-temporal (x larger than an XCD's L2: the stream must not evict it) or plain (x
+//     L2-resident: plain stream loads overlap the gathers better; tools/gatherbench2.hip: 56.8 vs 74.5 us at 1 MB of x).
+// ZFILL: y is NOT zeroed in front of the launch.  Every row that owns a semaphore is written exactly once (plain
+//     store) and the owner of a semaphore also zeroes the rows between the previous partition key and its own (the
+//     last partition: up to ny).  Only valid when no partition is longer than a span (no atomics), the tables are in
+//     key order without tombstones, and at least one partition exists — decided by the host (SpmvMeta).
+// ZFILL: rows without a partition between the previous partition key and `row` (exclusive); behind the last partition: up to ny
+__device__ __forceinline__ void zero_fill_front(double* __restrict__ y, int64_t ny, int64_t prev, int64_t row, bool tail) {
+    const int64_t lo = prev > 0 ? prev : 0;
+    const int64_t hi = row < ny + 1 ? row : ny + 1;
+    for (int64_t r = lo + 1; r < hi; ++r) y[r - 1] = 0.0;
+    if (tail) for (int64_t r = (row > 0 ? row : 0) + 1; r <= ny; ++r) y[r - 1] = 0.0;
+}
+
+template <bool WIDE, bool NT, bool ZFILL>
 __global__ __launch_bounds__(SP_BLOCK) void k_spmv_gather(KeyArr keys, const double* __restrict__ vals,
                                                           const uint64_t* __restrict__ occ, int64_t capacity,
                                                           const int64_t* __restrict__ sems,
@@ -196,7 +210,7 @@ __global__ __launch_bounds__(SP_BLOCK) void k_spmv_gather(KeyArr keys, const dou
                                                           double* __restrict__ y, int64_t ny, int pattern) {
     typedef typename std::conditional<WIDE, int64_t, int32_t>::type key_t;      // physical key width, fixed at compile time for the streams
     const key_t* __restrict__ kp = static_cast<const key_t*>(keys.p);
-    __shared__ double sPw[SP_WAVES][SW_SLOTS];
+    __shared__ double sPw[SP_WAVES][SW_SLOTS + 1];      // [SW_SLOTS]: ZFILL, key of the partition in front of the span's first semaphore
     __shared__ uint16_t sListw[SP_WAVES][SW_SLOTS];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -222,8 +236,8 @@ __global__ __launch_bounds__(SP_BLOCK) void k_spmv_gather(KeyArr keys, const dou
 #pragma unroll
     for (int j = 0; j <= SW_WORDS; ++j) {
         const int64_t w = w0 + j < nwords ? w0 + j : nwords - 1;
-        k[j] = (int64_t)__builtin_nontemporal_load(kp + (w << 6) + lane);
-        v[j] = __builtin_nontemporal_load(vals + (w << 6) + lane);
+        k[j] = (int64_t)(NT ? __builtin_nontemporal_load(kp + (w << 6) + lane) : kp[(w << 6) + lane]);
+        v[j] = NT ? __builtin_nontemporal_load(vals + (w << 6) + lane) : vals[(w << 6) + lane];
     }
     // the word in front: does the previous span own the cells before our first semaphore?
     const int64_t pw = w0 > 0 ? w0 - 1 : 0;
@@ -232,6 +246,8 @@ __global__ __launch_bounds__(SP_BLOCK) void k_spmv_gather(KeyArr keys, const dou
 
     // ---- semaphore ballots, one gather per lane and word -----------------------------------------------------------------
     uint64_t sb[SW_WORDS + 1], cm[SW_WORDS + 1];
+    bool has_last = false;         // ZFILL: the last partition of the table has its semaphore in this span
+    int64_t front_key = 0; bool front_mine = false;
     int64_t q[SW_WORDS + 1];       // cell: bits of x[key] ; semaphore: row key of its partition
     const uint32_t tlen = table_len < 0x7fffffff ? (uint32_t)table_len : 0x7fffffffu;
 #pragma unroll
@@ -250,8 +266,18 @@ __global__ __launch_bounds__(SP_BLOCK) void k_spmv_gather(KeyArr keys, const dou
         const int64_t idx = cell ? k[j] - 1 : (semrow ? (int64_t)id1 : 0);
         q[j] = base[idx];
         if (issem && !semrow) q[j] = 0;
+        if (ZFILL && j < SW_WORDS) {
+            // the first semaphore of the span fetches the key of the partition in front of it (ids ascend along the array);
+            // the last partition of the table is remembered: its owner zeroes the tail of y
+            bool earlier = (sb[j] & mask_lt(lane)) != 0;
+#pragma unroll
+            for (int i = 0; i < j; ++i) earlier = earlier || sb[i] != 0;
+            if (semrow && !earlier) { front_key = id1 > 0 ? part_keys[id1 - 1] : 0; front_mine = true; }
+            has_last = has_last || __ballot(semrow && id1 + 1 == tlen) != 0;
+        }
     }
     // ---- products and semaphore rows -> LDS ; compact the semaphores of the span ---------------------------------------
+    if (ZFILL && front_mine) sP[SW_SLOTS] = __longlong_as_double(front_key);
     int nsem = 0;
 #pragma unroll
     for (int j = 0; j <= SW_WORDS; ++j) {
@@ -280,6 +306,7 @@ __global__ __launch_bounds__(SP_BLOCK) void k_spmv_gather(KeyArr keys, const dou
             const bool is_last = e == nsem - 1;
             const int end = is_last ? endpos : (int)sList[e + 1];
             const int64_t row = __double_as_longlong(sP[a]);
+            if (ZFILL) zero_fill_front(y, ny, __double_as_longlong(sP[e > 0 ? (int)sList[e - 1] : SW_SLOTS]), row, is_last && has_last);
             double sum = 0.0;
             int t = a + 1;
             for (; t + 3 < end; t += 4) {
@@ -303,6 +330,7 @@ __global__ __launch_bounds__(SP_BLOCK) void k_spmv_gather(KeyArr keys, const dou
             const bool is_last = e == nsem - 1;
             const int end = is_last ? endpos : (int)sList[e + 1];
             const int64_t row = __double_as_longlong(sP[a]);
+            if (ZFILL && lane == 0) zero_fill_front(y, ny, __double_as_longlong(sP[e > 0 ? (int)sList[e - 1] : SW_SLOTS]), row, is_last && has_last);
             double sum = 0.0;
             for (int t = a + 1 + lane; t < end; t += 64) sum += sP[t];
             sum = wave_reduce_add_f64(sum);
@@ -445,35 +473,101 @@ hipError_t launch_scatter_x(const int64_t* xi, const double* xv, int64_t nx, dou
 }
 
 #include <cstdlib>
-static hipError_t launch_spmv(bool scatter, int pattern, KeyArr keys, const double* vals, const uint64_t* occ, int64_t capacity,
+// ---- what the gather launch may assume about one orientation (host cache: SpmvMeta in dsa_host.hip) --------------------
+// out[0] = longest partition extent in slots (semaphore .. slot in front of the next semaphore / end of the array),
+// out[1] = largest difference of two consecutive partition keys, out[2] = first key, out[3] = last key,
+// out[4] = 1 if keys do not strictly ascend with the id or a semaphore is missing (tombstone).  Tables without tombstones only.
+__global__ __launch_bounds__(256) void k_spmv_meta(const int64_t* __restrict__ sems, const int64_t* __restrict__ part_keys,
+                                                   int64_t table_len, int64_t capacity, unsigned long long* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long ext = 0, gap = 0, bad = 0;
+    if (i < table_len) {
+        const int64_t s0 = sems[i];
+        const int64_t s1 = i + 1 < table_len ? sems[i + 1] : capacity + 1;
+        if (s0 <= 0 || s1 <= s0) bad = 1; else ext = (unsigned long long)(s1 - s0);
+        if (i + 1 < table_len) {
+            const int64_t k0 = part_keys[i], k1 = part_keys[i + 1];
+            if (k1 <= k0) bad = 1; else gap = (unsigned long long)(k1 - k0);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long e2 = __shfl_xor(ext, o, 64), g2 = __shfl_xor(gap, o, 64), b2 = __shfl_xor(bad, o, 64);
+        ext = e2 > ext ? e2 : ext; gap = g2 > gap ? g2 : gap; bad |= b2;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (ext) atomicMax(&out[0], ext);
+        if (gap) atomicMax(&out[1], gap);
+        if (bad) atomicMax(&out[4], 1ull);
+    }
+    if (i == 0) { out[2] = (unsigned long long)part_keys[0]; out[3] = (unsigned long long)part_keys[table_len - 1]; }
+}
+hipError_t launch_spmv_meta(const int64_t* sems, const int64_t* part_keys, int64_t table_len, int64_t capacity,
+                            unsigned long long* out5, hipStream_t stream) {
+    hipError_t e = hipMemsetAsync(out5, 0, 5 * sizeof(unsigned long long), stream);
+    if (e != hipSuccess) return e;
+    if (table_len > 0)
+        hipLaunchKernelGGL(k_spmv_meta, dim3((unsigned)((table_len + 255) / 256)), dim3(256), 0, stream, sems, part_keys, table_len,
+                           capacity, out5);
+    return hipGetLastError();
+}
+
+template <bool WIDE, bool NT, bool ZFILL>
+static void launch_gather_t(int64_t grid, hipStream_t stream, KeyArr keys, const double* vals, const uint64_t* occ, int64_t capacity,
+                            const int64_t* sems, const int64_t* part_keys, int64_t table_len, const double* x, int64_t nx, double* y,
+                            int64_t ny, int pattern) {
+    hipLaunchKernelGGL((k_spmv_gather<WIDE, NT, ZFILL>), dim3((unsigned)grid), dim3(SP_BLOCK), 0, stream, keys, vals, occ, capacity, sems,
+                       part_keys, table_len, x, nx, y, ny, pattern);
+}
+
+// mode bit 0 (SPMV_ZFILL): skip the memset of y, the kernel zeroes the rows without a partition itself (see k_spmv_gather);
+// mode bit 1 (SPMV_PLAIN_STREAM): plain instead of non-temporal slot loads.  Scatter form: mode ignored.
+static hipError_t launch_spmv(bool scatter, int pattern, int mode, KeyArr keys, const double* vals, const uint64_t* occ, int64_t capacity,
                               const int64_t* sems, const int64_t* part_keys, int64_t table_len, const double* x, int64_t nx,
                               double* y, int64_t ny, hipStream_t stream) {
-    hipError_t e = hipMemsetAsync(y, 0, (size_t)ny * sizeof(double), stream);
-    if (e != hipSuccess) return e;
-    { static const char* dbg = getenv("DSA_DBG_SPMV"); if (dbg && pattern == 0) pattern = atoi(dbg); }
+    { static const char* dbg = getenv("DSA_DBG_SPMV"); if (dbg && pattern == 0) pattern = atoi(dbg) & 4; }
+    {   // dev knobs: DSA_SPMV_ZFILL=0 keeps the memset, DSA_SPMV_STREAM=nt|plain forces the stream policy
+        static const char* z = getenv("DSA_SPMV_ZFILL"); if (z && z[0] == '0') mode &= ~1;
+        static const char* st = getenv("DSA_SPMV_STREAM"); if (st) mode = (mode & ~2) | (st[0] == 'p' ? 2 : 0);
+    }
+    if (scatter) mode = 0;
+    const bool zfill = (mode & 1) && table_len > 0;
+    if (!zfill) {
+        hipError_t e = hipMemsetAsync(y, 0, (size_t)ny * sizeof(double), stream);
+        if (e != hipSuccess) return e;
+    }
     const int64_t ntiles = (capacity + SP_TILE - 1) / SP_TILE;
     const int64_t grid = ntiles >= 64 ? 8 * ((ntiles + 7) / 8) : ntiles;     // see the XCD-aware mapping in k_spmv
-    if (scatter)
+    if (scatter) {
         hipLaunchKernelGGL(k_spmv_scatter, dim3((unsigned)grid), dim3(SP_BLOCK), 0, stream, keys, vals, occ, capacity, sems,
                            part_keys, table_len, x, nx, y, ny, 0);
-    else if (keys.wide)
-        hipLaunchKernelGGL(k_spmv_gather<true>, dim3((unsigned)grid), dim3(SP_BLOCK), 0, stream, keys, vals, occ, capacity, sems,
-                           part_keys, table_len, x, nx, y, ny, pattern);
-    else
-        hipLaunchKernelGGL(k_spmv_gather<false>, dim3((unsigned)grid), dim3(SP_BLOCK), 0, stream, keys, vals, occ, capacity, sems,
-                           part_keys, table_len, x, nx, y, ny, pattern);
+        return hipGetLastError();
+    }
+    const int sel = (keys.wide ? 4 : 0) | ((mode & 2) ? 0 : 2) | (zfill ? 1 : 0);
+#define DSA_GATHER_CASE(W_, N_, Z_) launch_gather_t<W_, N_, Z_>(grid, stream, keys, vals, occ, capacity, sems, part_keys, table_len, x, nx, y, ny, pattern)
+    switch (sel) {
+        case 0: DSA_GATHER_CASE(false, false, false); break;
+        case 1: DSA_GATHER_CASE(false, false, true); break;
+        case 2: DSA_GATHER_CASE(false, true, false); break;
+        case 3: DSA_GATHER_CASE(false, true, true); break;
+        case 4: DSA_GATHER_CASE(true, false, false); break;
+        case 5: DSA_GATHER_CASE(true, false, true); break;
+        case 6: DSA_GATHER_CASE(true, true, false); break;
+        default: DSA_GATHER_CASE(true, true, true); break;
+    }
+#undef DSA_GATHER_CASE
     return hipGetLastError();
 }
 
 hipError_t launch_spmv_gather(KeyArr keys, const double* vals, const uint64_t* occ, int64_t capacity,
                               const int64_t* sems, const int64_t* part_keys, const uint8_t*, int64_t table_len,
-                              const double* x, int64_t nx, double* y, int64_t ny, int pattern, hipStream_t stream) {
-    return launch_spmv(false, pattern, keys, vals, occ, capacity, sems, part_keys, table_len, x, nx, y, ny, stream);
+                              const double* x, int64_t nx, double* y, int64_t ny, int pattern, int mode, hipStream_t stream) {
+    return launch_spmv(false, pattern, mode, keys, vals, occ, capacity, sems, part_keys, table_len, x, nx, y, ny, stream);
 }
 hipError_t launch_spmv_scatter(KeyArr keys, const double* vals, const uint64_t* occ, int64_t capacity,
                                const int64_t* sems, const int64_t* part_keys, const uint8_t*, int64_t table_len,
                                const double* x, int64_t nx, double* y, int64_t ny, hipStream_t stream) {
-    return launch_spmv(true, 0, keys, vals, occ, capacity, sems, part_keys, table_len, x, nx, y, ny, stream);
+    return launch_spmv(true, 0, 0, keys, vals, occ, capacity, sems, part_keys, table_len, x, nx, y, ny, stream);
 }
 
 }  // namespace dsa

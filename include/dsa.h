@@ -61,6 +61,7 @@ enum {
     DSA_INFO_STAT_PAR_ROUNDS = 11, /* batch-parallel rounds / ops applied in parallel / ops applied by the sequencer */
     DSA_INFO_STAT_PAR_OPS = 12,
     DSA_INFO_STAT_SEQ_OPS = 13,
+    DSA_INFO_STAT_SPMV_NOMEMSET = 14, /* instrumentation: gather SpMV launches over this orientation that needed no memset of y */
     DSA_INFO_COUNT = 16
 };
 

@@ -619,6 +619,74 @@ def test_spmv_device_pointers_gather_and_scatter(dsa, hip, oracle):
             np.testing.assert_allclose(yd.cpu().numpy(), ref, rtol=RTOL, atol=0)
 
 
+def test_spmv_without_memset_and_its_fallbacks(dsa, hip, oracle):
+    """The gather SpMV skips the memset of y when every row is written exactly once by the kernel:
+    rows without a partition are zeroed by the owner of the next partition.  y is pre-filled with NaN; the path
+    actually taken is read from the `stat_spmv_nomemset` counter.  Fallbacks to the memset: a partition longer than a
+    span (fp64 atomics join its parts), tombstones, wide key gaps."""
+    import ctypes as C
+    import torch
+    dev = torch.device("cuda:0")
+    m, n, per = 30000, 9000, 5
+    rows = 1 + (splitmix_array(15, n * per) % np.uint64(m)).astype(np.int64)
+    rows[rows % 7 == 3] += 1                                   # rows = 3 (mod 7) never occur: gaps of one key everywhere
+    rows = np.minimum(rows, m - 40)                            # and the last 40 rows stay empty (tail fill)
+    rows[rows < 6] = 6                                         # and the first 5 (head fill)
+    cols = np.repeat(np.arange(1, n + 1, dtype=np.int64), per)
+    vals = unit12_array(16, n * per)
+    a = dsa.dynamicsparse(rows, cols, vals, m, n, binding=hip)
+    b = dsa.dynamicsparse(rows, cols, vals, m, n, binding=oracle)
+    hip.call("mat_set_stream", a.h, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    x = unit12_array(17, max(m, n))
+
+    def check(expect_nomemset):
+        for transpose, nx, ny, o in ((0, n, m, 1), (1, m, n, 0)):
+            before = a.info(o)["stat_spmv_nomemset"]
+            xd = torch.from_numpy(x[:nx].copy()).to(dev)
+            yd = torch.full((ny,), float("nan"), dtype=torch.float64, device=dev)
+            hip.call("mat_spmv_dense_dev", a.h, transpose, 0, C.c_void_p(xd.data_ptr()), nx, C.c_void_p(yd.data_ptr()), ny)
+            torch.cuda.synchronize()
+            ref = b.mul(x[:nx], transpose=bool(transpose))
+            np.testing.assert_allclose(yd.cpu().numpy(), ref, rtol=RTOL, atol=0)
+            took = a.info(o)["stat_spmv_nomemset"] - before
+            if expect_nomemset is not None:
+                assert took == (1 if expect_nomemset[transpose] else 0), (transpose, took)
+
+    check({0: True, 1: True})
+    # a batch of writes keeps the property (and invalidates the cached meta: new rows 3 (mod 7) appear)
+    I2 = np.arange(3, 3 + 7 * 500, 7, dtype=np.int64)
+    J2 = 1 + (splitmix_array(18, len(I2)) % np.uint64(n)).astype(np.int64)
+    V2 = unit12_array(19, len(I2))
+    for mat in (a, b):
+        mat.set_batch(I2, J2, V2)
+    check({0: True, 1: True})
+    # one row longer than a span (600 cells): its parts are joined by atomics, so y must be zeroed in front
+    I3 = np.full(600, 77, dtype=np.int64)
+    J3 = np.arange(1, 601, dtype=np.int64) * 13
+    for mat in (a, b):
+        mat.set_batch(I3, J3, unit12_array(20, 600))
+    check({0: False, 1: True})
+    # a tombstone in the column table (deletecolumn!) and, through it, in no row: only the colmajor side falls back
+    for mat in (a, b):
+        mat.deletecolumn(4000)
+    check({0: False, 1: False})
+
+
+def test_spmv_without_memset_sparse_rows_fall_back(dsa, hip, oracle):
+    """Row keys 10 000 apart: zero-filling the gaps inside the kernel would serialise on single lanes -> memset path."""
+    rows = np.arange(1, 41, dtype=np.int64) * 10000
+    I = np.repeat(rows, 3)
+    J = np.tile(np.array([1, 2, 3], dtype=np.int64), 40)
+    V = unit12_array(21, len(I))
+    a = dsa.dynamicsparse(I, J, V, 400000, 3, binding=hip)
+    b = dsa.dynamicsparse(I, J, V, 400000, 3, binding=oracle)
+    x = np.array([1.0, 2.0, 3.0])
+    before = a.info(1)["stat_spmv_nomemset"]
+    np.testing.assert_allclose(a.mul(x), b.mul(x), rtol=RTOL, atol=0)
+    assert a.info(1)["stat_spmv_nomemset"] == before
+    np.testing.assert_allclose(a.mul(np.ones(400000), transpose=True), b.mul(np.ones(400000), transpose=True), rtol=RTOL, atol=0)
+
+
 def test_c3_scale_build_and_spmv_properties(dsa, hip):
     """BASELINE config 3 at a quarter of full size on the GPU alone (the oracle needs tens of seconds
     there): size-independent properties — capacity rule, sorted partitions, semaphore table,
