@@ -257,10 +257,25 @@ def extras(dsa, hip, torch, A, dev):
     res["roofline_rebalance"] = {"bound": "hbm", "achieved": round(b / 1e9 / (ms / 1e3), 2), "peak": HBM_PEAK_GBS,
                                  "unit": "GB/s", "frac": round(b / 1e9 / (ms / 1e3) / HBM_PEAK_GBS, 4),
                                  "window_slots": cap, "algorithmic_bytes": b, "ms": round(ms, 5),
-                                 "kernels": "k_tile_count2 + k_move<false, WIDE=false>"}
+                                 "kernels": "k_move2<false, WIDE=false> (one launch)",
+                                 "physical_bytes": 2 * (12 * cap + cap // 8),
+                                 "physical_frac": round(2 * (12 * cap + cap // 8) / 1e9 / (ms / 1e3) / HBM_PEAK_GBS, 4)}
     # --- the isolated rebalance on full windows of 2^20 / 2^21 / 2^24 slots at densities 0.35 / 0.70:
     #     a vector's PMA built from n = density * capacity keys, root pack + spread timed back to back
     sweep = []
+
+    def timed(fn, nrep):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        r0, r1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        r0.record(stream)
+        for _ in range(nrep):
+            fn()
+        r1.record(stream)
+        torch.cuda.synchronize()
+        return r0.elapsed_time(r1) / nrep * 1e3
+
     for lg in (20, 21, 24):
         for dens in (0.35, 0.70):
             capv = 1 << lg
@@ -270,19 +285,30 @@ def extras(dsa, hip, torch, A, dev):
             if vv.info()["capacity"] != capv:
                 continue
             hip.call("vec_set_stream", vv.h, C.c_void_p(stream.cuda_stream))
-            for _ in range(3):
-                vv.rebalance_root()
-            torch.cuda.synchronize()
-            r0, r1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             nrep = 50 if lg < 24 else 20
-            r0.record(stream)
-            for _ in range(nrep):
+            us = timed(vv.rebalance_root, nrep)
+            phys = 2 * (12 * capv + capv // 8)                         # int32 key + f64 value + 1 occupancy bit, read + written
+            row = {"window_slots": capv, "density": round(n / capv, 3), "source": "uniform (already spread)", "us": round(us, 2),
+                   "gbps": round(32 * capv / us / 1e3, 1), "frac": round(32 * capv / us / 1e3 / HBM_PEAK_GBS, 4),
+                   "physical_frac": round(phys / us / 1e3 / HBM_PEAK_GBS, 4)}
+            # skewed sources (dsa_vec_dev_relayout): time(relayout + rebalance) - time(relayout)
+            for mode, label in ((1, "packed_left_us"), (2, "gaps_left_us")):
+                def both():
+                    hip.call("vec_dev_relayout", vv.h, mode)
+                    vv.rebalance_root()
+                t_both = timed(both, max(nrep // 2, 5))
+                t_one = timed(lambda: hip.call("vec_dev_relayout", vv.h, mode), max(nrep // 2, 5))
+                row[label] = round(t_both - t_one, 2)
                 vv.rebalance_root()
-            r1.record(stream)
-            torch.cuda.synchronize()
-            us = r0.elapsed_time(r1) / nrep * 1e3
-            sweep.append({"window_slots": capv, "density": round(n / capv, 3), "us": round(us, 2),
-                          "gbps": round(32 * capv / us / 1e3, 1), "frac": round(32 * capv / us / 1e3 / HBM_PEAK_GBS, 4)})
+            if dens > 0.5:
+                # _extend! (read W, write 2W: 48 B per source slot) and _shrink! back (read 2W, write W), timed as a pair
+                def ext_shr():
+                    hip.call("vec_dev_relayout", vv.h, 3)
+                    hip.call("vec_dev_relayout", vv.h, 4)
+                us_pair = timed(ext_shr, max(nrep // 4, 5))
+                row["extend_plus_shrink_us"] = round(us_pair, 2)
+                row["extend_plus_shrink_frac"] = round(2 * 48 * capv / us_pair / 1e3 / HBM_PEAK_GBS, 4)
+            sweep.append(row)
             del vv
     res["rebalance_sweep"] = sweep
     # --- one C4 shard (BASELINE config 4 per GPU: 10M rows, 1.25M columns, 12.5M nnz, capacity 2^25, y = 10M doubles)

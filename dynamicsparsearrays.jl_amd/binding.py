@@ -126,6 +126,7 @@ _DEVICE_SIGS = {
     "vec_set_stream": [VP, VP],
     "mat_sync": [VP],
     "vec_sync": [VP],
+    "vec_dev_relayout": [VP, I32],
 }
 
 

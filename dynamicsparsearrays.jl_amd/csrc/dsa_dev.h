@@ -205,6 +205,9 @@ struct RebalanceWork {   // scratch owned by a PMA for the big pack+spread
     uint32_t* tile_cnt;    // one counter per 4096-slot source tile
     uint32_t* tile_off;    // exclusive prefix
     int64_t tiles_cap;
+    unsigned long long* status = nullptr;   // k_move2: one look-back status word per 2048-slot source tile (zeroed at allocation)
+    int64_t status_cap = 0;
+    unsigned long long gen = 0;              // generation of the last launch: stale words of earlier launches are "not ready"
 };
 
 // gathers the m occupied cells of src[src_ws..src_we] (in order) and spreads them over
@@ -215,6 +218,9 @@ hipError_t launch_rebalance(KeyArr src_keys, const double* src_vals, const uint6
                             KeyArr dst_keys, double* dst_vals, uint64_t* dst_occ,
                             int64_t dst_ws, int64_t dst_we, int64_t m, int64_t* sems,
                             RebalanceWork* work, hipStream_t stream);
+// bench hook: the m cells of slots 0..m-1 of (src) -> the LAST m slots of a cap-slot destination, bitmap included
+hipError_t launch_pack_right(KeyArr src_keys, const double* src_vals, int64_t m, KeyArr dst_keys, double* dst_vals, uint64_t* dst_occ,
+                             int64_t cap, hipStream_t stream);
 // K-permute: order-preserving move of the n0 cells of (src, src_occ) followed by the cells of ops[i0..] to the set bits of
 // dst_occ (already final), writing dst keys / vals and, if sems != nullptr, the semaphore table
 hipError_t launch_permute(KeyArr src_keys, const double* src_vals, const uint64_t* src_occ, int64_t src_cap,

@@ -85,6 +85,7 @@ struct Pma {
     BurstGraph burst, burst_short;      // cached graphs of a full burst of rounds and of a short one (conflict-heavy phases)
     Plan* d_plans = nullptr; uint32_t* d_flags = nullptr; RoundState* d_rs = nullptr; RoundState* h_rs = nullptr;   // batch-parallel writes
     int64_t* d_small = nullptr;                     // 8 x int64 scratch
+    int64_t* h_small = nullptr;                     // its pinned host mirror (small read-backs without a pageable staging copy)
     // bumped by every launch that can move cells or change the tables; SpmvMeta is recomputed when it differs
     int64_t layout_epoch = 0;
     int64_t stat_spmv_nomemset = 0;
@@ -109,6 +110,7 @@ void pma_free_buffers(Pma& P) {
     }
     if (P.work.tile_cnt) hipFree(P.work.tile_cnt);
     if (P.work.tile_off) hipFree(P.work.tile_off);
+    if (P.work.status) hipFree(P.work.status);
     P.work = RebalanceWork{nullptr, nullptr, 0};
     if (P.work2.tile_cnt) hipFree(P.work2.tile_cnt);
     if (P.work2.tile_off) hipFree(P.work2.tile_off);
@@ -135,6 +137,7 @@ void pma_destroy(Pma& P) {
     if (P.d_rs) hipFree(P.d_rs);
     if (P.h_rs) hipHostFree(P.h_rs);
     if (P.d_small) hipFree(P.d_small);
+    if (P.h_small) hipHostFree(P.h_small);
     if (P.run_cells) hipFree(P.run_cells);
     if (P.run_flags) hipFree(P.run_flags);
     if (P.run_out) hipFree(P.run_out);
@@ -186,6 +189,10 @@ void alloc_work(Pma& P, int64_t slots) {
     P.work.tiles_cap = slots / 4096 + 8;
     HIPCHK(hipMalloc(&P.work.tile_cnt, (size_t)P.work.tiles_cap * sizeof(uint32_t)));
     HIPCHK(hipMalloc(&P.work.tile_off, (size_t)P.work.tiles_cap * sizeof(uint32_t)));
+    if (P.work.status) hipFree(P.work.status);
+    P.work.status_cap = slots / 2048 + slots / (2048 * 64) + 16; P.work.gen = 0;
+    HIPCHK(hipMalloc(&P.work.status, (size_t)P.work.status_cap * sizeof(unsigned long long)));
+    HIPCHK(hipMemsetAsync(P.work.status, 0, (size_t)P.work.status_cap * sizeof(unsigned long long), P.stream));
     if (P.work2.tile_cnt) { hipFree(P.work2.tile_cnt); hipFree(P.work2.tile_off); }
     P.work2.tiles_cap = P.work.tiles_cap;
     HIPCHK(hipMalloc(&P.work2.tile_cnt, (size_t)P.work2.tiles_cap * sizeof(uint32_t)));
@@ -204,6 +211,7 @@ void pma_init_common(Pma& P, bool sems, bool cols) {
     std::memset(P.h_ctl, 0, sizeof(Ctl));
     HIPCHK(hipMalloc(&P.d_err, sizeof(int32_t)));
     HIPCHK(hipMalloc(&P.d_small, 8 * sizeof(int64_t)));
+    HIPCHK(hipHostMalloc(&P.h_small, 8 * sizeof(int64_t), hipHostMallocDefault));
 }
 
 void ensure_tables(Pma& P, int64_t need) {
@@ -1009,8 +1017,8 @@ const Pma::SpmvMeta& spmv_meta(Pma& P) {
     }
     hipError_t e = launch_spmv_meta(P.sems, P.col_keys, c.table_len, c.capacity, (unsigned long long*)P.d_small, P.stream);
     if (e != hipSuccess) fail(DSA_EHIP, std::string("spmv meta launch: ") + hipGetErrorString(e));
-    int64_t r[5];
-    HIPCHK(hipMemcpyAsync(r, P.d_small, sizeof(r), hipMemcpyDeviceToHost, P.stream));
+    int64_t* r = P.h_small;
+    HIPCHK(hipMemcpyAsync(r, P.d_small, 5 * sizeof(int64_t), hipMemcpyDeviceToHost, P.stream));
     HIPCHK(hipStreamSynchronize(P.stream));
     M.ordered = r[4] == 0;
     M.max_extent = r[0]; M.max_gap = r[1]; M.first_key = r[2]; M.last_key = r[3];
@@ -1238,6 +1246,33 @@ int32_t dsa_vec_rebalance_root(dsa_vec_t* h) {
         P.h_ctl->stat_rebalances += 1; P.h_ctl->stat_window_slots += P.capacity();
         root_rebalance(P, P.capacity(), P.capacity(), P.h_ctl->nb_elements, false);
     }
+    API_CATCH
+}
+int32_t dsa_vec_dev_relayout(dsa_vec_t* h, int32_t mode) {
+    API_TRY
+    vec_flush(h);
+    Pma& P = h->P;
+    Ctl& c = *P.h_ctl;
+    const int64_t cap = c.capacity, m = c.nb_elements;
+    if (m < 1) fail(DSA_EARG, "relayout of an empty vector");
+    if (mode == 1 || mode == 2) {
+        root_rebalance(P, cap, m, m, false);                   // W = m: no gaps -> the cells land on slots 1..m
+        if (mode == 2) {
+            const int alt = 1 - P.cur;
+            ++P.layout_epoch;
+            hipError_t e = launch_pack_right(P.K(), P.V(), m, P.KA(alt), P.vals[alt], P.occ[alt], cap, P.stream);
+            if (e != hipSuccess) fail(DSA_EHIP, std::string("pack-right launch: ") + hipGetErrorString(e));
+            P.occ_dirty[alt] = std::max<int64_t>(P.occ_dirty[alt], (cap + 63) / 64);
+            P.cur = alt;
+        }
+    } else if (mode == 3 || mode == 4) {
+        if (mode == 4 && (cap < 4 * c.segment_capacity || 2 * m > cap)) fail(DSA_EARG, "cannot shrink");
+        const int64_t old_cap = cap;
+        if (mode == 3) { c.capacity *= 2; c.nb_segments *= 2; c.height += 1; } else { c.capacity /= 2; c.nb_segments /= 2; c.height -= 1; }
+        compute_bounds(P);
+        root_rebalance(P, old_cap, c.capacity, m, false);
+        upload_ctl(P);
+    } else fail(DSA_EARG, "mode must be 1..4");
     API_CATCH
 }
 int32_t dsa_vec_check(dsa_vec_t* h, int64_t* report) { API_TRY vec_flush(h); pma_check(h->P, report); API_CATCH }

@@ -21,6 +21,7 @@
 //                  from two ballots, and semaphore positions are scattered to the table.
 #include "dsa_dev.h"
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <type_traits>
 
@@ -301,6 +302,230 @@ __global__ __launch_bounds__(MOVE_BLOCK) void k_move(MoveArgs a) {
             if (gq + 64 < a.Wd)
                 a.dst_occ[w + 1] = spread_bits32((uint32_t)(be >> 32)) | (spread_bits32((uint32_t)(bo >> 32)) << 1);
         }
+    }
+}
+
+// ---- k_move2: the window rebalance in ONE launch (source-driven, chained scan) --------------------------------------------
+// One 256-thread workgroup per 2048-slot SOURCE tile, in blockIdx order:
+//   1. the 32 occupancy words of the tile -> cell count c and in-tile word bases; all slot loads of the tile are issued
+//      with them (lane <-> slot, occupied or not);
+//   2. the cells are compacted into LDS by in-tile rank;
+//   0. the first ntiles/64 workgroups — dispatched first — each count one group of 64 tiles straight from the bitmap and
+//      publish the prefix table (status words = {generation, value}: exclusive prefix of every tile inside its group,
+//      total of every group) before doing their own tile;
+//   3. the number P of cells in front of the tile = its table entry + totals of the groups in front: ONE round of
+//      agent-scope loads issued together with the slot loads.  A workgroup only ever waits for LOWER block indices,
+//      which the hardware dispatched earlier and which wait for nobody; past the first wave of workgroups the table is
+//      complete before a workgroup starts (a per-tile chained scan was measured at 8-10 us of waiting PER TILE at 2^24
+//      slots: status words cross the fabric behind the bulk stores of the CUs that publish them);
+//   4. the tile owns the destination offsets (dest(P), dest(P + c)] — its cells and the gaps in front of each of
+//      them, the last tile also the gaps behind the last cell — with dest(r) = r + #gaps in front of rank r from the
+//      closed-form gap positions D(k) = floor(fl(k * fl(W/E))) (dsa_dev.h; scatter recipe of SURVEY App. A.3, at most
+//      one fix-up step).  Every owned offset is stored (gaps too: whole lines), occupancy words are closed-form in
+//      (W, m) and written by the owner of their first offset, semaphore cells update semaphores[id].
+// No count kernel, no scan kernel, no interpolation search: the time does not depend on how the cells are distributed
+// over the source window (uniform after a spread, packed to the left after appends, anything in between).
+// PACKED sources (K-build, pack! + _shrink!: cells are the first m slots) have closed-form prefixes and skip 1-3.
+constexpr int M2_TILE = 2048;
+constexpr int M2_WORDS = M2_TILE / 64;
+
+struct Move2Args {
+    KeyArr src_keys; const double* src_vals; const uint64_t* src_occ;
+    int64_t src_lo0, src_hi0;      // 0-based inclusive source slot range (src_lo0 a multiple of 64)
+    KeyArr dst_keys; double* dst_vals; uint64_t* dst_occ;
+    int64_t dst_lo0;               // 0-based first destination slot
+    int64_t Wd, m;
+    int64_t* sems;
+    unsigned long long* status;    // [0, ntiles): cells in front of the tile inside its group of 64, [ntiles, ..): cells per group; word = [63:34] generation, [31:0] value
+    unsigned long long gen;
+    int64_t ntiles;
+    double cells_to_gaps;          // E / m: starting guess of #gaps in front of a rank
+    int dbg;                       // DSA_DBG_MOVE2 ablation knob (dev only): 1 = no waiting for status words, 2 = no write phase, 4 = closed-form P
+};
+
+// 1-based destination offset of the cell of rank r (1 <= r <= m)
+__device__ __forceinline__ int dest_of_rank(const SpreadGeom& g, int r, double cells_to_gaps) {
+    const int E = (int)g.E;
+    if (E <= 0) return r;
+    int k = (int)((double)r * cells_to_gaps);
+    if (k > E) k = E;
+    if (k < 0) k = 0;
+#pragma clang loop vectorize(disable) unroll(disable)
+    while (k < E && gap_D(g, k + 1) <= r + k) ++k;
+#pragma clang loop vectorize(disable) unroll(disable)
+    while (k > 0 && gap_D(g, k) >= r + k) --k;
+    return r + k;
+}
+
+__device__ unsigned long long g_m2_prof[8192 * 5];      // dev profile (DSA_DBG_MOVE2 & 8): per-tile timestamps in 100 MHz ticks
+template <bool PACKED, bool WIDE, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_move2(Move2Args a) {
+    constexpr int NW = BLOCK / 64;            // waves per workgroup
+    unsigned long long tk0 = 0, tk1 = 0, tk2 = 0, tk3 = 0;
+    if (a.dbg & 8) tk0 = wall_clock64();
+    typedef typename std::conditional<WIDE, int64_t, int32_t>::type key_t;
+    const key_t* __restrict__ srck = static_cast<const key_t*>(a.src_keys.p);
+    key_t* __restrict__ dstk = static_cast<key_t*>(a.dst_keys.p);
+    __shared__ key_t sK[M2_TILE];
+    __shared__ double sV[M2_TILE];
+    __shared__ uint32_t sSum[NW];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int64_t t = blockIdx.x;
+    const SpreadGeom g = make_geom(a.Wd, a.m);
+    int64_t P;      // cells in front of this tile
+    int c;          // cells of this tile
+    if (PACKED) {
+        P = t * M2_TILE < a.m ? t * M2_TILE : a.m;
+        c = (int)(a.m - P < M2_TILE ? a.m - P : M2_TILE);
+    } else {
+        const int64_t w0 = (a.src_lo0 >> 6) + t * M2_WORDS;
+        const int64_t wlast = a.src_hi0 >> 6;
+        const int64_t ngroups = (a.ntiles + 63) >> 6;
+        unsigned long long* gstatus = a.status + a.ntiles;            // [ntiles, ntiles + ngroups): cells per group of 64 tiles
+        // ---- 0. the first `ngroups` workgroups (dispatched first) build the prefix table every tile reads: workgroup j counts
+        //         the 64 tiles of group j straight from the bitmap (2048 words, 8 per thread) and publishes the exclusive prefix
+        //         of each tile inside the group and the group total.  They depend on nobody.
+        if (t < ngroups) {
+            const int64_t gw0 = (a.src_lo0 >> 6) + t * (64 * M2_WORDS);
+            constexpr int WPT = 64 * M2_WORDS / BLOCK;               // words per thread (8 at 256 threads); NW threads per tile
+            uint32_t pc = 0;
+#pragma unroll
+            for (int u = 0; u < WPT; ++u) {
+                const int64_t w = gw0 + (int64_t)tid * WPT + u;
+                if (w <= wlast) pc += popc64(a.src_occ[w] & range_mask_for_word(w, a.src_lo0, a.src_hi0));
+            }
+#pragma unroll
+            for (int o = 1; o < NW; o <<= 1) pc += __shfl_xor(pc, o, 64);      // lanes NW*i .. NW*i + NW-1 hold one tile
+            __shared__ uint32_t sTile[64];
+            if ((lane & (NW - 1)) == 0) sTile[tid / NW] = pc;
+            __syncthreads();
+            if (wv == 0) {
+                const uint32_t tc = sTile[lane];
+                const uint32_t ex = wave_excl_scan(tc);
+                const int64_t tt = (t << 6) + lane;
+                if (tt < a.ntiles) __hip_atomic_store(a.status + tt, (a.gen << 34) | (unsigned long long)ex, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (lane == 63) __hip_atomic_store(gstatus + t, (a.gen << 34) | (unsigned long long)(ex + tc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        // ---- 1. ONE round of loads: the 32 occupancy words of the tile (every wave reads them: no barrier) and, without
+        //         waiting for them, the slots of this wave's 8 words — lane <-> slot, occupied or not: the lines are fetched
+        //         whole anyway, and the loads do not depend on the occupancy word.  16 loads in flight per lane.
+        uint64_t myword = 0;
+        if (lane < M2_WORDS && w0 + lane <= wlast) myword = a.src_occ[w0 + lane] & range_mask_for_word(w0 + lane, a.src_lo0, a.src_hi0);
+        constexpr int WPW = M2_WORDS / NW;     // 8 at 256 threads
+        key_t kk[WPW]; double vv[WPW];
+#pragma unroll
+        for (int u = 0; u < WPW; ++u) {
+            int64_t sidx = ((w0 + wv * WPW + u) << 6) + lane;
+            if (sidx > a.src_hi0) sidx = a.src_hi0;               // a tile that ends behind the source range
+            kk[u] = __builtin_nontemporal_load(srck + sidx);
+            vv[u] = __builtin_nontemporal_load(a.src_vals + sidx);
+        }
+        // ---- 2. ask for the prefix: the tile's entry (wave 0) and the totals of the groups in front (waves 1-3); in the
+        //         steady state the table is long complete and the answers arrive with the slots
+        if (a.dbg & 8) tk1 = wall_clock64();
+        const int64_t grp = t >> 6;
+        const unsigned long long ready = a.gen << 34;                 // a word that counts as published and adds nothing
+        const unsigned long long* poll = nullptr;
+        if (!(a.dbg & 1)) {
+            if (wv == 0) { if (lane == 0) poll = a.status + t; }
+            else if (tid - 64 < grp) poll = gstatus + (tid - 64);
+        }
+        unsigned long long st0 = poll ? __hip_atomic_load(poll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ready;
+        // ---- compact into LDS by in-tile rank ---------------------------------------------------------------------------------
+        const uint32_t mypc = popc64(myword);
+        const uint32_t myex = wave_excl_scan(mypc);
+        c = (int)__shfl(myex + mypc, M2_WORDS - 1, 64);
+#pragma unroll
+        for (int u = 0; u < WPW; ++u) {
+            const int j = wv * WPW + u;
+            const uint64_t wm = __shfl(myword, j, 64);
+            const uint32_t wb = __shfl(myex, j, 64);
+            if ((wm >> lane) & 1ull) {
+                const int r = (int)wb + popc64(wm & mask_lt(lane));
+                sK[r] = kk[u]; sV[r] = vv[u];
+            }
+        }
+        if (a.dbg & 8) tk2 = wall_clock64();
+        // ---- 3. cells in front of the tile ------------------------------------------------------------------------------------
+        while ((st0 >> 34) != a.gen) { __builtin_amdgcn_s_sleep(1); st0 = __hip_atomic_load(poll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+        uint32_t part = (uint32_t)st0;
+        if (wv >= 1 && !(a.dbg & 1)) {           // more than BLOCK - 64 groups in front (windows above 2^24 slots): further rounds
+            for (int64_t j = tid - 64 + (BLOCK - 64); j < grp; j += BLOCK - 64) {
+                unsigned long long st = __hip_atomic_load(gstatus + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                while ((st >> 34) != a.gen) { __builtin_amdgcn_s_sleep(1); st = __hip_atomic_load(gstatus + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+                part += (uint32_t)st;
+            }
+        }
+        part = wave_reduce_add(part);
+        if (lane == 0) sSum[wv] = part;
+        __syncthreads();      // also: LDS staging complete
+        P = 0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) P += sSum[w];
+        if (a.dbg & 5) P = (int64_t)((double)t * (double)a.m / (double)a.ntiles);
+        if (a.dbg & 8) tk3 = wall_clock64();
+    }
+    // ---- 4. owned destination offsets (Q0, Q1] ------------------------------------------------------------------------------
+    const int64_t Q0 = P == 0 ? 0 : dest_of_rank(g, (int)P, a.cells_to_gaps);
+    const int64_t Q1 = t == a.ntiles - 1 ? a.Wd : (c == 0 ? Q0 : dest_of_rank(g, (int)(P + c), a.cells_to_gaps));
+    if (Q1 <= Q0 || (a.dbg & 2)) return;
+    const int64_t g_first = Q0 & ~(int64_t)127, g_last = (Q1 - 1) & ~(int64_t)127;
+    for (int64_t gq = g_first + (int64_t)wv * 128; gq <= g_last; gq += NW * 128) {
+        const int64_t qa = gq + 2 * lane + 1;                         // 1-based offsets qa, qa+1
+        key_t k2[2] = {0, 0};
+        double v2[2] = {0.0, 0.0};
+        bool o2[2] = {false, false};
+        if (qa <= a.Wd) {
+            int k; bool gp[2];
+            gap_pair(g, (int)qa, &k, &gp[0], &gp[1]);
+            bool own[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const bool gap = gp[j];
+                if (j == 1 && gap) ++k;
+                own[j] = qa + j > Q0 && qa + j <= Q1;
+                o2[j] = !gap && qa + j <= a.Wd;
+                if (o2[j] && own[j]) {
+                    const int64_t rank = qa + j - k;
+                    if (PACKED) {
+                        k2[j] = srck[a.src_lo0 + rank - 1];
+                        v2[j] = a.src_vals[a.src_lo0 + rank - 1];
+                    } else {
+                        k2[j] = sK[rank - P - 1];
+                        v2[j] = sV[rank - P - 1];
+                    }
+                    if (a.sems != nullptr && k2[j] == SEM_KEY) a.sems[(int64_t)v2[j] - 1] = a.dst_lo0 + qa + j;   // 1-based slot
+                }
+            }
+            const int64_t d = a.dst_lo0 + qa - 1;
+            if (own[0] && own[1]) {
+                typedef double d2v __attribute__((ext_vector_type(2)));
+                d2v vv2; vv2.x = v2[0]; vv2.y = v2[1];
+                typedef key_t k2v __attribute__((ext_vector_type(2)));
+                k2v kv; kv.x = k2[0]; kv.y = k2[1];
+                __builtin_nontemporal_store(kv, reinterpret_cast<k2v*>(dstk + d));
+                __builtin_nontemporal_store(vv2, reinterpret_cast<d2v*>(a.dst_vals + d));
+            } else if (own[0]) {
+                dstk[d] = k2[0]; a.dst_vals[d] = v2[0];
+            } else if (own[1]) {
+                dstk[d + 1] = k2[1]; a.dst_vals[d + 1] = v2[1];
+            }
+        }
+        // occupancy words are closed-form: written by the owner of their first offset
+        const uint64_t be = __ballot(o2[0]);
+        const uint64_t bo = __ballot(o2[1]);
+        if (lane == 0) {
+            const int64_t w = (a.dst_lo0 + gq) >> 6;
+            if (gq + 1 > Q0 && gq + 1 <= Q1)
+                a.dst_occ[w] = spread_bits32((uint32_t)be) | (spread_bits32((uint32_t)bo) << 1);
+            if (gq + 64 < a.Wd && gq + 65 > Q0 && gq + 65 <= Q1)
+                a.dst_occ[w + 1] = spread_bits32((uint32_t)(be >> 32)) | (spread_bits32((uint32_t)(bo >> 32)) << 1);
+        }
+    }
+    if ((a.dbg & 8) && tid == 0) {
+        const unsigned long long tk4 = wall_clock64();
+        if (t < 8192) { g_m2_prof[t * 5] = tk0; g_m2_prof[t * 5 + 1] = tk1; g_m2_prof[t * 5 + 2] = tk2; g_m2_prof[t * 5 + 3] = tk3; g_m2_prof[t * 5 + 4] = tk4; }
     }
 }
 
@@ -604,11 +829,84 @@ hipError_t launch_clear_occ(uint64_t* occ, int64_t from, int64_t to, hipStream_t
     return hipGetLastError();
 }
 
+// bench hook (dsa_vec_dev_relayout mode 2): cells packed to the right end of the array — "all gaps at the left"
+__global__ __launch_bounds__(256) void k_pack_right(KeyArr src_keys, const double* __restrict__ src_vals, int64_t m, KeyArr dst_keys,
+                                                    double* __restrict__ dst_vals, uint64_t* __restrict__ dst_occ, int64_t cap) {
+    const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;          // destination slot (0-based); cap is a multiple of 64 or < 64
+    const bool in = s < cap && s >= cap - m;
+    if (in) { dst_keys[s] = (int64_t)src_keys[s - (cap - m)]; dst_vals[s] = src_vals[s - (cap - m)]; }
+    const uint64_t b = __ballot(in);
+    if ((threadIdx.x & 63) == 0 && s < cap) dst_occ[s >> 6] = b;
+}
+hipError_t launch_pack_right(KeyArr src_keys, const double* src_vals, int64_t m, KeyArr dst_keys, double* dst_vals, uint64_t* dst_occ,
+                             int64_t cap, hipStream_t stream) {
+    hipLaunchKernelGGL(k_pack_right, dim3((unsigned)((cap + 255) / 256)), dim3(256), 0, stream, src_keys, src_vals, m, dst_keys, dst_vals, dst_occ, cap);
+    return hipGetLastError();
+}
+
 hipError_t launch_rebalance(KeyArr src_keys, const double* src_vals, const uint64_t* src_occ,
                             int64_t src_ws, int64_t src_we, bool src_packed,
                             KeyArr dst_keys, double* dst_vals, uint64_t* dst_occ,
                             int64_t dst_ws, int64_t dst_we, int64_t m, int64_t* sems,
                             RebalanceWork* work, hipStream_t stream) {
+    static const bool v1 = [] { const char* e = getenv("DSA_MOVE_V1"); return e && e[0] == '1'; }();     // dev: count kernel + k_move (round 1)
+    if (!v1 || ((src_ws - 1) & 63) != 0) {
+        Move2Args a;
+        a.src_keys = src_keys; a.src_vals = src_vals; a.src_occ = src_occ;
+        a.src_lo0 = src_ws - 1; a.src_hi0 = src_we - 1;
+        a.dst_keys = dst_keys; a.dst_vals = dst_vals; a.dst_occ = dst_occ;
+        a.dst_lo0 = dst_ws - 1;
+        a.Wd = dst_we - dst_ws + 1; a.m = m;
+        a.sems = sems;
+        a.cells_to_gaps = m > 0 ? (double)(a.Wd - m) / (double)m : 0.0;
+        { static const char* e = getenv("DSA_DBG_MOVE2"); a.dbg = e ? atoi(e) : 0; }
+        if (((src_ws - 1) & 63) != 0 && !src_packed) return hipErrorInvalidValue;     // source windows start on an occupancy word
+        if (src_packed) {
+            a.ntiles = std::max<int64_t>(1, (m + M2_TILE - 1) / M2_TILE);
+            a.status = nullptr; a.gen = 0;
+            if (a.src_keys.wide) hipLaunchKernelGGL((k_move2<true, true, 256>), dim3((unsigned)a.ntiles), dim3(256), 0, stream, a);
+            else hipLaunchKernelGGL((k_move2<true, false, 256>), dim3((unsigned)a.ntiles), dim3(256), 0, stream, a);
+            return hipGetLastError();
+        }
+        a.ntiles = (src_we - src_ws + 1 + M2_TILE - 1) / M2_TILE;
+        if (a.ntiles + (a.ntiles >> 6) + 1 > work->status_cap || work->status == nullptr) return hipErrorInvalidValue;
+        if (++work->gen >= (1ull << 30)) {          // generation wrap: start over on a zeroed table
+            hipError_t e = hipMemsetAsync(work->status, 0, (size_t)work->status_cap * sizeof(unsigned long long), stream);
+            if (e != hipSuccess) return e;
+            work->gen = 1;
+        }
+        a.status = work->status; a.gen = work->gen;
+        // few tiles (windows up to 2^22 slots): the chain occupancy -> table -> write is latency, not bandwidth: 8 waves per tile
+        static const int force_block = [] { const char* e = getenv("DSA_MOVE2_BLOCK"); return e ? atoi(e) : 0; }();
+        const int block = force_block ? force_block : (a.ntiles <= 2048 ? 512 : 256);      // measured: 2^20 9.9 vs 11.5 us, 2^22 27.2 vs 29.3, 2^24 83.5 vs 77.4
+        if (block == 1024) {
+            if (a.src_keys.wide) hipLaunchKernelGGL((k_move2<false, true, 1024>), dim3((unsigned)a.ntiles), dim3(1024), 0, stream, a);
+            else hipLaunchKernelGGL((k_move2<false, false, 1024>), dim3((unsigned)a.ntiles), dim3(1024), 0, stream, a);
+        } else if (block == 512) {
+            if (a.src_keys.wide) hipLaunchKernelGGL((k_move2<false, true, 512>), dim3((unsigned)a.ntiles), dim3(512), 0, stream, a);
+            else hipLaunchKernelGGL((k_move2<false, false, 512>), dim3((unsigned)a.ntiles), dim3(512), 0, stream, a);
+        } else {
+            if (a.src_keys.wide) hipLaunchKernelGGL((k_move2<false, true, 256>), dim3((unsigned)a.ntiles), dim3(256), 0, stream, a);
+            else hipLaunchKernelGGL((k_move2<false, false, 256>), dim3((unsigned)a.ntiles), dim3(256), 0, stream, a);
+        }
+        if (a.dbg & 8) {
+            static unsigned long long pr[8192 * 5];
+            hipStreamSynchronize(stream);
+            hipMemcpyFromSymbol(pr, HIP_SYMBOL(g_m2_prof), sizeof(pr));
+            const int64_t n = a.ntiles < 8192 ? a.ntiles : 8192;
+            double ph[4] = {0, 0, 0, 0};
+            unsigned long long t_first = ~0ull, t_last = 0, s_last = 0;
+            for (int64_t i = 0; i < n; ++i) {
+                for (int k = 0; k < 4; ++k) ph[k] += (double)(pr[i * 5 + k + 1] - pr[i * 5 + k]);
+                if (pr[i * 5] < t_first) t_first = pr[i * 5];
+                if (pr[i * 5 + 4] > t_last) t_last = pr[i * 5 + 4];
+                if (pr[i * 5] > s_last) s_last = pr[i * 5];
+            }
+            fprintf(stderr, "k_move2 profile over %lld tiles (us per tile): occupancy %.2f  slots+staging %.2f  status %.2f  write %.2f | first start -> last end %.1f us, last start at %.1f us\n",
+                    (long long)n, ph[0] / 100.0 / n, ph[1] / 100.0 / n, ph[2] / 100.0 / n, ph[3] / 100.0 / n, (t_last - t_first) / 100.0, (s_last - t_first) / 100.0);
+        }
+        return hipGetLastError();
+    }
     MoveArgs a;
     a.src_keys = src_keys; a.src_vals = src_vals; a.src_occ = src_occ;
     a.src_lo0 = src_ws - 1; a.src_hi0 = src_we - 1;

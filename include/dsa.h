@@ -111,6 +111,14 @@ int32_t dsa_vec_export_layout(dsa_vec_t* h, int64_t* keys, double* vals, uint8_t
 /* _even_rebalance!(pma, 1, capacity, nb_elements) on the whole array  src/pma.jl:94-103
  * (benchmark / test hook for the full-window pack+spread kernel; layout-idempotent) */
 int32_t dsa_vec_rebalance_root(dsa_vec_t* h);
+/* Benchmark / test hook (no reference counterpart): puts the cells of the vector into a layout the reference reaches only
+ * in the middle of an operation, WITHOUT changing which cells are stored or their order, so that the next
+ * dsa_vec_rebalance_root can be timed on it:
+ *   1 = pack!(array, 1, capacity, n): all cells in slots 1..n            (src/moves.jl:94-110; the source of _shrink!)
+ *   2 = all cells in the LAST n slots (all gaps at the left: the window a run of appends leaves behind)
+ *   3 = _extend!  (src/pma.jl:143-151: capacity x 2, root spread)        4 = _shrink! (src/pma.jl:153-161: capacity / 2)
+ * 3 and 4 ignore the density thresholds; 1 and 2 leave a layout that violates them until the next root rebalance. */
+int32_t dsa_vec_dev_relayout(dsa_vec_t* h, int32_t mode);
 
 /* ---------------- PackedCSC (integer-indexed partitions) ---------------- */
 /* PackedCSC(row_keys::Vector{Vector}, values::Vector{Vector}, combine)  src/pcsr.jl:26-63

@@ -619,6 +619,42 @@ def test_spmv_device_pointers_gather_and_scatter(dsa, hip, oracle):
             np.testing.assert_allclose(yd.cpu().numpy(), ref, rtol=RTOL, atol=0)
 
 
+def test_rebalance_from_skewed_sources_and_extend_shrink(dsa, hip, oracle):
+    """The root pack + spread only depends on the ORDER and NUMBER of the cells (src/moves.jl:94-171): from a source packed to
+    the left (pack!), packed to the right (all gaps at the left) or uniformly spread, the single-launch rebalance must
+    produce the same slots as the oracle's layout; _extend! / _shrink! (src/pma.jl:143-161) round-trip to it as well."""
+    for n in (5, 90, 3000, 46000, 300000):
+        keys = np.arange(1, n + 1, dtype=np.int64) * 7 - 3
+        vals = unit12_array(30 + n % 7, n)
+        a = dsa.dynamicsparsevec(keys, vals, binding=hip)
+        b = dsa.dynamicsparsevec(keys, vals, binding=oracle)
+        ref = b.export_layout()
+        for mode in (1, 2):
+            hip.call("vec_dev_relayout", a.h, mode)
+            k, v, o = a.export_layout()
+            assert int(o.sum()) == n
+            occ = o.astype(bool)
+            pos = np.nonzero(occ)[0]
+            assert (pos[0] == 0 and pos[-1] == n - 1) if mode == 1 else (pos[0] == len(o) - n and pos[-1] == len(o) - 1)
+            np.testing.assert_array_equal(k[occ], keys)
+            a.rebalance_root()
+            got = a.export_layout()
+            for x, y in zip(got, ref):
+                np.testing.assert_array_equal(x, y)
+        cap = a.info()["capacity"]
+        hip.call("vec_dev_relayout", a.h, 3)                      # _extend!: capacity doubles, cells spread over it
+        assert a.info()["capacity"] == 2 * cap and a.info()["height"] == b.info()["height"] + 1
+        k, v, o = a.export_layout()
+        np.testing.assert_array_equal(k[o.astype(bool)], keys)
+        np.testing.assert_array_equal(v[o.astype(bool)], vals)
+        assert not a.check()[2:7].any()
+        hip.call("vec_dev_relayout", a.h, 4)                      # _shrink!: back to the reference layout
+        got = a.export_layout()
+        for x, y in zip(got, ref):
+            np.testing.assert_array_equal(x, y)
+        assert a.info()["capacity"] == cap
+
+
 def test_spmv_without_memset_and_its_fallbacks(dsa, hip, oracle):
     """The gather SpMV skips the memset of y when every row is written exactly once by the kernel:
     rows without a partition are zeroed by the owner of the next partition.  y is pre-filled with NaN; the path

@@ -12,6 +12,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <vector>
+#include <string>
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
 
@@ -171,7 +172,8 @@ static uint64_t splitmix() {
     return z ^ (z >> 31);
 }
 
-int main() {
+int main(int argc, char** argv) {
+    const bool prof = argc > 1 && std::string(argv[1]) == "prof";
     const int64_t S = 1 << 24;
     const int64_t nspans = S / (W * 64);
     int32_t* keys; double *vals, *x, *out;
@@ -183,6 +185,32 @@ int main() {
     const int64_t nonpers = nspans / 4;       // workgroups when every wave takes exactly one span
     printf("slots %lld, spans %lld, stream bytes %.1f MB\n", (long long)S, (long long)nspans, S * 12 / 1e6);
 
+    if (prof) {
+        // rocprofv3 --pmc mode: a fixed list of dispatches (3 of each), summarised per dispatch index by tools/scripts/pmc_gatherbench2.sh
+        auto fill = [&](int64_t NX) {
+            sm_state = 777;
+            for (int64_t i = 0; i < S; ++i) {
+                const uint64_t r = splitmix();
+                hk[i] = ((r & 0xffff) < 42991) ? (int32_t)((r >> 20) % (uint64_t)NX) : -1;
+            }
+            return hipMemcpy(keys, hk.data(), S * 4, hipMemcpyHostToDevice);
+        };
+        CK(fill(1000000));
+        const int32_t nx = 1000000, half = 500000;
+        int d = 0;
+        auto L = [&](const char* name) { printf("dispatch %d: %s\n", d++, name); };
+        for (int r = 0; r < 3; ++r) { hipLaunchKernelGGL((k_fused<0, 0, 1, true>), dim3((unsigned)nonpers), dim3(256), 0, 0, keys, vals, x, nspans, 0, nx, half, out); L("E0 stream only (12 B slots, nt)"); }
+        for (int r = 0; r < 3; ++r) { hipLaunchKernelGGL((k_fused<1, 0, 1, true>), dim3((unsigned)nonpers), dim3(256), 0, 0, keys, vals, x, nspans, 0, nx, half, out); L("E1 single pass, x 8 MB"); }
+        for (int r = 0; r < 3; ++r) {
+            hipLaunchKernelGGL((k_fused<1, 0, 1, true>), dim3((unsigned)nonpers), dim3(256), 0, 0, keys, vals, x, nspans, 0, half, half, out); L("E3 pass over the lower x half");
+            hipLaunchKernelGGL((k_fused<1, 0, 1, true>), dim3((unsigned)nonpers), dim3(256), 0, 0, keys, vals, x, nspans, half, nx, half, out); L("E3 pass over the upper x half");
+        }
+        for (int r = 0; r < 3; ++r) { hipLaunchKernelGGL((k_fused<1, 0, 2, true>), dim3(2048), dim3(256), 0, 0, keys, vals, x, nspans, 0, nx, half, out); L("E4 two XCD groups, one launch (persistent, 2048 wg)"); }
+        CK(fill(131072));
+        for (int r = 0; r < 3; ++r) { hipLaunchKernelGGL((k_fused<1, 0, 1, false>), dim3((unsigned)nonpers), dim3(256), 0, 0, keys, vals, x, nspans, 0, 131072, 65536, out); L("E1 single pass, x 1 MB (L2-resident), plain stream"); }
+        CK(hipDeviceSynchronize());
+        return 0;
+    }
     const int64_t NXs[] = {131072, 262144, 500000, 1000000};
     for (int64_t NX : NXs) {
         sm_state = 777;
