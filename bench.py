@@ -3,10 +3,12 @@
 plus inserts/s and rebalance GB/s as extra fields of the same JSON line.
 
 A "step" is one pass of the hot path over one batch of synthetic input: y = A x on the
-device-resident PCSR (config C3 of SURVEY.md §8d: 1M x 1M Float64, 10 entries per column = 10M nnz,
-dense x), followed — when N > 1 — by the RCCL all-reduce of y over xGMI.  Multi-GPU is weak scaling by
-column range: rank g owns columns (g*1M, (g+1)*1M] of a 1M x (N*1M) matrix (10M nnz per GPU) and the
-matching slice of x; the only data-path collective is the all-reduce of the 1M-entry y.
+device-resident PCSR, followed — when N > 1 — by the sum of the partial y over the ranks (RCCL over xGMI).
+  N = 1 : config C3 of SURVEY.md §8d (the configuration the metric is quoted on): 1M x 1M Float64, 10 entries per
+          column = 10M nnz, dense x.
+  N > 1 : config C4 per GPU: 10M rows, 1.25M columns and 12.5M nnz per rank (column-range sharding, weak scaling; at
+          N = 8 this is BASELINE config 4 exactly: 10M x 10M, 100M nnz), y = 10M doubles = 80 MB summed over the ranks.
+The multi-rank path is dynamicsparsearrays.jl_amd/sharding.py (ColumnShard): the same class the gloo tests run.
 
 Launch: python bench.py --gpus 1            (default)
         python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N
@@ -63,14 +65,46 @@ def c3_triplets(m, ncols, per, col0, seed_rows, seed_vals):
     return rows, cols_local + 1 + col0, vals
 
 
+def kernel_source_sha():
+    """sha256 over the kernel sources whose traffic the committed PMC summaries describe: a summary made from other
+    sources is stale and is not quoted."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("spmv.hip", "rebalance.hip", "dsa_dev.h"):
+        with open(os.path.join(ROOT, "dynamicsparsearrays.jl_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def committed_pmc():
+    """newest profiles/*_pmc_summary.json made from the CURRENT kernel sources (tools/summarize_prof.py records the hash), or None."""
+    import glob
+    sha = kernel_source_sha()
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")), reverse=True):
+        try:
+            with open(f) as fh:
+                pm = json.load(fh)
+        except Exception:
+            continue
+        if pm.get("kernel_source_sha") == sha:
+            return os.path.relpath(f, ROOT), pm
+    return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--rows", type=int, default=1_000_000)
-    ap.add_argument("--cols-per-gpu", type=int, default=1_000_000)
+    ap.add_argument("--config", choices=("auto", "c3", "c4"), default="auto",
+                    help="c3: 1M rows, 1M columns and 10M nnz per GPU (BASELINE config 3; the N = 1 default).  c4: 10M rows, 1.25M columns "
+                         "and 12.5M nnz per GPU, y = 10M doubles (the per-GPU shard of BASELINE config 4: at --gpus 8 the 10M x 10M, "
+                         "100M-nnz matrix exactly; the N > 1 default)")
+    ap.add_argument("--rows", type=int, default=None)
+    ap.add_argument("--cols-per-gpu", type=int, default=None)
     ap.add_argument("--per-col", type=int, default=10)
+    ap.add_argument("--schedule", choices=("all_reduce", "rs_ag", "direct"), default="all_reduce",
+                    help="how the partial y are summed over the ranks in the timed steps (sharding.py)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the inserts/s and rebalance legs")
     args = ap.parse_args()
@@ -89,6 +123,7 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    backend = "none"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("DSA_BENCH_BACKEND", "nccl")
@@ -103,39 +138,43 @@ def main():
     hip.call("set_device", local_rank)
 
     from dsa_amd import sharding
-    m, ncl, per = args.rows, args.cols_per_gpu, args.per_col
-    col0, ncl = sharding.column_range(rank, world, world * ncl)     # contiguous column-key range of this rank
-    I, J, V = c3_triplets(m, ncl, per, col0, seed_rows=5, seed_vals=6)
-    Jl = np.ascontiguousarray(J - col0)
-    # the shard is the reference-layout PCSR of its own sub-matrix: local column keys 1..ncl
+    cfg = args.config if args.config != "auto" else ("c3" if world == 1 else "c4")
+    m = args.rows if args.rows is not None else (1_000_000 if cfg == "c3" else 10_000_000)
+    ncl_per = args.cols_per_gpu if args.cols_per_gpu is not None else (1_000_000 if cfg == "c3" else 1_250_000)
+    per = args.per_col
+    seeds = (5, 6, 7) if cfg == "c3" else (8, 9, 10)          # rows / values / x
+    n_total = world * ncl_per
+    col0, ncl = sharding.column_range(rank, world, n_total)     # contiguous column-key range of this rank
+    I, J, V = c3_triplets(m, ncl, per, col0, seed_rows=seeds[0], seed_vals=seeds[1])
+    # the shard is the reference-layout PCSR of its own sub-matrix: local column keys 1..ncl (only this rank's columns are generated)
     t0 = time.time()
-    A = dsa.dynamicsparse(I, Jl, V, m, ncl, binding=hip)      # bulk build of both orientations on the device (incl. the H2D of I, J, V)
+    shard = sharding.ColumnShard(dsa, I, np.ascontiguousarray(J - col0), V, m, n_total, rank, world, binding=hip, device=dev,
+                                 local_columns=True)      # bulk build of both orientations on the device (incl. the H2D of I, J, V)
     build_s = time.time() - t0
+    A = shard.A
     info_row = A.info(dsa.ROWMAJOR)
     cap = info_row["capacity"]
     nnz = len(I)
 
     stream = torch.cuda.current_stream()
-    hip.call("mat_set_stream", A.h, C.c_void_p(stream.cuda_stream))
-    x = torch.from_numpy(unit12(7, ncl, start=col0)).to(dev)
-    # two output vectors: the RCCL all-reduce of step k (its own stream) overlaps the SpMV of step k+1
-    ys = [torch.zeros(m, dtype=torch.float64, device=dev) for _ in range(2 if world > 1 else 1)]
-    y = ys[0]
-    xp = C.c_void_p(x.data_ptr())
-    yps = [C.c_void_p(t.data_ptr()) for t in ys]
+    x = torch.from_numpy(unit12(seeds[2], ncl, start=col0)).to(dev)
+    # two output vectors: the all-reduce of step k (RCCL's stream) overlaps the SpMV of step k+1
+    overlap = world > 1 and args.schedule == "all_reduce"
+    ys = [shard.new_y() for _ in range(2 if overlap else 1)]
     pending = [None] * len(ys)
 
-    def spmv(k=0):
-        hip.call("mat_spmv_dense_dev", A.h, 0, 0, xp, ncl, yps[k % len(ys)], m)
-
-    def step(k):
+    def step(k, events=None):
         b = k % len(ys)
         if pending[b] is not None:
             pending[b].wait()                     # the collective that last used this buffer (two steps ago)
             pending[b] = None
-        spmv(k)
+        if events is not None:
+            events[0].record(stream)
+        shard.spmv_partial(x, ys[b])             # dsa_shard_spmv_dev: HIP kernel on torch's stream, y written in HBM
+        if events is not None:
+            events[1].record(stream)
         if world > 1:
-            pending[b] = dist.all_reduce(ys[b], op=dist.ReduceOp.SUM, async_op=True)
+            pending[b] = shard.reduce(ys[b], args.schedule, async_op=overlap)
 
     def drain():
         for b in range(len(ys)):
@@ -149,36 +188,37 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def max_over_ranks(v):
+        if world == 1:
+            return v
+        tt = torch.tensor([v], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item())
+
     for k in range(args.warmup):
         step(k)
     barrier()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t1 = time.perf_counter()
     for k in range(args.steps):
-        b = k % len(ys)
-        if pending[b] is not None:
-            pending[b].wait()
-            pending[b] = None
-        ev[k][0].record(stream)
-        spmv(k)
-        ev[k][1].record(stream)
-        if world > 1:
-            pending[b] = dist.all_reduce(ys[b], op=dist.ReduceOp.SUM, async_op=True)
+        step(k, ev[k])
     barrier()
-    elapsed = time.perf_counter() - t1
+    elapsed = max_over_ranks(time.perf_counter() - t1)
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
     ms_per_step = elapsed * 1e3 / args.steps
 
     # algorithmic bytes of one SpMV launch: 16 B per streamed slot + x read + y written
     bytes_launch = 16 * cap + 8 * ncl + 8 * m
     useful_bytes = 16 * nnz + 8 * ncl + 8 * m
+    slot_bytes = 16 if os.environ.get("DSA_KEYS_WIDE") == "1" else 12      # int32 keys in HBM while every key fits Int32 (KeyArr)
+    physical_bytes = slot_bytes * cap + cap // 8 + 8 * ncl + 8 * m            # what the kernel has to move at least: slots + bitmap + x + y
     value = world * bytes_launch / 1e9 / (ms_per_step / 1e3)
     achieved = bytes_launch / 1e9 / (kern_ms / 1e3)
+    nomemset = A.info(dsa.ROWMAJOR)["stat_spmv_nomemset"] > 0
 
+    workload = ("C3: PCSR %dx%d Float64, %d nnz per GPU, dense-x SpMV y=A*x (gather over the rowmajor twin)" % (m, n_total, nnz)) if cfg == "c3" else \
+               ("C4: PCSR %dx%d Float64, %d nnz, column-range sharded over %d GPUs (%d columns and %d nnz per GPU), dense-x SpMV "
+                "y=A*x + sum of the %d-entry partial y over the ranks" % (m, n_total, world * nnz, world, ncl, nnz, m))
     out = {
         "metric": "spmv_gbps_10M_nnz_pcsr",
         "value": round(value, 2),
@@ -192,30 +232,59 @@ def main():
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
-        "config": {"workload": "C3: PCSR %dx%d Float64, %d nnz per GPU, dense-x SpMV y=A*x (gather over the rowmajor twin)"
-                               % (m, ncl * world, nnz),
-                   "capacity_slots": cap, "density": round((nnz + m) / cap, 4), "sharding": "column-range x%d" % world,
-                   "physical_slot_bytes": 16 if os.environ.get("DSA_KEYS_WIDE") == "1" else 12,      # int32 keys in HBM while every key fits Int32 (KeyArr)
-                   "collective": ("RCCL all_reduce(y, %d f64) on its own stream, overlapped with the next step's SpMV (two y buffers)" % m) if world > 1 else "none"},
+        "config": {"workload": workload, "name": cfg,
+                   "capacity_slots": cap, "density": round((nnz + info_row["nb_partitions"]) / cap, 4), "sharding": "column-range x%d" % world,
+                   "physical_slot_bytes": slot_bytes,
+                   "collective": ("%s of y (%d f64 = %.0f MB) over %s%s" % (args.schedule, m, 8 * m / 1e6, "RCCL / xGMI" if backend == "nccl" else backend,
+                                  ", on RCCL's stream, overlapped with the next step's SpMV (two y buffers)" if overlap else "")) if world > 1 else "none"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                     "kernel": "dsa::k_spmv_gather (+ 8 MB y memset)", "algorithmic_bytes": bytes_launch,
+                     "kernel": "dsa::k_spmv_gather" + (" (no memset of y: the kernel zero-fills rows without a partition)" if nomemset else " (+ memset of y)"),
+                     "algorithmic_bytes": bytes_launch,
                      "kernel_ms": round(kern_ms, 5),
+                     "physical_bytes": physical_bytes,
+                     "physical_gbps": round(physical_bytes / 1e9 / (kern_ms / 1e3), 2),
+                     "physical_frac": round(physical_bytes / 1e9 / (kern_ms / 1e3) / HBM_PEAK_GBS, 4),
                      "useful_bytes_no_gaps": useful_bytes,
-                     "useful_gbps": round(useful_bytes / 1e9 / (kern_ms / 1e3), 2)},
+                     "useful_gbps": round(useful_bytes / 1e9 / (kern_ms / 1e3), 2),
+                     "note": "achieved / frac divide SURVEY's ALGORITHMIC bytes (16-byte logical slots) by the measured time; physical_* "
+                             "count the 12-byte slots + bitmap the kernel actually streams"},
         "nnz_per_s": round(world * nnz / (ms_per_step / 1e3), 1),
         "build_s": round(build_s, 3),
     }
 
-    # HBM-side traffic per launch from the committed rocprofv3 PMC passes of the same kernel on the same workload
-    # (separate --pmc FETCH_SIZE / WRITE_SIZE runs, gfx950 x2 correction on the coalesced-stream part): profiles/
-    pmc = os.path.join(ROOT, "profiles", "r01_final_pmc_summary.json")
-    pm = None
-    if os.path.exists(pmc) and m == 1_000_000 and ncl == 1_000_000 and per == 10:
-        with open(pmc) as f:
-            pm = json.load(f)
+    # HBM-side traffic per launch: only from a committed rocprofv3 PMC summary made from the CURRENT kernel sources
+    # (tools/scripts/profile_round.sh: separate --pmc FETCH_SIZE / WRITE_SIZE passes of the same workload); otherwise null
+    pmc_file, pm = committed_pmc()
+    if pm is not None and cfg == "c3" and m == 1_000_000 and ncl == 1_000_000 and per == 10:
         out["roofline"]["traffic"] = pm.get("k_spmv_gather_C3", {}).get("corrected_traffic_total")
-        out["roofline"]["traffic_source"] = "profiles/r01_final_pmc_summary.json (rocprofv3 --pmc, corrected)"
+        out["roofline"]["traffic_source"] = "%s (rocprofv3 --pmc, corrected; kernel sources %s)" % (pmc_file, pm.get("kernel_source_sha"))
+    else:
+        out["roofline"]["traffic_source"] = "none: no committed PMC summary matches the current kernel sources (%s)" % kernel_source_sha()
+
+    if world > 1:
+        # the three schedules of the sum of y, and the local product alone, timed back to back without overlap
+        # (max over ranks): what the collective costs next to the SpMV it follows
+        sched = {}
+        reps = max(5, min(args.steps, 20))
+
+        def timed(fn):
+            barrier()
+            t = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize()
+            return round(max_over_ranks(time.perf_counter() - t) / reps * 1e3, 4)
+
+        sched["local_spmv_ms"] = timed(lambda: shard.spmv_partial(x, ys[0]))
+        for name in sharding.SCHEDULES:
+            try:
+                sched[name + "_ms"] = timed(lambda: shard.reduce(ys[0], name))
+                sched[name + "_algbw_gbps"] = round(8 * m / 1e9 / (sched[name + "_ms"] / 1e3), 1)
+            except Exception as e:
+                sched[name + "_ms"] = "failed: %s" % str(e)[:120]
+        out["collective_schedules"] = sched
+        out["end_to_end_ms"] = {"local_spmv": sched["local_spmv_ms"], "step_overlapped": round(ms_per_step, 5)}
     if rank == 0 and world == 1 and not args.no_extras:          # the extra legs and the CPU baseline belong to the N = 1 line
         try:
             out.update(extras(dsa, hip, torch, A, dev))
@@ -437,14 +506,14 @@ def c5_streaming(dsa, hip, torch, dev, m5, ncols5, per5, every, binding=None, st
 
 def cpu_baseline(dsa, m, per):
     """The CPU oracle (a single-thread C++ restatement of the reference; the Julia reference cannot run
-    here) on a bounded sample of the same workload: the first 100k columns of the C3 matrix."""
+    here) on the SAME C3 input as the GPU leg (all 1M columns, 10M nnz: ~3 s of build + 3 products of ~0.5 s)."""
     import multiprocessing
     ora_path = os.path.join(ROOT, "oracle", "liboracle.so")
     if not os.path.exists(ora_path):
         import subprocess
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "liboracle.so"])
     ora = dsa.Binding(ora_path, "ora", device_api=False)
-    ncs = 400_000
+    ncs = 1_000_000 if m == 1_000_000 else 400_000
     I, J, V = c3_triplets(m, ncs, per, 0, seed_rows=5, seed_vals=6)
     t = time.perf_counter()
     B = dsa.dynamicsparse(I, J, V, m, ncs, binding=ora)
@@ -481,8 +550,9 @@ def cpu_baseline(dsa, m, per):
     return {"value": round(bytes_ / 1e9 / ts, 4), "unit": "GB/s", "cores": 1, "kind": "port",
             "c5_first_10k_columns": {k: c5[k] for k in ("columns", "element_writes", "write_s", "element_writes_per_s", "spmv_ms_avg")},
             "inserts_per_s": {"batch_A_ascending_appends": round(100000 / ta, 1), "batch_B_uniform": round(len(odd) / tb2, 1)},
-            "sample": "first 400k columns of the C3 matrix (1M x 400k, %d nnz, colmajor capacity %d): y = A*x with the "
-                      "reference's Dict accumulator (src/operations.jl:101), 1 thread of %d host cores" % (len(I), cap, multiprocessing.cpu_count()),
+            "sample": "%s C3 matrix (%d x %d, %d nnz, colmajor capacity %d): y = A*x with the "
+                      "reference's Dict accumulator (src/operations.jl:101), 3 products, 1 thread of %d host cores"
+                      % ("the full" if ncs == 1_000_000 else "first %d columns of the" % ncs, m, ncs, len(I), cap, multiprocessing.cpu_count()),
             "nnz_per_s": round(len(I) / ts, 1),
             "dense_accumulator_gbps": round(bytes_ / 1e9 / tf, 4), "dense_accumulator_nnz_per_s": round(len(I) / tf, 1),
             "build_s": round(tb, 2)}

@@ -12,6 +12,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <mutex>
 
 namespace dsa {
 
@@ -199,6 +200,20 @@ __device__ __forceinline__ uint64_t spread_bits32(uint32_t x) {
     return v;
 }
 #endif  // __HIPCC__
+
+// one-time kernel attribute setup (hipFuncSetAttribute is per device): thread-safe — the two orientations of a matrix are driven
+// from two host threads (dsa_host.hip: mat_apply_sets) — and repeated for every device a process uses
+struct PerDeviceOnce {
+    static constexpr int MAX_DEV = 32;
+    std::once_flag flag[MAX_DEV];
+    hipError_t err[MAX_DEV];
+    template <typename F> hipError_t run(F fn) {
+        int d = 0;
+        if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= MAX_DEV) return fn();
+        std::call_once(flag[d], [&] { err[d] = fn(); });
+        return err[d];
+    }
+};
 
 // ---- host-side launch wrappers (defined in the .hip files) ----------------------------------------
 struct RebalanceWork {   // scratch owned by a PMA for the big pack+spread

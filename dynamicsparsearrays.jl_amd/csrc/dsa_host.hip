@@ -16,10 +16,12 @@
 #include <chrono>
 #include <cstring>
 #include <numeric>
+#include <mutex>
 #include <exception>
 #include <string>
 #include <thread>
 #include <unordered_map>
+#include <unordered_set>
 #include <vector>
 
 using namespace dsa;
@@ -87,6 +89,8 @@ struct Pma {
     int64_t* d_small = nullptr;                     // 8 x int64 scratch
     int64_t* h_small = nullptr;                     // its pinned host mirror (small read-backs without a pageable staging copy)
     // bumped by every launch that can move cells or change the tables; SpmvMeta is recomputed when it differs
+    int device = 0;              // the device the handle lives on: re-selected at every API entry (a Julia task / finalizer thread or a
+                                 // second Python thread calls in with whatever device its thread last selected)
     int64_t layout_epoch = 0;
     int64_t stat_spmv_nomemset = 0;
     struct SpmvMeta { int64_t epoch = -1; bool ordered = false; int64_t max_extent = 0, max_gap = 0, first_key = 0, last_key = 0; } spmv_meta;
@@ -201,8 +205,11 @@ void alloc_work(Pma& P, int64_t slots) {
     HIPCHK(hipMalloc(&P.occ_old, (size_t)occ_words_for(slots) * sizeof(uint64_t)));
 }
 
+void bind_device(const Pma& P) { HIPCHK(hipSetDevice(P.device)); }
+
 void pma_init_common(Pma& P, bool sems, bool cols) {
     HIPCHK(hipSetDevice(g_device));
+    P.device = g_device;
     HIPCHK(hipStreamCreateWithFlags(&P.stream, hipStreamNonBlocking));
     P.own_stream = true;
     P.has_sems = sems; P.has_cols = cols;
@@ -817,13 +824,63 @@ void pma_build_from_host(Pma& P, const int64_t* part, const int64_t* key, const 
 constexpr size_t PENDING_FLUSH = 1u << 16;
 struct dsa_vec { Pma P; int64_t n = 0; std::vector<int64_t> pk; std::vector<double> pv; };
 struct dsa_pcsc { Pma P; };
-struct FillBuffer {     // Buffer  src/buffer.jl:1-4 (host staging in the reference too)
-    std::unordered_map<int64_t, size_t> index;
-    std::vector<int64_t> rowids;
-    std::vector<std::vector<int64_t>> colids;
-    std::vector<std::vector<double>> vals;
+// Buffer  src/buffer.jl:1-4 — the fill-mode write buffer, DEVICE-RESIDENT: appended triples are staged in two pinned host chunks
+// and uploaded asynchronously as a chunk fills (the copy of chunk k overlaps the caller's appends into chunk k+1), so that
+// closefillmode! finds the (row, col, value) stream already in HBM and only ships the last partial chunk.  The reference keeps
+// a Dict row -> (colids, vals); what it uses the per-row structure for — rejecting a second addrow! of a row id
+// (src/buffer.jl:13) — is the `rows` set here; the order of the entries is irrelevant after the (col, row) sort of the
+// builder, duplicates of (i, j) are accumulated with + at the flush like the reference (test/functional/sparsematrix.jl:433-437).
+struct FillBuffer {
+    static constexpr int64_t CHUNK = 1 << 20;            // triples per pinned staging chunk (24 MB)
+    std::vector<uint64_t> row_bits;                       // rows 1 .. 2^28 already written (one bit each, grown on demand)
+    std::unordered_set<int64_t> rows_far;                 // ... and the others
+    int64_t* hI[2] = {nullptr, nullptr}; int64_t* hJ[2] = {nullptr, nullptr}; double* hV[2] = {nullptr, nullptr};
+    hipEvent_t uploaded[2] = {nullptr, nullptr};
+    bool in_flight[2] = {false, false};
+    int cur = 0;
+    int64_t fill = 0;                                     // triples in the current pinned chunk
+    int64_t *dI = nullptr, *dJ = nullptr; double* dV = nullptr;
+    int64_t dcap = 0, dlen = 0;                           // triples allocated / resident in HBM
+    hipStream_t stream = nullptr;
     int64_t length = 0;
+    bool fit32_rows = true, fit32_cols = true;
+    int device = 0;
 };
+static inline bool fill_row_test_and_set(FillBuffer& b, int64_t row) {
+    if (row >= 1 && row < ((int64_t)1 << 28)) {
+        const size_t w = (size_t)(row >> 6);
+        if (w >= b.row_bits.size()) b.row_bits.resize(std::max<size_t>(2 * b.row_bits.size(), w + 1024), 0ull);
+        const uint64_t bit = 1ull << (row & 63);
+        const bool was = (b.row_bits[w] & bit) != 0;
+        b.row_bits[w] |= bit;
+        return was;
+    }
+    return !b.rows_far.insert(row).second;
+}
+// pinned staging chunks are expensive to allocate and free (milliseconds each): one set is kept for the next fill-mode matrix
+struct FillStagingCache { std::mutex mu; int64_t* hI[2] = {nullptr, nullptr}; int64_t* hJ[2] = {nullptr, nullptr}; double* hV[2] = {nullptr, nullptr}; int device = -1; };
+static FillStagingCache g_fill_cache;
+static void fill_release(FillBuffer& b) {
+    if (b.stream) hipStreamSynchronize(b.stream);
+    {
+        std::lock_guard<std::mutex> lk(g_fill_cache.mu);
+        if (b.hI[0] && g_fill_cache.hI[0] == nullptr) {
+            for (int k = 0; k < 2; ++k) { g_fill_cache.hI[k] = b.hI[k]; g_fill_cache.hJ[k] = b.hJ[k]; g_fill_cache.hV[k] = b.hV[k]; b.hI[k] = nullptr; b.hJ[k] = nullptr; b.hV[k] = nullptr; }
+            g_fill_cache.device = b.device;
+        }
+    }
+    for (int k = 0; k < 2; ++k) {
+        if (b.hI[k]) hipHostFree(b.hI[k]);
+        if (b.hJ[k]) hipHostFree(b.hJ[k]);
+        if (b.hV[k]) hipHostFree(b.hV[k]);
+        if (b.uploaded[k]) hipEventDestroy(b.uploaded[k]);
+    }
+    if (b.dI) hipFree(b.dI);
+    if (b.dJ) hipFree(b.dJ);
+    if (b.dV) hipFree(b.dV);
+    if (b.stream) hipStreamDestroy(b.stream);
+    b = FillBuffer();
+}
 struct dsa_mat {
     int64_t m = 0, n = 0;
     bool fillmode = false;
@@ -838,30 +895,20 @@ struct dsa_mat {
 
 namespace {
 
-void mat_build_major(dsa_mat* h, const int64_t* I, const int64_t* J, const double* V, int64_t nnz) {
-    pma_init_common(h->col, true, true);
-    pma_init_common(h->row, true, true);
-    int64_t *dI = nullptr, *dJ = nullptr; double* dV = nullptr;
-    const auto tup0 = std::chrono::steady_clock::now();
+// both orientations from (row, col, value) triples that are ALREADY in HBM (freed here): dynamicsparse(I, J, V) after its
+// upload, closefillmode! straight from the device-resident fill buffer
+void mat_build_major_dev(dsa_mat* h, int64_t* dI, int64_t* dJ, double* dV, int64_t nnz, bool wide_rows, bool wide_cols) {
     try {
-        if (nnz > 0) {
-            hipStream_t s = h->col.stream;
-            HIPCHK(hipMalloc(&dI, (size_t)nnz * sizeof(int64_t)));
-            HIPCHK(hipMalloc(&dJ, (size_t)nnz * sizeof(int64_t)));
-            HIPCHK(hipMalloc(&dV, (size_t)nnz * sizeof(double)));
-            HIPCHK(hipMemcpyAsync(dI, I, (size_t)nnz * sizeof(int64_t), hipMemcpyHostToDevice, s));
-            HIPCHK(hipMemcpyAsync(dJ, J, (size_t)nnz * sizeof(int64_t), hipMemcpyHostToDevice, s));
-            HIPCHK(hipMemcpyAsync(dV, V, (size_t)nnz * sizeof(double), hipMemcpyHostToDevice, s));
-            HIPCHK(hipStreamSynchronize(s));
-        }
+        pma_init_common(h->col, true, true);
+        pma_init_common(h->row, true, true);
         static const bool dbg_time = getenv("DSA_DBG_TIME") != nullptr;
         const auto tb0 = std::chrono::steady_clock::now();
-        pma_build_dev(h->col, dJ, dI, dV, nnz, DSA_COMBINE_ADD, 0, 0, !keys_fit32(I, nnz));      // dynamicsparsecolmajor(I, J, V): partitions = columns
+        pma_build_dev(h->col, dJ, dI, dV, nnz, DSA_COMBINE_ADD, 0, 0, wide_rows);      // dynamicsparsecolmajor(I, J, V): partitions = columns, keys = rows
         const auto tb1 = std::chrono::steady_clock::now();
-        pma_build_dev(h->row, dI, dJ, dV, nnz, DSA_COMBINE_ADD, 0, 0, !keys_fit32(J, nnz));      // dynamicsparsecolmajor(J, I, V): partitions = rows
+        pma_build_dev(h->row, dI, dJ, dV, nnz, DSA_COMBINE_ADD, 0, 0, wide_cols);      // dynamicsparsecolmajor(J, I, V): partitions = rows, keys = columns
         if (dbg_time)
-            fprintf(stderr, "[mat_build_major] nnz=%lld upload %.1f ms  colmajor %.1f ms  rowmajor %.1f ms\n", (long long)nnz,
-                    std::chrono::duration<double, std::milli>(tb0 - tup0).count(), std::chrono::duration<double, std::milli>(tb1 - tb0).count(),
+            fprintf(stderr, "[mat_build_major] nnz=%lld colmajor %.1f ms  rowmajor %.1f ms\n", (long long)nnz,
+                    std::chrono::duration<double, std::milli>(tb1 - tb0).count(),
                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tb1).count());
     } catch (...) {
         if (dI) hipFree(dI);
@@ -873,6 +920,31 @@ void mat_build_major(dsa_mat* h, const int64_t* I, const int64_t* J, const doubl
     if (dJ) hipFree(dJ);
     if (dV) hipFree(dV);
     h->has_major = true;
+}
+
+void mat_build_major(dsa_mat* h, const int64_t* I, const int64_t* J, const double* V, int64_t nnz) {
+    int64_t *dI = nullptr, *dJ = nullptr; double* dV = nullptr;
+    const auto tup0 = std::chrono::steady_clock::now();
+    HIPCHK(hipSetDevice(g_device));
+    try {
+        if (nnz > 0) {
+            HIPCHK(hipMalloc(&dI, (size_t)nnz * sizeof(int64_t)));
+            HIPCHK(hipMalloc(&dJ, (size_t)nnz * sizeof(int64_t)));
+            HIPCHK(hipMalloc(&dV, (size_t)nnz * sizeof(double)));
+            HIPCHK(hipMemcpy(dI, I, (size_t)nnz * sizeof(int64_t), hipMemcpyHostToDevice));
+            HIPCHK(hipMemcpy(dJ, J, (size_t)nnz * sizeof(int64_t), hipMemcpyHostToDevice));
+            HIPCHK(hipMemcpy(dV, V, (size_t)nnz * sizeof(double), hipMemcpyHostToDevice));
+        }
+    } catch (...) {
+        if (dI) hipFree(dI);
+        if (dJ) hipFree(dJ);
+        if (dV) hipFree(dV);
+        throw;
+    }
+    static const bool dbg_time = getenv("DSA_DBG_TIME") != nullptr;
+    if (dbg_time) fprintf(stderr, "[mat_build_major] upload of %lld triples from caller memory %.1f ms\n", (long long)nnz,
+                          std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tup0).count());
+    mat_build_major_dev(h, dI, dJ, dV, nnz, !keys_fit32(I, nnz), !keys_fit32(J, nnz));
 }
 
 Pma& orient(dsa_mat* h, int32_t o) {
@@ -912,7 +984,7 @@ void mat_apply_sets(dsa_mat* h, const int64_t* I, const int64_t* J, const double
         std::thread row_thread;
         if (side_by_side)
             row_thread = std::thread([&] {
-                try { if (hipSetDevice(g_device) != hipSuccess) fail(DSA_EHIP, "hipSetDevice"); dr = run_ops_parallel(h->row, orw, &er); }
+                try { bind_device(h->row); dr = run_ops_parallel(h->row, orw, &er); }
                 catch (...) { row_exc = std::current_exception(); }
             });
         const int64_t rounds0 = h->row.stat_par_rounds;
@@ -1107,6 +1179,7 @@ int32_t dsa_vec_get(dsa_vec_t* h, int64_t key, double* out) { return dsa_vec_get
 
 static void vec_apply(dsa_vec_t* h, const int64_t* keys, const double* vals, int64_t n);
 static void vec_flush(dsa_vec_t* h) {
+    bind_device(h->P);
     if (h->pk.empty()) return;
     std::vector<int64_t> k; std::vector<double> v;
     k.swap(h->pk); v.swap(h->pv);                      // the queue is empty even if the apply fails
@@ -1317,10 +1390,11 @@ int32_t dsa_pcsc_create_empty(dsa_pcsc_t** out) {
 }
 int32_t dsa_pcsc_destroy(dsa_pcsc_t* h) { if (h) { pma_destroy(h->P); delete h; } return DSA_OK; }
 int32_t dsa_pcsc_get(dsa_pcsc_t* h, int64_t key, int64_t partition, double* out) {
-    API_TRY get_batch(h->P, 1, &key, &partition, 1, out); API_CATCH
+    API_TRY bind_device(h->P); get_batch(h->P, 1, &key, &partition, 1, out); API_CATCH
 }
 int32_t dsa_pcsc_set(dsa_pcsc_t* h, double val, int64_t key, int64_t partition) {
     API_TRY
+    bind_device(h->P);
     if (partition > h->P.h_ctl->table_len + (1 << 24)) fail(DSA_EARG, "partition index unreasonably far past the last partition");
     std::vector<Op> ops{make_op(OP_PCSC_SET, key, partition, val)};
     int32_t err = 0;
@@ -1330,6 +1404,7 @@ int32_t dsa_pcsc_set(dsa_pcsc_t* h, double val, int64_t key, int64_t partition) 
 }
 int32_t dsa_pcsc_deletepartition(dsa_pcsc_t* h, int64_t partition) {
     API_TRY
+    bind_device(h->P);
     std::vector<Op> ops{make_op(OP_DELETE_PARTITION, 0, partition, 0.0)};
     int32_t err = 0;
     run_ops(h->P, ops, &err);
@@ -1342,6 +1417,7 @@ int32_t dsa_pcsc_info(dsa_pcsc_t* h, int64_t* info) { pma_info(h->P, h->P.h_ctl-
 int32_t dsa_pcsc_export_layout(dsa_pcsc_t* h, int64_t* keys, double* vals, uint8_t* occ, int64_t cap,
                                int64_t* semaphores, int64_t table_cap) {
     API_TRY
+    bind_device(h->P);
     export_slots(h->P, keys, vals, occ, cap);
     export_tables(h->P, semaphores, nullptr, nullptr, table_cap);
     API_CATCH
@@ -1407,6 +1483,7 @@ int32_t dsa_mat_create_empty(int32_t fill_mode, dsa_mat_t** out) {
 int32_t dsa_mat_destroy(dsa_mat_t* h) {
     if (h) {
         if (h->has_major) { pma_destroy(h->col); pma_destroy(h->row); }
+        fill_release(h->buf);
         if (h->d_x) hipFree(h->d_x);
         if (h->d_y) hipFree(h->d_y);
         if (h->sp_base) hipFree(h->sp_base);
@@ -1416,19 +1493,79 @@ int32_t dsa_mat_destroy(dsa_mat_t* h) {
     return DSA_OK;
 }
 
-static void fill_addelem(FillBuffer& b, int64_t row, int64_t col, double val) {   // addelem!  src/buffer.jl:20-31
-    auto it = b.index.find(row);
-    size_t r;
-    if (it == b.index.end()) {
-        r = b.rowids.size();
-        b.index.emplace(row, r);
-        b.rowids.push_back(row); b.colids.emplace_back(); b.vals.emplace_back();
-    } else r = it->second;
-    b.colids[r].push_back(col); b.vals[r].push_back(val);
-    b.length += 1;
+// ---- device-resident fill buffer --------------------------------------------------------------------------------------
+static void fill_init(FillBuffer& b) {
+    if (b.stream) return;
+    HIPCHK(hipSetDevice(g_device));
+    b.device = g_device;
+    HIPCHK(hipStreamCreateWithFlags(&b.stream, hipStreamNonBlocking));
+    {
+        std::lock_guard<std::mutex> lk(g_fill_cache.mu);
+        if (g_fill_cache.hI[0] != nullptr && g_fill_cache.device == b.device)
+            for (int k = 0; k < 2; ++k) { b.hI[k] = g_fill_cache.hI[k]; b.hJ[k] = g_fill_cache.hJ[k]; b.hV[k] = g_fill_cache.hV[k]; g_fill_cache.hI[k] = nullptr; g_fill_cache.hJ[k] = nullptr; g_fill_cache.hV[k] = nullptr; }
+    }
+    for (int k = 0; k < 2; ++k) {
+        HIPCHK(hipEventCreateWithFlags(&b.uploaded[k], hipEventDisableTiming));
+        if (b.hI[k]) continue;
+        HIPCHK(hipHostMalloc(&b.hI[k], (size_t)FillBuffer::CHUNK * sizeof(int64_t), hipHostMallocDefault));
+        HIPCHK(hipHostMalloc(&b.hJ[k], (size_t)FillBuffer::CHUNK * sizeof(int64_t), hipHostMallocDefault));
+        HIPCHK(hipHostMalloc(&b.hV[k], (size_t)FillBuffer::CHUNK * sizeof(double), hipHostMallocDefault));
+    }
+}
+// ships the current pinned chunk (b.fill triples) to HBM, asynchronously; the other chunk becomes current
+static void fill_upload_chunk(FillBuffer& b) {
+    if (b.fill == 0) return;
+    HIPCHK(hipSetDevice(b.device));
+    if (b.dlen + b.fill > b.dcap) {          // grow geometrically: new arrays, device-to-device copy of what is resident
+        const int64_t ncap = std::max<int64_t>(2 * b.dcap, std::max<int64_t>(b.dlen + b.fill, 4 * FillBuffer::CHUNK));
+        int64_t *nI = nullptr, *nJ = nullptr; double* nV = nullptr;
+        HIPCHK(hipMalloc(&nI, (size_t)ncap * sizeof(int64_t)));
+        HIPCHK(hipMalloc(&nJ, (size_t)ncap * sizeof(int64_t)));
+        HIPCHK(hipMalloc(&nV, (size_t)ncap * sizeof(double)));
+        if (b.dlen > 0) {
+            HIPCHK(hipMemcpyAsync(nI, b.dI, (size_t)b.dlen * sizeof(int64_t), hipMemcpyDeviceToDevice, b.stream));
+            HIPCHK(hipMemcpyAsync(nJ, b.dJ, (size_t)b.dlen * sizeof(int64_t), hipMemcpyDeviceToDevice, b.stream));
+            HIPCHK(hipMemcpyAsync(nV, b.dV, (size_t)b.dlen * sizeof(double), hipMemcpyDeviceToDevice, b.stream));
+        }
+        HIPCHK(hipStreamSynchronize(b.stream));       // earlier uploads into the old arrays have landed
+        if (b.dI) hipFree(b.dI);
+        if (b.dJ) hipFree(b.dJ);
+        if (b.dV) hipFree(b.dV);
+        b.dI = nI; b.dJ = nJ; b.dV = nV; b.dcap = ncap;
+    }
+    const int c = b.cur;
+    HIPCHK(hipMemcpyAsync(b.dI + b.dlen, b.hI[c], (size_t)b.fill * sizeof(int64_t), hipMemcpyHostToDevice, b.stream));
+    HIPCHK(hipMemcpyAsync(b.dJ + b.dlen, b.hJ[c], (size_t)b.fill * sizeof(int64_t), hipMemcpyHostToDevice, b.stream));
+    HIPCHK(hipMemcpyAsync(b.dV + b.dlen, b.hV[c], (size_t)b.fill * sizeof(double), hipMemcpyHostToDevice, b.stream));
+    HIPCHK(hipEventRecord(b.uploaded[c], b.stream));
+    b.in_flight[c] = true;
+    b.dlen += b.fill;
+    b.fill = 0;
+    b.cur = 1 - c;
+    if (b.in_flight[b.cur]) { HIPCHK(hipEventSynchronize(b.uploaded[b.cur])); b.in_flight[b.cur] = false; }   // its pinned memory is free again
+}
+// addelem!  src/buffer.jl:20-31 for n entries (n = 1: one setindex! in fill mode)
+static void fill_append(FillBuffer& b, const int64_t* I, const int64_t* J, const double* V, int64_t n) {
+    fill_init(b);
+    for (int64_t k = 0; k < n; ++k) {
+        b.fit32_rows = b.fit32_rows && key_fits32(I[k]);
+        b.fit32_cols = b.fit32_cols && key_fits32(J[k]);
+    }
+    int64_t k = 0;
+    while (k < n) {
+        const int64_t room = FillBuffer::CHUNK - b.fill;
+        const int64_t take = std::min(room, n - k);
+        std::memcpy(b.hI[b.cur] + b.fill, I + k, (size_t)take * sizeof(int64_t));
+        std::memcpy(b.hJ[b.cur] + b.fill, J + k, (size_t)take * sizeof(int64_t));
+        std::memcpy(b.hV[b.cur] + b.fill, V + k, (size_t)take * sizeof(double));
+        b.fill += take; k += take;
+        if (b.fill == FillBuffer::CHUNK) fill_upload_chunk(b);
+    }
+    b.length += n;
 }
 
 static void mat_flush(dsa_mat_t* h) {
+    if (h->has_major) bind_device(h->col);
     if (h->pi.empty()) return;
     std::vector<int64_t> i, j; std::vector<double> v;
     i.swap(h->pi); j.swap(h->pj); v.swap(h->pv);       // the queue is empty even if the apply fails
@@ -1440,7 +1577,8 @@ int32_t dsa_mat_set(dsa_mat_t* h, double val, int64_t row, int64_t col) {
     check_key(row); check_key(col);
     if (val != 0.0) { h->m = std::max(h->m, row); h->n = std::max(h->n, col); }      // src/matrix.jl:44-47
     if (h->fillmode) {
-        fill_addelem(h->buf, row, col, val);
+        fill_row_test_and_set(h->buf, row);
+        fill_append(h->buf, &row, &col, &val, 1);
     } else {
         h->pi.push_back(row); h->pj.push_back(col); h->pv.push_back(val);
         // with tombstones a write can hit the reference's assert / bounds paths: apply it now so the error surfaces here
@@ -1458,8 +1596,9 @@ int32_t dsa_mat_set_batch(dsa_mat_t* h, const int64_t* I, const int64_t* J, cons
     if (h->fillmode) {
         for (int64_t k = 0; k < n; ++k) {
             if (V[k] != 0.0) { h->m = std::max(h->m, I[k]); h->n = std::max(h->n, J[k]); }
-            fill_addelem(h->buf, I[k], J[k], V[k]);
+            fill_row_test_and_set(h->buf, I[k]);
         }
+        fill_append(h->buf, I, J, V, n);
     } else {
         mat_apply_sets(h, I, J, V, n);
     }
@@ -1482,15 +1621,9 @@ int32_t dsa_mat_addrow(dsa_mat_t* h, int64_t row, const int64_t* colids, const d
     for (int64_t k = 0; k < n; ++k) check_key(colids[k]);
     if (h->fillmode) {     // addrow!(buffer, ...)  src/buffer.jl:10-18
         FillBuffer& b = h->buf;
-        if (b.index.count(row)) fail(DSA_EMODE, "Row already written in dynamic sparse matrix buffer.");
-        std::vector<size_t> perm((size_t)n);
-        std::iota(perm.begin(), perm.end(), (size_t)0);
-        std::stable_sort(perm.begin(), perm.end(), [&](size_t a, size_t c) { return colids[a] < colids[c]; });
-        const size_t r = b.rowids.size();
-        b.index.emplace(row, r);
-        b.rowids.push_back(row); b.colids.emplace_back((size_t)n); b.vals.emplace_back((size_t)n);
-        for (size_t i = 0; i < (size_t)n; ++i) { b.colids[r][i] = colids[perm[i]]; b.vals[r][i] = vals[perm[i]]; }
-        b.length += n;
+        if (fill_row_test_and_set(b, row)) fail(DSA_EMODE, "Row already written in dynamic sparse matrix buffer.");
+        std::vector<int64_t> rows((size_t)n, row);       // (the reference stores the column ids of the row sorted: only its buffer views see that)
+        fill_append(b, rows.data(), colids, vals, n);
     } else {               // src/matrix.jl:119-121
         std::vector<int64_t> rows((size_t)n, row);
         mat_apply_sets(h, rows.data(), colids, vals, n);
@@ -1502,15 +1635,22 @@ int32_t dsa_mat_closefillmode(dsa_mat_t* h) {     // closefillmode!  src/matrix.
     API_TRY
     mat_flush(h);
     if (!h->fillmode) fail(DSA_EMODE, "Cannot close fill mode because matrix is not in fill mode.");
-    std::vector<int64_t> I, J; std::vector<double> V;     // get_rowids_colids_vals  src/buffer.jl:33-50
-    I.reserve((size_t)h->buf.length); J.reserve((size_t)h->buf.length); V.reserve((size_t)h->buf.length);
-    for (size_t r = 0; r < h->buf.rowids.size(); ++r)
-        for (size_t i = 0; i < h->buf.vals[r].size(); ++i) {
-            I.push_back(h->buf.rowids[r]); J.push_back(h->buf.colids[r][i]); V.push_back(h->buf.vals[r][i]);
-        }
-    mat_build_major(h, I.data(), J.data(), V.data(), (int64_t)I.size());
+    // get_rowids_colids_vals (src/buffer.jl:33-50) is a no-op here: the triples already sit in HBM; only the last partial
+    // chunk is still in pinned memory
+    FillBuffer& b = h->buf;
+    int64_t *dI = nullptr, *dJ = nullptr; double* dV = nullptr;
+    int64_t nnz = 0;
+    bool wr = false, wc = false;
+    if (b.stream) {
+        fill_upload_chunk(b);
+        HIPCHK(hipStreamSynchronize(b.stream));
+        dI = b.dI; dJ = b.dJ; dV = b.dV; nnz = b.dlen;
+        b.dI = nullptr; b.dJ = nullptr; b.dV = nullptr;          // ownership moves to the builder
+        wr = !b.fit32_rows; wc = !b.fit32_cols;
+    }
+    mat_build_major_dev(h, dI, dJ, dV, nnz, wr, wc);
     h->fillmode = false;
-    h->buf = FillBuffer();
+    fill_release(h->buf);
     API_CATCH
 }
 

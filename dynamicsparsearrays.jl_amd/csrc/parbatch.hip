@@ -547,14 +547,11 @@ __global__ __launch_bounds__(PB_BLOCK) void k_apply(KeyArr keys, double* vals, u
 
 // one round = plan -> conflicts -> resolve (+ cursor advance) -> apply, all driven by the device-resident RoundState
 static hipError_t configure_apply() {
-    static bool configured = false;
-    if (!configured) {
+    static PerDeviceOnce once;
+    return once.run([] {
         const size_t lds = (size_t)(PB_BLOCK / 64) * PB_MAX_W * (sizeof(int64_t) + sizeof(double));
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_apply), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        configured = true;
-    }
-    return hipSuccess;
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(k_apply), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    });
 }
 static hipError_t enqueue_round(KeyArr keys, double* vals, uint64_t* occ, int64_t* sems, int64_t* col_keys,
                                 uint8_t* col_live, Ctl* ctl, const Op* ops, RoundState* rs, Plan* plans, uint32_t* flags,

@@ -793,12 +793,11 @@ hipError_t launch_permute(KeyArr src_keys, const double* src_vals, const uint64_
     hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, stream, wdst->tile_cnt, wdst->tile_off, a.dst_tiles);
     a.src_off = wsrc->tile_off; a.dst_off = wdst->tile_off;
     a.n0 = n0; a.ops = ops; a.i0 = i0; a.sems = sems;
-    static bool configured = false;
     const size_t lds = (size_t)PERM_TILE * 16;
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_permute), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static PerDeviceOnce once;
+    {
+        hipError_t e = once.run([] { return hipFuncSetAttribute(reinterpret_cast<const void*>(k_permute), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
         if (e != hipSuccess) return e;
-        configured = true;
     }
     hipLaunchKernelGGL(k_permute, dim3((unsigned)a.dst_tiles), dim3(256), lds, stream, a);
     return hipGetLastError();

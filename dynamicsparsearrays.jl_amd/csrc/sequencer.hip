@@ -1434,13 +1434,13 @@ __global__ __launch_bounds__(SEQ_BLOCK) void k_sequencer(KeyArr keys, double* va
 hipError_t launch_sequencer(KeyArr keys, double* vals, uint64_t* occ, int64_t* sems, int64_t* col_keys,
                             uint8_t* col_live, Ctl* ctl, const Op* ops, int64_t n_ops, int64_t n_avail, bool run_ok,
                             hipStream_t stream) {
-    static bool configured = false;
     const size_t lds_bytes = (size_t)SMALL_W * (sizeof(int64_t) + sizeof(double));
-    if (!configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_sequencer),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    static PerDeviceOnce once;
+    {
+        hipError_t e = once.run([] {
+            return hipFuncSetAttribute(reinterpret_cast<const void*>(k_sequencer), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        });
         if (e != hipSuccess) return e;
-        configured = true;
     }
     hipLaunchKernelGGL(k_sequencer, dim3(1), dim3(SEQ_BLOCK), lds_bytes, stream, keys, vals, occ, sems, col_keys, col_live,
                        ctl, ops, n_ops, n_avail, run_ok ? 1 : 0);

@@ -1,16 +1,28 @@
 # DynamicSparseArraysAMD.jl — Julia host module over libdsa_hip.so (include/dsa.h).
 #
 # Drop-in for the PMA / PCSR hot path of DynamicSparseArrays.jl under Coluna: the same exported names
-# (reference src/DynamicSparseArrays.jl:5-16) with K = L = Int64, T = Float64, every method a thin
-# `ccall` into the C-ABI HIP shim.  NOTE: there is no Julia toolchain in the build image, so this file
-# has not been executed; the ABI itself is exercised through the Python mirror
-# (dynamicsparsearrays.jl_amd/api.py) by tests/.
+# (reference src/DynamicSparseArrays.jl:5-16), every method a thin `ccall` into the C-ABI HIP shim.
+# The shim fixes K = L = Int64, T = Float64 (SURVEY.md §8b); this file carries the part of the contract
+# that cannot cross a C ABI:
+#   * the KEY-MAPPING LAYER: containers are parametric in their key types like the reference's
+#     (`DynamicSparseVector{K}`, `DynamicSparseMatrix{K,L}`); every key crosses the ABI through
+#     `keyint(k)::Int64` (order-preserving: the library keeps partitions and cells in Int64 order, the
+#     reference in `isless` order of K) and comes back through `keyfrom(K, i)`.  Methods exist for the
+#     Integer types and for `Char` (test/functional/sparsematrix.jl:302-336); an id struct (Coluna's
+#     VarId / ConstrId) needs two one-line methods, or only `keyint` — then the container remembers
+#     the keys it has been given (`KeyMap.seen`) to translate results back;
+#   * arbitrary `combine` functions: `+`, `*` and "last" run in the library, anything else is folded
+#     here, left to right in input order, before the call (src/vector.jl:10-36, src/pcsr.jl:365-398).
+# NOTE: there is no Julia toolchain in the build image, so this file has not been executed; the ABI
+# itself is exercised through the Python mirror (dynamicsparsearrays.jl_amd/api.py) by tests/, and
+# tests/test_library_symbols.py checks every `ccall` below against include/dsa.h.
 module DynamicSparseArraysAMD
 
 using SparseArrays
 
-export DynamicSparseVector, DynamicSparseMatrix, PackedCSC, dynamicsparsevec, dynamicsparse, nbpartitions,
-       deletecolumn!, deleterow!, deletepartition!, addrow!, closefillmode!, shrink_size!, set_device!, shard_range, dynamicsparse_shard
+export DynamicSparseVector, DynamicSparseMatrix, DynamicMatrixColView, PackedCSC, dynamicsparsevec, dynamicsparse, nbpartitions,
+       deletecolumn!, deleterow!, deletepartition!, addrow!, closefillmode!, shrink_size!, set_device!, shard_range, dynamicsparse_shard,
+       keyint, keyfrom
 
 const libdsa = get(ENV, "DSA_HIP_LIB", joinpath(@__DIR__, "..", "csrc", "libdsa_hip.so"))
 
@@ -26,6 +38,7 @@ function _check(rc::Int32)
 end
 
 const COMBINE = IdDict{Function,Int32}(+ => Int32(0), * => Int32(1))
+const COMBINE_LAST = Int32(2)
 
 "one process per GPU: select the device before creating handles (dsa_set_device)"
 set_device!(dev::Integer) = _check(ccall((:dsa_set_device, libdsa), Int32, (Int32,), dev))
@@ -42,61 +55,97 @@ function shard_range(n::Integer, nshards::Integer, shard::Integer)
     return c0[], nc[]
 end
 
+# ------------------------------------------------------------------ key mapping  (SURVEY.md §8b)
+"`keyint(k)::Int64`: the key as it crosses the C ABI.  Must preserve the order of `isless` on the key type; 0 is the semaphore key of matrices (src/pcsr.jl:23)."
+keyint(k::Integer) = Int64(k)
+keyint(k::Char) = Int64(codepoint(k))
+"`keyfrom(K, i)`: inverse of `keyint`.  Optional for user types: without it a container translates through the keys it has seen."
+keyfrom(::Type{K}, i::Int64) where {K<:Integer} = K(i)
+keyfrom(::Type{Char}, i::Int64) = Char(i)
+
+struct KeyMap{K}
+    seen::Union{Nothing,Dict{Int64,K}}            # nothing: keyfrom(K, i) exists
+end
+KeyMap{K}() where {K} = KeyMap{K}(hasmethod(keyfrom, Tuple{Type{K},Int64}) ? nothing : Dict{Int64,K}())
+function _in(km::KeyMap{K}, k) where {K}
+    kk = convert(K, k)
+    i = keyint(kk)::Int64
+    km.seen === nothing || (km.seen[i] = kk)
+    return i
+end
+_in(km::KeyMap{K}, ks::AbstractVector) where {K} = Int64[_in(km, k) for k in ks]
+_out(km::KeyMap{K}, i::Int64) where {K} = km.seen === nothing ? keyfrom(K, i) : km.seen[i]
+_out(km::KeyMap{K}, is::Vector{Int64}) where {K} = K[_out(km, i) for i in is]
+
+# duplicates of a key (vector) or of a (partition, key) pair folded left to right in input order with an arbitrary `combine`;
+# returns the order-preserving selection of first occurrences with the folded values (src/vector.jl:10-36)
+function _prefold(keys::Vector{NTuple{N,Int64}}, V::Vector{Float64}, combine::Function) where {N}
+    first_at = Dict{NTuple{N,Int64},Int}()
+    keep = Int[]; vals = Float64[]
+    for k in eachindex(keys)
+        j = get(first_at, keys[k], 0)
+        if j == 0
+            push!(keep, k); push!(vals, V[k]); first_at[keys[k]] = length(keep)
+        else
+            vals[j] = combine(vals[j], V[k])
+        end
+    end
+    return keep, vals
+end
+
 # ------------------------------------------------------------------ vector  (reference src/vector.jl)
-mutable struct DynamicSparseVector <: AbstractSparseVector{Float64,Int64}
+mutable struct DynamicSparseVector{K} <: AbstractSparseVector{Float64,K}
     h::Ptr{Cvoid}
-    function DynamicSparseVector(h::Ptr{Cvoid})
-        v = new(h)
+    keys::KeyMap{K}
+    function DynamicSparseVector{K}(h::Ptr{Cvoid}, km::KeyMap{K} = KeyMap{K}()) where {K}
+        v = new{K}(h, km)
         finalizer(x -> ccall((:dsa_vec_destroy, libdsa), Int32, (Ptr{Cvoid},), x.h), v)
         return v
     end
 end
 
-function dynamicsparsevec(I::Vector{Int64}, V::Vector{Float64}, combine::Function = +, n::Int64 = -1)
+function dynamicsparsevec(I::AbstractVector{K}, V::AbstractVector, combine::Function = +, n::Integer = -1) where {K}
     length(I) == length(V) || throw(ArgumentError("keys & nonzeros vectors must have same length."))
-    if !haskey(COMBINE, combine)       # arbitrary combine: fold duplicates on the Julia side (src/vector.jl:10-36)
-        p = sortperm(I); I = I[p]; V = V[p]
-        keep = Int[]; 
-        for k in eachindex(I)
-            if !isempty(keep) && I[keep[end]] == I[k]
-                V[keep[end]] = combine(V[keep[end]], V[k])
-            else
-                push!(keep, k)
-            end
-        end
-        I = I[keep]; V = V[keep]; op = Int32(2)
-    else
-        op = COMBINE[combine]
+    km = KeyMap{K}()
+    Ii = _in(km, I); Vf = Vector{Float64}(V)
+    op = get(COMBINE, combine, COMBINE_LAST)
+    if !haskey(COMBINE, combine)       # arbitrary combine: fold duplicates here; the library then sees distinct keys
+        keep, Vf = _prefold([(i,) for i in Ii], Vf, combine)
+        Ii = Ii[keep]
     end
     out = Ref{Ptr{Cvoid}}(C_NULL)
-    GC.@preserve I V _check(ccall((:dsa_vec_create, libdsa), Int32,
-        (Ptr{Int64}, Ptr{Float64}, Int64, Int32, Int64, Ref{Ptr{Cvoid}}), I, V, length(I), op, n, out))
-    return DynamicSparseVector(out[])
+    GC.@preserve Ii Vf _check(ccall((:dsa_vec_create, libdsa), Int32,
+        (Ptr{Int64}, Ptr{Float64}, Int64, Int32, Int64, Ref{Ptr{Cvoid}}), Ii, Vf, length(Ii), op, Int64(n), out))
+    return DynamicSparseVector{K}(out[], km)
 end
-dynamicsparsevec(I::Vector{Int64}, V::Vector{Float64}, n::Int64) = dynamicsparsevec(I, V, +, n)
+dynamicsparsevec(I::AbstractVector, V::AbstractVector, n::Integer) = dynamicsparsevec(I, V, +, n)
+function dynamicsparsevec(::Type{K}, ::Type{Float64}) where {K}
+    out = Ref{Ptr{Cvoid}}(C_NULL)
+    _check(ccall((:dsa_vec_create_empty, libdsa), Int32, (Ref{Ptr{Cvoid}},), out))
+    return DynamicSparseVector{K}(out[])
+end
 
-function Base.getindex(v::DynamicSparseVector, key::Integer)
+function Base.getindex(v::DynamicSparseVector, key)
     out = Ref{Float64}(0.0)
-    _check(ccall((:dsa_vec_get, libdsa), Int32, (Ptr{Cvoid}, Int64, Ref{Float64}), v.h, key, out))
+    _check(ccall((:dsa_vec_get, libdsa), Int32, (Ptr{Cvoid}, Int64, Ref{Float64}), v.h, _in(v.keys, key), out))
     return out[]
 end
-function Base.setindex!(v::DynamicSparseVector, value, key::Integer)
-    _check(ccall((:dsa_vec_set, libdsa), Int32, (Ptr{Cvoid}, Int64, Float64), v.h, key, Float64(value)))
+function Base.setindex!(v::DynamicSparseVector, value, key)
+    _check(ccall((:dsa_vec_set, libdsa), Int32, (Ptr{Cvoid}, Int64, Float64), v.h, _in(v.keys, key), Float64(value)))
     return v
 end
-dynamicsparsevec(::Type{Int64}, ::Type{Float64}) = (out = Ref{Ptr{Cvoid}}(C_NULL);
-    _check(ccall((:dsa_vec_create_empty, libdsa), Int32, (Ref{Ptr{Cvoid}},), out)); DynamicSparseVector(out[]))
 "n getindex calls in one ccall"
-function getindex_batch(v::DynamicSparseVector, keys::Vector{Int64})
-    out = Vector{Float64}(undef, length(keys))
-    GC.@preserve keys out _check(ccall((:dsa_vec_get_batch, libdsa), Int32,
-        (Ptr{Cvoid}, Ptr{Int64}, Int64, Ptr{Float64}), v.h, keys, length(keys), out))
+function getindex_batch(v::DynamicSparseVector, keys::AbstractVector)
+    ki = _in(v.keys, keys); out = Vector{Float64}(undef, length(ki))
+    GC.@preserve ki out _check(ccall((:dsa_vec_get_batch, libdsa), Int32,
+        (Ptr{Cvoid}, Ptr{Int64}, Int64, Ptr{Float64}), v.h, ki, length(ki), out))
     return out
 end
 "n sequential setindex! calls in one ccall (sequential-equivalent batch)"
-function setindex_batch!(v::DynamicSparseVector, keys::Vector{Int64}, vals::Vector{Float64})
-    GC.@preserve keys vals _check(ccall((:dsa_vec_set_batch, libdsa), Int32,
-        (Ptr{Cvoid}, Ptr{Int64}, Ptr{Float64}, Int64), v.h, keys, vals, length(keys)))
+function setindex_batch!(v::DynamicSparseVector, keys::AbstractVector, vals::AbstractVector)
+    ki = _in(v.keys, keys); vf = Vector{Float64}(vals)
+    GC.@preserve ki vf _check(ccall((:dsa_vec_set_batch, libdsa), Int32,
+        (Ptr{Cvoid}, Ptr{Int64}, Ptr{Float64}, Int64), v.h, ki, vf, length(ki)))
     return v
 end
 function Base.length(v::DynamicSparseVector)
@@ -107,19 +156,20 @@ function SparseArrays.nnz(v::DynamicSparseVector)
     out = Ref{Int64}(0); _check(ccall((:dsa_vec_nnz, libdsa), Int32, (Ptr{Cvoid}, Ref{Int64}), v.h, out)); out[]
 end
 shrink_size!(v::DynamicSparseVector) = _check(ccall((:dsa_vec_shrink_size, libdsa), Int32, (Ptr{Cvoid},), v.h))
-function _stored(v::DynamicSparseVector)
+function _stored_int(v::DynamicSparseVector)
     n = nnz(v); ks = Vector{Int64}(undef, max(n, 1)); vs = Vector{Float64}(undef, max(n, 1)); m = Ref{Int64}(0)
     GC.@preserve ks vs _check(ccall((:dsa_vec_nonzeros, libdsa), Int32,
         (Ptr{Cvoid}, Ptr{Int64}, Ptr{Float64}, Int64, Ref{Int64}), v.h, ks, vs, length(ks), m))
     return resize!(ks, m[]), resize!(vs, m[])
 end
+_stored(v::DynamicSparseVector) = ((ks, vs) = _stored_int(v); (_out(v.keys, ks), vs))
 SparseArrays.nonzeroinds(v::DynamicSparseVector) = _stored(v)[1]
 SparseArrays.nonzeros(v::DynamicSparseVector) = _stored(v)[2]
 Base.iterate(v::DynamicSparseVector, st = (zip(_stored(v)...), nothing)) =
     (r = st[2] === nothing ? iterate(st[1]) : iterate(st[1], st[2]); r === nothing ? nothing : (r[1], (st[1], r[2])))
 
 # v1 == v2  (src/vector.jl:85-87): compared on the device, only the verdict comes back
-function Base.:(==)(a::DynamicSparseVector, b::DynamicSparseVector)
+function Base.:(==)(a::DynamicSparseVector{K}, b::DynamicSparseVector{K}) where {K}
     out = Ref{Int32}(0)
     _check(ccall((:dsa_vec_equal, libdsa), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ref{Int32}), a.h, b.h, out))
     return out[] == 1
@@ -127,79 +177,112 @@ end
 # v1 + v2, v1 - v2: the SparseVector the AbstractSparseVector fallbacks of the reference produce (test/functional/math.jl:53-94),
 # merged on the device.  Mixed operands (SparseVector with DynamicSparseVector) and -v keep using the stdlib fallbacks over
 # nonzeroinds / nonzeros above.
-function _axpby(a::DynamicSparseVector, alpha::Float64, b::DynamicSparseVector, beta::Float64)
+function _axpby(a::DynamicSparseVector{K}, alpha::Float64, b::DynamicSparseVector{K}, beta::Float64) where {K<:Integer}
     length(a) == length(b) || throw(DimensionMismatch("dimensions must match"))
     cap = max(nnz(a) + nnz(b), 1); ks = Vector{Int64}(undef, cap); vs = Vector{Float64}(undef, cap); m = Ref{Int64}(0)
     GC.@preserve ks vs _check(ccall((:dsa_vec_axpby, libdsa), Int32,
         (Ptr{Cvoid}, Float64, Ptr{Cvoid}, Float64, Ptr{Int64}, Ptr{Float64}, Int64, Ref{Int64}), a.h, alpha, b.h, beta, ks, vs, cap, m))
-    return SparseVector(length(a), resize!(ks, m[]), resize!(vs, m[]))
+    return SparseVector(length(a), K.(resize!(ks, m[])), resize!(vs, m[]))
 end
-Base.:(+)(a::DynamicSparseVector, b::DynamicSparseVector) = _axpby(a, 1.0, b, 1.0)
-Base.:(-)(a::DynamicSparseVector, b::DynamicSparseVector) = _axpby(a, 1.0, b, -1.0)
+Base.:(+)(a::DynamicSparseVector{K}, b::DynamicSparseVector{K}) where {K<:Integer} = _axpby(a, 1.0, b, 1.0)
+Base.:(-)(a::DynamicSparseVector{K}, b::DynamicSparseVector{K}) where {K<:Integer} = _axpby(a, 1.0, b, -1.0)
 # filter(f, v)  (src/vector.jl:83 -> src/pma.jl:224-234): the predicate runs in Julia on the packed entries, the result is a new vector
-function Base.filter(f, v::DynamicSparseVector)
+function Base.filter(f, v::DynamicSparseVector{K}) where {K}
     ks, vs = _stored(v)
     keep = [f((ks[i], vs[i])) for i in eachindex(ks)]
     return dynamicsparsevec(ks[keep], vs[keep])
 end
 
 # ------------------------------------------------------------------ matrix  (reference src/matrix.jl)
-mutable struct DynamicSparseMatrix
+mutable struct DynamicSparseMatrix{K,L}
     h::Ptr{Cvoid}
-    function DynamicSparseMatrix(h::Ptr{Cvoid})
-        m = new(h)
+    rows::KeyMap{K}
+    cols::KeyMap{L}
+    function DynamicSparseMatrix{K,L}(h::Ptr{Cvoid}, rk::KeyMap{K} = KeyMap{K}(), ck::KeyMap{L} = KeyMap{L}()) where {K,L}
+        m = new{K,L}(h, rk, ck)
         finalizer(x -> ccall((:dsa_mat_destroy, libdsa), Int32, (Ptr{Cvoid},), x.h), m)
         return m
     end
 end
 
-function dynamicsparse(I::Vector{Int64}, J::Vector{Int64}, V::Vector{Float64}, m::Int64 = -1, n::Int64 = -1)
+# dynamicsparse(I, J, V[, m, n][, combine])  src/matrix.jl:15-19 -> dynamicsparsecolmajor(J, I, V, combine) src/pcsr.jl:433-445:
+# the library folds duplicates of (i, j) with +; any other combine is folded here first
+function dynamicsparse(I::AbstractVector{K}, J::AbstractVector{L}, V::AbstractVector, m = -1, n = -1, combine::Function = +) where {K,L}
     length(I) == length(J) == length(V) ||
         throw(ArgumentError("rows, columns, and nonzeros do not have same length."))
+    rk = KeyMap{K}(); ck = KeyMap{L}()
+    Ii = _in(rk, I); Ji = _in(ck, J); Vf = Vector{Float64}(V)
+    if combine !== +
+        keep, Vf = _prefold([(Ji[k], Ii[k]) for k in eachindex(Ii)], Vf, combine)
+        Ii = Ii[keep]; Ji = Ji[keep]
+    end
+    mi = m isa Integer && m < 0 ? Int64(-1) : _in(rk, m); ni = n isa Integer && n < 0 ? Int64(-1) : _in(ck, n)
     out = Ref{Ptr{Cvoid}}(C_NULL)
-    GC.@preserve I J V _check(ccall((:dsa_mat_create_from_coo, libdsa), Int32,
-        (Ptr{Int64}, Ptr{Int64}, Ptr{Float64}, Int64, Int64, Int64, Ref{Ptr{Cvoid}}), I, J, V, length(I), m, n, out))
-    return DynamicSparseMatrix(out[])
+    GC.@preserve Ii Ji Vf _check(ccall((:dsa_mat_create_from_coo, libdsa), Int32,
+        (Ptr{Int64}, Ptr{Int64}, Ptr{Float64}, Int64, Int64, Int64, Ref{Ptr{Cvoid}}), Ii, Ji, Vf, length(Ii), mi, ni, out))
+    return DynamicSparseMatrix{K,L}(out[], rk, ck)
 end
-function dynamicsparse(::Type{Int64}, ::Type{Int64}, ::Type{Float64}; fill_mode = true)
+dynamicsparse(I::AbstractVector, J::AbstractVector, V::AbstractVector, combine::Function) = dynamicsparse(I, J, V, -1, -1, combine)
+function dynamicsparse(::Type{K}, ::Type{L}, ::Type{Float64}; fill_mode = true) where {K,L}
     out = Ref{Ptr{Cvoid}}(C_NULL)
     _check(ccall((:dsa_mat_create_empty, libdsa), Int32, (Int32, Ref{Ptr{Cvoid}}), fill_mode ? 1 : 0, out))
-    return DynamicSparseMatrix(out[])
+    return DynamicSparseMatrix{K,L}(out[])
 end
 
-function Base.setindex!(a::DynamicSparseMatrix, val, row::Int64, col::Int64)
-    _check(ccall((:dsa_mat_set, libdsa), Int32, (Ptr{Cvoid}, Float64, Int64, Int64), a.h, Float64(val), row, col))
+function Base.setindex!(a::DynamicSparseMatrix, val, row, col)
+    _check(ccall((:dsa_mat_set, libdsa), Int32, (Ptr{Cvoid}, Float64, Int64, Int64), a.h, Float64(val), _in(a.rows, row), _in(a.cols, col)))
     return a
 end
-function setindex_batch!(a::DynamicSparseMatrix, I::Vector{Int64}, J::Vector{Int64}, V::Vector{Float64})
-    GC.@preserve I J V _check(ccall((:dsa_mat_set_batch, libdsa), Int32,
-        (Ptr{Cvoid}, Ptr{Int64}, Ptr{Int64}, Ptr{Float64}, Int64), a.h, I, J, V, length(I)))
+function setindex_batch!(a::DynamicSparseMatrix, I::AbstractVector, J::AbstractVector, V::AbstractVector)
+    Ii = _in(a.rows, I); Ji = _in(a.cols, J); Vf = Vector{Float64}(V)
+    GC.@preserve Ii Ji Vf _check(ccall((:dsa_mat_set_batch, libdsa), Int32,
+        (Ptr{Cvoid}, Ptr{Int64}, Ptr{Int64}, Ptr{Float64}, Int64), a.h, Ii, Ji, Vf, length(Ii)))
     return a
 end
-function Base.getindex(a::DynamicSparseMatrix, row::Int64, col::Int64)
+function Base.getindex(a::DynamicSparseMatrix, row, col)
     out = Ref{Float64}(0.0)
-    _check(ccall((:dsa_mat_get, libdsa), Int32, (Ptr{Cvoid}, Int64, Int64, Ref{Float64}), a.h, row, col, out))
+    _check(ccall((:dsa_mat_get, libdsa), Int32, (Ptr{Cvoid}, Int64, Int64, Ref{Float64}), a.h, _in(a.rows, row), _in(a.cols, col), out))
     return out[]
 end
-function addrow!(a::DynamicSparseMatrix, row::Int64, colids::Vector{Int64}, vals::Vector{Float64})
-    GC.@preserve colids vals _check(ccall((:dsa_mat_addrow, libdsa), Int32,
-        (Ptr{Cvoid}, Int64, Ptr{Int64}, Ptr{Float64}, Int64), a.h, row, colids, vals, length(colids)))
+function addrow!(a::DynamicSparseMatrix, row, colids::AbstractVector, vals::AbstractVector)
+    ci = _in(a.cols, colids); vf = Vector{Float64}(vals)
+    GC.@preserve ci vf _check(ccall((:dsa_mat_addrow, libdsa), Int32,
+        (Ptr{Cvoid}, Int64, Ptr{Int64}, Ptr{Float64}, Int64), a.h, _in(a.rows, row), ci, vf, length(ci)))
     return true
 end
 closefillmode!(a::DynamicSparseMatrix) = (_check(ccall((:dsa_mat_closefillmode, libdsa), Int32, (Ptr{Cvoid},), a.h)); true)
-deletecolumn!(a::DynamicSparseMatrix, col::Int64) = (_check(ccall((:dsa_mat_deletecolumn, libdsa), Int32, (Ptr{Cvoid}, Int64), a.h, col)); true)
-deleterow!(a::DynamicSparseMatrix, row::Int64) = (_check(ccall((:dsa_mat_deleterow, libdsa), Int32, (Ptr{Cvoid}, Int64), a.h, row)); true)
+deletecolumn!(a::DynamicSparseMatrix, col) = (_check(ccall((:dsa_mat_deletecolumn, libdsa), Int32, (Ptr{Cvoid}, Int64), a.h, _in(a.cols, col))); true)
+deleterow!(a::DynamicSparseMatrix, row) = (_check(ccall((:dsa_mat_deleterow, libdsa), Int32, (Ptr{Cvoid}, Int64), a.h, _in(a.rows, row))); true)
 function SparseArrays.nnz(a::DynamicSparseMatrix)
     out = Ref{Int64}(0); _check(ccall((:dsa_mat_nnz, libdsa), Int32, (Ptr{Cvoid}, Ref{Int64}), a.h, out)); out[]
 end
+# size(A) is the running maximum of the keys written with a non-zero value, as keys (src/matrix.jl:44-47; `size == (5, 'e')`
+# at test/functional/sparsematrix.jl:302-336)
 function Base.size(a::DynamicSparseMatrix)
+    m = Ref{Int64}(0); n = Ref{Int64}(0)
+    _check(ccall((:dsa_mat_size, libdsa), Int32, (Ptr{Cvoid}, Ref{Int64}, Ref{Int64}), a.h, m, n))
+    return (_out(a.rows, m[]), _out(a.cols, n[]))
+end
+Base.size(a::DynamicSparseMatrix, i) = size(a)[i]
+function _size_int(a::DynamicSparseMatrix)
     m = Ref{Int64}(0); n = Ref{Int64}(0)
     _check(ccall((:dsa_mat_size, libdsa), Int32, (Ptr{Cvoid}, Ref{Int64}, Ref{Int64}), a.h, m, n)); (m[], n[])
 end
-Base.size(a::DynamicSparseMatrix, i) = size(a)[i]
 function nbpartitions(a::DynamicSparseMatrix, orientation::Integer)     # 0 = colmajor, 1 = rowmajor
     out = Ref{Int64}(0); _check(ccall((:dsa_mat_nbpartitions, libdsa), Int32, (Ptr{Cvoid}, Int32, Ref{Int64}), a.h, orientation, out)); out[]
 end
+
+# per-column iteration: DynamicMatrixColView (src/views.jl:3-36).  The reference's view is a lazy cursor over the slot array;
+# here the occupied cells of the column's slot range are packed on the device in slot order (K-pack, one launch) and the
+# view iterates over that snapshot: `for (row, val) in @view A[:, j]`.
+struct DynamicMatrixColView{K,L}
+    col_key::L
+    rows::Vector{K}
+    vals::Vector{Float64}
+end
+Base.iterate(dv::DynamicMatrixColView, i::Int = 1) = i > length(dv.rows) ? nothing : ((dv.rows[i], dv.vals[i]), i + 1)
+Base.length(dv::DynamicMatrixColView) = length(dv.rows)
+Base.eltype(::Type{DynamicMatrixColView{K,L}}) where {K,L} = Tuple{K,Float64}
 
 # ccall needs a literal (symbol, library) pair: the four entry points are stamped out with @eval
 for (fname, sym) in ((:_col_view, :dsa_mat_col_view), (:_row_view, :dsa_mat_row_view))
@@ -211,27 +294,33 @@ for (fname, sym) in ((:_col_view, :dsa_mat_col_view), (:_row_view, :dsa_mat_row_
                 (Ptr{Cvoid}, Int64, Ptr{Int64}, Ptr{Float64}, Int64, Ref{Int64}), a.h, key, ks, vs, cap, n)
             rc == 8 && (cap *= 8; continue)          # DSA_ECAP
             _check(rc)
-            return collect(zip(resize!(ks, n[]), resize!(vs, n[])))
+            return resize!(ks, n[]), resize!(vs, n[])
         end
     end
 end
-Base.view(a::DynamicSparseMatrix, ::Colon, col::Int64) = _col_view(a, col)   # src/matrix.jl:83-88
-Base.view(a::DynamicSparseMatrix, row::Int64, ::Colon) = _row_view(a, row)   # src/matrix.jl:70-81
+function Base.view(a::DynamicSparseMatrix{K,L}, ::Colon, col) where {K,L}                     # src/matrix.jl:83-88
+    ks, vs = _col_view(a, _in(a.cols, col))
+    return DynamicMatrixColView{K,L}(convert(L, col), _out(a.rows, ks), vs)
+end
+function Base.view(a::DynamicSparseMatrix{K,L}, row, ::Colon) where {K,L}                     # src/matrix.jl:70-81 (fill mode: buffer row)
+    ks, vs = _row_view(a, _in(a.rows, row))
+    return collect(zip(_out(a.cols, ks), vs))
+end
 
 for (fname, sym) in ((:_col_slice, :dsa_mat_col_slice), (:_row_slice, :dsa_mat_row_slice))
     @eval function $fname(a::DynamicSparseMatrix, key::Int64)
         out = Ref{Ptr{Cvoid}}(C_NULL)
         _check(ccall(($(QuoteNode(sym)), libdsa), Int32, (Ptr{Cvoid}, Int64, Ref{Ptr{Cvoid}}), a.h, key, out))
-        return DynamicSparseVector(out[])
+        return out[]
     end
 end
-Base.getindex(a::DynamicSparseMatrix, ::Colon, col::Int64) = _col_slice(a, col)
-Base.getindex(a::DynamicSparseMatrix, row::Int64, ::Colon) = _row_slice(a, row)
+Base.getindex(a::DynamicSparseMatrix{K,L}, ::Colon, col) where {K,L} = DynamicSparseVector{K}(_col_slice(a, _in(a.cols, col)), a.rows)
+Base.getindex(a::DynamicSparseMatrix{K,L}, row, ::Colon) where {K,L} = DynamicSparseVector{L}(_row_slice(a, _in(a.rows, row)), a.cols)
 "n getindex calls in one ccall"
-function getindex_batch(a::DynamicSparseMatrix, I::Vector{Int64}, J::Vector{Int64})
-    out = Vector{Float64}(undef, length(I))
-    GC.@preserve I J out _check(ccall((:dsa_mat_get_batch, libdsa), Int32,
-        (Ptr{Cvoid}, Ptr{Int64}, Ptr{Int64}, Int64, Ptr{Float64}), a.h, I, J, length(I), out))
+function getindex_batch(a::DynamicSparseMatrix, I::AbstractVector, J::AbstractVector)
+    Ii = _in(a.rows, I); Ji = _in(a.cols, J); out = Vector{Float64}(undef, length(Ii))
+    GC.@preserve Ii Ji out _check(ccall((:dsa_mat_get_batch, libdsa), Int32,
+        (Ptr{Cvoid}, Ptr{Int64}, Ptr{Int64}, Int64, Ptr{Float64}), a.h, Ii, Ji, length(Ii), out))
     return out
 end
 
@@ -240,44 +329,55 @@ function dynamicsparse_shard(I::Vector{Int64}, J::Vector{Int64}, V::Vector{Float
     out = Ref{Ptr{Cvoid}}(C_NULL)
     GC.@preserve I J V _check(ccall((:dsa_shard_create_from_coo, libdsa), Int32,
         (Ptr{Int64}, Ptr{Int64}, Ptr{Float64}, Int64, Int64, Int64, Int32, Int32, Ref{Ptr{Cvoid}}), I, J, V, length(I), m, n, nshards, shard, out))
-    return DynamicSparseMatrix(out[])
+    return DynamicSparseMatrix{Int64,Int64}(out[])
 end
 
 # ------------------------------------------------------------------ PackedCSC  (reference src/pcsr.jl:4-339)
-mutable struct PackedCSC
+mutable struct PackedCSC{K}
     h::Ptr{Cvoid}
-    function PackedCSC(h::Ptr{Cvoid})
-        p = new(h)
+    keys::KeyMap{K}
+    function PackedCSC{K}(h::Ptr{Cvoid}, km::KeyMap{K} = KeyMap{K}()) where {K}
+        p = new{K}(h, km)
         finalizer(x -> ccall((:dsa_pcsc_destroy, libdsa), Int32, (Ptr{Cvoid},), x.h), p)
         return p
     end
 end
 "PackedCSC(row_keys, values, combine): one vector of keys / values per partition (src/pcsr.jl:26-63)"
-function PackedCSC(row_keys::Vector{Vector{Int64}}, values::Vector{Vector{Float64}}, combine::Function = +)
+function PackedCSC(row_keys::Vector{Vector{K}}, values::Vector{<:AbstractVector}, combine::Function = +) where {K}
     length(row_keys) == length(values) || throw(ArgumentError("Must have same number of partitions."))
+    km = KeyMap{K}()
     colptr = Int64[0]; keys = Int64[]; vals = Float64[]          # CSC-style offsets (0-based, nparts + 1 entries)
     for (p, (ks, vs)) in enumerate(zip(row_keys, values))
         length(ks) == length(vs) || throw(ArgumentError("Partition $p: keys & values must have same length."))
-        append!(keys, ks); append!(vals, vs); push!(colptr, length(keys))
+        ki = _in(km, ks); vf = Vector{Float64}(vs)
+        if !haskey(COMBINE, combine)      # arbitrary combine: folded per partition here, the library then sees distinct keys
+            keep, vf = _prefold([(i,) for i in ki], vf, combine)
+            ki = ki[keep]
+        end
+        append!(keys, ki); append!(vals, vf); push!(colptr, length(keys))
     end
     out = Ref{Ptr{Cvoid}}(C_NULL)
     GC.@preserve colptr keys vals _check(ccall((:dsa_pcsc_create, libdsa), Int32,
         (Ptr{Int64}, Int64, Ptr{Int64}, Ptr{Float64}, Int32, Ref{Ptr{Cvoid}}),
-        colptr, length(row_keys), keys, vals, get(COMBINE, combine, Int32(0)), out))
-    return PackedCSC(out[])
+        colptr, length(row_keys), keys, vals, get(COMBINE, combine, COMBINE_LAST), out))
+    return PackedCSC{K}(out[], km)
 end
-PackedCSC() = (out = Ref{Ptr{Cvoid}}(C_NULL); _check(ccall((:dsa_pcsc_create_empty, libdsa), Int32, (Ref{Ptr{Cvoid}},), out)); PackedCSC(out[]))
-function Base.getindex(p::PackedCSC, key::Int64, partition::Int64)          # src/pcsr.jl:228-232
+function PackedCSC(::Type{K}, ::Type{Float64}) where {K}                    # src/pcsr.jl:65-68
+    out = Ref{Ptr{Cvoid}}(C_NULL)
+    _check(ccall((:dsa_pcsc_create_empty, libdsa), Int32, (Ref{Ptr{Cvoid}},), out))
+    return PackedCSC{K}(out[])
+end
+function Base.getindex(p::PackedCSC, key, partition::Integer)              # src/pcsr.jl:228-232
     out = Ref{Float64}(0.0)
-    _check(ccall((:dsa_pcsc_get, libdsa), Int32, (Ptr{Cvoid}, Int64, Int64, Ref{Float64}), p.h, key, partition, out))
+    _check(ccall((:dsa_pcsc_get, libdsa), Int32, (Ptr{Cvoid}, Int64, Int64, Ref{Float64}), p.h, _in(p.keys, key), Int64(partition), out))
     return out[]
 end
-function Base.setindex!(p::PackedCSC, value, key::Int64, partition::Int64)  # src/pcsr.jl:294-310
-    _check(ccall((:dsa_pcsc_set, libdsa), Int32, (Ptr{Cvoid}, Float64, Int64, Int64), p.h, Float64(value), key, partition))
+function Base.setindex!(p::PackedCSC, value, key, partition::Integer)      # src/pcsr.jl:294-310
+    _check(ccall((:dsa_pcsc_set, libdsa), Int32, (Ptr{Cvoid}, Float64, Int64, Int64), p.h, Float64(value), _in(p.keys, key), Int64(partition)))
     return p
 end
-deletepartition!(p::PackedCSC, partition::Int64) =                           # src/pcsr.jl:188-204
-    (_check(ccall((:dsa_pcsc_deletepartition, libdsa), Int32, (Ptr{Cvoid}, Int64), p.h, partition)); nothing)
+deletepartition!(p::PackedCSC, partition::Integer) =                          # src/pcsr.jl:188-204
+    (_check(ccall((:dsa_pcsc_deletepartition, libdsa), Int32, (Ptr{Cvoid}, Int64), p.h, Int64(partition))); nothing)
 function SparseArrays.nnz(p::PackedCSC)
     out = Ref{Int64}(0); _check(ccall((:dsa_pcsc_nnz, libdsa), Int32, (Ptr{Cvoid}, Ref{Int64}), p.h, out)); out[]
 end
@@ -290,7 +390,9 @@ struct Transposed{T}; array::T; end
 Base.transpose(a::DynamicSparseMatrix) = Transposed(a)
 Base.size(t::Transposed) = reverse(size(t.array))
 
-function _spmv_sparse(a::DynamicSparseMatrix, tr::Bool, xi::Vector{Int64}, xv::Vector{Float64}, n::Int64)
+# y = A x for a sparse x given by its stored entries: the touched rows in ascending order (_mul_output, src/operations.jl:11-12);
+# Integer output keys -> sparsevec, any other key type -> Dict (the reference returns its accumulator Dict there)
+function _spmv_sparse(a::DynamicSparseMatrix, tr::Bool, xi::Vector{Int64}, xv::Vector{Float64}, out_keys::KeyMap{KO}, n::Int64) where {KO}
     cap = 1024
     while true
         yi = Vector{Int64}(undef, cap); yv = Vector{Float64}(undef, cap); k = Ref{Int64}(0)
@@ -299,20 +401,20 @@ function _spmv_sparse(a::DynamicSparseMatrix, tr::Bool, xi::Vector{Int64}, xv::V
             a.h, tr ? 1 : 0, xi, xv, length(xi), yi, yv, cap, k)
         rc == 8 && (cap *= 16; continue)
         _check(rc)
-        return sparsevec(resize!(yi, k[]), resize!(yv, k[]), n)       # _mul_output  src/operations.jl:11-12
+        resize!(yi, k[]); resize!(yv, k[])
+        return KO <: Integer ? sparsevec(KO.(yi), yv, n) : Dict{KO,Float64}(_out(out_keys, yi[j]) => yv[j] for j in eachindex(yi))
     end
 end
-Base.:(*)(a::DynamicSparseMatrix, v::DynamicSparseVector) = _spmv_sparse(a, false, _stored(v)..., size(a, 1))
-Base.:(*)(a::DynamicSparseMatrix, v::SparseVector{Float64,Int64}) = _spmv_sparse(a, false, rowvals(v), nonzeros(v), size(a, 1))
-Base.:(*)(t::Transposed{DynamicSparseMatrix}, v::DynamicSparseVector) = _spmv_sparse(t.array, true, _stored(v)..., size(t.array, 2))
-Base.:(*)(t::Transposed{DynamicSparseMatrix}, v::SparseVector{Float64,Int64}) = _spmv_sparse(t.array, true, rowvals(v), nonzeros(v), size(t.array, 2))
-Base.:(*)(v::DynamicSparseVector, t::Transposed{DynamicSparseMatrix}) = t.array * v
-Base.:(*)(v::SparseVector{Float64,Int64}, t::Transposed{DynamicSparseMatrix}) = t.array * v
-Base.:(*)(v::DynamicSparseVector, a::DynamicSparseMatrix) = transpose(a) * v
-Base.:(*)(v::SparseVector{Float64,Int64}, a::DynamicSparseMatrix) = transpose(a) * v
-"dense x, dense y — the column-generation pricing product on device-resident data"
+_entries(km::KeyMap, v::DynamicSparseVector) = _stored_int(v)
+_entries(km::KeyMap, v::SparseVector) = (_in(km, rowvals(v)), Vector{Float64}(nonzeros(v)))
+const SpVec = Union{DynamicSparseVector,SparseVector}
+Base.:(*)(a::DynamicSparseMatrix, v::SpVec) = _spmv_sparse(a, false, _entries(a.cols, v)..., a.rows, _size_int(a)[1])          # src/operations.jl:14-24
+Base.:(*)(t::Transposed{<:DynamicSparseMatrix}, v::SpVec) = _spmv_sparse(t.array, true, _entries(t.array.rows, v)..., t.array.cols, _size_int(t.array)[2])   # :26-36
+Base.:(*)(v::SpVec, t::Transposed{<:DynamicSparseMatrix}) = t.array * v                                                            # :38-48
+Base.:(*)(v::SpVec, a::DynamicSparseMatrix) = transpose(a) * v                                                                     # :50-60
+"dense x, dense y — the column-generation pricing product on device-resident data (Integer keys 1..n)"
 function Base.:(*)(a::DynamicSparseMatrix, x::Vector{Float64})
-    y = Vector{Float64}(undef, size(a, 1))
+    y = Vector{Float64}(undef, _size_int(a)[1])
     GC.@preserve x y _check(ccall((:dsa_mat_spmv_dense, libdsa), Int32,
         (Ptr{Cvoid}, Int32, Ptr{Float64}, Int64, Ptr{Float64}, Int64), a.h, 0, x, length(x), y, length(y)))
     return y

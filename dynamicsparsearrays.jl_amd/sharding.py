@@ -3,13 +3,30 @@
 Rank g owns the contiguous column-key range (g*n/G, (g+1)*n/G] as an INDEPENDENT reference-layout
 PCSR of its sub-matrix (own capacity / height / semaphores / col_keys, both orientations restricted to
 those columns) plus the matching slice of x.  `y_g = A[:, range_g] * x[range_g]`; the only data-path
-collective is one all-reduce (sum) of y — RCCL over xGMI on the GPUs (`backend="nccl"`), gloo in the
-CPU tests.  One process per GPU; nothing else crosses ranks (writes go to the owner shard, rebalances
-are local).  The reference has no counterpart: it is single-process.
+collective is the sum of the partial y over the ranks — RCCL over xGMI on the GPUs (`backend="nccl"`),
+gloo in the CPU tests.  One process per GPU; nothing else crosses ranks (writes go to the owner shard,
+rebalances are local).  The reference has no counterpart: it is single-process.
+
+The class is the SAME code on both backends: x and y are torch tensors on the shard's device — CUDA
+tensors next to the HIP library (the partial product is written straight into y's HBM through
+`dsa_shard_spmv_dev`, on torch's current stream, nothing bounces through the host), CPU tensors next
+to the CPU oracle in the gloo tests — and the collectives are issued on those tensors.
+
+Three schedules for the sum of the m-entry partial results (config 4: m = 10^7, an 80 MB message):
+  "all_reduce"   one RCCL all-reduce (ring / tree chosen by RCCL)
+  "rs_ag"        reduce_scatter + all_gather (each rank reduces m/G entries, then the slices are gathered)
+  "direct"       all_to_all of the G slices (every rank sends slice j of its partial y straight to rank j: G-1
+                 point-to-point transfers on G-1 different xGMI links at once), local sum of the G received
+                 slices, all_gather of the reduced slices — the schedule that uses the full mesh instead of a ring
+All three leave the complete y on every rank (what the next column-generation step reads).
 """
 from __future__ import annotations
 
+import ctypes as C
+
 import numpy as np
+
+SCHEDULES = ("all_reduce", "rs_ag", "direct")
 
 
 def column_range(rank: int, world: int, n_total: int):
@@ -29,18 +46,23 @@ def owner_of_column(col: int, world: int, n_total: int) -> int:
 
 class ColumnShard:
     """The local shard of a column-range sharded matrix.  `api` is the dsa_amd module, `binding` the
-    library it runs on (the HIP product by default)."""
+    library it runs on (the HIP product by default), `device` the torch device of x / y (default: the
+    current CUDA device next to the HIP library, the CPU next to the oracle)."""
 
-    def __init__(self, api, I, J_global, V, m, n_total, rank, world, binding=None):
+    def __init__(self, api, I, J_global, V, m, n_total, rank, world, binding=None, device=None, local_columns=False):
+        import torch
         self.api, self.rank, self.world, self.m, self.n_total = api, rank, world, m, n_total
         self.col0, self.ncols = column_range(rank, world, n_total)
-        I = np.asarray(I, dtype=np.int64)
-        J = np.asarray(J_global, dtype=np.int64)
-        V = np.asarray(V, dtype=np.float64)
+        I = np.ascontiguousarray(I, dtype=np.int64)
+        J = np.ascontiguousarray(J_global, dtype=np.int64)
+        V = np.ascontiguousarray(V, dtype=np.float64)
         b = binding if binding is not None else api.product()
-        if b.device_api:
+        self.binding = b
+        if local_columns:
+            # the caller generated only this rank's columns, already as local keys 1..ncols
+            self.A = api.dynamicsparse(I, J, V, m, self.ncols, binding=b)
+        elif b.device_api:
             # the C-ABI shard constructor (include/dsa.h: dsa_shard_create_from_coo) — same split, done inside the library
-            import ctypes as C
             h = C.c_void_p()
             b.call("shard_create_from_coo", I.ctypes.data_as(C.POINTER(C.c_int64)), J.ctypes.data_as(C.POINTER(C.c_int64)),
                    V.ctypes.data_as(C.POINTER(C.c_double)), len(I), m, n_total, world, rank, C.byref(h))
@@ -49,23 +71,82 @@ class ColumnShard:
             mine = (J > self.col0) & (J <= self.col0 + self.ncols)
             # local column keys 1..ncols: the shard is the reference layout of its own sub-matrix
             self.A = api.dynamicsparse(I[mine], J[mine] - self.col0, V[mine], m, self.ncols, binding=b)
+        if b.device_api:
+            self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+            # kernels of this shard are ordered on torch's current stream, like the collectives that consume y
+            b.call("mat_set_stream", self.A.h, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
+        else:
+            self.device = torch.device("cpu")
+        # slices of the "rs_ag" / "direct" schedules: m padded to a multiple of the world size
+        self.chunk = -(-m // world)
+        self._scratch = {}
 
+    # ---- operands ----------------------------------------------------------------------------------------------------
     def x_slice(self, x_global):
-        return np.ascontiguousarray(x_global[self.col0:self.col0 + self.ncols])
-
-    def spmv_partial(self, x_local):
-        """partial y (length m) of this shard, host arrays."""
-        return self.A.mul(np.asarray(x_local, dtype=np.float64), dense_out=self.m)
-
-    def spmv(self, x_local):
-        """y = A x: local SpMV + all-reduce of the partial results (identity when world == 1)."""
+        """this rank's slice of a global x (numpy) as a tensor on the shard's device."""
         import torch
-        import torch.distributed as dist
-        y = torch.from_numpy(np.ascontiguousarray(self.spmv_partial(x_local)))
-        if self.world > 1:
-            dist.all_reduce(y, op=dist.ReduceOp.SUM)
-        return y.numpy()
+        return torch.from_numpy(np.ascontiguousarray(x_global[self.col0:self.col0 + self.ncols], dtype=np.float64)).to(self.device)
 
+    def new_y(self):
+        import torch
+        return torch.zeros(self.m, dtype=torch.float64, device=self.device)
+
+    def _buf(self, name, n):
+        import torch
+        t = self._scratch.get(name)
+        if t is None or t.numel() != n:
+            t = torch.zeros(n, dtype=torch.float64, device=self.device)
+            self._scratch[name] = t
+        return t
+
+    # ---- local product ----------------------------------------------------------------------------------------------
+    def spmv_partial(self, x_local, y=None):
+        """y_partial = A[:, range] * x[range] into the tensor y (length m) on the shard's device."""
+        if y is None:
+            y = self.new_y()
+        if self.binding.device_api:
+            self.binding.call("shard_spmv_dev", self.A.h, C.c_void_p(x_local.data_ptr()), self.ncols, C.c_void_p(y.data_ptr()), self.m)
+        else:
+            import torch
+            y.copy_(torch.from_numpy(self.A.mul(x_local.numpy(), dense_out=self.m)))
+        return y
+
+    # ---- the collective ---------------------------------------------------------------------------------------------
+    def reduce(self, y, schedule="all_reduce", async_op=False):
+        """sum of the partial y over the ranks, in place; every rank ends with the complete y.
+        async_op (all_reduce only): returns the work handle instead of waiting."""
+        if self.world == 1:
+            return None
+        import torch.distributed as dist
+        if schedule == "all_reduce":
+            return dist.all_reduce(y, op=dist.ReduceOp.SUM, async_op=async_op) if async_op else dist.all_reduce(y, op=dist.ReduceOp.SUM)
+        if async_op:
+            raise ValueError("async_op is only offered for the all_reduce schedule")
+        G, ch = self.world, self.chunk
+        pad = self._buf("pad", G * ch)
+        pad[:self.m].copy_(y)
+        if G * ch > self.m:
+            pad[self.m:].zero_()
+        mine = self._buf("mine", ch)
+        if schedule == "rs_ag":
+            dist.reduce_scatter_tensor(mine, pad, op=dist.ReduceOp.SUM)
+        elif schedule == "direct":
+            recv = self._buf("recv", G * ch)
+            dist.all_to_all_single(recv, pad)                 # slice j of every rank's partial y arrives on rank j
+            mine.copy_(recv.view(G, ch).sum(dim=0))
+        else:
+            raise ValueError("schedule must be one of %s" % (SCHEDULES,))
+        dist.all_gather_into_tensor(pad, mine)
+        y.copy_(pad[:self.m])
+        return None
+
+    def spmv(self, x_local, y=None, schedule="all_reduce"):
+        """y = A x: local SpMV + the sum over the ranks (identity when world == 1); returns the tensor y."""
+        y = self.spmv_partial(x_local, y)
+        self.reduce(y, schedule)
+        return y
+
+    # ---- writes -----------------------------------------------------------------------------------------------------
     def set(self, row, col_global, val):
         """A[row, col] = val on the owner shard (other ranks ignore the write)."""
         if self.col0 < col_global <= self.col0 + self.ncols:

@@ -200,6 +200,14 @@ static bool arrays_equal(const Elements& a1, const Elements& a2) {
         ++i; ++j;
     }
 }
+// _arrays_equal on two raw slot arrays (golden vectors of test/unit/comparison.jl:2-10)
+int32_t ora_raw_arrays_equal(const int64_t* k1, const double* v1, const uint8_t* o1, int64_t n1, const int64_t* k2, const double* v2,
+                             const uint8_t* o2, int64_t n2, int32_t* out) {
+    ORA_TRY
+    const Elements a1 = raw_load(k1, v1, o1, n1), a2 = raw_load(k2, v2, o2, n2);
+    *out = arrays_equal(a1, a2) ? 1 : 0;
+    ORA_CATCH
+}
 // v1 == v2  src/vector.jl:85-87 ; pma1 == pma2  src/pma.jl:262-266
 int32_t ora_vec_equal(ora_vec* a, ora_vec* b, int32_t* out) {
     ORA_TRY

@@ -67,6 +67,12 @@ cases["delete"] = dict(
            dict(op="delete", key=2, out=[0, False], expect=[N, [3, 10], N, [8, 10], [9, 10], N, [10, 10]]),
            dict(op="purge", frm=3, to=5, out=[4, 2], expect=[N, [3, 10], N, N, N, N, [10, 10]])])
 
+# ---------------------------------------------------------------- _arrays_equal (src/pma.jl:236-260)
+cases["arrays_equal"] = [
+    dict(ref="test/unit/comparison.jl:2-5", a=[N, [1, 1], N, N, [2, 1], N, [3, 2]], b=[N, [1, 1], [2, 1], [3, 2], N], expect=True),
+    dict(ref="test/unit/comparison.jl:7-10", a=[N, [1, 1], N, N, [2, 1], N, [3, 2]], b=[N, [1, 1], [2, 1], [3, 2], [4, 2]], expect=False),
+]
+
 # ---------------------------------------------------------------- scenarios
 S = []
 
@@ -105,6 +111,11 @@ S.append(dict(name="vec_equality_after_shrink", ref="test/functional/sparsevecto
               b=dict(I=[1, 2, 3, 5, 6, 8, 9, 10, 11], V=[1.0, 1.0, 1.0, 2.0, 1.0, 1.0, 3.0, 2.0, 3.0]),
               steps=[["expect_equal", False], ["b_set", 10, 0], ["b_set", 11, 0], ["shrink_both"],
                      ["expect_equal", True]]))
+
+# filter(f, vec) with f = "key is even"  test/functional/sparsevector.jl:81-86
+S.append(dict(name="vec_filter_even_keys", ref="test/functional/sparsevector.jl:81-86", kind="vector",
+              create=dict(I=[1, 2, 3], V=[2.0, 3.0, 4.0]),
+              steps=[["filter_even_keys_equals", [2], [3.0]]]))
 
 # test/functional/sparsematrix.jl:7-119  PackedCSC
 DENSE1 = [[2, 0, 3], [3, 2, 0], [4, 0, 0], [0, 0, 0], [0, 0, 0], [0, 4, 5], [0, 5, 0], [0, 0, 7]]

@@ -32,6 +32,10 @@ def run_vector(dsa, b, sc):
             assert v.info()["capacity"] == st[1], st
         elif op == "iter":
             assert [list(x) for x in v] == st[1], st
+        elif op == "filter_even_keys_equals":      # filter(e -> e[1] % 2 == 0, v) == dynamicsparsevec(I, V)
+            f = v.filter(lambda e: e[0] % 2 == 0)
+            assert f == dsa.dynamicsparsevec(st[1], st[2], binding=b), st
+            assert [list(x) for x in f] == [[k, float(x)] for k, x in zip(st[1], st[2])], st
         else:
             raise AssertionError(op)
     return v

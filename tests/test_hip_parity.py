@@ -723,6 +723,27 @@ def test_spmv_without_memset_sparse_rows_fall_back(dsa, hip, oracle):
     np.testing.assert_allclose(a.mul(np.ones(400000), transpose=True), b.mul(np.ones(400000), transpose=True), rtol=RTOL, atol=0)
 
 
+def test_column_shard_device_path_single_rank(dsa, hip, oracle):
+    """The class bench.py drives on N GPUs, here with world = 1 on the one GPU of the box: x and y stay CUDA tensors, the
+    partial product goes through dsa_shard_spmv_dev on torch's stream, every schedule is the identity."""
+    import torch
+    from dsa_amd import sharding
+    m, n, per = 5000, 3000, 7
+    rows = 1 + (splitmix_array(23, n * per) % np.uint64(m)).astype(np.int64)
+    cols = np.repeat(np.arange(1, n + 1, dtype=np.int64), per)
+    vals = unit12_array(24, n * per)
+    sh = sharding.ColumnShard(dsa, rows, cols, vals, m, n, 0, 1, binding=hip)
+    assert sh.device.type == "cuda"
+    x = unit12_array(25, n)
+    ref = dsa.dynamicsparse(rows, cols, vals, m, n, binding=oracle).mul(x)
+    xs = sh.x_slice(x)
+    for sched in sharding.SCHEDULES:
+        y = torch.full((m,), float("nan"), dtype=torch.float64, device=sh.device)
+        sh.spmv(xs, y, schedule=sched)
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(y.cpu().numpy(), ref, rtol=RTOL, atol=0)
+
+
 def test_c3_scale_build_and_spmv_properties(dsa, hip):
     """BASELINE config 3 at a quarter of full size on the GPU alone (the oracle needs tens of seconds
     there): size-independent properties — capacity rule, sorted partitions, semaphore table,
@@ -763,6 +784,69 @@ def test_c3_scale_build_and_spmv_properties(dsa, hip):
     import scipy.sparse as sp
     A = sp.csr_matrix((vals, (rows - 1, cols - 1)), shape=(m, n))
     np.testing.assert_allclose(y1, A @ x1, rtol=1e-12, atol=0)
+
+
+def test_c3_full_size_build_spmv_checker_and_rebalance_idempotence(dsa, hip):
+    """BASELINE config 3 at FULL size (1M x 1M, exactly 10M nnz, the matrix bench.py times): bulk build of both orientations,
+    the device-side invariant checker, y = A x and y = A' x against scipy on the same triplets (1e-12), the capacity rule,
+    and the root pack + spread leaving every slot where it was (idempotence of _even_rebalance! on an even layout)."""
+    import scipy.sparse as sp
+    import bench
+    m = n = 1_000_000
+    I, J, V = bench.c3_triplets(m, n, 10, 0, seed_rows=5, seed_vals=6)
+    assert len(I) == 10_000_000
+    a = dsa.dynamicsparse(I, J, V, m, n, binding=hip)
+    A = sp.csr_matrix((V, (I - 1, J - 1)), shape=(m, n))
+    x = bench.unit12(7, n)
+    np.testing.assert_allclose(a.mul(x), A @ x, rtol=1e-12, atol=0)
+    np.testing.assert_allclose(a.mul(x, transpose=True), A.T @ x, rtol=1e-12, atol=0)
+    for o in (dsa.COLMAJOR, dsa.ROWMAJOR):
+        inf = a.info(o)
+        nelem = len(I) + inf["nb_partitions"]
+        assert inf["nb_elements"] == nelem and inf["capacity"] == 1 << int(np.ceil(np.log2(np.ceil(nelem / 0.7)))) == 1 << 24
+        assert not a.check(o)[2:7].any()
+    assert a.info(dsa.COLMAJOR)["nb_partitions"] == n
+    before = a.export_layout(dsa.COLMAJOR)
+    a.rebalance_root(dsa.COLMAJOR)
+    after = a.export_layout(dsa.COLMAJOR)
+    for k in ("occ", "semaphores", "col_keys"):
+        assert np.array_equal(before[k], after[k]), k
+    occ = before["occ"].astype(bool)
+    assert np.array_equal(before["keys"][occ], after["keys"][occ]) and np.array_equal(before["vals"][occ], after["vals"][occ])
+    assert not a.check(dsa.COLMAJOR)[2:7].any()
+    np.testing.assert_allclose(a.mul(x), A @ x, rtol=1e-12, atol=0)
+
+
+def test_c5_full_size_streaming_first_10k_columns_vs_oracle_then_invariants(dsa, hip, oracle):
+    """BASELINE config 5 at FULL size (100 000 rows, 16 rows per column, columns streamed in ascending id, SpMV every 1000
+    columns).  The first 10 000 columns run side by side with the CPU oracle (2-3 s of oracle time): slot layout, tables and
+    y compared after every batch.  The remaining 40 000 columns run on the GPU alone: invariant checker, nnz, and y against
+    scipy on the triples streamed so far (1e-12)."""
+    import scipy.sparse as sp
+    import bench
+    m5, ncols5, per5 = bench.C5_FULL[:3]
+    every = 1000
+    I5, J5, V5 = bench.c5_columns(m5, ncols5, per5)
+    x5 = bench.unit12(13, ncols5)
+    a = dsa.dynamicsparse(fill_mode=False, binding=hip)
+    b = dsa.dynamicsparse(fill_mode=False, binding=oracle)
+    for c0 in range(0, ncols5, every):
+        sl = slice(c0 * per5, (c0 + every) * per5)
+        a.set_batch(I5[sl], J5[sl], V5[sl])
+        nc = c0 + every
+        ya = a.mul(x5[:nc], dense_out=m5)
+        if nc <= 10_000:
+            b.set_batch(I5[sl], J5[sl], V5[sl])
+            if nc % 2000 == 0 or nc <= 2000:
+                assert_mat_equal(a, b)
+            np.testing.assert_allclose(ya, b.mul(x5[:nc], dense_out=m5), rtol=RTOL, atol=0)
+        elif nc % 10_000 == 0:
+            for o in (dsa.COLMAJOR, dsa.ROWMAJOR):
+                assert not a.check(o)[2:7].any(), (nc, o)
+            assert a.nnz() == nc * per5
+            A = sp.csr_matrix((V5[: nc * per5], (I5[: nc * per5] - 1, J5[: nc * per5] - 1)), shape=(m5, nc))
+            np.testing.assert_allclose(ya, A @ x5[:nc], rtol=1e-12, atol=0)
+    assert a.size() == (int(I5.max()), ncols5)
 
 
 # ---------------------------------------------------------------- the reference's functional tests, our RNG, HIP vs oracle
@@ -1116,13 +1200,13 @@ def test_shard_entry_points_split_spmv_exactly(dsa, hip, oracle):
         ref = sharding.ColumnShard(dsa, I, J, V, m, n, g, G, binding=oracle)
         assert_mat_equal(sh.A, ref.A)
         assert sh.A.size() == (m, sh.ncols)
-        dx = torch.from_numpy(sh.x_slice(x)).cuda()
-        dy = torch.empty(m, dtype=torch.float64, device="cuda")
-        hip.call("mat_set_stream", sh.A.h, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        dx = sh.x_slice(x)                                       # CUDA tensor next to the HIP library
+        assert dx.is_cuda and not ref.x_slice(x).is_cuda
+        dy = torch.full((m,), float("nan"), dtype=torch.float64, device="cuda")
         hip.call("shard_spmv_dev", sh.A.h, C.c_void_p(dx.data_ptr()), sh.ncols, C.c_void_p(dy.data_ptr()), m)
         torch.cuda.synchronize()
         part = dy.cpu().numpy()
-        assert np.array_equal(part, sh.spmv_partial(sh.x_slice(x)))
-        np.testing.assert_allclose(part, ref.spmv_partial(ref.x_slice(x)), rtol=RTOL, atol=0)
+        assert np.array_equal(part, sh.spmv_partial(dx).cpu().numpy())
+        np.testing.assert_allclose(part, ref.spmv_partial(ref.x_slice(x)).numpy(), rtol=RTOL, atol=0)
         y += part
     np.testing.assert_allclose(y, y_ref, rtol=RTOL, atol=0)

@@ -111,3 +111,37 @@ def test_julia_wrapper_binds_only_declared_symbols():
     # symbols passed indirectly (the view / slice helpers take the symbol as an argument)
     for name in re.findall(r":(dsa_[a-z0-9_]+)", jl):
         assert name in protos, name
+
+
+# the twelve names the reference exports (reference src/DynamicSparseArrays.jl:5-16)
+REFERENCE_EXPORTS = ["DynamicSparseVector", "DynamicSparseMatrix", "DynamicMatrixColView", "dynamicsparsevec", "dynamicsparse",
+                     "nbpartitions", "deletepartition!", "deletecolumn!", "deleterow!", "addrow!", "closefillmode!", "shrink_size!"]
+
+
+def _exports(src):
+    names = []
+    for m in re.finditer(r"^export\s+((?:[^\n]*,\s*\n)*[^\n]*)", src, flags=re.M):
+        names += [n.strip() for n in m.group(1).replace("\n", " ").split(",") if n.strip()]
+    return names
+
+
+def test_julia_modules_export_the_reference_surface():
+    """Drop-in surface: the wrapper module AND the module offered under the reference's own name export every name the
+    reference exports; the latter exports nothing else.  Every exported name is defined in the wrapper; the key-mapping
+    layer (keyint / keyfrom, generic K and L) and the arbitrary-combine pre-fold are present."""
+    jdir = os.path.join(ROOT, "dynamicsparsearrays.jl_amd", "julia")
+    amd = open(os.path.join(jdir, "DynamicSparseArraysAMD.jl")).read()
+    dropin = open(os.path.join(jdir, "DynamicSparseArrays.jl")).read()
+    assert re.search(r"^module DynamicSparseArrays\s*$", dropin, flags=re.M)
+    assert 'include("DynamicSparseArraysAMD.jl")' in dropin and "using .DynamicSparseArraysAMD" in dropin
+    assert sorted(_exports(dropin)) == sorted(REFERENCE_EXPORTS)
+    amd_exports = _exports(amd)
+    for name in REFERENCE_EXPORTS:
+        assert name in amd_exports, name
+        base = re.escape(name)
+        assert re.search(r"(?:function\s+|struct\s+|^)" + base + r"(?:\{[^}]*\})?\s*[\(\{<\s]", amd, flags=re.M), name
+    for needed in ("keyint(k::Integer)", "keyint(k::Char)", "keyfrom(::Type{Char}", "struct KeyMap{K}", "function _prefold",
+                   "Base.iterate(dv::DynamicMatrixColView", "mutable struct DynamicSparseMatrix{K,L}", "mutable struct DynamicSparseVector{K}"):
+        assert needed in amd, needed
+    # an unsupported combine is never silently mapped to +
+    assert "get(COMBINE, combine, Int32(0))" not in amd

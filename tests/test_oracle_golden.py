@@ -54,6 +54,16 @@ def test_find_vectors(oracle, case):
             assert has.value == 1 and [fk.value, fv.value] == [exp_elem[0], float(exp_elem[1])]
 
 
+@pytest.mark.parametrize("case", CASES["arrays_equal"], ids=lambda c: c["ref"])
+def test_arrays_equal_vectors(oracle, case):
+    (k1, v1, o1), (k2, v2, o2) = to_arrays(case["a"]), to_arrays(case["b"])
+    out = C.c_int32(-1)
+    rc = oracle.lib.ora_raw_arrays_equal(k1.ctypes.data_as(P_I64), v1.ctypes.data_as(P_F64), o1.ctypes.data_as(P_U8), C.c_int64(len(o1)),
+                                         k2.ctypes.data_as(P_I64), v2.ctypes.data_as(P_F64), o2.ctypes.data_as(P_U8), C.c_int64(len(o2)),
+                                         C.byref(out))
+    assert rc == 0 and bool(out.value) is case["expect"]
+
+
 @pytest.mark.parametrize("case", CASES["insert"], ids=lambda c: c["ref"])
 def test_insert_vectors(oracle, case):
     k, v, o = to_arrays(case["array"])

@@ -1,6 +1,7 @@
-"""CPU test of the N > 1 path: world_size-2 gloo, column-range sharding + all-reduce of y.
-The local SpMV runs on the CPU oracle here (there is no GPU in the build container); on the GPU the
-same ColumnShard code runs on the HIP library with RCCL (bench.py)."""
+"""CPU test of the N > 1 path: world_size-2 gloo, column-range sharding + the three schedules of the sum of y
+(all_reduce, reduce_scatter + all_gather, all_to_all + local sum + all_gather).  The local SpMV runs on the
+CPU oracle here (there is no GPU in the build container); on the GPUs the SAME ColumnShard methods run with
+CUDA tensors on the HIP library and RCCL (bench.py drives exactly this class)."""
 import os
 import socket
 import sys
@@ -21,7 +22,7 @@ def _free_port():
 
 def _make_problem():
     rng = np.random.default_rng(7)
-    m, n, nnz = 300, 401, 4000          # odd n: uneven column ranges
+    m, n, nnz = 301, 401, 4000          # odd n: uneven column ranges; odd m: the sliced schedules pad y
     I = rng.integers(1, m + 1, nnz)
     J = rng.integers(1, n + 1, nnz)
     V = rng.integers(1, 10, nnz).astype(np.float64)
@@ -39,12 +40,19 @@ def _worker(rank, world, port, out_dir):
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     m, n, I, J, V, x = _make_problem()
     sh = sharding.ColumnShard(dsa, I, J, V, m, n, rank, world, binding=ora)
-    y = sh.spmv(sh.x_slice(x))
+    xs = sh.x_slice(x)                                   # a tensor on the shard's device (CPU next to the oracle)
+    ys = [sh.spmv(xs, schedule=s).numpy().copy() for s in sharding.SCHEDULES]
+    # the overlapped form bench.py uses: partial product, asynchronous all-reduce, wait
+    yb = sh.new_y()
+    sh.spmv_partial(xs, yb)
+    work = sh.reduce(yb, "all_reduce", async_op=True)
+    work.wait()
+    ys.append(yb.numpy().copy())
     # a write routed to its owner shard, then another product
     sh.set(5, 400, 3.5)
     sh.set(7, 2, 1.25)
-    y2 = sh.spmv(sh.x_slice(x))
-    np.save(os.path.join(out_dir, f"y_{rank}.npy"), np.stack([y, y2]))
+    y2 = sh.spmv(xs).numpy().copy()
+    np.save(os.path.join(out_dir, f"y_{rank}.npy"), np.stack(ys + [y2]))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -62,8 +70,9 @@ def test_column_sharded_spmv_world2(dsa, oracle, tmp_path):
     ref2 = full.mul(x)
     for r in range(world):
         got = np.load(os.path.join(str(tmp_path), f"y_{r}.npy"))
-        np.testing.assert_allclose(got[0], ref, rtol=1e-12, atol=0)
-        np.testing.assert_allclose(got[1], ref2, rtol=1e-12, atol=0)
+        for k in range(len(sharding.SCHEDULES) + 1):      # all_reduce, rs_ag, direct, async all_reduce
+            np.testing.assert_allclose(got[k], ref, rtol=1e-12, atol=0)
+        np.testing.assert_allclose(got[-1], ref2, rtol=1e-12, atol=0)
     # the column ranges tile 1..n exactly
     cover = []
     for r in range(world):

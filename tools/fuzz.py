@@ -1,9 +1,12 @@
 #!/usr/bin/env python3
 """Differential fuzzer (dev tool, GPU box): random write batches on matrices and vectors, HIP library vs the CPU oracle, slot
 layout + tables + values compared after every batch.  Usage: python tools/fuzz.py [seconds] [first_seed]"""
+import faulthandler
 import os
 import sys
 import time
+
+faulthandler.enable(all_threads=True)      # a SIGSEGV / SIGABRT in the native library prints the Python stack of every thread
 
 import numpy as np
 
@@ -162,6 +165,31 @@ def run_vector(seed):
     return "ok"
 
 
+def run_shared_words(seed):
+    """Targeted stress of the batch-parallel rounds (DESIGN §3.2b invariant): many writes of ONE batch land in the same
+    64-slot occupancy words — small arrays, dense key ranges — so that k_apply waves on different XCDs update bits of the
+    same word in the same launch (device-scope atomics) while their slot footprints stay disjoint."""
+    g = SplitMix64(seed)
+    n0 = [300, 2000, 20000][g.next() % 3]
+    stride = 2 + g.next() % 6
+    keys0 = np.arange(1, n0 + 1, dtype=np.int64) * stride
+    a = dsa.dynamicsparsevec(keys0, np.ones(n0), binding=hip)
+    b = dsa.dynamicsparsevec(keys0, np.ones(n0), binding=ora)
+    for step in range(6):
+        nb = [200, 1000, 4000][g.next() % 3]
+        raw = np.array([g.next() for _ in range(nb)], dtype=np.uint64)
+        keys = 1 + (raw % np.uint64(n0 * stride)).astype(np.int64)
+        vals = np.where((raw >> np.uint64(40)) % np.uint64(5) == 0, 0.0, 2.5)      # 20 % deletes
+        a.set_batch(keys, vals); b.set_batch(keys, vals)
+        ka, kb = a.export_layout(), b.export_layout()
+        assert np.array_equal(ka[2], kb[2]), (seed, step, "occ")
+        occ = ka[2].astype(bool)
+        assert np.array_equal(ka[0][occ], kb[0][occ]) and np.array_equal(ka[1][occ], kb[1][occ]), (seed, step, "cells")
+        if hip is not ora:
+            assert not a.check()[2:7].any(), (seed, step, "invariant checker")
+    return "ok"
+
+
 if __name__ == "__main__":
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
@@ -169,7 +197,7 @@ if __name__ == "__main__":
     n = 0
     res = {}
     while time.time() - t0 < budget:
-        r = run_matrix(seed) if seed % 4 else run_vector(seed)
+        r = run_shared_words(seed) if seed % 8 == 5 else (run_matrix(seed) if seed % 4 else run_vector(seed))
         res[r] = res.get(r, 0) + 1
         n += 1
         seed += 1

@@ -2,11 +2,13 @@
 """Launch sequence for the PMC passes (run under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE):
   3 x SpMV gather (C3)            -> k_spmv dispatches 0..2
   3 x SpMV gather with nx = 0     -> k_spmv dispatches 3..5  (streams only: calibrates the 8 B/lane coalesced pattern)
-  3 x root rebalance (colmajor)   -> k_move<false> dispatches (the LAST 3 of the run)
+  3 x root rebalance (colmajor)   -> k_move2<false> dispatches (the LAST 3 of the run)
 The same kernels as bench.py on the same C3 matrix; no timing here."""
 import ctypes as C
 import os
 import sys
+
+os.environ["DSA_SPMV_STREAM"] = "nt"      # the nx = 0 calibration launches must be the SAME kernel instantiation (non-temporal stream loads)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

@@ -1,9 +1,9 @@
 # usage (on the GPU box, from the repo root): bash tools/scripts/profile_round.sh <tag>
 # separate PMC passes (FETCH_SIZE / WRITE_SIZE), rocprofv3 kernel traces of bench.py, then the plain bench line (which quotes the
 # fresh PMC traffic); everything lands in gpurun_out/<tag>_* (+ profiles/<tag>_* written by summarize_prof.py)
-set -e
+set -euo pipefail
 TAG=${1:-r01_final}
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:?set GRAFT_REPO_ROOT (the repo root on the GPU box)}
 mkdir -p $R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --pmc FETCH_SIZE -d $R/gpurun_out/${TAG}_pmc_fetch -o f --output-format csv -- python3 $R/tools/prof_kernels.py > $R/gpurun_out/${TAG}_pmc_fetch.log 2>&1

@@ -1,5 +1,6 @@
+set -euo pipefail
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:?set GRAFT_REPO_ROOT (the repo root on the GPU box)}
 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/kt -o kt --output-format csv -- python3 $R/tools/prof_kernels.py > $R/gpurun_out/kt.log 2>&1
 cd $R && python3 - <<'PY'
 import csv, glob

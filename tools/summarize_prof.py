@@ -47,12 +47,15 @@ if sp:
         "corrected_traffic_total": round(2 * stream + (full - stream) + sum(w[0:3]) / 3 * KB),
         "algorithmic_bytes": 16 * 16777216 + 16 * 1000000,
     }
-mv = [k for k in F if "k_move<false" in k]
+mv = [k for k in F if "k_move2<false" in k] or [k for k in F if "k_move<false" in k]
 if mv:
     f, w = F[mv[0]][-3:], W[mv[0]][-3:]
     res["k_move_root_2^24"] = {"FETCH_SIZE": round(sum(f) / 3 * KB), "WRITE_SIZE": round(sum(w) / 3 * KB),
                                "corrected_fetch": round(2 * sum(f) / 3 * KB),
                                "corrected_traffic_total": round(2 * sum(f) / 3 * KB + sum(w) / 3 * KB),
                                "algorithmic_bytes": 32 * 16777216}
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402  (kernel_source_sha: bench.py quotes this file only while the kernel sources are unchanged)
+res["kernel_source_sha"] = bench.kernel_source_sha()
 json.dump(res, open(os.path.join(out_dir, f"{tag}_pmc_summary.json"), "w"), indent=1)
 print(json.dumps(res, indent=1))
