@@ -498,8 +498,14 @@ bool seq_step(SeqRun& r) {
             break;
         case SEQ_Y_APPEND_RUN: {
             if (getenv("DSA_DBG_RUN") && c.dbg[4])
-                fprintf(stderr, "[previous append run] ops=%lld slow=%lld fast=%.1fus slow=%.1fus shader clock %.0f MHz\n", (long long)c.dbg[4],
-                        (long long)c.dbg[0], c.dbg[2] / 100.0, c.dbg[3] / 100.0, c.dbg[5] ? 100.0 * c.dbg[1] / c.dbg[5] : 0.0);
+                fprintf(stderr, "[previous append run] ops=%lld slow=%lld fast=%.1fus slow=%.1fus shader clock %.0f MHz | model v2: entries %lld ops %lld wide events %lld "
+                        "pattern misses %lld exits [end %lld, word full %lld, word empty %lld, wider level %lld]\n", (long long)c.dbg[4],
+                        (long long)c.dbg[0], c.dbg[2] / 100.0, c.dbg[3] / 100.0, c.dbg[5] ? 100.0 * c.dbg[1] / c.dbg[5] : 0.0,
+                        (long long)c.prof[8], (long long)c.prof[9], (long long)c.prof[10], (long long)c.prof[11], (long long)c.prof[12], (long long)c.prof[13],
+                        (long long)c.prof[14], (long long)c.prof[15]);
+            if (getenv("DSA_DBG_RUN") && c.dbg[4])
+                fprintf(stderr, "    model v2: %lld epoch jumps; %lld wide events computed (not memoised) in %.1f us; whole model %.1f us (shader clock)\n", (long long)c.prof[4],
+                        (long long)c.prof[5], c.prof[6] / 2400.0, c.prof[7] / 2400.0);
             // save the bitmap, replay the run on the live bitmap, move the cells; all stream-ordered, no host wait.  The
             // device control block is authoritative afterwards (next_op, nb_elements, tables, statistics): no upload on relaunch.
             const int64_t words = (c.capacity + 63) / 64;

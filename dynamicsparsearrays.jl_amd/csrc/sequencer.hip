@@ -343,12 +343,228 @@ __device__ __forceinline__ uint64_t rdlane64(uint64_t v, int l) {
 
 // memo of spread! patterns for windows of up to 256 slots: the pattern depends on (W, c) only and an append run keeps
 // hitting the same few (level, count) pairs.  Filled on first use by wave 0.
+// ---- model v2 of the append replay --------------------------------------------------------------------
+// While the tail and the nearest gap stay inside the LAST occupancy word, an append is a handful of scalar bit operations on
+// that word — set the bit behind the tail, or the nearest zero bit left of the last slot (the shift-left of _insert!,
+// src/writes.jl:26-43) — and the density scan of the levels whose window fits the word (src/pma.jl:105-141) is a popcount
+// of an aligned sub-mask per level; their spread! is a memoised bit pattern.  Levels wider than a word are suffixes of
+// the array there: lane <-> level keeps their cell counts (+1 per append), a rebalance of level h with c cells resets the
+// counts below it in closed form and yields the new last word.  The bitmap itself is written by the caller when the model
+// is left: the last rebalance of every wide level that no wider one followed, widest first, then the last word.
+// A separate, never inlined function with an LDS mailbox: every loop-carried value is re-established as wave-uniform
+// (readfirstlane) so the loop compiles to scalar code with its own register allocation — inside the caller the same loop
+// was placed in vector registers under exec masks and ran at 700 ns per op instead of ~100.
+struct Model2IO {
+    uint64_t lw; int64_t idx, end, reb, slots; int32_t need, progressed, nlow, seg;
+    int32_t dbg_mid, dbg_miss, dbg_why, dbg_pad;      // dev counters (DSA_DBG_RUN)
+    int64_t dbg_t[4];
+    uint32_t cnt[64], W[64], Wb[64], lo[64], hi[64], ev_c[64], ev_valid[64];
+    int32_t eb[64], wb[64];
+    uint32_t outside[64];        // level h wider than the block: cells of its suffix IN FRONT of the last block (workgroup pass)
+    int32_t outside_valid;       // ... computed for the current bitmap
+    int32_t pending;             // exit with rebalances wider than the block still to be written (workgroup), then the in-block ones
+};
+__device__ __forceinline__ int u32(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ uint64_t u64(uint64_t v) {
+    return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+}
+struct RunMemo;
+__device__ __noinline__ void wave_model2(Model2IO* io, RunMemo* memo, const uint64_t* flags);
+
 constexpr int MEMO_ENTRIES = 640, MEMO_WORDS = 1664;
 constexpr int EV_WORDS = 512;
+constexpr int M2_EV = 1024;
 struct RunMemo {
     uint64_t words[MEMO_WORDS]; unsigned long long gapw[64];
+    // model v2: memo of the rebalances of wide levels up to 512 slots (entry = level base + cell count): counts of the wide levels
+    // below (16 bits each, bit 63 = valid), the last word after the rebalance, and the epoch that follows it — last word, number of
+    // in-word ops, their rebalances and window slots — up to the next op that needs a wide level
+    struct alignas(16) M2Entry { uint64_t cnt, lw, eplw, epr; } m2e[M2_EV];      // one 32-byte entry: two 16-byte LDS loads, one wait
+    Model2IO m2;             // model v2: mailbox between wave_fast_appends and wave_model2
     uint64_t ev[EV_WORDS];   // count model: outcome of a rebalance of level h <= 4 (W <= 256) with c cells: suffix counts of levels 0..3 (16 bits each), bit 63 = one trailing gap
 };   // gapw: scratch of the cooperative spread
+
+__device__ __noinline__ void wave_model2(Model2IO* io_, RunMemo* memo_, const uint64_t* flags_) {
+    constexpr uint64_t TOP = 1ull << 63;
+    // arguments of a non-kernel function arrive in vector registers and count as divergent: re-establish them as uniform
+    Model2IO* io = (Model2IO*)u64((uint64_t)io_);
+    RunMemo* memo = (RunMemo*)u64((uint64_t)memo_);
+    const uint64_t* flags = (const uint64_t*)u64((uint64_t)flags_);
+    const int lane = lane_id();
+    uint64_t lw = u64(io->lw);
+    int64_t idx = (int64_t)u64((uint64_t)io->idx);
+    const int64_t end = (int64_t)u64((uint64_t)io->end);
+    const int nlow = u32(io->nlow), seg = u32(io->seg);
+    int lo_s[6], hi_s[6], wb_s[6];
+#pragma unroll
+    for (int h = 0; h < 6; ++h) { lo_s[h] = u32((int)io->lo[h]); hi_s[h] = u32((int)io->hi[h]); wb_s[h] = u32(io->wb[h]); }
+    uint32_t cnt = io->cnt[lane];
+    const uint32_t my_W = io->W[lane], my_lo = io->lo[lane], my_hi = io->hi[lane];
+    const bool lvl_mid = my_W != 0;
+    // memo of the wide levels up to 512 slots: lane h holds the first entry of level h (entry = base + cell count)
+    int my_eb = -1;
+    {
+        int eb = 0;
+        for (int h = nlow; h < 64; ++h) {
+            const int Wh = seg << h;
+            if (Wh > 512 || eb + Wh + 1 > M2_EV) break;
+            if (h == lane) my_eb = eb;
+            eb += Wh + 1;
+        }
+    }
+    uint32_t ev_c = 0;
+    bool ev_valid = false;
+    int reb = 0;
+    int64_t slots = 0;
+    int need = 0, progressed = 0, dbg_mid = 0, dbg_miss = 0, dbg_why = 0, dbg_jump = 0, dbg_ncmp = 0;
+    int64_t dbg_tcmp = 0;
+    const int64_t dbg_t0 = clock64();
+    int64_t fw_idx = -1;
+    uint64_t fw = 0;
+    // epoch being recorded: the in-word ops that follow the rebalance of memo entry ep_entry, up to the next op that needs a wide level
+    int ep_entry = -1, ep_reb0 = 0;
+    int64_t ep_idx0 = 0, ep_slots0 = 0;
+    bool wide_next = false;                          // the op at idx is known to need a wide level (an epoch jump ended in front of it)
+    while (idx < end) {
+        // (re-established as wave-uniform every iteration: the loop then stays on the scalar unit)
+        lw = u64(lw); idx = (int64_t)u64((uint64_t)idx); fw = u64(fw); fw_idx = (int64_t)u64((uint64_t)fw_idx);
+        reb = u32(reb); slots = (int64_t)u64((uint64_t)slots);
+        ep_entry = u32(ep_entry); ep_reb0 = u32(ep_reb0); ep_idx0 = (int64_t)u64((uint64_t)ep_idx0); ep_slots0 = (int64_t)u64((uint64_t)ep_slots0);
+        if (!wide_next) {
+            bool is_sem = false;
+            if (flags != nullptr) {
+                if ((idx >> 6) != fw_idx) { fw_idx = idx >> 6; fw = u64(flags[fw_idx]); }
+                is_sem = (fw >> (idx & 63)) & 1ull;
+            }
+            // ---- the insert, on the last word
+            uint64_t nw = lw;
+            int bip;                                   // bit of the insert position
+            if (lw & TOP) {                            // tail on the last slot: the cells behind the nearest gap shift left
+                const uint64_t z = ~lw;
+                if (z == 0) { dbg_why = 1; break; }    // that gap is in an earlier word: general path
+                nw |= 1ull << (63 - __clzll((long long)z));
+                bip = 63;
+            } else if (!is_sem) {                      // behind the tail
+                if (lw == 0) { dbg_why = 2; break; }
+                bip = 64 - __clzll((long long)lw);
+                nw |= 1ull << bip;
+            } else {                                   // a semaphore goes to the last slot (src/pcsr.jl:99-112)
+                const uint64_t z = ~lw & ~TOP;
+                if (z == 0) { dbg_why = 1; break; }
+                const int pe = 63 - __clzll((long long)z);
+                if (pe == 62) nw |= TOP;
+                else nw = (nw | (1ull << pe) | TOP) & ~(1ull << 62);
+                bip = 63;
+            }
+            // ---- _look_for_rebalance!, levels inside the word
+            int h_acc = -1, c_acc = 0, sh_acc = 0, wbh = 0;
+#pragma unroll
+            for (int h = 0; h < 6; ++h) {
+                if (h < nlow && h_acc < 0) {
+                    const int W = seg << h;
+                    const int sh = bip & ~(W - 1);
+                    const uint64_t m = (W == 64 ? ~0ull : ((1ull << W) - 1ull)) << sh;
+                    const int c = popc64(nw & m);
+                    if (lo_s[h] <= c && c <= hi_s[h]) { h_acc = h; c_acc = c; sh_acc = sh; wbh = wb_s[h]; }
+                }
+            }
+            if (h_acc >= 0) {
+                if (h_acc > 0) {                       // _even_rebalance! inside the word: memoised pattern of (W, c)
+                    const int W = seg << h_acc;
+                    uint64_t pat = u64(memo->words[wbh + c_acc]);
+                    if (pat == 0) {
+                        ++dbg_miss;
+                        SpreadGeom g;
+                        g.W = W; g.E = W - c_acc;
+                        g.f = (double)W / (double)(W - c_acc);
+                        g.inv_f = (double)(W - c_acc) / (double)W;
+                        int rank;
+                        const bool cell = lane < W && !slot_is_gap(g, lane + 1, &rank);
+                        pat = __ballot(cell);
+                        if (lane == 0) memo->words[wbh + c_acc] = pat;
+                    }
+                    const uint64_t m = (W == 64 ? ~0ull : ((1ull << W) - 1ull)) << sh_acc;
+                    nw = (nw & ~m) | (pat << sh_acc);
+                    reb += 1; slots += W;
+                }
+                lw = nw;
+                cnt += cnt < my_W ? 1u : 0u;
+                ++idx; progressed = 1;
+                continue;
+            }
+        }
+        wide_next = false;
+        // ---- the op needs a level wider than a word.  The epoch since the last memoised rebalance ends in front of it: record it
+        if (ep_entry >= 0) {
+            const int64_t n = idx - ep_idx0;
+            if (n < 65535 && reb - ep_reb0 < 65535 && slots - ep_slots0 < (1ll << 31) && lane == 0) {
+                memo->m2e[ep_entry].eplw = lw;
+                memo->m2e[ep_entry].epr = ((uint64_t)(uint32_t)(slots - ep_slots0) << 32) | ((uint64_t)(uint32_t)(reb - ep_reb0) << 16) | (uint64_t)(n + 1);
+            }
+            ep_entry = -1;
+        }
+        const uint32_t cnt2 = cnt + (cnt < my_W ? 1u : 0u);
+        const uint64_t acc = __ballot(lvl_mid && my_lo <= cnt2 && cnt2 <= my_hi);
+        if (acc == 0) { need = 1; dbg_why = 3; break; }         // a window wider than the block (or _extend!) decides
+        cnt = cnt2;
+        ++idx; progressed = 1; ++dbg_mid;
+        const int h = __ffsll((unsigned long long)acc) - 1;
+        const int W = seg << h;
+        const int c = (int)rdlane(cnt, h);
+        reb += 1; slots += W;
+        if (lane == h) { ev_c = (uint32_t)c; ev_valid = true; }
+        else if (lane < h) ev_valid = false;
+        const int eb = (int)rdlane((uint32_t)my_eb, h);
+        const int entry = eb >= 0 ? eb + c : -1;
+        uint64_t e = 0, en_lw = 0, en_eplw = 0, en_epr = 0;
+        if (entry >= 0) {
+            const RunMemo::M2Entry en = memo->m2e[entry];
+            e = u64(en.cnt); en_lw = u64(en.lw); en_eplw = u64(en.eplw); en_epr = u64(en.epr);
+        }
+        if (e == 0) {
+            en_epr = 0;
+            const int64_t tc0 = clock64();
+            ++dbg_ncmp;
+            SpreadGeom g;
+            g.W = W; g.E = W - c;
+            g.f = (double)W / (double)(W - c);
+            g.inv_f = (double)(W - c) / (double)W;
+            uint32_t below = 0;
+            if (lane < h && lvl_mid) below = my_W - (uint32_t)((W - c) - gaps_le(g, W - (int)my_W));
+            int rank;
+            const bool cell = !slot_is_gap(g, W - 63 + lane, &rank);
+            lw = __ballot(cell);
+            if (lane < h && lvl_mid) cnt = below;
+            if (entry >= 0) {          // counts of the (at most three) wide levels below h, 16 bits each
+                e = (uint64_t)rdlane(below, nlow) | ((uint64_t)rdlane(below, nlow + 1) << 16) | ((uint64_t)rdlane(below, nlow + 2) << 32) | (1ull << 63);
+                if (lane == 0) { memo->m2e[entry].cnt = e; memo->m2e[entry].lw = lw; memo->m2e[entry].epr = 0ull; }
+            }
+            dbg_tcmp += clock64() - tc0;
+        } else {
+            const int k = lane - nlow;
+            if (lane < h && lvl_mid) cnt = (uint32_t)(e >> (16 * (k & 3))) & 0xffffu;
+            lw = en_lw;
+        }
+        if (entry >= 0 && flags == nullptr) {
+            // the in-word ops that follow are a function of the new last word alone: replay them from the memo (vector runs)
+            const uint64_t r = en_epr;
+            const int64_t n = (int64_t)(r & 0xffffu) - 1;
+            if (n >= 0 && idx + n < end) {
+                lw = en_eplw;
+                idx += n;
+                const uint32_t room = my_W - cnt;                  // cnt <= my_W
+                cnt += (uint32_t)n < room ? (uint32_t)n : room;
+                reb += (int)((r >> 16) & 0xffffu);
+                slots += (int64_t)(r >> 32);
+                wide_next = true;
+                ++dbg_jump;
+            } else if (n < 0) { ep_entry = entry; ep_idx0 = idx; ep_reb0 = reb; ep_slots0 = slots; }
+        }
+    }
+    io->ev_c[lane] = ev_c; io->ev_valid[lane] = ev_valid ? 1u : 0u;
+    if (lane == 0) { io->lw = lw; io->idx = idx; io->need = need; io->progressed = progressed; io->reb = reb; io->slots = slots;
+                     io->dbg_mid = dbg_mid; io->dbg_miss = dbg_miss; io->dbg_why = dbg_why; io->dbg_t[0] = dbg_jump; io->dbg_t[1] = dbg_ncmp; io->dbg_t[2] = dbg_tcmp; io->dbg_t[3] = clock64() - dbg_t0; }
+}
 
 // wave 0: replays appends rc->idx .. end-1 on the register-resident block until one needs the workgroup path (need = 1).
 // Everything per op is wave-uniform register work: lane <-> occupancy word of the block for the bitmap, lane <-> level
@@ -463,7 +679,12 @@ __device__ void wave_fast_appends(Seq& S, RunComm* rc, RunMemo* memo, const uint
             eb += (int)Wh + 1;
         }
     }
-    const bool model_ok = cap >= (P)RUN_BLOCK && rc->pad == 0;      // whole 4096-slot block in front of the end: last_lane == 63
+    const bool model_ok = cap >= (P)RUN_BLOCK && rc->pad == 2;      // v1 count model (DSA_COUNT_MODEL=1); whole 4096-slot block in front of the end: last_lane == 63
+    // v2 (default): the last word is simulated bit-exactly, wider levels by their suffix counts
+    const int nlow = 7 - lseg;                                      // levels whose window fits one occupancy word (W = seg << h <= 64)
+    const bool model2_ok = cap >= (P)RUN_BLOCK && rc->pad == 0 && nlow >= 1 && nlow <= 6 && (int)seg << (nlow - 1) == 64;
+    bool skip_model = false;                                        // the model could not place the current op: one op through the general path
+    bool wrote_block = true;                                        // false: the block in registers is discarded (the workgroup rewrites wider windows first)
     const P last_blk = (cap - 1) >> RUN_BLOCK_LOG2;
     // cell types of the run (MappedPackedCSC: bit set = semaphore cell of a new column); one word per 64 cells
     P fw_idx = -1;
@@ -485,6 +706,65 @@ __device__ void wave_fast_appends(Seq& S, RunComm* rc, RunMemo* memo, const uint
             //      gaps of the closed-form spread pattern that fall into the last W_j offsets.  The bitmap is not touched per op:
             //      when the model is left, the LAST rebalance of every level (each still valid outside the suffix of the next lower
             //      one) is written once and the gaps consumed since — all in the last leaf — are filled from the right.
+            // ---- model v2 (wave_model2 below): the last occupancy word simulated bit-exactly, wider levels by suffix counts
+            if (model2_ok && !skip_model && blk == last_blk && L > cap - 64 && !memo->m2.outside_valid) { need = 3; break; }   // the workgroup recounts first
+            if (model2_ok && !skip_model && blk == last_blk && L > cap - 64) {
+                Model2IO* io = &memo->m2;
+                {
+                    uint32_t sb[7];
+                    sb[0] = (uint32_t)popc64(word);
+#pragma unroll
+                    for (int j = 1; j < 7; ++j) sb[j] = sb[j - 1] + __shfl_xor(sb[j - 1], 1 << (j - 1), 64);
+                    const uint32_t s1 = rdlane(sb[1], 63), s2 = rdlane(sb[2], 63), s3 = rdlane(sb[3], 63), s4 = rdlane(sb[4], 63),
+                                   s5 = rdlane(sb[5], 63), s6 = rdlane(sb[6], 63);
+                    const uint32_t c_mid = my_j == 1 ? s1 : my_j == 2 ? s2 : my_j == 3 ? s3 : my_j == 4 ? s4 : my_j == 5 ? s5 : s6;
+                    // levels wider than the block: cells in front of the block (io->outside, workgroup pass) + the whole block
+                    io->cnt[lane] = lvl_mid ? c_mid : (lvl_valid && !lvl_in_block ? io->outside[lane] + s6 : 0u);
+                }
+                io->W[lane] = lvl_valid && Wl > 64 ? (uint32_t)Wl : 0u;
+                io->Wb[lane] = lvl_in_block ? (uint32_t)Wl : 0u;
+                io->lo[lane] = lvl_valid ? (uint32_t)S.lo[lane] : 1u; io->hi[lane] = lvl_valid ? (uint32_t)S.hi[lane] : 0u;
+                io->eb[lane] = my_eb; io->wb[lane] = my_wb;
+                if (lane == 0) {
+                    io->lw = rdlane64(word, 63); io->idx = (int64_t)idx; io->end = (int64_t)end; io->nlow = nlow; io->seg = (int)seg;
+                    io->need = 0; io->progressed = 0; io->reb = 0; io->slots = 0;
+                }
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                wave_model2(io, memo, flags);
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                if (lane == 0) { S.ctl->prof[8] += 1; S.ctl->prof[9] += io->idx - (int64_t)idx; S.ctl->prof[10] += io->dbg_mid; S.ctl->prof[11] += io->dbg_miss;
+                                 S.ctl->prof[12 + (io->dbg_why & 3)] += 1; S.ctl->prof[4] += io->dbg_t[0]; S.ctl->prof[5] += io->dbg_t[1]; S.ctl->prof[6] += io->dbg_t[2]; S.ctl->prof[7] += io->dbg_t[3]; }
+                idx = (P)io->idx; reb += io->reb; slots += io->slots;
+                const uint64_t lw = io->lw;
+                fw_idx = -1;                                   // (the callee read the cell-type words itself)
+                if (lw != 0) L = cap - 63 + (P)(63 - __clzll((long long)lw));
+                // the surviving wide rebalances, widest first, then the last word.  Windows wider than the block are written by the
+                // whole workgroup (k_append_run), which then calls wave_apply_inblock for the rest
+                const uint64_t vm_all = __ballot(io->ev_valid[lane] != 0);
+                const uint64_t vm_out = vm_all & __ballot(lvl_valid && !lvl_in_block);
+                if (vm_out != 0) {
+                    if (lane == 0) io->pending = 1;
+                    need = io->need ? 1 : 2;
+                    wrote_block = false;
+                    break;
+                }
+                uint64_t vm = vm_all;
+                const uint32_t ev_c = io->ev_c[lane];
+                while (vm != 0) {
+                    const int j = 63 - __clzll((long long)vm);
+                    vm &= ~(1ull << j);
+                    const int Wj = (int)seg << j;
+                    const P wsj = cap - Wj + 1;
+                    wave_spread_bits<P>(word, memo, lane, Wj, (int)rdlane(ev_c, j), (int)rdlane((uint32_t)my_wb, j), wsj, (int)(((wsj - 1) >> 6) & 63));
+                }
+                if (lane == 63) word = lw;
+                if (io->need) { need = 1; break; }
+                skip_model = io->progressed == 0;
+                continue;
+            }
+            skip_model = false;
             if (model_ok && L == cap && blk == last_blk) {
                 uint32_t cnt;
                 {
@@ -617,6 +897,7 @@ __device__ void wave_fast_appends(Seq& S, RunComm* rc, RunMemo* memo, const uint
                 break;
             }
             const int h = __ffsll((unsigned long long)acc) - 1;
+            if (blk != last_blk && memo->m2.outside_valid) { if (lane == 0) memo->m2.outside_valid = 0; }     // cells in front of the last block changed
             if (h == 0) { L = ip; ++idx; continue; }
             // _even_rebalance!: spread! of c cells over the window, bits only
             const int W = (int)seg << h;                                      // <= 4096
@@ -627,9 +908,44 @@ __device__ void wave_fast_appends(Seq& S, RunComm* rc, RunMemo* memo, const uint
             L = wave_spread_bits<P>(word, memo, lane, W, c, (int)rdlane((uint32_t)my_wb, h), ws, lw0);
             ++idx;
         }
-        if (w < nwords) S.occ[w] = word;
+        if (w < nwords && wrote_block) S.occ[w] = word;
+        wrote_block = true;
     }
     if (lane == 0) { rc->idx = (int64_t)idx; rc->L = (int64_t)L; rc->reb = reb; rc->slots = slots; rc->small = reb; rc->need = need; }
+}
+
+// model v2, second half of an exit that had rebalances wider than the block (written by the workgroup in between): the in-block
+// survivors, widest first, then the last word, on the last block of the bitmap.  Wave 0.
+__device__ void wave_apply_inblock(Seq& S, RunMemo* memo) {
+    const int lane = lane_id();
+    Model2IO* io = &memo->m2;
+    const int64_t cap = S.capacity, seg = S.seg;
+    const int height = (int)S.height;
+    const int64_t last_blk = (cap - 1) >> RUN_BLOCK_LOG2;
+    const int64_t w = last_blk * 64 + lane;
+    uint64_t word = S.occ[w];
+    int my_wb = 0;                      // memo base of level h = lane (W <= 256), as in wave_fast_appends
+    {
+        int wb = 0;
+        for (int h = 0; h < 64; ++h) {
+            const int64_t Wh = seg << h;
+            if (h > height || Wh > 256) break;
+            if (h == lane) my_wb = wb;
+            wb += ((int)Wh + 1) * (Wh <= 64 ? 1 : (int)(Wh >> 6));
+        }
+    }
+    const bool in_block = lane <= height && (seg << lane) <= RUN_BLOCK && (seg << lane) > 64;
+    uint64_t vm = __ballot(in_block && io->ev_valid[lane] != 0);
+    const uint32_t ev_c = io->ev_c[lane];
+    while (vm != 0) {
+        const int j = 63 - __clzll((long long)vm);
+        vm &= ~(1ull << j);
+        const int Wj = (int)(seg << j);
+        const int64_t wsj = cap - Wj + 1;
+        wave_spread_bits<int64_t>(word, memo, lane, Wj, (int)rdlane(ev_c, j), (int)rdlane((uint32_t)my_wb, j), wsj, (int)(((wsj - 1) >> 6) & 63));
+    }
+    if (lane == 63) word = io->lw;
+    S.occ[w] = word;
 }
 
 // spread! of m cells over [ws, we], occupancy words only (workgroup-wide)
@@ -846,6 +1162,7 @@ __global__ __launch_bounds__(SEQ_BLOCK) void k_append_run(uint64_t* occ, Ctl* ct
     __shared__ int64_t sLo[MAX_LEVELS], sHi[MAX_LEVELS];
     for (int k = threadIdx.x; k < MEMO_WORDS; k += SEQ_BLOCK) sMemo.words[k] = 0ull;      // 0 = entry not computed yet
     for (int k = threadIdx.x; k < EV_WORDS; k += SEQ_BLOCK) sMemo.ev[k] = 0ull;
+    for (int k = threadIdx.x; k < M2_EV; k += SEQ_BLOCK) { sMemo.m2e[k].cnt = 0ull; sMemo.m2e[k].epr = 0ull; }
     Seq S;
     S.keys = KeyArr{nullptr, 1, 0}; S.vals = nullptr; S.occ = occ; S.sems = nullptr; S.col_keys = nullptr; S.col_live = nullptr; S.ctl = ctl;
     S.capacity = ctl->capacity; S.seg = ctl->segment_capacity; S.height = ctl->height;
@@ -864,7 +1181,22 @@ __global__ __launch_bounds__(SEQ_BLOCK) void k_append_run(uint64_t* occ, Ctl* ct
     int64_t t_fast = 0, t_slow = 0, n_slow = 0;
     const bool narrow_pos = !wide_pos && S.capacity <= (1ll << 30) && end <= (1ll << 30);
     const int64_t c_begin = clock64(), w_begin = wall_clock64();
+    const bool use_v2 = no_model == 0 && S.capacity >= RUN_BLOCK;
+    if (threadIdx.x == 0) { sMemo.m2.outside_valid = 0; sMemo.m2.pending = 0; }
+    __syncthreads();
     while (idx < end) {
+        if (use_v2 && !sMemo.m2.outside_valid) {
+            // model v2: suffix cell counts of the levels wider than the block, without the last block (all threads, uniform)
+            for (int j = 0; j <= (int)S.height && j < 64; ++j) {
+                const int64_t W = S.seg << j;
+                if (W > RUN_BLOCK && W <= S.capacity) {
+                    const int64_t c = blk_count(S, S.capacity - W + 1, S.capacity - RUN_BLOCK + 1);
+                    if (threadIdx.x == 0) sMemo.m2.outside[j] = (uint32_t)c;
+                }
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) sMemo.m2.outside_valid = 1;
+        }
         if (threadIdx.x == 0) { rc->idx = idx; rc->L = L; rc->pad = no_model; }
         __syncthreads();
         const int64_t t0 = wall_clock64();
@@ -882,7 +1214,20 @@ __global__ __launch_bounds__(SEQ_BLOCK) void k_append_run(uint64_t* occ, Ctl* ct
         idx = nidx;
         const int need = rc->need;
         __syncthreads();
-        if (!need) continue;
+        if (sMemo.m2.pending) {
+            // model v2 left with rebalances wider than the block: the workgroup writes them, widest first, then wave 0 the rest
+            for (int j = (int)S.height; j >= 0; --j) {
+                const int64_t W = S.seg << j;
+                if (W > RUN_BLOCK && W <= S.capacity && sMemo.m2.ev_valid[j] != 0) blk_rewrite_bits(S, S.capacity - W + 1, S.capacity, (int64_t)sMemo.m2.ev_c[j]);
+            }
+            __syncthreads();
+            if (threadIdx.x < 64) wave_apply_inblock(S, &sMemo);
+            __syncthreads();
+            if (threadIdx.x == 0) { sMemo.m2.pending = 0; sMemo.m2.outside_valid = 0; }
+            __syncthreads();
+        }
+        if (need != 1) continue;
+        if (threadIdx.x == 0) sMemo.m2.outside_valid = 0;      // (the slow op changes the bitmap in front of the block)
         const bool ok = blk_slow_append(S, L, flags != nullptr && ((flags[idx >> 6] >> (idx & 63)) & 1ull));
         t_slow += wall_clock64() - t1; ++n_slow;
         if (!ok) break;
@@ -920,7 +1265,8 @@ __global__ __launch_bounds__(SEQ_BLOCK) void k_append_run(uint64_t* occ, Ctl* ct
 hipError_t launch_append_run(uint64_t* occ, Ctl* ctl, int64_t i0, int64_t R, const uint64_t* flags, const int64_t* d_T,
                              hipStream_t stream) {
     static const int wide_pos = [] { const char* e = getenv("DSA_POS_WIDE"); return (e && e[0] == '1') ? 1 : 0; }();   // dev knob: 64-bit positions
-    static const int no_model = [] { const char* e = getenv("DSA_COUNT_MODEL"); return (e && e[0] == '0') ? 1 : 0; }();   // dev knob: bitmap replay only
+    // dev knob DSA_COUNT_MODEL: 0 = bitmap replay only, 1 = the suffix-count model of round 1, unset / 2 = model v2 (last word bit-exact)
+    static const int no_model = [] { const char* e = getenv("DSA_COUNT_MODEL"); return !e ? 0 : (e[0] == '0' ? 1 : (e[0] == '1' ? 2 : 0)); }();
     hipLaunchKernelGGL(k_append_run, dim3(1), dim3(SEQ_BLOCK), 0, stream, occ, ctl, i0, R, flags, d_T, wide_pos, no_model);
     return hipGetLastError();
 }
