@@ -423,6 +423,7 @@ __device__ __noinline__ void wave_model2(Model2IO* io_, RunMemo* memo_, const ui
     uint64_t fw = 0;
     // epoch being recorded: the in-word ops that follow the rebalance of memo entry ep_entry, up to the next op that needs a wide level
     int ep_entry = -1, ep_reb0 = 0;
+    bool ep_sem = false;                             // a semaphore cell was placed inside the epoch: it is not a function of the last word alone
     int64_t ep_idx0 = 0, ep_slots0 = 0;
     bool wide_next = false;                          // the op at idx is known to need a wide level (an epoch jump ended in front of it)
     while (idx < end) {
@@ -435,6 +436,7 @@ __device__ __noinline__ void wave_model2(Model2IO* io_, RunMemo* memo_, const ui
             if (flags != nullptr) {
                 if ((idx >> 6) != fw_idx) { fw_idx = idx >> 6; fw = u64(flags[fw_idx]); }
                 is_sem = (fw >> (idx & 63)) & 1ull;
+                ep_sem = ep_sem || is_sem;
             }
             // ---- the insert, on the last word
             uint64_t nw = lw;
@@ -497,7 +499,7 @@ __device__ __noinline__ void wave_model2(Model2IO* io_, RunMemo* memo_, const ui
         // ---- the op needs a level wider than a word.  The epoch since the last memoised rebalance ends in front of it: record it
         if (ep_entry >= 0) {
             const int64_t n = idx - ep_idx0;
-            if (n < 65535 && reb - ep_reb0 < 65535 && slots - ep_slots0 < (1ll << 31) && lane == 0) {
+            if (!ep_sem && n < 65535 && reb - ep_reb0 < 65535 && slots - ep_slots0 < (1ll << 31) && lane == 0) {
                 memo->m2e[ep_entry].eplw = lw;
                 memo->m2e[ep_entry].epr = ((uint64_t)(uint32_t)(slots - ep_slots0) << 32) | ((uint64_t)(uint32_t)(reb - ep_reb0) << 16) | (uint64_t)(n + 1);
             }
@@ -545,20 +547,30 @@ __device__ __noinline__ void wave_model2(Model2IO* io_, RunMemo* memo_, const ui
             if (lane < h && lvl_mid) cnt = (uint32_t)(e >> (16 * (k & 3))) & 0xffffu;
             lw = en_lw;
         }
-        if (entry >= 0 && flags == nullptr) {
-            // the in-word ops that follow are a function of the new last word alone: replay them from the memo (vector runs)
+        if (entry >= 0) {
+            // the in-word ops that follow are a function of the new last word alone as long as they are all cells: replay them
+            // from the memo (a matrix run: only if none of the next n cells is a semaphore, read from one word of the type flags)
             const uint64_t r = en_epr;
             const int64_t n = (int64_t)(r & 0xffffu) - 1;
-            if (n >= 0 && idx + n < end) {
+            bool cells_only = true;
+            if (flags != nullptr && n > 0) {
+                if ((idx >> 6) != ((idx + n - 1) >> 6)) cells_only = false;
+                else {
+                    if ((idx >> 6) != fw_idx) { fw_idx = idx >> 6; fw = u64(flags[fw_idx]); }
+                    const uint64_t m = (n >= 64 ? ~0ull : ((1ull << n) - 1ull)) << (idx & 63);
+                    cells_only = (fw & m) == 0;
+                }
+            }
+            if (n >= 0 && idx + n < end && cells_only) {
                 lw = en_eplw;
                 idx += n;
                 const uint32_t room = my_W - cnt;                  // cnt <= my_W
                 cnt += (uint32_t)n < room ? (uint32_t)n : room;
                 reb += (int)((r >> 16) & 0xffffu);
                 slots += (int64_t)(r >> 32);
-                wide_next = true;
+                wide_next = flags == nullptr;      // the op behind the epoch was a cell when it was recorded: a semaphore there may still fit the word
                 ++dbg_jump;
-            } else if (n < 0) { ep_entry = entry; ep_idx0 = idx; ep_reb0 = reb; ep_slots0 = slots; }
+            } else if (n < 0) { ep_entry = entry; ep_idx0 = idx; ep_reb0 = reb; ep_slots0 = slots; ep_sem = false; }
         }
     }
     io->ev_c[lane] = ev_c; io->ev_valid[lane] = ev_valid ? 1u : 0u;
