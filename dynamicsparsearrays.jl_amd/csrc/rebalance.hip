@@ -9,16 +9,11 @@
 // Bound: HBM.  Algorithmic bytes per W-slot window = 2 * 16 * W (read + write every slot);
 // the occupancy bitmap (W/8 B each way) and the tile counters are not counted.
 //
-//   k_tile_count2: cells per 4096-slot source tile (lane <-> occupancy word, popcount + wave reduce), written as a
-//                  two-level prefix: exclusive prefix inside each group of 64 tiles + one total per group.  No scan
-//                  kernel: k_move adds the totals of the groups in front itself (one wave-wide load + reduce).
+//   k_move2      : the whole rebalance in ONE launch, one workgroup per 2048-slot SOURCE tile (see the comment at the
+//                  kernel): prefix table published by the first workgroups, cells compacted into LDS by in-tile rank,
+//                  every owned destination offset — gaps included, so lines are written whole — stored as 16-byte
+//                  key / value pairs, occupancy words closed-form, semaphore positions scattered to the table.
 //   k_tile_count / k_tile_scan : flat prefix (count, then a one-workgroup scan) for k_compact / k_permute / views
-//   k_move       : one workgroup per 2048-slot DESTINATION tile.  Source cells whose rank falls in
-//                  the tile are compacted into LDS with wave64 ballot-style prefix popcounts (only
-//                  occupancy words that intersect the rank range are touched, so each source line is
-//                  read ~once), then every destination slot — gaps included, so lines are written
-//                  whole — is stored as 16-byte key / value pairs, the occupancy words are rebuilt
-//                  from two ballots, and semaphore positions are scattered to the table.
 #include "dsa_dev.h"
 #include <algorithm>
 #include <cstdio>
@@ -29,7 +24,6 @@ namespace dsa {
 
 constexpr int SRC_TILE_WORDS = 64;                 // 4096 slots
 constexpr int64_t SRC_TILE = 64 * SRC_TILE_WORDS;
-constexpr int DST_TILE = 2048;
 constexpr int MOVE_BLOCK = 256;
 
 __device__ __forceinline__ uint64_t range_mask_for_word(int64_t w, int64_t lo0, int64_t hi0) {
@@ -105,206 +99,6 @@ __global__ __launch_bounds__(1024) void k_tile_scan(const uint32_t* __restrict__
     if (tid == 0) off[n] = carry;
 }
 
-// k_tile_count2: the prefix source of k_move in ONE launch, no scan kernel.  Workgroup g counts the occupied slots of the 64
-// source tiles of group g (16 waves; wave w: tiles 64g+4w .. +3, lane <-> occupancy word), writes their exclusive prefix INSIDE the group
-// (local_off) and the group total (coarse); k_move adds the totals of the groups in front — one wave-wide load + reduce, issued
-// together with the local_off load, so a lookup costs one memory round trip like a read of a global prefix table would.
-constexpr int CNT2_SHIFT = 6, CNT2_TILES = 1 << CNT2_SHIFT, CNT2_THREADS = CNT2_TILES / 4 * 64;
-__global__ __launch_bounds__(CNT2_THREADS) void k_tile_count2(const uint64_t* __restrict__ occ, int64_t lo0, int64_t hi0, int64_t w0,
-                                                     int64_t nwords, int64_t ntiles, uint32_t* __restrict__ local_off,
-                                                     uint32_t* __restrict__ coarse) {
-    __shared__ uint32_t sT[CNT2_TILES];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    uint32_t pc[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int64_t t = (int64_t)blockIdx.x * CNT2_TILES + wv * 4 + i;
-        const int64_t w = t * SRC_TILE_WORDS + lane;
-        pc[i] = 0;
-        if (t < ntiles && w < nwords) pc[i] = popc64(occ[w0 + w] & range_mask_for_word(w0 + w, lo0, hi0));
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const uint32_t r = wave_reduce_add(pc[i]);
-        if (lane == 0) sT[wv * 4 + i] = r;
-    }
-    __syncthreads();
-    if (wv == 0) {
-        const uint32_t v = lane < CNT2_TILES ? sT[lane] : 0u;
-        const uint32_t ex = wave_excl_scan(v);
-        const int64_t t = (int64_t)blockIdx.x * CNT2_TILES + lane;
-        if (lane < CNT2_TILES && t < ntiles) local_off[t] = ex;
-        if (lane == CNT2_TILES - 1) coarse[blockIdx.x] = ex + v;
-    }
-}
-
-struct MoveArgs {
-    KeyArr src_keys; const double* src_vals; const uint64_t* src_occ;
-    int64_t src_lo0, src_hi0;      // 0-based inclusive source slot range
-    int64_t src_w0;                // first source occupancy word
-    KeyArr dst_keys; double* dst_vals; uint64_t* dst_occ;
-    int64_t dst_lo0;               // 0-based first destination slot (multiple of the window size)
-    int64_t Wd, m;
-    int64_t* sems;
-    const uint32_t* tile_off; int64_t ntiles;
-    const uint32_t* coarse;         // cells per group of 64 source tiles; tile_off then holds the prefix INSIDE the group (k_tile_count2)
-    double tiles_per_cell;          // ntiles / m: interpolation guess for the source tile of a rank
-    int dbg;   // DSA_DBG_MOVE ablation knob (dev only): 1 = skip staging, 2 = skip the write phase
-};
-
-
-// prefix lookups over the two-level table of k_tile_count2 (wave-uniform arguments).
-// group_prefix(g): cells in the groups in front of group g — one wave-wide load + reduce per 64 groups (one for <= 2^24 slots).
-static __device__ __forceinline__ int64_t group_prefix(const uint32_t* __restrict__ coarse, int64_t g, int lane) {
-    uint32_t sum = 0;
-    for (int64_t b = lane; b < g; b += 64) sum += coarse[b];     // 32-bit: a PMA holds < 2^32 cells (tile_off is 32-bit too)
-    return wave_reduce_add(sum);
-}
-
-template <bool PACKED, bool WIDE>
-__global__ __launch_bounds__(MOVE_BLOCK) void k_move(MoveArgs a) {
-    typedef typename std::conditional<WIDE, int64_t, int32_t>::type key_t;
-    const key_t* __restrict__ srck = static_cast<const key_t*>(a.src_keys.p);
-    key_t* __restrict__ dstk = static_cast<key_t*>(a.dst_keys.p);
-    __shared__ key_t sK[DST_TILE];
-    __shared__ double sV[DST_TILE];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const SpreadGeom g = make_geom(a.Wd, a.m);
-    const int64_t q0 = (int64_t)blockIdx.x * DST_TILE;          // this tile covers offsets q0+1 .. qend
-    const int64_t qend = (q0 + DST_TILE < a.Wd) ? q0 + DST_TILE : a.Wd;
-    const int64_t kA = gaps_le(g, (int)q0), kB = gaps_le(g, (int)qend);
-    const int64_t R0 = q0 - kA;                                  // cells placed before this tile
-    const int64_t cnt = (qend - q0) - (kB - kA);                 // cells landing in this tile: ranks R0+1..R0+cnt
-
-    if (!PACKED && a.dbg == 1) {      // ablation: no staging, harmless LDS contents
-        for (int i = tid; i < DST_TILE; i += MOVE_BLOCK) { sK[i] = 1; sV[i] = 1.0; }
-    }
-    if (!PACKED && a.dbg != 1) {
-        // ---- locate the first source tile holding rank R0+1: the largest t with tile_off[t] <= R0.
-        // Interpolated guess + short walk (cell density is near-uniform after a spread); bisection fallback.
-        // Each probe issues its loads together (the two in-group prefixes, the group totals): one memory round trip.
-        int64_t lo = 0;
-        int64_t cg = -1, cP = 0;                 // cached group prefix
-        if (cnt > 0) {
-            lo = (int64_t)((double)R0 * a.tiles_per_cell);
-            if (lo > a.ntiles - 1) lo = a.ntiles - 1;
-            int64_t l = 0, h = a.ntiles - 1;     // the answer lies in [l, h]
-            int steps = 0;
-            while (true) {
-                const int64_t gl = lo >> CNT2_SHIFT;
-                const bool edge = (lo + 1 >= a.ntiles) || ((lo + 1) >> CNT2_SHIFT) != gl;     // lo is the last tile of its group
-                const uint32_t l0 = a.tile_off[lo];
-                const uint32_t l1 = edge ? a.coarse[gl] : a.tile_off[lo + 1];
-                if (gl != cg) { cP = group_prefix(a.coarse, gl, lane); cg = gl; }
-                const int64_t o0 = cP + l0, o1 = cP + l1;
-                if (o0 > R0) h = lo - 1;
-                else if (o1 <= R0 && lo < a.ntiles - 1) l = lo + 1;
-                else break;
-                if (l >= h) { lo = l; break; }
-                ++steps;
-                lo = steps < 6 ? (o0 > R0 ? lo - 1 : lo + 1) : ((l + h + 1) >> 1);   // short walk, then bisection
-            }
-        }
-        // ---- passes of MOVE_BLOCK/64 source tiles: wave w describes tile tb+w (word masks + rank bases) in LDS,
-        //      then the intersecting words are dealt round-robin to the waves, 4 words (8 loads) per step.
-        __shared__ uint64_t sWM[MOVE_BLOCK];
-        __shared__ int32_t sWB[MOVE_BLOCK];        // rank base of the word relative to R0 (clamped)
-        for (int64_t tb = lo; cnt > 0 && tb < a.ntiles; tb += MOVE_BLOCK / 64) {
-            const int64_t t = tb + wv;
-            uint64_t myword = 0;
-            int64_t base = (int64_t)1 << 40;
-            if (t < a.ntiles) {
-                const int64_t wl = a.src_w0 + t * SRC_TILE_WORDS + lane;       // lane <-> word of the tile
-                myword = a.src_occ[wl] & range_mask_for_word(wl, a.src_lo0, a.src_hi0);
-                const uint32_t lt = a.tile_off[t];
-                if ((t >> CNT2_SHIFT) != cg) { cg = t >> CNT2_SHIFT; cP = group_prefix(a.coarse, cg, lane); }
-                base = cP + lt;
-            }
-            const uint32_t mypc = popc64(myword);
-            const int64_t wbase = base + wave_excl_scan(mypc) - R0;            // cells of earlier words, relative to R0
-            sWM[tid] = myword;
-            sWB[tid] = (int32_t)(wbase < -(1 << 30) ? -(1 << 30) : (wbase > (1 << 30) ? (1 << 30) : wbase));
-            const int before = __syncthreads_count(mypc == 0 ? (wbase <= 0) : (wbase + mypc <= 0));   // words entirely in front
-            const int notafter = __syncthreads_count(wbase < cnt);                                      // words starting before the end
-            // empty words in front of the range are counted in `before`; words [before, notafter) may intersect
-#pragma unroll 1
-            for (int jb = before + wv * 4; jb < notafter; jb += MOVE_BLOCK / 64 * 4) {
-                key_t kk[4]; double vv[4]; int rk[4]; bool act[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int j = jb + u;
-                    const bool in = j < notafter;
-                    const uint64_t mask = in ? sWM[j] : 0ull;
-                    const int off = in ? sWB[j] : 0;
-                    rk[u] = off + popc64(mask & mask_lt(lane));                 // 0-based rank relative to R0
-                    act[u] = ((mask >> lane) & 1ull) && rk[u] >= 0 && rk[u] < cnt;
-                    const int64_t word_index = a.src_w0 + (tb + (j >> 6)) * SRC_TILE_WORDS + (j & 63);
-                    // unconditional loads (inactive lanes read the word's first slot, inside the allocation)
-                    const int64_t s = (word_index << 6) + (act[u] ? lane : 0);
-                    const int64_t s_safe = in ? s : a.src_lo0;
-                    kk[u] = __builtin_nontemporal_load(srck + s_safe);
-                    vv[u] = __builtin_nontemporal_load(a.src_vals + s_safe);
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    if (act[u]) { sK[rk[u]] = kk[u]; sV[rk[u]] = vv[u]; }
-            }
-            __syncthreads();
-            if (notafter < MOVE_BLOCK) break;      // a word of this pass starts behind the last rank: so does every later one
-        }
-    }
-    __syncthreads();
-    if (a.dbg == 2) return;
-
-    // ---- write phase: lane <-> 2 adjacent destination slots, 128 slots per wave-iteration ----
-    constexpr int PER_WAVE = DST_TILE / (MOVE_BLOCK / 64);   // 512
-#pragma unroll
-    for (int it = 0; it < PER_WAVE / 128; ++it) {
-        const int64_t gq = q0 + (int64_t)wv * PER_WAVE + it * 128;   // 0-based offset of the 128-slot group
-        if (gq >= a.Wd) break;                                        // wave-uniform
-        const int64_t qa = gq + 2 * lane + 1;                         // 1-based offsets qa, qa+1
-        key_t k2[2] = {0, 0};
-        double v2[2] = {0.0, 0.0};
-        bool o2[2] = {false, false};
-        if (qa <= a.Wd) {
-            int k; bool gp[2];
-            gap_pair(g, (int)qa, &k, &gp[0], &gp[1]);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const bool gap = gp[j];
-                if (j == 1 && gap) ++k;
-                const int64_t rank = qa + j - k;
-                if (!gap) {
-                    o2[j] = true;
-                    if (PACKED) {
-                        k2[j] = srck[a.src_lo0 + rank - 1];
-                        v2[j] = a.src_vals[a.src_lo0 + rank - 1];
-                    } else {
-                        k2[j] = sK[rank - R0 - 1];
-                        v2[j] = sV[rank - R0 - 1];
-                    }
-                    if (a.sems != nullptr && a.dbg != 3 && k2[j] == SEM_KEY) a.sems[(int64_t)v2[j] - 1] = a.dst_lo0 + qa + j;   // 1-based slot
-                }
-            }
-            const int64_t d = a.dst_lo0 + qa - 1;
-            typedef double d2v __attribute__((ext_vector_type(2)));
-            d2v vv2; vv2.x = v2[0]; vv2.y = v2[1];
-            typedef key_t k2v __attribute__((ext_vector_type(2)));
-            k2v kv; kv.x = k2[0]; kv.y = k2[1];
-            __builtin_nontemporal_store(kv, reinterpret_cast<k2v*>(dstk + d));
-            __builtin_nontemporal_store(vv2, reinterpret_cast<d2v*>(a.dst_vals + d));
-        }
-        const uint64_t be = __ballot(o2[0]);
-        const uint64_t bo = __ballot(o2[1]);
-        if (lane == 0) {
-            const int64_t w = (a.dst_lo0 + gq) >> 6;
-            a.dst_occ[w] = spread_bits32((uint32_t)be) | (spread_bits32((uint32_t)bo) << 1);
-            if (gq + 64 < a.Wd)
-                a.dst_occ[w + 1] = spread_bits32((uint32_t)(be >> 32)) | (spread_bits32((uint32_t)(bo >> 32)) << 1);
-        }
-    }
-}
-
 // ---- k_move2: the window rebalance in ONE launch (source-driven, chained scan) --------------------------------------------
 // One 256-thread workgroup per 2048-slot SOURCE tile, in blockIdx order:
 //   1. the 32 occupancy words of the tile -> cell count c and in-tile word bases; all slot loads of the tile are issued
@@ -357,12 +151,9 @@ __device__ __forceinline__ int dest_of_rank(const SpreadGeom& g, int r, double c
     return r + k;
 }
 
-__device__ unsigned long long g_m2_prof[8192 * 5];      // dev profile (DSA_DBG_MOVE2 & 8): per-tile timestamps in 100 MHz ticks
 template <bool PACKED, bool WIDE, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_move2(Move2Args a) {
     constexpr int NW = BLOCK / 64;            // waves per workgroup
-    unsigned long long tk0 = 0, tk1 = 0, tk2 = 0, tk3 = 0;
-    if (a.dbg & 8) tk0 = wall_clock64();
     typedef typename std::conditional<WIDE, int64_t, int32_t>::type key_t;
     const key_t* __restrict__ srck = static_cast<const key_t*>(a.src_keys.p);
     key_t* __restrict__ dstk = static_cast<key_t*>(a.dst_keys.p);
@@ -423,7 +214,6 @@ __global__ __launch_bounds__(BLOCK) void k_move2(Move2Args a) {
         }
         // ---- 2. ask for the prefix: the tile's entry (wave 0) and the totals of the groups in front (waves 1-3); in the
         //         steady state the table is long complete and the answers arrive with the slots
-        if (a.dbg & 8) tk1 = wall_clock64();
         const int64_t grp = t >> 6;
         const unsigned long long ready = a.gen << 34;                 // a word that counts as published and adds nothing
         const unsigned long long* poll = nullptr;
@@ -446,7 +236,6 @@ __global__ __launch_bounds__(BLOCK) void k_move2(Move2Args a) {
                 sK[r] = kk[u]; sV[r] = vv[u];
             }
         }
-        if (a.dbg & 8) tk2 = wall_clock64();
         // ---- 3. cells in front of the tile ------------------------------------------------------------------------------------
         while ((st0 >> 34) != a.gen) { __builtin_amdgcn_s_sleep(1); st0 = __hip_atomic_load(poll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
         uint32_t part = (uint32_t)st0;
@@ -464,7 +253,6 @@ __global__ __launch_bounds__(BLOCK) void k_move2(Move2Args a) {
 #pragma unroll
         for (int w = 0; w < NW; ++w) P += sSum[w];
         if (a.dbg & 5) P = (int64_t)((double)t * (double)a.m / (double)a.ntiles);
-        if (a.dbg & 8) tk3 = wall_clock64();
     }
     // ---- 4. owned destination offsets (Q0, Q1] ------------------------------------------------------------------------------
     const int64_t Q0 = P == 0 ? 0 : dest_of_rank(g, (int)P, a.cells_to_gaps);
@@ -522,10 +310,6 @@ __global__ __launch_bounds__(BLOCK) void k_move2(Move2Args a) {
             if (gq + 64 < a.Wd && gq + 65 > Q0 && gq + 65 <= Q1)
                 a.dst_occ[w + 1] = spread_bits32((uint32_t)(be >> 32)) | (spread_bits32((uint32_t)(bo >> 32)) << 1);
         }
-    }
-    if ((a.dbg & 8) && tid == 0) {
-        const unsigned long long tk4 = wall_clock64();
-        if (t < 8192) { g_m2_prof[t * 5] = tk0; g_m2_prof[t * 5 + 1] = tk1; g_m2_prof[t * 5 + 2] = tk2; g_m2_prof[t * 5 + 3] = tk3; g_m2_prof[t * 5 + 4] = tk4; }
     }
 }
 
@@ -848,8 +632,7 @@ hipError_t launch_rebalance(KeyArr src_keys, const double* src_vals, const uint6
                             KeyArr dst_keys, double* dst_vals, uint64_t* dst_occ,
                             int64_t dst_ws, int64_t dst_we, int64_t m, int64_t* sems,
                             RebalanceWork* work, hipStream_t stream) {
-    static const bool v1 = [] { const char* e = getenv("DSA_MOVE_V1"); return e && e[0] == '1'; }();     // dev: count kernel + k_move (round 1)
-    if (!v1 || ((src_ws - 1) & 63) != 0) {
+    {
         Move2Args a;
         a.src_keys = src_keys; a.src_vals = src_vals; a.src_occ = src_occ;
         a.src_lo0 = src_ws - 1; a.src_hi0 = src_we - 1;
@@ -877,62 +660,16 @@ hipError_t launch_rebalance(KeyArr src_keys, const double* src_vals, const uint6
         a.status = work->status; a.gen = work->gen;
         // few tiles (windows up to 2^22 slots): the chain occupancy -> table -> write is latency, not bandwidth: 8 waves per tile
         static const int force_block = [] { const char* e = getenv("DSA_MOVE2_BLOCK"); return e ? atoi(e) : 0; }();
-        const int block = force_block ? force_block : (a.ntiles <= 2048 ? 512 : 256);      // measured: 2^20 9.9 vs 11.5 us, 2^22 27.2 vs 29.3, 2^24 83.5 vs 77.4
-        if (block == 1024) {
-            if (a.src_keys.wide) hipLaunchKernelGGL((k_move2<false, true, 1024>), dim3((unsigned)a.ntiles), dim3(1024), 0, stream, a);
-            else hipLaunchKernelGGL((k_move2<false, false, 1024>), dim3((unsigned)a.ntiles), dim3(1024), 0, stream, a);
-        } else if (block == 512) {
+        const int block = force_block ? force_block : (a.ntiles <= 2048 ? 512 : 256);      // measured 512 vs 256 threads: 2^20 9.9 vs 11.5 us, 2^22 27.2 vs 29.3, 2^24 83.5 vs 77.4 (1024 threads: 12.9 / 41 / 152)
+        if (block == 512) {
             if (a.src_keys.wide) hipLaunchKernelGGL((k_move2<false, true, 512>), dim3((unsigned)a.ntiles), dim3(512), 0, stream, a);
             else hipLaunchKernelGGL((k_move2<false, false, 512>), dim3((unsigned)a.ntiles), dim3(512), 0, stream, a);
         } else {
             if (a.src_keys.wide) hipLaunchKernelGGL((k_move2<false, true, 256>), dim3((unsigned)a.ntiles), dim3(256), 0, stream, a);
             else hipLaunchKernelGGL((k_move2<false, false, 256>), dim3((unsigned)a.ntiles), dim3(256), 0, stream, a);
         }
-        if (a.dbg & 8) {
-            static unsigned long long pr[8192 * 5];
-            hipStreamSynchronize(stream);
-            hipMemcpyFromSymbol(pr, HIP_SYMBOL(g_m2_prof), sizeof(pr));
-            const int64_t n = a.ntiles < 8192 ? a.ntiles : 8192;
-            double ph[4] = {0, 0, 0, 0};
-            unsigned long long t_first = ~0ull, t_last = 0, s_last = 0;
-            for (int64_t i = 0; i < n; ++i) {
-                for (int k = 0; k < 4; ++k) ph[k] += (double)(pr[i * 5 + k + 1] - pr[i * 5 + k]);
-                if (pr[i * 5] < t_first) t_first = pr[i * 5];
-                if (pr[i * 5 + 4] > t_last) t_last = pr[i * 5 + 4];
-                if (pr[i * 5] > s_last) s_last = pr[i * 5];
-            }
-            fprintf(stderr, "k_move2 profile over %lld tiles (us per tile): occupancy %.2f  slots+staging %.2f  status %.2f  write %.2f | first start -> last end %.1f us, last start at %.1f us\n",
-                    (long long)n, ph[0] / 100.0 / n, ph[1] / 100.0 / n, ph[2] / 100.0 / n, ph[3] / 100.0 / n, (t_last - t_first) / 100.0, (s_last - t_first) / 100.0);
-        }
         return hipGetLastError();
     }
-    MoveArgs a;
-    a.src_keys = src_keys; a.src_vals = src_vals; a.src_occ = src_occ;
-    a.src_lo0 = src_ws - 1; a.src_hi0 = src_we - 1;
-    a.src_w0 = a.src_lo0 >> 6;
-    a.dst_keys = dst_keys; a.dst_vals = dst_vals; a.dst_occ = dst_occ;
-    a.dst_lo0 = dst_ws - 1;
-    a.Wd = dst_we - dst_ws + 1; a.m = m;
-    a.sems = sems;
-    a.tile_off = nullptr; a.coarse = nullptr; a.ntiles = 0; a.tiles_per_cell = 0.0;
-    { static const char* e = getenv("DSA_DBG_MOVE"); a.dbg = e ? atoi(e) : 0; }
-    const int64_t ndst = (a.Wd + DST_TILE - 1) / DST_TILE;
-    if (src_packed) {
-        if (a.src_keys.wide) hipLaunchKernelGGL((k_move<true, true>), dim3((unsigned)ndst), dim3(MOVE_BLOCK), 0, stream, a);
-        else hipLaunchKernelGGL((k_move<true, false>), dim3((unsigned)ndst), dim3(MOVE_BLOCK), 0, stream, a);
-        return hipGetLastError();
-    }
-    const int64_t nwords = (a.src_hi0 >> 6) - a.src_w0 + 1;
-    const int64_t ntiles = (nwords + SRC_TILE_WORDS - 1) / SRC_TILE_WORDS;
-    if (ntiles + 1 > work->tiles_cap) return hipErrorInvalidValue;
-    // the occupancy array is allocated in whole 64-word tiles (see Pma::alloc), so lane <-> word reads stay in bounds
-    hipLaunchKernelGGL(k_tile_count2, dim3((unsigned)((ntiles + CNT2_TILES - 1) / CNT2_TILES)), dim3(CNT2_THREADS), 0, stream, src_occ, a.src_lo0,
-                       a.src_hi0, a.src_w0, nwords, ntiles, work->tile_off, work->tile_cnt);
-    a.tile_off = work->tile_off; a.coarse = work->tile_cnt; a.ntiles = ntiles;
-    a.tiles_per_cell = m > 0 ? (double)ntiles / (double)m : 0.0;
-    if (a.src_keys.wide) hipLaunchKernelGGL((k_move<false, true>), dim3((unsigned)ndst), dim3(MOVE_BLOCK), 0, stream, a);
-    else hipLaunchKernelGGL((k_move<false, false>), dim3((unsigned)ndst), dim3(MOVE_BLOCK), 0, stream, a);
-    return hipGetLastError();
 }
 
 }  // namespace dsa

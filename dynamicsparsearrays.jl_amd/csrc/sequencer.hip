@@ -359,7 +359,7 @@ struct Model2IO {
     int32_t dbg_mid, dbg_miss, dbg_why, dbg_pad;      // dev counters (DSA_DBG_RUN)
     int64_t dbg_t[4];
     uint32_t cnt[64], W[64], Wb[64], lo[64], hi[64], ev_c[64], ev_valid[64];
-    int32_t eb[64], wb[64];
+    int32_t wb[64];
     uint32_t outside[64];        // level h wider than the block: cells of its suffix IN FRONT of the last block (workgroup pass)
     int32_t outside_valid;       // ... computed for the current bitmap
     int32_t pending;             // exit with rebalances wider than the block still to be written (workgroup), then the in-block ones
@@ -372,7 +372,6 @@ struct RunMemo;
 __device__ __noinline__ void wave_model2(Model2IO* io, RunMemo* memo, const uint64_t* flags);
 
 constexpr int MEMO_ENTRIES = 640, MEMO_WORDS = 1664;
-constexpr int EV_WORDS = 512;
 constexpr int M2_EV = 1024;
 struct RunMemo {
     uint64_t words[MEMO_WORDS]; unsigned long long gapw[64];
@@ -381,7 +380,6 @@ struct RunMemo {
     // in-word ops, their rebalances and window slots — up to the next op that needs a wide level
     struct alignas(16) M2Entry { uint64_t cnt, lw, eplw, epr; } m2e[M2_EV];      // one 32-byte entry: two 16-byte LDS loads, one wait
     Model2IO m2;             // model v2: mailbox between wave_fast_appends and wave_model2
-    uint64_t ev[EV_WORDS];   // count model: outcome of a rebalance of level h <= 4 (W <= 256) with c cells: suffix counts of levels 0..3 (16 bits each), bit 63 = one trailing gap
 };   // gapw: scratch of the cooperative spread
 
 __device__ __noinline__ void wave_model2(Model2IO* io_, RunMemo* memo_, const uint64_t* flags_) {
@@ -681,18 +679,7 @@ __device__ void wave_fast_appends(Seq& S, RunComm* rc, RunMemo* memo, const uint
     const int last_lane = (int)((nwords - 1) & 63);
     const uint64_t cap_bit = 1ull << ((cap - 1) & 63);
     int need = 0;
-    int my_eb = -1;                                       // lane h: first word of level h in memo->ev, or -1 (level not memoised)
-    {
-        int eb = 0;
-        for (int h = 1; h <= 4; ++h) {
-            const int64_t Wh = (int64_t)seg << h;
-            if (h > height || Wh > 256) break;
-            if (h == lane) my_eb = eb;
-            eb += (int)Wh + 1;
-        }
-    }
-    const bool model_ok = cap >= (P)RUN_BLOCK && rc->pad == 2;      // v1 count model (DSA_COUNT_MODEL=1); whole 4096-slot block in front of the end: last_lane == 63
-    // v2 (default): the last word is simulated bit-exactly, wider levels by their suffix counts
+    // model v2: the last word is simulated bit-exactly, wider levels by their suffix counts (whole 4096-slot block in front of the end: last_lane == 63)
     const int nlow = 7 - lseg;                                      // levels whose window fits one occupancy word (W = seg << h <= 64)
     const bool model2_ok = cap >= (P)RUN_BLOCK && rc->pad == 0 && nlow >= 1 && nlow <= 6 && (int)seg << (nlow - 1) == 64;
     bool skip_model = false;                                        // the model could not place the current op: one op through the general path
@@ -736,7 +723,7 @@ __device__ void wave_fast_appends(Seq& S, RunComm* rc, RunMemo* memo, const uint
                 io->W[lane] = lvl_valid && Wl > 64 ? (uint32_t)Wl : 0u;
                 io->Wb[lane] = lvl_in_block ? (uint32_t)Wl : 0u;
                 io->lo[lane] = lvl_valid ? (uint32_t)S.lo[lane] : 1u; io->hi[lane] = lvl_valid ? (uint32_t)S.hi[lane] : 0u;
-                io->eb[lane] = my_eb; io->wb[lane] = my_wb;
+                io->wb[lane] = my_wb;
                 if (lane == 0) {
                     io->lw = rdlane64(word, 63); io->idx = (int64_t)idx; io->end = (int64_t)end; io->nlow = nlow; io->seg = (int)seg;
                     io->need = 0; io->progressed = 0; io->reb = 0; io->slots = 0;
@@ -777,79 +764,6 @@ __device__ void wave_fast_appends(Seq& S, RunComm* rc, RunMemo* memo, const uint
                 continue;
             }
             skip_model = false;
-            if (model_ok && L == cap && blk == last_blk) {
-                uint32_t cnt;
-                {
-                    const uint64_t wl_ = rdlane64(word, 63);
-                    const uint32_t c_low = (uint32_t)popc64(wl_ & (my_low_mask << (63 & my_low_align)));
-                    uint32_t sb[7];
-                    sb[0] = (uint32_t)popc64(word);
-#pragma unroll
-                    for (int j = 1; j < 7; ++j) sb[j] = sb[j - 1] + __shfl_xor(sb[j - 1], 1 << (j - 1), 64);
-                    const uint32_t s1 = rdlane(sb[1], 63), s2 = rdlane(sb[2], 63), s3 = rdlane(sb[3], 63), s4 = rdlane(sb[4], 63),
-                                   s5 = rdlane(sb[5], 63), s6 = rdlane(sb[6], 63);
-                    const uint32_t c_mid = my_j == 1 ? s1 : my_j == 2 ? s2 : my_j == 3 ? s3 : my_j == 4 ? s4 : my_j == 5 ? s5 : s6;
-                    cnt = lvl_low ? c_low : (lvl_mid ? c_mid : 0u);
-                }
-                const uint32_t my_W = lvl_in_block ? (uint32_t)Wl : 0u;
-                uint32_t ev_c = 0;                      // lane <-> level: cell count of the level's last rebalance ...
-                bool ev_valid = false;                  // ... if no wider rebalance came after it
-                int t_since = 0;                        // appends since the last rebalance (level-0 accepts: gaps of the last leaf)
-                bool last_empty = false;                // right after a rebalance the last slot is a gap
-                P L_ev = L;
-                while (idx < end) {
-                    if (__builtin_expect(flags != nullptr && (idx >> 6) != fw_idx, 0)) { fw_idx = idx >> 6; fw = flags[fw_idx]; }
-                    if (__builtin_expect(last_empty && ((fw >> (idx & 63)) & 1ull), 0)) break;       // a semaphore while the last slot is empty: general path
-                    const uint32_t cnt2 = cnt + (cnt < my_W ? 1u : 0u);
-                    const uint64_t acc = __ballot(lvl_in_block && my_lo <= cnt2 && cnt2 <= my_hi);
-                    if (__builtin_expect(acc == 0, 0)) { need = 1; break; }      // a window wider than the block (or _extend!) decides
-                    cnt = cnt2;
-                    ++idx;
-                    const int h = __ffsll((unsigned long long)acc) - 1;
-                    if (__builtin_expect(h == 0, 0)) { ++t_since; last_empty = false; continue; }
-                    const int W = (int)seg << h;
-                    const int c = (int)rdlane(cnt, h);
-                    reb += 1; slots += W;
-                    if (lane == h) { ev_c = (uint32_t)c; ev_valid = true; }
-                    else if (lane < h) ev_valid = false;
-                    t_since = 0; last_empty = true;
-                    const int eb = (int)rdlane((uint32_t)my_eb, h);
-                    uint64_t e = eb >= 0 ? memo->ev[eb + c] : 0ull;           // same address in every lane
-                    if (__builtin_expect(e == 0, 0)) {
-                        SpreadGeom g;
-                        g.W = W; g.E = W - c;
-                        g.f = (double)W / (double)(W - c);
-                        g.inv_f = (double)(W - c) / (double)W;
-                        if (lane < h) cnt = my_W - (uint32_t)((W - c) - gaps_le(g, W - (int)my_W));
-                        L_ev = cap - W + (P)spread_last_cell(g);
-                        if (eb >= 0) {
-                            e = (uint64_t)rdlane(cnt, 0) | ((uint64_t)(h > 1 ? rdlane(cnt, 1) : 0u) << 16) | ((uint64_t)(h > 2 ? rdlane(cnt, 2) : 0u) << 32) |
-                                ((uint64_t)(h > 3 ? rdlane(cnt, 3) : 0u) << 48) | (L_ev == cap - 1 ? 1ull << 63 : 0ull);
-                            if (lane == 0) memo->ev[eb + c] = e;
-                        }
-                    } else {
-                        if (lane < h) cnt = (uint32_t)(e >> (16 * lane)) & 0x7fffu;
-                        L_ev = (e >> 63) ? cap - 1 : cap - 2;             // the exact position is recomputed when the model is left
-                    }
-                    if (__builtin_expect(L_ev != cap - 1, 0)) break;          // several trailing gaps: the next appends fill them left to right (general path)
-                }
-                // ---- leave the model: write the surviving rebalances, widest first, then the consumed gaps
-                uint64_t vm = __ballot(ev_valid);
-                while (vm != 0) {
-                    const int j = 63 - __clzll((long long)vm);
-                    vm &= ~(1ull << j);
-                    const int Wj = (int)seg << j;
-                    const P wsj = cap - Wj + 1;
-                    L = wave_spread_bits<P>(word, memo, lane, Wj, (int)rdlane(ev_c, j), (int)rdlane((uint32_t)my_wb, j), wsj, (int)(((wsj - 1) >> 6) & 63));
-                }
-                if (t_since > 0) {
-                    if (lane == 63)
-                        for (int q = 0; q < t_since; ++q) word |= 1ull << (63 - __clzll((long long)~word));
-                    L = cap;
-                }
-                if (need) break;
-                continue;
-            }
             const uint64_t word_saved = word;
             P ip;
             if (L < cap && !is_sem) {
@@ -1173,7 +1087,6 @@ __global__ __launch_bounds__(SEQ_BLOCK) void k_append_run(uint64_t* occ, Ctl* ct
     __shared__ RunMemo sMemo;
     __shared__ int64_t sLo[MAX_LEVELS], sHi[MAX_LEVELS];
     for (int k = threadIdx.x; k < MEMO_WORDS; k += SEQ_BLOCK) sMemo.words[k] = 0ull;      // 0 = entry not computed yet
-    for (int k = threadIdx.x; k < EV_WORDS; k += SEQ_BLOCK) sMemo.ev[k] = 0ull;
     for (int k = threadIdx.x; k < M2_EV; k += SEQ_BLOCK) { sMemo.m2e[k].cnt = 0ull; sMemo.m2e[k].epr = 0ull; }
     Seq S;
     S.keys = KeyArr{nullptr, 1, 0}; S.vals = nullptr; S.occ = occ; S.sems = nullptr; S.col_keys = nullptr; S.col_live = nullptr; S.ctl = ctl;
@@ -1277,8 +1190,8 @@ __global__ __launch_bounds__(SEQ_BLOCK) void k_append_run(uint64_t* occ, Ctl* ct
 hipError_t launch_append_run(uint64_t* occ, Ctl* ctl, int64_t i0, int64_t R, const uint64_t* flags, const int64_t* d_T,
                              hipStream_t stream) {
     static const int wide_pos = [] { const char* e = getenv("DSA_POS_WIDE"); return (e && e[0] == '1') ? 1 : 0; }();   // dev knob: 64-bit positions
-    // dev knob DSA_COUNT_MODEL: 0 = bitmap replay only, 1 = the suffix-count model of round 1, unset / 2 = model v2 (last word bit-exact)
-    static const int no_model = [] { const char* e = getenv("DSA_COUNT_MODEL"); return !e ? 0 : (e[0] == '0' ? 1 : (e[0] == '1' ? 2 : 0)); }();
+    // dev knob DSA_COUNT_MODEL=0: bitmap replay only (the general per-op path; A/B runs and coverage of that path)
+    static const int no_model = [] { const char* e = getenv("DSA_COUNT_MODEL"); return (e && e[0] == '0') ? 1 : 0; }();
     hipLaunchKernelGGL(k_append_run, dim3(1), dim3(SEQ_BLOCK), 0, stream, occ, ctl, i0, R, flags, d_T, wide_pos, no_model);
     return hipGetLastError();
 }

@@ -4,6 +4,7 @@ slot on seeded inputs.  Integer keys, slot positions, semaphore tables: bit-exac
 accumulations: relative 1e-12 (north_star tolerance)."""
 import json
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -12,6 +13,7 @@ import ka
 from scenario import run_scenario
 from util import SplitMix64, check_key_order, check_semaphores, layouts_equal, splitmix_array, unit12_array
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 with open(os.path.join(HERE, "golden", "reference_cases.json")) as f:
@@ -784,6 +786,16 @@ def test_c3_scale_build_and_spmv_properties(dsa, hip):
     import scipy.sparse as sp
     A = sp.csr_matrix((vals, (rows - 1, cols - 1)), shape=(m, n))
     np.testing.assert_allclose(y1, A @ x1, rtol=1e-12, atol=0)
+
+
+def test_parallel_batches_share_occupancy_words(dsa, hip, oracle):
+    """DESIGN §3.2b invariant (I2): many writes of ONE batch land in the same 64-slot occupancy words — small arrays, dense key
+    ranges — so that k_apply waves on different XCDs update bits of the same word in the same launch; slot layout vs the oracle
+    and the device invariant checker after every batch (the scenario of tools/fuzz.py::run_shared_words)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import fuzz
+    for seed in range(4005, 4005 + 8 * 12, 8):
+        assert fuzz.run_shared_words(seed) == "ok"
 
 
 def test_c3_full_size_build_spmv_checker_and_rebalance_idempotence(dsa, hip):
