@@ -986,11 +986,12 @@ void mat_apply_sets(dsa_mat* h, const int64_t* I, const int64_t* J, const double
         const auto t0 = std::chrono::steady_clock::now();
         int64_t dc = 0, dr = 0;
         std::exception_ptr row_exc;
+        auto t_row_done = t0;
         const bool side_by_side = h->col.stream != h->row.stream;
         std::thread row_thread;
         if (side_by_side)
             row_thread = std::thread([&] {
-                try { bind_device(h->row); dr = run_ops_parallel(h->row, orw, &er); }
+                try { bind_device(h->row); dr = run_ops_parallel(h->row, orw, &er); t_row_done = std::chrono::steady_clock::now(); }
                 catch (...) { row_exc = std::current_exception(); }
             });
         const int64_t rounds0 = h->row.stat_par_rounds;
@@ -1000,10 +1001,10 @@ void mat_apply_sets(dsa_mat* h, const int64_t* I, const int64_t* J, const double
         if (side_by_side) { row_thread.join(); if (row_exc) std::rethrow_exception(row_exc); }
         else dr = run_ops_parallel(h->row, orw, &er);
         if (dbg_time)
-            fprintf(stderr, "[mat_apply_sets] n=%lld both orientations %.2f ms (colmajor done after %.2f ms)  colmajor (par %lld seq %lld ext %lld)  "
+            fprintf(stderr, "[mat_apply_sets] n=%lld both orientations %.2f ms (colmajor done after %.2f ms, rowmajor after %.2f ms)  colmajor (par %lld seq %lld ext %lld)  "
                     "rowmajor (par %lld seq %lld ext %lld rounds +%lld)\n", (long long)n,
                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(),
-                    std::chrono::duration<double, std::milli>(t1 - t0).count(), (long long)h->col.stat_par_ops,
+                    std::chrono::duration<double, std::milli>(t1 - t0).count(), std::chrono::duration<double, std::milli>(t_row_done - t0).count(), (long long)h->col.stat_par_ops,
                     (long long)h->col.stat_seq_ops, (long long)h->col.h_ctl->stat_extends, (long long)h->row.stat_par_ops, (long long)h->row.stat_seq_ops,
                     (long long)h->row.h_ctl->stat_extends, (long long)(h->row.stat_par_rounds - rounds0));
         if (dbg_time)
