@@ -105,6 +105,9 @@ def main():
     ap.add_argument("--per-col", type=int, default=10)
     ap.add_argument("--schedule", choices=("all_reduce", "rs_ag", "direct"), default="all_reduce",
                     help="how the partial y are summed over the ranks in the timed steps (sharding.py)")
+    ap.add_argument("--all-schedules", action="store_true",
+                    help="N > 1: also time the two schedules that are NOT used in the timed steps (extra collectives: off by default so that "
+                         "an unexpected failure of one of them on some node cannot cost the headline line)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the inserts/s and rebalance legs")
     args = ap.parse_args()
@@ -259,12 +262,14 @@ def main():
     if pm is not None and cfg == "c3" and m == 1_000_000 and ncl == 1_000_000 and per == 10:
         out["roofline"]["traffic"] = pm.get("k_spmv_gather_C3", {}).get("corrected_traffic_total")
         out["roofline"]["traffic_source"] = "%s (rocprofv3 --pmc, corrected; kernel sources %s)" % (pmc_file, pm.get("kernel_source_sha"))
-    else:
+    elif cfg == "c3" and m == 1_000_000 and ncl == 1_000_000 and per == 10:
         out["roofline"]["traffic_source"] = "none: no committed PMC summary matches the current kernel sources (%s)" % kernel_source_sha()
+    else:
+        out["roofline"]["traffic_source"] = "none: the committed PMC passes profile the C3 workload only"
 
     if world > 1:
-        # the three schedules of the sum of y, and the local product alone, timed back to back without overlap
-        # (max over ranks): what the collective costs next to the SpMV it follows
+        # the local product alone and the schedule of the sum of y used above (all three with --all-schedules), timed back to
+        # back without overlap (max over ranks): what the collective costs next to the SpMV it follows
         sched = {}
         reps = max(5, min(args.steps, 20))
 
@@ -277,7 +282,8 @@ def main():
             return round(max_over_ranks(time.perf_counter() - t) / reps * 1e3, 4)
 
         sched["local_spmv_ms"] = timed(lambda: shard.spmv_partial(x, ys[0]))
-        for name in sharding.SCHEDULES:
+        names = sharding.SCHEDULES if (args.all_schedules or os.environ.get("DSA_BENCH_ALL_SCHEDULES") == "1") else (args.schedule,)
+        for name in names:
             try:
                 sched[name + "_ms"] = timed(lambda: shard.reduce(ys[0], name))
                 sched[name + "_algbw_gbps"] = round(8 * m / 1e9 / (sched[name + "_ms"] / 1e3), 1)
