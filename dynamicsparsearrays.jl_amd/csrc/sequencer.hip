@@ -373,12 +373,15 @@ __device__ __noinline__ void wave_model2(Model2IO* io, RunMemo* memo, const uint
 
 constexpr int MEMO_ENTRIES = 640, MEMO_WORDS = 1664;
 constexpr int M2_EV = 1024;
+constexpr int M2_HASH = 256;
 struct RunMemo {
     uint64_t words[MEMO_WORDS]; unsigned long long gapw[64];
     // model v2: memo of the rebalances of wide levels up to 512 slots (entry = level base + cell count): counts of the wide levels
     // below (16 bits each, bit 63 = valid), the last word after the rebalance, and the epoch that follows it — last word, number of
     // in-word ops, their rebalances and window slots — up to the next op that needs a wide level
     struct alignas(16) M2Entry { uint64_t cnt, lw, eplw, epr; } m2e[M2_EV];      // one 32-byte entry: two 16-byte LDS loads, one wait
+    // epochs behind rebalances of levels WITHOUT an entry (wider than 512 slots): keyed by the last word itself (direct-mapped hash)
+    struct alignas(16) M2Hash { uint64_t key, eplw, epr, pad_; } m2h[M2_HASH];
     Model2IO m2;             // model v2: mailbox between wave_fast_appends and wave_model2
 };   // gapw: scratch of the cooperative spread
 
@@ -420,7 +423,8 @@ __device__ __noinline__ void wave_model2(Model2IO* io_, RunMemo* memo_, const ui
     int64_t fw_idx = -1;
     uint64_t fw = 0;
     // epoch being recorded: the in-word ops that follow the rebalance of memo entry ep_entry, up to the next op that needs a wide level
-    int ep_entry = -1, ep_reb0 = 0;
+    int ep_entry = -1, ep_reb0 = 0;                  // >= 0: memo entry; <= -2: slot -2 - ep_entry of the hash table, key ep_key
+    uint64_t ep_key = 0;
     bool ep_sem = false;                             // a semaphore cell was placed inside the epoch: it is not a function of the last word alone
     int64_t ep_idx0 = 0, ep_slots0 = 0;
     bool wide_next = false;                          // the op at idx is known to need a wide level (an epoch jump ended in front of it)
@@ -494,11 +498,12 @@ __device__ __noinline__ void wave_model2(Model2IO* io_, RunMemo* memo_, const ui
         }
         wide_next = false;
         // ---- the op needs a level wider than a word.  The epoch since the last memoised rebalance ends in front of it: record it
-        if (ep_entry >= 0) {
+        if (ep_entry != -1) {
             const int64_t n = idx - ep_idx0;
             if (!ep_sem && n < 65535 && reb - ep_reb0 < 65535 && slots - ep_slots0 < (1ll << 31) && lane == 0) {
-                memo->m2e[ep_entry].eplw = lw;
-                memo->m2e[ep_entry].epr = ((uint64_t)(uint32_t)(slots - ep_slots0) << 32) | ((uint64_t)(uint32_t)(reb - ep_reb0) << 16) | (uint64_t)(n + 1);
+                const uint64_t r = ((uint64_t)(uint32_t)(slots - ep_slots0) << 32) | ((uint64_t)(uint32_t)(reb - ep_reb0) << 16) | (uint64_t)(n + 1);
+                if (ep_entry >= 0) { memo->m2e[ep_entry].eplw = lw; memo->m2e[ep_entry].epr = r; }
+                else { RunMemo::M2Hash& hs = memo->m2h[-2 - ep_entry]; hs.key = ep_key; hs.eplw = lw; hs.epr = r; }
             }
             ep_entry = -1;
         }
@@ -544,7 +549,15 @@ __device__ __noinline__ void wave_model2(Model2IO* io_, RunMemo* memo_, const ui
             if (lane < h && lvl_mid) cnt = (uint32_t)(e >> (16 * (k & 3))) & 0xffffu;
             lw = en_lw;
         }
-        if (entry >= 0) {
+        int hslot = -1;
+        if (entry < 0) {                           // no memo entry for this level: the epoch cache keyed by the last word
+            hslot = (int)((lw * 0x9E3779B97F4A7C15ull) >> 56) & (M2_HASH - 1);
+            const RunMemo::M2Hash hs = memo->m2h[hslot];
+            const bool hit = u64(hs.key) == lw;
+            en_eplw = u64(hs.eplw);
+            en_epr = hit ? u64(hs.epr) : 0ull;
+        }
+        {
             // the in-word ops that follow are a function of the new last word alone as long as they are all cells: replay them
             // from the memo (a matrix run: only if none of the next n cells is a semaphore, read from one word of the type flags)
             const uint64_t r = en_epr;
@@ -569,7 +582,7 @@ __device__ __noinline__ void wave_model2(Model2IO* io_, RunMemo* memo_, const ui
                 // again; a semaphore there may still fit the word and takes the in-word path first
                 wide_next = flags == nullptr || ((idx >> 6) == fw_idx && ((fw >> (idx & 63)) & 1ull) == 0);
                 ++dbg_jump;
-            } else if (n < 0) { ep_entry = entry; ep_idx0 = idx; ep_reb0 = reb; ep_slots0 = slots; ep_sem = false; }
+            } else if (n < 0) { ep_entry = entry >= 0 ? entry : -2 - hslot; ep_key = lw; ep_idx0 = idx; ep_reb0 = reb; ep_slots0 = slots; ep_sem = false; }
         }
     }
     io->ev_c[lane] = ev_c; io->ev_valid[lane] = ev_valid ? 1u : 0u;
@@ -1089,6 +1102,7 @@ __global__ __launch_bounds__(SEQ_BLOCK) void k_append_run(uint64_t* occ, Ctl* ct
     __shared__ int64_t sLo[MAX_LEVELS], sHi[MAX_LEVELS];
     for (int k = threadIdx.x; k < MEMO_WORDS; k += SEQ_BLOCK) sMemo.words[k] = 0ull;      // 0 = entry not computed yet
     for (int k = threadIdx.x; k < M2_EV; k += SEQ_BLOCK) { sMemo.m2e[k].cnt = 0ull; sMemo.m2e[k].epr = 0ull; }
+    for (int k = threadIdx.x; k < M2_HASH; k += SEQ_BLOCK) { sMemo.m2h[k].key = 0ull; sMemo.m2h[k].epr = 0ull; }
     Seq S;
     S.keys = KeyArr{nullptr, 1, 0}; S.vals = nullptr; S.occ = occ; S.sems = nullptr; S.col_keys = nullptr; S.col_live = nullptr; S.ctl = ctl;
     S.capacity = ctl->capacity; S.seg = ctl->segment_capacity; S.height = ctl->height;
