@@ -95,8 +95,8 @@ struct Ctl {
     // instrumentation
     int64_t stat_window_slots, stat_rebalances, stat_extends, stat_shrinks, stat_small_rebalances;
     int64_t no_run_at;     // op index that must take the normal path (an append run made no progress there), or -1
-    int64_t n_pending;     // table entries [table_len - n_pending, table_len) were created by batch-parallel rounds at the END of the
-                           // tables (arrival order, not key order); the sequencer merges them (sequencer.hip); 0 at every API boundary
+    int64_t n_pending;     // table entries [table_len - n_pending, table_len) were created by the running batch at the END of the tables
+                           // (arrival order, not key order; <= 1024); merged into key order by tables.hip; 0 at every API boundary
     int64_t prof[16];      // dev profile of the sequencer (shader cycles): table lookup, new partition, element write, merges; counts
     int64_t dbg[6];        // append-run profile of the last run: slow ops, ticks (100 MHz) in setup / fast loop / slow path, blocks loaded
     // vector length n (src/vector.jl:2) is host-only
@@ -284,6 +284,15 @@ hipError_t launch_append_run(uint64_t* occ, Ctl* ctl, int64_t i0, int64_t R, con
                              hipStream_t stream);
 hipError_t launch_run_expand(const Op* ops, int64_t i0, int64_t R, const Ctl* ctl, int64_t* col_keys, uint8_t* col_live, Op* cells,
                              uint64_t* flags, int64_t* out, hipStream_t stream);
+
+// ---- grid-wide merge of the pending partition-table entries (tables.hip) -------------------------------------------------
+struct TableMerge {
+    int64_t* sems2; int64_t* keys2;               // scratch tables, table_cap entries each
+    int64_t* pkey; int64_t* pdst; int64_t* psem;  // pending entries by key rank: key, destination index, semaphore slot (1024 each)
+    int64_t* hdr;                                 // [0] K (0: nothing to do) [1] first table index that moves [2] fault flag
+};
+hipError_t launch_table_merge(int64_t* sems, int64_t* col_keys, uint8_t* col_live, double* vals, Ctl* ctl, TableMerge tm, int64_t table_cap,
+                              hipStream_t stream);
 
 // ---- batch-parallel writes of a vector's PMA (parbatch.hip) ------------------------------------------------------------
 struct Plan {

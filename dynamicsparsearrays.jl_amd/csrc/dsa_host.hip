@@ -86,6 +86,8 @@ struct Pma {
     int64_t stat_par_rounds = 0, stat_par_ops = 0, stat_seq_ops = 0, stat_seq_launches = 0;      // batch-parallel instrumentation
     BurstGraph burst, burst_short;      // cached graphs of a full burst of rounds and of a short one (conflict-heavy phases)
     Plan* d_plans = nullptr; uint32_t* d_flags = nullptr; RoundState* d_rs = nullptr; RoundState* h_rs = nullptr;   // batch-parallel writes
+    TableMerge tmerge{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; int64_t tmerge_cap = 0;   // scratch of the grid-wide table merge (tables.hip)
+    int64_t stat_table_merges = 0;
     int64_t* d_small = nullptr;                     // 8 x int64 scratch
     int64_t* h_small = nullptr;                     // its pinned host mirror (small read-backs without a pageable staging copy)
     // bumped by every launch that can move cells or change the tables; SpmvMeta is recomputed when it differs
@@ -142,6 +144,9 @@ void pma_destroy(Pma& P) {
     if (P.h_rs) hipHostFree(P.h_rs);
     if (P.d_small) hipFree(P.d_small);
     if (P.h_small) hipHostFree(P.h_small);
+    if (P.tmerge.sems2) hipFree(P.tmerge.sems2);
+    if (P.tmerge.keys2) hipFree(P.tmerge.keys2);
+    if (P.tmerge.pkey) hipFree(P.tmerge.pkey);
     if (P.run_cells) hipFree(P.run_cells);
     if (P.run_flags) hipFree(P.run_flags);
     if (P.run_out) hipFree(P.run_out);
@@ -426,6 +431,30 @@ void ensure_key_width(Pma& P, const std::vector<Op>& ops) {
 
 // ---- the yield loop around the device sequencer, as a resumable state machine so that the two orientations of a
 // matrix can run their sequencers concurrently on their own streams ------------------------------------------------
+// Pending partition-table entries (created by the running batch at the end of the tables, Ctl::n_pending) back into key order:
+// the grid-wide pass of tables.hip, stream-ordered, no host wait.  h_ctl->table_cap must be current.
+void merge_tables(Pma& P) {
+    if (!P.has_cols) return;
+    const int64_t cap = P.h_ctl->table_cap;
+    if (P.tmerge_cap < cap) {
+        if (P.tmerge.sems2) HIPCHK(hipFree(P.tmerge.sems2));          // hipFree waits for the work that may still use them
+        if (P.tmerge.keys2) HIPCHK(hipFree(P.tmerge.keys2));
+        P.tmerge.sems2 = P.tmerge.keys2 = nullptr; P.tmerge_cap = 0;
+        HIPCHK(hipMalloc(&P.tmerge.sems2, (size_t)cap * sizeof(int64_t)));
+        HIPCHK(hipMalloc(&P.tmerge.keys2, (size_t)cap * sizeof(int64_t)));
+        P.tmerge_cap = cap;
+    }
+    if (!P.tmerge.pkey) {
+        HIPCHK(hipMalloc(&P.tmerge.pkey, (size_t)(3 * 1024 + 8) * sizeof(int64_t)));
+        P.tmerge.pdst = P.tmerge.pkey + 1024; P.tmerge.psem = P.tmerge.pkey + 2048; P.tmerge.hdr = P.tmerge.pkey + 3072;
+    }
+    ++P.layout_epoch;
+    hipError_t e = launch_table_merge(P.sems, P.col_keys, P.col_live, P.V(), P.d_ctl, P.tmerge, cap, P.stream);
+    if (e != hipSuccess) fail(DSA_EHIP, std::string("table merge launch: ") + hipGetErrorString(e));
+    P.h_ctl->n_pending = 0;
+    P.stat_table_merges += 1;
+}
+
 struct SeqRun {
     Pma* P = nullptr;
     const std::vector<Op>* ops = nullptr;
@@ -435,6 +464,7 @@ struct SeqRun {
     int32_t err = 0;         // status of the failing op (0 if none)
     int64_t applied = 0;     // ops fully applied
     int64_t guard = 0;
+    bool defer_merge = false; // leave pending table entries to the caller (a batch that goes on with more launches)
 };
 
 void seq_launch(SeqRun& r, bool upload = true) {
@@ -470,9 +500,11 @@ bool seq_step(SeqRun& r) {
     switch (c.status) {
         case SEQ_DONE:
             r.applied = std::max(r.n, c.next_op); r.active = false;
+            if (!r.defer_merge && c.n_pending > 0) merge_tables(P);
             return false;
         case SEQ_ERROR:
             r.err = seq_err_to_status(c.err); r.applied = c.next_op; r.active = false;
+            if (!r.defer_merge && c.n_pending > 0) merge_tables(P);
             return false;
         case SEQ_Y_REBALANCE:
             window_rebalance(P, c.y_ws, c.y_we, c.y_m);
@@ -560,6 +592,7 @@ int64_t run_ops_parallel(Pma& P, const std::vector<Op>& ops, int32_t* err) {
     const int64_t n = (int64_t)ops.size();
     if (n == 0) return 0;
     constexpr int GMAX = 1024, MIN_PREFIX = 4, ROUNDS_PER_SYNC = 12, ROUNDS_SHORT = 3;
+    constexpr int64_t MERGE_AT = 256;       // pending table entries (of at most 1024) that trigger the grid-wide merge between launches
     ensure_key_width(P, ops);
     ensure_ops(P, n);
     HIPCHK(hipMemcpyAsync(P.d_ops, ops.data(), (size_t)n * sizeof(Op), hipMemcpyHostToDevice, P.stream));
@@ -578,8 +611,12 @@ int64_t run_ops_parallel(Pma& P, const std::vector<Op>& ops, int32_t* err) {
     // a burst that stops in its first rounds (short conflict-free prefix, barrier op) leaves the rest of its graph as no-op
     // launches (~2.5 us each, four per round): after such a stop the next burst is a short one, until one runs to its end
     int burst_rounds = ROUNDS_PER_SYNC;
-    bool host_ctl_stale = false;
+    static const bool dbg_split = getenv("DSA_DBG_SPLIT") != nullptr;
+    double t_burst = 0, t_seq = 0; int64_t n_burst = 0, n_seq = 0, n_yield = 0;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
     while (i < n) {
+        const auto tb0 = now();
         // ---- a burst of rounds driven by the device-resident cursor; one host synchronisation per burst
         RoundState& rs = *P.h_rs;
         std::memset(&rs, 0, sizeof(rs));
@@ -593,11 +630,15 @@ int64_t run_ops_parallel(Pma& P, const std::vector<Op>& ops, int32_t* err) {
             if (e != hipSuccess) fail(DSA_EHIP, std::string("burst launch: ") + hipGetErrorString(e));
         }
         HIPCHK(hipMemcpyAsync(P.h_rs, P.d_rs, sizeof(RoundState), hipMemcpyDeviceToHost, P.stream));
+        HIPCHK(hipMemcpyAsync(P.h_ctl, P.d_ctl, sizeof(Ctl), hipMemcpyDeviceToHost, P.stream));      // table_len, n_pending, counts of the burst
         HIPCHK(hipStreamSynchronize(P.stream));
+        t_burst += ms(tb0, now()); ++n_burst;
         // the prefix of the last round of the burst has been applied but is folded into the cursor only by the next k_resolve
         if (rs.pad != 0) fail(DSA_EASSERT, "batch-parallel column creation left its footprint (internal invariant)");
         const int64_t reached = rs.cursor + rs.d;
-        if (reached > i) { host_ctl_stale = true; seq_chunk = SEQ_CHUNK0; }
+        if (reached > i) seq_chunk = SEQ_CHUNK0;
+        // new partitions of the rounds sit at the end of the tables: back into key order with the whole chip once enough have piled up
+        if (P.h_ctl->n_pending >= MERGE_AT) merge_tables(P);
         P.stat_par_rounds += rs.rounds + (rs.d > 0 ? 1 : 0); P.stat_par_ops += rs.par_ops + rs.d;
         for (int q = 0; q < 8; ++q) P.stat_why[q] += rs.why[q];
         i = reached;
@@ -605,27 +646,24 @@ int64_t run_ops_parallel(Pma& P, const std::vector<Op>& ops, int32_t* err) {
         burst_rounds = (rs.stop == 1 && rs.rounds <= ROUNDS_SHORT) ? ROUNDS_SHORT : ROUNDS_PER_SYNC;
         if (rs.stop != 1) continue;                       // burst used up (0) or batch finished (2)
         // ---- short prefix at op i: sequential sequencer for ops [i, i + seq_chunk)
-        if (host_ctl_stale) { download_ctl(P); host_ctl_stale = false; }
+        const auto ts0 = now();
         SeqRun r;
-        r.P = &P; r.ops = &ops; r.n = std::min<int64_t>(n, i + seq_chunk); r.n_avail = n; r.active = true;
+        r.P = &P; r.ops = &ops; r.n = std::min<int64_t>(n, i + seq_chunk); r.n_avail = n; r.active = true; r.defer_merge = true;
         P.h_ctl->next_op = i; P.h_ctl->status = 0; P.h_ctl->err = 0; P.h_ctl->no_run_at = -1;
         seq_launch(r);
-        while (seq_step(r)) {}
-        if (r.err) { *err = r.err; return r.applied; }
+        while (seq_step(r)) ++n_yield;
+        t_seq += ms(ts0, now()); ++n_seq;
+        if (r.err) { if (P.h_ctl->n_pending > 0) merge_tables(P); *err = r.err; return r.applied; }
+        if (P.h_ctl->n_pending >= MERGE_AT) merge_tables(P);
         P.stat_seq_ops += r.applied - i; P.stat_seq_launches += 1;
         i = r.applied;
         seq_chunk = std::min<int64_t>(seq_chunk * 2, 8192);
         G = 64;
     }
-    if (host_ctl_stale) download_ctl(P);
-    if (P.h_ctl->n_pending > 0) {
-        // columns created by the last rounds still sit at the end of the tables: an empty sequencer run merges them
-        SeqRun r;
-        r.P = &P; r.ops = &ops; r.n = n; r.n_avail = n; r.active = true;
-        P.h_ctl->next_op = n; P.h_ctl->status = 0; P.h_ctl->err = 0; P.h_ctl->no_run_at = -1;
-        seq_launch(r);
-        while (seq_step(r)) {}
-    }
+    if (dbg_split)
+        fprintf(stderr, "  [run_ops_parallel %s] n=%lld: %lld bursts %.2f ms, %lld sequencer chunks (%lld yields) %.2f ms\n", P.has_cols ? "pcsc" : "vec", (long long)n,
+                (long long)n_burst, t_burst, (long long)n_seq, (long long)n_yield, t_seq);
+    if (P.h_ctl->n_pending > 0) merge_tables(P);          // the tables leave the batch in key order (the reference's numbering)
     return n;
 }
 
@@ -1012,6 +1050,14 @@ void mat_apply_sets(dsa_mat* h, const int64_t* I, const int64_t* J, const double
                     "5 window %lld, 6 scan %lld, 7 conflict %lld]\n", (long long)h->row.stat_seq_launches, (long long)h->row.stat_why[0], (long long)h->row.stat_why[1],
                     (long long)h->row.stat_why[2], (long long)h->row.stat_why[3], (long long)h->row.stat_why[4], (long long)h->row.stat_why[5],
                     (long long)h->row.stat_why[6], (long long)h->row.stat_why[7]);
+        if (dbg_time && h->row.h_ctl->prof[7] != 0) {      // -DDSA_PROFILE builds only: shader-clock split of the rowmajor sequencer (cumulative)
+            const int64_t* q = h->row.h_ctl->prof;
+            const double us = 1.0 / 100.0;                   // s_memtime ticks at 100 MHz
+            fprintf(stderr, "    rowmajor sequencer profile (cumulative): kernel %.0f us | %lld matrix writes: table lookup %.0f us, %lld new partitions %.0f us, write in partition %.0f us "
+                    "[partition end %.0f, find %.0f, insert/shift %.0f, scan+rebalance %.0f (%lld in-block rebalances %.0f us, %lld slots)] | %lld table merges %.0f us\n",
+                    q[7] * us, (long long)q[4], q[0] * us, (long long)q[5], q[1] * us, q[2] * us, q[11] * us, q[8] * us, q[9] * us, q[10] * us, (long long)q[13], q[12] * us,
+                    (long long)q[14], (long long)q[6], q[3] * us);
+        }
         const int64_t done = std::min(dc, dr);
         for (int64_t k = 0; k < std::min(done + 1, n); ++k) if (V[k] != 0.0) { h->m = std::max(h->m, I[k]); h->n = std::max(h->n, J[k]); }
         if (ec) fail(ec, err_text(ec));

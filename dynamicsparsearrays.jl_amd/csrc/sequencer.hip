@@ -1376,10 +1376,12 @@ __device__ int d_addpartition_middle(Seq& S, int64_t prev, bool with_col, int64_
 // key order), not on its number.  So inside one launch a new partition is appended at the END of the tables with the next
 // free id (cells and tables stay consistent with each other: shifts, rebalances and spreads keep working on ids), its key
 // is kept in a small sorted list in LDS, lookups consult the sorted table part + that list, and the tables are brought
-// back to key order — ONE merge pass with ONE renumbering of the cells — when the list is full, before any op that is not a
-// plain MappedPackedCSC write, and always before the kernel exits (the host, the batch-parallel kernels and the big
-// rebalance never see pending entries).  Only used while no tombstone exists (nb_partitions == table_len); the
-// tombstone-reuse and @assert paths of the reference run on the literal code below.
+// back to key order — ONE merge pass with ONE renumbering of the cells — when the list is full and before any op that is not
+// a plain MappedPackedCSC write (d_merge_pending below, one workgroup), or by the host between launches and before the batch
+// returns (tables.hip: the same pass with the whole chip; entries still pending when the kernel exits are counted in
+// Ctl::n_pending and re-imported by the next launch; the big rebalance and the batch-parallel kernels work on ids and do not
+// care about the order).  Only used while no tombstone exists (nb_partitions == table_len); the tombstone-reuse and @assert
+// paths of the reference run on the literal code below.
 __device__ int pend_lower_bound(const Seq& S, int64_t key) {          // first j with pKey[j] >= key
     int lo = 0, hi = S.n_pend;
     while (lo < hi) {
@@ -1468,7 +1470,9 @@ __device__ void d_merge_pending(Seq& S) {
     S.prof[3] += DSA_TICK() - tm0; S.prof[6] += 1;
 }
 
-// entries appended by the batch-parallel rounds (Ctl::n_pending, arrival order): build the sorted list and merge at once
+// entries left at the end of the tables by earlier launches of the batch (Ctl::n_pending, arrival order: batch-parallel rounds and
+// previous sequencer chunks): rebuild the sorted list; the merge itself is the host's grid-wide pass (tables.hip) or, when the
+// list fills up inside this launch, d_merge_pending
 __device__ void d_import_pending(Seq& S, int64_t K) {
     if (K <= 0) return;
     const int64_t ns = S.table_len - K;
@@ -1486,7 +1490,6 @@ __device__ void d_import_pending(Seq& S, int64_t K) {
     }
     __syncthreads();
     S.n_pend = (int)K;
-    d_merge_pending(S);
 }
 
 // _pos_of_partition_end  src/pcsr.jl:177-186
@@ -1700,7 +1703,8 @@ __global__ __launch_bounds__(SEQ_BLOCK) void k_sequencer(KeyArr keys, double* va
         }
         op = nxt;
     }
-    d_merge_pending(S);            // the tables leave the kernel in key order
+    // pending entries stay at the end of the tables (Ctl::n_pending): the host merges them with the whole chip (tables.hip) when
+    // enough have piled up and before the batch returns; the next launch re-imports what is left
     __syncthreads();
     if (threadIdx.x == 0) {
         ctl->next_op = i;
@@ -1708,7 +1712,7 @@ __global__ __launch_bounds__(SEQ_BLOCK) void k_sequencer(KeyArr keys, double* va
         ctl->err = S.err;
         ctl->err_op = (status == SEQ_ERROR) ? i : -1;
         ctl->nb_elements = S.nb_elements; ctl->nb_partitions = S.nb_partitions; ctl->table_len = S.table_len;
-        ctl->n_pending = 0;
+        ctl->n_pending = S.n_pend;
         ctl->y_ws = S.y_ws; ctl->y_we = S.y_we; ctl->y_m = S.y_m;
         ctl->stat_window_slots = S.stat_window_slots; ctl->stat_rebalances = S.stat_rebalances;
         ctl->stat_small_rebalances = S.stat_small;
