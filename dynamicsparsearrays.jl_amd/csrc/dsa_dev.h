@@ -311,6 +311,8 @@ struct RoundState {
     int32_t d;             // prefix length decided by k_resolve for the round in flight
     int32_t stop;          // 0 running, 1 short prefix at `cursor` (sequencer must take over), 2 batch finished
     int32_t min_prefix, G_next, pad;   // pad: fault flag raised by k_apply (an op left its planned footprint: cannot happen, checked by the host)
+    int32_t ema, pad2;     // running average of the prefix lengths x16 (carried from burst to burst by the host): a short prefix only stops
+                           // the rounds while the recent ones were short too (appends, one hot key), not for one unlucky collision
     int64_t rounds, par_ops;
     int64_t why[8];        // dev: what cut the prefixes (index = Plan::count of the first BARRIER op; 7 = a conflict)
 };

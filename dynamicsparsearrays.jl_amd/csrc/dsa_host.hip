@@ -536,7 +536,7 @@ bool seq_step(SeqRun& r) {
                         (long long)c.prof[8], (long long)c.prof[9], (long long)c.prof[10], (long long)c.prof[11], (long long)c.prof[12], (long long)c.prof[13],
                         (long long)c.prof[14], (long long)c.prof[15]);
             if (getenv("DSA_DBG_RUN") && c.dbg[4])
-                fprintf(stderr, "    model v2: %lld epoch jumps; %lld wide events computed (not memoised) in %.1f us; whole model %.1f us (shader clock)\n", (long long)c.prof[4],
+                fprintf(stderr, "    model v2: %lld in-word ops simulated one by one; %lld epoch jumps; %lld wide events computed (not memoised) in %.1f us; whole model %.1f us (shader clock)\n", (long long)c.prof[3], (long long)c.prof[4],
                         (long long)c.prof[5], c.prof[6] / 2400.0, c.prof[7] / 2400.0);
             // save the bitmap, replay the run on the live bitmap, move the cells; all stream-ordered, no host wait.  The
             // device control block is authoritative afterwards (next_op, nb_elements, tables, statistics): no upload on relaunch.
@@ -608,6 +608,7 @@ int64_t run_ops_parallel(Pma& P, const std::vector<Op>& ops, int32_t* err) {
     static const int64_t SEQ_CHUNK0 = [] { const char* e = getenv("DSA_SEQ_CHUNK"); return e ? (int64_t)atoi(e) : (int64_t)8; }();
     int64_t i = 0, seq_chunk = SEQ_CHUNK0;
     int G = 256;
+    int ema = 16 * 16;                      // RoundState::ema, carried across the bursts of the batch
     // a burst that stops in its first rounds (short conflict-free prefix, barrier op) leaves the rest of its graph as no-op
     // launches (~2.5 us each, four per round): after such a stop the next burst is a short one, until one runs to its end
     int burst_rounds = ROUNDS_PER_SYNC;
@@ -620,7 +621,7 @@ int64_t run_ops_parallel(Pma& P, const std::vector<Op>& ops, int32_t* err) {
         // ---- a burst of rounds driven by the device-resident cursor; one host synchronisation per burst
         RoundState& rs = *P.h_rs;
         std::memset(&rs, 0, sizeof(rs));
-        rs.cursor = i; rs.limit = n; rs.G = G; rs.min_prefix = MIN_PREFIX;
+        rs.cursor = i; rs.limit = n; rs.G = G; rs.min_prefix = MIN_PREFIX; rs.ema = ema;
         HIPCHK(hipMemcpyAsync(P.d_rs, P.h_rs, sizeof(RoundState), hipMemcpyHostToDevice, P.stream));
         {
             ++P.layout_epoch;
@@ -642,7 +643,7 @@ int64_t run_ops_parallel(Pma& P, const std::vector<Op>& ops, int32_t* err) {
         P.stat_par_rounds += rs.rounds + (rs.d > 0 ? 1 : 0); P.stat_par_ops += rs.par_ops + rs.d;
         for (int q = 0; q < 8; ++q) P.stat_why[q] += rs.why[q];
         i = reached;
-        G = rs.G;
+        G = rs.G; ema = rs.ema;
         burst_rounds = (rs.stop == 1 && rs.rounds <= ROUNDS_SHORT) ? ROUNDS_SHORT : ROUNDS_PER_SYNC;
         if (rs.stop != 1) continue;                       // burst used up (0) or batch finished (2)
         // ---- short prefix at op i: sequential sequencer for ops [i, i + seq_chunk)

@@ -255,8 +255,12 @@ __global__ __launch_bounds__(1024) void k_resolve(const Plan* plans, RoundState*
         if (left <= 0) { rs->stop = 2; rs->d = 0; return; }          // finished
         int d = sC1 < sB ? sC1 : sB;
         if (d > G) d = G;
-        // a short prefix means the ops around the cursor collide (appends, one hot key): hand over to the sequencer
-        if (d < rs->min_prefix && d < G) { rs->why[sB <= sC1 ? (plans[sB < G ? sB : 0].count & 7) : 7] += 1; rs->stop = 1; rs->d = 0; return; }
+        // short prefixes one after the other mean the ops around the cursor collide (appends, one hot key): hand over to the
+        // sequencer.  A single short prefix between long ones (a small array, where windows are wide) is still cheaper as a round
+        // of d >= 1 ops than as a sequencer launch.
+        const int ema = (3 * rs->ema + 16 * d) >> 2;
+        rs->ema = ema;
+        if (d < rs->min_prefix && d < G && (d == 0 || ema < 16 * rs->min_prefix)) { rs->why[sB <= sC1 ? (plans[sB < G ? sB : 0].count & 7) : 7] += 1; rs->stop = 1; rs->d = 0; return; }
         rs->d = d;
         int Gn = 2 * d;
         if (Gn < 64) Gn = 64;

@@ -368,33 +368,54 @@ __device__ __forceinline__ int u32(int v) { return __builtin_amdgcn_readfirstlan
 __device__ __forceinline__ uint64_t u64(uint64_t v) {
     return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
 }
+#ifdef DSA_M2_PROF
+#define M2_T() clock64()
+#else
+#define M2_T() 0ll
+#endif
 struct RunMemo;
 __device__ __noinline__ void wave_model2(Model2IO* io, RunMemo* memo, const uint64_t* flags);
 
 constexpr int MEMO_ENTRIES = 640, MEMO_WORDS = 1664;
-constexpr int M2_EV = 1024;
-constexpr int M2_HASH = 256;
+// memo entries: [0, M2_DIRECT) indexed by (level, count) for windows up to 256 slots, the rest hashed by (level, count).  The memo
+// lives in dynamic LDS (128 KB of the CU's 160 KB: the kernel is one workgroup)
+constexpr int M2_DIRECT = 512, M2_HASHED_LOG2 = 11, M2_HASHED = 1 << M2_HASHED_LOG2, M2_EV = M2_DIRECT + M2_HASHED;
+constexpr int M2_HASH_LOG2 = 10, M2_HASH = 1 << M2_HASH_LOG2;
 struct RunMemo {
     uint64_t words[MEMO_WORDS]; unsigned long long gapw[64];
-    // model v2: memo of the rebalances of wide levels up to 512 slots (entry = level base + cell count): counts of the wide levels
-    // below (16 bits each, bit 63 = valid), the last word after the rebalance, and the epoch that follows it — last word, number of
-    // in-word ops, their rebalances and window slots — up to the next op that needs a wide level
+    // model v2: memo of the rebalances of the wide levels, tagged (level << 16 | cell count) — windows up to 256 slots have their own
+    // entry (level base + count), wider ones (up to the 4096-slot block) share a direct-mapped hash: counts of the wide levels below
+    // (12 bits each), the last word after the rebalance, and the EPOCH that follows it — last word, number of in-word ops, their
+    // rebalances and window slots — up to the next op that needs a wide level.  Epoch word: [7:0] ops + 1 (0: none) [8] partial
+    // [16:9] rebalances [30:17] window slots [63:32] tag of the entry (0xffffffff: empty).
     struct alignas(16) M2Entry { uint64_t cnt, lw, eplw, epr; } m2e[M2_EV];      // one 32-byte entry: two 16-byte LDS loads, one wait
-    // epochs behind rebalances of levels WITHOUT an entry (wider than 512 slots): keyed by the last word itself (direct-mapped hash)
-    struct alignas(16) M2Hash { uint64_t key, eplw, epr, pad_; } m2h[M2_HASH];
+    // epochs keyed by the last word after the rebalance and the position of the first semaphore among the ops that follow (8: none
+    // among the first eight): what the entry above cannot hold — rebalances of levels without an entry, and, in a typed run, epochs
+    // that run through semaphore cells (`pat`: the cell types of the epoch's ops, bit k = op k is a semaphore).  Direct-mapped.
+    struct alignas(16) M2Hash { uint64_t key, eplw, epr, pat; } m2h[M2_HASH];
     Model2IO m2;             // model v2: mailbox between wave_fast_appends and wave_model2
 };   // gapw: scratch of the cooperative spread
+
+__device__ __forceinline__ int ep_n(uint64_t r) { return (int)(r & 0xffu) - 1; }
+__device__ __forceinline__ int ep_reb(uint64_t r) { return (int)((r >> 9) & 0xffu); }
+__device__ __forceinline__ int ep_slots(uint64_t r) { return (int)((r >> 17) & 0x3fffu); }
 
 __device__ __noinline__ void wave_model2(Model2IO* io_, RunMemo* memo_, const uint64_t* flags_) {
     constexpr uint64_t TOP = 1ull << 63;
     // arguments of a non-kernel function arrive in vector registers and count as divergent: re-establish them as uniform
     Model2IO* io = (Model2IO*)u64((uint64_t)io_);
     RunMemo* memo = (RunMemo*)u64((uint64_t)memo_);
-    const uint64_t* flags = (const uint64_t*)u64((uint64_t)flags_);
     const int lane = lane_id();
     uint64_t lw = u64(io->lw);
-    int64_t idx = (int64_t)u64((uint64_t)io->idx);
-    const int64_t end = (int64_t)u64((uint64_t)io->end);
+    // ops are counted in 32 bits from a 64-aligned base (64-bit compares have no scalar form): op j is bit (j & 63) of cell-type word
+    // fwp[j >> 6]; a longer run leaves at jend and comes back
+    const int64_t idx0 = (int64_t)u64((uint64_t)io->idx), end0 = (int64_t)u64((uint64_t)io->end);
+    const int64_t base = idx0 & ~63ll;
+    const uint64_t* flags = (const uint64_t*)u64((uint64_t)flags_);
+    const uint64_t* fwp = flags != nullptr ? flags + (base >> 6) : nullptr;
+    const bool typed = fwp != nullptr;               // MappedPackedCSC run: some cells are semaphores
+    int j = u32((int)(idx0 - base));
+    const int jend = u32((int)(end0 - base < 0x7fff0000ll ? end0 - base : 0x7fff0000ll));
     const int nlow = u32(io->nlow), seg = u32(io->seg);
     int lo_s[6], hi_s[6], wb_s[6];
 #pragma unroll
@@ -402,41 +423,123 @@ __device__ __noinline__ void wave_model2(Model2IO* io_, RunMemo* memo_, const ui
     uint32_t cnt = io->cnt[lane];
     const uint32_t my_W = io->W[lane], my_lo = io->lo[lane], my_hi = io->hi[lane];
     const bool lvl_mid = my_W != 0;
-    // memo of the wide levels up to 512 slots: lane h holds the first entry of level h (entry = base + cell count)
+    // memo of the wide levels: lane h holds the first entry of level h for windows up to 256 slots (entry = base + cell count);
+    // wider levels hash (level, count) into [M2_DIRECT, M2_EV)
     int my_eb = -1;
     {
         int eb = 0;
         for (int h = nlow; h < 64; ++h) {
             const int Wh = seg << h;
-            if (Wh > 512 || eb + Wh + 1 > M2_EV) break;
+            if (Wh > 256 || eb + Wh + 1 > M2_DIRECT) break;
             if (h == lane) my_eb = eb;
             eb += Wh + 1;
         }
     }
+    auto entry_of = [&](int h, int c, int eb) -> int {
+        // (levels whose lower wide levels would not fit the 5 x 12-bit counts of an entry — windows of more than 4096 slots — have none)
+        return eb >= 0 ? eb + c : (h - nlow <= 5 ? M2_DIRECT + (int)((((uint32_t)h * 0x9E3779B1u) ^ ((uint32_t)c * 0x85EBCA6Bu)) >> (32 - M2_HASHED_LOG2)) : -1);
+    };
+    auto hslot_of = [&](uint64_t w, int p) -> int { return (int)(((w + (uint64_t)p) * 0x9E3779B97F4A7C15ull) >> (64 - M2_HASH_LOG2)); };
+    const int my_k = lane - nlow < 0 ? 0 : (lane - nlow > 4 ? 4 : lane - nlow);
+    const int my_sh = 12 * my_k;                     // where this level's count sits in a memo entry (at most 5 wide levels below the widest)
     uint32_t ev_c = 0;
     bool ev_valid = false;
     int reb = 0;
     int64_t slots = 0;
-    int need = 0, progressed = 0, dbg_mid = 0, dbg_miss = 0, dbg_why = 0, dbg_jump = 0, dbg_ncmp = 0;
-    int64_t dbg_tcmp = 0;
+    int need = 0, progressed = 0, dbg_mid = 0, dbg_miss = 0, dbg_why = 0, dbg_jump = 0, dbg_ncmp = 0, dbg_sim = 0;
+    int64_t dbg_tcmp = 0, pt_fast = 0, pt_sim = 0, pt_gen = 0;
+    int pn_fast = 0;
     const int64_t dbg_t0 = clock64();
-    int64_t fw_idx = -1;
+    int fw_j = -1;                                   // cell-type word held in fw (index j >> 6)
     uint64_t fw = 0;
-    // epoch being recorded: the in-word ops that follow the rebalance of memo entry ep_entry, up to the next op that needs a wide level
-    int ep_entry = -1, ep_reb0 = 0;                  // >= 0: memo entry; <= -2: slot -2 - ep_entry of the hash table, key ep_key
+    // epoch being recorded: the in-word ops behind the rebalance that left the last word ep_key, up to the next op that needs a wide
+    // level.  Cells only: it goes to the rebalance's memo entry (ep_entry >= 0) or, without one, to the hash under (ep_key, 8).  In a
+    // typed run the cells in front of the first semaphore are recorded there as a PARTIAL epoch (it says nothing about the op behind
+    // it), and the whole epoch with its cell types (at most 8 ops) goes to the hash under (ep_key, position of that semaphore).
+    bool ep_on = false, ep_sem = false;
+    int ep_entry = -1, ep_reb0 = 0, ep_j0 = 0;
+    uint32_t ep_tag = 0, ep_pat = 0;
     uint64_t ep_key = 0;
-    bool ep_sem = false;                             // a semaphore cell was placed inside the epoch: it is not a function of the last word alone
-    int64_t ep_idx0 = 0, ep_slots0 = 0;
-    bool wide_next = false;                          // the op at idx is known to need a wide level (an epoch jump ended in front of it)
-    while (idx < end) {
+    int64_t ep_slots0 = 0;
+    bool wide_next = false;                          // the op at j is known to need a wide level (an epoch jump ended in front of it)
+    auto pack_epoch = [&](bool partial, uint64_t hi32) -> uint64_t {      // 0: does not fit the fields
+        const int n = j - ep_j0, nr = reb - ep_reb0;
+        const int64_t ns = slots - ep_slots0;
+        if (n > 254 || nr > 255 || ns > 16383) return 0ull;
+        return (hi32 << 32) | ((uint64_t)ns << 17) | ((uint64_t)nr << 9) | (partial ? 0x100ull : 0ull) | (uint64_t)(n + 1);
+    };
+    auto record_plain = [&](bool partial) {          // cells only, up to (not including) op j
+        const uint64_t r = pack_epoch(partial, ep_entry >= 0 ? (uint64_t)ep_tag : 0ull);
+        if (r == 0 || lane != 0) return;
+        if (ep_entry >= 0) { memo->m2e[ep_entry].eplw = lw; memo->m2e[ep_entry].epr = r; }
+        else { RunMemo::M2Hash& hs = memo->m2h[hslot_of(ep_key, 8)]; hs.key = ep_key; hs.eplw = lw; hs.epr = r & 0xffffffffull; hs.pat = 0ull; }
+    };
+    auto start_epoch = [&](int entry, uint32_t tag, uint64_t key) {
+        ep_on = true; ep_sem = false; ep_entry = entry; ep_tag = tag; ep_key = key; ep_pat = 0u; ep_j0 = j; ep_reb0 = reb; ep_slots0 = slots;
+    };
+    while (j < jend) {
         // (re-established as wave-uniform every iteration: the loop then stays on the scalar unit)
-        lw = u64(lw); idx = (int64_t)u64((uint64_t)idx);
+        lw = u64(lw); j = u32(j); reb = u32(reb);
+        const int64_t pt0 = M2_T();
+        if (wide_next) {
+            // ---- the common chain: an op that needs a wide level with a memo entry, followed by the recorded epoch of that entry.
+            //      Straight-line and decided before anything is modified; every other case takes the general code below.
+            const uint32_t cnt2 = cnt + (cnt < my_W ? 1u : 0u);
+            const uint64_t acc = __ballot(lvl_mid && my_lo <= cnt2 && cnt2 <= my_hi);
+            if (acc != 0) {
+                const int h = __ffsll((unsigned long long)acc) - 1;
+                const int c = (int)rdlane(cnt2, h);
+                const int eb = (int)rdlane((uint32_t)my_eb, h);
+                const int entry = entry_of(h, c, eb);
+                if (entry >= 0) {
+                    const RunMemo::M2Entry en = memo->m2e[entry];
+                    const uint64_t r = u64(en.epr);
+                    const int n = ep_n(r);
+                    bool ok = (uint32_t)(r >> 32) == (((uint32_t)h << 16) | (uint32_t)c) && n >= 0 && j + 1 + n < jend;
+                    bool next_wide = (r & 0x100u) == 0;
+                    if (typed && ok) {
+                        // the n ops behind the event must be cells (one word of the type flags), and the op behind them too if it is to
+                        // skip the in-word path
+                        const int j1 = j + 1;
+                        if ((j1 >> 6) != fw_j) { fw_j = j1 >> 6; fw = u64(fwp[fw_j]); }
+                        ok = ((j1 + n) >> 6) == fw_j;                              // (then n <= 63)
+                        const uint64_t cells = ((1ull << (n & 63)) - 1ull) << (j1 & 63);
+                        ok = ok && (fw & cells) == 0;
+                        next_wide = next_wide && ((fw >> ((j1 + n) & 63)) & 1ull) == 0;
+                    }
+                    if (ok) {
+                        const uint32_t below = (uint32_t)(en.cnt >> my_sh) & 0xfffu;
+                        cnt = (lane < h && lvl_mid) ? below : cnt2;
+                        if (lane == h) { ev_c = (uint32_t)c; ev_valid = true; }
+                        else if (lane < h) ev_valid = false;
+                        const uint32_t room = my_W - cnt;                  // cnt <= my_W
+                        cnt += (uint32_t)n < room ? (uint32_t)n : room;
+                        j += 1; reb += 1; slots += (int64_t)(seg << h);
+                        if (r & 0x100u) {
+                            // a partial epoch (it was cut by a semaphore when it was recorded): keep recording from the event on, a
+                            // longer one replaces it when this visit gets further
+                            start_epoch(entry, (uint32_t)(r >> 32), u64(en.lw));
+                        }
+                        lw = u64(en.eplw);
+                        j += n; reb += ep_reb(r); slots += (int64_t)ep_slots(r);
+                        progressed = 1; ++dbg_mid; ++dbg_jump;
+                        wide_next = next_wide;
+                        pt_fast += M2_T() - pt0; ++pn_fast;
+                        continue;
+                    }
+                }
+            }
+        }
+        bool is_sem = false;
         if (!wide_next) {
-            bool is_sem = false;
-            if (flags != nullptr) {
-                if ((idx >> 6) != fw_idx) { fw_idx = idx >> 6; fw = u64(flags[fw_idx]); }
-                is_sem = (fw >> (idx & 63)) & 1ull;
-                ep_sem = ep_sem || is_sem;
+            if (typed) {
+                if ((j >> 6) != fw_j) { fw_j = j >> 6; fw = u64(fwp[fw_j]); }
+                is_sem = (fw >> (j & 63)) & 1ull;
+                if (is_sem && ep_on) {
+                    if (!ep_sem) record_plain(true);              // the cells so far are a valid (partial) epoch of the entry
+                    ep_sem = true;
+                    if (j - ep_j0 < 8) ep_pat |= 1u << (j - ep_j0); else ep_on = false;
+                }
             }
             // ---- the insert, on the last word  (a branch-free form of this block — selects between the three inserts, all six
             //      levels evaluated — was measured slower: 12.6 vs 10.2 ms per 41 k appends; the cost is instructions, not branches)
@@ -492,26 +595,31 @@ __device__ __noinline__ void wave_model2(Model2IO* io_, RunMemo* memo_, const ui
                 }
                 lw = nw;
                 cnt += cnt < my_W ? 1u : 0u;
-                ++idx; progressed = 1;
+                ++j; progressed = 1; ++dbg_sim;
+                pt_sim += M2_T() - pt0;
                 continue;
             }
         }
         wide_next = false;
-        // ---- the op needs a level wider than a word.  The epoch since the last memoised rebalance ends in front of it: record it
-        if (ep_entry != -1) {
-            const int64_t n = idx - ep_idx0;
-            if (!ep_sem && n < 65535 && reb - ep_reb0 < 65535 && slots - ep_slots0 < (1ll << 31) && lane == 0) {
-                const uint64_t r = ((uint64_t)(uint32_t)(slots - ep_slots0) << 32) | ((uint64_t)(uint32_t)(reb - ep_reb0) << 16) | (uint64_t)(n + 1);
-                if (ep_entry >= 0) { memo->m2e[ep_entry].eplw = lw; memo->m2e[ep_entry].epr = r; }
-                else { RunMemo::M2Hash& hs = memo->m2h[-2 - ep_entry]; hs.key = ep_key; hs.eplw = lw; hs.epr = r; }
+        // ---- the op needs a level wider than a word.  The epoch being recorded ends in front of it.
+        if (ep_on) {
+            if (!ep_sem) record_plain(false);
+            else if (j - ep_j0 < 8) {
+                // the whole epoch with its cell types, under (last word behind the rebalance, position of the first semaphore)
+                const uint32_t pat = ep_pat | (is_sem ? 1u << (j - ep_j0) : 0u);          // bit n: the op that did not fit
+                const uint64_t r = pack_epoch(false, 0ull);
+                if (r != 0 && lane == 0) {
+                    RunMemo::M2Hash& hs = memo->m2h[hslot_of(ep_key, __ffs((int)ep_pat) - 1)];
+                    hs.key = ep_key; hs.eplw = lw; hs.epr = r; hs.pat = (uint64_t)pat;
+                }
             }
-            ep_entry = -1;
+            ep_on = false;
         }
         const uint32_t cnt2 = cnt + (cnt < my_W ? 1u : 0u);
         const uint64_t acc = __ballot(lvl_mid && my_lo <= cnt2 && cnt2 <= my_hi);
         if (acc == 0) { need = 1; dbg_why = 3; break; }         // a window wider than the block (or _extend!) decides
         cnt = cnt2;
-        ++idx; progressed = 1; ++dbg_mid;
+        ++j; progressed = 1; ++dbg_mid;
         const int h = __ffsll((unsigned long long)acc) - 1;
         const int W = seg << h;
         const int c = (int)rdlane(cnt, h);
@@ -519,13 +627,16 @@ __device__ __noinline__ void wave_model2(Model2IO* io_, RunMemo* memo_, const ui
         if (lane == h) { ev_c = (uint32_t)c; ev_valid = true; }
         else if (lane < h) ev_valid = false;
         const int eb = (int)rdlane((uint32_t)my_eb, h);
-        const int entry = eb >= 0 ? eb + c : -1;
+        const int entry = entry_of(h, c, eb);
+        const uint32_t tagv = ((uint32_t)h << 16) | (uint32_t)c;
         uint64_t e = 0, en_lw = 0, en_eplw = 0, en_epr = 0;
+        bool filled = false;
         if (entry >= 0) {
             const RunMemo::M2Entry en = memo->m2e[entry];
             e = u64(en.cnt); en_lw = u64(en.lw); en_eplw = u64(en.eplw); en_epr = u64(en.epr);
+            filled = (uint32_t)(en_epr >> 32) == tagv;
         }
-        if (e == 0) {
+        if (!filled) {
             en_epr = 0;
             const int64_t tc0 = clock64();
             ++dbg_ncmp;
@@ -539,55 +650,85 @@ __device__ __noinline__ void wave_model2(Model2IO* io_, RunMemo* memo_, const ui
             const bool cell = !slot_is_gap(g, W - 63 + lane, &rank);
             lw = __ballot(cell);
             if (lane < h && lvl_mid) cnt = below;
-            if (entry >= 0) {          // counts of the (at most three) wide levels below h, 16 bits each
-                e = (uint64_t)rdlane(below, nlow) | ((uint64_t)rdlane(below, nlow + 1) << 16) | ((uint64_t)rdlane(below, nlow + 2) << 32) | (1ull << 63);
-                if (lane == 0) { memo->m2e[entry].cnt = e; memo->m2e[entry].lw = lw; memo->m2e[entry].epr = 0ull; }
+            if (entry >= 0) {          // counts of the (at most five) wide levels below h, 12 bits each (a level below h holds < 4096 slots)
+                e = (uint64_t)rdlane(below, nlow) | ((uint64_t)rdlane(below, nlow + 1) << 12) | ((uint64_t)rdlane(below, nlow + 2) << 24) |
+                    ((uint64_t)rdlane(below, nlow + 3) << 36) | ((uint64_t)rdlane(below, nlow + 4) << 48);
+                if (lane == 0) { memo->m2e[entry].cnt = e; memo->m2e[entry].lw = lw; memo->m2e[entry].epr = (uint64_t)tagv << 32; }
             }
             dbg_tcmp += clock64() - tc0;
         } else {
-            const int k = lane - nlow;
-            if (lane < h && lvl_mid) cnt = (uint32_t)(e >> (16 * (k & 3))) & 0xffffu;
+            if (lane < h && lvl_mid) cnt = (uint32_t)(e >> my_sh) & 0xfffu;
             lw = en_lw;
         }
-        int hslot = -1;
-        if (entry < 0) {                           // no memo entry for this level: the epoch cache keyed by the last word
-            hslot = (int)((lw * 0x9E3779B97F4A7C15ull) >> 56) & (M2_HASH - 1);
-            const RunMemo::M2Hash hs = memo->m2h[hslot];
-            const bool hit = u64(hs.key) == lw;
-            en_eplw = u64(hs.eplw);
-            en_epr = hit ? u64(hs.epr) : 0ull;
+        // ---- the in-word ops that follow are a function of the new last word and of their cell types alone: replay them from the memo
+        uint32_t pat8 = 0;                             // cell types of the next (up to 8) ops, as far as the current type word reaches
+        int pat_n = 8;
+        if (typed) {
+            if ((j >> 6) != fw_j) { fw_j = j >> 6; fw = u64(fwp[fw_j]); }
+            pat8 = (uint32_t)(fw >> (j & 63)) & 0xffu;
+            pat_n = 64 - (j & 63) < 8 ? 64 - (j & 63) : 8;
+            pat8 &= (1u << pat_n) - 1u;
         }
-        {
-            // the in-word ops that follow are a function of the new last word alone as long as they are all cells: replay them
-            // from the memo (a matrix run: only if none of the next n cells is a semaphore, read from one word of the type flags)
-            const uint64_t r = en_epr;
-            const int64_t n = (int64_t)(r & 0xffffu) - 1;
-            bool cells_only = true;
-            if (flags != nullptr && n > 0) {
-                if ((idx >> 6) != ((idx + n - 1) >> 6)) cells_only = false;
-                else {
-                    if ((idx >> 6) != fw_idx) { fw_idx = idx >> 6; fw = u64(flags[fw_idx]); }
-                    const uint64_t m = (n >= 64 ? ~0ull : ((1ull << n) - 1ull)) << (idx & 63);
-                    cells_only = (fw & m) == 0;
-                }
+        const int p_sem = pat8 != 0 ? __ffs((int)pat8) - 1 : 8;      // position of the first semaphore among the next ops (8: none)
+        // the hash: (last word, position of the first semaphore) — rebalances without an entry, and epochs that run through semaphores
+        auto try_hash = [&](int p) -> bool {
+            const RunMemo::M2Hash hs = memo->m2h[hslot_of(lw, p)];
+            const uint64_t r = u64(hs.epr);
+            const int n = ep_n(r);
+            const uint32_t hp = (uint32_t)u64(hs.pat);
+            bool ok = u64(hs.key) == lw && n >= 0 && j + n < jend;
+            if (ok && typed) {
+                if (p < 8) ok = n + 1 <= pat_n && ((pat8 ^ hp) & ((2u << n) - 1u)) == 0;          // the same types for the n ops and the op behind them
+                else ok = hp == 0 && (j >> 6) == ((j + n) >> 6) && (fw & (((2ull << (n & 63)) - 1ull) << (j & 63))) == 0;
             }
-            if (n >= 0 && idx + n < end && cells_only) {
+            if (!ok) return false;
+            lw = u64(hs.eplw);
+            j += n;
+            const uint32_t room = my_W - cnt;                      // cnt <= my_W
+            cnt += (uint32_t)n < room ? (uint32_t)n : room;
+            reb += ep_reb(r); slots += (int64_t)ep_slots(r);
+            // the op behind it had this type when the epoch was recorded and needed a wide level: it does again (kept to cells)
+            wide_next = (r & 0x100u) == 0 && !((hp >> n) & 1u);      // (a partial epoch says nothing about the op behind it)
+            ++dbg_jump;
+            if (p == 8 && entry >= 0 && lane == 0) { memo->m2e[entry].eplw = lw; memo->m2e[entry].epr = ((uint64_t)tagv << 32) | (r & 0xffffffffull); }
+            return true;
+        };
+        bool jumped = false;
+        if (p_sem < 8) jumped = try_hash(p_sem);
+        if (!jumped) {
+            // the cells-only epoch of the entry
+            const uint64_t r = en_epr;
+            const int n = ep_n(r);
+            bool cells_only = true;
+            if (typed && n > 0) {
+                if ((j >> 6) != ((j + n - 1) >> 6)) cells_only = false;
+                else cells_only = (fw & (((1ull << (n & 63)) - 1ull) << (j & 63))) == 0;
+            }
+            if (n >= 0 && j + n < jend && cells_only) {
+                if (r & 0x100u) start_epoch(entry, tagv, lw);      // partial epoch: go on recording, a longer one replaces it
                 lw = en_eplw;
-                idx += n;
+                j += n;
                 const uint32_t room = my_W - cnt;                  // cnt <= my_W
                 cnt += (uint32_t)n < room ? (uint32_t)n : room;
-                reb += (int)((r >> 16) & 0xffffu);
-                slots += (int64_t)(r >> 32);
-                // the op behind the epoch was a cell when it was recorded (it did not fit the word): the same holds now if it is a cell
-                // again; a semaphore there may still fit the word and takes the in-word path first
-                wide_next = flags == nullptr || ((idx >> 6) == fw_idx && ((fw >> (idx & 63)) & 1ull) == 0);
+                reb += ep_reb(r); slots += (int64_t)ep_slots(r);
+                // the op behind a complete epoch was a cell when it was recorded (it did not fit the word): the same holds now if it is a
+                // cell again; a semaphore there may still fit the word and takes the in-word path first.  A partial epoch says nothing.
+                wide_next = (r & 0x100u) == 0 && (!typed || ((j >> 6) == fw_j && ((fw >> (j & 63)) & 1ull) == 0));
                 ++dbg_jump;
-            } else if (n < 0) { ep_entry = entry >= 0 ? entry : -2 - hslot; ep_key = lw; ep_idx0 = idx; ep_reb0 = reb; ep_slots0 = slots; ep_sem = false; }
+                jumped = true;
+            }
         }
+        if (!jumped && p_sem == 8) jumped = try_hash(8);
+        if (!jumped) start_epoch(entry, tagv, lw);
+        pt_gen += M2_T() - pt0;
     }
     io->ev_c[lane] = ev_c; io->ev_valid[lane] = ev_valid ? 1u : 0u;
-    if (lane == 0) { io->lw = lw; io->idx = idx; io->need = need; io->progressed = progressed; io->reb = reb; io->slots = slots;
-                     io->dbg_mid = dbg_mid; io->dbg_miss = dbg_miss; io->dbg_why = dbg_why; io->dbg_t[0] = dbg_jump; io->dbg_t[1] = dbg_ncmp; io->dbg_t[2] = dbg_tcmp; io->dbg_t[3] = clock64() - dbg_t0; }
+    if (lane == 0) { io->lw = lw; io->idx = base + j; io->need = need; io->progressed = progressed; io->reb = reb; io->slots = slots;
+                     io->dbg_mid = dbg_mid; io->dbg_miss = dbg_miss; io->dbg_why = dbg_why; io->dbg_pad = dbg_sim; io->dbg_t[0] = dbg_jump; io->dbg_t[1] = dbg_ncmp; io->dbg_t[2] = dbg_tcmp; io->dbg_t[3] = clock64() - dbg_t0;
+#ifdef DSA_M2_PROF
+                     printf("m2 prof: fast %d events %lld clk, sim %d ops %lld clk, general %d events %lld clk, total %lld\n", pn_fast, (long long)pt_fast, dbg_sim, (long long)pt_sim, dbg_mid - pn_fast, (long long)pt_gen, (long long)(clock64() - dbg_t0));
+#endif
+    }
 }
 
 // wave 0: replays appends rc->idx .. end-1 on the register-resident block until one needs the workgroup path (need = 1).
@@ -748,7 +889,7 @@ __device__ void wave_fast_appends(Seq& S, RunComm* rc, RunMemo* memo, const uint
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_s_waitcnt(0xc07f);
                 if (lane == 0) { S.ctl->prof[8] += 1; S.ctl->prof[9] += io->idx - (int64_t)idx; S.ctl->prof[10] += io->dbg_mid; S.ctl->prof[11] += io->dbg_miss;
-                                 S.ctl->prof[12 + (io->dbg_why & 3)] += 1; S.ctl->prof[4] += io->dbg_t[0]; S.ctl->prof[5] += io->dbg_t[1]; S.ctl->prof[6] += io->dbg_t[2]; S.ctl->prof[7] += io->dbg_t[3]; }
+                                 S.ctl->prof[12 + (io->dbg_why & 3)] += 1; S.ctl->prof[3] += io->dbg_pad; S.ctl->prof[4] += io->dbg_t[0]; S.ctl->prof[5] += io->dbg_t[1]; S.ctl->prof[6] += io->dbg_t[2]; S.ctl->prof[7] += io->dbg_t[3]; }
                 idx = (P)io->idx; reb += io->reb; slots += io->slots;
                 const uint64_t lw = io->lw;
                 fw_idx = -1;                                   // (the callee read the cell-type words itself)
@@ -1098,10 +1239,11 @@ __global__ __launch_bounds__(SEQ_BLOCK) void k_append_run(uint64_t* occ, Ctl* ct
                                                           const int64_t* d_T, int wide_pos, int no_model) {
     __shared__ int64_t sRed[SEQ_BLOCK / 64];
     __shared__ RunComm sRun;
-    __shared__ RunMemo sMemo;
+    extern __shared__ __attribute__((aligned(16))) unsigned char run_lds[];
+    RunMemo& sMemo = *reinterpret_cast<RunMemo*>(run_lds);
     __shared__ int64_t sLo[MAX_LEVELS], sHi[MAX_LEVELS];
     for (int k = threadIdx.x; k < MEMO_WORDS; k += SEQ_BLOCK) sMemo.words[k] = 0ull;      // 0 = entry not computed yet
-    for (int k = threadIdx.x; k < M2_EV; k += SEQ_BLOCK) { sMemo.m2e[k].cnt = 0ull; sMemo.m2e[k].epr = 0ull; }
+    for (int k = threadIdx.x; k < M2_EV; k += SEQ_BLOCK) { sMemo.m2e[k].cnt = 0ull; sMemo.m2e[k].epr = ~0ull << 32; }
     for (int k = threadIdx.x; k < M2_HASH; k += SEQ_BLOCK) { sMemo.m2h[k].key = 0ull; sMemo.m2h[k].epr = 0ull; }
     Seq S;
     S.keys = KeyArr{nullptr, 1, 0}; S.vals = nullptr; S.occ = occ; S.sems = nullptr; S.col_keys = nullptr; S.col_live = nullptr; S.ctl = ctl;
@@ -1207,7 +1349,14 @@ hipError_t launch_append_run(uint64_t* occ, Ctl* ctl, int64_t i0, int64_t R, con
     static const int wide_pos = [] { const char* e = getenv("DSA_POS_WIDE"); return (e && e[0] == '1') ? 1 : 0; }();   // dev knob: 64-bit positions
     // dev knob DSA_COUNT_MODEL=0: bitmap replay only (the general per-op path; A/B runs and coverage of that path)
     static const int no_model = [] { const char* e = getenv("DSA_COUNT_MODEL"); return (e && e[0] == '0') ? 1 : 0; }();
-    hipLaunchKernelGGL(k_append_run, dim3(1), dim3(SEQ_BLOCK), 0, stream, occ, ctl, i0, R, flags, d_T, wide_pos, no_model);
+    static PerDeviceOnce once;
+    {
+        hipError_t e = once.run([] {
+            return hipFuncSetAttribute(reinterpret_cast<const void*>(k_append_run), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(RunMemo));
+        });
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(k_append_run, dim3(1), dim3(SEQ_BLOCK), sizeof(RunMemo), stream, occ, ctl, i0, R, flags, d_T, wide_pos, no_model);
     return hipGetLastError();
 }
 
