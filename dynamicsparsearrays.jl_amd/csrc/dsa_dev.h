@@ -308,10 +308,11 @@ struct RoundState {
     int64_t cursor;        // next op of the batch
     int64_t limit;         // one past the last op
     int32_t G;             // ops planned per round (adapted on the device to 2x the last prefix, 64..1024)
-    int32_t d;             // prefix length decided by k_resolve for the round in flight
+    int32_t d;             // prefix length decided by the resolve step (k_plan's last workgroup) for the round in flight
     int32_t stop;          // 0 running, 1 short prefix at `cursor` (sequencer must take over), 2 batch finished
     int32_t min_prefix, G_next, pad;   // pad: fault flag raised by k_apply (an op left its planned footprint: cannot happen, checked by the host)
-    int32_t ema, pad2;     // running average of the prefix lengths x16 (carried from burst to burst by the host): a short prefix only stops
+    uint32_t ticket;       // workgroups of k_plan that have finished (the last one resolves the round; 0 between launches)
+    int32_t ema;           // running average of the prefix lengths x16 (carried from burst to burst by the host): a short prefix only stops
                            // the rounds while the recent ones were short too (appends, one hot key), not for one unlucky collision
     int64_t rounds, par_ops;
     int64_t why[8];        // dev: what cut the prefixes (index = Plan::count of the first BARRIER op; 7 = a conflict)

@@ -634,7 +634,7 @@ int64_t run_ops_parallel(Pma& P, const std::vector<Op>& ops, int32_t* err) {
         HIPCHK(hipMemcpyAsync(P.h_ctl, P.d_ctl, sizeof(Ctl), hipMemcpyDeviceToHost, P.stream));      // table_len, n_pending, counts of the burst
         HIPCHK(hipStreamSynchronize(P.stream));
         t_burst += ms(tb0, now()); ++n_burst;
-        // the prefix of the last round of the burst has been applied but is folded into the cursor only by the next k_resolve
+        // the prefix of the last round of the burst has been applied but is folded into the cursor only by the next round's resolve step
         if (rs.pad != 0) fail(DSA_EASSERT, "batch-parallel column creation left its footprint (internal invariant)");
         const int64_t reached = rs.cursor + rs.d;
         if (reached > i) seq_chunk = SEQ_CHUNK0;

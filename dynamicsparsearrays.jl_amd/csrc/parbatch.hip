@@ -9,9 +9,9 @@
 //             the hull of { predecessor slot and the slot after it (what find depends on), the shifted run, the accepted
 //             window (every window whose count was consulted lies inside it) }.  Ops whose scan is not accepted within
 //             PB_MAX_W slots (big rebalance, _extend!, _shrink!), or that are not vector writes, are BARRIERs.
-//   k_resolve (one workgroup): an op conflicts if its footprint overlaps another op's.  Every overlapping pair (i < j)
-//             has j >= the second-smallest conflicting index c1, so ops [0, d), d = min(c1, first BARRIER), are pairwise
-//             disjoint: each of them sees, when executed alone in order, exactly the state it was planned on.
+//   resolve   (the workgroup of k_plan that finishes last, found by a ticket — no launch of its own): d = min(first BARRIER,
+//             smallest j whose footprint overlaps the footprint of an EARLIER op).  Ops [0, d) are pairwise disjoint: each of
+//             them sees, when executed alone in order, exactly the state it was planned on.
 //   k_apply   (one wave per op): shift, write, occupancy update (atomics: footprints are disjoint in slots, not in 64-slot
 //             bitmap words), then the small-window pack + spread through the wave's LDS slice.
 //
@@ -24,6 +24,7 @@ namespace dsa {
 
 constexpr int PB_BLOCK = 256;                 // 4 waves = 4 ops per workgroup
 constexpr int PB_MAX_W = 1024;                // largest window a single wave rebalances (16 KB of LDS per wave)
+constexpr int PB_GMAX = 1024;                 // ops planned per round at most (one wave each)
 
 enum : int32_t { PB_NOOP = 0, PB_OVERWRITE = 1, PB_INS_R = 2, PB_INS_L = 3, PB_DELETE = 4, PB_BARRIER = 5, PB_NEWCOL = 6 };
 constexpr int64_t PB_PEND_MAX = 1024;         // = PEND_MAX of the sequencer, which imports and merges the pending table entries
@@ -48,14 +49,14 @@ __device__ int64_t pb_wave_count(const uint64_t* occ, int64_t ws, int64_t we, bo
 
 __global__ __launch_bounds__(PB_BLOCK) void k_plan(KeyArr keys, const double* vals, const uint64_t* occ,
                                                    const int64_t* sems, const int64_t* col_keys, const uint8_t* col_live,
-                                                   const Ctl* ctl, const Op* ops, const RoundState* rs, Plan* plans) {
+                                                   const Ctl* ctl, const Op* ops, RoundState* rs, Plan* plans) {
     // the round's window of ops comes from the device-resident cursor: rounds are enqueued back to back without host syncs
     if (rs->stop) return;
-    const int64_t i0 = rs->cursor + rs->d;            // k_resolve of this round folds the previous prefix into the cursor
+    const int64_t i0 = rs->cursor + rs->d;            // the resolve step of this round folds the previous prefix into the cursor
     const int64_t left = rs->limit - i0;
     const int G = (int)(left < rs->G ? left : rs->G);
     const int w = blockIdx.x * (PB_BLOCK / 64) + (threadIdx.x >> 6);
-    if (w >= G) return;
+    if (w < G) {
     const int64_t capacity = ctl->capacity, seg = ctl->segment_capacity, height = ctl->height;
     const Op op = ops[i0 + w];
     Plan pl;
@@ -199,72 +200,67 @@ __global__ __launch_bounds__(PB_BLOCK) void k_plan(KeyArr keys, const double* va
     }
     if (pl.action == PB_BARRIER) pl.count = why;
     if (lane_id() == 0) plans[w] = pl;
-}
-
-// pairwise overlap test, spread over the grid: block b owns 64 candidate partners j, thread i tests op i against them
-__global__ __launch_bounds__(1024) void k_conflicts(const Plan* plans, const RoundState* rs, uint32_t* flags) {
-    if (rs->stop) return;
-    const int64_t left = rs->limit - (rs->cursor + rs->d);
-    const int G = (int)(left < rs->G ? left : rs->G);
-    __shared__ int64_t sLo[64], sHi[64];
-    const int i = threadIdx.x, j0 = blockIdx.x * 64;
-    if (j0 >= G) return;
-    if (i < 64) {
-        int64_t lo = 1, hi = 0;
-        if (j0 + i < G) { lo = plans[j0 + i].lo; hi = plans[j0 + i].hi; }
-        sLo[i] = lo; sHi[i] = hi;
+    }
+    // ---- resolve, by the workgroup that finishes last (a ticket; no second and third launch per round): folds the previous round's
+    //      prefix into the cursor and decides this round's prefix d = min(first BARRIER, smallest j whose footprint overlaps the footprint
+    //      of an earlier op): ops [0, d) are pairwise disjoint, each sees exactly the state it was planned on.  k_apply works on (cursor, d).
+    __shared__ int sLast, sC, sB;
+    __shared__ int64_t sLo[PB_GMAX], sHi[PB_GMAX];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();                                               // this workgroup's plans are visible device-wide before its ticket
+        const unsigned t = atomicAdd(&rs->ticket, 1u);
+        sLast = t == gridDim.x - 1 ? 1 : 0;
+        sC = G; sB = G;
     }
     __syncthreads();
-    if (i >= G) return;
-    const int64_t lo = plans[i].lo, hi = plans[i].hi;
-    if (lo > hi) return;
-    bool conflict = false;
-#pragma unroll 8
-    for (int k = 0; k < 64; ++k) {
-        const int64_t l2 = sLo[k], h2 = sHi[k];
-        conflict = conflict || (j0 + k != i && l2 <= h2 && l2 <= hi && lo <= h2);
-    }
-    if (conflict) flags[i] = 1u;
-}
-
-// single workgroup: (1) folds the previous round's prefix into the cursor, (2) decides this round's prefix
-// d = min(second-smallest conflicting op, first barrier) and the next group size.  k_apply then works on (cursor, d).
-__global__ __launch_bounds__(1024) void k_resolve(const Plan* plans, RoundState* rs, uint32_t* flags) {
-    if (rs->stop) return;
-    __shared__ int sC0, sC1, sB;
-    const int d_prev = rs->d;
-    const int64_t i0 = rs->cursor + d_prev;
-    const int64_t left = rs->limit - i0;
-    const int G = (int)(left < rs->G ? left : rs->G);
-    const int i = threadIdx.x;
-    if (i == 0) { sC0 = G; sC1 = G; sB = G; }
-    __syncthreads();
-    bool conflict = false;
-    if (i < G) {
-        conflict = flags[i] != 0u;
-        flags[i] = 0u;                                               // re-armed for the next round
-        if (conflict) atomicMin(&sC0, i);
-        if (plans[i].action == PB_BARRIER) atomicMin(&sB, i);
+    if (!sLast) return;
+    __threadfence();                                                   // (acquire: the other workgroups' plans)
+    const int tid = threadIdx.x;
+    for (int j = tid; j < G; j += PB_BLOCK) {
+        const Plan* q = plans + j;
+        sLo[j] = __hip_atomic_load(&q->lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sHi[j] = __hip_atomic_load(&q->hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__hip_atomic_load(&q->action, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == PB_BARRIER) atomicMin(&sB, j);
     }
     __syncthreads();
-    if (conflict && i > sC0) atomicMin(&sC1, i);
-    __syncthreads();
-    if (i == 0) {
+    // smallest j that overlaps an earlier op, in chunks of PB_BLOCK ops (a hit in a chunk ends the search; ops behind the first BARRIER do not matter)
+    for (int j0 = 0; j0 < G; j0 += PB_BLOCK) {
+        const int j = j0 + tid;
+        if (j < G && j < sB) {
+            const int64_t lo = sLo[j], hi = sHi[j];
+            if (lo <= hi) {
+                bool hit = false;
+                for (int i = 0; i < j && !hit; ++i) { const int64_t l2 = sLo[i], h2 = sHi[i]; hit = l2 <= h2 && l2 <= hi && lo <= h2; }
+                if (hit) atomicMin(&sC, j);
+            }
+        }
+        __syncthreads();
+        const int c_now = sC;
+        __syncthreads();                                               // (everyone has read sC before the next chunk may lower it)
+        if (c_now < G || j0 + PB_BLOCK >= sB) break;
+    }
+    if (tid == 0) {
+        const int d_prev = rs->d;
+        rs->ticket = 0u;                                               // re-armed for the next round
         rs->cursor = i0;
         if (d_prev > 0) { rs->rounds += 1; rs->par_ops += d_prev; }
-        if (left <= 0) { rs->stop = 2; rs->d = 0; return; }          // finished
-        int d = sC1 < sB ? sC1 : sB;
+        if (left <= 0) { rs->stop = 2; rs->d = 0; return; }           // finished
+        int d = sC < sB ? sC : sB;
         if (d > G) d = G;
         // short prefixes one after the other mean the ops around the cursor collide (appends, one hot key): hand over to the
         // sequencer.  A single short prefix between long ones (a small array, where windows are wide) is still cheaper as a round
         // of d >= 1 ops than as a sequencer launch.
         const int ema = (3 * rs->ema + 16 * d) >> 2;
         rs->ema = ema;
-        if (d < rs->min_prefix && d < G && (d == 0 || ema < 16 * rs->min_prefix)) { rs->why[sB <= sC1 ? (plans[sB < G ? sB : 0].count & 7) : 7] += 1; rs->stop = 1; rs->d = 0; return; }
+        if (d < rs->min_prefix && d < G && (d == 0 || ema < 16 * rs->min_prefix)) {
+            rs->why[sB <= sC ? (__hip_atomic_load(&plans[sB < G ? sB : 0].count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 7) : 7] += 1;
+            rs->stop = 1; rs->d = 0; return;
+        }
         rs->d = d;
         int Gn = 2 * d;
         if (Gn < 64) Gn = 64;
-        if (Gn > 1024) Gn = 1024;
+        if (Gn > PB_GMAX) Gn = PB_GMAX;
         rs->G_next = Gn;
     }
 }
@@ -549,7 +545,7 @@ __global__ __launch_bounds__(PB_BLOCK) void k_apply(KeyArr keys, double* vals, u
     }
 }
 
-// one round = plan -> conflicts -> resolve (+ cursor advance) -> apply, all driven by the device-resident RoundState
+// one round = plan (+ resolve and cursor advance by its last workgroup) -> apply, all driven by the device-resident RoundState
 static hipError_t configure_apply() {
     static PerDeviceOnce once;
     return once.run([] {
@@ -561,11 +557,9 @@ static hipError_t enqueue_round(KeyArr keys, double* vals, uint64_t* occ, int64_
                                 uint8_t* col_live, Ctl* ctl, const Op* ops, RoundState* rs, Plan* plans, uint32_t* flags,
                                 hipStream_t stream) {
     const size_t lds = (size_t)(PB_BLOCK / 64) * PB_MAX_W * (sizeof(int64_t) + sizeof(double));
-    constexpr int GMAX = 1024;
-    hipLaunchKernelGGL(k_plan, dim3(GMAX / 4), dim3(PB_BLOCK), 0, stream, keys, vals, occ, sems, col_keys, col_live, ctl, ops, rs, plans);
-    hipLaunchKernelGGL(k_conflicts, dim3(GMAX / 64), dim3(1024), 0, stream, plans, rs, flags);
-    hipLaunchKernelGGL(k_resolve, dim3(1), dim3(1024), 0, stream, plans, rs, flags);
-    hipLaunchKernelGGL(k_apply, dim3(GMAX / 4), dim3(PB_BLOCK), lds, stream, keys, vals, occ, sems, col_keys, col_live, ctl, ops, rs, plans);
+    (void)flags;
+    hipLaunchKernelGGL(k_plan, dim3(PB_GMAX / 4), dim3(PB_BLOCK), 0, stream, keys, vals, occ, sems, col_keys, col_live, ctl, ops, rs, plans);
+    hipLaunchKernelGGL(k_apply, dim3(PB_GMAX / 4), dim3(PB_BLOCK), lds, stream, keys, vals, occ, sems, col_keys, col_live, ctl, ops, rs, plans);
     return hipGetLastError();
 }
 

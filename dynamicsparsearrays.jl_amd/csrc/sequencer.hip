@@ -447,8 +447,9 @@ __device__ __noinline__ void wave_model2(Model2IO* io_, RunMemo* memo_, const ui
     int reb = 0;
     int64_t slots = 0;
     int need = 0, progressed = 0, dbg_mid = 0, dbg_miss = 0, dbg_why = 0, dbg_jump = 0, dbg_ncmp = 0, dbg_sim = 0;
-    int64_t dbg_tcmp = 0, pt_fast = 0, pt_sim = 0, pt_gen = 0;
-    int pn_fast = 0;
+    int64_t dbg_tcmp = 0;
+    [[maybe_unused]] int64_t pt_fast = 0, pt_sim = 0, pt_gen = 0;      // dev profile, -DDSA_M2_PROF
+    [[maybe_unused]] int pn_fast = 0;
     const int64_t dbg_t0 = clock64();
     int fw_j = -1;                                   // cell-type word held in fw (index j >> 6)
     uint64_t fw = 0;
