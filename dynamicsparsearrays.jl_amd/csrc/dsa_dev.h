@@ -322,8 +322,11 @@ struct BurstGraph {        // cached hipGraph of one burst of rounds (host-side)
     const void* key[12] = {};
     bool disabled = false;
 };
-hipError_t launch_burst(KeyArr keys, double* vals, uint64_t* occ, int64_t* sems, int64_t* col_keys, uint8_t* col_live,
-                        Ctl* ctl, const Op* ops, RoundState* rs, Plan* plans, uint32_t* flags, int rounds, BurstGraph* cache,
+// the arrays the rounds work on, read by the kernels from device memory: a root rebalance swaps the slot buffers and the tables
+// grow, but the launch arguments — and with them the cached graph — stay the same (re-instantiating the graphs after every
+// _extend! cost ~1 ms a time while an array was growing)
+struct DevBufs { void* keys; double* vals; uint64_t* occ; int64_t* sems; int64_t* col_keys; uint8_t* col_live; int32_t wide, pad; };
+hipError_t launch_burst(const DevBufs* bufs, Ctl* ctl, const Op* ops, RoundState* rs, Plan* plans, int rounds, BurstGraph* cache,
                         hipStream_t stream);
 void burst_graph_destroy(BurstGraph* cache);
 

@@ -85,7 +85,8 @@ struct Pma {
     int32_t* d_err = nullptr;
     int64_t stat_par_rounds = 0, stat_par_ops = 0, stat_seq_ops = 0, stat_seq_launches = 0;      // batch-parallel instrumentation
     BurstGraph burst, burst_short;      // cached graphs of a full burst of rounds and of a short one (conflict-heavy phases)
-    Plan* d_plans = nullptr; uint32_t* d_flags = nullptr; RoundState* d_rs = nullptr; RoundState* h_rs = nullptr;   // batch-parallel writes
+    Plan* d_plans = nullptr; RoundState* d_rs = nullptr; RoundState* h_rs = nullptr;   // batch-parallel writes
+    DevBufs* d_bufs = nullptr; DevBufs* h_bufs = nullptr;      // the arrays the rounds work on, read from device memory (pinned mirror)
     TableMerge tmerge{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; int64_t tmerge_cap = 0;   // scratch of the grid-wide table merge (tables.hip)
     int64_t stat_table_merges = 0;
     int64_t* d_small = nullptr;                     // 8 x int64 scratch
@@ -139,7 +140,8 @@ void pma_destroy(Pma& P) {
     burst_graph_destroy(&P.burst);
     burst_graph_destroy(&P.burst_short);
     if (P.d_plans) hipFree(P.d_plans);
-    if (P.d_flags) hipFree(P.d_flags);
+    if (P.d_bufs) hipFree(P.d_bufs);
+    if (P.h_bufs) hipHostFree(P.h_bufs);
     if (P.d_rs) hipFree(P.d_rs);
     if (P.h_rs) hipHostFree(P.h_rs);
     if (P.d_small) hipFree(P.d_small);
@@ -229,8 +231,8 @@ void pma_init_common(Pma& P, bool sems, bool cols) {
 void ensure_tables(Pma& P, int64_t need) {
     if (!P.has_sems) return;
     if (need <= P.h_ctl->table_cap) return;
-    int64_t ncap = std::max<int64_t>(64, P.h_ctl->table_cap * 2);
-    while (ncap < need) ncap *= 2;
+    int64_t ncap = std::max<int64_t>(1024, P.h_ctl->table_cap * 4);
+    while (ncap < need) ncap *= 4;
     int64_t* ns = nullptr; int64_t* nk = nullptr; uint8_t* nl = nullptr;
     HIPCHK(hipMalloc(&ns, (size_t)ncap * sizeof(int64_t)));
     HIPCHK(hipMemsetAsync(ns, 0, (size_t)ncap * sizeof(int64_t), P.stream));
@@ -296,8 +298,11 @@ void download_ctl(Pma& P) {
 // grow both slot buffers to at least `slots` (contents of the current buffer are preserved)
 void ensure_capacity_alloc(Pma& P, int64_t slots) {
     if (slots <= P.cap_alloc) return;
+    // growth in steps of 4x (at least 64k slots once the first 4096 are outgrown): a growing array re-allocates its two buffers
+    // (13 hipMalloc / hipFree and a stream wait each time) 4 times on the way to 4M slots instead of 10; HBM is not the scarce resource
     int64_t n = std::max<int64_t>(P.cap_alloc, 4096);
-    while (n < slots) n *= 2;
+    if (n < slots) n = std::max<int64_t>(4 * n, 65536);
+    while (n < slots) n *= 4;
     void* ok[2] = {P.keys[0], P.keys[1]}; double* ov[2] = {P.vals[0], P.vals[1]}; uint64_t* oo[2] = {P.occ[0], P.occ[1]};
     const int64_t old_words = P.occ_words, old_slots = P.cap_alloc;
     for (int b = 0; b < 2; ++b) { P.keys[b] = nullptr; P.vals[b] = nullptr; P.occ[b] = nullptr; }
@@ -598,8 +603,9 @@ int64_t run_ops_parallel(Pma& P, const std::vector<Op>& ops, int32_t* err) {
     HIPCHK(hipMemcpyAsync(P.d_ops, ops.data(), (size_t)n * sizeof(Op), hipMemcpyHostToDevice, P.stream));
     if (!P.d_plans) {
         HIPCHK(hipMalloc(&P.d_plans, (size_t)GMAX * sizeof(Plan)));
-        HIPCHK(hipMalloc(&P.d_flags, (size_t)GMAX * sizeof(uint32_t)));
-        HIPCHK(hipMemsetAsync(P.d_flags, 0, (size_t)GMAX * sizeof(uint32_t), P.stream));
+        HIPCHK(hipMalloc(&P.d_bufs, sizeof(DevBufs)));
+        HIPCHK(hipHostMalloc(&P.h_bufs, sizeof(DevBufs), hipHostMallocDefault));
+        std::memset(P.h_bufs, 0, sizeof(DevBufs));
         HIPCHK(hipMalloc(&P.d_rs, sizeof(RoundState)));
         HIPCHK(hipHostMalloc(&P.h_rs, sizeof(RoundState), hipHostMallocDefault));
     }
@@ -625,8 +631,14 @@ int64_t run_ops_parallel(Pma& P, const std::vector<Op>& ops, int32_t* err) {
         HIPCHK(hipMemcpyAsync(P.d_rs, P.h_rs, sizeof(RoundState), hipMemcpyHostToDevice, P.stream));
         {
             ++P.layout_epoch;
-            hipError_t e = launch_burst(P.K(), P.V(), P.O(), P.has_sems ? P.sems : nullptr, P.has_cols ? P.col_keys : nullptr,
-                                        P.has_cols ? P.col_live : nullptr, P.d_ctl, P.d_ops, P.d_rs, P.d_plans, P.d_flags,
+            // (every burst is followed by a stream wait, so the pinned mirror is never rewritten under a copy in flight)
+            const DevBufs now{P.K().p, P.V(), P.O(), P.has_sems ? P.sems : nullptr, P.has_cols ? P.col_keys : nullptr,
+                              P.has_cols ? P.col_live : nullptr, P.wide ? 1 : 0, 0};
+            if (std::memcmp(&now, P.h_bufs, sizeof(DevBufs)) != 0) {
+                *P.h_bufs = now;
+                HIPCHK(hipMemcpyAsync(P.d_bufs, P.h_bufs, sizeof(DevBufs), hipMemcpyHostToDevice, P.stream));
+            }
+            hipError_t e = launch_burst(P.d_bufs, P.d_ctl, P.d_ops, P.d_rs, P.d_plans,
                                         burst_rounds, burst_rounds == ROUNDS_PER_SYNC ? &P.burst : &P.burst_short, P.stream);
             if (e != hipSuccess) fail(DSA_EHIP, std::string("burst launch: ") + hipGetErrorString(e));
         }

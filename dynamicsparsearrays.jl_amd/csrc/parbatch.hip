@@ -47,11 +47,13 @@ __device__ int64_t pb_wave_count(const uint64_t* occ, int64_t ws, int64_t we, bo
     return pb_wave_sum(c);
 }
 
-__global__ __launch_bounds__(PB_BLOCK) void k_plan(KeyArr keys, const double* vals, const uint64_t* occ,
-                                                   const int64_t* sems, const int64_t* col_keys, const uint8_t* col_live,
-                                                   const Ctl* ctl, const Op* ops, RoundState* rs, Plan* plans) {
+__global__ __launch_bounds__(PB_BLOCK) void k_plan(const DevBufs* bufs, const Ctl* ctl, const Op* ops, RoundState* rs, Plan* plans) {
     // the round's window of ops comes from the device-resident cursor: rounds are enqueued back to back without host syncs
     if (rs->stop) return;
+    const DevBufs db = *bufs;
+    const KeyArr keys{db.keys, db.wide, 0};
+    const double* vals = db.vals; const uint64_t* occ = db.occ;
+    const int64_t* sems = db.sems; const int64_t* col_keys = db.col_keys; const uint8_t* col_live = db.col_live;
     const int64_t i0 = rs->cursor + rs->d;            // the resolve step of this round folds the previous prefix into the cursor
     const int64_t left = rs->limit - i0;
     const int G = (int)(left < rs->G ? left : rs->G);
@@ -199,48 +201,104 @@ __global__ __launch_bounds__(PB_BLOCK) void k_plan(KeyArr keys, const double* va
         }
     }
     if (pl.action == PB_BARRIER) pl.count = why;
-    if (lane_id() == 0) plans[w] = pl;
+    if (lane_id() == 0) {
+        // device-scope (write-through) stores: the workgroup that resolves the round may sit on another XCD; a release FENCE per
+        // workgroup instead would write back that XCD's whole L2, which k_apply has just dirtied
+        Plan* q = plans + w;
+        __hip_atomic_store(&q->lo, pl.lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&q->hi, pl.hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&q->pos, pl.pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&q->aux, pl.aux, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&q->ws, pl.ws, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&q->we, pl.we, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&q->count, pl.count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&q->action, pl.action, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     }
     // ---- resolve, by the workgroup that finishes last (a ticket; no second and third launch per round): folds the previous round's
     //      prefix into the cursor and decides this round's prefix d = min(first BARRIER, smallest j whose footprint overlaps the footprint
     //      of an earlier op): ops [0, d) are pairwise disjoint, each sees exactly the state it was planned on.  k_apply works on (cursor, d).
     __shared__ int sLast, sC, sB;
-    __shared__ int64_t sLo[PB_GMAX], sHi[PB_GMAX];
+    // footprints as 32-bit pairs (arrays beyond 2^31 slots: in units of 2^shift slots, rounded outwards — conservative)
+    struct alignas(8) Iv { int32_t lo, hi; };
+    __shared__ Iv sIv[PB_GMAX + 8];
+    __builtin_amdgcn_s_waitcnt(0);                                     // the plan stores of this wave have been acknowledged at device scope
     __syncthreads();
     if (threadIdx.x == 0) {
-        __threadfence();                                               // this workgroup's plans are visible device-wide before its ticket
-        const unsigned t = atomicAdd(&rs->ticket, 1u);
+        const unsigned t = __hip_atomic_fetch_add(&rs->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         sLast = t == gridDim.x - 1 ? 1 : 0;
         sC = G; sB = G;
     }
     __syncthreads();
     if (!sLast) return;
-    __threadfence();                                                   // (acquire: the other workgroups' plans)
+    [[maybe_unused]] const long long tr0 = clock64();      // dev profile, -DDSA_PB_PROF
     const int tid = threadIdx.x;
-    for (int j = tid; j < G; j += PB_BLOCK) {
-        const Plan* q = plans + j;
-        sLo[j] = __hip_atomic_load(&q->lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        sHi[j] = __hip_atomic_load(&q->hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (__hip_atomic_load(&q->action, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == PB_BARRIER) atomicMin(&sB, j);
+    int shift = 0;
+    while (((ctl->capacity) >> shift) > 0x7fffffffll) ++shift;
+    for (int j = tid; j < G + 8; j += PB_BLOCK) {
+        Iv iv{INT32_MAX, INT32_MIN};                                   // an empty footprint overlaps nothing
+        if (j < G) {
+            const Plan* q = plans + j;
+            const int64_t lo = __hip_atomic_load(&q->lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int64_t hi = __hip_atomic_load(&q->hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lo <= hi) { iv.lo = (int32_t)(lo >> shift); iv.hi = (int32_t)(hi >> shift); }
+            if (__hip_atomic_load(&q->action, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == PB_BARRIER) atomicMin(&sB, j);
+        }
+        sIv[j] = iv;
     }
     __syncthreads();
-    // smallest j that overlaps an earlier op, in chunks of PB_BLOCK ops (a hit in a chunk ends the search; ops behind the first BARRIER do not matter)
-    for (int j0 = 0; j0 < G; j0 += PB_BLOCK) {
-        const int j = j0 + tid;
-        if (j < G && j < sB) {
-            const int64_t lo = sLo[j], hi = sHi[j];
-            if (lo <= hi) {
-                bool hit = false;
-                for (int i = 0; i < j && !hit; ++i) { const int64_t l2 = sLo[i], h2 = sHi[i]; hit = l2 <= h2 && l2 <= hi && lo <= h2; }
-                if (hit) atomicMin(&sC, j);
-            }
-        }
-        __syncthreads();
-        const int c_now = sC;
-        __syncthreads();                                               // (everyone has read sC before the next chunk may lower it)
-        if (c_now < G || j0 + PB_BLOCK >= sB) break;
+    [[maybe_unused]] const long long tr1 = clock64();
+    // smallest j that overlaps an earlier op: a spatial hash instead of all pairs (G^2 / 2 tests by one workgroup cost 7 .. 36 us).
+    // Cells of 2048 slots; a footprint of up to 2048 slots lies in one or two cells and is chained into their buckets, then every op
+    // walks the chains of its own cells and tests the earlier ops it meets there exactly.  The (rare) longer footprints are tested
+    // against everybody.  Ops at or behind the first BARRIER do not matter.
+    constexpr int CS = 11, NB = 4096;
+    __shared__ int sHead[NB];
+    __shared__ int sNext[2 * PB_GMAX];
+    __shared__ int sWide[PB_GMAX];
+    __shared__ int sNWide;
+    for (int k = tid; k < NB; k += PB_BLOCK) sHead[k] = -1;
+    if (tid == 0) sNWide = 0;
+    __syncthreads();
+    const int Gc = sB < G ? sB : G;
+    auto bucket = [](int cell) { return (int)(((uint32_t)cell * 0x9E3779B1u) >> 20) & (NB - 1); };
+    for (int j = tid; j < Gc; j += PB_BLOCK) {
+        const Iv iv = sIv[j];
+        if (iv.lo > iv.hi) continue;
+        const int c0 = iv.lo >> CS, c1 = iv.hi >> CS;
+        if (c1 - c0 > 1) { sWide[atomicAdd(&sNWide, 1)] = j; continue; }
+        for (int k = 0; k <= c1 - c0; ++k) { const int e = 2 * j + k; sNext[e] = atomicExch(&sHead[bucket(c0 + k)], e); }
     }
+    __syncthreads();
+    for (int j = tid; j < Gc; j += PB_BLOCK) {
+        const Iv me = sIv[j];
+        if (me.lo > me.hi) continue;
+        const int c0 = me.lo >> CS, c1 = me.hi >> CS;
+        if (c1 - c0 > 1) continue;
+        bool hit = false;
+        for (int k = 0; k <= c1 - c0; ++k)
+            for (int e = sHead[bucket(c0 + k)]; e >= 0; e = sNext[e]) {
+                const int i = e >> 1;
+                const Iv o = sIv[i];
+                hit = hit | ((i < j) & (o.lo <= me.hi) & (me.lo <= o.hi));
+            }
+        if (hit) atomicMin(&sC, j);
+    }
+    __syncthreads();
+    const int nwide = sNWide;
+    for (int w = 0; w < nwide; ++w) {
+        const int j = sWide[w];
+        const Iv me = sIv[j];
+        for (int i = tid; i < Gc; i += PB_BLOCK) {
+            const Iv o = sIv[i];
+            if (i != j && o.lo <= me.hi && me.lo <= o.hi) atomicMin(&sC, i > j ? i : j);
+        }
+    }
+    __syncthreads();
     if (tid == 0) {
+#ifdef DSA_PB_PROF
+        printf("resolve: G %d sB %d sC %d load %lld clk conflicts %lld clk\n", G, sB, sC, tr1 - tr0, (long long)clock64() - tr1);
+#endif
         const int d_prev = rs->d;
         rs->ticket = 0u;                                               // re-armed for the next round
         rs->cursor = i0;
@@ -448,10 +506,13 @@ __device__ bool pb_scan_and_rebalance_live(KeyArr keys, double* vals, uint64_t* 
     return true;
 }
 
-__global__ __launch_bounds__(PB_BLOCK) void k_apply(KeyArr keys, double* vals, uint64_t* occ, int64_t* sems, int64_t* col_keys,
-                                                    uint8_t* col_live, Ctl* ctl, const Op* ops, const RoundState* rs, const Plan* plans) {
+__global__ __launch_bounds__(PB_BLOCK) void k_apply(const DevBufs* bufs, Ctl* ctl, const Op* ops, const RoundState* rs, const Plan* plans) {
     extern __shared__ __attribute__((aligned(16))) unsigned char pb_lds[];
     if (rs->stop) return;
+    const DevBufs db = *bufs;
+    const KeyArr keys{db.keys, db.wide, 0};
+    double* vals = db.vals; uint64_t* occ = db.occ;
+    int64_t* sems = db.sems; int64_t* col_keys = db.col_keys; uint8_t* col_live = db.col_live;
     const int64_t i0 = rs->cursor;
     const int d = rs->d;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -553,33 +614,29 @@ static hipError_t configure_apply() {
         return hipFuncSetAttribute(reinterpret_cast<const void*>(k_apply), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     });
 }
-static hipError_t enqueue_round(KeyArr keys, double* vals, uint64_t* occ, int64_t* sems, int64_t* col_keys,
-                                uint8_t* col_live, Ctl* ctl, const Op* ops, RoundState* rs, Plan* plans, uint32_t* flags,
-                                hipStream_t stream) {
+static hipError_t enqueue_round(const DevBufs* bufs, Ctl* ctl, const Op* ops, RoundState* rs, Plan* plans, hipStream_t stream) {
     const size_t lds = (size_t)(PB_BLOCK / 64) * PB_MAX_W * (sizeof(int64_t) + sizeof(double));
-    (void)flags;
-    hipLaunchKernelGGL(k_plan, dim3(PB_GMAX / 4), dim3(PB_BLOCK), 0, stream, keys, vals, occ, sems, col_keys, col_live, ctl, ops, rs, plans);
-    hipLaunchKernelGGL(k_apply, dim3(PB_GMAX / 4), dim3(PB_BLOCK), lds, stream, keys, vals, occ, sems, col_keys, col_live, ctl, ops, rs, plans);
+    hipLaunchKernelGGL(k_plan, dim3(PB_GMAX / 4), dim3(PB_BLOCK), 0, stream, bufs, ctl, ops, rs, plans);
+    hipLaunchKernelGGL(k_apply, dim3(PB_GMAX / 4), dim3(PB_BLOCK), lds, stream, bufs, ctl, ops, rs, plans);
     return hipGetLastError();
 }
 
 // A burst of `rounds` rounds.  The launch sequence depends only on pointers, so it is captured once into a hipGraph and
-// replayed (one graph launch instead of 4 x rounds kernel launches: the rounds are launch-bound); re-captured when a buffer
-// moves (root rebalance swaps the slot buffers, a bigger batch re-allocates the op array).  Falls back to eager launches
-// when the stream cannot be captured.
-hipError_t launch_burst(KeyArr keys, double* vals, uint64_t* occ, int64_t* sems, int64_t* col_keys, uint8_t* col_live,
-                        Ctl* ctl, const Op* ops, RoundState* rs, Plan* plans, uint32_t* flags, int rounds, BurstGraph* cache,
+// replayed (one graph launch instead of 2 x rounds kernel launches: the rounds are launch-bound); the slot buffers and tables
+// are reached through DevBufs, so the graph only changes when a bigger batch re-allocates the op array.  Falls back to eager
+// launches when the stream cannot be captured.
+hipError_t launch_burst(const DevBufs* bufs, Ctl* ctl, const Op* ops, RoundState* rs, Plan* plans, int rounds, BurstGraph* cache,
                         hipStream_t stream) {
     hipError_t e = configure_apply();
     if (e != hipSuccess) return e;
-    const void* key[12] = {keys.p, vals, occ, sems, col_keys, col_live, ctl, ops, rs, plans, flags, (const void*)(intptr_t)(rounds * 2 + keys.wide)};
+    const void* key[12] = {bufs, ctl, ops, rs, plans, (const void*)(intptr_t)rounds, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     bool same = cache->exec != nullptr && cache->stream == stream;
     for (int k = 0; k < 12 && same; ++k) same = cache->key[k] == key[k];
     if (!same && !cache->disabled) {
         if (cache->exec) { (void)hipGraphExecDestroy(cache->exec); cache->exec = nullptr; }
         if (cache->graph) { (void)hipGraphDestroy(cache->graph); cache->graph = nullptr; }
         if (hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-            for (int r = 0; r < rounds; ++r) (void)enqueue_round(keys, vals, occ, sems, col_keys, col_live, ctl, ops, rs, plans, flags, stream);
+            for (int r = 0; r < rounds; ++r) (void)enqueue_round(bufs, ctl, ops, rs, plans, stream);
             hipGraph_t g = nullptr;
             e = hipStreamEndCapture(stream, &g);
             if (e == hipSuccess && g != nullptr && hipGraphInstantiate(&cache->exec, g, nullptr, nullptr, 0) == hipSuccess) {
@@ -598,7 +655,7 @@ hipError_t launch_burst(KeyArr keys, double* vals, uint64_t* occ, int64_t* sems,
     }
     if (cache->exec != nullptr && !cache->disabled) return hipGraphLaunch(cache->exec, stream);
     for (int r = 0; r < rounds; ++r) {
-        e = enqueue_round(keys, vals, occ, sems, col_keys, col_live, ctl, ops, rs, plans, flags, stream);
+        e = enqueue_round(bufs, ctl, ops, rs, plans, stream);
         if (e != hipSuccess) return e;
     }
     return hipSuccess;
