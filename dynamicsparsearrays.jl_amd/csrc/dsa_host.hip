@@ -14,6 +14,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <chrono>
+#include <cstddef>
 #include <cstring>
 #include <numeric>
 #include <mutex>
@@ -612,6 +613,7 @@ int64_t run_ops_parallel(Pma& P, const std::vector<Op>& ops, int32_t* err) {
     P.h_ctl->next_op = 0; P.h_ctl->status = 0; P.h_ctl->err = 0; P.h_ctl->no_run_at = -1;
     upload_ctl(P);
     static const int64_t SEQ_CHUNK0 = [] { const char* e = getenv("DSA_SEQ_CHUNK"); return e ? (int64_t)atoi(e) : (int64_t)8; }();
+    static const int64_t BARRIER_CHUNK0 = [] { const char* e = getenv("DSA_BARRIER_CHUNK"); return e ? (int64_t)atoi(e) : (int64_t)1; }();
     int64_t i = 0, seq_chunk = SEQ_CHUNK0;
     int G = 256;
     int ema = 16 * 16;                      // RoundState::ema, carried across the bursts of the batch
@@ -649,7 +651,10 @@ int64_t run_ops_parallel(Pma& P, const std::vector<Op>& ops, int32_t* err) {
         // the prefix of the last round of the burst has been applied but is folded into the cursor only by the next round's resolve step
         if (rs.pad != 0) fail(DSA_EASSERT, "batch-parallel column creation left its footprint (internal invariant)");
         const int64_t reached = rs.cursor + rs.d;
-        if (reached > i) seq_chunk = SEQ_CHUNK0;
+        // what the sequencer takes after a stop: the op that cannot be planned alone when the rounds were otherwise making progress
+        // (the ops behind it are cheaper in a round: ~1 us each against 5-15 us), a chunk of SEQ_CHUNK0 ops when short prefixes
+        // stopped them (the ops around the cursor collide); doubled while the rounds make no progress at all
+        if (reached > i) seq_chunk = rs.why[7] > 0 ? SEQ_CHUNK0 : BARRIER_CHUNK0;
         // new partitions of the rounds sit at the end of the tables: back into key order with the whole chip once enough have piled up
         if (P.h_ctl->n_pending >= MERGE_AT) merge_tables(P);
         P.stat_par_rounds += rs.rounds + (rs.d > 0 ? 1 : 0); P.stat_par_ops += rs.par_ops + rs.d;
@@ -744,12 +749,15 @@ void pma_check(Pma& P, int64_t* report) {
     hipError_t e = launch_check(P.K(), P.V(), P.O(), P.capacity(), P.occ_words, P.has_sems ? P.sems : nullptr,
                                 P.has_cols ? P.col_keys : nullptr, P.has_cols ? P.col_live : nullptr, P.h_ctl->table_len, d, P.stream);
     if (e == hipSuccess) e = hipMemcpyAsync(r, d, sizeof(r), hipMemcpyDeviceToHost, P.stream);
+    // no table entry may be pending outside a batch (tables.hip): the DEVICE copy of the counter is the one the kernels trust
+    int64_t dev_pending = 0;
+    if (e == hipSuccess) e = hipMemcpyAsync(&dev_pending, reinterpret_cast<const char*>(P.d_ctl) + offsetof(Ctl, n_pending), sizeof(int64_t), hipMemcpyDeviceToHost, P.stream);
     if (e == hipSuccess) e = hipStreamSynchronize(P.stream);
     hipFree(d);
     if (e != hipSuccess) fail(DSA_EHIP, std::string("check: ") + hipGetErrorString(e));
     for (int i = 0; i < 8; ++i) report[i] = (int64_t)r[i];
     const int64_t live = P.has_sems ? P.h_ctl->nb_partitions : 0;
-    report[6] = (report[0] != P.h_ctl->nb_elements || report[1] != live) ? 1 : 0;
+    report[6] = (report[0] != P.h_ctl->nb_elements || report[1] != live || dev_pending != 0 || P.h_ctl->n_pending != 0) ? 1 : 0;
 }
 
 void ensure_q(Pma& P, int64_t n) {

@@ -23,7 +23,8 @@
 namespace dsa {
 
 constexpr int PB_BLOCK = 256;                 // 4 waves = 4 ops per workgroup
-constexpr int PB_MAX_W = 1024;                // largest window a single wave rebalances (16 KB of LDS per wave)
+constexpr int PB_MAX_W_LOG2 = 11;
+constexpr int PB_MAX_W = 1 << PB_MAX_W_LOG2;  // largest window a single wave rebalances (32 KB of LDS per wave, 128 KB per workgroup)
 constexpr int PB_GMAX = 1024;                 // ops planned per round at most (one wave each)
 
 enum : int32_t { PB_NOOP = 0, PB_OVERWRITE = 1, PB_INS_R = 2, PB_INS_L = 3, PB_DELETE = 4, PB_BARRIER = 5, PB_NEWCOL = 6 };
@@ -249,10 +250,10 @@ __global__ __launch_bounds__(PB_BLOCK) void k_plan(const DevBufs* bufs, const Ct
     __syncthreads();
     [[maybe_unused]] const long long tr1 = clock64();
     // smallest j that overlaps an earlier op: a spatial hash instead of all pairs (G^2 / 2 tests by one workgroup cost 7 .. 36 us).
-    // Cells of 2048 slots; a footprint of up to 2048 slots lies in one or two cells and is chained into their buckets, then every op
+    // Cells of 2 * PB_MAX_W slots; a footprint of up to that many slots lies in one or two cells and is chained into their buckets, then every op
     // walks the chains of its own cells and tests the earlier ops it meets there exactly.  The (rare) longer footprints are tested
     // against everybody.  Ops at or behind the first BARRIER do not matter.
-    constexpr int CS = 11, NB = 4096;
+    constexpr int CS = PB_MAX_W_LOG2 + 1, NB = 4096;
     __shared__ int sHead[NB];
     __shared__ int sNext[2 * PB_GMAX];
     __shared__ int sWide[PB_GMAX];
