@@ -280,8 +280,11 @@ hipError_t launch_sequencer(KeyArr keys, double* vals, uint64_t* occ, int64_t* s
                             uint8_t* col_live, Ctl* ctl, const Op* ops, int64_t n_ops, int64_t n_avail, bool run_ok,
                             hipStream_t stream);
 // flags / d_T: cell types and cell count written by k_run_expand (MappedPackedCSC runs), nullptr for a vector run
+// saved_memo: append_run_memo_bytes() of zero-initialised device memory owned by the handle (the replay's memo survives in it from
+// run to run while the array's geometry stays the same), or nullptr
+size_t append_run_memo_bytes();
 hipError_t launch_append_run(uint64_t* occ, Ctl* ctl, int64_t i0, int64_t R, const uint64_t* flags, const int64_t* d_T,
-                             hipStream_t stream);
+                             uint64_t* saved_memo, hipStream_t stream);
 hipError_t launch_run_expand(const Op* ops, int64_t i0, int64_t R, const Ctl* ctl, int64_t* col_keys, uint8_t* col_live, Op* cells,
                              uint64_t* flags, int64_t* out, hipStream_t stream);
 

@@ -81,6 +81,7 @@ struct Pma {
     RebalanceWork work2{nullptr, nullptr, 0};   // second prefix table of K-permute (old and new bitmap)
     uint64_t* occ_old = nullptr;                // bitmap saved by the sequencer at the start of an append run
     Op* run_cells = nullptr; uint64_t* run_flags = nullptr; int64_t* run_out = nullptr; int64_t run_cap = 0;   // cell stream of a MappedPackedCSC append run
+    uint64_t* run_memo = nullptr;               // the append replay's memo between runs (sequencer.hip: k_append_run)
     Op* d_ops = nullptr; int64_t ops_cap = 0;
     double* d_q = nullptr; int64_t q_cap = 0;      // scratch for lookups (3 arrays of q_cap)
     int32_t* d_err = nullptr;
@@ -153,6 +154,7 @@ void pma_destroy(Pma& P) {
     if (P.run_cells) hipFree(P.run_cells);
     if (P.run_flags) hipFree(P.run_flags);
     if (P.run_out) hipFree(P.run_out);
+    if (P.run_memo) hipFree(P.run_memo);
     if (P.own_stream && P.stream) hipStreamDestroy(P.stream);
     P = Pma();
 }
@@ -565,7 +567,11 @@ bool seq_step(SeqRun& r) {
                 if (e != hipSuccess) fail(DSA_EHIP, std::string("run expand launch: ") + hipGetErrorString(e));
             }
             HIPCHK(hipMemcpyAsync(P.occ_old, P.O(), (size_t)words * sizeof(uint64_t), hipMemcpyDeviceToDevice, P.stream));
-            e = launch_append_run(P.O(), P.d_ctl, i0, R, P.has_cols ? P.run_flags : nullptr, P.has_cols ? P.run_out : nullptr, P.stream);
+            if (!P.run_memo) {
+                HIPCHK(hipMalloc(&P.run_memo, append_run_memo_bytes()));
+                HIPCHK(hipMemsetAsync(P.run_memo, 0, append_run_memo_bytes(), P.stream));
+            }
+            e = launch_append_run(P.O(), P.d_ctl, i0, R, P.has_cols ? P.run_flags : nullptr, P.has_cols ? P.run_out : nullptr, P.run_memo, P.stream);
             if (e != hipSuccess) fail(DSA_EHIP, std::string("append run launch: ") + hipGetErrorString(e));
             permute_run(P, P.has_cols ? P.run_cells : P.d_ops, P.has_cols ? 0 : i0, n0);
             if (++r.guard > 4 * r.n + 1000000) fail(DSA_EASSERT, "sequencer made no progress");
