@@ -264,6 +264,7 @@ struct BuildScratch {
     uint32_t *idx0 = nullptr, *idx1 = nullptr, *idx2 = nullptr, *fpart = nullptr, *fcell = nullptr, *spart = nullptr, *scell = nullptr;
     int64_t *k1 = nullptr, *p1 = nullptr, *p2 = nullptr, *k2 = nullptr;
     void* temp = nullptr; size_t temp_bytes = 0;
+    void* base = nullptr; hipStream_t stream = nullptr;      // the one allocation all of the above are carved from
 };
 // phase 1: sort by (partition, key, input order), flags, scans; counts[0] = distinct cells, counts[1] = partitions
 hipError_t build_prepare(const int64_t* d_part, const int64_t* d_key, int64_t nnz, BuildScratch& s, int64_t counts[2],

@@ -974,9 +974,21 @@ void mat_build_major_dev(dsa_mat* h, int64_t* dI, int64_t* dJ, double* dV, int64
         pma_init_common(h->row, true, true);
         static const bool dbg_time = getenv("DSA_DBG_TIME") != nullptr;
         const auto tb0 = std::chrono::steady_clock::now();
-        pma_build_dev(h->col, dJ, dI, dV, nnz, DSA_COMBINE_ADD, 0, 0, wide_rows);      // dynamicsparsecolmajor(I, J, V): partitions = columns, keys = rows
+        // the two orientations are independent structures on their own streams and both only read the triples: built side by side
+        // (the rowmajor one on a helper thread; each build waits once for its cell / partition counts)
+        std::exception_ptr row_exc;
+        std::thread row_thread;
+        const bool side_by_side = h->col.stream != h->row.stream && nnz > 0;
+        if (side_by_side)
+            row_thread = std::thread([&] {
+                try { bind_device(h->row); pma_build_dev(h->row, dI, dJ, dV, nnz, DSA_COMBINE_ADD, 0, 0, wide_cols); }
+                catch (...) { row_exc = std::current_exception(); }
+            });
+        try { pma_build_dev(h->col, dJ, dI, dV, nnz, DSA_COMBINE_ADD, 0, 0, wide_rows); }      // dynamicsparsecolmajor(I, J, V): partitions = columns, keys = rows
+        catch (...) { if (row_thread.joinable()) row_thread.join(); throw; }
         const auto tb1 = std::chrono::steady_clock::now();
-        pma_build_dev(h->row, dI, dJ, dV, nnz, DSA_COMBINE_ADD, 0, 0, wide_cols);      // dynamicsparsecolmajor(J, I, V): partitions = rows, keys = columns
+        if (side_by_side) { row_thread.join(); if (row_exc) std::rethrow_exception(row_exc); }
+        else pma_build_dev(h->row, dI, dJ, dV, nnz, DSA_COMBINE_ADD, 0, 0, wide_cols);      // dynamicsparsecolmajor(J, I, V): partitions = rows, keys = columns
         if (dbg_time)
             fprintf(stderr, "[mat_build_major] nnz=%lld colmajor %.1f ms  rowmajor %.1f ms\n", (long long)nnz,
                     std::chrono::duration<double, std::milli>(tb1 - tb0).count(),
