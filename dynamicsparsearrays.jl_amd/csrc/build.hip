@@ -85,24 +85,13 @@ __global__ void k_emit_sems(const int64_t* __restrict__ part_sorted, const uint3
     out_vals[pos] = (double)p;
 }
 
-// The scratch of a build is ONE stream-ordered allocation from the device's default pool (release threshold raised once, so the
-// pool keeps what it is given back): twelve hipMalloc + hipFree and a stream wait per build cost ~2 ms of the 5.3 ms a 10 M-triple
-// orientation took.
+// The scratch of a build is ONE allocation carved into its twelve arrays: twelve hipMalloc + hipFree pairs cost ~2 ms of the 5.3 ms a
+// 10 M-triple orientation took.  (Stream-ordered allocation from the default pool — hipMallocAsync with a raised release
+// threshold — was tried for it: 4 ms builds most of the time, but stalls of 120-150 ms in hipMallocAsync or in the next plain
+// hipMalloc when the two orientations build side by side on two host threads.  Dropped.)
 static void free_scratch(BuildScratch& s) {
-    if (s.base) (void)hipFreeAsync(s.base, s.stream);
+    if (s.base) (void)hipFree(s.base);
     s = BuildScratch();
-}
-static hipError_t pool_keep_memory() {
-    static PerDeviceOnce once;
-    return once.run([] {
-        int dev = 0;
-        hipError_t e = hipGetDevice(&dev);
-        hipMemPool_t pool = nullptr;
-        if (e == hipSuccess) e = hipDeviceGetDefaultMemPool(&pool, dev);
-        uint64_t keep = ~0ull;
-        if (e == hipSuccess) e = hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
-        return e;
-    });
 }
 
 #define BCHK(e) do { hipError_t _e = (e); if (_e != hipSuccess) { free_scratch(s); return _e; } } while (0)
@@ -121,8 +110,7 @@ hipError_t build_prepare(const int64_t* d_part, const int64_t* d_key, int64_t nn
     {
         auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
         const size_t a4 = up(n * 4), a8 = up(n * 8);
-        BCHK(pool_keep_memory());
-        BCHK(hipMallocAsync(&s.base, 7 * a4 + 4 * a8 + up(s.temp_bytes), stream));
+        BCHK(hipMalloc(&s.base, 7 * a4 + 4 * a8 + up(s.temp_bytes)));
         char* q = static_cast<char*>(s.base);
         auto take = [&q](size_t b) { char* r = q; q += b; return r; };
         s.idx0 = (uint32_t*)take(a4); s.idx1 = (uint32_t*)take(a4); s.idx2 = (uint32_t*)take(a4);
@@ -166,7 +154,8 @@ hipError_t build_emit(const double* d_val, int32_t combine, BuildScratch& s, Key
         hipLaunchKernelGGL(k_emit_sems, dim3((unsigned)((nparts_explicit + 255) / 256)), dim3(256), 0, stream, s.p2, s.scell, s.n,
                            nparts_explicit, out_keys, out_vals);
     hipError_t e = hipGetLastError();
-    free_scratch(s);                   // stream-ordered: behind the emit kernels, no host wait
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    free_scratch(s);
     return e;
 }
 

@@ -1009,6 +1009,10 @@ void mat_build_major(dsa_mat* h, const int64_t* I, const int64_t* J, const doubl
     int64_t *dI = nullptr, *dJ = nullptr; double* dV = nullptr;
     const auto tup0 = std::chrono::steady_clock::now();
     HIPCHK(hipSetDevice(g_device));
+    // the key-width scans of the caller's arrays (80 MB each at config 3: ~5 ms apiece) run on a helper thread under the upload
+    bool wide_rows = false, wide_cols = false;
+    std::thread scan([&] { wide_rows = !keys_fit32(I, nnz); wide_cols = !keys_fit32(J, nnz); });
+    struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{scan};
     try {
         if (nnz > 0) {
             HIPCHK(hipMalloc(&dI, (size_t)nnz * sizeof(int64_t)));
@@ -1027,7 +1031,8 @@ void mat_build_major(dsa_mat* h, const int64_t* I, const int64_t* J, const doubl
     static const bool dbg_time = getenv("DSA_DBG_TIME") != nullptr;
     if (dbg_time) fprintf(stderr, "[mat_build_major] upload of %lld triples from caller memory %.1f ms\n", (long long)nnz,
                           std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tup0).count());
-    mat_build_major_dev(h, dI, dJ, dV, nnz, !keys_fit32(I, nnz), !keys_fit32(J, nnz));
+    scan.join();
+    mat_build_major_dev(h, dI, dJ, dV, nnz, wide_rows, wide_cols);
 }
 
 Pma& orient(dsa_mat* h, int32_t o) {
