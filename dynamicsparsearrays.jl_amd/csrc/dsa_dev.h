@@ -333,6 +333,9 @@ struct DevBufs { void* keys; double* vals; uint64_t* occ; int64_t* sems; int64_t
 hipError_t launch_burst(const DevBufs* bufs, Ctl* ctl, const Op* ops, RoundState* rs, Plan* plans, int rounds, BurstGraph* cache,
                         hipStream_t stream);
 void burst_graph_destroy(BurstGraph* cache);
+// the same rounds by one persistent workgroup (phases with short conflict-free prefixes); leaves with RoundState::stop = 0 (max_rounds
+// used up), 1 (the op at the cursor needs the sequencer), 2 (batch finished) or 3 (full prefixes: back to the grid rounds)
+hipError_t launch_local_rounds(const DevBufs* bufs, Ctl* ctl, const Op* ops, RoundState* rs, int max_rounds, hipStream_t stream);
 
 // batched read-only lookups.  mode 0: getindex(pma, key) ; 1: getindex(pcsc, key, partition) ;
 // 2: getindex(mpcsc, row, col).  err_out: first error code (0 if none)

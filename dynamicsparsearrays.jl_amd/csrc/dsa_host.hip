@@ -623,11 +623,15 @@ int64_t run_ops_parallel(Pma& P, const std::vector<Op>& ops, int32_t* err) {
     int64_t i = 0, seq_chunk = SEQ_CHUNK0;
     int G = 256;
     int ema = 16 * 16;                      // RoundState::ema, carried across the bursts of the batch
+    // local rounds (parbatch.hip: k_local_rounds) while the prefixes are short; a small array starts with them
+    static const bool local_ok = [] { const char* e = getenv("DSA_LOCAL_ROUNDS"); return !(e && e[0] == '0'); }();
+    constexpr int LOCAL_ROUNDS = 2048, LOCAL_BELOW = 6;
+    bool use_local = local_ok && P.h_ctl->capacity <= (1 << 16);
     // a burst that stops in its first rounds (short conflict-free prefix, barrier op) leaves the rest of its graph as no-op
     // launches (~2.5 us each, four per round): after such a stop the next burst is a short one, until one runs to its end
     int burst_rounds = ROUNDS_PER_SYNC;
     static const bool dbg_split = getenv("DSA_DBG_SPLIT") != nullptr;
-    double t_burst = 0, t_seq = 0; int64_t n_burst = 0, n_seq = 0, n_yield = 0;
+    double t_burst = 0, t_seq = 0, t_local = 0; int64_t n_burst = 0, n_seq = 0, n_yield = 0, n_local = 0, r_local = 0, o_local = 0;
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
     while (i < n) {
@@ -646,21 +650,24 @@ int64_t run_ops_parallel(Pma& P, const std::vector<Op>& ops, int32_t* err) {
                 *P.h_bufs = now;
                 HIPCHK(hipMemcpyAsync(P.d_bufs, P.h_bufs, sizeof(DevBufs), hipMemcpyHostToDevice, P.stream));
             }
-            hipError_t e = launch_burst(P.d_bufs, P.d_ctl, P.d_ops, P.d_rs, P.d_plans,
-                                        burst_rounds, burst_rounds == ROUNDS_PER_SYNC ? &P.burst : &P.burst_short, P.stream);
+            // short conflict-free prefixes (a small array, colliding ops): the rounds of one persistent workgroup, no launch per round
+            hipError_t e = use_local ? launch_local_rounds(P.d_bufs, P.d_ctl, P.d_ops, P.d_rs, LOCAL_ROUNDS, P.stream)
+                                     : launch_burst(P.d_bufs, P.d_ctl, P.d_ops, P.d_rs, P.d_plans,
+                                                    burst_rounds, burst_rounds == ROUNDS_PER_SYNC ? &P.burst : &P.burst_short, P.stream);
             if (e != hipSuccess) fail(DSA_EHIP, std::string("burst launch: ") + hipGetErrorString(e));
         }
         HIPCHK(hipMemcpyAsync(P.h_rs, P.d_rs, sizeof(RoundState), hipMemcpyDeviceToHost, P.stream));
         HIPCHK(hipMemcpyAsync(P.h_ctl, P.d_ctl, sizeof(Ctl), hipMemcpyDeviceToHost, P.stream));      // table_len, n_pending, counts of the burst
         HIPCHK(hipStreamSynchronize(P.stream));
         t_burst += ms(tb0, now()); ++n_burst;
+        if (use_local) { t_local += ms(tb0, now()); ++n_local; r_local += rs.rounds; o_local += rs.par_ops; }
         // the prefix of the last round of the burst has been applied but is folded into the cursor only by the next round's resolve step
         if (rs.pad != 0) fail(DSA_EASSERT, "batch-parallel column creation left its footprint (internal invariant)");
         const int64_t reached = rs.cursor + rs.d;
         // what the sequencer takes after a stop: the op that cannot be planned alone when the rounds were otherwise making progress
         // (the ops behind it are cheaper in a round: ~1 us each against 5-15 us), a chunk of SEQ_CHUNK0 ops when short prefixes
-        // stopped them (the ops around the cursor collide); doubled while the rounds make no progress at all
-        if (reached > i) seq_chunk = rs.why[7] > 0 ? SEQ_CHUNK0 : BARRIER_CHUNK0;
+        // stopped them (the ops around the cursor collide); doubled while the rounds apply fewer than two ops each
+        if (reached - i >= 2 * std::max<int64_t>(1, rs.rounds)) seq_chunk = rs.why[7] > 0 ? SEQ_CHUNK0 : BARRIER_CHUNK0;
         // new partitions of the rounds sit at the end of the tables: back into key order with the whole chip once enough have piled up
         if (P.h_ctl->n_pending >= MERGE_AT) merge_tables(P);
         P.stat_par_rounds += rs.rounds + (rs.d > 0 ? 1 : 0); P.stat_par_ops += rs.par_ops + rs.d;
@@ -668,7 +675,9 @@ int64_t run_ops_parallel(Pma& P, const std::vector<Op>& ops, int32_t* err) {
         i = reached;
         G = rs.G; ema = rs.ema;
         burst_rounds = (rs.stop == 1 && rs.rounds <= ROUNDS_SHORT) ? ROUNDS_SHORT : ROUNDS_PER_SYNC;
-        if (rs.stop != 1) continue;                       // burst used up (0) or batch finished (2)
+        if (use_local) { if (rs.stop == 3) { use_local = false; ema = 16 * 64; G = 64; } }   // full prefixes: the grid rounds pay again
+        else if (local_ok && rs.rounds > 0 && ema < 16 * LOCAL_BELOW) use_local = true;  // prefixes of a few ops: one workgroup is enough
+        if (rs.stop != 1) continue;                       // burst used up (0), batch finished (2), or a switch of round kind (3)
         // ---- short prefix at op i: sequential sequencer for ops [i, i + seq_chunk)
         const auto ts0 = now();
         SeqRun r;
@@ -685,8 +694,9 @@ int64_t run_ops_parallel(Pma& P, const std::vector<Op>& ops, int32_t* err) {
         G = 64;
     }
     if (dbg_split)
-        fprintf(stderr, "  [run_ops_parallel %s] n=%lld: %lld bursts %.2f ms, %lld sequencer chunks (%lld yields) %.2f ms\n", P.has_cols ? "pcsc" : "vec", (long long)n,
-                (long long)n_burst, t_burst, (long long)n_seq, (long long)n_yield, t_seq);
+        fprintf(stderr, "  [run_ops_parallel %s] n=%lld: %lld bursts %.2f ms (of which %lld local launches %.2f ms: %lld mini-rounds, %lld ops), %lld sequencer chunks (%lld yields) %.2f ms\n",
+                P.has_cols ? "pcsc" : "vec", (long long)n, (long long)n_burst, t_burst, (long long)n_local, t_local, (long long)r_local, (long long)o_local,
+                (long long)n_seq, (long long)n_yield, t_seq);
     if (P.h_ctl->n_pending > 0) merge_tables(P);          // the tables leave the batch in key order (the reference's numbering)
     return n;
 }

@@ -48,20 +48,11 @@ __device__ int64_t pb_wave_count(const uint64_t* occ, int64_t ws, int64_t we, bo
     return pb_wave_sum(c);
 }
 
-__global__ __launch_bounds__(PB_BLOCK) void k_plan(const DevBufs* bufs, const Ctl* ctl, const Op* ops, RoundState* rs, Plan* plans) {
-    // the round's window of ops comes from the device-resident cursor: rounds are enqueued back to back without host syncs
-    if (rs->stop) return;
-    const DevBufs db = *bufs;
-    const KeyArr keys{db.keys, db.wide, 0};
-    const double* vals = db.vals; const uint64_t* occ = db.occ;
-    const int64_t* sems = db.sems; const int64_t* col_keys = db.col_keys; const uint8_t* col_live = db.col_live;
-    const int64_t i0 = rs->cursor + rs->d;            // the resolve step of this round folds the previous prefix into the cursor
-    const int64_t left = rs->limit - i0;
-    const int G = (int)(left < rs->G ? left : rs->G);
-    const int w = blockIdx.x * (PB_BLOCK / 64) + (threadIdx.x >> 6);
-    if (w < G) {
+// Plan of ONE op by one wave (read-only): what the op would do on the current state, and its footprint.  w = index of the op in its
+// round (new columns take table entries in that order), max_w = largest window one wave of the caller rebalances.
+__device__ Plan pb_plan_one(KeyArr keys, const double* vals, const uint64_t* occ, const int64_t* sems, const int64_t* col_keys,
+                            const uint8_t* col_live, const Ctl* ctl, const Op op, int w, int max_w) {
     const int64_t capacity = ctl->capacity, seg = ctl->segment_capacity, height = ctl->height;
-    const Op op = ops[i0 + w];
     Plan pl;
     pl.lo = 1; pl.hi = 0; pl.pos = 0; pl.aux = 0; pl.ws = 0; pl.we = 0; pl.count = 0; pl.action = PB_BARRIER;
     int why = 0;           // dev: reason of a BARRIER (kept in pl.count): 0 not plannable, 1 new column w/o successor or v == 0, 2 limits, 3 shifts, 4 sem leaf, 5 window, 6 scan
@@ -135,7 +126,7 @@ __global__ __launch_bounds__(PB_BLOCK) void k_plan(const DevBufs* bufs, const Ct
                 why = 5;
                 for (int64_t h = 0; h <= height; ++h) {
                     const int64_t W = seg << h;
-                    if (W > PB_MAX_W) break;
+                    if (W > max_w) break;
                     const int64_t A = ((ip1 - 1) / W) * W + 1, B = A + W - 1;
                     if (ne2 > B || ip1 >= B) continue;
                     const int64_t cnt = pb_wave_count(occ, A, B, false);
@@ -184,7 +175,7 @@ __global__ __launch_bounds__(PB_BLOCK) void k_plan(const DevBufs* bufs, const Ct
             int64_t ws = 1, we = 0, c = 0;
             for (int64_t h = 0; h <= height; ++h) {
                 const int64_t W = seg << h;
-                if (W > PB_MAX_W && h > 0) break;
+                if (W > max_w && h > 0) break;
                 ws = ((ip - 1) / W) * W + 1;
                 we = ws + W - 1;
                 c = pb_wave_count(occ, ws, we, false) + ((changed >= ws && changed <= we) ? delta : 0);
@@ -202,6 +193,22 @@ __global__ __launch_bounds__(PB_BLOCK) void k_plan(const DevBufs* bufs, const Ct
         }
     }
     if (pl.action == PB_BARRIER) pl.count = why;
+    return pl;
+}
+
+__global__ __launch_bounds__(PB_BLOCK) void k_plan(const DevBufs* bufs, const Ctl* ctl, const Op* ops, RoundState* rs, Plan* plans) {
+    // the round's window of ops comes from the device-resident cursor: rounds are enqueued back to back without host syncs
+    if (rs->stop) return;
+    const DevBufs db = *bufs;
+    const KeyArr keys{db.keys, db.wide, 0};
+    const double* vals = db.vals; const uint64_t* occ = db.occ;
+    const int64_t* sems = db.sems; const int64_t* col_keys = db.col_keys; const uint8_t* col_live = db.col_live;
+    const int64_t i0 = rs->cursor + rs->d;            // the resolve step of this round folds the previous prefix into the cursor
+    const int64_t left = rs->limit - i0;
+    const int G = (int)(left < rs->G ? left : rs->G);
+    const int w = blockIdx.x * (PB_BLOCK / 64) + (threadIdx.x >> 6);
+    if (w < G) {
+    const Plan pl = pb_plan_one(keys, vals, occ, sems, col_keys, col_live, ctl, ops[i0 + w], w, PB_MAX_W);
     if (lane_id() == 0) {
         // device-scope (write-through) stores: the workgroup that resolves the round may sit on another XCD; a release FENCE per
         // workgroup instead would write back that XCD's whole L2, which k_apply has just dirtied
@@ -507,23 +514,11 @@ __device__ bool pb_scan_and_rebalance_live(KeyArr keys, double* vals, uint64_t* 
     return true;
 }
 
-__global__ __launch_bounds__(PB_BLOCK) void k_apply(const DevBufs* bufs, Ctl* ctl, const Op* ops, const RoundState* rs, const Plan* plans) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char pb_lds[];
-    if (rs->stop) return;
-    const DevBufs db = *bufs;
-    const KeyArr keys{db.keys, db.wide, 0};
-    double* vals = db.vals; uint64_t* occ = db.occ;
-    int64_t* sems = db.sems; int64_t* col_keys = db.col_keys; uint8_t* col_live = db.col_live;
-    const int64_t i0 = rs->cursor;
-    const int d = rs->d;
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int w = blockIdx.x * (PB_BLOCK / 64) + wv;
-    if (w == 0 && lane == 0) const_cast<RoundState*>(rs)->G = rs->G_next;     // group size of the NEXT round (G is not read any more)
-    if (w >= d) return;
-    int64_t* sK = reinterpret_cast<int64_t*>(pb_lds) + (size_t)wv * PB_MAX_W;
-    double* sV = reinterpret_cast<double*>(pb_lds + (size_t)(PB_BLOCK / 64) * PB_MAX_W * sizeof(int64_t)) + (size_t)wv * PB_MAX_W;
-    const Plan pl = plans[w];
-    const Op op = ops[i0 + w];
+// ONE planned op applied by one wave: shift, write, occupancy update, then the small-window pack + spread through the wave's LDS slice
+// (sK / sV).  fault: raised if an op leaves its planned footprint (cannot happen, checked by the host).
+__device__ void pb_apply_one(KeyArr keys, double* vals, uint64_t* occ, int64_t* sems, int64_t* col_keys, uint8_t* col_live, Ctl* ctl,
+                             int32_t* fault, const Op op, const Plan pl, int64_t* sK, double* sV) {
+    const int lane = lane_id();
     const int64_t seg = ctl->segment_capacity;
     int64_t delta = 0;
     switch (pl.action) {
@@ -580,7 +575,7 @@ __global__ __launch_bounds__(PB_BLOCK) void k_apply(const DevBufs* bufs, Ctl* ct
             const int64_t ne2 = pb_next_empty_live(occ, s1, capacity);
             if (ne2 == 0 || ne2 > pl.hi || s1 < pl.lo || s1 >= pl.hi) {
                 // cannot happen (see k_plan); if it ever does, fail loudly instead of writing outside the footprint
-                if (lane == 0) atomicExch(&const_cast<RoundState*>(rs)->pad, 1);      // RoundState::pad = fault flag, read by the host after every burst
+                if (lane == 0) atomicExch(fault, 1);      // RoundState::pad = fault flag, read by the host after every burst
                 break;
             }
             pb_shift_right_live(keys, vals, sems, s1 + 1, ne2);
@@ -605,6 +600,110 @@ __global__ __launch_bounds__(PB_BLOCK) void k_apply(const DevBufs* bufs, Ctl* ct
             }
         }
     }
+}
+
+__global__ __launch_bounds__(PB_BLOCK) void k_apply(const DevBufs* bufs, Ctl* ctl, const Op* ops, const RoundState* rs, const Plan* plans) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char pb_lds[];
+    if (rs->stop) return;
+    const DevBufs db = *bufs;
+    const KeyArr keys{db.keys, db.wide, 0};
+    double* vals = db.vals; uint64_t* occ = db.occ;
+    int64_t* sems = db.sems; int64_t* col_keys = db.col_keys; uint8_t* col_live = db.col_live;
+    const int64_t i0 = rs->cursor;
+    const int d = rs->d;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int w = blockIdx.x * (PB_BLOCK / 64) + wv;
+    if (w == 0 && lane == 0) const_cast<RoundState*>(rs)->G = rs->G_next;     // group size of the NEXT round (G is not read any more)
+    if (w >= d) return;
+    int64_t* sK = reinterpret_cast<int64_t*>(pb_lds) + (size_t)wv * PB_MAX_W;
+    double* sV = reinterpret_cast<double*>(pb_lds + (size_t)(PB_BLOCK / 64) * PB_MAX_W * sizeof(int64_t)) + (size_t)wv * PB_MAX_W;
+    const Plan pl = plans[w];
+    const Op op = ops[i0 + w];
+    pb_apply_one(keys, vals, occ, sems, col_keys, col_live, ctl, &const_cast<RoundState*>(rs)->pad, op, pl, sK, sV);
+}
+
+// ---- local rounds: the same plan / resolve / apply, by ONE workgroup, for phases with little parallelism --------------------------
+// A grid round costs two launches (~15 us) whatever it applies; while the conflict-free prefixes are short — a small, fast-growing
+// array whose windows are wide relative to it (the first batches of config 5: 19 ops per round), a small vector — the launches are
+// all there is.  Here one persistent workgroup plans the next LR_WAVES ops (one wave each), decides the prefix in LDS, applies it,
+// and goes on: a mini-round is two workgroup barriers instead of two launches.  Between mini-rounds the waves' stores are waited
+// for and the scalar and vector L1 caches are invalidated (everything runs on one CU and one L2; the counters of the control block
+// change by atomics at the L2).  The kernel leaves at an op that cannot be planned or after 16 one-op prefixes in a row (stop = 1: the
+// sequencer), when the batch is done (2), when eight mini-rounds in a row applied all their ops (3: parallelism is back, grid
+// rounds), or after max_rounds.
+constexpr int LR_WAVES = 8;
+constexpr int LR_MAX_W = 1024;                // largest window a wave rebalances here (16 KB of LDS per wave)
+constexpr int LR_BLOCK = LR_WAVES * 64;
+
+__global__ __launch_bounds__(LR_BLOCK) void k_local_rounds(const DevBufs* bufs, Ctl* ctl, const Op* ops, RoundState* rs, int max_rounds) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lr_lds[];
+    __shared__ Plan sPlan[LR_WAVES];
+    __shared__ int sD;
+    const DevBufs db = *bufs;
+    const KeyArr keys{db.keys, db.wide, 0};
+    double* vals = db.vals; uint64_t* occ = db.occ;
+    int64_t* sems = db.sems; int64_t* col_keys = db.col_keys; uint8_t* col_live = db.col_live;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int64_t* sK = reinterpret_cast<int64_t*>(lr_lds) + (size_t)wv * LR_MAX_W;
+    double* sV = reinterpret_cast<double*>(lr_lds + (size_t)LR_WAVES * LR_MAX_W * sizeof(int64_t)) + (size_t)wv * LR_MAX_W;
+    int64_t cursor = rs->cursor + rs->d;
+    const int64_t limit = rs->limit;
+    int rounds = 0, stop = 0, why = 0, full_streak = 0, single_streak = 0;
+    int64_t par_ops = 0;
+    while (rounds < max_rounds) {
+        const int64_t left = limit - cursor;
+        if (left <= 0) { stop = 2; break; }
+        const int G = (int)(left < LR_WAVES ? left : LR_WAVES);
+        if (wv < G) {
+            const Plan pl = pb_plan_one(keys, vals, occ, sems, col_keys, col_live, ctl, ops[cursor + wv], wv, LR_MAX_W);
+            if (lane == 0) sPlan[wv] = pl;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            // d = min(first BARRIER, smallest j whose footprint overlaps the footprint of an earlier op)
+            int dd = G;
+            for (int j = 0; j < G && dd == G; ++j) {
+                if (sPlan[j].action == PB_BARRIER) { dd = j; break; }
+                const int64_t lo = sPlan[j].lo, hi = sPlan[j].hi;
+                if (lo > hi) continue;
+                for (int i = 0; i < j; ++i) {
+                    const int64_t l2 = sPlan[i].lo, h2 = sPlan[i].hi;
+                    if (l2 <= h2 && l2 <= hi && lo <= h2) { dd = j; break; }
+                }
+            }
+            sD = dd;
+        }
+        __syncthreads();
+        const int dd = sD;
+        if (dd == 0) { stop = 1; why = sPlan[0].count & 7; break; }       // the op at the cursor cannot be planned: the sequencer's
+        if (wv < dd) pb_apply_one(keys, vals, occ, sems, col_keys, col_live, ctl, &rs->pad, ops[cursor + wv], sPlan[wv], sK, sV);
+        cursor += dd; par_ops += dd; ++rounds;
+        full_streak = dd == LR_WAVES ? full_streak + 1 : 0;
+        single_streak = (dd == 1 && G > 1) ? single_streak + 1 : 0;
+        __builtin_amdgcn_s_waitcnt(0);                 // this wave's stores and atomics have been acknowledged
+        __syncthreads();
+        __builtin_amdgcn_s_dcache_inv();               // what the next plans read through the scalar cache ...
+        asm volatile("buffer_inv sc0" ::: "memory");          // ... and the vector L1 of this CU (not the L2: everything here runs on one XCD)
+        if (full_streak >= 8) { stop = 3; break; }
+        if (single_streak >= 16) { stop = 1; why = 7; break; }          // every op collides with its predecessor (appends, one hot key): the sequencer's
+    }
+    if (threadIdx.x == 0) {
+        rs->cursor = cursor; rs->d = 0;
+        rs->rounds += rounds; rs->par_ops += par_ops;
+        rs->stop = stop;
+        if (stop == 1) rs->why[why] += 1;
+    }
+}
+
+hipError_t launch_local_rounds(const DevBufs* bufs, Ctl* ctl, const Op* ops, RoundState* rs, int max_rounds, hipStream_t stream) {
+    constexpr size_t lds = (size_t)LR_WAVES * LR_MAX_W * (sizeof(int64_t) + sizeof(double));
+    static PerDeviceOnce once;
+    hipError_t e = once.run([] {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(k_local_rounds), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    });
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_local_rounds, dim3(1), dim3(LR_BLOCK), lds, stream, bufs, ctl, ops, rs, max_rounds);
+    return hipGetLastError();
 }
 
 // one round = plan (+ resolve and cursor advance by its last workgroup) -> apply, all driven by the device-resident RoundState
