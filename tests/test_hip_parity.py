@@ -1222,3 +1222,95 @@ def test_shard_entry_points_split_spmv_exactly(dsa, hip, oracle):
         np.testing.assert_allclose(part, ref.spmv_partial(ref.x_slice(x)).numpy(), rtol=RTOL, atol=0)
         y += part
     np.testing.assert_allclose(y, y_ref, rtol=RTOL, atol=0)
+
+
+# ---------------------------------------------------------------- round 2: the replay's memo between runs, grid-wide table merges
+@pytest.mark.gpu
+def test_append_memo_survives_runs_on_one_geometry_and_is_dropped_at_extend(dsa, hip, oracle):
+    """Several append runs on the SAME handle: the replay's memo (a pure function of the geometry) is reloaded from HBM while the
+    capacity is unchanged and rebuilt after _extend! (csrc/sequencer.hip: k_append_run, saved_memo).  Vector runs and matrix runs
+    with columns of different lengths (epochs through semaphore cells are keyed by the cell types)."""
+    n0 = 300000
+    keys0 = np.arange(1, n0 + 1, dtype=np.int64) * 2
+    vals0 = unit12_array(3, n0)
+    a = dsa.dynamicsparsevec(keys0, vals0, binding=hip)
+    b = dsa.dynamicsparsevec(keys0, vals0, binding=oracle)
+    nxt = 2 * n0 + 1
+    cap0 = a.info()["capacity"]
+    extended = False
+    for r, cnt in enumerate([3000, 3000, 5000, 700, 80000, 3000, 3000]):       # the 80000 run crosses the extend
+        ks = np.arange(nxt, nxt + cnt, dtype=np.int64)
+        vs = unit12_array(40 + r, cnt)
+        a.set_batch(ks, vs)
+        b.set_batch(ks, vs)
+        nxt += cnt
+        assert_vec_equal(a, b)
+        extended = extended or a.info()["capacity"] != cap0
+    assert extended
+    # matrix: columns streamed in ascending id, 1..9 ascending rows each, four batches on one geometry
+    A = dsa.dynamicsparse(fill_mode=False, binding=hip)
+    B = dsa.dynamicsparse(fill_mode=False, binding=oracle)
+    g = SplitMix64(77)
+    col = 0
+    for r, ncols in enumerate([900, 900, 2500, 900]):
+        I, J = [], []
+        for _ in range(ncols):
+            col += 1
+            rows = sorted({1 + g.next() % 5000 for _ in range(1 + g.next() % 9)})
+            I += rows
+            J += [col] * len(rows)
+        V = unit12_array(60 + r, len(I))
+        A.set_batch(I, J, V)
+        B.set_batch(I, J, V)
+        assert_mat_equal(A, B)
+    for o in (0, 1):
+        assert not A.check(o)[2:7].any(), A.check(o)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,batches", [(91, [200, 300, 1500, 5000, 40, 9000]), (92, [3000, 3000, 3000])])
+def test_new_partitions_by_the_thousand_merge_between_launches(dsa, hip, oracle, seed, batches):
+    """Batches that create 100 .. several 1000 new rows AND columns in random key order next to writes to existing ones, from an
+    empty matrix on: the first batches run on the local rounds, every batch leaves pending table entries across several launches
+    and the grid-wide merge (csrc/tables.hip) brings the tables back to key order between them and before the batch returns."""
+    A = dsa.dynamicsparse(fill_mode=False, binding=hip)
+    B = dsa.dynamicsparse(fill_mode=False, binding=oracle)
+    g = SplitMix64(seed)
+    span = 20000
+    for r, nb in enumerate(batches):
+        I = [int(1 + g.next() % span) for _ in range(nb)]
+        J = [int(1 + g.next() % span) for _ in range(nb)]
+        V = unit12_array(seed * 10 + r, nb)
+        A.set_batch(I, J, V)
+        B.set_batch(I, J, V)
+        assert_mat_equal(A, B)
+        for o in (0, 1):
+            assert not A.check(o)[2:7].any(), A.check(o)     # report[6] also covers "no table entry pending outside a batch"
+    # a few deletes of whole columns afterwards (tombstones: the literal paths), then more new columns
+    for j in sorted({int(1 + g.next() % span) for _ in range(40)}):
+        try:
+            A.deletecolumn(j)
+            ok = True
+        except Exception:
+            ok = False
+        try:
+            B.deletecolumn(j)
+            okb = True
+        except Exception:
+            okb = False
+        assert ok == okb
+    nb = 2000
+    I = [int(1 + g.next() % span) for _ in range(nb)]
+    J = [int(span + 1 + g.next() % span) for _ in range(nb)]
+    V = unit12_array(seed * 10 + 9, nb)
+    try:
+        A.set_batch(I, J, V); ea = None
+    except Exception as e:
+        ea = type(e).__name__
+    try:
+        B.set_batch(I, J, V); eb = None
+    except Exception as e:
+        eb = type(e).__name__
+    assert ea == eb
+    if ea is None:
+        assert_mat_equal(A, B)
