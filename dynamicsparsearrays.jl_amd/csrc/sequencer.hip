@@ -379,8 +379,8 @@ __device__ __noinline__ void wave_model2(Model2IO* io, RunMemo* memo, const uint
 constexpr int MEMO_ENTRIES = 640, MEMO_WORDS = 1664;
 // memo entries: [0, M2_DIRECT) indexed by (level, count) for windows up to 256 slots, the rest hashed by (level, count).  The memo
 // lives in dynamic LDS (128 KB of the CU's 160 KB: the kernel is one workgroup)
-constexpr int M2_DIRECT = 512, M2_HASHED_LOG2 = 11, M2_HASHED = 1 << M2_HASHED_LOG2, M2_EV = M2_DIRECT + M2_HASHED;
-constexpr int M2_HASH_LOG2 = 10, M2_HASH = 1 << M2_HASH_LOG2;
+constexpr int M2_DIRECT = 512, M2_HASHED_LOG2 = 10, M2_HASHED = 1 << M2_HASHED_LOG2, M2_EV = M2_DIRECT + M2_HASHED;
+constexpr int M2_HASH_LOG2 = 11, M2_HASH = 1 << M2_HASH_LOG2;
 struct RunMemo {
     uint64_t words[MEMO_WORDS]; unsigned long long gapw[64];
     // model v2: memo of the rebalances of the wide levels, tagged (level << 16 | cell count) — windows up to 256 slots have their own
