@@ -186,14 +186,29 @@ static __device__ DFoundKey d_find_table_fast(const int64_t* ck, const uint8_t* 
     }
     const int64_t p = L + 1 + lane;
     bool viol = false;
-    if (p <= H && (dense || live[p - 1])) viol = ck[p - 1] >= key;
+    int64_t myk = 0;
+    if (p <= H && (dense || live[p - 1])) { myk = ck[p - 1]; viol = myk >= key; }
     const uint64_t b = __ballot(viol);
     const int64_t pstar = b ? L + __ffsll((unsigned long long)b) - 1 : H;
+    if (dense) {
+        // the two keys the answer needs were just loaded by the lanes that probed positions pstar + 1 and pstar (if they lie in
+        // (L, H]): a shuffle instead of two more dependent round trips
+        const int64_t nxt = pstar + 1;
+        if (nxt <= len) {
+            const int64_t kn = (nxt > L && nxt <= H) ? __shfl(myk, (int)(nxt - L - 1), 64) : ck[nxt - 1];
+            if (kn == key) return DFoundKey{nxt, key, true};
+        }
+        if (pstar > 0) {
+            const int64_t ki = (pstar > L && pstar <= H) ? __shfl(myk, (int)(pstar - L - 1), 64) : ck[pstar - 1];
+            return DFoundKey{pstar, ki, true};
+        }
+        return DFoundKey{0, 0, false};
+    }
     int64_t nxt = pstar + 1;
-    if (!dense) while (nxt <= len && !live[nxt - 1]) ++nxt;
+    while (nxt <= len && !live[nxt - 1]) ++nxt;
     if (nxt <= len && ck[nxt - 1] == key) return DFoundKey{nxt, key, true};
     int64_t i = pstar;
-    if (!dense) while (i > 0 && !live[i - 1]) --i;
+    while (i > 0 && !live[i - 1]) --i;
     if (i > 0) return DFoundKey{i, ck[i - 1], true};
     return DFoundKey{0, 0, false};
 }
