@@ -480,6 +480,26 @@ def extras(dsa, hip, torch, A, dev):
     #     element by element into an empty matrix — both orientations —, SpMV every 1000 columns.  Parity of this loop vs the
     #     oracle: tests/test_hip_parity.py::test_matrix_from_empty_streaming_columns_c5_scaled
     res["c5_streaming"] = c5_streaming(dsa, hip, torch, dev, *C5_FULL)
+    # --- buffered writes: the C3 triples through the fill buffer in ten batches of 1 M, then
+    #     closefillmode! (the flush = two bulk builds); and dynamicsparse(I, J, V) from caller memory.  Second of two passes (the
+    #     first one pays the pinned staging chunks, which are kept).
+    I3, J3, V3 = c3_triplets(1_000_000, 1_000_000, 10, 0, seed_rows=5, seed_vals=6)
+    fill = {}
+    for _ in range(2):
+        F = dsa.dynamicsparse(fill_mode=True, binding=hip)
+        t = time.perf_counter()
+        for c in range(0, len(I3), 1_000_000):
+            F.set_batch(I3[c:c + 1_000_000], J3[c:c + 1_000_000], V3[c:c + 1_000_000])
+        t1 = time.perf_counter()
+        F.closefillmode()
+        t2 = time.perf_counter()
+        fill = {"triples": int(len(I3)), "appends_ms": round((t1 - t) * 1e3, 2), "closefillmode_ms": round((t2 - t1) * 1e3, 2), "nnz": int(F.nnz())}
+        del F
+    t = time.perf_counter()
+    F = dsa.dynamicsparse(I3, J3, V3, 1_000_000, 1_000_000, binding=hip)
+    fill["dynamicsparse_from_caller_memory_ms"] = round((time.perf_counter() - t) * 1e3, 2)
+    del F
+    res["buffered_writes"] = fill
     return res
 
 
