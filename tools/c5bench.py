@@ -11,8 +11,8 @@ m5, ncols5, per5 = (100_000, 50_000, 16) if full else (10_000, 5_000, 16)
 step = 1000 if full else 500
 if '--cold' not in sys.argv:      # warm the process (code objects, first graph instantiation, allocator) like bench.py's earlier legs do
     W = dsa.dynamicsparse(fill_mode=False, binding=hip)
-    rw = 1 + (bench.splitmix_array(3, 40000) % np.uint64(5000)).astype(np.int64)
-    W.set_batch(rw[:20000], np.repeat(np.arange(1, 1251), 16), bench.unit12(4, 20000))
+    Iw, Jw, Vw = bench.c5_columns(5000, 1250, 16)        # the same kind of stream at 1/40 of the size
+    W.set_batch(Iw, Jw, Vw)
     del W
 B = dsa.dynamicsparse(fill_mode=False, binding=hip)
 rows5 = 1 + (bench.splitmix_array(11, ncols5 * per5 * 2) % np.uint64(m5)).astype(np.int64)
