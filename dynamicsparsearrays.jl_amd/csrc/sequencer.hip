@@ -374,7 +374,7 @@ __device__ __forceinline__ uint64_t u64(uint64_t v) {
 #define M2_T() 0ll
 #endif
 struct RunMemo;
-__device__ __noinline__ void wave_model2(Model2IO* io, RunMemo* memo, const uint64_t* flags);
+template <int NLOW, bool TYPED> __device__ __noinline__ void wave_model2_t(Model2IO* io, RunMemo* memo, const uint64_t* flags);
 
 constexpr int MEMO_ENTRIES = 640, MEMO_WORDS = 1664;
 // memo entries: [0, M2_DIRECT) indexed by (level, count) for windows up to 256 slots, the rest hashed by (level, count).  The memo
@@ -400,7 +400,11 @@ __device__ __forceinline__ int ep_n(uint64_t r) { return (int)(r & 0xffu) - 1; }
 __device__ __forceinline__ int ep_reb(uint64_t r) { return (int)((r >> 9) & 0xffu); }
 __device__ __forceinline__ int ep_slots(uint64_t r) { return (int)((r >> 17) & 0x3fffu); }
 
-__device__ __noinline__ void wave_model2(Model2IO* io_, RunMemo* memo_, const uint64_t* flags_) {
+// NLOW = number of levels whose window fits one occupancy word, a template parameter: the segment size (64 >> (NLOW - 1)), the
+// level masks and the trip count of the in-word scan are constants of each instantiation, and the levels that do not exist cost no
+// scalar registers (with six run-time levels the thresholds lived in spilled SGPRs, read back with v_readlane at every use).
+// TYPED = the run has cell types (MappedPackedCSC: some cells are semaphores); a vector run carries none of that code.
+template <int NLOW, bool TYPED> __device__ __noinline__ void wave_model2_t(Model2IO* io_, RunMemo* memo_, const uint64_t* flags_) {
     constexpr uint64_t TOP = 1ull << 63;
     // arguments of a non-kernel function arrive in vector registers and count as divergent: re-establish them as uniform
     Model2IO* io = (Model2IO*)u64((uint64_t)io_);
@@ -412,14 +416,14 @@ __device__ __noinline__ void wave_model2(Model2IO* io_, RunMemo* memo_, const ui
     const int64_t idx0 = (int64_t)u64((uint64_t)io->idx), end0 = (int64_t)u64((uint64_t)io->end);
     const int64_t base = idx0 & ~63ll;
     const uint64_t* flags = (const uint64_t*)u64((uint64_t)flags_);
-    const uint64_t* fwp = flags != nullptr ? flags + (base >> 6) : nullptr;
-    const bool typed = fwp != nullptr;               // MappedPackedCSC run: some cells are semaphores
+    const uint64_t* fwp = TYPED ? flags + (base >> 6) : nullptr;
+    constexpr bool typed = TYPED;                    // MappedPackedCSC run: some cells are semaphores
     int j = u32((int)(idx0 - base));
     const int jend = u32((int)(end0 - base < 0x7fff0000ll ? end0 - base : 0x7fff0000ll));
-    const int nlow = u32(io->nlow), seg = u32(io->seg);
-    int lo_s[6], hi_s[6], wb_s[6];
+    constexpr int nlow = NLOW, seg = 64 >> (NLOW - 1);
+    int lo_s[NLOW], hi_s[NLOW], wb_s[NLOW];
 #pragma unroll
-    for (int h = 0; h < 6; ++h) { lo_s[h] = u32((int)io->lo[h]); hi_s[h] = u32((int)io->hi[h]); wb_s[h] = u32(io->wb[h]); }
+    for (int h = 0; h < NLOW; ++h) { lo_s[h] = u32((int)io->lo[h]); hi_s[h] = u32((int)io->hi[h]); wb_s[h] = u32(io->wb[h]); }
     uint32_t cnt = io->cnt[lane];
     const uint32_t my_W = io->W[lane], my_lo = io->lo[lane], my_hi = io->hi[lane];
     const bool lvl_mid = my_W != 0;
@@ -566,14 +570,12 @@ __device__ __noinline__ void wave_model2(Model2IO* io_, RunMemo* memo_, const ui
             // ---- _look_for_rebalance!, levels inside the word
             int h_acc = -1, c_acc = 0, sh_acc = 0, wbh = 0;
 #pragma unroll
-            for (int h = 0; h < 6; ++h) {
-                if (h < nlow && h_acc < 0) {
-                    const int W = seg << h;
-                    const int sh = bip & ~(W - 1);
-                    const uint64_t m = (W == 64 ? ~0ull : ((1ull << W) - 1ull)) << sh;
-                    const int c = popc64(nw & m);
-                    if (lo_s[h] <= c && c <= hi_s[h]) { h_acc = h; c_acc = c; sh_acc = sh; wbh = wb_s[h]; }
-                }
+            for (int h = 0; h < NLOW; ++h) {
+                const int W = seg << h;
+                const int sh = bip & ~(W - 1);
+                const uint64_t m = (W == 64 ? ~0ull : ((1ull << W) - 1ull)) << sh;
+                const int c = popc64(nw & m);
+                if (lo_s[h] <= c && c <= hi_s[h]) { h_acc = h; c_acc = c; sh_acc = sh; wbh = wb_s[h]; break; }
             }
             if (h_acc >= 0) {
                 if (h_acc > 0) {                       // _even_rebalance! inside the word: memoised pattern of (W, c)
@@ -886,7 +888,25 @@ __device__ void wave_fast_appends(Seq& S, RunComm* rc, RunMemo* memo, const uint
                 }
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_s_waitcnt(0xc07f);
-                wave_model2(io, memo, flags);
+                if (flags != nullptr) {
+                    switch (nlow) {
+                        case 1: wave_model2_t<1, true>(io, memo, flags); break;
+                        case 2: wave_model2_t<2, true>(io, memo, flags); break;
+                        case 3: wave_model2_t<3, true>(io, memo, flags); break;
+                        case 4: wave_model2_t<4, true>(io, memo, flags); break;
+                        case 5: wave_model2_t<5, true>(io, memo, flags); break;
+                        default: wave_model2_t<6, true>(io, memo, flags); break;
+                    }
+                } else {
+                    switch (nlow) {
+                        case 1: wave_model2_t<1, false>(io, memo, flags); break;
+                        case 2: wave_model2_t<2, false>(io, memo, flags); break;
+                        case 3: wave_model2_t<3, false>(io, memo, flags); break;
+                        case 4: wave_model2_t<4, false>(io, memo, flags); break;
+                        case 5: wave_model2_t<5, false>(io, memo, flags); break;
+                        default: wave_model2_t<6, false>(io, memo, flags); break;
+                    }
+                }
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_s_waitcnt(0xc07f);
                 if (lane == 0) { S.ctl->prof[8] += 1; S.ctl->prof[9] += io->idx - (int64_t)idx; S.ctl->prof[10] += io->dbg_mid; S.ctl->prof[11] += io->dbg_miss;
