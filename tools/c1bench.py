@@ -10,4 +10,3 @@ for rep in range(3):
     t = time.perf_counter(); v.set_batch(newk, bench.unit12(9, 1000)); dt = time.perf_counter() - t
     inf = v.info()
     print("C1-like: 1000 random writes on a 10k vector: %.2f ms (%.0f ops/s) rounds %d par %d seq %d" % (dt*1e3, 1000/dt, inf["stat_par_rounds"], inf["stat_par_ops"], inf["stat_seq_ops"]))
-    newk = np.arange(10**7 + 1, 10**7 + 1001, dtype=np.int64)
