@@ -644,10 +644,10 @@ int64_t run_ops_parallel(Pma& P, const std::vector<Op>& ops, int32_t* err) {
         {
             ++P.layout_epoch;
             // (every burst is followed by a stream wait, so the pinned mirror is never rewritten under a copy in flight)
-            const DevBufs now{P.K().p, P.V(), P.O(), P.has_sems ? P.sems : nullptr, P.has_cols ? P.col_keys : nullptr,
-                              P.has_cols ? P.col_live : nullptr, P.wide ? 1 : 0, 0};
-            if (std::memcmp(&now, P.h_bufs, sizeof(DevBufs)) != 0) {
-                *P.h_bufs = now;
+            const DevBufs bufs_now{P.K().p, P.V(), P.O(), P.has_sems ? P.sems : nullptr, P.has_cols ? P.col_keys : nullptr,
+                                   P.has_cols ? P.col_live : nullptr, P.wide ? 1 : 0, 0};
+            if (std::memcmp(&bufs_now, P.h_bufs, sizeof(DevBufs)) != 0) {
+                *P.h_bufs = bufs_now;
                 HIPCHK(hipMemcpyAsync(P.d_bufs, P.h_bufs, sizeof(DevBufs), hipMemcpyHostToDevice, P.stream));
             }
             // short conflict-free prefixes (a small array, colliding ops): the rounds of one persistent workgroup, no launch per round
