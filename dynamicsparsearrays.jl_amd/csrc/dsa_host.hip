@@ -970,6 +970,7 @@ struct dsa_mat {
     Pma col, row;          // colmajor / rowmajor MappedPackedCSC
     double* d_x = nullptr; double* d_y = nullptr; int64_t x_cap = 0, y_cap = 0;
     void* sp_base = nullptr; size_t sp_bytes = 0;             // scratch of the sparse-x SpMV (grown, never shrunk)
+    void* sp_pin = nullptr; size_t sp_pin_bytes = 0;          // pinned staging of its x upload and result download
     RebalanceWork sp_work{nullptr, nullptr, 0};
     std::vector<int64_t> pi, pj; std::vector<double> pv;      // queued single writes (non-fill mode)
 };
@@ -1594,6 +1595,7 @@ int32_t dsa_mat_destroy(dsa_mat_t* h) {
         if (h->d_x) hipFree(h->d_x);
         if (h->d_y) hipFree(h->d_y);
         if (h->sp_base) hipFree(h->sp_base);
+        if (h->sp_pin) hipHostFree(h->sp_pin);
         if (h->sp_work.tile_cnt) { hipFree(h->sp_work.tile_cnt); hipFree(h->sp_work.tile_off); }
         delete h;
     }
@@ -1941,8 +1943,22 @@ int32_t dsa_mat_spmv_sparse(dsa_mat_t* h, int32_t transpose, const int64_t* xi, 
     ensure_xy(h, std::max<int64_t>(nxdd, 1), 2 * ny);
     Pma& P = xdriven ? (transpose ? h->row : h->col) : (transpose ? h->col : h->row);      // the structure that is walked
     hipStream_t s = P.stream;
-    HIPCHK(hipMemcpyAsync(d_xi, xi, (size_t)nx * 8, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(d_xv, xv, (size_t)nx * 8, hipMemcpyHostToDevice, s));
+    // x up and the result down through a pinned staging area of the handle: copies between the device and the caller's PAGEABLE
+    // arrays take anything from 3 to 14 ms for these 16 MB depending on the state of the caller's pages (measured: the same call 4.5
+    // or 15 ms from one bench run to the next); DMA to pinned memory + a host memcpy does not
+    {
+        const size_t need = 16 * (size_t)std::max<int64_t>(nx, ny);
+        if (need > h->sp_pin_bytes) {
+            if (h->sp_pin) { HIPCHK(hipStreamSynchronize(s)); HIPCHK(hipHostFree(h->sp_pin)); }
+            h->sp_pin = nullptr; h->sp_pin_bytes = 0;
+            HIPCHK(hipHostMalloc(&h->sp_pin, need + need / 2, hipHostMallocDefault));
+            h->sp_pin_bytes = need + need / 2;
+        }
+    }
+    char* pin = static_cast<char*>(h->sp_pin);
+    std::memcpy(pin, xi, (size_t)nx * 8);
+    std::memcpy(pin + (size_t)nx * 8, xv, (size_t)nx * 8);
+    HIPCHK(hipMemcpyAsync(d_xi, pin, (size_t)nx * 16, hipMemcpyHostToDevice, s));           // d_xi and d_xv are adjacent
     hipError_t e;
     int64_t cnt = 0;
     if (xdriven) {
@@ -1960,10 +1976,14 @@ int32_t dsa_mat_spmv_sparse(dsa_mat_t* h, int32_t transpose, const int64_t* xi, 
     if (e != hipSuccess) fail(DSA_EHIP, std::string("touched-row compaction: ") + hipGetErrorString(e));
     if (cnt > cap) { HIPCHK(hipStreamSynchronize(s)); fail(DSA_ECAP, "output buffers too small"); }
     if (cnt > 0) {
-        HIPCHK(hipMemcpyAsync(yi, d_oi, (size_t)cnt * 8, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipMemcpyAsync(yv, d_ov, (size_t)cnt * 8, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(pin, d_oi, (size_t)cnt * 8, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(pin + (size_t)cnt * 8, d_ov, (size_t)cnt * 8, hipMemcpyDeviceToHost, s));
     }
     HIPCHK(hipStreamSynchronize(s));
+    if (cnt > 0) {
+        std::memcpy(yi, pin, (size_t)cnt * 8);
+        std::memcpy(yv, pin + (size_t)cnt * 8, (size_t)cnt * 8);
+    }
     *n_out = cnt;
     API_CATCH
 }
