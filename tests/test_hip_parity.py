@@ -1138,6 +1138,10 @@ def test_forced_64bit_keys_and_replay_variants_in_subprocesses(dsa, hip, oracle)
     assert r.returncode == 0 and "append parity ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz.py"), "8", "777"], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "fuzz done" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    # DSA_LOCAL_ROUNDS=0: small structures through the grid rounds only (the suite itself runs them on the local rounds)
+    env = dict(os.environ, DSA_LOCAL_ROUNDS="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz.py"), "8", "4242"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "fuzz done" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 @pytest.mark.gpu
