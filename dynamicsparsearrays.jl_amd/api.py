@@ -174,6 +174,21 @@ def dynamicsparsevec(I, V, combine="+", n=None, binding: Binding | None = None) 
     return DynamicSparseVector(b, h)
 
 
+def import_vector_layout(keys, vals, occ, segment_capacity, n=None, binding: Binding | None = None) -> DynamicSparseVector:
+    """A vector restored from an exported layout (`DynamicSparseVector.export_layout` + its segment capacity): snapshot / restore,
+    and the way a test puts a structure into an arbitrary state.  No reference counterpart (include/dsa.h: dsa_vec_import_layout)."""
+    b = _bind(binding)
+    k, kp = _i64(keys)
+    v, vp = _f64(vals)
+    o = np.ascontiguousarray(occ, dtype=np.uint8)
+    assert len(k) == len(v) == len(o)
+    if n is None:
+        n = int(k[o.astype(bool)].max()) if o.any() else 0
+    h = VP()
+    b.call("vec_import_layout", kp, vp, o.ctypes.data_as(P_U8), len(o), int(segment_capacity), int(n), C.byref(h))
+    return DynamicSparseVector(b, h)
+
+
 class PackedCSC(_Handle):
     """PackedCSC{Int64,Float64}  (src/pcsr.jl:4-9)."""
     _destroy = "pcsc_destroy"
@@ -234,6 +249,18 @@ def packedcsc(row_keys, values, combine="+", binding: Binding | None = None) -> 
     h = VP()
     b.call("pcsc_create", colptr.ctypes.data_as(P_I64), len(row_keys), rk.ctypes.data_as(P_I64),
            vv.ctypes.data_as(P_F64), COMBINE[combine], C.byref(h))
+    return PackedCSC(b, h)
+
+
+def import_packedcsc_layout(keys, vals, occ, segment_capacity, semaphores, binding: Binding | None = None) -> PackedCSC:
+    """A PackedCSC restored from an exported layout (include/dsa.h: dsa_pcsc_import_layout)."""
+    b = _bind(binding)
+    k, kp = _i64(keys)
+    v, vp = _f64(vals)
+    o = np.ascontiguousarray(occ, dtype=np.uint8)
+    s, sp = _i64(semaphores if len(semaphores) else [0])
+    h = VP()
+    b.call("pcsc_import_layout", kp, vp, o.ctypes.data_as(P_U8), len(o), int(segment_capacity), sp, len(semaphores), C.byref(h))
     return PackedCSC(b, h)
 
 

@@ -78,6 +78,8 @@ _SIGS = {
     "vec_info": [VP, P_I64],
     "vec_export_layout": [VP, P_I64, P_F64, P_U8, I64],
     "vec_rebalance_root": [VP],
+    "vec_import_layout": [P_I64, P_F64, P_U8, I64, I64, I64, C.POINTER(VP)],
+    "pcsc_import_layout": [P_I64, P_F64, P_U8, I64, I64, P_I64, I64, C.POINTER(VP)],
     "pcsc_create": [P_I64, I64, P_I64, P_F64, I32, C.POINTER(VP)],
     "pcsc_create_empty": [C.POINTER(VP)],
     "pcsc_destroy": [VP],
@@ -127,6 +129,12 @@ _DEVICE_SIGS = {
     "mat_sync": [VP],
     "vec_sync": [VP],
     "vec_dev_relayout": [VP, I32],
+    # parity hooks: device slot-array primitives on raw slot arrays (include/dsa.h)
+    "dbg_raw_find": [P_I64, P_F64, P_U8, I64, I64, I64, I64, I32, I32, P_I64, P_I32, P_I64, P_F64],
+    "dbg_raw_insert": [P_I64, P_F64, P_U8, I64, I64, F64, I64, I64, P_I64, I64, I32, I32, P_I64, P_I32],
+    "dbg_raw_delete": [P_I64, P_F64, P_U8, I64, I64, I64, I64, I32, I32, P_I64, P_I32],
+    "dbg_raw_purge": [P_I64, P_F64, P_U8, I64, I64, I64, P_I64, P_I64],
+    "dbg_raw_rebalance": [P_I64, P_F64, P_U8, I64, I64, I64, P_I64, I64, I32],
 }
 
 

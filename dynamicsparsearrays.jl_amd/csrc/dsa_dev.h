@@ -343,6 +343,16 @@ hipError_t launch_get_batch(int mode, KeyArr keys, const double* vals, const uin
                             const int64_t* sems, const int64_t* col_keys, const uint8_t* col_live, int64_t table_len,
                             const int64_t* qa, const int64_t* qb, int64_t n, double* out, int32_t* err_out,
                             hipStream_t stream);
+// parity hooks (include/dsa.h: dsa_dbg_raw_*): ONE slot-array primitive on a raw slot array of `len` slots; out = 6 x int64 device
+// scratch {error, position, flag, found key, found value bits, cells purged}.  _block: the sequencer's workgroup primitives
+// (sequencer.hip), _wave: the wave-level primitives of the batch-parallel rounds (parbatch.hip).  *_FAST: K-find in its
+// wave-parallel 64-ary form (d_find_fast) instead of the literal bisection (d_find).
+enum DbgRawOp : int32_t { DBG_FIND = 0, DBG_FIND_FAST = 1, DBG_INSERT = 2, DBG_INSERT_FAST = 3, DBG_DELETE = 4, DBG_DELETE_FAST = 5,
+                          DBG_PURGE = 6, DBG_REBALANCE = 7 };
+hipError_t launch_dbg_raw_block(KeyArr keys, double* vals, uint64_t* occ, int64_t* sems, int64_t len, int op, int64_t key, double val,
+                                int64_t from, int64_t to, int64_t m, int64_t* out, hipStream_t stream);
+hipError_t launch_dbg_raw_wave(KeyArr keys, double* vals, uint64_t* occ, int64_t* sems, int64_t len, int op, int64_t key, double val,
+                               int64_t from, int64_t to, int64_t m, int64_t* out, hipStream_t stream);
 // device-side invariant checker; report[0..5] as documented at k_check_slots (8 x uint64 device scratch)
 hipError_t launch_check(KeyArr keys, const double* vals, const uint64_t* occ, int64_t capacity, int64_t occ_words,
                         const int64_t* sems, const int64_t* col_keys, const uint8_t* col_live, int64_t table_len,

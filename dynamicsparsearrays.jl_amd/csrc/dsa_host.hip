@@ -1331,7 +1331,8 @@ int32_t dsa_vec_nonzeros(dsa_vec_t* h, int64_t* keys, double* vals, int64_t cap,
     API_CATCH
 }
 // K-pack of the whole vector into its alternate slot buffer (free between rebalances); returns the number of stored cells.
-// Synchronises the vector's stream.
+// The count is known on return, the packed cells are still being written on the vector's OWN stream: a consumer on another stream
+// (the other operand of == / +) must wait for it (wait_for_pack).
 static int64_t vec_pack_alt(dsa_vec_t* h) {
     Pma& P = h->P;
     int64_t cnt = 0;
@@ -1339,6 +1340,11 @@ static int64_t vec_pack_alt(dsa_vec_t* h) {
     hipError_t e = launch_compact_range(P.K(), P.V(), P.O(), 1, P.capacity(), P.KA(alt), P.vals[alt], P.cap_alloc, &P.work, &cnt, P.stream);
     if (e != hipSuccess) fail(DSA_EHIP, std::string("compact launch: ") + hipGetErrorString(e));
     return cnt;
+}
+// the packed cells of `producer` (vec_pack_alt) are complete before anything enqueued on `consumer`'s stream afterwards runs
+static void wait_for_pack(dsa_vec_t* producer, dsa_vec_t* consumer) {
+    if (producer->P.stream == consumer->P.stream) return;
+    HIPCHK(hipStreamSynchronize(producer->P.stream));
 }
 // v1 == v2  src/vector.jl:85-87 (lengths, then src/pma.jl:262-266: nb_elements, then the stored tuples pairwise in slot order,
 // _arrays_equal src/pma.jl:236-260); compared on the device, only the verdict crosses PCIe
@@ -1353,6 +1359,7 @@ int32_t dsa_vec_equal(dsa_vec_t* a, dsa_vec_t* b, int32_t* out) {
     if (n == 0) { *out = 1; return DSA_OK; }
     if (vec_pack_alt(a) != n || vec_pack_alt(b) != n) fail(DSA_EASSERT, "stored-cell count differs from nb_elements");
     Pma &A = a->P, &B = b->P;
+    wait_for_pack(b, a);
     HIPCHK(hipMemsetAsync(A.d_err, 0, sizeof(int32_t), A.stream));
     hipError_t e = launch_packed_equal(A.KA(1 - A.cur), A.vals[1 - A.cur], B.KA(1 - B.cur), B.vals[1 - B.cur], n, A.d_err, A.stream);
     if (e != hipSuccess) fail(DSA_EHIP, std::string("compare launch: ") + hipGetErrorString(e));
@@ -1375,6 +1382,7 @@ int32_t dsa_vec_axpby(dsa_vec_t* a, double alpha, dsa_vec_t* b, double beta, int
     const int64_t total = na + nb;
     if (total == 0) return DSA_OK;
     Pma &A = a->P, &B = b->P;
+    if (b != a) wait_for_pack(b, a);
     const int64_t nwords = (total + 63) >> 6, ntiles = (nwords + 63) / 64;
     char* scratch = nullptr;
     const size_t off_mv = (size_t)total * 8, off_ok = 2 * off_mv, off_ov = 3 * off_mv, off_keep = 4 * off_mv,
@@ -2004,6 +2012,213 @@ int32_t dsa_mat_sync(dsa_mat_t* h) {
     API_TRY
     mat_flush(h);
     if (h->has_major) { HIPCHK(hipStreamSynchronize(h->col.stream)); HIPCHK(hipStreamSynchronize(h->row.stream)); }
+    API_CATCH
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------------
+// parity hooks: the device slot-array primitives on a caller-supplied raw slot array (dsa_dbg_raw_*), and handles
+// restored from an exported layout (dsa_*_import_layout).  Test / snapshot entry points: no reference counterpart.
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+// a temporary PMA around a raw slot array of `len` slots (no geometry: capacity = len, any length)
+void raw_load(Pma& P, const int64_t* keys, const double* vals, const uint8_t* occ, int64_t len, const int64_t* sems, int64_t nsems,
+              int64_t extra_key) {
+    if (len < 1) fail(DSA_EARG, "raw slot array must hold at least one slot");
+    if (nsems < 0 || (sems == nullptr && nsems > 0)) fail(DSA_EARG, "bad semaphore table");
+    pma_init_common(P, sems != nullptr, false);
+    P.wide = !keys_fit32(keys, len) || !key_fits32(extra_key);
+    P.h_ctl->capacity = len;
+    ensure_capacity_alloc(P, len);
+    std::vector<uint64_t> words((size_t)P.occ_words, 0ull);
+    for (int64_t i = 0; i < len; ++i) if (occ[i]) words[(size_t)(i >> 6)] |= 1ull << (i & 63);
+    upload_keys(P, P.keys[P.cur], keys, len);
+    HIPCHK(hipMemcpyAsync(P.V(), vals, (size_t)len * sizeof(double), hipMemcpyHostToDevice, P.stream));
+    HIPCHK(hipMemcpyAsync(P.O(), words.data(), words.size() * sizeof(uint64_t), hipMemcpyHostToDevice, P.stream));
+    P.occ_dirty[P.cur] = (len + 63) / 64;
+    if (sems != nullptr) {
+        ensure_tables(P, std::max<int64_t>(nsems, 1));
+        P.h_ctl->table_len = nsems;
+        if (nsems > 0) HIPCHK(hipMemcpyAsync(P.sems, sems, (size_t)nsems * sizeof(int64_t), hipMemcpyHostToDevice, P.stream));
+    }
+    HIPCHK(hipStreamSynchronize(P.stream));
+}
+void raw_store(Pma& P, int64_t* keys, double* vals, uint8_t* occ, int64_t len, int64_t* sems, int64_t nsems) {
+    export_slots(P, keys, vals, occ, len);
+    if (sems != nullptr && nsems > 0) {
+        HIPCHK(hipMemcpyAsync(sems, P.sems, (size_t)nsems * sizeof(int64_t), hipMemcpyDeviceToHost, P.stream));
+        HIPCHK(hipStreamSynchronize(P.stream));
+    }
+}
+struct RawGuard { Pma P; ~RawGuard() { if (P.stream) pma_destroy(P); } };
+
+// one primitive on the loaded array; r = {error, position, flag, found key, found value bits, cells purged}
+void raw_run(Pma& P, int32_t engine, int op, int64_t key, double val, int64_t from, int64_t to, int64_t m, int64_t r[6]) {
+    hipError_t e;
+    if (engine == DSA_DBG_ENGINE_BLOCK)
+        e = launch_dbg_raw_block(P.K(), P.V(), P.O(), P.has_sems ? P.sems : nullptr, P.capacity(), op, key, val, from, to, m, P.d_small, P.stream);
+    else if (engine == DSA_DBG_ENGINE_WAVE)
+        e = launch_dbg_raw_wave(P.K(), P.V(), P.O(), P.has_sems ? P.sems : nullptr, P.capacity(), op, key, val, from, to, m, P.d_small, P.stream);
+    else fail(DSA_EARG, "engine must be DSA_DBG_ENGINE_BLOCK or DSA_DBG_ENGINE_WAVE for this primitive");
+    if (e != hipSuccess) fail(DSA_EHIP, std::string("parity hook launch: ") + hipGetErrorString(e));
+    HIPCHK(hipMemcpyAsync(P.h_small, P.d_small, 6 * sizeof(int64_t), hipMemcpyDeviceToHost, P.stream));
+    HIPCHK(hipStreamSynchronize(P.stream));
+    for (int i = 0; i < 6; ++i) r[i] = P.h_small[i];
+}
+void check_range_args(int64_t len, int64_t from, int64_t to) {
+    // find() walks [from, to] and, on a miss, left of `to` down to slot 1 (src/finds.jl:50-52): both ends must address the array
+    if (from < 1 || to > len || to < 0 || from > len + 1) fail(DSA_EBOUNDS, "range outside the slot array");
+}
+
+// a handle restored from an exported layout: geometry (src/pma.jl:8-24) from capacity and segment capacity
+void import_slots(Pma& P, const int64_t* keys, const double* vals, const uint8_t* occ, int64_t capacity, int64_t segment_capacity) {
+    auto pow2 = [](int64_t x) { return x > 0 && (x & (x - 1)) == 0; };
+    if (!pow2(capacity) || !pow2(segment_capacity) || segment_capacity > capacity / 2)
+        fail(DSA_EARG, "capacity and segment capacity must be powers of two with at least two segments");
+    int64_t n = 0;
+    for (int64_t i = 0; i < capacity; ++i) n += occ[i] ? 1 : 0;
+    std::vector<int64_t> kk((size_t)capacity);
+    for (int64_t i = 0; i < capacity; ++i) kk[(size_t)i] = occ[i] ? keys[i] : 0;
+    P.wide = !keys_fit32(kk.data(), capacity);
+    Ctl& c = *P.h_ctl;
+    c.capacity = capacity; c.segment_capacity = segment_capacity; c.nb_segments = capacity / segment_capacity;
+    c.height = 0; while (((int64_t)1 << c.height) < c.nb_segments) ++c.height;
+    c.nb_elements = n;
+    compute_bounds(P);
+    ensure_capacity_alloc(P, 2 * capacity);
+    std::vector<uint64_t> words((size_t)P.occ_words, 0ull);
+    for (int64_t i = 0; i < capacity; ++i) if (occ[i]) words[(size_t)(i >> 6)] |= 1ull << (i & 63);
+    upload_keys(P, P.keys[P.cur], kk.data(), capacity);
+    HIPCHK(hipMemcpyAsync(P.V(), vals, (size_t)capacity * sizeof(double), hipMemcpyHostToDevice, P.stream));
+    HIPCHK(hipMemcpyAsync(P.O(), words.data(), words.size() * sizeof(uint64_t), hipMemcpyHostToDevice, P.stream));
+    P.occ_dirty[P.cur] = (capacity + 63) / 64;
+    ++P.layout_epoch;
+    HIPCHK(hipStreamSynchronize(P.stream));          // the staging vectors above go out of scope
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t dsa_dbg_raw_find(const int64_t* keys, const double* vals, const uint8_t* occ, int64_t len, int64_t key, int64_t from, int64_t to,
+                         int32_t engine, int32_t fast, int64_t* pos, int32_t* has, int64_t* fkey, double* fval) {
+    API_TRY
+    check_range_args(len, from, to);
+    RawGuard g;
+    raw_load(g.P, keys, vals, occ, len, nullptr, 0, key);
+    int64_t r[6];
+    raw_run(g.P, engine, fast ? DBG_FIND_FAST : DBG_FIND, key, 0.0, from, to, 0, r);
+    *pos = r[1]; *has = (int32_t)r[2]; *fkey = r[3]; std::memcpy(fval, &r[4], sizeof(double));
+    API_CATCH
+}
+int32_t dsa_dbg_raw_insert(int64_t* keys, double* vals, uint8_t* occ, int64_t len, int64_t key, double value, int64_t from, int64_t to,
+                           int64_t* sems, int64_t nsems, int32_t engine, int32_t fast, int64_t* pos, int32_t* is_new) {
+    API_TRY
+    check_range_args(len, from, to);
+    RawGuard g;
+    raw_load(g.P, keys, vals, occ, len, sems, nsems, key);
+    int64_t r[6];
+    raw_run(g.P, engine, fast ? DBG_INSERT_FAST : DBG_INSERT, key, value, from, to, 0, r);
+    if (r[0] != 0) fail((int32_t)r[0], err_text((int32_t)r[0]));
+    *pos = r[1]; *is_new = (int32_t)r[2];
+    raw_store(g.P, keys, vals, occ, len, sems, nsems);
+    API_CATCH
+}
+int32_t dsa_dbg_raw_delete(int64_t* keys, double* vals, uint8_t* occ, int64_t len, int64_t key, int64_t from, int64_t to,
+                           int32_t engine, int32_t fast, int64_t* pos, int32_t* deleted) {
+    API_TRY
+    check_range_args(len, from, to);
+    RawGuard g;
+    raw_load(g.P, keys, vals, occ, len, nullptr, 0, key);
+    int64_t r[6];
+    raw_run(g.P, engine, fast ? DBG_DELETE_FAST : DBG_DELETE, key, 0.0, from, to, 0, r);
+    *pos = r[1]; *deleted = (int32_t)r[2];
+    raw_store(g.P, keys, vals, occ, len, nullptr, 0);
+    API_CATCH
+}
+int32_t dsa_dbg_raw_purge(int64_t* keys, double* vals, uint8_t* occ, int64_t len, int64_t from, int64_t to, int64_t* mid, int64_t* nb) {
+    API_TRY
+    if (to >= from) check_range_args(len, from, to);
+    RawGuard g;
+    raw_load(g.P, keys, vals, occ, len, nullptr, 0, 0);
+    int64_t r[6];
+    raw_run(g.P, DSA_DBG_ENGINE_BLOCK, DBG_PURGE, 0, 0.0, from, to, 0, r);
+    *mid = r[1]; *nb = r[5];
+    raw_store(g.P, keys, vals, occ, len, nullptr, 0);
+    API_CATCH
+}
+int32_t dsa_dbg_raw_rebalance(int64_t* keys, double* vals, uint8_t* occ, int64_t len, int64_t ws, int64_t we, int64_t* sems, int64_t nsems,
+                              int32_t engine) {
+    API_TRY
+    if (ws < 1 || we > len || we < ws) fail(DSA_EBOUNDS, "window outside the slot array");
+    const int64_t W = we - ws + 1;
+    const bool in_word = ((ws - 1) >> 6) == ((we - 1) >> 6);
+    const bool aligned = ((ws - 1) & 63) == 0 && (W & 63) == 0;
+    int64_t m = 0;
+    for (int64_t i = ws - 1; i < we; ++i) m += occ[i] ? 1 : 0;
+    RawGuard g;
+    raw_load(g.P, keys, vals, occ, len, sems, nsems, 0);
+    if (engine == DSA_DBG_ENGINE_GRID) {
+        // k_move2 reads whole occupancy words and writes whole destination words: windows of whole words
+        if (!aligned) fail(DSA_EARG, "the grid-wide rebalance takes windows of whole occupancy words");
+        if (m > 0) {
+            Pma& P = g.P;
+            const int alt = 1 - P.cur;
+            hipError_t e = launch_rebalance(P.K(), P.V(), P.O(), ws, we, false, P.KA(alt), P.vals[alt], P.occ[alt], ws, we, m,
+                                            P.has_sems ? P.sems : nullptr, &P.work, P.stream);
+            if (e != hipSuccess) fail(DSA_EHIP, std::string("rebalance launch: ") + hipGetErrorString(e));
+            HIPCHK(hipMemcpyAsync((char*)P.keys[P.cur] + (size_t)(ws - 1) * P.kb(), (char*)P.keys[alt] + (size_t)(ws - 1) * P.kb(), (size_t)W * P.kb(), hipMemcpyDeviceToDevice, P.stream));
+            HIPCHK(hipMemcpyAsync(P.V() + (ws - 1), P.vals[alt] + (ws - 1), (size_t)W * sizeof(double), hipMemcpyDeviceToDevice, P.stream));
+            HIPCHK(hipMemcpyAsync(P.O() + ((ws - 1) >> 6), P.occ[alt] + ((ws - 1) >> 6), (size_t)(W >> 6) * sizeof(uint64_t), hipMemcpyDeviceToDevice, P.stream));
+        }
+    } else {
+        const int64_t maxw = engine == DSA_DBG_ENGINE_BLOCK ? 8192 : 2048;
+        if (!(in_word || aligned) || W > maxw) fail(DSA_EARG, "window must lie inside one occupancy word or be made of whole words, within the engine's limit");
+        int64_t r[6];
+        raw_run(g.P, engine, DBG_REBALANCE, 0, 0.0, ws, we, m, r);
+    }
+    raw_store(g.P, keys, vals, occ, len, sems, nsems);
+    API_CATCH
+}
+
+int32_t dsa_vec_import_layout(const int64_t* keys, const double* vals, const uint8_t* occ, int64_t capacity, int64_t segment_capacity,
+                              int64_t len, dsa_vec_t** out) {
+    API_TRY
+    auto* h = new dsa_vec();
+    try {
+        pma_init_common(h->P, false, false);
+        import_slots(h->P, keys, vals, occ, capacity, segment_capacity);
+        upload_ctl(h->P);
+    } catch (...) { pma_destroy(h->P); delete h; throw; }
+    h->n = len;
+    *out = h;
+    API_CATCH
+}
+int32_t dsa_pcsc_import_layout(const int64_t* keys, const double* vals, const uint8_t* occ, int64_t capacity, int64_t segment_capacity,
+                               const int64_t* semaphores, int64_t table_len, dsa_pcsc_t** out) {
+    API_TRY
+    if (table_len < 0) fail(DSA_EARG, "negative table length");
+    auto* h = new dsa_pcsc();
+    try {
+        Pma& P = h->P;
+        pma_init_common(P, true, false);
+        ensure_tables(P, std::max<int64_t>(2 * table_len, 64));
+        int64_t live = 0;
+        for (int64_t i = 0; i < table_len; ++i) {
+            const int64_t s = semaphores[i];
+            if (s == 0) continue;
+            if (s < 1 || s > capacity || !occ[s - 1] || keys[s - 1] != SEM_KEY || vals[s - 1] != (double)(i + 1))
+                fail(DSA_EARG, "semaphores[id] must point at the cell (0, id)");
+            ++live;
+        }
+        P.h_ctl->table_len = table_len; P.h_ctl->nb_partitions = live;
+        import_slots(P, keys, vals, occ, capacity, segment_capacity);
+        if (table_len > 0) HIPCHK(hipMemcpyAsync(P.sems, semaphores, (size_t)table_len * sizeof(int64_t), hipMemcpyHostToDevice, P.stream));
+        upload_ctl(P);
+    } catch (...) { pma_destroy(h->P); delete h; throw; }
+    *out = h;
     API_CATCH
 }
 

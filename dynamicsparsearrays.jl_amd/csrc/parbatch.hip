@@ -766,4 +766,71 @@ void burst_graph_destroy(BurstGraph* cache) {
     *cache = BurstGraph();
 }
 
+// ---- parity hooks (include/dsa.h: dsa_dbg_raw_*), wave-level engine ------------------------------------------------------------
+// The primitives one WAVE of k_apply uses — pb_shift_right / pb_shift_left with the occupancy atomics of pb_apply_one, and
+// pb_wave_rebalance — on a caller-supplied raw slot array (see k_dbg_raw in sequencer.hip for the workgroup-level engine and the
+// layout of out[]).  One wave, one op.
+__global__ __launch_bounds__(64) void k_dbg_raw_wave(KeyArr keys, double* vals, uint64_t* occ, int64_t* sems, int64_t len, int op,
+                                                     int64_t key, double val, int64_t from, int64_t to, int64_t m, int64_t* out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char pb_lds[];
+    int64_t* sK = reinterpret_cast<int64_t*>(pb_lds);
+    double* sV = reinterpret_cast<double*>(pb_lds + (size_t)PB_MAX_W * sizeof(int64_t));
+    const int lane = lane_id();
+    int64_t err = 0, r_pos = 0, r_flag = 0, r_key = 0; double r_val = 0.0;
+    switch (op) {
+        case DBG_FIND: case DBG_FIND_FAST: {
+            const DFound f = op == DBG_FIND ? d_find(keys, vals, occ, key, from, to) : d_find_fast(keys, vals, occ, key, from, to);
+            r_pos = f.pos; r_flag = f.has ? 1 : 0; r_key = f.key; r_val = f.val;
+            break;
+        }
+        case DBG_INSERT: case DBG_INSERT_FAST: {                   // insert! + _insert!  src/writes.jl:14-43, the way k_plan / k_apply split it
+            const DFound f = op == DBG_INSERT ? d_find(keys, vals, occ, key, from, to) : d_find_fast(keys, vals, occ, key, from, to);
+            if (f.has && f.key == key && from <= f.pos && f.pos <= to) {
+                if (lane == 0) vals[f.pos - 1] = val;              // PB_OVERWRITE
+                r_pos = f.pos;
+                break;
+            }
+            const int64_t p = f.pos;
+            const int64_t ne = d_next_empty(occ, p, len);
+            r_flag = 1;
+            if (ne != 0) {                                         // PB_INS_R
+                pb_shift_right(keys, vals, sems, p + 1, ne);
+                if (lane == 0) { keys[p] = key; vals[p] = val; pb_bit_set(occ, ne); }
+                r_pos = p + 1;
+                break;
+            }
+            const int64_t pe = d_prev_empty(occ, p);
+            if (pe == 0) { err = E_FULL; break; }
+            const bool last_occ = (pb_occ_load(occ, (p - 1) >> 6) >> ((p - 1) & 63)) & 1ull;     // PB_INS_L
+            pb_shift_left(keys, vals, sems, pe, p, last_occ);
+            if (lane == 0) {
+                keys[p - 1] = key; vals[p - 1] = val;
+                if (pe < p - 1) { pb_bit_set(occ, pe); if (!last_occ) pb_bit_clear(occ, p - 1); }
+                else if (last_occ) pb_bit_set(occ, pe);
+                pb_bit_set(occ, p);
+            }
+            r_pos = p;
+            break;
+        }
+        case DBG_DELETE: case DBG_DELETE_FAST: {                   // PB_DELETE
+            const DFound f = op == DBG_DELETE ? d_find(keys, vals, occ, key, from, to) : d_find_fast(keys, vals, occ, key, from, to);
+            if (f.has && f.key == key) { if (lane == 0) pb_bit_clear(occ, f.pos); r_pos = f.pos; r_flag = 1; }
+            break;
+        }
+        case DBG_REBALANCE:
+            pb_wave_rebalance(keys, vals, occ, sems, from, to, m, sK, sV);
+            break;
+        default:
+            err = E_ARG;
+    }
+    if (lane == 0) { out[0] = err; out[1] = r_pos; out[2] = r_flag; out[3] = r_key; out[4] = __double_as_longlong(r_val); out[5] = 0; }
+}
+
+hipError_t launch_dbg_raw_wave(KeyArr keys, double* vals, uint64_t* occ, int64_t* sems, int64_t len, int op, int64_t key, double val,
+                               int64_t from, int64_t to, int64_t m, int64_t* out, hipStream_t stream) {
+    const size_t lds_bytes = (size_t)PB_MAX_W * (sizeof(int64_t) + sizeof(double));
+    hipLaunchKernelGGL(k_dbg_raw_wave, dim3(1), dim3(64), lds_bytes, stream, keys, vals, occ, sems, len, op, key, val, from, to, m, out);
+    return hipGetLastError();
+}
+
 }  // namespace dsa

@@ -1722,6 +1722,18 @@ __device__ int d_pcsc_set(Seq& S, double val, int64_t key, int64_t partition) {
     return d_set_in_range(S, key, val, from + 1, to, from);
 }
 
+// purge!(array, from, to)  src/writes.jl:80-91: clears every slot of [from, to]; returns the number of cells deleted
+__device__ int64_t blk_purge(Seq& S, int64_t from, int64_t to) {
+    if (to < from) return 0;
+    const int64_t nb = blk_count(S, from, to + 1);
+    __syncthreads();
+    const int64_t lo0 = from - 1, hi0 = to - 1;
+    const int64_t w0 = lo0 >> 6, w1 = hi0 >> 6;
+    for (int64_t w = w0 + threadIdx.x; w <= w1; w += SEQ_BLOCK) S.occ[w] &= ~word_range_mask(w, lo0, hi0);
+    __syncthreads();
+    return nb;
+}
+
 // deletepartition!  src/pcsr.jl:188-204
 __device__ int d_deletepartition(Seq& S, int64_t partition) {
     if (!(1 <= partition && partition <= S.table_len)) { S.err = E_BOUNDS; return SEQ_ERROR; }
@@ -1729,14 +1741,7 @@ __device__ int d_deletepartition(Seq& S, int64_t partition) {
     const int64_t sem_pos = S.sems[partition - 1];
     if (sem_pos == 0) { S.err = E_ASSERT; return SEQ_ERROR; }
     const int64_t end = d_partition_end(S, partition);
-    // purge!(array, sem_pos, end)  src/writes.jl:80-91
-    const int64_t nb = blk_count(S, sem_pos, end + 1);
-    __syncthreads();
-    {
-        const int64_t lo0 = sem_pos - 1, hi0 = end - 1;
-        const int64_t w0 = lo0 >> 6, w1 = hi0 >> 6;
-        for (int64_t w = w0 + threadIdx.x; w <= w1; w += SEQ_BLOCK) S.occ[w] &= ~word_range_mask(w, lo0, hi0);
-    }
+    const int64_t nb = blk_purge(S, sem_pos, end);
     if (threadIdx.x == 0) S.sems[partition - 1] = 0;
     __syncthreads();
     const int64_t mid = sem_pos + (end - sem_pos) / 2;
@@ -2112,6 +2117,83 @@ hipError_t launch_view_small(KeyArr keys, const double* vals, const uint64_t* oc
 hipError_t launch_partition_range(const int64_t* sems, const int64_t* col_keys, const uint8_t* col_live,
                                   int64_t table_len, int64_t capacity, int64_t col, int64_t* out, hipStream_t stream) {
     hipLaunchKernelGGL(k_partition_range, dim3(1), dim3(64), 0, stream, sems, col_keys, col_live, table_len, capacity, col, out);
+    return hipGetLastError();
+}
+
+// ---- parity hooks (include/dsa.h: dsa_dbg_raw_*) ------------------------------------------------------------------------------
+// The slot-array primitives of the sequencer run on a caller-supplied RAW slot array (any length, any content), so that the
+// reference's own unit-test vectors (test/unit/finds.jl, test/unit/writes.jl) are checked on the device code itself and not only on
+// the CPU oracle.  One workgroup, one op.  out[0] = error code, out[1] = position, out[2] = flag (element found / new key / deleted),
+// out[3] = key of the element found, out[4] = its value (bits), out[5] = cells purged.
+__global__ __launch_bounds__(SEQ_BLOCK) void k_dbg_raw(KeyArr keys, double* vals, uint64_t* occ, int64_t* sems, int64_t len, int op,
+                                                       int64_t key, double val, int64_t from, int64_t to, int64_t m, int64_t* out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    __shared__ int64_t sRed[SEQ_BLOCK / 64];
+    __shared__ uint32_t sWordOff[SMALL_W / 64 + 1];
+    Seq S;
+    S.keys = keys; S.vals = vals; S.occ = occ; S.sems = sems; S.col_keys = nullptr; S.col_live = nullptr; S.ctl = nullptr;
+    S.capacity = len; S.seg = 1; S.height = 0; S.nb_elements = 0; S.nb_partitions = 0; S.table_len = 0; S.table_cap = 0;
+    S.stat_window_slots = S.stat_rebalances = S.stat_small = 0;
+    S.y_ws = S.y_we = S.y_m = 0; S.err = 0; S.tail_hint = false;
+    S.n_sorted = 0; S.n_pend = 0; S.pKey = nullptr; S.pIdx = nullptr; S.pLb = nullptr;
+    for (int q = 0; q < 16; ++q) S.prof[q] = 0;
+    S.sK = reinterpret_cast<int64_t*>(lds);
+    S.sV = reinterpret_cast<double*>(lds + SMALL_W * sizeof(int64_t));
+    S.sWordOff = sWordOff; S.sRed = sRed; S.lo = nullptr; S.hi = nullptr;
+    int64_t r_pos = 0, r_flag = 0, r_key = 0, r_nb = 0; double r_val = 0.0;
+    switch (op) {
+        case DBG_FIND: case DBG_FIND_FAST: {                       // find(array, key, from, to)  src/finds.jl:29-57
+            const DFound f = op == DBG_FIND ? d_find(keys, vals, occ, key, from, to) : d_find_fast(keys, vals, occ, key, from, to);
+            r_pos = f.pos; r_flag = f.has ? 1 : 0; r_key = f.key; r_val = f.val;
+            break;
+        }
+        case DBG_INSERT: case DBG_INSERT_FAST: {                   // insert!(array, key, value, from, to, semaphores)  src/writes.jl:14-43
+            const DFound f = op == DBG_INSERT ? d_find(keys, vals, occ, key, from, to) : d_find_fast(keys, vals, occ, key, from, to);
+            if (f.has && f.key == key && from <= f.pos && f.pos <= to) {
+                __syncthreads();
+                if (threadIdx.x == 0) vals[f.pos - 1] = val;
+                r_pos = f.pos; r_flag = 0;
+            } else {
+                r_pos = d_insert_after(S, key, val, f.pos);
+                r_flag = 1;
+            }
+            break;
+        }
+        case DBG_DELETE: case DBG_DELETE_FAST: {                   // delete!(array, key, from, to)  src/writes.jl:57-68
+            const DFound f = op == DBG_DELETE ? d_find(keys, vals, occ, key, from, to) : d_find_fast(keys, vals, occ, key, from, to);
+            if (f.has && f.key == key) {
+                __syncthreads();
+                if (threadIdx.x == 0) occ_clear(S, f.pos);
+                r_pos = f.pos; r_flag = 1;
+            }
+            break;
+        }
+        case DBG_PURGE:                                            // purge!(array, from, to)  src/writes.jl:80-91
+            if (to >= from) { r_nb = blk_purge(S, from, to); r_pos = from + (to - from) / 2; }
+            break;
+        case DBG_REBALANCE:                                        // pack! + spread! of [from, to] holding m cells  src/moves.jl:94-171
+            blk_rebalance_small(S, from, to, m);
+            break;
+        default:
+            S.err = E_ARG;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        out[0] = S.err; out[1] = r_pos; out[2] = r_flag; out[3] = r_key; out[4] = __double_as_longlong(r_val); out[5] = r_nb;
+    }
+}
+
+hipError_t launch_dbg_raw_block(KeyArr keys, double* vals, uint64_t* occ, int64_t* sems, int64_t len, int op, int64_t key, double val,
+                                int64_t from, int64_t to, int64_t m, int64_t* out, hipStream_t stream) {
+    const size_t lds_bytes = (size_t)SMALL_W * (sizeof(int64_t) + sizeof(double));
+    static PerDeviceOnce once;
+    {
+        hipError_t e = once.run([] {
+            return hipFuncSetAttribute(reinterpret_cast<const void*>(k_dbg_raw), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        });
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(k_dbg_raw, dim3(1), dim3(SEQ_BLOCK), lds_bytes, stream, keys, vals, occ, sems, len, op, key, val, from, to, m, out);
     return hipGetLastError();
 }
 

@@ -219,6 +219,42 @@ int32_t dsa_vec_set_stream(dsa_vec_t* h, void* hip_stream);
 int32_t dsa_mat_sync(dsa_mat_t* h);
 int32_t dsa_vec_sync(dsa_vec_t* h);
 
+/* ---- parity hooks and snapshots (no reference counterpart as entry points; the primitives they run are the reference's) ----
+ * dsa_dbg_raw_*: ONE slot-array primitive of src/finds.jl / src/writes.jl / src/moves.jl executed by the DEVICE code on a
+ * caller-supplied raw slot array (keys[i], vals[i], occ[i] in {0,1}, i < len; any length, any content) — the form the reference's
+ * own unit tests use (test/unit/finds.jl:4-107, test/unit/writes.jl:5-70).  Arrays are uploaded, the kernel runs, the arrays (and
+ * semaphores[], if given) are downloaded again.  engine selects which device implementation runs:
+ *   DSA_DBG_ENGINE_BLOCK  the write sequencer's workgroup primitives (d_find / d_find_fast, d_insert_after + blk_shift_*, blk_purge,
+ *                         blk_rebalance_small: windows <= 8192 slots)
+ *   DSA_DBG_ENGINE_WAVE   the wave-level primitives of the batch-parallel rounds (pb_shift_*, pb_wave_rebalance: windows <= 2048 slots)
+ *   DSA_DBG_ENGINE_GRID   the grid-wide rebalance kernel k_move2 (dsa_dbg_raw_rebalance only; windows of whole 64-slot words)
+ * fast = 0: K-find replays the reference bisection probe for probe; fast = 1: its wave-parallel 64-ary form, which the write paths
+ * use wherever the searched range is key-partitioned (only then are the two required to agree). */
+enum { DSA_DBG_ENGINE_BLOCK = 0, DSA_DBG_ENGINE_WAVE = 1, DSA_DBG_ENGINE_GRID = 2 };
+/* find(array, key, from, to)  src/finds.jl:29-57 -> (pos, elem) ; *has = 0 <=> elem === nothing */
+int32_t dsa_dbg_raw_find(const int64_t* keys, const double* vals, const uint8_t* occ, int64_t len, int64_t key, int64_t from, int64_t to,
+                         int32_t engine, int32_t fast, int64_t* pos, int32_t* has, int64_t* fkey, double* fval);
+/* insert!(array, key, value, from, to, semaphores)  src/writes.jl:14-43 ; sems may be NULL ; DSA_EFULL as the reference's error */
+int32_t dsa_dbg_raw_insert(int64_t* keys, double* vals, uint8_t* occ, int64_t len, int64_t key, double value, int64_t from, int64_t to,
+                           int64_t* sems, int64_t nsems, int32_t engine, int32_t fast, int64_t* pos, int32_t* is_new);
+/* delete!(array, key, from, to)  src/writes.jl:57-68 */
+int32_t dsa_dbg_raw_delete(int64_t* keys, double* vals, uint8_t* occ, int64_t len, int64_t key, int64_t from, int64_t to,
+                           int32_t engine, int32_t fast, int64_t* pos, int32_t* deleted);
+/* purge!(array, from, to)  src/writes.jl:80-91 -> (mid, number of cells deleted) */
+int32_t dsa_dbg_raw_purge(int64_t* keys, double* vals, uint8_t* occ, int64_t len, int64_t from, int64_t to, int64_t* mid, int64_t* nb);
+/* pack! + spread! of the window [ws, we] (its cell count is taken from occ)  src/moves.jl:94-171 ; with sems: the semaphore-aware
+ * spread! (:142-171).  Windows lie inside one occupancy word or consist of whole words, like every window the density scan yields. */
+int32_t dsa_dbg_raw_rebalance(int64_t* keys, double* vals, uint8_t* occ, int64_t len, int64_t ws, int64_t we, int64_t* sems, int64_t nsems,
+                              int32_t engine);
+/* Handles restored from an exported layout (the inverse of dsa_vec_export_layout / dsa_pcsc_export_layout: snapshot / restore, and
+ * the way a test puts a structure into an arbitrary state).  capacity and segment_capacity are powers of two (segment_capacity is
+ * state, not a function of the capacity: SURVEY App. A.1); nb_segments, height and the density thresholds follow as in
+ * src/pma.jl:42-49,143-161; nb_elements = number of occupied slots; semaphores[id] = slot of the cell (0, id) or 0 (tombstone). */
+int32_t dsa_vec_import_layout(const int64_t* keys, const double* vals, const uint8_t* occ, int64_t capacity, int64_t segment_capacity,
+                              int64_t len, dsa_vec_t** out);
+int32_t dsa_pcsc_import_layout(const int64_t* keys, const double* vals, const uint8_t* occ, int64_t capacity, int64_t segment_capacity,
+                               const int64_t* semaphores, int64_t table_len, dsa_pcsc_t** out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -435,4 +435,44 @@ int32_t ora_mat_spmv_dense_fastacc(ora_mat* h, int32_t transpose, const double* 
     ORA_CATCH
 }
 
+
+// ---------------- layouts restored from an export (tests put both implementations into the same arbitrary state) ----------------
+// geometry from capacity and segment capacity as in src/pma.jl:42-49,143-161
+static void import_pma(PMA& p, const int64_t* keys, const double* vals, const uint8_t* occ, int64_t capacity, int64_t segment_capacity) {
+    auto pow2 = [](int64_t x) { return x > 0 && (x & (x - 1)) == 0; };
+    if (!pow2(capacity) || !pow2(segment_capacity) || segment_capacity > capacity / 2)
+        throw Err{EARG, "capacity and segment capacity must be powers of two with at least two segments"};
+    p = PMA();
+    p.capacity = capacity; p.segment_capacity = segment_capacity; p.nb_segments = capacity / segment_capacity;
+    p.height = 0; while (((int64_t)1 << p.height) < p.nb_segments) ++p.height;
+    p.t_d = (p.t_h - p.t_0) / (double)p.height;
+    p.p_d = (p.p_h - p.p_0) / (double)p.height;
+    p.array.resize(capacity);
+    for (int64_t i = 0; i < capacity; ++i) if (occ[i]) { p.array.set(i + 1, keys[i], vals[i]); p.nb_elements += 1; }
+}
+int32_t ora_vec_import_layout(const int64_t* keys, const double* vals, const uint8_t* occ, int64_t capacity, int64_t segment_capacity,
+                              int64_t len, ora_vec** out) {
+    ORA_TRY
+    auto* h = new ora_vec();
+    try { import_pma(h->v.pma, keys, vals, occ, capacity, segment_capacity); } catch (...) { delete h; throw; }
+    h->v.n = len;
+    *out = h;
+    ORA_CATCH
+}
+int32_t ora_pcsc_import_layout(const int64_t* keys, const double* vals, const uint8_t* occ, int64_t capacity, int64_t segment_capacity,
+                               const int64_t* semaphores, int64_t table_len, ora_pcsc** out) {
+    ORA_TRY
+    auto* h = new ora_pcsc();
+    try {
+        import_pma(h->c.pma, keys, vals, occ, capacity, segment_capacity);
+        h->c.semaphores.resize(table_len);
+        for (int64_t i = 0; i < table_len; ++i) {
+            h->c.semaphores.v[i] = semaphores[i]; h->c.semaphores.live[i] = semaphores[i] != 0;
+            if (semaphores[i] != 0) h->c.nb_partitions += 1;
+        }
+    } catch (...) { delete h; throw; }
+    *out = h;
+    ORA_CATCH
+}
+
 }  // extern "C"
