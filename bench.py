@@ -551,11 +551,9 @@ def cpu_baseline(dsa, m, per):
     """The CPU oracle (a single-thread C++ restatement of the reference; the Julia reference cannot run
     here) on the SAME C3 input as the GPU leg (all 1M columns, 10M nnz: ~3 s of build + 3 products of ~0.5 s)."""
     import multiprocessing
-    ora_path = os.path.join(ROOT, "oracle", "liboracle.so")
-    if not os.path.exists(ora_path):
-        import subprocess
-        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "liboracle.so"])
-    ora = dsa.Binding(ora_path, "ora", device_api=False)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_binding
+    ora = oracle_binding.load(dsa)
     ncs = 1_000_000 if m == 1_000_000 else 400_000
     I, J, V = c3_triplets(m, ncs, per, 0, seed_rows=5, seed_vals=6)
     t = time.perf_counter()

@@ -1,10 +1,10 @@
 """ctypes binding of the C ABI declared in include/dsa.h.
 
-`Binding(path, prefix)` binds one shared library whose entry points are named
-`<prefix>_*`.  The product library is `libdsa_hip.so` with prefix ``dsa``
-(see :func:`product`).  The CPU oracle under ``oracle/`` exports the same call
-shapes with prefix ``ora`` and is bound ONLY by tests / smoke / the bench's
-cpu_baseline leg — nothing in this package loads it.
+`Binding(path)` binds `libdsa_hip.so`: every entry point of the header, named
+``dsa_*`` (see :func:`product`).  `PREFIX` and `SIGNATURES` are class attributes
+so that a test harness can bind another library that exports the same call shapes
+(the checker under ``oracle/`` does, in ``oracle/oracle_binding.py``); nothing in
+this package does.
 """
 from __future__ import annotations
 
@@ -114,7 +114,7 @@ _SIGS = {
     "mat_spmv_dense": [VP, I32, P_F64, I64, P_F64, I64],
     "mat_spmv_sparse": [VP, I32, P_I64, P_F64, I64, P_I64, P_F64, I64, P_I64],
 }
-# entry points only the HIP product library has
+# device-resident operands, streams, shards, invariant checker, parity hooks
 _DEVICE_SIGS = {
     "device_count": [P_I32],
     "set_device": [I32],
@@ -148,28 +148,29 @@ def _f64(a):
     return a, a.ctypes.data_as(P_F64)
 
 
+SIGNATURES = {**_SIGS, **_DEVICE_SIGS}
+
+
 class Binding:
-    def __init__(self, path: str, prefix: str, device_api: bool):
+    PREFIX = "dsa"
+    SIGNATURES = SIGNATURES
+
+    def __init__(self, path: str):
         self.path = path
-        self.prefix = prefix
+        self.prefix = self.PREFIX
         self.lib = C.CDLL(path)
-        self.device_api = device_api
-        sigs = dict(_SIGS)
-        if device_api:
-            sigs.update(_DEVICE_SIGS)
-        for name, argtypes in sigs.items():
-            fn = getattr(self.lib, f"{prefix}_{name}")   # AttributeError if the symbol is missing
+        for name, argtypes in self.SIGNATURES.items():
+            fn = getattr(self.lib, f"{self.prefix}_{name}")   # AttributeError if the symbol is missing
             fn.argtypes = argtypes
             fn.restype = I32
             setattr(self, "_" + name, fn)
-        self._errmsg = getattr(self.lib, f"{prefix}_last_error_message")
+        self._errmsg = getattr(self.lib, f"{self.prefix}_last_error_message")
         self._errmsg.restype = C.c_char_p
         self._errmsg.argtypes = []
 
-    @staticmethod
-    def declared_symbols(device_api: bool):
-        names = list(_SIGS) + (list(_DEVICE_SIGS) if device_api else []) + ["last_error_message"]
-        return names
+    @classmethod
+    def declared_symbols(cls):
+        return list(cls.SIGNATURES) + ["last_error_message"]
 
     def call(self, name, *args):
         rc = getattr(self, "_" + name)(*args)
@@ -216,5 +217,5 @@ def product() -> Binding:
             raise RuntimeError(
                 f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
-        _PRODUCT = Binding(path, "dsa", device_api=True)
+        _PRODUCT = Binding(path)
     return _PRODUCT

@@ -99,6 +99,9 @@ struct Pma {
     int64_t layout_epoch = 0;
     int64_t stat_spmv_nomemset = 0;
     struct SpmvMeta { int64_t epoch = -1; bool ordered = false; int64_t max_extent = 0, max_gap = 0, first_key = 0, last_key = 0; } spmv_meta;
+    // its device side: scratch of k_spmv_meta, pinned landing area of the 5 result words, and the epoch a prefetch (enqueued behind
+    // the write batch that changed the layout) is in flight for
+    unsigned long long* d_meta = nullptr; int64_t* h_meta = nullptr; hipEvent_t meta_ev = nullptr; int64_t meta_inflight_epoch = -1;
     // thresholds  src/pma.jl:58,70,87
     double t_h = 0.7, t_0 = 0.92, p_h = 0.3, p_0 = 0.08, t_d = 0.0, p_d = 0.0;
 
@@ -148,6 +151,9 @@ void pma_destroy(Pma& P) {
     if (P.h_rs) hipHostFree(P.h_rs);
     if (P.d_small) hipFree(P.d_small);
     if (P.h_small) hipHostFree(P.h_small);
+    if (P.d_meta) hipFree(P.d_meta);
+    if (P.h_meta) hipHostFree(P.h_meta);
+    if (P.meta_ev) hipEventDestroy(P.meta_ev);
     if (P.tmerge.sems2) hipFree(P.tmerge.sems2);
     if (P.tmerge.keys2) hipFree(P.tmerge.keys2);
     if (P.tmerge.pkey) hipFree(P.tmerge.pkey);
@@ -829,6 +835,8 @@ void read_range(Pma& P, int64_t from, int64_t to, std::vector<int64_t>& ks, std:
 void pma_build_dev(Pma& P, const int64_t* d_part, const int64_t* d_key, const double* d_val, int64_t nnz, int32_t combine,
                    int mode, int64_t nparts_explicit, bool wide) {
     P.wide = wide;                     // decided by the caller from the host copy of the keys, before anything is allocated
+    // fault injection for the error paths of the builders (tests): DSA_FAIL_BUILD=1 fails every build while it is set
+    if (const char* fe = getenv("DSA_FAIL_BUILD")) if (fe[0] == '1') fail(DSA_EHIP, "injected build failure (DSA_FAIL_BUILD)");
     if (nnz == 0) {
         std::vector<int64_t> ks; std::vector<double> vs;
         const int64_t np = mode == 2 ? nparts_explicit : 0;
@@ -977,9 +985,9 @@ struct dsa_mat {
 
 namespace {
 
-// both orientations from (row, col, value) triples that are ALREADY in HBM (freed here): dynamicsparse(I, J, V) after its
-// upload, closefillmode! straight from the device-resident fill buffer
-void mat_build_major_dev(dsa_mat* h, int64_t* dI, int64_t* dJ, double* dV, int64_t nnz, bool wide_rows, bool wide_cols) {
+// both orientations from (row, col, value) triples that are ALREADY in HBM (they stay the caller's): dynamicsparse(I, J, V) after its
+// upload, closefillmode! straight from the device-resident fill buffer.  On failure nothing of the two structures is left behind.
+void mat_build_major_dev(dsa_mat* h, const int64_t* dI, const int64_t* dJ, const double* dV, int64_t nnz, bool wide_rows, bool wide_cols) {
     try {
         pma_init_common(h->col, true, true);
         pma_init_common(h->row, true, true);
@@ -1005,14 +1013,11 @@ void mat_build_major_dev(dsa_mat* h, int64_t* dI, int64_t* dJ, double* dV, int64
                     std::chrono::duration<double, std::milli>(tb1 - tb0).count(),
                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tb1).count());
     } catch (...) {
-        if (dI) hipFree(dI);
-        if (dJ) hipFree(dJ);
-        if (dV) hipFree(dV);
+        // streams, control blocks and whatever slot buffers / tables exist by now (dsa_mat_destroy only looks at them once has_major is set)
+        pma_destroy(h->col);
+        pma_destroy(h->row);
         throw;
     }
-    if (dI) hipFree(dI);
-    if (dJ) hipFree(dJ);
-    if (dV) hipFree(dV);
     h->has_major = true;
 }
 
@@ -1043,7 +1048,16 @@ void mat_build_major(dsa_mat* h, const int64_t* I, const int64_t* J, const doubl
     if (dbg_time) fprintf(stderr, "[mat_build_major] upload of %lld triples from caller memory %.1f ms\n", (long long)nnz,
                           std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tup0).count());
     scan.join();
-    mat_build_major_dev(h, dI, dJ, dV, nnz, wide_rows, wide_cols);
+    try { mat_build_major_dev(h, dI, dJ, dV, nnz, wide_rows, wide_cols); }
+    catch (...) {
+        if (dI) hipFree(dI);
+        if (dJ) hipFree(dJ);
+        if (dV) hipFree(dV);
+        throw;
+    }
+    if (dI) hipFree(dI);
+    if (dJ) hipFree(dJ);
+    if (dV) hipFree(dV);
 }
 
 Pma& orient(dsa_mat* h, int32_t o) {
@@ -1183,33 +1197,61 @@ void ensure_xy(dsa_mat* h, int64_t nx, int64_t ny) {
 // rowmajor one (:26-36).  Gather form: the twin orientation, whose partitions are the OUTPUT index.
 // What the gather launch may assume about an orientation (recomputed after every launch that can change the layout or
 // the tables: one small kernel + an 8-byte round trip, amortised over the SpMV calls between two write batches).
+// Tables with tombstones or unmerged entries take the memset path whatever the layout: nothing to compute.
+bool spmv_meta_applicable(const Pma& P) {
+    const Ctl& c = *P.h_ctl;
+    return P.has_cols && c.table_len > 0 && c.nb_partitions == c.table_len && c.n_pending == 0;
+}
+// Enqueues k_spmv_meta + the copy of its 5 result words behind whatever is on the stream (one launch, no host wait).  Called at the
+// end of every write batch / build, so that the product that follows finds the words already in pinned memory: the product after a
+// write batch costs what its kernel costs (round 2: a 359 us meta kernel + a host round trip in front of an 8.7 us SpMV in config 5).
+void prefetch_spmv_meta(Pma& P) {
+    if (P.spmv_meta.epoch == P.layout_epoch || P.meta_inflight_epoch == P.layout_epoch || !spmv_meta_applicable(P)) return;
+    if (!P.d_meta) {
+        HIPCHK(hipMalloc(&P.d_meta, SPMV_META_WORDS * sizeof(unsigned long long)));
+        HIPCHK(hipMemsetAsync(P.d_meta, 0, SPMV_META_WORDS * sizeof(unsigned long long), P.stream));
+        HIPCHK(hipHostMalloc(&P.h_meta, 8 * sizeof(int64_t), hipHostMallocDefault));
+        HIPCHK(hipEventCreateWithFlags(&P.meta_ev, hipEventDisableTiming));
+    }
+    unsigned long long* out5 = P.d_meta + 3 * SPMV_META_BLOCKS + 1;
+    hipError_t e = launch_spmv_meta(P.sems, P.col_keys, P.h_ctl->table_len, P.h_ctl->capacity, P.d_meta, out5, P.stream);
+    if (e != hipSuccess) fail(DSA_EHIP, std::string("spmv meta launch: ") + hipGetErrorString(e));
+    HIPCHK(hipMemcpyAsync(P.h_meta, out5, 5 * sizeof(int64_t), hipMemcpyDeviceToHost, P.stream));
+    HIPCHK(hipEventRecord(P.meta_ev, P.stream));
+    P.meta_inflight_epoch = P.layout_epoch;
+}
 const Pma::SpmvMeta& spmv_meta(Pma& P) {
     Pma::SpmvMeta& M = P.spmv_meta;
     if (M.epoch == P.layout_epoch) return M;
     M = Pma::SpmvMeta();
     M.epoch = P.layout_epoch;
-    const Ctl& c = *P.h_ctl;
-    if (!P.has_cols || c.table_len <= 0 || c.nb_partitions != c.table_len || c.n_pending != 0) {     // tombstones: memset path
-        static const char* dbg = getenv("DSA_DBG_SPMV_META");
+    static const char* dbg = getenv("DSA_DBG_SPMV_META");
+    if (!spmv_meta_applicable(P)) {     // tombstones: memset path
+        const Ctl& c = *P.h_ctl;
         if (dbg) fprintf(stderr, "spmv_meta: has_cols %d table_len %lld nb_partitions %lld n_pending %lld\n", (int)P.has_cols, (long long)c.table_len,
                          (long long)c.nb_partitions, (long long)c.n_pending);
         return M;
     }
-    hipError_t e = launch_spmv_meta(P.sems, P.col_keys, c.table_len, c.capacity, (unsigned long long*)P.d_small, P.stream);
-    if (e != hipSuccess) fail(DSA_EHIP, std::string("spmv meta launch: ") + hipGetErrorString(e));
-    int64_t* r = P.h_small;
-    HIPCHK(hipMemcpyAsync(r, P.d_small, 5 * sizeof(int64_t), hipMemcpyDeviceToHost, P.stream));
-    HIPCHK(hipStreamSynchronize(P.stream));
+    M.epoch = -1;
+    prefetch_spmv_meta(P);                      // no-op when the write batch has already enqueued it
+    HIPCHK(hipEventSynchronize(P.meta_ev));
+    M.epoch = P.layout_epoch;
+    const int64_t* r = P.h_meta;
     M.ordered = r[4] == 0;
     M.max_extent = r[0]; M.max_gap = r[1]; M.first_key = r[2]; M.last_key = r[3];
-    { static const char* dbg = getenv("DSA_DBG_SPMV_META");
-      if (dbg) fprintf(stderr, "spmv_meta: table_len %lld ordered %d max_extent %lld max_gap %lld first %lld last %lld\n", (long long)c.table_len,
-                       (int)M.ordered, (long long)M.max_extent, (long long)M.max_gap, (long long)M.first_key, (long long)M.last_key); }
+    if (dbg) fprintf(stderr, "spmv_meta: table_len %lld ordered %d max_extent %lld max_gap %lld first %lld last %lld\n", (long long)P.h_ctl->table_len,
+                     (int)M.ordered, (long long)M.max_extent, (long long)M.max_gap, (long long)M.first_key, (long long)M.last_key);
     return M;
 }
 
 // mat * v walks the colmajor orientation in the reference (src/operations.jl:14-24), transpose(mat) * v the
 // rowmajor one (:26-36).  Gather form: the twin orientation, whose partitions are the OUTPUT index.
+void mat_prefetch_spmv_meta(dsa_mat* h) {
+    if (!h->has_major) return;
+    prefetch_spmv_meta(h->row);
+    prefetch_spmv_meta(h->col);
+}
+
 void spmv_dev(dsa_mat* h, int32_t transpose, int32_t algo, const double* d_x, int64_t nx, double* d_y, int64_t ny, hipStream_t s,
               int pattern = 0) {
     if (!h->has_major) fail(DSA_EMODE, "matrix is in fill mode");
@@ -1549,7 +1591,7 @@ int32_t dsa_mat_create_from_coo(const int64_t* I, const int64_t* J, const double
     if (m < 0) { m = 0; for (int64_t k = 0; k < nnz; ++k) m = std::max(m, I[k]); }
     if (n < 0) { n = 0; for (int64_t k = 0; k < nnz; ++k) n = std::max(n, J[k]); }
     auto* h = new dsa_mat();
-    try { mat_build_major(h, I, J, V, nnz); } catch (...) { pma_destroy(h->col); pma_destroy(h->row); delete h; throw; }
+    try { mat_build_major(h, I, J, V, nnz); mat_prefetch_spmv_meta(h); } catch (...) { pma_destroy(h->col); pma_destroy(h->row); delete h; throw; }
     h->m = m; h->n = n;
     *out = h;
     API_CATCH
@@ -1687,6 +1729,7 @@ static void mat_flush(dsa_mat_t* h) {
     std::vector<int64_t> i, j; std::vector<double> v;
     i.swap(h->pi); j.swap(h->pj); v.swap(h->pv);       // the queue is empty even if the apply fails
     mat_apply_sets(h, i.data(), j.data(), v.data(), (int64_t)i.size());
+    mat_prefetch_spmv_meta(h);
 }
 
 int32_t dsa_mat_set(dsa_mat_t* h, double val, int64_t row, int64_t col) {
@@ -1718,6 +1761,7 @@ int32_t dsa_mat_set_batch(dsa_mat_t* h, const int64_t* I, const int64_t* J, cons
         fill_append(h->buf, I, J, V, n);
     } else {
         mat_apply_sets(h, I, J, V, n);
+        mat_prefetch_spmv_meta(h);
     }
     API_CATCH
 }
@@ -1744,6 +1788,7 @@ int32_t dsa_mat_addrow(dsa_mat_t* h, int64_t row, const int64_t* colids, const d
     } else {               // src/matrix.jl:119-121
         std::vector<int64_t> rows((size_t)n, row);
         mat_apply_sets(h, rows.data(), colids, vals, n);
+        mat_prefetch_spmv_meta(h);
     }
     API_CATCH
 }
@@ -1755,19 +1800,20 @@ int32_t dsa_mat_closefillmode(dsa_mat_t* h) {     // closefillmode!  src/matrix.
     // get_rowids_colids_vals (src/buffer.jl:33-50) is a no-op here: the triples already sit in HBM; only the last partial
     // chunk is still in pinned memory
     FillBuffer& b = h->buf;
-    int64_t *dI = nullptr, *dJ = nullptr; double* dV = nullptr;
     int64_t nnz = 0;
     bool wr = false, wc = false;
     if (b.stream) {
         fill_upload_chunk(b);
         HIPCHK(hipStreamSynchronize(b.stream));
-        dI = b.dI; dJ = b.dJ; dV = b.dV; nnz = b.dlen;
-        b.dI = nullptr; b.dJ = nullptr; b.dV = nullptr;          // ownership moves to the builder
+        nnz = b.dlen;
         wr = !b.fit32_rows; wc = !b.fit32_cols;
     }
-    mat_build_major_dev(h, dI, dJ, dV, nnz, wr, wc);
+    // a failed build (out of memory, a HIP error) leaves the matrix what it was: in fill mode, with all of its triples — the
+    // builder only reads them — so the caller may free memory and close again, or keep appending
+    mat_build_major_dev(h, b.dI, b.dJ, b.dV, nnz, wr, wc);
     h->fillmode = false;
     fill_release(h->buf);
+    mat_prefetch_spmv_meta(h);
     API_CATCH
 }
 

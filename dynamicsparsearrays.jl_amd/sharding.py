@@ -7,10 +7,11 @@ collective is the sum of the partial y over the ranks — RCCL over xGMI on the 
 gloo in the CPU tests.  One process per GPU; nothing else crosses ranks (writes go to the owner shard,
 rebalances are local).  The reference has no counterpart: it is single-process.
 
-The class is the SAME code on both backends: x and y are torch tensors on the shard's device — CUDA
-tensors next to the HIP library (the partial product is written straight into y's HBM through
-`dsa_shard_spmv_dev`, on torch's current stream, nothing bounces through the host), CPU tensors next
-to the CPU oracle in the gloo tests — and the collectives are issued on those tensors.
+x and y are torch tensors on the shard's device: CUDA tensors next to the HIP library — the partial product
+is written straight into y's HBM through `dsa_shard_spmv_dev`, on torch's current stream, nothing bounces
+through the host — and the collectives are issued on those tensors.  The three places that touch the library
+(`_build`, `_device_of`, `spmv_partial`) are methods, so the world-size-2 gloo test (tests/cpu_shard.py) runs
+every other line of this class — ranges, slices, the three schedules, write routing — with CPU tensors.
 
 Three schedules for the sum of the m-entry partial results (config 4: m = 10^7, an 80 MB message):
   "all_reduce"   one RCCL all-reduce (ring / tree chosen by RCCL)
@@ -47,39 +48,48 @@ def owner_of_column(col: int, world: int, n_total: int) -> int:
 class ColumnShard:
     """The local shard of a column-range sharded matrix.  `api` is the dsa_amd module, `binding` the
     library it runs on (the HIP product by default), `device` the torch device of x / y (default: the
-    current CUDA device next to the HIP library, the CPU next to the oracle)."""
+    current CUDA device)."""
 
     def __init__(self, api, I, J_global, V, m, n_total, rank, world, binding=None, device=None, local_columns=False):
-        import torch
         self.api, self.rank, self.world, self.m, self.n_total = api, rank, world, m, n_total
         self.col0, self.ncols = column_range(rank, world, n_total)
         I = np.ascontiguousarray(I, dtype=np.int64)
         J = np.ascontiguousarray(J_global, dtype=np.int64)
         V = np.ascontiguousarray(V, dtype=np.float64)
-        b = binding if binding is not None else api.product()
-        self.binding = b
-        if local_columns:
-            # the caller generated only this rank's columns, already as local keys 1..ncols
-            self.A = api.dynamicsparse(I, J, V, m, self.ncols, binding=b)
-        elif b.device_api:
-            # the C-ABI shard constructor (include/dsa.h: dsa_shard_create_from_coo) — same split, done inside the library
-            h = C.c_void_p()
-            b.call("shard_create_from_coo", I.ctypes.data_as(C.POINTER(C.c_int64)), J.ctypes.data_as(C.POINTER(C.c_int64)),
-                   V.ctypes.data_as(C.POINTER(C.c_double)), len(I), m, n_total, world, rank, C.byref(h))
-            self.A = api.DynamicSparseMatrix(b, h)
-        else:
-            mine = (J > self.col0) & (J <= self.col0 + self.ncols)
-            # local column keys 1..ncols: the shard is the reference layout of its own sub-matrix
-            self.A = api.dynamicsparse(I[mine], J[mine] - self.col0, V[mine], m, self.ncols, binding=b)
-        if b.device_api:
-            self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-            # kernels of this shard are ordered on torch's current stream, like the collectives that consume y
-            b.call("mat_set_stream", self.A.h, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
-        else:
-            self.device = torch.device("cpu")
+        self.binding = binding if binding is not None else api.product()
+        self.A = self._build(I, J, V, local_columns)
+        self.device = self._device_of(device)
         # slices of the "rs_ag" / "direct" schedules: m padded to a multiple of the world size
         self.chunk = -(-m // world)
         self._scratch = {}
+
+    # ---- the library-facing part ---------------------------------------------------------------------------------------
+    def _build(self, I, J, V, local_columns):
+        b = self.binding
+        if local_columns:
+            # the caller generated only this rank's columns, already as local keys 1..ncols
+            return self.api.dynamicsparse(I, J, V, self.m, self.ncols, binding=b)
+        # the C-ABI shard constructor (include/dsa.h: dsa_shard_create_from_coo): the triples of this rank's column range as an
+        # independent reference-layout matrix with local column keys 1..ncols
+        h = C.c_void_p()
+        b.call("shard_create_from_coo", I.ctypes.data_as(C.POINTER(C.c_int64)), J.ctypes.data_as(C.POINTER(C.c_int64)),
+               V.ctypes.data_as(C.POINTER(C.c_double)), len(I), self.m, self.n_total, self.world, self.rank, C.byref(h))
+        return self.api.DynamicSparseMatrix(b, h)
+
+    def _device_of(self, device):
+        import torch
+        dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self._bind_stream(dev)
+        return dev
+
+    def _bind_stream(self, dev):
+        """kernels of this shard are ordered on torch's CURRENT stream of `dev`, like the producer of x and the collective that
+        consumes y; re-bound by spmv_partial whenever the caller has switched streams since"""
+        import torch
+        s = torch.cuda.current_stream(dev).cuda_stream
+        if getattr(self, "_stream", None) != s:
+            self.binding.call("mat_set_stream", self.A.h, C.c_void_p(s))
+            self._stream = s
 
     # ---- operands ----------------------------------------------------------------------------------------------------
     def x_slice(self, x_global):
@@ -104,11 +114,8 @@ class ColumnShard:
         """y_partial = A[:, range] * x[range] into the tensor y (length m) on the shard's device."""
         if y is None:
             y = self.new_y()
-        if self.binding.device_api:
-            self.binding.call("shard_spmv_dev", self.A.h, C.c_void_p(x_local.data_ptr()), self.ncols, C.c_void_p(y.data_ptr()), self.m)
-        else:
-            import torch
-            y.copy_(torch.from_numpy(self.A.mul(x_local.numpy(), dense_out=self.m)))
+        self._bind_stream(self.device)
+        self.binding.call("shard_spmv_dev", self.A.h, C.c_void_p(x_local.data_ptr()), self.ncols, C.c_void_p(y.data_ptr()), self.m)
         return y
 
     # ---- the collective ---------------------------------------------------------------------------------------------

@@ -23,11 +23,9 @@ def dsa():
 @pytest.fixture(scope="session")
 def oracle(dsa):
     """The CPU oracle (test infrastructure).  Built on demand with g++."""
-    so = os.path.join(ROOT, "oracle", "liboracle.so")
-    srcs = [os.path.join(ROOT, "oracle", f) for f in ("oracle.cpp", "oracle_capi.cpp", "oracle.hpp")]
-    if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
-        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "liboracle.so"])
-    return dsa.Binding(so, "ora", device_api=False)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_binding
+    return oracle_binding.load(dsa)
 
 
 @pytest.fixture(scope="session")

@@ -798,35 +798,73 @@ def test_parallel_batches_share_occupancy_words(dsa, hip, oracle):
         assert fuzz.run_shared_words(seed) == "ok"
 
 
-def test_c3_full_size_build_spmv_checker_and_rebalance_idempotence(dsa, hip):
-    """BASELINE config 3 at FULL size (1M x 1M, exactly 10M nnz, the matrix bench.py times): bulk build of both orientations,
-    the device-side invariant checker, y = A x and y = A' x against scipy on the same triplets (1e-12), the capacity rule,
-    and the root pack + spread leaving every slot where it was (idempotence of _even_rebalance! on an even layout)."""
+def test_c3_full_size_build_spmv_checker_and_rebalance_idempotence(dsa, hip, oracle):
+    """BASELINE config 3 at FULL size (1M x 1M, exactly 10M nnz, the matrix bench.py times): bulk build of both orientations
+    compared SLOT FOR SLOT with the CPU oracle's build of the same triples (2 x 2^24 slots: keys, value bits, occupancy, scalars,
+    semaphore and column-key tables; ~3 s of oracle time), the device-side invariant checker, y = A x and y = A' x against the
+    oracle's products and scipy on the same triplets (1e-12), the capacity rule, and the root pack + spread of both orientations
+    leaving every slot where the oracle has it (idempotence of _even_rebalance! on an even layout)."""
     import scipy.sparse as sp
     import bench
     m = n = 1_000_000
     I, J, V = bench.c3_triplets(m, n, 10, 0, seed_rows=5, seed_vals=6)
     assert len(I) == 10_000_000
     a = dsa.dynamicsparse(I, J, V, m, n, binding=hip)
+    b = dsa.dynamicsparse(I, J, V, m, n, binding=oracle)
+    assert_mat_equal(a, b)
     A = sp.csr_matrix((V, (I - 1, J - 1)), shape=(m, n))
     x = bench.unit12(7, n)
-    np.testing.assert_allclose(a.mul(x), A @ x, rtol=1e-12, atol=0)
-    np.testing.assert_allclose(a.mul(x, transpose=True), A.T @ x, rtol=1e-12, atol=0)
+    ya, yt = a.mul(x), a.mul(x, transpose=True)
+    np.testing.assert_allclose(ya, A @ x, rtol=1e-12, atol=0)
+    np.testing.assert_allclose(yt, A.T @ x, rtol=1e-12, atol=0)
+    np.testing.assert_allclose(ya, b.mul(x), rtol=1e-12, atol=0)
+    np.testing.assert_allclose(yt, b.mul(x, transpose=True), rtol=1e-12, atol=0)
     for o in (dsa.COLMAJOR, dsa.ROWMAJOR):
         inf = a.info(o)
         nelem = len(I) + inf["nb_partitions"]
         assert inf["nb_elements"] == nelem and inf["capacity"] == 1 << int(np.ceil(np.log2(np.ceil(nelem / 0.7)))) == 1 << 24
         assert not a.check(o)[2:7].any()
     assert a.info(dsa.COLMAJOR)["nb_partitions"] == n
-    before = a.export_layout(dsa.COLMAJOR)
-    a.rebalance_root(dsa.COLMAJOR)
-    after = a.export_layout(dsa.COLMAJOR)
-    for k in ("occ", "semaphores", "col_keys"):
-        assert np.array_equal(before[k], after[k]), k
-    occ = before["occ"].astype(bool)
-    assert np.array_equal(before["keys"][occ], after["keys"][occ]) and np.array_equal(before["vals"][occ], after["vals"][occ])
-    assert not a.check(dsa.COLMAJOR)[2:7].any()
+    for o in (dsa.COLMAJOR, dsa.ROWMAJOR):
+        a.rebalance_root(o)
+        b.rebalance_root(o)
+    assert_mat_equal(a, b)
+    assert not a.check(dsa.COLMAJOR)[2:7].any() and not a.check(dsa.ROWMAJOR)[2:7].any()
     np.testing.assert_allclose(a.mul(x), A @ x, rtol=1e-12, atol=0)
+
+
+def test_root_rebalance_at_2_24_slots_from_every_relayout_mode_matches_oracle(dsa, hip, oracle):
+    """The window the north-star roofline is quoted on: 11 M cells in 2^24 slots (the density of config 3).  From a source packed
+    to the left (pack!), packed to the right (all gaps at the left), after _extend! (2^25 slots: compared with the oracle's
+    pack! + spread! of the same cells over 2^25 raw slots) and after _shrink! back, the root rebalance must reproduce the oracle's
+    layout slot for slot (src/moves.jl:94-171, src/pma.jl:94-103,143-161)."""
+    import ctypes as C
+    n = 11_000_000
+    keys = np.arange(1, n + 1, dtype=np.int64) * 3 - 1
+    vals = unit12_array(41, n)
+    a = dsa.dynamicsparsevec(keys, vals, binding=hip)
+    b = dsa.dynamicsparsevec(keys, vals, binding=oracle)
+    assert a.info()["capacity"] == 1 << 24
+    assert_vec_equal(a, b)
+    ref = b.export_layout()
+    for mode in (1, 2):
+        hip.call("vec_dev_relayout", a.h, mode)
+        a.rebalance_root()
+        assert layouts_equal(a.export_layout(), ref), mode
+    hip.call("vec_dev_relayout", a.h, 3)                          # _extend!
+    assert a.info()["capacity"] == 1 << 25
+    cap2 = 1 << 25
+    k2 = np.zeros(cap2, dtype=np.int64); v2 = np.zeros(cap2, dtype=np.float64); o2 = np.zeros(cap2, dtype=np.uint8)
+    k2[:n], v2[:n], o2[:n] = keys, vals, 1
+    P_I64, P_F64, P_U8 = C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_uint8)
+    rc = oracle.lib.ora_raw_pack_spread(k2.ctypes.data_as(P_I64), v2.ctypes.data_as(P_F64), o2.ctypes.data_as(P_U8), C.c_int64(cap2),
+                                        C.c_int64(1), C.c_int64(cap2), C.c_int64(n), None, C.c_int64(0), C.c_int32(0), C.c_int32(1))
+    assert rc == 0
+    assert layouts_equal(a.export_layout(), (k2, v2, o2))
+    del k2, v2, o2
+    hip.call("vec_dev_relayout", a.h, 4)                          # _shrink!
+    assert_vec_equal(a, b)
+    assert not a.check()[2:7].any()
 
 
 def test_c5_full_size_streaming_first_10k_columns_vs_oracle_then_invariants(dsa, hip, oracle):
@@ -950,6 +988,38 @@ def test_fill_mode_flush_matches_oracle(dsa, hip, oracle):
     assert_mat_equal(dsa.dynamicsparse(I, J, V, binding=hip), dsa.dynamicsparse(I, J, V, binding=oracle))
 
 
+def test_failed_closefillmode_leaves_a_usable_fill_mode_matrix(dsa, hip, oracle):
+    """A build that fails inside closefillmode! (out of memory, a HIP error: injected with DSA_FAIL_BUILD) must leave the matrix in
+    fill mode with every triple it held — no dangling device pointers, no leaked streams — so that more rows can be appended and
+    the next closefillmode! builds everything; also for a matrix built from caller memory (nothing half-built survives)."""
+    g = SplitMix64(18)
+    row = [1 + g.next() % 500 for _ in range(6000)]
+    col = [1 + g.next() % 500 for _ in range(6000)]
+    val = [float(1 + g.next() % 1000) for _ in range(6000)]
+    a = dsa.dynamicsparse(fill_mode=True, binding=hip)
+    b = dsa.dynamicsparse(fill_mode=True, binding=oracle)
+    for m_ in (a, b):
+        m_.set_batch(row[:4000], col[:4000], val[:4000])
+    os.environ["DSA_FAIL_BUILD"] = "1"
+    try:
+        for _ in range(2):
+            with pytest.raises(dsa.DsaError) as ei:
+                a.closefillmode()
+            assert ei.value.code == dsa.binding.EHIP
+        with pytest.raises(dsa.DsaError):
+            dsa.dynamicsparse(row, col, val, binding=hip)
+    finally:
+        del os.environ["DSA_FAIL_BUILD"]
+    with pytest.raises(dsa.DsaError):           # still in fill mode: no lookups
+        a[1, 1]
+    for m_ in (a, b):
+        m_.addrow(2000, [5, 3, 9], [1.0, 2.0, 3.0])
+        m_.set_batch(row[4000:], col[4000:], val[4000:])
+        m_.closefillmode()
+    assert_mat_equal(a, b)
+    assert not a.check(0)[2:7].any() and not a.check(1)[2:7].any()
+
+
 def test_negative_and_huge_keys_match_oracle(dsa, hip, oracle):
     res = []
     for bnd in (hip, oracle):
@@ -981,10 +1051,11 @@ def test_row_and_column_slices_match_oracle(dsa, hip, oracle):
         assert_vec_equal(a.row_slice(key), b.row_slice(key))
 
 
-def test_c4_shard_scale_build_spmv_and_root_rebalance(dsa, hip):
-    """One shard of BASELINE config 4 at full size on the GPU alone: 1.25 M columns x 10 M rows, 12.5 M nnz ->
-    capacity 2^25 in both orientations (colmajor density 0.41, rowmajor 0.67).  Size-independent properties:
-    capacity rule, element counts, semaphore table, SpMV vs scipy (1e-12), rebalance idempotence (digest)."""
+def test_c4_shard_scale_build_spmv_and_root_rebalance(dsa, hip, oracle):
+    """One shard of BASELINE config 4 at full size: 1.25 M columns x 10 M rows, 12.5 M nnz -> capacity 2^25 in both
+    orientations (colmajor density 0.41, rowmajor 0.67).  Both orientations SLOT FOR SLOT against the oracle's build of the
+    same triples (scalars, 2 x 2^25 slots, tables), again after a root rebalance of each; capacity rule, element counts,
+    semaphore table, SpMV vs scipy and the oracle (1e-12), device invariant checker."""
     import scipy.sparse as sp
     m, n, per = 10_000_000, 1_250_000, 10
     rows = 1 + (splitmix_array(8, n * per) % np.uint64(m)).astype(np.int64)
@@ -993,30 +1064,75 @@ def test_c4_shard_scale_build_spmv_and_root_rebalance(dsa, hip):
     key = cols * np.int64(m + 1) + rows
     _, first = np.unique(key, return_index=True)
     rows, cols, vals = rows[first], cols[first], vals[first]
+    del key, first
     a = dsa.dynamicsparse(rows, cols, vals, m, n, binding=hip)
+    b = dsa.dynamicsparse(rows, cols, vals, m, n, binding=oracle)
     for o in (0, 1):
         inf = a.info(o)
         assert inf["capacity"] == 1 << 25, inf
         assert inf["nb_elements"] == len(rows) + inf["nb_partitions"]
     assert a.info(0)["nb_partitions"] == n
+    assert_mat_equal(a, b)
     x = unit12_array(10, n)
     y = a.mul(x)
     A = sp.csr_matrix((vals, (rows - 1, cols - 1)), shape=(m, n))
     np.testing.assert_allclose(y, A @ x, rtol=RTOL, atol=0)
+    np.testing.assert_allclose(y, b.mul(x), rtol=RTOL, atol=0)
     xt = unit12_array(11, m)
     np.testing.assert_allclose(a.mul(xt, transpose=True), A.T @ xt, rtol=RTOL, atol=0)
+    del A
     L0 = a.export_layout(0)
     occ = L0["occ"].astype(bool)
     pos = np.nonzero(occ)[0] + 1
     sem = L0["keys"][occ] == 0
     assert np.array_equal(pos[sem], L0["semaphores"])
+    del L0, occ, pos, sem
     for o in (0, 1):                         # device-side invariant checker at full size
         rep = a.check(o)
         assert rep[0] == a.info(o)["nb_elements"] and rep[1] == a.info(o)["nb_partitions"] and not rep[2:7].any(), rep
-    a.rebalance_root(0)                      # full 2^25-slot window: layout-idempotent
-    L1 = a.export_layout(0)
-    assert np.array_equal(L0["occ"], L1["occ"]) and np.array_equal(L0["keys"], L1["keys"])
-    assert np.array_equal(L0["semaphores"], L1["semaphores"])
+    for o in (0, 1):                         # full 2^25-slot windows: layout-idempotent, on both implementations
+        a.rebalance_root(o)
+        b.rebalance_root(o)
+    assert_mat_equal(a, b)
+
+
+def test_c4_full_config_eight_shards_sum_of_partials_vs_scipy(dsa, hip):
+    """BASELINE config 4 as a CONFIG: 10 M x 10 M, 10 rows per column = 10^8 triples, split into 8 contiguous column ranges of
+    1.25 M columns.  The test box has one GPU, so the 8 shards are built and multiplied one after the other through the product
+    class bench.py drives (sharding.ColumnShard, world = 8, rank g) and their partial y are summed on the device — exactly what
+    the all-reduce computes; compared with scipy on all 10^8 triples (1e-12).  Every shard: capacity 2^25, invariant checker."""
+    import scipy.sparse as sp
+    import torch
+    from dsa_amd import sharding
+    m = n = 10_000_000
+    per, G = 10, 8
+    dev = torch.device("cuda:0")
+    x = unit12_array(10, n)
+    y_sum = torch.zeros(m, dtype=torch.float64, device=dev)
+    y_ref = np.zeros(m)
+    for g in range(G):
+        c0 = g * (n // G)
+        nc = n // G
+        rows = 1 + (splitmix_array(8, nc * per) % np.uint64(m)).astype(np.int64) if g == 0 else \
+            1 + (splitmix_array(8 + 100 * g, nc * per) % np.uint64(m)).astype(np.int64)
+        cols = np.repeat(np.arange(c0 + 1, c0 + nc + 1, dtype=np.int64), per)
+        vals = unit12_array(9 + 100 * g, nc * per)
+        # the shard receives the triples of ITS column range with GLOBAL column keys, as bench.py hands them over
+        sh = sharding.ColumnShard(dsa, rows, cols, vals, m, n, g, G, binding=hip)
+        assert (sh.col0, sh.ncols) == (c0, nc)
+        for o in (0, 1):
+            inf = sh.A.info(o)
+            assert inf["capacity"] == 1 << 25, (g, o, inf)
+            assert not sh.A.check(o)[2:7].any()
+        xs = sh.x_slice(x)
+        yp = torch.full((m,), float("nan"), dtype=torch.float64, device=dev)
+        sh.spmv_partial(xs, yp)
+        torch.cuda.synchronize()
+        y_sum += yp
+        A = sp.csr_matrix((vals, (rows - 1, cols - 1 - c0)), shape=(m, nc))      # duplicates inside a column are summed by both
+        y_ref += A @ x[c0:c0 + nc]
+        del A, sh, rows, cols, vals, yp
+    np.testing.assert_allclose(y_sum.cpu().numpy(), y_ref, rtol=RTOL, atol=1e-300)
 
 
 def test_write_combined_single_sets_match_oracle(dsa, hip, oracle):
@@ -1202,6 +1318,7 @@ def test_shard_entry_points_split_spmv_exactly(dsa, hip, oracle):
     sub-matrix (slot-for-slot equal to the oracle's build of the filtered triples) and the partial products sum to A*x."""
     import ctypes as C
     import torch
+    import cpu_shard
     from dsa_amd import sharding
     m, n, nnz, G = 5000, 3001, 40000, 3
     I = 1 + (splitmix_array(501, nnz) % np.uint64(m)).astype(np.int64)
@@ -1213,7 +1330,7 @@ def test_shard_entry_points_split_spmv_exactly(dsa, hip, oracle):
     y = np.zeros(m)
     for g in range(G):
         sh = sharding.ColumnShard(dsa, I, J, V, m, n, g, G, binding=hip)
-        ref = sharding.ColumnShard(dsa, I, J, V, m, n, g, G, binding=oracle)
+        ref = cpu_shard.make_cpu_shard_class(sharding)(dsa, I, J, V, m, n, g, G, binding=oracle)
         assert_mat_equal(sh.A, ref.A)
         assert sh.A.size() == (m, sh.ncols)
         dx = sh.x_slice(x)                                       # CUDA tensor next to the HIP library

@@ -23,7 +23,7 @@ def test_library_builds_and_exports_header_symbols(dsa):
     missing = [n for n in names if not hasattr(lib, n)]
     assert not missing, missing
     # the ctypes binding declares the same set
-    bound = {"dsa_" + n for n in dsa.Binding.declared_symbols(device_api=True)}
+    bound = {"dsa_" + n for n in dsa.Binding.declared_symbols()}
     assert bound == set(names), sorted(bound ^ set(names))
 
 

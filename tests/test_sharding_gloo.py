@@ -1,7 +1,7 @@
 """CPU test of the N > 1 path: world_size-2 gloo, column-range sharding + the three schedules of the sum of y
-(all_reduce, reduce_scatter + all_gather, all_to_all + local sum + all_gather).  The local SpMV runs on the
-CPU oracle here (there is no GPU in the build container); on the GPUs the SAME ColumnShard methods run with
-CUDA tensors on the HIP library and RCCL (bench.py drives exactly this class)."""
+(all_reduce, reduce_scatter + all_gather, all_to_all + local sum + all_gather).  The product class sharding.ColumnShard runs
+with its three library-facing methods pointed at the CPU oracle and CPU tensors (tests/cpu_shard.py: there is no GPU in the build
+container); on the GPUs the same ranges, slices and schedules run with CUDA tensors on the HIP library and RCCL (bench.py)."""
 import os
 import socket
 import sys
@@ -36,10 +36,15 @@ def _worker(rank, world, port, out_dir):
     import dsa_loader
     dsa = dsa_loader.load()
     from dsa_amd import sharding          # registered by dsa_loader
-    ora = dsa.Binding(os.path.join(ROOT, "oracle", "liboracle.so"), "ora", device_api=False)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_binding
+    import cpu_shard
+    ora = oracle_binding.load(dsa)
+    CpuColumnShard = cpu_shard.make_cpu_shard_class(sharding)
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     m, n, I, J, V, x = _make_problem()
-    sh = sharding.ColumnShard(dsa, I, J, V, m, n, rank, world, binding=ora)
+    sh = CpuColumnShard(dsa, I, J, V, m, n, rank, world, binding=ora)
     xs = sh.x_slice(x)                                   # a tensor on the shard's device (CPU next to the oracle)
     ys = [sh.spmv(xs, schedule=s).numpy().copy() for s in sharding.SCHEDULES]
     # the overlapped form bench.py uses: partial product, asynchronous all-reduce, wait

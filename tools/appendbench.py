@@ -16,7 +16,7 @@ for rep in range(2):
     print("batch A: %.2f ms  %.0f appends/s" % (dt * 1e3, len(app) / dt), v.info()["capacity"])
 
 if "--check" in sys.argv:      # parity of the batch against the CPU oracle (used by the test-suite under DSA_POS_WIDE=1)
-    ora = dsa.Binding(os.path.join(ROOT, "oracle", "liboracle.so"), "ora", device_api=False)
+    sys.path.insert(0, os.path.join(ROOT, "oracle")); import oracle_binding; ora = oracle_binding.load(dsa)
     o = dsa.dynamicsparsevec(keys0, bench.unit12(3, n0), binding=ora)
     o.set_batch(app, va)
     a, b = v.export_layout(), o.export_layout()

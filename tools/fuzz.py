@@ -19,7 +19,7 @@ from util import SplitMix64  # noqa: E402
 dsa = dsa_loader.load()
 BIG = os.environ.get("FUZZ_BIG") == "1"       # larger key spaces and batches: big-window yields, extends, > 1024 pending columns
 hip = None if os.environ.get("FUZZ_SELF") == "1" else dsa.product()
-ora = dsa.Binding(os.path.join(ROOT, "oracle", "liboracle.so"), "ora", device_api=False)
+sys.path.insert(0, os.path.join(ROOT, "oracle")); import oracle_binding; ora = oracle_binding.load(dsa)
 if hip is None:
     hip = ora            # dry run of the script itself (oracle vs oracle)
 
