@@ -1,29 +1,445 @@
 // csrc/build.hip — K-build: the bulk (fill-mode flush) constructor on the device.
 //
-// Reproduces _dynamicsparse (src/pcsr.jl:354-431) + the PackedCSC constructor's cell stream
-// (src/pcsr.jl:26-63) for one orientation: sort the (partition, key) pairs, combine duplicates, count the
-// cells per partition and emit the ordered stream  [sem(0, id), entries...]  per partition, plus the
-// partition keys.  The stream is written straight into the PMA's slot buffer; the full-array spread
-// (src/pma.jl:42-55) is then one k_move<true> launch (rebalance.hip).
+// Reproduces _dynamicsparse (src/pcsr.jl:354-431) + the PackedCSC constructor's cell stream (src/pcsr.jl:26-63) for one
+// orientation: sort the (partition, key) pairs, combine duplicates, count the cells per partition and emit the ordered stream
+// [sem(0, id), entries...] per partition, plus the partition keys.  The stream is written straight into the PMA's slot buffer;
+// the full-array spread (src/pma.jl:42-55) is then one k_move2<PACKED> launch (rebalance.hip).
 //
-//   sort      : two stable LSD radix sorts (rocPRIM device_radix_sort, 64-bit signed keys) — by key, then by
-//               partition — carrying the input index, so equal (partition, key) pairs stay in INPUT order.
-//               The reference sorts with an unstable QuickSort (src/pcsr.jl:360); input order is one of its
-//               legal outcomes and makes the Float64 fold of duplicates deterministic.
-//   flags     : new-partition / new-cell flags from neighbour compares (coalesced).
-//   scans     : two inclusive scans (rocPRIM device_scan) give the partition id and the cell rank.
-//   emit      : every first-of-run lane folds its duplicate run left to right (src/pcsr.jl:374-375) and
-//               writes its cell at  rank-1 + partition_id  ; every first-of-partition lane writes the
-//               semaphore cell (0, id) at  rank-1 + id-1  and the partition key.
-// Bound: HBM (sort passes dominate: 8 B key + 4 B index, 2 x 8 digit passes).
+//   sort   : ONE hand-written stable LSD radix sort (8-bit digits) of 64-bit composites
+//                comp = (partition - pmin) << kbits | (key - kmin)
+//            carrying the Float64 value — only over the bits the composite really has: kbits + pbits, from a min / max pass
+//            over the input (config 3: 20 + 20 bits = 5 passes; round 2 ran 2 x 16 passes of a 64-bit library sort plus two index
+//            gathers).  Stable, so equal (partition, key) pairs stay in INPUT order: the reference sorts with an unstable QuickSort
+//            (src/pcsr.jl:360); input order is one of its legal outcomes and makes the Float64 fold of duplicates deterministic.
+//            A pass is three launches: per-tile digit histogram (LDS atomics), one workgroup per digit scans its row of the
+//            histogram matrix (no look-back chain: see DESIGN §3.1 on what chained scans cost on this part), and the scatter:
+//            ranks by wave-wide digit matching (8 ballots), the tile sorted through LDS so that runs of equal digits leave as
+//            contiguous stores.
+//   flags  : new-partition / new-cell flags from neighbour compares of the sorted composites; per-tile counts, one small scan.
+//   emit   : every first-of-run lane folds its duplicate run left to right (src/pcsr.jl:374-375) and writes its cell at
+//            rank-1 + partition_id ; every first-of-partition lane writes the semaphore cell (0, id) at rank-1 + id-1 and the
+//            partition key.  Runs longer than 64 duplicates are finished by a wave each (k_fold_long): coalesced loads, the same
+//            left-to-right order.
+// Composites that do not fit 64 bits (partition AND key ranges beyond 2^32) take the general path at the end of the file: two
+// stable 64-bit sorts by key then by partition (rocPRIM) carrying the input index.
+// Bound: HBM (sort passes: 40 B per triple and pass).
 #include "dsa_dev.h"
 
+#include <algorithm>
 #include <cstring>
+#include <mutex>
+#include <vector>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
 
 namespace dsa {
 
+constexpr int RS_BLOCK = 256, RS_WAVES = RS_BLOCK / 64, RS_ITEMS = 16, RS_TILE = RS_BLOCK * RS_ITEMS, RS_BINS = 256;
+constexpr int RS_PER_WAVE = RS_TILE / RS_WAVES;
+constexpr int FOLD_INLINE = 64;            // duplicates of one cell folded by the emitting lane itself
+
+// device-resident scalars of one build
+struct BuildCtl {
+    long long pmin, pmax, kmin, kmax;      // k_minmax
+    unsigned long long ncells, nparts;     // k_bf_scan
+    unsigned long long nlong;              // runs handed to k_fold_long
+    unsigned long long zeros;              // k_minmax: bit 0 = a partition key is 0, bit 1 = a key is 0 (the reserved semaphore key)
+};
+struct LongRun { int64_t next; int64_t pos; double acc; uint64_t comp; };
+
+// min / max of the key arrays when the caller does not know them: per-workgroup partials, folded by the workgroup that finishes
+// last (64-bit signed atomic min / max from thousands of waves on four words cost 450 us at 10 M triples)
+constexpr int MM_BLOCKS = 1024;
+__global__ __launch_bounds__(256) void k_minmax(const int64_t* __restrict__ part, const int64_t* __restrict__ key, int64_t n, BuildCtl* c,
+                                                long long* __restrict__ partial /*[4 * gridDim]*/, unsigned int* __restrict__ ticket /*[2]: ticket, zero flags*/) {
+    unsigned int* zflags = ticket + 1;
+    __shared__ long long sM[4][4];
+    __shared__ unsigned int sLast;
+    long long m[4] = {INT64_MAX, INT64_MIN, INT64_MAX, INT64_MIN};      // pmin, pmax, kmin, kmax
+    unsigned int z = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const long long k = key[i];
+        m[2] = k < m[2] ? k : m[2]; m[3] = k > m[3] ? k : m[3];
+        if (k == 0) z |= 2u;
+        if (part != nullptr) { const long long p = part[i]; m[0] = p < m[0] ? p : m[0]; m[1] = p > m[1] ? p : m[1]; if (p == 0) z |= 1u; }
+    }
+    if (__ballot(z & 1u)) z |= 1u;
+    if (__ballot(z & 2u)) z |= 2u;
+    if (z && (threadIdx.x & 63) == 0) atomicOr(zflags, z);
+    auto fold = [&](long long* v) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const long long a = __shfl_xor(v[q], o, 64); v[q] = (q & 1) ? (a > v[q] ? a : v[q]) : (a < v[q] ? a : v[q]); }
+        }
+    };
+    fold(m);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) for (int q = 0; q < 4; ++q) sM[wv][q] = m[q];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) for (int q = 0; q < 4; ++q) m[q] = (q & 1) ? (sM[w][q] > m[q] ? sM[w][q] : m[q]) : (sM[w][q] < m[q] ? sM[w][q] : m[q]);
+        for (int q = 0; q < 4; ++q) __hip_atomic_store(partial + 4 * blockIdx.x + q, m[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();
+        sLast = atomicAdd(ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!sLast) return;
+    m[0] = m[2] = INT64_MAX; m[1] = m[3] = INT64_MIN;
+    for (int b = threadIdx.x; b < (int)gridDim.x; b += 256)
+        for (int q = 0; q < 4; ++q) {
+            const long long a = __hip_atomic_load(partial + 4 * b + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            m[q] = (q & 1) ? (a > m[q] ? a : m[q]) : (a < m[q] ? a : m[q]);
+        }
+    fold(m);
+    __syncthreads();
+    if (lane == 0) for (int q = 0; q < 4; ++q) sM[wv][q] = m[q];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) for (int q = 0; q < 4; ++q) m[q] = (q & 1) ? (sM[w][q] > m[q] ? sM[w][q] : m[q]) : (sM[w][q] < m[q] ? sM[w][q] : m[q]);
+        c->pmin = m[0]; c->pmax = m[1]; c->kmin = m[2]; c->kmax = m[3];
+        c->zeros = __hip_atomic_load(zflags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *ticket = 0; *zflags = 0;
+    }
+}
+
+// ---- the radix pass ---------------------------------------------------------------------------------------------------
+// element order inside a tile: wave w owns RS_PER_WAVE consecutive elements, iteration j of the wave 64 consecutive ones
+__device__ __forceinline__ int64_t rs_index(int64_t tile0, int wv, int j, int lane) { return tile0 + (int64_t)wv * RS_PER_WAVE + j * 64 + lane; }
+
+// composites from (partition, key) + the histogram of the first pass: hist[d * nblocks + b]
+__global__ __launch_bounds__(RS_BLOCK) void k_comp_hist(const int64_t* __restrict__ part, const int64_t* __restrict__ key, int64_t n,
+                                                        int64_t pmin, int64_t kmin, int kbits, uint64_t* __restrict__ comp,
+                                                        int shift, uint32_t* __restrict__ hist, int64_t nblocks) {
+    __shared__ uint32_t h[RS_BINS];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    h[tid] = 0;
+    __syncthreads();
+    const int64_t tile0 = (int64_t)blockIdx.x * RS_TILE;
+    int64_t kk[RS_ITEMS], pp[RS_ITEMS];
+#pragma unroll
+    for (int j = 0; j < RS_ITEMS; ++j) {
+        const int64_t i = rs_index(tile0, wv, j, lane);
+        kk[j] = i < n ? __builtin_nontemporal_load(key + i) : 0;
+        pp[j] = (part != nullptr && i < n) ? __builtin_nontemporal_load(part + i) : pmin;
+    }
+#pragma unroll
+    for (int j = 0; j < RS_ITEMS; ++j) {
+        const int64_t i = rs_index(tile0, wv, j, lane);
+        if (i < n) {
+            uint64_t c = (uint64_t)kk[j] - (uint64_t)kmin;
+            if (part != nullptr) c |= ((uint64_t)pp[j] - (uint64_t)pmin) << kbits;
+            comp[i] = c;
+            atomicAdd(&h[(c >> shift) & (RS_BINS - 1)], 1u);
+        }
+    }
+    __syncthreads();
+    hist[(int64_t)tid * nblocks + blockIdx.x] = h[tid];
+}
+
+__global__ __launch_bounds__(RS_BLOCK) void k_rs_hist(const uint64_t* __restrict__ in_key, int64_t n, int shift, uint32_t* __restrict__ hist,
+                                                      int64_t nblocks) {
+    __shared__ uint32_t h[RS_BINS];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    h[tid] = 0;
+    __syncthreads();
+    const int64_t tile0 = (int64_t)blockIdx.x * RS_TILE;
+    uint64_t k[RS_ITEMS];
+#pragma unroll
+    for (int j = 0; j < RS_ITEMS; ++j) {
+        const int64_t i = rs_index(tile0, wv, j, lane);
+        k[j] = i < n ? __builtin_nontemporal_load(in_key + i) : 0ull;
+    }
+#pragma unroll
+    for (int j = 0; j < RS_ITEMS; ++j)
+        if (rs_index(tile0, wv, j, lane) < n) atomicAdd(&h[(k[j] >> shift) & (RS_BINS - 1)], 1u);
+    __syncthreads();
+    hist[(int64_t)tid * nblocks + blockIdx.x] = h[tid];
+}
+
+__device__ __forceinline__ uint32_t bld_wave_excl_scan(uint32_t v) {
+    const int lane = lane_id();
+    uint32_t x = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t y = __shfl_up(x, o, 64);
+        if (lane >= o) x += y;
+    }
+    return x - v;
+}
+// exclusive scan over the 256 threads of a workgroup; *total = sum (same in every thread)
+__device__ __forceinline__ uint32_t bld_block_excl_scan(uint32_t v, uint32_t* sW /*[RS_WAVES]*/, uint32_t* total) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t ex = bld_wave_excl_scan(v);
+    __syncthreads();                                    // sW may still be read from a previous use
+    if (lane == 63) sW[wv] = ex + v;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < RS_WAVES; ++w) { const uint32_t s = sW[w]; if (w < wv) base += s; tot += s; }
+    *total = tot;
+    return base + ex;
+}
+
+// one workgroup per digit: hist[d][0..nblocks) becomes the number of elements with digit d in the tiles in front of each tile,
+// tot[d] their number over all tiles (the scatter kernel turns the 256 totals into digit bases itself)
+__global__ __launch_bounds__(RS_BLOCK) void k_rs_scan(uint32_t* __restrict__ hist, uint32_t* __restrict__ tot, int64_t nblocks) {
+    __shared__ uint32_t sW[RS_WAVES];
+    const int tid = threadIdx.x, d = blockIdx.x;
+    uint32_t* row = hist + (int64_t)d * nblocks;
+    const int64_t ipt = (nblocks + RS_BLOCK - 1) / RS_BLOCK;
+    const int64_t i0 = (int64_t)tid * ipt, i1 = i0 + ipt < nblocks ? i0 + ipt : nblocks;
+    uint32_t local = 0;
+    for (int64_t i = i0; i < i1; ++i) local += row[i];
+    uint32_t total;
+    uint32_t run = bld_block_excl_scan(local, sW, &total);
+    for (int64_t i = i0; i < i1; ++i) { const uint32_t c = row[i]; row[i] = run; run += c; }
+    if (tid == 0) tot[d] = total;
+}
+
+__global__ __launch_bounds__(RS_BLOCK) void k_rs_scatter(const uint64_t* __restrict__ in_key, const double* __restrict__ in_val, int64_t n, int shift,
+                                                         const uint32_t* __restrict__ gbase, const uint32_t* __restrict__ dtot,
+                                                         uint64_t* __restrict__ out_key, double* __restrict__ out_val, int64_t nblocks) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char rs_lds[];
+    uint64_t* sKey = reinterpret_cast<uint64_t*>(rs_lds);
+    double* sVal = reinterpret_cast<double*>(rs_lds + (size_t)RS_TILE * sizeof(uint64_t));
+    __shared__ uint32_t sCnt[RS_WAVES][RS_BINS];
+    __shared__ uint32_t sStart[RS_BINS], sBase[RS_BINS], sW[RS_WAVES];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int64_t tile0 = (int64_t)blockIdx.x * RS_TILE;
+#pragma unroll
+    for (int w = 0; w < RS_WAVES; ++w) sCnt[w][tid] = 0;
+    uint64_t k[RS_ITEMS]; double v[RS_ITEMS]; uint32_t r[RS_ITEMS];
+#pragma unroll
+    for (int j = 0; j < RS_ITEMS; ++j) {
+        const int64_t i = rs_index(tile0, wv, j, lane);
+        const bool valid = i < n;
+        k[j] = valid ? __builtin_nontemporal_load(in_key + i) : ~0ull;
+        v[j] = valid ? __builtin_nontemporal_load(in_val + i) : 0.0;
+    }
+    __syncthreads();
+    // ranks inside the wave, per digit, in element order: lanes with the same digit find each other with 8 ballots; the lowest
+    // of them advances the wave's counter of that digit
+#pragma unroll
+    for (int j = 0; j < RS_ITEMS; ++j) {
+        const bool valid = rs_index(tile0, wv, j, lane) < n;
+        const uint32_t d = (uint32_t)(k[j] >> shift) & (RS_BINS - 1);
+        uint64_t peers = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const bool bit = (d >> b) & 1u;
+            const uint64_t bb = __ballot(bit);
+            peers &= bit ? bb : ~bb;
+        }
+        const int leader = peers ? __ffsll((unsigned long long)peers) - 1 : 0;
+        uint32_t old = 0;
+        if (valid && lane == leader) { old = sCnt[wv][d]; sCnt[wv][d] = old + (uint32_t)popc64(peers); }
+        old = __shfl(old, leader, 64);
+        r[j] = old + (uint32_t)popc64(peers & mask_lt(lane));
+    }
+    __syncthreads();
+    {   // thread <-> digit: wave offsets, tile-local start of the digit, its global base
+        const uint32_t c0 = sCnt[0][tid], c1 = sCnt[1][tid], c2 = sCnt[2][tid], c3 = sCnt[3][tid];
+        sCnt[0][tid] = 0; sCnt[1][tid] = c0; sCnt[2][tid] = c0 + c1; sCnt[3][tid] = c0 + c1 + c2;
+        uint32_t tot;
+        const uint32_t ex = bld_block_excl_scan(c0 + c1 + c2 + c3, sW, &tot);
+        const uint32_t dbase = bld_block_excl_scan(dtot[tid], sW, &tot);       // elements with a smaller digit, all tiles
+        sStart[tid] = ex;
+        sBase[tid] = dbase + gbase[(int64_t)tid * nblocks + blockIdx.x] - ex;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < RS_ITEMS; ++j) {
+        if (rs_index(tile0, wv, j, lane) < n) {
+            const uint32_t d = (uint32_t)(k[j] >> shift) & (RS_BINS - 1);
+            const uint32_t p = sStart[d] + sCnt[wv][d] + r[j];
+            sKey[p] = k[j]; sVal[p] = v[j];
+        }
+    }
+    __syncthreads();
+    const int count = (int)(n - tile0 < RS_TILE ? n - tile0 : RS_TILE);
+    for (int i = tid; i < count; i += RS_BLOCK) {
+        const uint64_t kk = sKey[i];
+        const uint32_t g = sBase[(uint32_t)(kk >> shift) & (RS_BINS - 1)] + (uint32_t)i;
+        out_key[g] = kk; out_val[g] = sVal[i];
+    }
+}
+
+// ---- flags, counts, emit ---------------------------------------------------------------------------------------------
+// new-cell / new-partition flags of one element from its predecessor in the sorted order
+struct BfFlags { uint64_t fc, fp; };      // ballots over the wave's 64 elements of one iteration
+__device__ __forceinline__ BfFlags bf_flags(const uint64_t* __restrict__ comp, int64_t i, int64_t n, uint64_t cur, int kbits, bool has_part, int lane) {
+    uint64_t prev = __shfl_up(cur, 1, 64);
+    if (lane == 0 && i > 0 && i < n) prev = comp[i - 1];
+    const bool valid = i < n;
+    const bool fc = valid && (i == 0 || cur != prev);
+    const bool fp = valid && (i == 0 || (has_part && (cur >> kbits) != (prev >> kbits)));
+    BfFlags f; f.fc = __ballot(fc); f.fp = __ballot(fp);
+    return f;
+}
+
+__global__ __launch_bounds__(RS_BLOCK) void k_bf_count(const uint64_t* __restrict__ comp, int64_t n, int kbits, int has_part,
+                                                       uint32_t* __restrict__ cnt_c, uint32_t* __restrict__ cnt_p) {
+    __shared__ uint32_t sC[RS_WAVES], sP[RS_WAVES];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int64_t tile0 = (int64_t)blockIdx.x * RS_TILE;
+    uint32_t c = 0, p = 0;
+#pragma unroll 4
+    for (int j = 0; j < RS_ITEMS; ++j) {
+        const int64_t i = rs_index(tile0, wv, j, lane);
+        const uint64_t cur = i < n ? comp[i] : 0ull;
+        const BfFlags f = bf_flags(comp, i, n, cur, kbits, has_part != 0, lane);
+        c += (uint32_t)popc64(f.fc); p += (uint32_t)popc64(f.fp);
+    }
+    if (lane == 0) { sC[wv] = c; sP[wv] = p; }
+    __syncthreads();
+    if (tid == 0) { cnt_c[blockIdx.x] = sC[0] + sC[1] + sC[2] + sC[3]; cnt_p[blockIdx.x] = sP[0] + sP[1] + sP[2] + sP[3]; }
+}
+
+// one workgroup: exclusive prefixes of the per-tile counts (in place), totals to the control block
+__global__ __launch_bounds__(1024) void k_bf_scan(uint32_t* __restrict__ cnt_c, uint32_t* __restrict__ cnt_p, int64_t ntiles, BuildCtl* ctl) {
+    __shared__ uint32_t wsum[2][16];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    uint32_t carry[2] = {0, 0};
+    uint32_t* arr[2] = {cnt_c, cnt_p};
+    for (int64_t base = 0; base < ntiles; base += 1024) {
+        const int64_t i = base + tid;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const uint32_t v = i < ntiles ? arr[a][i] : 0u;
+            const uint32_t ex = bld_wave_excl_scan(v);
+            if (lane == 63) wsum[a][wv] = ex + v;
+            __syncthreads();
+            uint32_t run = carry[a] + ex, total = 0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) { const uint32_t s = wsum[a][k]; if (k < wv) run += s; total += s; }
+            if (i < ntiles) arr[a][i] = run;
+            carry[a] += total;
+            __syncthreads();
+        }
+    }
+    if (tid == 0) { ctl->ncells = carry[0]; ctl->nparts = carry[1]; ctl->nlong = 0; }
+}
+
+__device__ __forceinline__ double bld_combine(double a, double b, int32_t combine) {
+    return combine == 0 ? a + b : (combine == 1 ? a * b : b);
+}
+
+// mode 0: mapped partitions (ids = rank of the distinct partition keys, semaphore emitted by the first cell of a partition)
+// mode 1: plain vector (no semaphores)   mode 2: explicit partition ids 1..P (semaphores by k_emit_sems)
+__global__ __launch_bounds__(RS_BLOCK) void k_bf_emit(const uint64_t* __restrict__ comp, const double* __restrict__ val, int64_t n, int kbits,
+                                                      int64_t pmin, int64_t kmin, int mode, int32_t combine,
+                                                      const uint32_t* __restrict__ off_c, const uint32_t* __restrict__ off_p,
+                                                      KeyArr out_keys, double* __restrict__ out_vals, int64_t* __restrict__ part_keys,
+                                                      uint32_t* __restrict__ scell, BuildCtl* ctl, LongRun* __restrict__ queue) {
+    __shared__ uint32_t sC[RS_WAVES], sP[RS_WAVES];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int64_t tile0 = (int64_t)blockIdx.x * RS_TILE;
+    const bool has_part = mode != 1;
+    const uint64_t kmask = kbits >= 64 ? ~0ull : ((1ull << kbits) - 1ull);
+    uint64_t cur[RS_ITEMS], fcb[RS_ITEMS], fpb[RS_ITEMS];
+    double vj[RS_ITEMS];
+    uint32_t c = 0, p = 0;
+#pragma unroll
+    for (int j = 0; j < RS_ITEMS; ++j) {
+        const int64_t i = rs_index(tile0, wv, j, lane);
+        cur[j] = i < n ? __builtin_nontemporal_load(comp + i) : 0ull;
+        vj[j] = i < n ? __builtin_nontemporal_load(val + i) : 0.0;
+    }
+#pragma unroll
+    for (int j = 0; j < RS_ITEMS; ++j) {
+        const int64_t i = rs_index(tile0, wv, j, lane);
+        const BfFlags f = bf_flags(comp, i, n, cur[j], kbits, has_part, lane);
+        fcb[j] = f.fc; fpb[j] = f.fp;
+        c += (uint32_t)popc64(f.fc); p += (uint32_t)popc64(f.fp);
+    }
+    if (lane == 0) { sC[wv] = c; sP[wv] = p; }
+    __syncthreads();
+    uint32_t rc = off_c[blockIdx.x], rp = off_p[blockIdx.x];       // cells / partition starts in front of this wave's elements
+    for (int w = 0; w < wv; ++w) { rc += sC[w]; rp += sP[w]; }
+#pragma unroll
+    for (int j = 0; j < RS_ITEMS; ++j) {
+        const int64_t i = rs_index(tile0, wv, j, lane);
+        const uint64_t le = lane == 63 ? ~0ull : mask_lt(lane + 1);
+        const uint32_t rank = rc + (uint32_t)popc64(fcb[j] & le);            // 1-based rank of the cell this element belongs to
+        const uint32_t pidr = rp + (uint32_t)popc64(fpb[j] & le);            // 1-based rank of its partition
+        uint64_t nxt = __shfl_down(cur[j], 1, 64);
+        if (lane == 63) nxt = i + 1 < n ? comp[i + 1] : ~cur[j];
+        if (i + 1 >= n) nxt = ~cur[j];
+        if (i < n) {
+            if (scell != nullptr) scell[i] = rank;
+            if ((fcb[j] >> lane) & 1ull) {
+                const uint64_t cc = cur[j];
+                const int64_t key = (int64_t)((cc & kmask) + (uint64_t)kmin);
+                const int64_t part = has_part ? (int64_t)((kbits >= 64 ? 0ull : (cc >> kbits)) + (uint64_t)pmin) : 0;
+                const int64_t pid = mode == 0 ? (int64_t)pidr : (mode == 1 ? 0 : part);
+                const int64_t pos = (int64_t)rank - 1 + pid;
+                double acc = vj[j];
+                if (nxt == cc) {                                  // duplicates: left fold in input order  src/pcsr.jl:374-375
+                    int64_t t = i + 1;
+                    int len = 1;
+                    while (t < n && len < FOLD_INLINE && comp[t] == cc) { acc = bld_combine(acc, val[t], combine); ++t; ++len; }
+                    if (t < n && len == FOLD_INLINE && comp[t] == cc) {      // a long run: a wave finishes it (k_fold_long)
+                        const unsigned long long q = atomicAdd(&ctl->nlong, 1ull);
+                        LongRun lr; lr.next = t; lr.pos = pos; lr.acc = acc; lr.comp = cc;
+                        queue[q] = lr;
+                    }
+                }
+                out_keys[pos] = key;
+                out_vals[pos] = acc;
+                if (mode == 0 && ((fpb[j] >> lane) & 1ull)) {
+                    out_keys[pos - 1] = SEM_KEY;
+                    out_vals[pos - 1] = (double)pid;
+                    part_keys[pid - 1] = part;
+                }
+            }
+        }
+        rc += (uint32_t)popc64(fcb[j]); rp += (uint32_t)popc64(fpb[j]);
+    }
+}
+
+// the rest of the duplicate runs longer than FOLD_INLINE: one wave per run, 64 values per coalesced load, folded in order
+__global__ __launch_bounds__(64) void k_fold_long(const uint64_t* __restrict__ comp, const double* __restrict__ val, int64_t n, int32_t combine,
+                                                  const BuildCtl* ctl, const LongRun* __restrict__ queue, double* __restrict__ out_vals) {
+    const int lane = threadIdx.x;
+    const unsigned long long nl = ctl->nlong;
+    for (unsigned long long q = blockIdx.x; q < nl; q += gridDim.x) {
+        const LongRun lr = queue[q];
+        double acc = lr.acc;
+        int64_t t = lr.next;
+        while (true) {
+            const int64_t i = t + lane;
+            const bool same = i < n && comp[i] == lr.comp;
+            const double v = same ? val[i] : 0.0;
+            const uint64_t b = __ballot(same);
+            const int cnt = b == ~0ull ? 64 : __ffsll((unsigned long long)~b) - 1;      // leading run of equal composites
+            for (int l = 0; l < cnt; ++l) acc = bld_combine(acc, __shfl(v, l, 64), combine);
+            if (cnt < 64) break;
+            t += 64;
+        }
+        if (lane == 0) out_vals[lr.pos] = acc;
+    }
+}
+
+// mode 2: semaphore cell of every partition p = 1..P (empty partitions included, src/pcsr.jl:36-41):
+// position = (#distinct cells of partitions < p) + p - 1
+__global__ void k_emit_sems(const uint64_t* __restrict__ comp, int kbits, int64_t pmin, const uint32_t* __restrict__ scell, int64_t n,
+                            int64_t nparts, KeyArr out_keys, double* __restrict__ out_vals) {
+    const int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x + 1;
+    if (p > nparts) return;
+    int64_t lo = 0, hi = n;                     // first index with part >= p
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        const int64_t pm = (int64_t)((kbits >= 64 ? 0ull : (comp[mid] >> kbits)) + (uint64_t)pmin);
+        if (pm < p) lo = mid + 1; else hi = mid;
+    }
+    const int64_t cells_before = lo == 0 ? 0 : (int64_t)scell[lo - 1];
+    const int64_t pos = cells_before + p - 1;
+    out_keys[pos] = SEM_KEY;
+    out_vals[pos] = (double)p;
+}
+
+// ---- general path (composite wider than 64 bits): two stable 64-bit library sorts carrying the input index ----------------
 __global__ void k_iota(uint32_t* idx, int64_t n) {
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (i < n) idx[i] = (uint32_t)i;
@@ -36,28 +452,21 @@ __global__ void k_flags(const int64_t* __restrict__ part, const int64_t* __restr
                         uint32_t* __restrict__ fcell, int64_t n) {
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (i >= n) return;
-    // part == nullptr: a plain vector (one implicit partition, no semaphore cells)
     const bool np = part == nullptr ? (i == 0) : ((i == 0) || part[i] != part[i - 1]);
     fpart[i] = np ? 1u : 0u;
     fcell[i] = (np || key[i] != key[i - 1]) ? 1u : 0u;
 }
-__global__ void k_emit(const int64_t* __restrict__ part, const int64_t* __restrict__ key, const uint32_t* __restrict__ idx,
-                       const double* __restrict__ val, const uint32_t* __restrict__ fpart, const uint32_t* __restrict__ fcell,
-                       const uint32_t* __restrict__ spart, const uint32_t* __restrict__ scell, int64_t n, int32_t combine,
-                       KeyArr out_keys, double* __restrict__ out_vals, int64_t* __restrict__ part_keys,
-                       int mode) {
-    // mode 0: mapped partitions (ids = rank of the distinct partition keys, semaphore emitted by the first cell)
-    // mode 1: plain vector (no semaphores)   mode 2: explicit partition ids 1..P in `part` (semaphores by k_emit_sems)
+__global__ void k_emit_wide(const int64_t* __restrict__ part, const int64_t* __restrict__ key, const uint32_t* __restrict__ idx,
+                            const double* __restrict__ val, const uint32_t* __restrict__ fpart, const uint32_t* __restrict__ fcell,
+                            const uint32_t* __restrict__ spart, const uint32_t* __restrict__ scell, int64_t n, int32_t combine,
+                            KeyArr out_keys, double* __restrict__ out_vals, int64_t* __restrict__ part_keys, int mode) {
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (i >= n) return;
     if (!fcell[i]) return;
-    const int64_t pid = mode == 0 ? (int64_t)spart[i] : (mode == 1 ? 0 : part[i]);   // semaphore cells in front of this cell
-    const int64_t rank = scell[i];           // 1-based rank among the distinct cells
+    const int64_t pid = mode == 0 ? (int64_t)spart[i] : (mode == 1 ? 0 : part[i]);
+    const int64_t rank = scell[i];
     double acc = val[idx[i]];
-    for (int64_t j = i + 1; j < n && !fcell[j]; ++j) {     // left fold of the duplicates, input order
-        const double v = val[idx[j]];
-        acc = combine == 0 ? acc + v : (combine == 1 ? acc * v : v);
-    }
+    for (int64_t j = i + 1; j < n && !fcell[j]; ++j) acc = bld_combine(acc, val[idx[j]], combine);
     const int64_t pos = rank - 1 + pid;
     out_keys[pos] = key[i];
     out_vals[pos] = acc;
@@ -67,14 +476,11 @@ __global__ void k_emit(const int64_t* __restrict__ part, const int64_t* __restri
         part_keys[pid - 1] = part[i];
     }
 }
-
-// mode 2: semaphore cell of every partition p = 1..P (empty partitions included, src/pcsr.jl:36-41):
-// position = (#distinct cells of partitions < p) + p - 1
-__global__ void k_emit_sems(const int64_t* __restrict__ part_sorted, const uint32_t* __restrict__ scell, int64_t n, int64_t nparts,
-                            KeyArr out_keys, double* __restrict__ out_vals) {
+__global__ void k_emit_sems_wide(const int64_t* __restrict__ part_sorted, const uint32_t* __restrict__ scell, int64_t n, int64_t nparts,
+                                 KeyArr out_keys, double* __restrict__ out_vals) {
     const int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x + 1;
     if (p > nparts) return;
-    int64_t lo = 0, hi = n;                     // first index with part >= p
+    int64_t lo = 0, hi = n;
     while (lo < hi) {
         const int64_t mid = (lo + hi) >> 1;
         if (part_sorted[mid] < p) lo = mid + 1; else hi = mid;
@@ -85,23 +491,172 @@ __global__ void k_emit_sems(const int64_t* __restrict__ part_sorted, const uint3
     out_vals[pos] = (double)p;
 }
 
-// The scratch of a build is ONE allocation carved into its twelve arrays: twelve hipMalloc + hipFree pairs cost ~2 ms of the 5.3 ms a
-// 10 M-triple orientation took.  (Stream-ordered allocation from the default pool — hipMallocAsync with a raised release
-// threshold — was tried for it: 4 ms builds most of the time, but stalls of 120-150 ms in hipMallocAsync or in the next plain
-// hipMalloc when the two orientations build side by side on two host threads.  Dropped.)
+// ---- host side ----------------------------------------------------------------------------------------------------------
+// The scratch of a build is ONE block from the caching allocator (pool.hip), carved into its arrays: a second build of the same
+// size finds it again without a driver call.
+// the pinned mirror of BuildCtl: a handful of them are kept (hipHostMalloc / hipHostFree cost more than a sort pass)
+static std::mutex g_pin_mu;
+static std::vector<void*> g_pin_free;
+static hipError_t pinned_ctl_get(void** out) {
+    {
+        std::lock_guard<std::mutex> lk(g_pin_mu);
+        if (!g_pin_free.empty()) { *out = g_pin_free.back(); g_pin_free.pop_back(); return hipSuccess; }
+    }
+    return hipHostMalloc(out, 256, hipHostMallocDefault);
+}
+static void pinned_ctl_put(void* p) {
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    if (g_pin_free.size() < 16) g_pin_free.push_back(p); else (void)hipHostFree(p);
+}
 static void free_scratch(BuildScratch& s) {
-    if (s.base) (void)hipFree(s.base);
+    if (s.base) pool_free(s.base);
+    if (s.h_ctl) pinned_ctl_put(s.h_ctl);
     s = BuildScratch();
 }
 
 #define BCHK(e) do { hipError_t _e = (e); if (_e != hipSuccess) { free_scratch(s); return _e; } } while (0)
 
-// Phase 1: sort + flags + scans.  d_part / d_key / d_val: the nnz input triples in HBM.
-// Returns the number of distinct cells and of partitions through counts[0..1] (host).  The scratch stays alive
-// for phase 2 (build_emit), which writes n_cells + n_parts stream cells.
-hipError_t build_prepare(const int64_t* d_part, const int64_t* d_key, int64_t nnz, BuildScratch& s, int64_t counts[2],
-                         hipStream_t stream) {
+static int bit_width_u64(uint64_t x) { int b = 0; while (x) { ++b; x >>= 1; } return b; }
+
+static hipError_t prepare_wide(const int64_t* d_part, const int64_t* d_key, int64_t nnz, BuildScratch& s, int64_t counts[2], hipStream_t stream);
+
+// value ranges and reserved-key check of two key arrays that are already in HBM (a and b: rows and columns of a triple stream): one
+// pass on the device instead of a host loop over arrays the host would otherwise not touch at all; synchronises the stream
+hipError_t device_key_scan(const int64_t* d_a, const int64_t* d_b, int64_t n, KeyRange* ra, KeyRange* rb, bool* a_zero, bool* b_zero,
+                           hipStream_t stream) {
+    *ra = KeyRange(); *rb = KeyRange(); *a_zero = *b_zero = false;
+    if (n <= 0) return hipSuccess;
+    void* base = nullptr; void* pin = nullptr;
+    hipError_t e = pool_alloc(&base, 256 + 4 * MM_BLOCKS * 8 + 64);
+    if (e != hipSuccess) return e;
+    e = pinned_ctl_get(&pin);
+    if (e != hipSuccess) { pool_free(base); return e; }
+    BuildCtl* dctl = static_cast<BuildCtl*>(base);
+    long long* partial = reinterpret_cast<long long*>(static_cast<char*>(base) + 256);
+    unsigned int* ticket = reinterpret_cast<unsigned int*>(partial + 4 * MM_BLOCKS);
+    e = hipMemsetAsync(ticket, 0, 2 * sizeof(unsigned int), stream);
+    if (e == hipSuccess) {
+        const int mm_blocks = (int)std::min<int64_t>(MM_BLOCKS, (n + 1023) / 1024);
+        hipLaunchKernelGGL(k_minmax, dim3(mm_blocks), dim3(256), 0, stream, d_a, d_b, n, dctl, partial, ticket);
+        e = hipMemcpyAsync(pin, dctl, sizeof(BuildCtl), hipMemcpyDeviceToHost, stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    if (e == hipSuccess) {
+        const BuildCtl* h = static_cast<const BuildCtl*>(pin);
+        ra->lo = h->pmin; ra->hi = h->pmax; rb->lo = h->kmin; rb->hi = h->kmax;
+        *a_zero = (h->zeros & 1ull) != 0; *b_zero = (h->zeros & 2ull) != 0;
+    }
+    pinned_ctl_put(pin);
+    pool_free(base);
+    return e;
+}
+
+// Phase 1: sort + flags + counts.  d_part / d_key / d_val: the nnz input triples in HBM (d_part == nullptr: a plain vector).
+// Returns the number of distinct cells and of partitions through counts[0..1] (host).  The scratch stays alive for phase 2
+// (build_emit), which writes counts[0] + #partitions stream cells.
+hipError_t build_prepare(const int64_t* d_part, const int64_t* d_key, const double* d_val, int64_t nnz, KeyRange part_range, KeyRange key_range,
+                         BuildScratch& s, int64_t counts[2], hipStream_t stream) {
+    s = BuildScratch();
     s.n = nnz; s.stream = stream;
+    const size_t n = (size_t)nnz;
+    static const bool force_wide = [] { const char* e = getenv("DSA_BUILD_WIDE"); return e && e[0] == '1'; }();
+    static const bool force_minmax = [] { const char* e = getenv("DSA_BUILD_MINMAX"); return e && e[0] == '1'; }();      // dev: ignore the caller's ranges
+    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const int64_t nblocks = (nnz + RS_TILE - 1) / RS_TILE;
+    BCHK(pinned_ctl_get(&s.h_ctl));
+    const size_t b_ctl = up(sizeof(BuildCtl)), b_gh = up(8 * RS_BINS * 4 + 4 * MM_BLOCKS * 8 + 64), b_comp = up(n * 8),
+                 b_hist = up((size_t)RS_BINS * nblocks * 4), b_cnt = up((size_t)(nblocks + 1) * 4),
+                 b_queue = up((n / FOLD_INLINE + 2) * sizeof(LongRun)), b_scell = up(n * 4);
+    BCHK(pool_alloc(&s.base, b_ctl + b_gh + 4 * b_comp + b_hist + 2 * b_cnt + b_queue + b_scell));
+    char* q = static_cast<char*>(s.base);
+    auto take = [&q](size_t b) { char* r = q; q += b; return r; };
+    s.d_ctl = take(b_ctl); s.ghist = (uint32_t*)take(b_gh);
+    s.comp[0] = (uint64_t*)take(b_comp); s.comp[1] = (uint64_t*)take(b_comp); s.val[0] = (double*)take(b_comp); s.val[1] = (double*)take(b_comp);
+    s.hist = (uint32_t*)take(b_hist); s.cnt_c = (uint32_t*)take(b_cnt); s.cnt_p = (uint32_t*)take(b_cnt);
+    s.queue = take(b_queue); s.scell = (uint32_t*)take(b_scell);
+    BuildCtl* dctl = static_cast<BuildCtl*>(s.d_ctl);
+    BuildCtl* hctl = static_cast<BuildCtl*>(s.h_ctl);
+    // ---- key ranges: how many bits the composite needs
+    if (!key_range.known() || (d_part != nullptr && !part_range.known()) || force_minmax) {
+        long long* partial = reinterpret_cast<long long*>(s.ghist + 8 * RS_BINS);
+        unsigned int* ticket = reinterpret_cast<unsigned int*>(partial + 4 * MM_BLOCKS);
+        BCHK(hipMemsetAsync(ticket, 0, 2 * sizeof(unsigned int), stream));
+        const int mm_blocks = (int)std::min<int64_t>(MM_BLOCKS, (nnz + 1023) / 1024);
+        hipLaunchKernelGGL(k_minmax, dim3(mm_blocks), dim3(256), 0, stream, d_part, d_key, nnz, dctl, partial, ticket);
+        BCHK(hipMemcpyAsync(hctl, dctl, sizeof(BuildCtl), hipMemcpyDeviceToHost, stream));
+        BCHK(hipStreamSynchronize(stream));
+        key_range.lo = hctl->kmin; key_range.hi = hctl->kmax;
+        if (d_part) { part_range.lo = hctl->pmin; part_range.hi = hctl->pmax; }
+    }
+    s.kmin = key_range.lo; s.pmin = d_part ? part_range.lo : 0;
+    s.kbits = std::max(1, bit_width_u64((uint64_t)key_range.hi - (uint64_t)key_range.lo));
+    s.pbits = d_part ? bit_width_u64((uint64_t)part_range.hi - (uint64_t)part_range.lo) : 0;
+    if (s.kbits + s.pbits > 64 || force_wide) {
+        free_scratch(s);
+        s.n = nnz; s.stream = stream; s.wide_path = true;
+        return prepare_wide(d_part, d_key, nnz, s, counts, stream);
+    }
+    // ---- the sort: passes over bits [0, kbits + pbits)
+    static PerDeviceOnce once;
+    const size_t lds_bytes = (size_t)RS_TILE * (sizeof(uint64_t) + sizeof(double));
+    BCHK(once.run([&] { return hipFuncSetAttribute(reinterpret_cast<const void*>(k_rs_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); }));
+    const int total_bits = s.kbits + s.pbits;
+    const int npass = (total_bits + 7) / 8;
+    const dim3 grid((unsigned)nblocks), block(RS_BLOCK);
+    int cur = 0;                                    // comp[cur] holds the current order; values: d_val before the first scatter
+    const double* vin = d_val;
+    for (int pass = 0; pass < npass; ++pass) {
+        const int shift = 8 * pass;
+        uint32_t* dtot = s.ghist + pass * RS_BINS;
+        if (pass == 0) hipLaunchKernelGGL(k_comp_hist, grid, block, 0, stream, s.pbits > 0 ? d_part : (const int64_t*)nullptr, d_key, nnz, s.pmin, s.kmin, s.kbits, s.comp[0], shift, s.hist, nblocks);
+        else hipLaunchKernelGGL(k_rs_hist, grid, block, 0, stream, (const uint64_t*)s.comp[cur], nnz, shift, s.hist, nblocks);
+        hipLaunchKernelGGL(k_rs_scan, dim3(RS_BINS), block, 0, stream, s.hist, dtot, nblocks);
+        hipLaunchKernelGGL(k_rs_scatter, grid, block, lds_bytes, stream, (const uint64_t*)s.comp[cur], vin, nnz, shift, (const uint32_t*)s.hist,
+                           (const uint32_t*)dtot, s.comp[1 - cur], s.val[1 - cur], nblocks);
+        cur = 1 - cur;
+        vin = s.val[cur];
+    }
+    s.sorted = cur;
+    s.vsorted = vin;
+    // ---- flags: per-tile counts of new cells / new partitions, their prefixes, the totals
+    hipLaunchKernelGGL(k_bf_count, grid, block, 0, stream, (const uint64_t*)s.comp[cur], nnz, s.kbits, d_part ? 1 : 0, s.cnt_c, s.cnt_p);
+    hipLaunchKernelGGL(k_bf_scan, dim3(1), dim3(1024), 0, stream, s.cnt_c, s.cnt_p, nblocks, dctl);
+    BCHK(hipMemcpyAsync(hctl, dctl, sizeof(BuildCtl), hipMemcpyDeviceToHost, stream));
+    BCHK(hipStreamSynchronize(stream));
+    counts[0] = (int64_t)hctl->ncells; counts[1] = (int64_t)hctl->nparts;
+    return hipGetLastError();
+}
+
+static hipError_t emit_wide(const double* d_val, int32_t combine, BuildScratch& s, KeyArr out_keys, double* out_vals, int64_t* part_keys, int mode,
+                            int64_t nparts_explicit, hipStream_t stream);
+
+hipError_t build_emit(const double* d_val, int32_t combine, BuildScratch& s, KeyArr out_keys, double* out_vals,
+                      int64_t* part_keys, int mode, int64_t nparts_explicit, hipStream_t stream) {
+    if (s.wide_path) return emit_wide(d_val, combine, s, out_keys, out_vals, part_keys, mode, nparts_explicit, stream);
+    const int64_t nblocks = (s.n + RS_TILE - 1) / RS_TILE;
+    BuildCtl* dctl = static_cast<BuildCtl*>(s.d_ctl);
+    const uint64_t* comp = s.comp[s.sorted];
+    hipLaunchKernelGGL(k_bf_emit, dim3((unsigned)nblocks), dim3(RS_BLOCK), 0, stream, comp, s.vsorted, s.n, s.kbits, s.pmin, s.kmin, mode, combine,
+                       (const uint32_t*)s.cnt_c, (const uint32_t*)s.cnt_p, out_keys, out_vals, part_keys, mode == 2 ? s.scell : (uint32_t*)nullptr,
+                       dctl, static_cast<LongRun*>(s.queue));
+    hipLaunchKernelGGL(k_fold_long, dim3(256), dim3(64), 0, stream, comp, s.vsorted, s.n, combine, (const BuildCtl*)dctl,
+                       (const LongRun*)s.queue, out_vals);
+    if (mode == 2 && nparts_explicit > 0)
+        hipLaunchKernelGGL(k_emit_sems, dim3((unsigned)((nparts_explicit + 255) / 256)), dim3(256), 0, stream, comp, s.kbits, s.pmin,
+                           (const uint32_t*)s.scell, s.n, nparts_explicit, out_keys, out_vals);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    free_scratch(s);
+    return e;
+}
+
+void build_abort(BuildScratch& s) {
+    if (s.stream) (void)hipStreamSynchronize(s.stream);
+    free_scratch(s);
+}
+
+// ---- general path, host side ----
+static hipError_t prepare_wide(const int64_t* d_part, const int64_t* d_key, int64_t nnz, BuildScratch& s, int64_t counts[2], hipStream_t stream) {
     const size_t n = (size_t)nnz;
     size_t t1 = 0, t2 = 0;
     BCHK(rocprim::radix_sort_pairs(nullptr, t1, d_key, s.k1, s.idx0, s.idx1, n, 0, 64, stream));
@@ -110,7 +665,7 @@ hipError_t build_prepare(const int64_t* d_part, const int64_t* d_key, int64_t nn
     {
         auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
         const size_t a4 = up(n * 4), a8 = up(n * 8);
-        BCHK(hipMalloc(&s.base, 7 * a4 + 4 * a8 + up(s.temp_bytes)));
+        BCHK(pool_alloc(&s.base, 7 * a4 + 4 * a8 + up(s.temp_bytes)));
         char* q = static_cast<char*>(s.base);
         auto take = [&q](size_t b) { char* r = q; q += b; return r; };
         s.idx0 = (uint32_t*)take(a4); s.idx1 = (uint32_t*)take(a4); s.idx2 = (uint32_t*)take(a4);
@@ -145,20 +700,18 @@ hipError_t build_prepare(const int64_t* d_part, const int64_t* d_key, int64_t nn
     return hipGetLastError();
 }
 
-hipError_t build_emit(const double* d_val, int32_t combine, BuildScratch& s, KeyArr out_keys, double* out_vals,
-                      int64_t* part_keys, int mode, int64_t nparts_explicit, hipStream_t stream) {
+static hipError_t emit_wide(const double* d_val, int32_t combine, BuildScratch& s, KeyArr out_keys, double* out_vals, int64_t* part_keys, int mode,
+                            int64_t nparts_explicit, hipStream_t stream) {
     const unsigned blocks = (unsigned)((s.n + 255) / 256);
-    hipLaunchKernelGGL(k_emit, dim3(blocks), dim3(256), 0, stream, mode == 1 ? (const int64_t*)nullptr : s.p2, s.k2, s.idx2, d_val,
+    hipLaunchKernelGGL(k_emit_wide, dim3(blocks), dim3(256), 0, stream, mode == 1 ? (const int64_t*)nullptr : s.p2, s.k2, s.idx2, d_val,
                        s.fpart, s.fcell, s.spart, s.scell, s.n, combine, out_keys, out_vals, part_keys, mode);
     if (mode == 2 && nparts_explicit > 0)
-        hipLaunchKernelGGL(k_emit_sems, dim3((unsigned)((nparts_explicit + 255) / 256)), dim3(256), 0, stream, s.p2, s.scell, s.n,
+        hipLaunchKernelGGL(k_emit_sems_wide, dim3((unsigned)((nparts_explicit + 255) / 256)), dim3(256), 0, stream, s.p2, s.scell, s.n,
                            nparts_explicit, out_keys, out_vals);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(stream);
     free_scratch(s);
     return e;
 }
-
-void build_abort(BuildScratch& s) { free_scratch(s); }
 
 }  // namespace dsa

@@ -258,17 +258,41 @@ hipError_t launch_widen_keys(const void* src32, void* dst64, int64_t n, hipStrea
 // clears occupancy bits of slots [from, to] (1-based, inclusive); from/to word-aligned or inside one word
 hipError_t launch_clear_occ(uint64_t* occ, int64_t from, int64_t to, hipStream_t stream);
 
+// ---- caching allocator for HBM blocks (pool.hip): the scratch of a bulk build and the slot buffers of a structure come from
+// here; a block handed back must not be referenced by work still in flight
+hipError_t pool_alloc(void** out, size_t bytes);
+void pool_free(void* p);
+void pool_trim(size_t keep_bytes);
+size_t pool_idle_bytes();
+hipError_t pinned_alloc(void** out, size_t bytes);      // pinned host blocks, kept by size class
+void pinned_free(void* p);
+hipError_t stream_get(hipStream_t* out);                // a non-blocking stream of the current device, kept when a handle dies
+void stream_put(hipStream_t s, int device);             // (the caller has synchronised it)
+
 // ---- K-build (build.hip): device bulk constructor of one orientation ---------------------------------------------
 struct BuildScratch {
     int64_t n = 0;
+    void* base = nullptr; hipStream_t stream = nullptr;      // the one block (pool.hip) all device arrays below are carved from
+    // composite path: comp = (partition - pmin) << kbits | (key - kmin), sorted with its value (build.hip)
+    void* d_ctl = nullptr; void* h_ctl = nullptr;            // BuildCtl on the device / its pinned mirror
+    uint32_t* ghist = nullptr; uint32_t* hist = nullptr; uint32_t* cnt_c = nullptr; uint32_t* cnt_p = nullptr;
+    uint64_t* comp[2] = {nullptr, nullptr}; double* val[2] = {nullptr, nullptr};
+    void* queue = nullptr;
+    int64_t kmin = 0, pmin = 0; int kbits = 0, pbits = 0, sorted = 0; const double* vsorted = nullptr;
+    // general path (composite wider than 64 bits)
+    bool wide_path = false;
     uint32_t *idx0 = nullptr, *idx1 = nullptr, *idx2 = nullptr, *fpart = nullptr, *fcell = nullptr, *spart = nullptr, *scell = nullptr;
     int64_t *k1 = nullptr, *p1 = nullptr, *p2 = nullptr, *k2 = nullptr;
     void* temp = nullptr; size_t temp_bytes = 0;
-    void* base = nullptr; hipStream_t stream = nullptr;      // the one allocation all of the above are carved from
 };
-// phase 1: sort by (partition, key, input order), flags, scans; counts[0] = distinct cells, counts[1] = partitions
-hipError_t build_prepare(const int64_t* d_part, const int64_t* d_key, int64_t nnz, BuildScratch& s, int64_t counts[2],
-                         hipStream_t stream);
+// bounds of the values of a key array (closed; need not be tight): they fix how many bits of the composite are sorted.  The host has
+// seen every key it uploads (it scans them for their storage width anyway); unknown() ranges cost one min / max pass on the device.
+struct KeyRange { int64_t lo = 0, hi = -1; bool known() const { return hi >= lo; } };
+hipError_t device_key_scan(const int64_t* d_a, const int64_t* d_b, int64_t n, KeyRange* ra, KeyRange* rb, bool* a_zero, bool* b_zero,
+                           hipStream_t stream);
+// phase 1: sort by (partition, key, input order), flags, counts; counts[0] = distinct cells, counts[1] = partitions
+hipError_t build_prepare(const int64_t* d_part, const int64_t* d_key, const double* d_val, int64_t nnz, KeyRange part_range, KeyRange key_range,
+                         BuildScratch& s, int64_t counts[2], hipStream_t stream);
 // phase 2: emit the ordered cell stream [sem(0,id), entries...] (counts[0]+counts[1] cells) and the partition keys
 // mode 0: mapped partitions (semaphores + partition keys) ; 1: plain vector (d_part was nullptr) ; 2: explicit partition
 // ids 1..nparts_explicit in d_part (PackedCSC: empty partitions keep their semaphore)

@@ -115,9 +115,7 @@ struct Pma {
 
 void pma_free_buffers(Pma& P) {
     for (int b = 0; b < 2; ++b) {
-        if (P.keys[b]) hipFree(P.keys[b]);
-        if (P.vals[b]) hipFree(P.vals[b]);
-        if (P.occ[b]) hipFree(P.occ[b]);
+        pool_free(P.keys[b]); pool_free(P.vals[b]); pool_free(P.occ[b]);     // (the caller has synchronised the stream)
         P.keys[b] = nullptr; P.vals[b] = nullptr; P.occ[b] = nullptr;
     }
     if (P.work.tile_cnt) hipFree(P.work.tile_cnt);
@@ -134,14 +132,12 @@ void pma_free_buffers(Pma& P) {
 void pma_destroy(Pma& P) {
     if (P.stream) hipStreamSynchronize(P.stream);
     pma_free_buffers(P);
-    if (P.sems) hipFree(P.sems);
-    if (P.col_keys) hipFree(P.col_keys);
-    if (P.col_live) hipFree(P.col_live);
-    if (P.d_ctl) hipFree(P.d_ctl);
-    if (P.h_ctl) hipHostFree(P.h_ctl);
+    pool_free(P.sems); pool_free(P.col_keys); pool_free(P.col_live);
+    pool_free(P.d_ctl);
+    pinned_free(P.h_ctl);
     if (P.d_ops) hipFree(P.d_ops);
     if (P.d_q) hipFree(P.d_q);
-    if (P.d_err) hipFree(P.d_err);
+    pool_free(P.d_err);
     burst_graph_destroy(&P.burst);
     burst_graph_destroy(&P.burst_short);
     if (P.d_plans) hipFree(P.d_plans);
@@ -149,8 +145,8 @@ void pma_destroy(Pma& P) {
     if (P.h_bufs) hipHostFree(P.h_bufs);
     if (P.d_rs) hipFree(P.d_rs);
     if (P.h_rs) hipHostFree(P.h_rs);
-    if (P.d_small) hipFree(P.d_small);
-    if (P.h_small) hipHostFree(P.h_small);
+    pool_free(P.d_small);
+    pinned_free(P.h_small);
     if (P.d_meta) hipFree(P.d_meta);
     if (P.h_meta) hipHostFree(P.h_meta);
     if (P.meta_ev) hipEventDestroy(P.meta_ev);
@@ -161,7 +157,7 @@ void pma_destroy(Pma& P) {
     if (P.run_flags) hipFree(P.run_flags);
     if (P.run_out) hipFree(P.run_out);
     if (P.run_memo) hipFree(P.run_memo);
-    if (P.own_stream && P.stream) hipStreamDestroy(P.stream);
+    if (P.own_stream && P.stream) stream_put(P.stream, P.device);      // synchronised at the top of this function
     P = Pma();
 }
 
@@ -191,16 +187,32 @@ bool keys_fit32(const int64_t* k, int64_t n) {
     return true;
 }
 
+// one pass over a key array the host is about to upload: value range (what K-build's composite needs), storage width, the reserved key
+struct KeyScan {
+    int64_t lo = INT64_MAX, hi = INT64_MIN; bool zero = false;
+    void add(int64_t k) { lo = k < lo ? k : lo; hi = k > hi ? k : hi; zero = zero || k == 0; }
+    void add(const int64_t* k, int64_t n) {
+        int64_t l = lo, h = hi; bool z = zero;
+        for (int64_t i = 0; i < n; ++i) { const int64_t v = k[i]; l = v < l ? v : l; h = v > h ? v : h; z |= v == 0; }
+        lo = l; hi = h; zero = z;
+    }
+    bool empty() const { return hi < lo; }
+    bool fit32() const { return !g_force_wide && (empty() || (key_fits32(lo) && key_fits32(hi))); }
+    KeyRange range() const { KeyRange r; if (!empty()) { r.lo = lo; r.hi = hi; } return r; }
+};
+
 int64_t occ_words_for(int64_t slots) {
     const int64_t w = (slots + 63) / 64;
     return ((w + 63) / 64) * 64;      // whole 64-word tiles (k_tile_count / k_move read lane <-> word)
 }
 
+// slot buffers come from the caching allocator (pool.hip): a structure built after another one of the same size was destroyed
+// finds its ~100 MB blocks again without a driver call
 void alloc_one_buffer(Pma& P, int b, int64_t slots) {
-    HIPCHK(hipMalloc(&P.keys[b], (size_t)slots * P.kb()));
-    HIPCHK(hipMalloc(&P.vals[b], (size_t)slots * sizeof(double)));
+    HIPCHK(pool_alloc(&P.keys[b], (size_t)slots * P.kb()));
+    HIPCHK(pool_alloc(reinterpret_cast<void**>(&P.vals[b]), (size_t)slots * sizeof(double)));
     const int64_t words = occ_words_for(slots);
-    HIPCHK(hipMalloc(&P.occ[b], (size_t)words * sizeof(uint64_t)));
+    HIPCHK(pool_alloc(reinterpret_cast<void**>(&P.occ[b]), (size_t)words * sizeof(uint64_t)));
     HIPCHK(hipMemsetAsync(P.occ[b], 0, (size_t)words * sizeof(uint64_t), P.stream));
 }
 
@@ -226,15 +238,17 @@ void bind_device(const Pma& P) { HIPCHK(hipSetDevice(P.device)); }
 void pma_init_common(Pma& P, bool sems, bool cols) {
     HIPCHK(hipSetDevice(g_device));
     P.device = g_device;
-    HIPCHK(hipStreamCreateWithFlags(&P.stream, hipStreamNonBlocking));
+    // stream, control blocks and landing areas come from the caches of pool.hip: a handle is created without a driver call once
+    // another one has died (0.5 ms per PMA otherwise: two per matrix, inside every closefillmode! / dynamicsparse)
+    HIPCHK(stream_get(&P.stream));
     P.own_stream = true;
     P.has_sems = sems; P.has_cols = cols;
-    HIPCHK(hipMalloc(&P.d_ctl, sizeof(Ctl)));
-    HIPCHK(hipHostMalloc(&P.h_ctl, sizeof(Ctl), hipHostMallocDefault));
+    HIPCHK(pool_alloc(reinterpret_cast<void**>(&P.d_ctl), sizeof(Ctl)));
+    HIPCHK(pinned_alloc(reinterpret_cast<void**>(&P.h_ctl), sizeof(Ctl)));
     std::memset(P.h_ctl, 0, sizeof(Ctl));
-    HIPCHK(hipMalloc(&P.d_err, sizeof(int32_t)));
-    HIPCHK(hipMalloc(&P.d_small, 8 * sizeof(int64_t)));
-    HIPCHK(hipHostMalloc(&P.h_small, 8 * sizeof(int64_t), hipHostMallocDefault));
+    HIPCHK(pool_alloc(reinterpret_cast<void**>(&P.d_err), sizeof(int32_t)));
+    HIPCHK(pool_alloc(reinterpret_cast<void**>(&P.d_small), 8 * sizeof(int64_t)));
+    HIPCHK(pinned_alloc(reinterpret_cast<void**>(&P.h_small), 8 * sizeof(int64_t)));
 }
 
 void ensure_tables(Pma& P, int64_t need) {
@@ -243,13 +257,13 @@ void ensure_tables(Pma& P, int64_t need) {
     int64_t ncap = std::max<int64_t>(1024, P.h_ctl->table_cap * 4);
     while (ncap < need) ncap *= 4;
     int64_t* ns = nullptr; int64_t* nk = nullptr; uint8_t* nl = nullptr;
-    HIPCHK(hipMalloc(&ns, (size_t)ncap * sizeof(int64_t)));
+    HIPCHK(pool_alloc(reinterpret_cast<void**>(&ns), (size_t)ncap * sizeof(int64_t)));
     HIPCHK(hipMemsetAsync(ns, 0, (size_t)ncap * sizeof(int64_t), P.stream));
     const int64_t len = P.h_ctl->table_len;
     if (P.sems && len > 0) HIPCHK(hipMemcpyAsync(ns, P.sems, (size_t)len * sizeof(int64_t), hipMemcpyDeviceToDevice, P.stream));
     if (P.has_cols) {
-        HIPCHK(hipMalloc(&nk, (size_t)ncap * sizeof(int64_t)));
-        HIPCHK(hipMalloc(&nl, (size_t)ncap));
+        HIPCHK(pool_alloc(reinterpret_cast<void**>(&nk), (size_t)ncap * sizeof(int64_t)));
+        HIPCHK(pool_alloc(reinterpret_cast<void**>(&nl), (size_t)ncap));
         HIPCHK(hipMemsetAsync(nk, 0, (size_t)ncap * sizeof(int64_t), P.stream));
         HIPCHK(hipMemsetAsync(nl, 0, (size_t)ncap, P.stream));
         if (P.col_keys && len > 0) {
@@ -258,9 +272,7 @@ void ensure_tables(Pma& P, int64_t need) {
         }
     }
     HIPCHK(hipStreamSynchronize(P.stream));
-    if (P.sems) hipFree(P.sems);
-    if (P.col_keys) hipFree(P.col_keys);
-    if (P.col_live) hipFree(P.col_live);
+    pool_free(P.sems); pool_free(P.col_keys); pool_free(P.col_live);
     P.sems = ns; P.col_keys = nk; P.col_live = nl;
     P.h_ctl->table_cap = ncap;
 }
@@ -322,7 +334,7 @@ void ensure_capacity_alloc(Pma& P, int64_t slots) {
         HIPCHK(hipMemcpyAsync(P.occ[P.cur], oo[P.cur], (size_t)old_words * sizeof(uint64_t), hipMemcpyDeviceToDevice, P.stream));
     }
     HIPCHK(hipStreamSynchronize(P.stream));
-    for (int b = 0; b < 2; ++b) { if (ok[b]) hipFree(ok[b]); if (ov[b]) hipFree(ov[b]); if (oo[b]) hipFree(oo[b]); }
+    for (int b = 0; b < 2; ++b) { pool_free(ok[b]); pool_free(ov[b]); pool_free(oo[b]); }
     P.occ_dirty[1 - P.cur] = 0;                       // fresh, zero-filled; occ_dirty[cur] keeps its value
     P.cap_alloc = n;
     P.occ_words = occ_words_for(n);
@@ -428,13 +440,13 @@ void widen_keys(Pma& P) {
     if (P.wide) return;
     HIPCHK(hipStreamSynchronize(P.stream));
     void* old[2] = {P.keys[0], P.keys[1]};
-    for (int b = 0; b < 2; ++b) { P.keys[b] = nullptr; if (P.cap_alloc > 0) HIPCHK(hipMalloc(&P.keys[b], (size_t)P.cap_alloc * sizeof(int64_t))); }
+    for (int b = 0; b < 2; ++b) { P.keys[b] = nullptr; if (P.cap_alloc > 0) HIPCHK(pool_alloc(&P.keys[b], (size_t)P.cap_alloc * sizeof(int64_t))); }
     if (P.cap_alloc > 0 && old[P.cur] != nullptr) {
         hipError_t e = launch_widen_keys(old[P.cur], P.keys[P.cur], P.cap_alloc, P.stream);
         if (e != hipSuccess) fail(DSA_EHIP, std::string("widen launch: ") + hipGetErrorString(e));
         HIPCHK(hipStreamSynchronize(P.stream));
     }
-    for (int b = 0; b < 2; ++b) if (old[b]) hipFree(old[b]);
+    for (int b = 0; b < 2; ++b) pool_free(old[b]);
     P.wide = true;
 }
 void ensure_key_width(Pma& P, const std::vector<Op>& ops) {
@@ -833,7 +845,7 @@ void read_range(Pma& P, int64_t from, int64_t to, std::vector<int64_t>& ks, std:
 //   mode 1: a vector (d_part == nullptr, no semaphores)         dynamicsparsevec  src/vector.jl:38-62
 //   mode 2: PackedCSC with explicit partition ids 1..nparts      PackedCSC ctor    src/pcsr.jl:26-63
 void pma_build_dev(Pma& P, const int64_t* d_part, const int64_t* d_key, const double* d_val, int64_t nnz, int32_t combine,
-                   int mode, int64_t nparts_explicit, bool wide) {
+                   int mode, int64_t nparts_explicit, bool wide, KeyRange part_range = KeyRange(), KeyRange key_range = KeyRange()) {
     P.wide = wide;                     // decided by the caller from the host copy of the keys, before anything is allocated
     // fault injection for the error paths of the builders (tests): DSA_FAIL_BUILD=1 fails every build while it is set
     if (const char* fe = getenv("DSA_FAIL_BUILD")) if (fe[0] == '1') fail(DSA_EHIP, "injected build failure (DSA_FAIL_BUILD)");
@@ -849,7 +861,7 @@ void pma_build_dev(Pma& P, const int64_t* d_part, const int64_t* d_key, const do
     int64_t counts[2] = {0, 0};
     static const bool dbg_time = getenv("DSA_DBG_TIME") != nullptr;
     const auto tp0 = std::chrono::steady_clock::now();
-    hipError_t e = build_prepare(d_part, d_key, nnz, sc, counts, P.stream);
+    hipError_t e = build_prepare(d_part, d_key, d_val, nnz, part_range, key_range, sc, counts, P.stream);
     const auto tp1 = std::chrono::steady_clock::now();
     if (e != hipSuccess) fail(DSA_EHIP, std::string("K-build prepare: ") + hipGetErrorString(e));
     const int64_t np = mode == 0 ? counts[1] : (mode == 2 ? nparts_explicit : 0);
@@ -884,23 +896,24 @@ void pma_build_dev(Pma& P, const int64_t* d_part, const int64_t* d_key, const do
 void pma_build_from_host(Pma& P, const int64_t* part, const int64_t* key, const double* val, int64_t nnz, int32_t combine,
                          int mode, int64_t nparts_explicit) {
     int64_t *dP = nullptr, *dK = nullptr; double* dV = nullptr;
+    auto release = [&] { pool_free(dP); pool_free(dK); pool_free(dV); };
     try {
         if (nnz > 0) {
-            if (part) { HIPCHK(hipMalloc(&dP, (size_t)nnz * 8)); HIPCHK(hipMemcpyAsync(dP, part, (size_t)nnz * 8, hipMemcpyHostToDevice, P.stream)); }
-            HIPCHK(hipMalloc(&dK, (size_t)nnz * 8)); HIPCHK(hipMemcpyAsync(dK, key, (size_t)nnz * 8, hipMemcpyHostToDevice, P.stream));
-            HIPCHK(hipMalloc(&dV, (size_t)nnz * 8)); HIPCHK(hipMemcpyAsync(dV, val, (size_t)nnz * 8, hipMemcpyHostToDevice, P.stream));
+            if (part) { HIPCHK(pool_alloc(reinterpret_cast<void**>(&dP), (size_t)nnz * 8)); HIPCHK(hipMemcpyAsync(dP, part, (size_t)nnz * 8, hipMemcpyHostToDevice, P.stream)); }
+            HIPCHK(pool_alloc(reinterpret_cast<void**>(&dK), (size_t)nnz * 8)); HIPCHK(hipMemcpyAsync(dK, key, (size_t)nnz * 8, hipMemcpyHostToDevice, P.stream));
+            HIPCHK(pool_alloc(reinterpret_cast<void**>(&dV), (size_t)nnz * 8)); HIPCHK(hipMemcpyAsync(dV, val, (size_t)nnz * 8, hipMemcpyHostToDevice, P.stream));
             HIPCHK(hipStreamSynchronize(P.stream));
         }
-        pma_build_dev(P, dP, dK, dV, nnz, combine, mode, nparts_explicit, !keys_fit32(key, nnz));
+        KeyScan ks; ks.add(key, nnz);                        // (runs while the uploads above are in flight when they are asynchronous)
+        KeyRange pr;
+        if (part && mode == 2) { pr.lo = 1; pr.hi = std::max<int64_t>(nparts_explicit, 1); }
+        pma_build_dev(P, dP, dK, dV, nnz, combine, mode, nparts_explicit, !ks.fit32(), pr, ks.range());
     } catch (...) {
-        if (dP) hipFree(dP);
-        if (dK) hipFree(dK);
-        if (dV) hipFree(dV);
+        (void)hipStreamSynchronize(P.stream);
+        release();
         throw;
     }
-    if (dP) hipFree(dP);
-    if (dK) hipFree(dK);
-    if (dV) hipFree(dV);
+    release();
 }
 
 }  // namespace
@@ -921,6 +934,7 @@ struct dsa_pcsc { Pma P; };
 // builder, duplicates of (i, j) are accumulated with + at the flush like the reference (test/functional/sparsematrix.jl:433-437).
 struct FillBuffer {
     static constexpr int64_t CHUNK = 1 << 20;            // triples per pinned staging chunk (24 MB)
+    static constexpr int64_t EAGER = 1 << 16;            // a finished batch ships its staged triples at once from this many on
     std::vector<uint64_t> row_bits;                       // rows 1 .. 2^28 already written (one bit each, grown on demand)
     std::unordered_set<int64_t> rows_far;                 // ... and the others
     int64_t* hI[2] = {nullptr, nullptr}; int64_t* hJ[2] = {nullptr, nullptr}; double* hV[2] = {nullptr, nullptr};
@@ -932,7 +946,6 @@ struct FillBuffer {
     int64_t dcap = 0, dlen = 0;                           // triples allocated / resident in HBM
     hipStream_t stream = nullptr;
     int64_t length = 0;
-    bool fit32_rows = true, fit32_cols = true;
     int device = 0;
 };
 static inline bool fill_row_test_and_set(FillBuffer& b, int64_t row) {
@@ -964,10 +977,8 @@ static void fill_release(FillBuffer& b) {
         if (b.hV[k]) hipHostFree(b.hV[k]);
         if (b.uploaded[k]) hipEventDestroy(b.uploaded[k]);
     }
-    if (b.dI) hipFree(b.dI);
-    if (b.dJ) hipFree(b.dJ);
-    if (b.dV) hipFree(b.dV);
-    if (b.stream) hipStreamDestroy(b.stream);
+    pool_free(b.dI); pool_free(b.dJ); pool_free(b.dV);
+    if (b.stream) stream_put(b.stream, b.device);
     b = FillBuffer();
 }
 struct dsa_mat {
@@ -987,12 +998,15 @@ namespace {
 
 // both orientations from (row, col, value) triples that are ALREADY in HBM (they stay the caller's): dynamicsparse(I, J, V) after its
 // upload, closefillmode! straight from the device-resident fill buffer.  On failure nothing of the two structures is left behind.
-void mat_build_major_dev(dsa_mat* h, const int64_t* dI, const int64_t* dJ, const double* dV, int64_t nnz, bool wide_rows, bool wide_cols) {
+void mat_build_major_dev(dsa_mat* h, const int64_t* dI, const int64_t* dJ, const double* dV, int64_t nnz, bool wide_rows, bool wide_cols,
+                         KeyRange rows = KeyRange(), KeyRange cols = KeyRange()) {
     try {
+        static const bool dbg_time = getenv("DSA_DBG_TIME") != nullptr;
+        const auto ti0 = std::chrono::steady_clock::now();
         pma_init_common(h->col, true, true);
         pma_init_common(h->row, true, true);
-        static const bool dbg_time = getenv("DSA_DBG_TIME") != nullptr;
         const auto tb0 = std::chrono::steady_clock::now();
+        if (dbg_time) fprintf(stderr, "[mat_build_major] handles (streams, control blocks) %.2f ms\n", std::chrono::duration<double, std::milli>(tb0 - ti0).count());
         // the two orientations are independent structures on their own streams and both only read the triples: built side by side
         // (the rowmajor one on a helper thread; each build waits once for its cell / partition counts)
         std::exception_ptr row_exc;
@@ -1000,14 +1014,14 @@ void mat_build_major_dev(dsa_mat* h, const int64_t* dI, const int64_t* dJ, const
         const bool side_by_side = h->col.stream != h->row.stream && nnz > 0;
         if (side_by_side)
             row_thread = std::thread([&] {
-                try { bind_device(h->row); pma_build_dev(h->row, dI, dJ, dV, nnz, DSA_COMBINE_ADD, 0, 0, wide_cols); }
+                try { bind_device(h->row); pma_build_dev(h->row, dI, dJ, dV, nnz, DSA_COMBINE_ADD, 0, 0, wide_cols, rows, cols); }
                 catch (...) { row_exc = std::current_exception(); }
             });
-        try { pma_build_dev(h->col, dJ, dI, dV, nnz, DSA_COMBINE_ADD, 0, 0, wide_rows); }      // dynamicsparsecolmajor(I, J, V): partitions = columns, keys = rows
+        try { pma_build_dev(h->col, dJ, dI, dV, nnz, DSA_COMBINE_ADD, 0, 0, wide_rows, cols, rows); }      // dynamicsparsecolmajor(I, J, V): partitions = columns, keys = rows
         catch (...) { if (row_thread.joinable()) row_thread.join(); throw; }
         const auto tb1 = std::chrono::steady_clock::now();
         if (side_by_side) { row_thread.join(); if (row_exc) std::rethrow_exception(row_exc); }
-        else pma_build_dev(h->row, dI, dJ, dV, nnz, DSA_COMBINE_ADD, 0, 0, wide_cols);      // dynamicsparsecolmajor(J, I, V): partitions = rows, keys = columns
+        else pma_build_dev(h->row, dI, dJ, dV, nnz, DSA_COMBINE_ADD, 0, 0, wide_cols, rows, cols);      // dynamicsparsecolmajor(J, I, V): partitions = rows, keys = columns
         if (dbg_time)
             fprintf(stderr, "[mat_build_major] nnz=%lld colmajor %.1f ms  rowmajor %.1f ms\n", (long long)nnz,
                     std::chrono::duration<double, std::milli>(tb1 - tb0).count(),
@@ -1021,43 +1035,38 @@ void mat_build_major_dev(dsa_mat* h, const int64_t* dI, const int64_t* dJ, const
     h->has_major = true;
 }
 
-void mat_build_major(dsa_mat* h, const int64_t* I, const int64_t* J, const double* V, int64_t nnz) {
+void check_key(int64_t k) { if (k == 0) fail(DSA_EKEY, "0 is the reserved semaphore key (src/pcsr.jl:23)"); }
+
+// dynamicsparse(I, J, V): upload + both builds; *rows_out / *cols_out receive the value ranges of the keys
+void mat_build_major(dsa_mat* h, const int64_t* I, const int64_t* J, const double* V, int64_t nnz, KeyRange* rows_out = nullptr, KeyRange* cols_out = nullptr) {
     int64_t *dI = nullptr, *dJ = nullptr; double* dV = nullptr;
     const auto tup0 = std::chrono::steady_clock::now();
     HIPCHK(hipSetDevice(g_device));
-    // the key-width scans of the caller's arrays (80 MB each at config 3: ~5 ms apiece) run on a helper thread under the upload
-    bool wide_rows = false, wide_cols = false;
-    std::thread scan([&] { wide_rows = !keys_fit32(I, nnz); wide_cols = !keys_fit32(J, nnz); });
-    struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{scan};
     try {
+        KeyRange rows, cols;
+        bool zr = false, zc = false;
         if (nnz > 0) {
-            HIPCHK(hipMalloc(&dI, (size_t)nnz * sizeof(int64_t)));
-            HIPCHK(hipMalloc(&dJ, (size_t)nnz * sizeof(int64_t)));
-            HIPCHK(hipMalloc(&dV, (size_t)nnz * sizeof(double)));
+            HIPCHK(pool_alloc(reinterpret_cast<void**>(&dI), (size_t)nnz * sizeof(int64_t)));
+            HIPCHK(pool_alloc(reinterpret_cast<void**>(&dJ), (size_t)nnz * sizeof(int64_t)));
+            HIPCHK(pool_alloc(reinterpret_cast<void**>(&dV), (size_t)nnz * sizeof(double)));
             HIPCHK(hipMemcpy(dI, I, (size_t)nnz * sizeof(int64_t), hipMemcpyHostToDevice));
             HIPCHK(hipMemcpy(dJ, J, (size_t)nnz * sizeof(int64_t), hipMemcpyHostToDevice));
             HIPCHK(hipMemcpy(dV, V, (size_t)nnz * sizeof(double), hipMemcpyHostToDevice));
+            // value ranges (K-build's composite, the storage width of the keys, the size guesses) and the reserved key 0: one pass on
+            // the device over the arrays just uploaded — the host never loops over the caller's 10^7 keys
+            hipError_t e = device_key_scan(dI, dJ, nnz, &rows, &cols, &zr, &zc, nullptr);
+            if (e != hipSuccess) fail(DSA_EHIP, std::string("key scan: ") + hipGetErrorString(e));
         }
-    } catch (...) {
-        if (dI) hipFree(dI);
-        if (dJ) hipFree(dJ);
-        if (dV) hipFree(dV);
-        throw;
-    }
-    static const bool dbg_time = getenv("DSA_DBG_TIME") != nullptr;
-    if (dbg_time) fprintf(stderr, "[mat_build_major] upload of %lld triples from caller memory %.1f ms\n", (long long)nnz,
-                          std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tup0).count());
-    scan.join();
-    try { mat_build_major_dev(h, dI, dJ, dV, nnz, wide_rows, wide_cols); }
-    catch (...) {
-        if (dI) hipFree(dI);
-        if (dJ) hipFree(dJ);
-        if (dV) hipFree(dV);
-        throw;
-    }
-    if (dI) hipFree(dI);
-    if (dJ) hipFree(dJ);
-    if (dV) hipFree(dV);
+        static const bool dbg_time = getenv("DSA_DBG_TIME") != nullptr;
+        if (dbg_time) fprintf(stderr, "[mat_build_major] upload of %lld triples from caller memory + key scan %.1f ms\n", (long long)nnz,
+                              std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tup0).count());
+        if (rows_out) *rows_out = rows;
+        if (cols_out) *cols_out = cols;
+        if (zr || zc) check_key(0);
+        auto fit32 = [](const KeyRange& r) { return !g_force_wide && (!r.known() || (key_fits32(r.lo) && key_fits32(r.hi))); };
+        mat_build_major_dev(h, dI, dJ, dV, nnz, !fit32(rows), !fit32(cols), rows, cols);
+    } catch (...) { pool_free(dI); pool_free(dJ); pool_free(dV); throw; }      // (a failed build has synchronised and destroyed its streams)
+    pool_free(dI); pool_free(dJ); pool_free(dV);
 }
 
 Pma& orient(dsa_mat* h, int32_t o) {
@@ -1065,8 +1074,6 @@ Pma& orient(dsa_mat* h, int32_t o) {
     if (o != DSA_COLMAJOR && o != DSA_ROWMAJOR) fail(DSA_EARG, "orientation must be 0 or 1");
     return o == DSA_COLMAJOR ? h->col : h->row;
 }
-
-void check_key(int64_t k) { if (k == 0) fail(DSA_EKEY, "0 is the reserved semaphore key (src/pcsr.jl:23)"); }
 
 Op make_op(int32_t kind, int64_t a, int64_t b, double v) { Op o; o.a = a; o.b = b; o.v = v; o.kind = kind; o.pad = 0; return o; }
 
@@ -1511,7 +1518,7 @@ int32_t dsa_vec_set_stream(dsa_vec_t* h, void* s) {
     API_TRY
     vec_flush(h);
     HIPCHK(hipStreamSynchronize(h->P.stream));
-    if (h->P.own_stream) hipStreamDestroy(h->P.stream);
+    if (h->P.own_stream) stream_put(h->P.stream, h->P.device);
     h->P.stream = (hipStream_t)s; h->P.own_stream = false;
     API_CATCH
 }
@@ -1587,11 +1594,11 @@ int32_t dsa_mat_create_from_coo(const int64_t* I, const int64_t* J, const double
     API_TRY
     if (nnz < 0) fail(DSA_EARG, "negative length");
     if (nnz > 0xffffffffll) fail(DSA_EARG, "more than 2^32-1 triples in one call");
-    for (int64_t k = 0; k < nnz; ++k) { check_key(I[k]); check_key(J[k]); }
-    if (m < 0) { m = 0; for (int64_t k = 0; k < nnz; ++k) m = std::max(m, I[k]); }
-    if (n < 0) { n = 0; for (int64_t k = 0; k < nnz; ++k) n = std::max(n, J[k]); }
     auto* h = new dsa_mat();
-    try { mat_build_major(h, I, J, V, nnz); mat_prefetch_spmv_meta(h); } catch (...) { pma_destroy(h->col); pma_destroy(h->row); delete h; throw; }
+    KeyRange rows, cols;
+    try { mat_build_major(h, I, J, V, nnz, &rows, &cols); mat_prefetch_spmv_meta(h); } catch (...) { pma_destroy(h->col); pma_destroy(h->row); delete h; throw; }
+    if (m < 0) m = rows.known() ? std::max<int64_t>(0, rows.hi) : 0;        // _guess_length  src/vector.jl:6
+    if (n < 0) n = cols.known() ? std::max<int64_t>(0, cols.hi) : 0;
     h->m = m; h->n = n;
     *out = h;
     API_CATCH
@@ -1657,7 +1664,7 @@ static void fill_init(FillBuffer& b) {
     if (b.stream) return;
     HIPCHK(hipSetDevice(g_device));
     b.device = g_device;
-    HIPCHK(hipStreamCreateWithFlags(&b.stream, hipStreamNonBlocking));
+    HIPCHK(stream_get(&b.stream));
     {
         std::lock_guard<std::mutex> lk(g_fill_cache.mu);
         if (g_fill_cache.hI[0] != nullptr && g_fill_cache.device == b.device)
@@ -1678,18 +1685,16 @@ static void fill_upload_chunk(FillBuffer& b) {
     if (b.dlen + b.fill > b.dcap) {          // grow geometrically: new arrays, device-to-device copy of what is resident
         const int64_t ncap = std::max<int64_t>(2 * b.dcap, std::max<int64_t>(b.dlen + b.fill, 4 * FillBuffer::CHUNK));
         int64_t *nI = nullptr, *nJ = nullptr; double* nV = nullptr;
-        HIPCHK(hipMalloc(&nI, (size_t)ncap * sizeof(int64_t)));
-        HIPCHK(hipMalloc(&nJ, (size_t)ncap * sizeof(int64_t)));
-        HIPCHK(hipMalloc(&nV, (size_t)ncap * sizeof(double)));
+        HIPCHK(pool_alloc(reinterpret_cast<void**>(&nI), (size_t)ncap * sizeof(int64_t)));
+        HIPCHK(pool_alloc(reinterpret_cast<void**>(&nJ), (size_t)ncap * sizeof(int64_t)));
+        HIPCHK(pool_alloc(reinterpret_cast<void**>(&nV), (size_t)ncap * sizeof(double)));
         if (b.dlen > 0) {
             HIPCHK(hipMemcpyAsync(nI, b.dI, (size_t)b.dlen * sizeof(int64_t), hipMemcpyDeviceToDevice, b.stream));
             HIPCHK(hipMemcpyAsync(nJ, b.dJ, (size_t)b.dlen * sizeof(int64_t), hipMemcpyDeviceToDevice, b.stream));
             HIPCHK(hipMemcpyAsync(nV, b.dV, (size_t)b.dlen * sizeof(double), hipMemcpyDeviceToDevice, b.stream));
         }
         HIPCHK(hipStreamSynchronize(b.stream));       // earlier uploads into the old arrays have landed
-        if (b.dI) hipFree(b.dI);
-        if (b.dJ) hipFree(b.dJ);
-        if (b.dV) hipFree(b.dV);
+        pool_free(b.dI); pool_free(b.dJ); pool_free(b.dV);
         b.dI = nI; b.dJ = nJ; b.dV = nV; b.dcap = ncap;
     }
     const int c = b.cur;
@@ -1706,10 +1711,6 @@ static void fill_upload_chunk(FillBuffer& b) {
 // addelem!  src/buffer.jl:20-31 for n entries (n = 1: one setindex! in fill mode)
 static void fill_append(FillBuffer& b, const int64_t* I, const int64_t* J, const double* V, int64_t n) {
     fill_init(b);
-    for (int64_t k = 0; k < n; ++k) {
-        b.fit32_rows = b.fit32_rows && key_fits32(I[k]);
-        b.fit32_cols = b.fit32_cols && key_fits32(J[k]);
-    }
     int64_t k = 0;
     while (k < n) {
         const int64_t room = FillBuffer::CHUNK - b.fill;
@@ -1720,6 +1721,9 @@ static void fill_append(FillBuffer& b, const int64_t* I, const int64_t* J, const
         b.fill += take; k += take;
         if (b.fill == FillBuffer::CHUNK) fill_upload_chunk(b);
     }
+    // a batch of appends has ended: what is staged goes up now (asynchronously), so that closefillmode! finds almost nothing left
+    // in pinned memory — single-element appends (setindex! in fill mode) only ship whole quarter chunks
+    if (b.fill >= (n > 1 ? FillBuffer::EAGER : FillBuffer::CHUNK / 4)) fill_upload_chunk(b);
     b.length += n;
 }
 
@@ -1802,18 +1806,35 @@ int32_t dsa_mat_closefillmode(dsa_mat_t* h) {     // closefillmode!  src/matrix.
     FillBuffer& b = h->buf;
     int64_t nnz = 0;
     bool wr = false, wc = false;
+    static const bool dbg_time = getenv("DSA_DBG_TIME") != nullptr;
+    const auto tc0 = std::chrono::steady_clock::now();
     if (b.stream) {
         fill_upload_chunk(b);
         HIPCHK(hipStreamSynchronize(b.stream));
         nnz = b.dlen;
-        wr = !b.fit32_rows; wc = !b.fit32_cols;
+    }
+    // value ranges of everything appended (K-build's composite, the storage width of the keys): one pass on the device over the
+    // resident triples — the appends themselves never look at a key twice
+    KeyRange rows, cols;
+    if (nnz > 0) {
+        bool zr = false, zc = false;
+        hipError_t e = device_key_scan(b.dI, b.dJ, nnz, &rows, &cols, &zr, &zc, b.stream);
+        if (e != hipSuccess) fail(DSA_EHIP, std::string("key scan: ") + hipGetErrorString(e));
+        wr = g_force_wide || !(key_fits32(rows.lo) && key_fits32(rows.hi));
+        wc = g_force_wide || !(key_fits32(cols.lo) && key_fits32(cols.hi));
     }
     // a failed build (out of memory, a HIP error) leaves the matrix what it was: in fill mode, with all of its triples — the
     // builder only reads them — so the caller may free memory and close again, or keep appending
-    mat_build_major_dev(h, b.dI, b.dJ, b.dV, nnz, wr, wc);
+    const auto tc1 = std::chrono::steady_clock::now();
+    mat_build_major_dev(h, b.dI, b.dJ, b.dV, nnz, wr, wc, rows, cols);
+    const auto tc2 = std::chrono::steady_clock::now();
     h->fillmode = false;
     fill_release(h->buf);
     mat_prefetch_spmv_meta(h);
+    if (dbg_time) {
+        auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b2) { return std::chrono::duration<double, std::milli>(b2 - a).count(); };
+        fprintf(stderr, "[closefillmode] last chunk %.2f ms  build %.2f ms  release + prefetch %.2f ms\n", ms(tc0, tc1), ms(tc1, tc2), ms(tc2, std::chrono::steady_clock::now()));
+    }
     API_CATCH
 }
 
@@ -2049,7 +2070,7 @@ int32_t dsa_mat_set_stream(dsa_mat_t* h, void* s) {
     if (!h->has_major) fail(DSA_EMODE, "matrix is in fill mode");
     for (Pma* P : {&h->col, &h->row}) {
         HIPCHK(hipStreamSynchronize(P->stream));
-        if (P->own_stream) hipStreamDestroy(P->stream);
+        if (P->own_stream) stream_put(P->stream, P->device);
         P->stream = (hipStream_t)s; P->own_stream = false;
     }
     API_CATCH

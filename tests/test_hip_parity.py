@@ -988,6 +988,69 @@ def test_fill_mode_flush_matches_oracle(dsa, hip, oracle):
     assert_mat_equal(dsa.dynamicsparse(I, J, V, binding=hip), dsa.dynamicsparse(I, J, V, binding=oracle))
 
 
+@pytest.mark.parametrize("nnz", [1, 63, 64, 65, 4095, 4096, 4097, 8193, 70001])
+def test_kbuild_sort_tile_boundaries_match_oracle(dsa, hip, oracle, nnz):
+    """the hand-written radix sort of K-build (csrc/build.hip) around its tile sizes (64-element wave rows, 4096-element tiles):
+    random triples with duplicates, both orientations slot for slot; the vector constructor with each combine."""
+    g = np.random.default_rng(nnz)
+    I = g.integers(1, 300, nnz)
+    J = g.integers(1, 70000, nnz)
+    V = g.integers(1, 1000, nnz).astype(np.float64) / 7.0
+    assert_mat_equal(dsa.dynamicsparse(I, J, V, binding=hip), dsa.dynamicsparse(I, J, V, binding=oracle))
+    for comb in ("+", "*", "last"):
+        K = g.integers(1, max(2, nnz // 3), nnz)
+        assert_vec_equal(dsa.dynamicsparsevec(K, V, comb, binding=hip), dsa.dynamicsparsevec(K, V, comb, binding=oracle))
+
+
+def test_kbuild_long_duplicate_runs_fold_in_input_order(dsa, hip, oracle):
+    """duplicates of one (i, j) far beyond what a lane folds itself (64): the rest of the run is folded by a wave, 64 values per
+    coalesced load, still left to right in input order (src/pcsr.jl:374-375) — non-associative Float64 sums must match bit for bit."""
+    g = np.random.default_rng(77)
+    n_other = 20000
+    I = np.concatenate([g.integers(1, 500, n_other), np.full(30000, 42), np.full(65, 7), np.full(64, 8), np.full(129, 9)])
+    J = np.concatenate([g.integers(1, 500, n_other), np.full(30000, 17), np.full(65, 3), np.full(64, 3), np.full(129, 3)])
+    V = g.random(len(I)) * np.where(g.random(len(I)) < 0.5, 1e10, 1e-3)
+    perm = g.permutation(len(I))
+    I, J, V = I[perm], J[perm], V[perm]
+    a = dsa.dynamicsparse(I, J, V, binding=hip)
+    b = dsa.dynamicsparse(I, J, V, binding=oracle)
+    assert_mat_equal(a, b)
+    assert a[42, 17] == b[42, 17] and a[9, 3] == b[9, 3]
+    K = np.concatenate([np.full(100000, 5), g.integers(1, 50, 1000)])
+    W = 1.0 + g.random(len(K)) * 1e-6
+    for comb in ("+", "*", "last"):
+        assert_vec_equal(dsa.dynamicsparsevec(K, W, comb, binding=hip), dsa.dynamicsparsevec(K, W, comb, binding=oracle))
+
+
+def test_kbuild_key_ranges_composite_and_general_paths(dsa, hip, oracle):
+    """the composite (partition, key) of K-build is as wide as the two key RANGES: negative keys, offsets near 2^62, one side wide and
+    the other narrow (still one 64-bit composite), and both sides wider than 32 bits (the general two-sort path)."""
+    g = np.random.default_rng(5)
+    n = 30000
+    cases = {
+        "negative": (g.integers(-5000, 5000, n), g.integers(-300, 300, n)),
+        "offset": (g.integers(1, 1000, n) + (1 << 62), g.integers(1, 1000, n) - (1 << 61)),
+        "wide_rows": (g.integers(1, 1 << 50, n), g.integers(1, 4000, n)),
+        "wide_cols": (g.integers(1, 4000, n), g.integers(-(1 << 45), 1 << 45, n)),
+        "both_wide": (g.integers(1, 1 << 40, n), g.integers(1, 1 << 40, n)),            # 80-bit composite: general path
+        "single_column": (g.integers(1, 100000, n), np.full(n, 12)),
+        "single_row": (np.full(n, -3), g.integers(1, 100000, n)),
+    }
+    for name, (I, J) in cases.items():
+        I = np.where(I == 0, 1, I)
+        J = np.where(J == 0, 1, J)
+        V = g.integers(1, 50, n).astype(np.float64)
+        assert_mat_equal(dsa.dynamicsparse(I, J, V, binding=hip), dsa.dynamicsparse(I, J, V, binding=oracle))
+    rows = [np.sort(g.choice(5000, size=int(c), replace=True)) + 1 for c in g.integers(0, 40, 200)]
+    rows[0] = np.array([], dtype=np.int64)
+    rows[57] = np.array([], dtype=np.int64)
+    rows[199] = np.array([], dtype=np.int64)
+    vals = [g.random(len(r)) + 1.0 for r in rows]
+    pa, pb = dsa.packedcsc(rows, vals, binding=hip), dsa.packedcsc(rows, vals, binding=oracle)
+    la, lb = pa.export_layout(), pb.export_layout()
+    assert layouts_equal(la[:3], lb[:3]) and np.array_equal(la[3], lb[3])
+
+
 def test_failed_closefillmode_leaves_a_usable_fill_mode_matrix(dsa, hip, oracle):
     """A build that fails inside closefillmode! (out of memory, a HIP error: injected with DSA_FAIL_BUILD) must leave the matrix in
     fill mode with every triple it held — no dangling device pointers, no leaked streams — so that more rows can be appended and
