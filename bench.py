@@ -108,6 +108,10 @@ def main():
     ap.add_argument("--all-schedules", action="store_true",
                     help="N > 1: also time the two schedules that are NOT used in the timed steps (extra collectives: off by default so that "
                          "an unexpected failure of one of them on some node cannot cost the headline line)")
+    ap.add_argument("--collective", choices=("torch", "abi"), default="torch",
+                    help="N > 1: who issues the all-reduce of y — torch.distributed (RCCL through PyTorch; default) or the C ABI of the library "
+                         "itself (dsa_comm_* / dsa_shard_allreduce_dev: RCCL bound inside libdsa_hip.so, the path a Julia host uses; "
+                         "stream-ordered behind the SpMV, all_reduce schedule only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the inserts/s and rebalance legs")
     args = ap.parse_args()
@@ -151,8 +155,9 @@ def main():
     I, J, V = c3_triplets(m, ncl, per, col0, seed_rows=seeds[0], seed_vals=seeds[1])
     # the shard is the reference-layout PCSR of its own sub-matrix: local column keys 1..ncl (only this rank's columns are generated)
     t0 = time.time()
+    abi_comm = sharding.AbiComm(hip, rank, world) if (world > 1 and args.collective == "abi" and args.schedule == "all_reduce") else None
     shard = sharding.ColumnShard(dsa, I, np.ascontiguousarray(J - col0), V, m, n_total, rank, world, binding=hip, device=dev,
-                                 local_columns=True)      # bulk build of both orientations on the device (incl. the H2D of I, J, V)
+                                 local_columns=True, comm=abi_comm)      # bulk build of both orientations on the device (incl. the H2D of I, J, V)
     build_s = time.time() - t0
     A = shard.A
     info_row = A.info(dsa.ROWMAJOR)
@@ -162,7 +167,7 @@ def main():
     stream = torch.cuda.current_stream()
     x = torch.from_numpy(unit12(seeds[2], ncl, start=col0)).to(dev)
     # two output vectors: the all-reduce of step k (RCCL's stream) overlaps the SpMV of step k+1
-    overlap = world > 1 and args.schedule == "all_reduce"
+    overlap = world > 1 and args.schedule == "all_reduce" and abi_comm is None      # (the ABI collective is stream-ordered behind the product)
     ys = [shard.new_y() for _ in range(2 if overlap else 1)]
     pending = [None] * len(ys)
 
@@ -238,7 +243,7 @@ def main():
         "config": {"workload": workload, "name": cfg,
                    "capacity_slots": cap, "density": round((nnz + info_row["nb_partitions"]) / cap, 4), "sharding": "column-range x%d" % world,
                    "physical_slot_bytes": slot_bytes,
-                   "collective": ("%s of y (%d f64 = %.0f MB) over %s%s" % (args.schedule, m, 8 * m / 1e6, "RCCL / xGMI" if backend == "nccl" else backend,
+                   "collective": ("%s of y (%d f64 = %.0f MB) over %s%s" % (args.schedule, m, 8 * m / 1e6, ("RCCL / xGMI" + (" behind the C ABI (dsa_shard_allreduce_dev)" if abi_comm is not None else "")) if backend == "nccl" else backend,
                                   ", on RCCL's stream, overlapped with the next step's SpMV (two y buffers)" if overlap else "")) if world > 1 else "none"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
@@ -525,6 +530,8 @@ def c5_streaming(dsa, hip, torch, dev, m5, ncols5, per5, every, binding=None, st
         sl = slice(c0 * per5, (c0 + every) * per5)
         t = time.perf_counter()
         B.set_batch(I5[sl], J5[sl], V5[sl])
+        if binding is None:
+            hip.call("mat_sync", B.h)      # the batch's device work (table merge, meta prefetch) belongs to the write, not to the product behind it
         t_w += time.perf_counter() - t
         t = time.perf_counter()
         if binding is None:

@@ -28,8 +28,8 @@ INFO = dict(capacity=0, segment_capacity=1, nb_segments=2, nb_elements=3, height
             stat_extends=9, stat_shrinks=10, stat_par_rounds=11, stat_par_ops=12, stat_seq_ops=13,
             stat_spmv_nomemset=14)
 
-OK, EARG, EBOUNDS, EDELETED, EFULL, EMODE, EASSERT, EHIP, ECAP, EKEY = range(10)
-STATUS_NAMES = ["OK", "EARG", "EBOUNDS", "EDELETED", "EFULL", "EMODE", "EASSERT", "EHIP", "ECAP", "EKEY"]
+OK, EARG, EBOUNDS, EDELETED, EFULL, EMODE, EASSERT, EHIP, ECAP, EKEY, ERCCL = range(11)
+STATUS_NAMES = ["OK", "EARG", "EBOUNDS", "EDELETED", "EFULL", "EMODE", "EASSERT", "EHIP", "ECAP", "EKEY", "ERCCL"]
 
 
 class DsaError(RuntimeError):
@@ -122,6 +122,12 @@ _DEVICE_SIGS = {
     "shard_range": [I64, I32, I32, P_I64, P_I64],
     "shard_create_from_coo": [P_I64, P_I64, P_F64, I64, I64, I64, I32, I32, C.POINTER(VP)],
     "shard_spmv_dev": [VP, VP, I64, VP, I64],
+    "comm_unique_id": [P_U8],
+    "comm_init": [I32, I32, P_U8, C.POINTER(VP)],
+    "comm_destroy": [VP],
+    "comm_info": [VP, P_I32, P_I32],
+    "shard_allreduce_dev": [VP, VP, I64, VP],
+    "shard_spmv_allreduce_dev": [VP, VP, VP, I64, VP, I64],
     "vec_check": [VP, P_I64],
     "mat_check": [VP, I32, P_I64],
     "mat_set_stream": [VP, VP],

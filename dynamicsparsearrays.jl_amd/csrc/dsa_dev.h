@@ -201,6 +201,8 @@ __device__ __forceinline__ uint64_t spread_bits32(uint32_t x) {
 }
 #endif  // __HIPCC__
 
+void set_last_error(const char* msg);      // text behind dsa_last_error_message() for entry points outside dsa_host.hip
+
 // one-time kernel attribute setup (hipFuncSetAttribute is per device): thread-safe — the two orientations of a matrix are driven
 // from two host threads (dsa_host.hip: mat_apply_sets) — and repeated for every device a process uses
 struct PerDeviceOnce {
@@ -397,9 +399,10 @@ constexpr int SPMV_ZFILL = 1;          // launch_spmv_gather mode bits (spmv.hip
 constexpr int SPMV_PLAIN_STREAM = 2;
 constexpr int64_t SPMV_SPAN_SLOTS = 512;      // slots one wave of k_spmv_gather owns
 constexpr int SPMV_META_BLOCKS = 512;         // workgroups of k_spmv_meta at most
-constexpr int SPMV_META_WORDS = 3 * SPMV_META_BLOCKS + 1 + 8;     // its device scratch (zeroed once): partials, ticket, out[5]
+constexpr int SPMV_META_WORDS = 3 * SPMV_META_BLOCKS + 1;     // its device scratch (zeroed once): partials, ticket
+// out6_pinned: six words of PINNED host memory — the five results, then `seq` (written last, system scope: the host polls for it)
 hipError_t launch_spmv_meta(const int64_t* sems, const int64_t* part_keys, int64_t table_len, int64_t capacity,
-                            unsigned long long* scratch, unsigned long long* out5, hipStream_t stream);
+                            unsigned long long* scratch, unsigned long long* out6_pinned, unsigned long long seq, hipStream_t stream);
 // y[key] += x[part_key[p]] * val, scatter form with fp64 atomics (the literal _mul loop nest)
 hipError_t launch_spmv_scatter(KeyArr keys, const double* vals, const uint64_t* occ, int64_t capacity,
                                const int64_t* sems, const int64_t* part_keys, const uint8_t* part_live, int64_t table_len,

@@ -101,7 +101,7 @@ struct Pma {
     struct SpmvMeta { int64_t epoch = -1; bool ordered = false; int64_t max_extent = 0, max_gap = 0, first_key = 0, last_key = 0; } spmv_meta;
     // its device side: scratch of k_spmv_meta, pinned landing area of the 5 result words, and the epoch a prefetch (enqueued behind
     // the write batch that changed the layout) is in flight for
-    unsigned long long* d_meta = nullptr; int64_t* h_meta = nullptr; hipEvent_t meta_ev = nullptr; int64_t meta_inflight_epoch = -1;
+    unsigned long long* d_meta = nullptr; int64_t* h_meta = nullptr; unsigned long long meta_seq = 0; int64_t meta_inflight_epoch = -1;
     // thresholds  src/pma.jl:58,70,87
     double t_h = 0.7, t_0 = 0.92, p_h = 0.3, p_0 = 0.08, t_d = 0.0, p_d = 0.0;
 
@@ -148,8 +148,7 @@ void pma_destroy(Pma& P) {
     pool_free(P.d_small);
     pinned_free(P.h_small);
     if (P.d_meta) hipFree(P.d_meta);
-    if (P.h_meta) hipHostFree(P.h_meta);
-    if (P.meta_ev) hipEventDestroy(P.meta_ev);
+    pinned_free(P.h_meta);
     if (P.tmerge.sems2) hipFree(P.tmerge.sems2);
     if (P.tmerge.keys2) hipFree(P.tmerge.keys2);
     if (P.tmerge.pkey) hipFree(P.tmerge.pkey);
@@ -1217,14 +1216,14 @@ void prefetch_spmv_meta(Pma& P) {
     if (!P.d_meta) {
         HIPCHK(hipMalloc(&P.d_meta, SPMV_META_WORDS * sizeof(unsigned long long)));
         HIPCHK(hipMemsetAsync(P.d_meta, 0, SPMV_META_WORDS * sizeof(unsigned long long), P.stream));
-        HIPCHK(hipHostMalloc(&P.h_meta, 8 * sizeof(int64_t), hipHostMallocDefault));
-        HIPCHK(hipEventCreateWithFlags(&P.meta_ev, hipEventDisableTiming));
+        HIPCHK(pinned_alloc(reinterpret_cast<void**>(&P.h_meta), 8 * sizeof(int64_t)));
+        std::memset(P.h_meta, 0, 8 * sizeof(int64_t));
+        P.meta_seq = 0;
     }
-    unsigned long long* out5 = P.d_meta + 3 * SPMV_META_BLOCKS + 1;
-    hipError_t e = launch_spmv_meta(P.sems, P.col_keys, P.h_ctl->table_len, P.h_ctl->capacity, P.d_meta, out5, P.stream);
+    // the kernel writes its five words and then the sequence number straight into pinned host memory
+    hipError_t e = launch_spmv_meta(P.sems, P.col_keys, P.h_ctl->table_len, P.h_ctl->capacity, P.d_meta,
+                                    reinterpret_cast<unsigned long long*>(P.h_meta), ++P.meta_seq, P.stream);
     if (e != hipSuccess) fail(DSA_EHIP, std::string("spmv meta launch: ") + hipGetErrorString(e));
-    HIPCHK(hipMemcpyAsync(P.h_meta, out5, 5 * sizeof(int64_t), hipMemcpyDeviceToHost, P.stream));
-    HIPCHK(hipEventRecord(P.meta_ev, P.stream));
     P.meta_inflight_epoch = P.layout_epoch;
 }
 const Pma::SpmvMeta& spmv_meta(Pma& P) {
@@ -1241,7 +1240,15 @@ const Pma::SpmvMeta& spmv_meta(Pma& P) {
     }
     M.epoch = -1;
     prefetch_spmv_meta(P);                      // no-op when the write batch has already enqueued it
-    HIPCHK(hipEventSynchronize(P.meta_ev));
+    // wait for the sequence number: normally there already (the kernel was enqueued behind the write batch); a stream wait if it
+    // does not show up within a millisecond
+    volatile int64_t* seqp = P.h_meta + 5;
+    const auto t0 = std::chrono::steady_clock::now();
+    bool synced = false;
+    while ((unsigned long long)__atomic_load_n(seqp, __ATOMIC_ACQUIRE) != P.meta_seq) {
+        if (!synced && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(1)) { HIPCHK(hipStreamSynchronize(P.stream)); synced = true; continue; }
+        if (synced) fail(DSA_EHIP, "SpMV meta kernel finished without publishing its result");
+    }
     M.epoch = P.layout_epoch;
     const int64_t* r = P.h_meta;
     M.ordered = r[4] == 0;
@@ -1251,8 +1258,6 @@ const Pma::SpmvMeta& spmv_meta(Pma& P) {
     return M;
 }
 
-// mat * v walks the colmajor orientation in the reference (src/operations.jl:14-24), transpose(mat) * v the
-// rowmajor one (:26-36).  Gather form: the twin orientation, whose partitions are the OUTPUT index.
 void mat_prefetch_spmv_meta(dsa_mat* h) {
     if (!h->has_major) return;
     prefetch_spmv_meta(h->row);
@@ -1285,6 +1290,8 @@ void spmv_dev(dsa_mat* h, int32_t transpose, int32_t algo, const double* d_x, in
 }
 
 }  // namespace
+
+namespace dsa { void set_last_error(const char* msg) { g_err = msg ? msg : ""; } }
 
 // ------------------------------------------------------------------------------------------------
 // C ABI
@@ -1632,6 +1639,13 @@ int32_t dsa_shard_create_from_coo(const int64_t* I, const int64_t* J, const doub
 // stream; the all-reduce over the shards belongs to the host layer (RCCL through torch.distributed, one process per GPU)
 int32_t dsa_shard_spmv_dev(dsa_mat_t* h, const double* d_x_local, int64_t nx, double* d_y_partial, int64_t ny) {
     return dsa_mat_spmv_dense_dev(h, 0, 0, d_x_local, nx, d_y_partial, ny);
+}
+// y = A x of the whole sharded matrix: the local product, then the RCCL all-reduce of the partial y over the ranks (comm.hip),
+// both on the shard's stream — the one collective of the path, entirely behind the ABI (dsa_shard_spmv)
+int32_t dsa_shard_spmv_allreduce_dev(dsa_mat_t* h, dsa_comm_t* comm, const double* d_x_local, int64_t nx, double* d_y, int64_t ny) {
+    const int32_t rc = dsa_mat_spmv_dense_dev(h, 0, 0, d_x_local, nx, d_y, ny);
+    if (rc != DSA_OK) return rc;
+    return dsa_shard_allreduce_dev(comm, d_y, ny, h->row.stream);
 }
 int32_t dsa_mat_create_empty(int32_t fill_mode, dsa_mat_t** out) {
     API_TRY

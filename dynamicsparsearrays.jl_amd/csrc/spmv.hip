@@ -482,7 +482,7 @@ hipError_t launch_scatter_x(const int64_t* xi, const double* xv, int64_t nx, dou
 // partials into out[0..4] and resets the ticket for the next launch.  scratch = 3 * SPMV_META_BLOCKS partials + the ticket word.
 __global__ __launch_bounds__(256) void k_spmv_meta(const int64_t* __restrict__ sems, const int64_t* __restrict__ part_keys,
                                                    int64_t table_len, int64_t capacity, unsigned long long* __restrict__ scratch,
-                                                   unsigned long long* __restrict__ out) {
+                                                   unsigned long long* __restrict__ out, unsigned long long seq) {
     __shared__ unsigned long long sE[4], sG[4], sB[4];
     __shared__ unsigned int sLast;
     unsigned long long ext = 0, gap = 0, bad = 0;
@@ -535,17 +535,21 @@ __global__ __launch_bounds__(256) void k_spmv_meta(const int64_t* __restrict__ s
     __syncthreads();
     if (threadIdx.x == 0) {
         for (int w = 1; w < 4; ++w) { ext = sE[w] > ext ? sE[w] : ext; gap = sG[w] > gap ? sG[w] : gap; bad |= sB[w]; }
-        out[0] = ext; out[1] = gap; out[2] = (unsigned long long)part_keys[0]; out[3] = (unsigned long long)part_keys[table_len - 1];
-        out[4] = bad ? 1ull : 0ull;
+        // `out` is PINNED HOST memory: the five words, a system-scope release fence, then the sequence number the host polls for —
+        // no copy command, no event, no driver call on the host side of the hand-over
+        const unsigned long long r[5] = {ext, gap, (unsigned long long)part_keys[0], (unsigned long long)part_keys[table_len - 1], bad ? 1ull : 0ull};
+        for (int q = 0; q < 5; ++q) __hip_atomic_store(out + q, r[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __atomic_thread_fence(__ATOMIC_RELEASE);
+        __hip_atomic_store(out + 5, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(ticket, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 hipError_t launch_spmv_meta(const int64_t* sems, const int64_t* part_keys, int64_t table_len, int64_t capacity,
-                            unsigned long long* scratch, unsigned long long* out5, hipStream_t stream) {
-    if (table_len <= 0) return hipMemsetAsync(out5, 0, 5 * sizeof(unsigned long long), stream);
+                            unsigned long long* scratch, unsigned long long* out6_pinned, unsigned long long seq, hipStream_t stream) {
+    if (table_len <= 0) return hipErrorInvalidValue;
     int64_t blocks = (table_len + 1023) / 1024;               // >= 4 entries per thread
     if (blocks > SPMV_META_BLOCKS) blocks = SPMV_META_BLOCKS;
-    hipLaunchKernelGGL(k_spmv_meta, dim3((unsigned)blocks), dim3(256), 0, stream, sems, part_keys, table_len, capacity, scratch, out5);
+    hipLaunchKernelGGL(k_spmv_meta, dim3((unsigned)blocks), dim3(256), 0, stream, sems, part_keys, table_len, capacity, scratch, out6_pinned, seq);
     return hipGetLastError();
 }
 

@@ -21,7 +21,8 @@ module DynamicSparseArraysAMD
 using SparseArrays
 
 export DynamicSparseVector, DynamicSparseMatrix, DynamicMatrixColView, PackedCSC, dynamicsparsevec, dynamicsparse, nbpartitions,
-       deletecolumn!, deleterow!, deletepartition!, addrow!, closefillmode!, shrink_size!, set_device!, shard_range, dynamicsparse_shard,
+       deletecolumn!, deleterow!, deletepartition!, addrow!, closefillmode!, shrink_size!, set_device!, shard_range, dynamicsparse_shard, comm_unique_id, ShardComm, shard_allreduce!,
+       shard_spmv_allreduce!,
        keyint, keyfrom
 
 const libdsa = get(ENV, "DSA_HIP_LIB", joinpath(@__DIR__, "..", "csrc", "libdsa_hip.so"))
@@ -331,6 +332,33 @@ function dynamicsparse_shard(I::Vector{Int64}, J::Vector{Int64}, V::Vector{Float
         (Ptr{Int64}, Ptr{Int64}, Ptr{Float64}, Int64, Int64, Int64, Int32, Int32, Ref{Ptr{Cvoid}}), I, J, V, length(I), m, n, nshards, shard, out))
     return DynamicSparseMatrix{Int64,Int64}(out[])
 end
+
+# ---- the collective of the column-range sharded product: RCCL behind the C ABI (include/dsa.h: dsa_comm_*), one process per GPU.
+# Rank 0 calls comm_unique_id() and hands the 128 bytes to the other ranks (MPI.Bcast!, a file, ...); every rank then calls
+# ShardComm(rank, nranks, id) — a collective — and shard_spmv_allreduce!(shard, comm, x, y) leaves y = A x on every rank.
+"128 opaque bytes identifying a new communicator (ncclUniqueId) — dsa_comm_unique_id"
+function comm_unique_id()
+    id = Vector{UInt8}(undef, 128)
+    GC.@preserve id _check(ccall((:dsa_comm_unique_id, libdsa), Int32, (Ptr{UInt8},), id))
+    return id
+end
+mutable struct ShardComm
+    h::Ptr{Cvoid}
+    function ShardComm(rank::Integer, nranks::Integer, id::Union{Nothing,Vector{UInt8}})
+        out = Ref{Ptr{Cvoid}}(C_NULL)
+        idp = id === nothing ? Ptr{UInt8}(C_NULL) : pointer(id)
+        GC.@preserve id _check(ccall((:dsa_comm_init, libdsa), Int32, (Int32, Int32, Ptr{UInt8}, Ref{Ptr{Cvoid}}), rank, nranks, idp, out))
+        c = new(out[])
+        finalizer(x -> ccall((:dsa_comm_destroy, libdsa), Int32, (Ptr{Cvoid},), x.h), c)
+        return c
+    end
+end
+"y (a device pointer to m Float64 in HBM) <- sum over the ranks, in place, asynchronous on `stream` — dsa_shard_allreduce_dev"
+shard_allreduce!(c::ShardComm, d_y::Ptr{Cvoid}, m::Integer, stream::Ptr{Cvoid} = C_NULL) =
+    _check(ccall((:dsa_shard_allreduce_dev, libdsa), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}), c.h, d_y, m, stream))
+"y = A x of the whole sharded matrix on every rank: local product + all-reduce, x / y device pointers — dsa_shard_spmv_allreduce_dev"
+shard_spmv_allreduce!(a::DynamicSparseMatrix, c::ShardComm, d_x::Ptr{Cvoid}, nx::Integer, d_y::Ptr{Cvoid}, ny::Integer) =
+    _check(ccall((:dsa_shard_spmv_allreduce_dev, libdsa), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Int64), a.h, c.h, d_x, nx, d_y, ny))
 
 # ------------------------------------------------------------------ PackedCSC  (reference src/pcsr.jl:4-339)
 mutable struct PackedCSC{K}

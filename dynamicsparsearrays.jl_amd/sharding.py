@@ -45,13 +45,51 @@ def owner_of_column(col: int, world: int, n_total: int) -> int:
     raise IndexError(col)
 
 
+class AbiComm:
+    """The communicator of include/dsa.h (dsa_comm_*): RCCL bound inside libdsa_hip.so, the path a Julia host uses.  Rank 0 draws the
+    128-byte id; `bcast(bytes_or_None) -> bytes` hands it to the other ranks — torch.distributed's object broadcast by default (any
+    process group will do: the id is 128 bytes of host memory), MPI.Bcast from Julia."""
+
+    def __init__(self, binding, rank, world, bcast=None, with_rccl=True):
+        self.b, self.rank, self.world = binding, rank, world
+        idb = None
+        if world > 1 or with_rccl:
+            buf = (C.c_uint8 * 128)()
+            if rank == 0:
+                binding.call("comm_unique_id", buf)
+            raw = bytes(buf) if rank == 0 else None
+            if world > 1:
+                if bcast is None:
+                    import torch.distributed as dist
+                    box = [raw]
+                    dist.broadcast_object_list(box, src=0)
+                    raw = box[0]
+                else:
+                    raw = bcast(raw)
+            idb = (C.c_uint8 * 128).from_buffer_copy(raw)
+        self.h = C.c_void_p()
+        binding.call("comm_init", rank, world, idb, C.byref(self.h))      # collective over the ranks
+
+    def close(self):
+        if self.h:
+            self.b.call("comm_destroy", self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class ColumnShard:
     """The local shard of a column-range sharded matrix.  `api` is the dsa_amd module, `binding` the
     library it runs on (the HIP product by default), `device` the torch device of x / y (default: the
     current CUDA device)."""
 
-    def __init__(self, api, I, J_global, V, m, n_total, rank, world, binding=None, device=None, local_columns=False):
+    def __init__(self, api, I, J_global, V, m, n_total, rank, world, binding=None, device=None, local_columns=False, comm=None):
         self.api, self.rank, self.world, self.m, self.n_total = api, rank, world, m, n_total
+        self.comm = comm            # an AbiComm: the "all_reduce" schedule then runs RCCL behind the C ABI instead of torch.distributed
         self.col0, self.ncols = column_range(rank, world, n_total)
         I = np.ascontiguousarray(I, dtype=np.int64)
         J = np.ascontiguousarray(J_global, dtype=np.int64)
@@ -122,6 +160,11 @@ class ColumnShard:
     def reduce(self, y, schedule="all_reduce", async_op=False):
         """sum of the partial y over the ranks, in place; every rank ends with the complete y.
         async_op (all_reduce only): returns the work handle instead of waiting."""
+        if self.comm is not None and schedule == "all_reduce" and not async_op:
+            # stream-ordered behind the product on the shard's stream: nothing to wait for on the host
+            self._bind_stream(self.device)
+            self.binding.call("shard_allreduce_dev", self.comm.h, C.c_void_p(y.data_ptr()), self.m, C.c_void_p(self._stream))
+            return None
         if self.world == 1:
             return None
         import torch.distributed as dist

@@ -39,7 +39,8 @@ enum {
     DSA_EASSERT = 6,   /* reference @assert sites: src/pcsr.jl:124,132,173,182 */
     DSA_EHIP = 7,      /* HIP runtime failure / no device */
     DSA_ECAP = 8,      /* caller-provided output buffer too small */
-    DSA_EKEY = 9       /* reserved key 0 used as a matrix row/column key */
+    DSA_EKEY = 9,      /* reserved key 0 used as a matrix row/column key */
+    DSA_ERCCL = 10     /* RCCL failure / librccl.so not loadable (dsa_comm_*) */
 };
 
 enum { DSA_COMBINE_ADD = 0, DSA_COMBINE_MUL = 1, DSA_COMBINE_LAST = 2 };
@@ -196,8 +197,8 @@ int32_t dsa_mat_spmv_dense_dev(dsa_mat_t* h, int32_t transpose, int32_t algo, co
                                int64_t nx, double* d_y, int64_t ny);
 /* ---- column-range shards.  No reference counterpart: the reference is single-process.  One PROCESS per GPU:
  * each process selects its device (dsa_set_device), builds ITS shard and runs the local SpMV; the single data-path collective —
- * the all-reduce (sum) of the partial y — is issued by the host layer (RCCL through torch.distributed in bench.py / sharding.py;
- * MPI.jl or NCCL.jl from Julia), so no communicator crosses this ABI.
+ * the all-reduce (sum) of the partial y — is dsa_shard_allreduce_dev below (RCCL behind this ABI), or whatever the host layer has
+ * (torch.distributed in bench.py / sharding.py).
  * dsa_shard_range: shard g of G owns the global column keys (col0, col0 + ncols].
  * dsa_shard_create_from_coo: the triples of the shard's range as an independent reference-layout matrix (own capacity, height,
  *   semaphores, column table; both orientations) with LOCAL column keys 1..ncols; size m x ncols.  n = global column count.
@@ -207,6 +208,21 @@ int32_t dsa_shard_range(int64_t n, int32_t nshards, int32_t shard, int64_t* col0
 int32_t dsa_shard_create_from_coo(const int64_t* I, const int64_t* J, const double* V, int64_t nnz, int64_t m, int64_t n,
                                   int32_t nshards, int32_t shard, dsa_mat_t** out);
 int32_t dsa_shard_spmv_dev(dsa_mat_t* shard, const double* d_x_local, int64_t nx, double* d_y_partial, int64_t ny);
+/* ---- the one data-path collective: the sum of the partial y over the ranks, RCCL over xGMI, behind the ABI.
+ * One process per GPU.  Rank 0 calls dsa_comm_unique_id and hands the 128 bytes to the other ranks by whatever means the host has
+ * (MPI.Bcast from Julia, a file, torch.distributed); then EVERY rank calls dsa_comm_init (collective: ncclCommInitRank on the
+ * current device).  librccl.so is bound at run time; a copy already mapped into the process is reused.
+ * dsa_shard_allreduce_dev: in place, y <- sum over ranks (ncclAllReduce, ncclDouble, ncclSum), asynchronous on hip_stream.
+ * dsa_shard_spmv_allreduce_dev: dsa_shard_spmv_dev + that all-reduce on the shard's stream = y = A x of the whole matrix on every
+ * rank.  id == NULL with nranks == 1: a communicator without RCCL (single GPU); with an id a real single-rank RCCL communicator. */
+#define DSA_COMM_ID_BYTES 128
+typedef struct dsa_comm dsa_comm_t;
+int32_t dsa_comm_unique_id(uint8_t id[DSA_COMM_ID_BYTES]);
+int32_t dsa_comm_init(int32_t rank, int32_t nranks, const uint8_t id[DSA_COMM_ID_BYTES], dsa_comm_t** out);
+int32_t dsa_comm_destroy(dsa_comm_t* comm);
+int32_t dsa_comm_info(dsa_comm_t* comm, int32_t* rank, int32_t* nranks);
+int32_t dsa_shard_allreduce_dev(dsa_comm_t* comm, double* d_y, int64_t m, void* hip_stream);
+int32_t dsa_shard_spmv_allreduce_dev(dsa_mat_t* shard, dsa_comm_t* comm, const double* d_x_local, int64_t nx, double* d_y, int64_t ny);
 /* Device-side invariant checker (the structural checks of the reference's test/utils.jl:68-113, runnable at full size):
  * report[0] occupied cells, [1] semaphore cells, [2] semaphore cells whose table entry does not point back, [3] key-order
  * violations, [4] bad table entries (not pointing at their semaphore / dead key / unsorted column keys), [5] occupancy bits at or

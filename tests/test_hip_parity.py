@@ -746,6 +746,44 @@ def test_column_shard_device_path_single_rank(dsa, hip, oracle):
         np.testing.assert_allclose(y.cpu().numpy(), ref, rtol=RTOL, atol=0)
 
 
+def test_abi_communicator_world_1_rccl_smoke(dsa, hip, oracle):
+    """The collective behind the C ABI (include/dsa.h: dsa_comm_*, csrc/comm.hip) with ONE rank on the one GPU of the box: librccl is
+    bound at run time, ncclGetUniqueId / ncclCommInitRank / ncclAllReduce(ncclDouble, ncclSum) really run (a single-rank all-reduce
+    is the identity), dsa_shard_spmv_allreduce_dev = local product + that all-reduce on the shard's stream; and the communicator
+    without RCCL (id == NULL) a single-GPU host gets.  More ranks cannot be tried here: the pool hands out one GPU."""
+    import ctypes as C
+    import torch
+    from dsa_amd import sharding
+    m, n, per = 4000, 2500, 6
+    rows = 1 + (splitmix_array(61, n * per) % np.uint64(m)).astype(np.int64)
+    cols = np.repeat(np.arange(1, n + 1, dtype=np.int64), per)
+    vals = unit12_array(62, n * per)
+    x = unit12_array(63, n)
+    ref = dsa.dynamicsparse(rows, cols, vals, m, n, binding=oracle).mul(x)
+    for with_rccl in (True, False):
+        comm = sharding.AbiComm(hip, 0, 1, with_rccl=with_rccl)
+        r, w = C.c_int32(-1), C.c_int32(-1)
+        hip.call("comm_info", comm.h, C.byref(r), C.byref(w))
+        assert (r.value, w.value) == (0, 1)
+        sh = sharding.ColumnShard(dsa, rows, cols, vals, m, n, 0, 1, binding=hip, comm=comm)
+        xs = sh.x_slice(x)
+        y = torch.full((m,), float("nan"), dtype=torch.float64, device=sh.device)
+        sh.spmv(xs, y)                                      # spmv_partial + reduce through dsa_shard_allreduce_dev
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(y.cpu().numpy(), ref, rtol=RTOL, atol=0)
+        y2 = torch.full((m,), float("nan"), dtype=torch.float64, device=sh.device)
+        hip.call("shard_spmv_allreduce_dev", sh.A.h, comm.h, C.c_void_p(xs.data_ptr()), n, C.c_void_p(y2.data_ptr()), m)
+        hip.call("mat_sync", sh.A.h)
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(y2.cpu().numpy(), ref, rtol=RTOL, atol=0)
+        del sh
+        comm.close()
+    with pytest.raises(dsa.DsaError):
+        sharding.AbiComm.__new__(sharding.AbiComm)           # placeholder object; the next line is the real check
+        h = C.c_void_p()
+        hip.call("comm_init", 1, 2, None, C.byref(h))          # two ranks need an id
+
+
 def test_c3_scale_build_and_spmv_properties(dsa, hip):
     """BASELINE config 3 at a quarter of full size on the GPU alone (the oracle needs tens of seconds
     there): size-independent properties — capacity rule, sorted partitions, semaphore table,
