@@ -261,6 +261,21 @@ def main():
         "build_s": round(build_s, 3),
     }
 
+    # what the access pattern itself costs on this part (tools/gatherbench2.hip through tools/scripts/gather_floor.sh, committed as
+    # profiles/gather_floor.json): the slot stream alone, the 11 M gathers from an 8.4 MB x alone, and both in one kernel — the
+    # ceiling a single-pass kernel on uniformly random columns has, in the record next to the fraction it explains
+    if cfg == "c3" and m == 1_000_000 and ncl == 1_000_000 and per == 10:
+        try:
+            with open(os.path.join(ROOT, "profiles", "gather_floor.json")) as f:
+                gf = json.load(f)
+            out["roofline"]["stream_only_us"] = gf["stream_only_us"]
+            out["roofline"]["gather_only_floor_us"] = gf["gather_only_us"]
+            out["roofline"]["stream_and_gather_one_kernel_us"] = gf["stream_and_gather_one_kernel_us"]
+            out["roofline"]["frac_ceiling_single_pass"] = round(bytes_launch / 1e9 / (gf["gather_only_us"] / 1e6) / HBM_PEAK_GBS, 4)
+            out["roofline"]["floor_source"] = gf["source"]
+        except (OSError, KeyError, ValueError):
+            out["roofline"]["floor_source"] = "none: profiles/gather_floor.json missing"
+
     # HBM-side traffic per launch: only from a committed rocprofv3 PMC summary made from the CURRENT kernel sources
     # (tools/scripts/profile_round.sh: separate --pmc FETCH_SIZE / WRITE_SIZE passes of the same workload); otherwise null
     pmc_file, pm = committed_pmc()

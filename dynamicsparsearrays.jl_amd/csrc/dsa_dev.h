@@ -19,6 +19,9 @@ namespace dsa {
 constexpr int WAVE = 64;
 constexpr int64_t SEM_KEY = 0;            // semaphore_key(::Type{<:Integer})  src/pcsr.jl:23
 constexpr int MAX_LEVELS = 48;
+// partition-table entries a batch may leave unmerged at the END of the tables (Ctl::n_pending): the one limit the sequencer's LDS
+// list (sequencer.hip), the batch-parallel rounds (parbatch.hip) and the grid-wide merge (tables.hip) share
+constexpr int TABLE_PEND_MAX = 1024;
 
 // ---- physical key storage ---------------------------------------------------------------------------
 // K = Int64 at the API; in HBM a slot array keeps its keys in 32 bits as long as every key ever written fits Int32
@@ -350,7 +353,8 @@ struct RoundState {
 struct BurstGraph {        // cached hipGraph of one burst of rounds (host-side)
     hipGraphExec_t exec = nullptr; hipGraph_t graph = nullptr; hipStream_t stream = nullptr;
     const void* key[12] = {};
-    bool disabled = false;
+    bool disabled = false;              // capture failed on `failed_on` (e.g. the legacy null stream): eager launches until the stream changes
+    hipStream_t failed_on = nullptr;
 };
 // the arrays the rounds work on, read by the kernels from device memory: a root rebalance swaps the slot buffers and the tables
 // grow, but the launch arguments — and with them the cached graph — stay the same (re-instantiating the graphs after every

@@ -10,6 +10,8 @@
 #include "../../include/dsa.h"
 #include "dsa_dev.h"
 
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -40,7 +42,33 @@ struct Fail { int32_t code; std::string msg; };
         if (_e != hipSuccess) fail(DSA_EHIP, std::string(#expr) + ": " + hipGetErrorString(_e));   \
     } while (0)
 
-#define API_TRY try {
+// roctx ranges around every ABI entry point (tracing): DSA_ROCTX=1 binds librocprofiler-sdk-roctx.so (or the legacy
+// libroctx64.so) at run time, and `rocprofv3 --marker-trace` then shows which call a kernel belongs to; without the knob the
+// cost is one predictable branch per call and no profiler library is mapped.
+struct Roctx {
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx() {
+        const char* e = getenv("DSA_ROCTX");
+        if (!(e && e[0] == '1')) return;
+        for (const char* n : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"}) {
+            void* lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+            if (!lib) continue;
+            push = reinterpret_cast<int (*)(const char*)>(dlsym(lib, "roctxRangePushA"));
+            pop = reinterpret_cast<int (*)()>(dlsym(lib, "roctxRangePop"));
+            if (push && pop) return;
+            push = nullptr; pop = nullptr;
+        }
+    }
+};
+const Roctx& roctx() { static const Roctx r; return r; }
+struct ApiRange {
+    bool on;
+    explicit ApiRange(const char* name) : on(roctx().push != nullptr) { if (on) roctx().push(name); }
+    ~ApiRange() { if (on) roctx().pop(); }
+};
+
+#define API_TRY ApiRange _api_range(__func__); try {
 #define API_CATCH                                                              \
     } catch (const Fail& f) { g_err = f.msg; return f.code;                    \
     } catch (const std::bad_alloc&) { g_err = "host allocation failed"; return DSA_EHIP; \
@@ -253,8 +281,8 @@ void pma_init_common(Pma& P, bool sems, bool cols) {
 void ensure_tables(Pma& P, int64_t need) {
     if (!P.has_sems) return;
     if (need <= P.h_ctl->table_cap) return;
-    int64_t ncap = std::max<int64_t>(1024, P.h_ctl->table_cap * 4);
-    while (ncap < need) ncap *= 4;
+    int64_t ncap = std::max<int64_t>(1024, P.h_ctl->table_cap * (P.h_ctl->table_cap < (1 << 20) ? 4 : 2));      // 4x steps below 1 M entries, 2x above
+    while (ncap < need) ncap *= ncap < (1 << 20) ? 4 : 2;
     int64_t* ns = nullptr; int64_t* nk = nullptr; uint8_t* nl = nullptr;
     HIPCHK(pool_alloc(reinterpret_cast<void**>(&ns), (size_t)ncap * sizeof(int64_t)));
     HIPCHK(hipMemsetAsync(ns, 0, (size_t)ncap * sizeof(int64_t), P.stream));
@@ -320,9 +348,11 @@ void ensure_capacity_alloc(Pma& P, int64_t slots) {
     if (slots <= P.cap_alloc) return;
     // growth in steps of 4x (at least 64k slots once the first 4096 are outgrown): a growing array re-allocates its two buffers
     // (13 hipMalloc / hipFree and a stream wait each time) 4 times on the way to 4M slots instead of 10; HBM is not the scarce resource
+    // ... up to 2^24 slots; above that the steps are 2x (a structure one slot past a 4x boundary would otherwise hold 4x what it
+    // needs twice over: 2^26 + 1 slots -> 2 x 2^28 x 12 B)
     int64_t n = std::max<int64_t>(P.cap_alloc, 4096);
-    if (n < slots) n = std::max<int64_t>(4 * n, 65536);
-    while (n < slots) n *= 4;
+    if (n < slots) n = std::max<int64_t>(n < (1 << 24) ? 4 * n : 2 * n, 65536);
+    while (n < slots) n *= n < (1 << 24) ? 4 : 2;
     void* ok[2] = {P.keys[0], P.keys[1]}; double* ov[2] = {P.vals[0], P.vals[1]}; uint64_t* oo[2] = {P.occ[0], P.occ[1]};
     const int64_t old_words = P.occ_words, old_slots = P.cap_alloc;
     for (int b = 0; b < 2; ++b) { P.keys[b] = nullptr; P.vals[b] = nullptr; P.occ[b] = nullptr; }
@@ -474,6 +504,7 @@ void merge_tables(Pma& P) {
         P.tmerge.pdst = P.tmerge.pkey + 1024; P.tmerge.psem = P.tmerge.pkey + 2048; P.tmerge.hdr = P.tmerge.pkey + 3072;
     }
     ++P.layout_epoch;
+    if (P.h_ctl->n_pending > TABLE_PEND_MAX) fail(DSA_EASSERT, "more pending partition-table entries than the merge takes (internal invariant)");
     hipError_t e = launch_table_merge(P.sems, P.col_keys, P.col_live, P.V(), P.d_ctl, P.tmerge, cap, P.stream);
     if (e != hipSuccess) fail(DSA_EHIP, std::string("table merge launch: ") + hipGetErrorString(e));
     P.h_ctl->n_pending = 0;
@@ -745,6 +776,9 @@ void pma_info(Pma& P, int64_t nb_partitions_or_len, int64_t* info) {
     info[DSA_INFO_STAT_SHRINKS] = c.stat_shrinks;
     info[11] = P.stat_par_rounds; info[12] = P.stat_par_ops; info[13] = P.stat_seq_ops;
     info[DSA_INFO_STAT_SPMV_NOMEMSET] = P.stat_spmv_nomemset;
+    // HBM held by the structure: both slot buffers (keys, values, bitmap), the saved bitmap of append runs, the tables and the merge scratch
+    info[DSA_INFO_HBM_BYTES] = 2 * (P.cap_alloc * (int64_t)(P.kb() + sizeof(double)) + P.occ_words * 8) + (P.occ_old ? P.occ_words * 8 : 0) +
+                               (P.has_sems ? c.table_cap * 8 : 0) + (P.has_cols ? c.table_cap * 9 : 0) + 2 * P.tmerge_cap * 8;
 }
 
 void export_slots(Pma& P, int64_t* keys, double* vals, uint8_t* occ, int64_t cap) {
@@ -783,14 +817,20 @@ void pma_check(Pma& P, int64_t* report) {
                                 P.has_cols ? P.col_keys : nullptr, P.has_cols ? P.col_live : nullptr, P.h_ctl->table_len, d, P.stream);
     if (e == hipSuccess) e = hipMemcpyAsync(r, d, sizeof(r), hipMemcpyDeviceToHost, P.stream);
     // no table entry may be pending outside a batch (tables.hip): the DEVICE copy of the counter is the one the kernels trust
-    int64_t dev_pending = 0;
+    int64_t dev_pending = 0, merge_fault = 0;
     if (e == hipSuccess) e = hipMemcpyAsync(&dev_pending, reinterpret_cast<const char*>(P.d_ctl) + offsetof(Ctl, n_pending), sizeof(int64_t), hipMemcpyDeviceToHost, P.stream);
+    // the grid-wide table merge raises hdr[2] if it was ever handed more entries than it takes (cannot happen: TABLE_PEND_MAX)
+    if (e == hipSuccess && P.tmerge.hdr != nullptr) e = hipMemcpyAsync(&merge_fault, P.tmerge.hdr + 2, sizeof(int64_t), hipMemcpyDeviceToHost, P.stream);
+    unsigned long long move_fault = 0;
+    if (e == hipSuccess && P.work.status != nullptr)
+        e = hipMemcpyAsync(&move_fault, P.work.status + P.work.status_cap - 1, sizeof(move_fault), hipMemcpyDeviceToHost, P.stream);
     if (e == hipSuccess) e = hipStreamSynchronize(P.stream);
     hipFree(d);
     if (e != hipSuccess) fail(DSA_EHIP, std::string("check: ") + hipGetErrorString(e));
+    if (move_fault != 0) fail(DSA_EHIP, "a rebalance launch gave up waiting for its prefix table (k_move2: dispatch-order assumption violated)");
     for (int i = 0; i < 8; ++i) report[i] = (int64_t)r[i];
     const int64_t live = P.has_sems ? P.h_ctl->nb_partitions : 0;
-    report[6] = (report[0] != P.h_ctl->nb_elements || report[1] != live || dev_pending != 0 || P.h_ctl->n_pending != 0) ? 1 : 0;
+    report[6] = (report[0] != P.h_ctl->nb_elements || report[1] != live || dev_pending != 0 || P.h_ctl->n_pending != 0 || merge_fault != 0) ? 1 : 0;
 }
 
 void ensure_q(Pma& P, int64_t n) {

@@ -28,7 +28,7 @@ constexpr int PB_MAX_W = 1 << PB_MAX_W_LOG2;  // largest window a single wave re
 constexpr int PB_GMAX = 1024;                 // ops planned per round at most (one wave each)
 
 enum : int32_t { PB_NOOP = 0, PB_OVERWRITE = 1, PB_INS_R = 2, PB_INS_L = 3, PB_DELETE = 4, PB_BARRIER = 5, PB_NEWCOL = 6 };
-constexpr int64_t PB_PEND_MAX = 1024;         // = PEND_MAX of the sequencer, which imports and merges the pending table entries
+constexpr int64_t PB_PEND_MAX = TABLE_PEND_MAX;  // the sequencer imports, tables.hip merges the pending table entries
 
 __device__ __forceinline__ int64_t pb_wave_sum(int64_t v) {
 #pragma unroll
@@ -731,6 +731,7 @@ hipError_t launch_burst(const DevBufs* bufs, Ctl* ctl, const Op* ops, RoundState
     const void* key[12] = {bufs, ctl, ops, rs, plans, (const void*)(intptr_t)rounds, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     bool same = cache->exec != nullptr && cache->stream == stream;
     for (int k = 0; k < 12 && same; ++k) same = cache->key[k] == key[k];
+    if (cache->disabled && cache->failed_on != stream) cache->disabled = false;      // another stream: capture may work there
     if (!same && !cache->disabled) {
         if (cache->exec) { (void)hipGraphExecDestroy(cache->exec); cache->exec = nullptr; }
         if (cache->graph) { (void)hipGraphDestroy(cache->graph); cache->graph = nullptr; }
@@ -744,11 +745,11 @@ hipError_t launch_burst(const DevBufs* bufs, Ctl* ctl, const Op* ops, RoundState
                 cache->stream = stream;
             } else {
                 if (g) (void)hipGraphDestroy(g);
-                cache->exec = nullptr; cache->disabled = true;
+                cache->exec = nullptr; cache->disabled = true; cache->failed_on = stream;
                 (void)hipGetLastError();
             }
         } else {
-            cache->disabled = true;
+            cache->disabled = true; cache->failed_on = stream;
             (void)hipGetLastError();
         }
     }

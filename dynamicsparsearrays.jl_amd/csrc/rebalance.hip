@@ -133,6 +133,7 @@ struct Move2Args {
     unsigned long long* status;    // [0, ntiles): cells in front of the tile inside its group of 64, [ntiles, ..): cells per group; word = [63:34] generation, [31:0] value
     unsigned long long gen;
     int64_t ntiles;
+    unsigned long long* fault;     // raised by a workgroup that gave up waiting for a status word (see M2_SPIN_MAX)
     double cells_to_gaps;          // E / m: starting guess of #gaps in front of a rank
     int dbg;                       // DSA_DBG_MOVE2 ablation knob (dev only): 1 = no waiting for status words, 2 = no write phase, 4 = closed-form P
 };
@@ -150,6 +151,14 @@ __device__ __forceinline__ int dest_of_rank(const SpreadGeom& g, int r, double c
     while (k > 0 && gap_D(g, k) >= r + k) --k;
     return r + k;
 }
+
+// DISPATCH-ORDER ASSUMPTION.  Workgroup t only ever waits for status words published by workgroups with a LOWER blockIdx (the first
+// ntiles/64 of the same launch), which wait for nobody.  That is deadlock-free as long as the hardware starts workgroups in blockIdx
+// order — what every AMD command processor does for a 1-D grid — so that a waiting workgroup can never occupy the slot its producer
+// needs.  The wait is nevertheless bounded: after M2_SPIN_MAX polls (~seconds) a workgroup raises Move2Args::fault and carries on
+// with whatever it read (the result is garbage, the stream is not hung); the host turns the flag into DSA_EHIP at its next
+// synchronisation point (pma_sync_check) and the invariant checker reports it.
+constexpr unsigned int M2_SPIN_MAX = 1u << 24;
 
 template <bool PACKED, bool WIDE, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_move2(Move2Args a) {
@@ -237,12 +246,18 @@ __global__ __launch_bounds__(BLOCK) void k_move2(Move2Args a) {
             }
         }
         // ---- 3. cells in front of the tile ------------------------------------------------------------------------------------
-        while ((st0 >> 34) != a.gen) { __builtin_amdgcn_s_sleep(1); st0 = __hip_atomic_load(poll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+        for (unsigned int spin = 0; (st0 >> 34) != a.gen; ++spin) {
+            if (spin == M2_SPIN_MAX) { atomicExch(a.fault, 1ull); break; }
+            __builtin_amdgcn_s_sleep(1); st0 = __hip_atomic_load(poll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         uint32_t part = (uint32_t)st0;
         if (wv >= 1 && !(a.dbg & 1)) {           // more than BLOCK - 64 groups in front (windows above 2^24 slots): further rounds
             for (int64_t j = tid - 64 + (BLOCK - 64); j < grp; j += BLOCK - 64) {
                 unsigned long long st = __hip_atomic_load(gstatus + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                while ((st >> 34) != a.gen) { __builtin_amdgcn_s_sleep(1); st = __hip_atomic_load(gstatus + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+                for (unsigned int spin = 0; (st >> 34) != a.gen; ++spin) {
+                    if (spin == M2_SPIN_MAX) { atomicExch(a.fault, 1ull); break; }
+                    __builtin_amdgcn_s_sleep(1); st = __hip_atomic_load(gstatus + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
                 part += (uint32_t)st;
             }
         }
@@ -643,21 +658,25 @@ hipError_t launch_rebalance(KeyArr src_keys, const double* src_vals, const uint6
         a.cells_to_gaps = m > 0 ? (double)(a.Wd - m) / (double)m : 0.0;
         { static const char* e = getenv("DSA_DBG_MOVE2"); a.dbg = e ? atoi(e) : 0; }
         if (((src_ws - 1) & 63) != 0 && !src_packed) return hipErrorInvalidValue;     // source windows start on an occupancy word
+        // ranks, gap indices and offsets inside a window are 32-bit in the kernel (dest_of_rank, gap_pair: single-instruction
+        // int <-> double conversions): windows of 2^31 slots or more are refused, not wrapped
+        if (a.Wd >= ((int64_t)1 << 31) || src_we - src_ws + 1 >= ((int64_t)1 << 31) || m >= ((int64_t)1 << 31)) return hipErrorInvalidValue;
         if (src_packed) {
             a.ntiles = std::max<int64_t>(1, (m + M2_TILE - 1) / M2_TILE);
-            a.status = nullptr; a.gen = 0;
+            a.status = nullptr; a.gen = 0; a.fault = nullptr;
             if (a.src_keys.wide) hipLaunchKernelGGL((k_move2<true, true, 256>), dim3((unsigned)a.ntiles), dim3(256), 0, stream, a);
             else hipLaunchKernelGGL((k_move2<true, false, 256>), dim3((unsigned)a.ntiles), dim3(256), 0, stream, a);
             return hipGetLastError();
         }
         a.ntiles = (src_we - src_ws + 1 + M2_TILE - 1) / M2_TILE;
-        if (a.ntiles + (a.ntiles >> 6) + 1 > work->status_cap || work->status == nullptr) return hipErrorInvalidValue;
+        if (a.ntiles + (a.ntiles >> 6) + 2 > work->status_cap || work->status == nullptr) return hipErrorInvalidValue;
         if (++work->gen >= (1ull << 30)) {          // generation wrap: start over on a zeroed table
             hipError_t e = hipMemsetAsync(work->status, 0, (size_t)work->status_cap * sizeof(unsigned long long), stream);
             if (e != hipSuccess) return e;
             work->gen = 1;
         }
         a.status = work->status; a.gen = work->gen;
+        a.fault = work->status + work->status_cap - 1;              // the last word of the table is not a status word (alloc_work)
         // few tiles (windows up to 2^22 slots): the chain occupancy -> table -> write is latency, not bandwidth: 8 waves per tile
         static const int force_block = [] { const char* e = getenv("DSA_MOVE2_BLOCK"); return e ? atoi(e) : 0; }();
         const int block = force_block ? force_block : (a.ntiles <= 2048 ? 512 : 256);      // measured 512 vs 256 threads: 2^20 9.9 vs 11.5 us, 2^22 27.2 vs 29.3, 2^24 83.5 vs 77.4 (1024 threads: 12.9 / 41 / 152)

@@ -55,7 +55,8 @@ struct Seq {
     int64_t prof[16];
     int64_t* pKey; uint32_t* pIdx; uint32_t* pLb;      // pLb: number of SORTED keys below the pending key
 };
-constexpr int PEND_MAX = 1024;
+constexpr int PEND_MAX = TABLE_PEND_MAX;
+static_assert(PEND_MAX % SEQ_BLOCK == 0, "d_import_pending distributes the list over the workgroup");
 
 
 // ---- workgroup-parallel primitives ------------------------------------------------------------------

@@ -19,7 +19,8 @@
 
 namespace dsa {
 
-constexpr int MG_PEND_MAX = 1024;      // = PEND_MAX (sequencer.hip) = PB_PEND_MAX (parbatch.hip)
+constexpr int MG_PEND_MAX = TABLE_PEND_MAX;
+static_assert(MG_PEND_MAX <= 1024, "k_merge_sort ranks the pending keys with one thread each");
 
 __global__ __launch_bounds__(1024) void k_merge_sort(const int64_t* sems, const int64_t* col_keys, const Ctl* ctl, TableMerge tm) {
     __shared__ int64_t sKey[MG_PEND_MAX];

@@ -63,6 +63,7 @@ enum {
     DSA_INFO_STAT_PAR_OPS = 12,
     DSA_INFO_STAT_SEQ_OPS = 13,
     DSA_INFO_STAT_SPMV_NOMEMSET = 14, /* instrumentation: gather SpMV launches over this orientation that needed no memset of y */
+    DSA_INFO_HBM_BYTES = 15,          /* bytes of HBM the structure holds (slot buffers x 2, bitmaps, tables, merge scratch) */
     DSA_INFO_COUNT = 16
 };
 
