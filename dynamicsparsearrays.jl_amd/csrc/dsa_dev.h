@@ -350,6 +350,7 @@ struct RoundState {
     int64_t rounds, par_ops;
     int64_t why[8];        // dev: what cut the prefixes (index = Plan::count of the first BARRIER op; 7 = a conflict)
 };
+constexpr int ROUND_GMAX = 1024;       // ops planned per round at most (parbatch.hip: one wave each; the host sizes the plan array)
 struct BurstGraph {        // cached hipGraph of one burst of rounds (host-side)
     hipGraphExec_t exec = nullptr; hipGraph_t graph = nullptr; hipStream_t stream = nullptr;
     const void* key[12] = {};

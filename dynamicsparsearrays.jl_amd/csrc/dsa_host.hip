@@ -389,21 +389,29 @@ void root_rebalance(Pma& P, int64_t src_cap, int64_t new_cap, int64_t m, bool sr
     P.cur = alt;
 }
 
-// in-place semantic for an interior window: rebalance into the alternate buffer, copy the window back
+// an interior window (too wide for the LDS paths): pack! into the alternate buffer, spread! back from there — the two halves of
+// _even_rebalance! (src/pma.jl:94-103) as two launches of the same kernel: unpacked source -> m packed cells, packed source ->
+// spread window.  (2 W + 2 m) cells of traffic and two launches; round 2 rebalanced into the alternate buffer and copied the
+// window back with three device-to-device copies: 4 W cells, four launches.)
 void window_rebalance(Pma& P, int64_t ws, int64_t we, int64_t m) {
     if (ws == 1 && we == P.capacity()) { root_rebalance(P, P.capacity(), P.capacity(), m, false); return; }
     const int alt = 1 - P.cur;
     ++P.layout_epoch;
-    hipError_t e = launch_rebalance(P.K(), P.V(), P.O(), ws, we, false, P.KA(alt), P.vals[alt], P.occ[alt], ws, we, m,
-                                    P.has_sems ? P.sems : nullptr, &P.work, P.stream);
-    if (e != hipSuccess) fail(DSA_EHIP, std::string("rebalance launch: ") + hipGetErrorString(e));
-    const int64_t W = we - ws + 1;
-    P.occ_dirty[alt] = std::max<int64_t>(P.occ_dirty[alt], (we + 63) / 64);
-    HIPCHK(hipMemcpyAsync((char*)P.keys[P.cur] + (size_t)(ws - 1) * P.kb(), (char*)P.keys[alt] + (size_t)(ws - 1) * P.kb(), (size_t)W * P.kb(),
-                          hipMemcpyDeviceToDevice, P.stream));
-    HIPCHK(hipMemcpyAsync(P.V() + (ws - 1), P.vals[alt] + (ws - 1), (size_t)W * sizeof(double), hipMemcpyDeviceToDevice, P.stream));
-    HIPCHK(hipMemcpyAsync(P.O() + ((ws - 1) >> 6), P.occ[alt] + ((ws - 1) >> 6), (size_t)(W >> 6) * sizeof(uint64_t),
-                          hipMemcpyDeviceToDevice, P.stream));
+    if (m <= 0) {                                     // nothing to move: every slot of the window becomes a gap
+        hipError_t e0 = launch_clear_occ(P.O(), ws, we, P.stream);
+        if (e0 != hipSuccess) fail(DSA_EHIP, std::string("clear launch: ") + hipGetErrorString(e0));
+        return;
+    }
+    // pack!: the m cells of [ws, we] -> alt[ws .. ws + m - 1] (no gaps: the destination window has exactly m slots); the semaphore
+    // table is not touched (positions in the scratch buffer mean nothing)
+    hipError_t e = launch_rebalance(P.K(), P.V(), P.O(), ws, we, false, P.KA(alt), P.vals[alt], P.occ[alt], ws, ws + m - 1, m,
+                                    nullptr, &P.work, P.stream);
+    if (e != hipSuccess) fail(DSA_EHIP, std::string("rebalance launch (pack): ") + hipGetErrorString(e));
+    P.occ_dirty[alt] = std::max<int64_t>(P.occ_dirty[alt], (ws + m - 1 + 63) / 64);      // the scratch bitmap words written by the pack
+    // spread!: packed source -> the window in the current buffer, occupancy words and semaphores[] included
+    e = launch_rebalance(P.KA(alt), P.vals[alt], P.occ[alt], ws, ws + m - 1, true, P.K(), P.V(), P.O(), ws, we, m,
+                         P.has_sems ? P.sems : nullptr, &P.work, P.stream);
+    if (e != hipSuccess) fail(DSA_EHIP, std::string("rebalance launch (spread): ") + hipGetErrorString(e));
 }
 
 // PackedMemoryArray(keys, values; sort=false) + _pma  src/pma.jl:42-55,69-84 from an already ordered
@@ -651,7 +659,7 @@ int64_t run_ops_parallel(Pma& P, const std::vector<Op>& ops, int32_t* err) {
     *err = 0;
     const int64_t n = (int64_t)ops.size();
     if (n == 0) return 0;
-    constexpr int GMAX = 1024, MIN_PREFIX = 4, ROUNDS_PER_SYNC = 12, ROUNDS_SHORT = 3;
+    constexpr int GMAX = ROUND_GMAX, MIN_PREFIX = 4, ROUNDS_PER_SYNC = 12, ROUNDS_SHORT = 3;
     constexpr int64_t MERGE_AT = 256;       // pending table entries (of at most 1024) that trigger the grid-wide merge between launches
     ensure_key_width(P, ops);
     ensure_ops(P, n);

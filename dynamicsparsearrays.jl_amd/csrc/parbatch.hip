@@ -22,10 +22,12 @@
 
 namespace dsa {
 
-constexpr int PB_BLOCK = 256;                 // 4 waves = 4 ops per workgroup
+constexpr int PB_BLOCK = 256;                 // k_apply: 4 waves = 4 ops per workgroup (32 KB of LDS per wave)
+constexpr int PL_BLOCK = 1024;                // k_plan: 16 waves = 16 ops per workgroup; the workgroup that finishes last resolves the round with
+                                              // one thread per op (with 256 threads the chain walks of the resolve step were the longest part of a round)
 constexpr int PB_MAX_W_LOG2 = 11;
 constexpr int PB_MAX_W = 1 << PB_MAX_W_LOG2;  // largest window a single wave rebalances (32 KB of LDS per wave, 128 KB per workgroup)
-constexpr int PB_GMAX = 1024;                 // ops planned per round at most (one wave each)
+constexpr int PB_GMAX = ROUND_GMAX;           // ops planned per round at most (one wave each)
 
 enum : int32_t { PB_NOOP = 0, PB_OVERWRITE = 1, PB_INS_R = 2, PB_INS_L = 3, PB_DELETE = 4, PB_BARRIER = 5, PB_NEWCOL = 6 };
 constexpr int64_t PB_PEND_MAX = TABLE_PEND_MAX;  // the sequencer imports, tables.hip merges the pending table entries
@@ -185,9 +187,12 @@ __device__ Plan pb_plan_one(KeyArr keys, const double* vals, const uint64_t* occ
                 pl.action = PB_BARRIER; why = 6;
             } else {
                 pl.ws = ws; pl.we = we; pl.count = (int32_t)c;
-                int64_t lo = ws < wlo ? ws : wlo, hi = we > whi ? we : whi;
-                if (rlo < lo) lo = rlo;
-                if (rhi > hi) hi = rhi;
+                // what the op reads for its decisions or moves, apart from the COUNT of its window: predecessor and the slot behind
+                // it, the shifted run up to the gap it fills
+                int64_t lo = wlo < rlo ? wlo : rlo, hi = whi > rhi ? whi : rhi;
+                // accepted by its leaf (no rebalance follows): the plan carries this TIGHT hull; the resolve step widens it to the
+                // leaf unless the leaf provably accepts every order of the window's ops that change its count (pb_is_leaf_only)
+                if (we - ws + 1 != seg) { if (ws < lo) lo = ws; if (we > hi) hi = we; }
                 pl.lo = lo; pl.hi = hi;
             }
         }
@@ -196,17 +201,29 @@ __device__ Plan pb_plan_one(KeyArr keys, const double* vals, const uint64_t* occ
     return pl;
 }
 
-__global__ __launch_bounds__(PB_BLOCK) void k_plan(const DevBufs* bufs, const Ctl* ctl, const Op* ops, RoundState* rs, Plan* plans) {
+// an op whose density scan stopped at its leaf: nothing but the leaf's COUNT ties it to the rest of the leaf (Plan::lo / hi then hold
+// the tight hull, see pb_plan_one)
+__device__ __forceinline__ bool pb_is_leaf_only(int32_t action, int64_t ws, int64_t we, int64_t seg) {
+    return (action == PB_INS_R || action == PB_INS_L || action == PB_DELETE) && we - ws + 1 == seg;
+}
+// slot whose occupancy the op changes, and by how much
+__device__ __forceinline__ int64_t pb_changed_slot(int32_t action, int64_t pos, int64_t aux) { return action == PB_DELETE ? pos : aux; }
+__device__ __forceinline__ int pb_delta(int32_t action) { return (action == PB_INS_R || action == PB_INS_L) ? 1 : (action == PB_DELETE ? -1 : 0); }
+
+__global__ __launch_bounds__(PL_BLOCK) void k_plan(const DevBufs* bufs, const Ctl* ctl, const Op* ops, RoundState* rs, Plan* plans) {
     // the round's window of ops comes from the device-resident cursor: rounds are enqueued back to back without host syncs
     if (rs->stop) return;
     const DevBufs db = *bufs;
     const KeyArr keys{db.keys, db.wide, 0};
     const double* vals = db.vals; const uint64_t* occ = db.occ;
     const int64_t* sems = db.sems; const int64_t* col_keys = db.col_keys; const uint8_t* col_live = db.col_live;
+    // scalars of the control block the resolve step needs: requested now, so that the last workgroup does not start with a dependent
+    // round trip to memory (~2 us across XCDs)
+    const int64_t cap0 = ctl->capacity, seg0 = ctl->segment_capacity, lo00 = ctl->lo[0], hi00 = ctl->hi[0];
     const int64_t i0 = rs->cursor + rs->d;            // the resolve step of this round folds the previous prefix into the cursor
     const int64_t left = rs->limit - i0;
     const int G = (int)(left < rs->G ? left : rs->G);
-    const int w = blockIdx.x * (PB_BLOCK / 64) + (threadIdx.x >> 6);
+    const int w = blockIdx.x * (PL_BLOCK / 64) + (threadIdx.x >> 6);
     if (w < G) {
     const Plan pl = pb_plan_one(keys, vals, occ, sems, col_keys, col_live, ctl, ops[i0 + w], w, PB_MAX_W);
     {
@@ -241,15 +258,47 @@ __global__ __launch_bounds__(PB_BLOCK) void k_plan(const DevBufs* bufs, const Ct
     [[maybe_unused]] const long long tr0 = clock64();      // dev profile, -DDSA_PB_PROF
     const int tid = threadIdx.x;
     int shift = 0;
-    while (((ctl->capacity) >> shift) > 0x7fffffffll) ++shift;
-    for (int j = tid; j < G + 8; j += PB_BLOCK) {
+    while ((cap0 >> shift) > 0x7fffffffll) ++shift;
+    // Ops accepted by their LEAF move nothing but their shifted run; what else ties two of them together is the leaf's cell COUNT
+    // (src/pma.jl:118-126).  If the leaf accepts the count whatever subset of the window's ops has changed it — count0 + all inserts
+    // into the leaf <= hi[0], count0 - all deletes >= lo[0] — every order of those ops takes the same decisions, and the op's
+    // footprint is just its tight hull (predecessor .. filled gap): two inserts into one 16-slot leaf no longer collide, only
+    // overlapping runs do.  Otherwise the footprint is widened to the leaf, as for every op with a wider window.  (Round 2 always
+    // used the leaf: conflict-free prefixes of ~250 ops on a 2^21-slot array, birthday-bound by 16-slot footprints.)
+    // The sums per leaf come from a walk of the same spatial hash the overlap test uses: an op that changes the count of leaf L
+    // has the changed slot in its hull, so it is chained in the cell of L.
+    __shared__ int32_t sChg[PB_GMAX];                                  // slot whose occupancy the op changes (0: none), exact: tight mode needs shift == 0
+    __shared__ signed char sDl[PB_GMAX];                               // +1 insert, -1 delete, 0 otherwise
+    __shared__ int32_t sLeafLo[PB_GMAX];                               // first slot of the op's leaf if it is leaf-only, else 0
+    __shared__ int32_t sCnt0[PB_GMAX];                                 // cells of that leaf before the round
+    const int64_t seg = seg0;
+    for (int j = tid; j < G + 8; j += PL_BLOCK) {
         Iv iv{INT32_MAX, INT32_MIN};                                   // an empty footprint overlaps nothing
         if (j < G) {
             const Plan* q = plans + j;
             const int64_t lo = __hip_atomic_load(&q->lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const int64_t hi = __hip_atomic_load(&q->hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (lo <= hi) { iv.lo = (int32_t)(lo >> shift); iv.hi = (int32_t)(hi >> shift); }
-            if (__hip_atomic_load(&q->action, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == PB_BARRIER) atomicMin(&sB, j);
+            const int64_t ws = __hip_atomic_load(&q->ws, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int64_t we = __hip_atomic_load(&q->we, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int64_t pos = __hip_atomic_load(&q->pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int64_t aux = __hip_atomic_load(&q->aux, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int32_t cnt = __hip_atomic_load(&q->count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int32_t act = __hip_atomic_load(&q->action, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (act == PB_BARRIER) atomicMin(&sB, j);
+            const int dl = pb_delta(act);
+            const int64_t chg = pb_changed_slot(act, pos, aux);
+            const bool leaf_only = pb_is_leaf_only(act, ws, we, seg);
+            sDl[j] = (signed char)dl;
+            sChg[j] = (dl != 0 && shift == 0) ? (int32_t)chg : 0;
+            int64_t flo = lo, fhi = hi;
+            if (leaf_only && shift == 0) {
+                sLeafLo[j] = (int32_t)ws;
+                sCnt0[j] = cnt - ((chg >= ws && chg <= we) ? dl : 0);
+            } else {
+                sLeafLo[j] = 0; sCnt0[j] = 0;
+                if (leaf_only && lo <= hi) { if (ws < flo) flo = ws; if (we > fhi) fhi = we; }      // (arrays beyond 2^31 slots: always the leaf)
+            }
+            if (flo <= fhi) { iv.lo = (int32_t)(flo >> shift); iv.hi = (int32_t)(fhi >> shift); }
         }
         sIv[j] = iv;
     }
@@ -264,12 +313,12 @@ __global__ __launch_bounds__(PB_BLOCK) void k_plan(const DevBufs* bufs, const Ct
     __shared__ int sNext[2 * PB_GMAX];
     __shared__ int sWide[PB_GMAX];
     __shared__ int sNWide;
-    for (int k = tid; k < NB; k += PB_BLOCK) sHead[k] = -1;
+    for (int k = tid; k < NB; k += PL_BLOCK) sHead[k] = -1;
     if (tid == 0) sNWide = 0;
     __syncthreads();
     const int Gc = sB < G ? sB : G;
     auto bucket = [](int cell) { return (int)(((uint32_t)cell * 0x9E3779B1u) >> 20) & (NB - 1); };
-    for (int j = tid; j < Gc; j += PB_BLOCK) {
+    for (int j = tid; j < Gc; j += PL_BLOCK) {
         const Iv iv = sIv[j];
         if (iv.lo > iv.hi) continue;
         const int c0 = iv.lo >> CS, c1 = iv.hi >> CS;
@@ -277,7 +326,53 @@ __global__ __launch_bounds__(PB_BLOCK) void k_plan(const DevBufs* bufs, const Ct
         for (int k = 0; k <= c1 - c0; ++k) { const int e = 2 * j + k; sNext[e] = atomicExch(&sHead[bucket(c0 + k)], e); }
     }
     __syncthreads();
-    for (int j = tid; j < Gc; j += PB_BLOCK) {
+    {   // leaf-only ops: inserts into / deletes from their leaf by ANY op of the window in front of the first BARRIER (themselves
+        // included); the leaf must accept every count in between, else the footprint is widened to the leaf
+        const int64_t lo0 = lo00, hi0 = hi00;
+        const int nwide0 = sNWide;
+        bool widen[PB_GMAX / PL_BLOCK];
+#pragma unroll
+        for (int u = 0; u < PB_GMAX / PL_BLOCK; ++u) {
+            const int j = tid + u * PL_BLOCK;
+            widen[u] = false;
+            if (j >= Gc) continue;
+            const int32_t l0 = sLeafLo[j];
+            if (l0 == 0) continue;
+            const int32_t l1 = l0 + (int32_t)seg - 1;
+            const Iv me = sIv[j];
+            const int c0 = me.lo >> CS, c1 = me.hi >> CS;
+            int ins = 0, del = 0;
+            if (c1 - c0 > 1) { widen[u] = true; continue; }              // (a tight hull over three cells: keep it simple)
+            const int cl = l0 >> CS;                                    // the cell of the leaf (= one of the hull's cells: the insertion point lies in both)
+            for (int e = sHead[bucket(cl)]; e >= 0; e = sNext[e]) {
+                const int i = e >> 1;
+                if ((e & 1) && (sIv[i].lo >> CS) == cl) continue;       // an op chained twice into this bucket's cell is counted once
+                const int32_t ch = sChg[i];
+                if (ch >= l0 && ch <= l1) { if (sDl[i] > 0) ++ins; else ++del; }
+            }
+            for (int w2 = 0; w2 < nwide0; ++w2) {
+                const int i = sWide[w2];
+                const int32_t ch = sChg[i];
+                if (ch >= l0 && ch <= l1) { if (sDl[i] > 0) ++ins; else ++del; }
+            }
+            const int64_t cnt0 = sCnt0[j];
+            widen[u] = !(cnt0 + ins <= hi0 && cnt0 - del >= lo0);
+        }
+        __syncthreads();                                               // every walk has read the tight hulls
+#pragma unroll
+        for (int u = 0; u < PB_GMAX / PL_BLOCK; ++u) {
+            const int j = tid + u * PL_BLOCK;
+            if (j < Gc && widen[u]) {
+                Iv me = sIv[j];
+                const int32_t l0 = sLeafLo[j], l1 = l0 + (int32_t)seg - 1;
+                if (l0 < me.lo) me.lo = l0;
+                if (l1 > me.hi) me.hi = l1;
+                sIv[j] = me;                                           // (still inside the cells it is chained in: a leaf never straddles a cell)
+            }
+        }
+    }
+    __syncthreads();
+    for (int j = tid; j < Gc; j += PL_BLOCK) {
         const Iv me = sIv[j];
         if (me.lo > me.hi) continue;
         const int c0 = me.lo >> CS, c1 = me.hi >> CS;
@@ -296,7 +391,7 @@ __global__ __launch_bounds__(PB_BLOCK) void k_plan(const DevBufs* bufs, const Ct
     for (int w = 0; w < nwide; ++w) {
         const int j = sWide[w];
         const Iv me = sIv[j];
-        for (int i = tid; i < Gc; i += PB_BLOCK) {
+        for (int i = tid; i < Gc; i += PL_BLOCK) {
             const Iv o = sIv[i];
             if (i != j && o.lo <= me.hi && me.lo <= o.hi) atomicMin(&sC, i > j ? i : j);
         }
@@ -323,7 +418,7 @@ __global__ __launch_bounds__(PB_BLOCK) void k_plan(const DevBufs* bufs, const Ct
             rs->stop = 1; rs->d = 0; return;
         }
         rs->d = d;
-        int Gn = 2 * d;
+        int Gn = d + (d >> 1) + 32;                                      // the next window: half as much again as what ran (the resolve step costs per planned op)
         if (Gn < 64) Gn = 64;
         if (Gn > PB_GMAX) Gn = PB_GMAX;
         rs->G_next = Gn;
@@ -663,10 +758,17 @@ __global__ __launch_bounds__(LR_BLOCK) void k_local_rounds(const DevBufs* bufs, 
             int dd = G;
             for (int j = 0; j < G && dd == G; ++j) {
                 if (sPlan[j].action == PB_BARRIER) { dd = j; break; }
-                const int64_t lo = sPlan[j].lo, hi = sPlan[j].hi;
+                // (leaf-only ops carry their tight hull: widened to the leaf here — no count bookkeeping in the mini-rounds)
+                auto full = [&](const Plan& q, int64_t& lo_, int64_t& hi_) {
+                    lo_ = q.lo; hi_ = q.hi;
+                    if (lo_ <= hi_ && pb_is_leaf_only(q.action, q.ws, q.we, ctl->segment_capacity)) { if (q.ws < lo_) lo_ = q.ws; if (q.we > hi_) hi_ = q.we; }
+                };
+                int64_t lo, hi;
+                full(sPlan[j], lo, hi);
                 if (lo > hi) continue;
                 for (int i = 0; i < j; ++i) {
-                    const int64_t l2 = sPlan[i].lo, h2 = sPlan[i].hi;
+                    int64_t l2, h2;
+                    full(sPlan[i], l2, h2);
                     if (l2 <= h2 && l2 <= hi && lo <= h2) { dd = j; break; }
                 }
             }
@@ -715,7 +817,7 @@ static hipError_t configure_apply() {
 }
 static hipError_t enqueue_round(const DevBufs* bufs, Ctl* ctl, const Op* ops, RoundState* rs, Plan* plans, hipStream_t stream) {
     const size_t lds = (size_t)(PB_BLOCK / 64) * PB_MAX_W * (sizeof(int64_t) + sizeof(double));
-    hipLaunchKernelGGL(k_plan, dim3(PB_GMAX / 4), dim3(PB_BLOCK), 0, stream, bufs, ctl, ops, rs, plans);
+    hipLaunchKernelGGL(k_plan, dim3(PB_GMAX / (PL_BLOCK / 64)), dim3(PL_BLOCK), 0, stream, bufs, ctl, ops, rs, plans);
     hipLaunchKernelGGL(k_apply, dim3(PB_GMAX / 4), dim3(PB_BLOCK), lds, stream, bufs, ctl, ops, rs, plans);
     return hipGetLastError();
 }
