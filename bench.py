@@ -433,6 +433,29 @@ def extras(dsa, hip, torch, A, dev):
         del A4, x4, y4
     except Exception as e:           # an extra must never cost the headline line
         res["c4_shard_spmv"] = {"error": str(e)[:200]}
+    # --- an EXTRA, never the headline: the same kernel on a matrix WITH column locality — config 3's shape (1M x 1M, 10 distinct rows
+    #     per column) but rows within +-4096 of the column index (banded).  The x entries a stretch of rows gathers then sit in a few
+    #     hundred KB: every gather is an L2 hit, the kernel leaves the fabric-bound regime of the uniformly random matrix
+    try:
+        mb = nb = 1_000_000
+        z = splitmix_array(51, nb * 10)
+        colb = np.repeat(np.arange(1, nb + 1, dtype=np.int64), 10)
+        rowb = np.clip(colb + (z % np.uint64(8192)).astype(np.int64) - 4096, 1, mb)
+        keyb = colb * np.int64(mb + 1) + rowb
+        _, firstb = np.unique(keyb, return_index=True)
+        Ab = dsa.dynamicsparse(rowb[firstb], colb[firstb], unit12(52, len(firstb)), mb, nb, binding=hip)
+        hip.call("mat_set_stream", Ab.h, C.c_void_p(stream.cuda_stream))
+        capb = Ab.info(dsa.ROWMAJOR)["capacity"]
+        xb = torch.from_numpy(unit12(53, nb)).to(dev)
+        yb = torch.zeros(mb, dtype=torch.float64, device=dev)
+        usb = timed(lambda: hip.call("mat_spmv_dense_dev", Ab.h, 0, 0, C.c_void_p(xb.data_ptr()), nb, C.c_void_p(yb.data_ptr()), mb), 20)
+        bb = 16 * capb + 8 * nb + 8 * mb
+        res["spmv_banded_extra"] = {"rows": mb, "columns": nb, "nnz": int(len(firstb)), "band": "+-4096", "capacity_slots": capb, "us": round(usb, 2),
+                                    "algorithmic_bytes": bb, "gbps": round(bb / usb / 1e3, 1), "frac": round(bb / usb / 1e3 / HBM_PEAK_GBS, 4),
+                                    "note": "NOT the headline workload: a banded variant of config 3, reported to show what the kernel does when x has locality"}
+        del Ab, xb, yb
+    except Exception as e:
+        res["spmv_banded_extra"] = {"error": str(e)[:200]}
     # --- sparse x through the host-pointer entry point (the _mul shape Coluna calls, src/operations.jl:107-135): result = touched
     #     rows in ascending order; few stored entries -> x-driven kernel, many -> densify + gather + pattern pass.  Times include
     #     the PCIe copies of x and of the result.
@@ -518,6 +541,11 @@ def extras(dsa, hip, torch, A, dev):
     t = time.perf_counter()
     F = dsa.dynamicsparse(I3, J3, V3, 1_000_000, 1_000_000, binding=hip)
     fill["dynamicsparse_from_caller_memory_ms"] = round((time.perf_counter() - t) * 1e3, 2)
+    # the flush against its stream bound: 24 B per triple in, both orientations' slot arrays out (16 B per slot of capacity), once each
+    capF = F.info(dsa.COLMAJOR)["capacity"] + F.info(dsa.ROWMAJOR)["capacity"]
+    fill["closefillmode_stream_bound_ms"] = round((24 * len(I3) + 16 * capF) / (HBM_PEAK_GBS * 1e9) * 1e3, 4)
+    fill["closefillmode_frac_of_stream_bound"] = round(fill["closefillmode_stream_bound_ms"] / fill["closefillmode_ms"], 4)
+    fill["kbuild"] = "hand-written LSD radix sort of a (partition, key) composite over its significant bits: 5 passes of 8 bits at this size (csrc/build.hip)"
     del F
     res["buffered_writes"] = fill
     return res

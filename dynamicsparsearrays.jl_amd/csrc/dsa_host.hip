@@ -249,7 +249,7 @@ void alloc_work(Pma& P, int64_t slots) {
     HIPCHK(hipMalloc(&P.work.tile_cnt, (size_t)P.work.tiles_cap * sizeof(uint32_t)));
     HIPCHK(hipMalloc(&P.work.tile_off, (size_t)P.work.tiles_cap * sizeof(uint32_t)));
     if (P.work.status) hipFree(P.work.status);
-    P.work.status_cap = slots / 2048 + slots / (2048 * 64) + 16; P.work.gen = 0;
+    P.work.status_cap = slots / 1024 + slots / (1024 * 64) + 16; P.work.gen = 0;      // one word per 1024-slot tile + one per 64 tiles + the fault word
     HIPCHK(hipMalloc(&P.work.status, (size_t)P.work.status_cap * sizeof(unsigned long long)));
     HIPCHK(hipMemsetAsync(P.work.status, 0, (size_t)P.work.status_cap * sizeof(unsigned long long), P.stream));
     if (P.work2.tile_cnt) { hipFree(P.work2.tile_cnt); hipFree(P.work2.tile_off); }

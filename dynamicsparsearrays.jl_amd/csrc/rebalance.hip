@@ -120,8 +120,8 @@ __global__ __launch_bounds__(1024) void k_tile_scan(const uint32_t* __restrict__
 // No count kernel, no scan kernel, no interpolation search: the time does not depend on how the cells are distributed
 // over the source window (uniform after a spread, packed to the left after appends, anything in between).
 // PACKED sources (K-build, pack! + _shrink!: cells are the first m slots) have closed-form prefixes and skip 1-3.
-constexpr int M2_TILE = 2048;
-constexpr int M2_WORDS = M2_TILE / 64;
+constexpr int M2_TILE_BIG = 2048;      // source slots per workgroup (M2_TILE_SMALL: dev knob, see launch_rebalance)
+constexpr int M2_TILE_SMALL = 1024;
 
 struct Move2Args {
     KeyArr src_keys; const double* src_vals; const uint64_t* src_occ;
@@ -160,8 +160,9 @@ __device__ __forceinline__ int dest_of_rank(const SpreadGeom& g, int r, double c
 // synchronisation point (pma_sync_check) and the invariant checker reports it.
 constexpr unsigned int M2_SPIN_MAX = 1u << 24;
 
-template <bool PACKED, bool WIDE, int BLOCK>
+template <bool PACKED, bool WIDE, int BLOCK, int TILE>
 __global__ __launch_bounds__(BLOCK) void k_move2(Move2Args a) {
+    constexpr int M2_TILE = TILE, M2_WORDS = TILE / 64;     // source slots / occupancy words per workgroup
     constexpr int NW = BLOCK / 64;            // waves per workgroup
     typedef typename std::conditional<WIDE, int64_t, int32_t>::type key_t;
     const key_t* __restrict__ srck = static_cast<const key_t*>(a.src_keys.p);
@@ -662,13 +663,20 @@ hipError_t launch_rebalance(KeyArr src_keys, const double* src_vals, const uint6
         // int <-> double conversions): windows of 2^31 slots or more are refused, not wrapped
         if (a.Wd >= ((int64_t)1 << 31) || src_we - src_ws + 1 >= ((int64_t)1 << 31) || m >= ((int64_t)1 << 31)) return hipErrorInvalidValue;
         if (src_packed) {
-            a.ntiles = std::max<int64_t>(1, (m + M2_TILE - 1) / M2_TILE);
+            a.ntiles = std::max<int64_t>(1, (m + M2_TILE_BIG - 1) / M2_TILE_BIG);
             a.status = nullptr; a.gen = 0; a.fault = nullptr;
-            if (a.src_keys.wide) hipLaunchKernelGGL((k_move2<true, true, 256>), dim3((unsigned)a.ntiles), dim3(256), 0, stream, a);
-            else hipLaunchKernelGGL((k_move2<true, false, 256>), dim3((unsigned)a.ntiles), dim3(256), 0, stream, a);
+            if (a.src_keys.wide) hipLaunchKernelGGL((k_move2<true, true, 256, M2_TILE_BIG>), dim3((unsigned)a.ntiles), dim3(256), 0, stream, a);
+            else hipLaunchKernelGGL((k_move2<true, false, 256, M2_TILE_BIG>), dim3((unsigned)a.ntiles), dim3(256), 0, stream, a);
             return hipGetLastError();
         }
-        a.ntiles = (src_we - src_ws + 1 + M2_TILE - 1) / M2_TILE;
+        const int64_t Ws = src_we - src_ws + 1;
+        // few tiles (windows up to 2^22 slots): the chain occupancy -> table -> write is latency, not bandwidth: 8 waves per tile; above: 4.
+        // Tiles of 1024 slots (twice the workgroups, half the write phase each; DSA_MOVE2_TILE=1024) were measured in round 3 and LOSE:
+        // 2^20 slots 11.1 vs 10.1 us, 2^21 18.0 vs 15.0, 2^22 26.1 vs 25.2, 2^24 76.7 vs 77.7 — more status words to publish and poll
+        static const int force_block = [] { const char* e = getenv("DSA_MOVE2_BLOCK"); return e ? atoi(e) : 0; }();
+        static const int force_tile = [] { const char* e = getenv("DSA_MOVE2_TILE"); return e ? atoi(e) : 0; }();
+        const int tile = force_tile == M2_TILE_SMALL ? M2_TILE_SMALL : M2_TILE_BIG;
+        a.ntiles = (Ws + tile - 1) / tile;
         if (a.ntiles + (a.ntiles >> 6) + 2 > work->status_cap || work->status == nullptr) return hipErrorInvalidValue;
         if (++work->gen >= (1ull << 30)) {          // generation wrap: start over on a zeroed table
             hipError_t e = hipMemsetAsync(work->status, 0, (size_t)work->status_cap * sizeof(unsigned long long), stream);
@@ -677,16 +685,17 @@ hipError_t launch_rebalance(KeyArr src_keys, const double* src_vals, const uint6
         }
         a.status = work->status; a.gen = work->gen;
         a.fault = work->status + work->status_cap - 1;              // the last word of the table is not a status word (alloc_work)
-        // few tiles (windows up to 2^22 slots): the chain occupancy -> table -> write is latency, not bandwidth: 8 waves per tile
-        static const int force_block = [] { const char* e = getenv("DSA_MOVE2_BLOCK"); return e ? atoi(e) : 0; }();
         const int block = force_block ? force_block : (a.ntiles <= 2048 ? 512 : 256);      // measured 512 vs 256 threads: 2^20 9.9 vs 11.5 us, 2^22 27.2 vs 29.3, 2^24 83.5 vs 77.4 (1024 threads: 12.9 / 41 / 152)
-        if (block == 512) {
-            if (a.src_keys.wide) hipLaunchKernelGGL((k_move2<false, true, 512>), dim3((unsigned)a.ntiles), dim3(512), 0, stream, a);
-            else hipLaunchKernelGGL((k_move2<false, false, 512>), dim3((unsigned)a.ntiles), dim3(512), 0, stream, a);
+#define DSA_MOVE2_LAUNCH(W_, B_, T_) hipLaunchKernelGGL((k_move2<false, W_, B_, T_>), dim3((unsigned)a.ntiles), dim3(B_), 0, stream, a)
+        const bool wide = a.src_keys.wide != 0;
+        if (tile == M2_TILE_SMALL) {
+            if (block == 512) { if (wide) DSA_MOVE2_LAUNCH(true, 512, M2_TILE_SMALL); else DSA_MOVE2_LAUNCH(false, 512, M2_TILE_SMALL); }
+            else { if (wide) DSA_MOVE2_LAUNCH(true, 256, M2_TILE_SMALL); else DSA_MOVE2_LAUNCH(false, 256, M2_TILE_SMALL); }
         } else {
-            if (a.src_keys.wide) hipLaunchKernelGGL((k_move2<false, true, 256>), dim3((unsigned)a.ntiles), dim3(256), 0, stream, a);
-            else hipLaunchKernelGGL((k_move2<false, false, 256>), dim3((unsigned)a.ntiles), dim3(256), 0, stream, a);
+            if (block == 512) { if (wide) DSA_MOVE2_LAUNCH(true, 512, M2_TILE_BIG); else DSA_MOVE2_LAUNCH(false, 512, M2_TILE_BIG); }
+            else { if (wide) DSA_MOVE2_LAUNCH(true, 256, M2_TILE_BIG); else DSA_MOVE2_LAUNCH(false, 256, M2_TILE_BIG); }
         }
+#undef DSA_MOVE2_LAUNCH
         return hipGetLastError();
     }
 }

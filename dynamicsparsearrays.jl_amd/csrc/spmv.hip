@@ -547,7 +547,7 @@ __global__ __launch_bounds__(256) void k_spmv_meta(const int64_t* __restrict__ s
 hipError_t launch_spmv_meta(const int64_t* sems, const int64_t* part_keys, int64_t table_len, int64_t capacity,
                             unsigned long long* scratch, unsigned long long* out6_pinned, unsigned long long seq, hipStream_t stream) {
     if (table_len <= 0) return hipErrorInvalidValue;
-    int64_t blocks = (table_len + 1023) / 1024;               // >= 4 entries per thread
+    int64_t blocks = (table_len + 255) / 256;                 // one entry per thread, grid-stride beyond SPMV_META_BLOCKS workgroups
     if (blocks > SPMV_META_BLOCKS) blocks = SPMV_META_BLOCKS;
     hipLaunchKernelGGL(k_spmv_meta, dim3((unsigned)blocks), dim3(256), 0, stream, sems, part_keys, table_len, capacity, scratch, out6_pinned, seq);
     return hipGetLastError();
