@@ -196,3 +196,62 @@ def test_vector_equality_and_filter(dsa, oracle):
     fk, fv = f.nonzeros()
     sel = (k % 2 == 0) & (v > 10)
     assert np.array_equal(fk, k[sel]) and np.array_equal(fv, v[sel]) and len(f) == int(k[sel].max())
+
+
+def test_oracle_layout_import_export_round_trip(dsa, oracle):
+    """ora_vec_import_layout / ora_pcsc_import_layout (the checker's side of dsa_*_import_layout): a structure restored from an
+    exported layout has the same scalars and slots, and goes on behaving like the original."""
+    import numpy as np
+    from util import layouts_equal, check_semaphores
+    rng = np.random.default_rng(3)
+    keys = np.sort(rng.choice(50000, size=3000, replace=False)) + 1
+    a = dsa.dynamicsparsevec(keys, rng.random(3000) + 1.0, binding=oracle)
+    a.set_batch(rng.choice(50000, size=2000) + 1, np.where(rng.random(2000) < 0.3, 0.0, 2.0))
+    k, v, o = a.export_layout()
+    b = dsa.import_vector_layout(k, v, o, a.info()["segment_capacity"], n=len(a), binding=oracle)
+    for f in ("capacity", "segment_capacity", "nb_segments", "nb_elements", "height"):
+        assert a.info()[f] == b.info()[f], f
+    assert layouts_equal(a.export_layout(), b.export_layout()) and a == b
+    ops_k, ops_v = rng.choice(50000, size=4000) + 1, np.where(rng.random(4000) < 0.4, 0.0, 3.0)
+    a.set_batch(ops_k, ops_v)
+    b.set_batch(ops_k, ops_v)
+    assert layouts_equal(a.export_layout(), b.export_layout()) and a.info()["capacity"] == b.info()["capacity"]
+    rows = [np.sort(rng.choice(900, size=int(c), replace=False)) + 1 for c in rng.integers(0, 30, 40)]
+    p = dsa.packedcsc(rows, [rng.random(len(r)) + 1.0 for r in rows], binding=oracle)
+    p.deletepartition(7)
+    pk, pv, po, ps = p.export_layout()
+    q = dsa.import_packedcsc_layout(pk, pv, po, p.info()["segment_capacity"], ps, binding=oracle)
+    assert q.nbpartitions() == p.nbpartitions() and q.nnz() == p.nnz()
+    for t in (p, q):
+        t[5, 12] = 4.0
+        t[901, 3] = 1.5
+    lp, lq = p.export_layout(), q.export_layout()
+    assert layouts_equal(lp[:3], lq[:3]) and np.array_equal(lp[3], lq[3])
+    check_semaphores(lq[0], lq[1], lq[2], lq[3])
+
+
+def test_raw_find_agrees_with_a_linear_scan_when_the_range_is_key_partitioned(oracle):
+    """find (src/finds.jl:29-57) on raw arrays against a brute-force statement of its contract: the cell holding the key if it is
+    stored in [from, to]; else the last cell of the range with a smaller key; else the nearest cell left of `from`; else (0, nothing)."""
+    import numpy as np
+    from rawhooks import Raw, key_partitioned, random_partitioned_array
+    rng = np.random.default_rng(12)
+    ref = Raw(oracle)
+    for _ in range(60):
+        n = int(rng.choice([5, 17, 64, 200]))
+        k, v, o, _s = random_partitioned_array(rng, n, float(rng.choice([0.2, 0.6, 0.95])), 0, key_hi=3 * n)
+        for _q in range(20):
+            frm = int(rng.integers(1, n + 1)); to = int(rng.integers(frm - 1, n + 1)); key = int(rng.integers(0, 3 * n + 2))
+            assert key_partitioned(k, o, key, frm, to)
+            pos, elem = ref.find(k, v, o, key, frm, to)
+            occ = [i + 1 for i in range(n) if o[i]]
+            inr = [p for p in occ if frm <= p <= to]
+            hit = [p for p in inr if k[p - 1] == key]
+            if hit:
+                exp = hit[0]
+            else:
+                smaller = [p for p in inr if k[p - 1] < key]
+                left = [p for p in occ if p < frm]
+                exp = smaller[-1] if smaller else (left[-1] if left else 0)
+            assert pos == exp, (key, frm, to, pos, exp)
+            assert (elem is None) == (exp == 0)
