@@ -349,6 +349,8 @@ struct RoundState {
                            // the rounds while the recent ones were short too (appends, one hot key), not for one unlucky collision
     int64_t rounds, par_ops;
     int64_t why[8];        // dev: what cut the prefixes (index = Plan::count of the first BARRIER op; 7 = a conflict)
+    int32_t tight;         // tight footprints (parbatch.hip): bit 0 leaf-accepted inserts / deletes, bit 1 leaf-accepted new columns (dev knob DSA_TIGHT, default 3)
+    int32_t pad2;
 };
 constexpr int ROUND_GMAX = 1024;       // ops planned per round at most (parbatch.hip: one wave each; the host sizes the plan array)
 struct BurstGraph {        // cached hipGraph of one burst of rounds (host-side)

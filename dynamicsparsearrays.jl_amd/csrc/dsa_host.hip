@@ -695,7 +695,8 @@ int64_t run_ops_parallel(Pma& P, const std::vector<Op>& ops, int32_t* err) {
         // ---- a burst of rounds driven by the device-resident cursor; one host synchronisation per burst
         RoundState& rs = *P.h_rs;
         std::memset(&rs, 0, sizeof(rs));
-        rs.cursor = i; rs.limit = n; rs.G = G; rs.min_prefix = MIN_PREFIX; rs.ema = ema;
+        static const int tight = [] { const char* e = getenv("DSA_TIGHT"); return e ? atoi(e) : 3; }();
+        rs.cursor = i; rs.limit = n; rs.G = G; rs.min_prefix = MIN_PREFIX; rs.ema = ema; rs.tight = tight;
         HIPCHK(hipMemcpyAsync(P.d_rs, P.h_rs, sizeof(RoundState), hipMemcpyHostToDevice, P.stream));
         {
             ++P.layout_epoch;
@@ -719,6 +720,11 @@ int64_t run_ops_parallel(Pma& P, const std::vector<Op>& ops, int32_t* err) {
         if (use_local) { t_local += ms(tb0, now()); ++n_local; r_local += rs.rounds; o_local += rs.par_ops; }
         // the prefix of the last round of the burst has been applied but is folded into the cursor only by the next round's resolve step
         if (rs.pad != 0) fail(DSA_EASSERT, "batch-parallel column creation left its footprint (internal invariant)");
+        static const bool dbg_burst = getenv("DSA_DBG_BURST") != nullptr;
+        if (dbg_burst)
+            fprintf(stderr, "    burst%s: rounds %lld ops %lld (+ last prefix %d) stop %d G %d ema %.1f pending %lld table %lld/%lld cap %lld\n", use_local ? " (local)" : "",
+                    (long long)rs.rounds, (long long)rs.par_ops, rs.d, rs.stop, rs.G, rs.ema / 16.0, (long long)P.h_ctl->n_pending,
+                    (long long)P.h_ctl->table_len, (long long)P.h_ctl->table_cap, (long long)P.h_ctl->capacity);
         const int64_t reached = rs.cursor + rs.d;
         // what the sequencer takes after a stop: the op that cannot be planned alone when the rounds were otherwise making progress
         // (the ops behind it are cheaper in a round: ~1 us each against 5-15 us), a chunk of SEQ_CHUNK0 ops when short prefixes

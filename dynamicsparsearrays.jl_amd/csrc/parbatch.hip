@@ -134,8 +134,12 @@ __device__ Plan pb_plan_one(KeyArr keys, const double* vals, const uint64_t* occ
                     const int64_t cnt = pb_wave_count(occ, A, B, false);
                     if (ctl->lo[h] <= cnt + 1 && cnt + 2 <= ctl->hi[h]) {
                         pl.action = PB_NEWCOL; pl.pos = p1; pl.aux = ne1;
-                        pl.ws = A; pl.we = B; pl.count = (int32_t)h;
+                        pl.ws = A; pl.we = B; pl.count = (int32_t)h | ((int32_t)cnt << 8);      // level, and the cells of [A, B] before the round
                         pl.lo = p1 < A ? p1 : A; pl.hi = B;
+                        // accepted by the LEAF: neither insert is followed by a rebalance, the two shifted runs [p1 + 1, ne1] and
+                        // [p1 + 2, ne2] are all that moves: the plan carries that tight hull, the resolve step widens it to the leaf
+                        // unless the leaf accepts every order of the window's ops that change its count (see pb_is_leaf_only)
+                        if (h == 0) { pl.lo = p1; pl.hi = ne2; }
                         break;
                     }
                 }
@@ -204,11 +208,14 @@ __device__ Plan pb_plan_one(KeyArr keys, const double* vals, const uint64_t* occ
 // an op whose density scan stopped at its leaf: nothing but the leaf's COUNT ties it to the rest of the leaf (Plan::lo / hi then hold
 // the tight hull, see pb_plan_one)
 __device__ __forceinline__ bool pb_is_leaf_only(int32_t action, int64_t ws, int64_t we, int64_t seg) {
-    return (action == PB_INS_R || action == PB_INS_L || action == PB_DELETE) && we - ws + 1 == seg;
+    return (action == PB_INS_R || action == PB_INS_L || action == PB_DELETE || action == PB_NEWCOL) && we - ws + 1 == seg;
 }
 // slot whose occupancy the op changes, and by how much
 __device__ __forceinline__ int64_t pb_changed_slot(int32_t action, int64_t pos, int64_t aux) { return action == PB_DELETE ? pos : aux; }
-__device__ __forceinline__ int pb_delta(int32_t action) { return (action == PB_INS_R || action == PB_INS_L) ? 1 : (action == PB_DELETE ? -1 : 0); }
+// (a new column accepted by its leaf adds two cells to it — semaphore and element; one with a wider window is covered by its footprint)
+__device__ __forceinline__ int pb_delta(int32_t action, bool leaf_only = false) {
+    return (action == PB_INS_R || action == PB_INS_L) ? 1 : (action == PB_DELETE ? -1 : ((action == PB_NEWCOL && leaf_only) ? 2 : 0));
+}
 
 __global__ __launch_bounds__(PL_BLOCK) void k_plan(const DevBufs* bufs, const Ctl* ctl, const Op* ops, RoundState* rs, Plan* plans) {
     // the round's window of ops comes from the device-resident cursor: rounds are enqueued back to back without host syncs
@@ -285,15 +292,15 @@ __global__ __launch_bounds__(PL_BLOCK) void k_plan(const DevBufs* bufs, const Ct
             const int32_t cnt = __hip_atomic_load(&q->count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const int32_t act = __hip_atomic_load(&q->action, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (act == PB_BARRIER) atomicMin(&sB, j);
-            const int dl = pb_delta(act);
-            const int64_t chg = pb_changed_slot(act, pos, aux);
             const bool leaf_only = pb_is_leaf_only(act, ws, we, seg);
+            const int dl = pb_delta(act, leaf_only);
+            const int64_t chg = pb_changed_slot(act, pos, aux);
             sDl[j] = (signed char)dl;
             sChg[j] = (dl != 0 && shift == 0) ? (int32_t)chg : 0;
             int64_t flo = lo, fhi = hi;
             if (leaf_only && shift == 0) {
                 sLeafLo[j] = (int32_t)ws;
-                sCnt0[j] = cnt - ((chg >= ws && chg <= we) ? dl : 0);
+                sCnt0[j] = act == PB_NEWCOL ? (cnt >> 8) : cnt - ((chg >= ws && chg <= we) ? dl : 0);
             } else {
                 sLeafLo[j] = 0; sCnt0[j] = 0;
                 if (leaf_only && lo <= hi) { if (ws < flo) flo = ws; if (we > fhi) fhi = we; }      // (arrays beyond 2^31 slots: always the leaf)
@@ -330,6 +337,7 @@ __global__ __launch_bounds__(PL_BLOCK) void k_plan(const DevBufs* bufs, const Ct
         // included); the leaf must accept every count in between, else the footprint is widened to the leaf
         const int64_t lo0 = lo00, hi0 = hi00;
         const int nwide0 = sNWide;
+        const int tight_mask = rs->tight;
         bool widen[PB_GMAX / PL_BLOCK];
 #pragma unroll
         for (int u = 0; u < PB_GMAX / PL_BLOCK; ++u) {
@@ -348,15 +356,15 @@ __global__ __launch_bounds__(PL_BLOCK) void k_plan(const DevBufs* bufs, const Ct
                 const int i = e >> 1;
                 if ((e & 1) && (sIv[i].lo >> CS) == cl) continue;       // an op chained twice into this bucket's cell is counted once
                 const int32_t ch = sChg[i];
-                if (ch >= l0 && ch <= l1) { if (sDl[i] > 0) ++ins; else ++del; }
+                if (ch >= l0 && ch <= l1) { if (sDl[i] > 0) ins += sDl[i]; else ++del; }
             }
             for (int w2 = 0; w2 < nwide0; ++w2) {
                 const int i = sWide[w2];
                 const int32_t ch = sChg[i];
-                if (ch >= l0 && ch <= l1) { if (sDl[i] > 0) ++ins; else ++del; }
+                if (ch >= l0 && ch <= l1) { if (sDl[i] > 0) ins += sDl[i]; else ++del; }
             }
             const int64_t cnt0 = sCnt0[j];
-            widen[u] = !(cnt0 + ins <= hi0 && cnt0 - del >= lo0);
+            widen[u] = !(cnt0 + ins <= hi0 && cnt0 - del >= lo0) || !((tight_mask >> (sDl[j] == 2 ? 1 : 0)) & 1);
         }
         __syncthreads();                                               // every walk has read the tight hulls
 #pragma unroll
@@ -644,7 +652,7 @@ __device__ void pb_apply_one(KeyArr keys, double* vals, uint64_t* occ, int64_t* 
             delta = -1;
             break;
         case PB_NEWCOL: {                                          // new column + its first element: two inserts in order (see k_plan)
-            const int64_t p1 = pl.pos, ne1 = pl.aux, hmax = pl.count, capacity = ctl->capacity;
+            const int64_t p1 = pl.pos, ne1 = pl.aux, hmax = pl.count & 0xff, capacity = ctl->capacity;
             // ids are labels: the next free table entry, whatever the key order (merged by the sequencer: Ctl::n_pending)
             int64_t idx = 0;
             if (lane == 0) {

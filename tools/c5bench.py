@@ -19,7 +19,8 @@ rows5 = 1 + (bench.splitmix_array(11, ncols5 * per5 * 2) % np.uint64(m5)).astype
 vals5 = bench.unit12(12, ncols5 * per5)
 pos = 0; nw = 0; t_w = 0.0; t_d = 0.0; nd = 0
 deletes = '--deletes' in sys.argv      # delete 5 % of the streamed columns after every batch (tombstones in the colmajor tables)
-for c0 in range(0, ncols5, step):
+nb_max = int(os.environ.get('C5_BATCHES', '1000'))
+for c0 in range(0, min(ncols5, nb_max * step), step):
     I5, J5 = [], []
     for j in range(c0 + 1, c0 + step + 1):
         seen = set()
