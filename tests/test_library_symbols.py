@@ -27,6 +27,15 @@ def test_library_builds_and_exports_header_symbols(dsa):
     assert bound == set(names), sorted(bound ^ set(names))
 
 
+def test_header_is_plain_c(tmp_path):
+    """include/dsa.h is the drop-in boundary: it must be consumable from C (cgo / ccall / ctypes generators) as well as C++."""
+    src = tmp_path / "use_header.c"
+    src.write_text('#include "dsa.h"\nint main(void) { dsa_vec_t* v = 0; (void)v; return DSA_OK; }\n')
+    inc = os.path.join(ROOT, "include")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-I" + inc, str(src)])
+    subprocess.check_call(["g++", "-std=c++11", "-Wall", "-Werror", "-fsyntax-only", "-I" + inc, "-x", "c++", str(src)])
+
+
 def test_product_code_object_is_gfx950_only():
     csrc = os.path.join(ROOT, "dynamicsparsearrays.jl_amd", "csrc")
     out = subprocess.run(["/opt/rocm/lib/llvm/bin/clang-offload-bundler", "--list", "--type=o",
