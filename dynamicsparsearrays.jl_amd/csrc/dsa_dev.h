@@ -405,7 +405,7 @@ hipError_t launch_spmv_gather(KeyArr keys, const double* vals, const uint64_t* o
 constexpr int SPMV_ZFILL = 1;          // launch_spmv_gather mode bits (spmv.hip)
 constexpr int SPMV_PLAIN_STREAM = 2;
 constexpr int64_t SPMV_SPAN_SLOTS = 512;      // slots one wave of k_spmv_gather owns
-constexpr int SPMV_META_BLOCKS = 4096;        // workgroups of k_spmv_meta at most (one table entry per thread up to 1 M entries)
+constexpr int SPMV_META_BLOCKS = 1024;        // workgroups of k_spmv_meta at most (four table entries per thread and step)
 constexpr int SPMV_META_WORDS = 3 * SPMV_META_BLOCKS + 1;     // its device scratch (zeroed once): partials, ticket
 // out6_pinned: six words of PINNED host memory — the five results, then `seq` (written last, system scope: the host polls for it)
 hipError_t launch_spmv_meta(const int64_t* sems, const int64_t* part_keys, int64_t table_len, int64_t capacity,

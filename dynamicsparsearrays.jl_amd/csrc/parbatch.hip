@@ -136,10 +136,34 @@ __device__ Plan pb_plan_one(KeyArr keys, const double* vals, const uint64_t* occ
                         pl.action = PB_NEWCOL; pl.pos = p1; pl.aux = ne1;
                         pl.ws = A; pl.we = B; pl.count = (int32_t)h | ((int32_t)cnt << 8);      // level, and the cells of [A, B] before the round
                         pl.lo = p1 < A ? p1 : A; pl.hi = B;
-                        // accepted by the LEAF: neither insert is followed by a rebalance, the two shifted runs [p1 + 1, ne1] and
-                        // [p1 + 2, ne2] are all that moves: the plan carries that tight hull, the resolve step widens it to the leaf
-                        // unless the leaf accepts every order of the window's ops that change its count (see pb_is_leaf_only)
-                        if (h == 0) { pl.lo = p1; pl.hi = ne2; }
+                        // Both scans accepted by the LEAF of the new semaphore (the element lands in the same leaf): neither insert is
+                        // followed by a rebalance, the two shifted runs [p1 + 1, ne1] and [p1 + 2, ne2] are all that moves — wherever
+                        // the two gaps are inside [A, B] (a run that leaves the leaf pushes one cell out for the one that comes in).
+                        // The plan then carries that TIGHT hull, flag 0x80 and the leaf's cell count; the resolve step widens it to
+                        // [A, B] unless the leaf accepts every order of the window's ops that change its count (pb_is_leaf_only).
+                        const int64_t l0 = ((ip1 - 1) / seg) * seg + 1, l1 = l0 + seg - 1;
+                        if (seg > 64) {
+                            // (counts travel in 7 bits)
+                        } else if (ip1 < l1) {
+                            const int64_t cl = h == 0 ? cnt : pb_wave_count(occ, l0, l1, false);
+                            const int64_t c1 = cl + (ne1 <= l1 ? 1 : 0), c2 = c1 + (ne2 <= l1 ? 1 : 0);
+                            if (ctl->lo[0] <= c1 && c2 <= ctl->hi[0]) {
+                                pl.lo = p1; pl.hi = ne2;
+                                pl.count = (int32_t)h | 0x80 | ((int32_t)cl << 8);
+                            }
+                        } else if (l1 + seg <= capacity) {
+                            // The semaphore lands on the LAST slot of its leaf (the successor's semaphore moves on into the next one), the
+                            // element on the first slot of the next leaf: the first scan reads this leaf — its count unchanged —, the
+                            // second the next one, which receives whatever gaps of its own the two runs fill.  Two leaves to accept
+                            // (flag 0x8000 + the second count); without this a semaphore on slot 512 k needed a window of 1024 slots.
+                            const int64_t m1 = l1 + seg;
+                            const int64_t cl = pb_wave_count(occ, l0, l1, false), cm = pb_wave_count(occ, l1 + 1, m1, false);
+                            const int64_t c2 = cm + (ne1 <= m1 ? 1 : 0) + (ne2 <= m1 ? 1 : 0);
+                            if (ctl->lo[0] <= cl && cl <= ctl->hi[0] && ctl->lo[0] <= cm && c2 <= ctl->hi[0]) {
+                                pl.lo = p1; pl.hi = ne2;
+                                pl.count = (int32_t)h | 0x80 | ((int32_t)cl << 8) | 0x8000 | ((int32_t)cm << 16);
+                            }
+                        }
                         break;
                     }
                 }
@@ -207,14 +231,16 @@ __device__ Plan pb_plan_one(KeyArr keys, const double* vals, const uint64_t* occ
 
 // an op whose density scan stopped at its leaf: nothing but the leaf's COUNT ties it to the rest of the leaf (Plan::lo / hi then hold
 // the tight hull, see pb_plan_one)
-__device__ __forceinline__ bool pb_is_leaf_only(int32_t action, int64_t ws, int64_t we, int64_t seg) {
-    return (action == PB_INS_R || action == PB_INS_L || action == PB_DELETE || action == PB_NEWCOL) && we - ws + 1 == seg;
+__device__ __forceinline__ bool pb_is_leaf_only(int32_t action, int64_t ws, int64_t we, int64_t seg, int32_t count) {
+    if (action == PB_NEWCOL) return (count & 0x80) != 0;
+    return (action == PB_INS_R || action == PB_INS_L || action == PB_DELETE) && we - ws + 1 == seg;
 }
 // slot whose occupancy the op changes, and by how much
 __device__ __forceinline__ int64_t pb_changed_slot(int32_t action, int64_t pos, int64_t aux) { return action == PB_DELETE ? pos : aux; }
-// (a new column accepted by its leaf adds two cells to it — semaphore and element; one with a wider window is covered by its footprint)
+// (a new column accepted by its leaf fills two gaps — Plan::aux and the end of its tight hull; one whose footprint is its window counts
+// for nobody: no leaf-only op can share that window)
 __device__ __forceinline__ int pb_delta(int32_t action, bool leaf_only = false) {
-    return (action == PB_INS_R || action == PB_INS_L) ? 1 : (action == PB_DELETE ? -1 : ((action == PB_NEWCOL && leaf_only) ? 2 : 0));
+    return (action == PB_INS_R || action == PB_INS_L) ? 1 : (action == PB_DELETE ? -1 : ((action == PB_NEWCOL && leaf_only) ? 1 : 0));
 }
 
 __global__ __launch_bounds__(PL_BLOCK) void k_plan(const DevBufs* bufs, const Ctl* ctl, const Op* ops, RoundState* rs, Plan* plans) {
@@ -275,7 +301,10 @@ __global__ __launch_bounds__(PL_BLOCK) void k_plan(const DevBufs* bufs, const Ct
     // The sums per leaf come from a walk of the same spatial hash the overlap test uses: an op that changes the count of leaf L
     // has the changed slot in its hull, so it is chained in the cell of L.
     __shared__ int32_t sChg[PB_GMAX];                                  // slot whose occupancy the op changes (0: none), exact: tight mode needs shift == 0
+    __shared__ int32_t sChg2[PB_GMAX];                                 // the second gap a leaf-accepted new column fills (0: none)
     __shared__ signed char sDl[PB_GMAX];                               // +1 insert, -1 delete, 0 otherwise
+    __shared__ unsigned char sLvl[PB_GMAX];                            // level of the window a leaf-only op falls back to (0 unless a new column)
+    __shared__ signed char sCnt02[PB_GMAX];                            // cells of the NEXT leaf if the op needs that one to accept as well (-1: no)
     __shared__ int32_t sLeafLo[PB_GMAX];                               // first slot of the op's leaf if it is leaf-only, else 0
     __shared__ int32_t sCnt0[PB_GMAX];                                 // cells of that leaf before the round
     const int64_t seg = seg0;
@@ -292,18 +321,22 @@ __global__ __launch_bounds__(PL_BLOCK) void k_plan(const DevBufs* bufs, const Ct
             const int32_t cnt = __hip_atomic_load(&q->count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const int32_t act = __hip_atomic_load(&q->action, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (act == PB_BARRIER) atomicMin(&sB, j);
-            const bool leaf_only = pb_is_leaf_only(act, ws, we, seg);
+            const bool leaf_only = pb_is_leaf_only(act, ws, we, seg, cnt);
             const int dl = pb_delta(act, leaf_only);
             const int64_t chg = pb_changed_slot(act, pos, aux);
+            const bool newcol = act == PB_NEWCOL;
             sDl[j] = (signed char)dl;
             sChg[j] = (dl != 0 && shift == 0) ? (int32_t)chg : 0;
+            sChg2[j] = (newcol && leaf_only && shift == 0) ? (int32_t)hi : 0;
+            sLvl[j] = newcol ? (unsigned char)(cnt & 0x7f) : 0;
             int64_t flo = lo, fhi = hi;
             if (leaf_only && shift == 0) {
-                sLeafLo[j] = (int32_t)ws;
-                sCnt0[j] = act == PB_NEWCOL ? (cnt >> 8) : cnt - ((chg >= ws && chg <= we) ? dl : 0);
+                sLeafLo[j] = newcol ? (int32_t)((pos / seg) * seg + 1) : (int32_t)ws;      // (new column: the leaf of pos + 1, its semaphore)
+                sCnt0[j] = newcol ? ((cnt >> 8) & 0x7f) : cnt - ((chg >= ws && chg <= we) ? dl : 0);
+                sCnt02[j] = (newcol && (cnt & 0x8000)) ? (signed char)((cnt >> 16) & 0x7f) : (signed char)-1;
             } else {
                 sLeafLo[j] = 0; sCnt0[j] = 0;
-                if (leaf_only && lo <= hi) { if (ws < flo) flo = ws; if (we > fhi) fhi = we; }      // (arrays beyond 2^31 slots: always the leaf)
+                if (leaf_only && lo <= hi) { if (ws < flo) flo = ws; if (we > fhi) fhi = we; }      // (arrays beyond 2^31 slots: always the window)
             }
             if (flo <= fhi) { iv.lo = (int32_t)(flo >> shift); iv.hi = (int32_t)(fhi >> shift); }
         }
@@ -346,25 +379,32 @@ __global__ __launch_bounds__(PL_BLOCK) void k_plan(const DevBufs* bufs, const Ct
             if (j >= Gc) continue;
             const int32_t l0 = sLeafLo[j];
             if (l0 == 0) continue;
-            const int32_t l1 = l0 + (int32_t)seg - 1;
             const Iv me = sIv[j];
             const int c0 = me.lo >> CS, c1 = me.hi >> CS;
-            int ins = 0, del = 0;
             if (c1 - c0 > 1) { widen[u] = true; continue; }              // (a tight hull over three cells: keep it simple)
-            const int cl = l0 >> CS;                                    // the cell of the leaf (= one of the hull's cells: the insertion point lies in both)
-            for (int e = sHead[bucket(cl)]; e >= 0; e = sNext[e]) {
-                const int i = e >> 1;
-                if ((e & 1) && (sIv[i].lo >> CS) == cl) continue;       // an op chained twice into this bucket's cell is counted once
-                const int32_t ch = sChg[i];
-                if (ch >= l0 && ch <= l1) { if (sDl[i] > 0) ins += sDl[i]; else ++del; }
-            }
-            for (int w2 = 0; w2 < nwide0; ++w2) {
-                const int i = sWide[w2];
-                const int32_t ch = sChg[i];
-                if (ch >= l0 && ch <= l1) { if (sDl[i] > 0) ins += sDl[i]; else ++del; }
-            }
-            const int64_t cnt0 = sCnt0[j];
-            widen[u] = !(cnt0 + ins <= hi0 && cnt0 - del >= lo0) || !((tight_mask >> (sDl[j] == 2 ? 1 : 0)) & 1);
+            // does the leaf [a, a + seg) with c cells before the round accept every count the window's ops can leave in it?
+            auto accepts = [&](int32_t a, int64_t c) {
+                const int32_t b = a + (int32_t)seg - 1;
+                int ins = 0, del = 0;
+                const int cl = a >> CS;                                 // the cell of the leaf (= one of the hull's cells: the op writes into the leaf)
+                for (int e = sHead[bucket(cl)]; e >= 0; e = sNext[e]) {
+                    const int i = e >> 1;
+                    if ((e & 1) && (sIv[i].lo >> CS) == cl) continue;   // an op chained twice into this bucket's cell is counted once
+                    const int32_t ch = sChg[i], ch2 = sChg2[i];
+                    if (ch >= a && ch <= b) { if (sDl[i] > 0) ++ins; else ++del; }
+                    if (ch2 >= a && ch2 <= b) ++ins;
+                }
+                for (int w2 = 0; w2 < nwide0; ++w2) {
+                    const int i = sWide[w2];
+                    const int32_t ch = sChg[i], ch2 = sChg2[i];
+                    if (ch >= a && ch <= b) { if (sDl[i] > 0) ++ins; else ++del; }
+                    if (ch2 >= a && ch2 <= b) ++ins;
+                }
+                return c + ins <= hi0 && c - del >= lo0;
+            };
+            bool ok = accepts(l0, sCnt0[j]);
+            if (ok && sCnt02[j] >= 0) ok = accepts(l0 + (int32_t)seg, sCnt02[j]);
+            widen[u] = !ok || !((tight_mask >> (sChg2[j] != 0 ? 1 : 0)) & 1);
         }
         __syncthreads();                                               // every walk has read the tight hulls
 #pragma unroll
@@ -372,10 +412,12 @@ __global__ __launch_bounds__(PL_BLOCK) void k_plan(const DevBufs* bufs, const Ct
             const int j = tid + u * PL_BLOCK;
             if (j < Gc && widen[u]) {
                 Iv me = sIv[j];
-                const int32_t l0 = sLeafLo[j], l1 = l0 + (int32_t)seg - 1;
-                if (l0 < me.lo) me.lo = l0;
-                if (l1 > me.hi) me.hi = l1;
-                sIv[j] = me;                                           // (still inside the cells it is chained in: a leaf never straddles a cell)
+                // back to the window the plan was accepted in: the leaf, or the level-H window of a new column
+                const int32_t W = (int32_t)seg << sLvl[j];
+                const int32_t a = ((sLeafLo[j] - 1) / W) * W + 1, b = a + W - 1;
+                if (a < me.lo) me.lo = a;
+                if (b > me.hi) me.hi = b;
+                sIv[j] = me;                                           // (still inside the cells it is chained in: an aligned window of up to PB_MAX_W slots never straddles a cell)
             }
         }
     }
@@ -408,6 +450,17 @@ __global__ __launch_bounds__(PL_BLOCK) void k_plan(const DevBufs* bufs, const Ct
     if (tid == 0) {
 #ifdef DSA_PB_PROF
         printf("resolve: G %d sB %d sC %d load %lld clk conflicts %lld clk\n", G, sB, sC, tr1 - tr0, (long long)clock64() - tr1);
+        if (sC < G && sC <= sB) {      // who cut the prefix: the op at sC and the first earlier op it overlaps (actions, levels, footprints)
+            const Iv me = sIv[sC];
+            for (int i = 0; i < sC; ++i) {
+                const Iv o = sIv[i];
+                if (o.lo <= me.hi && me.lo <= o.hi) {
+                    printf("  cut: j %d act %d lvl %d tight %d [%d,%d] pos %lld  by i %d act %d lvl %d tight %d [%d,%d] pos %lld\n", sC, plans[sC].action, sLvl[sC],
+                           sLeafLo[sC] != 0, me.lo, me.hi, (long long)plans[sC].pos, i, plans[i].action, sLvl[i], sLeafLo[i] != 0, o.lo, o.hi, (long long)plans[i].pos);
+                    break;
+                }
+            }
+        } else if (sB < G) printf("  cut: barrier why %d\n", plans[sB].count & 7);
 #endif
         const int d_prev = rs->d;
         rs->ticket = 0u;                                               // re-armed for the next round
@@ -652,7 +705,10 @@ __device__ void pb_apply_one(KeyArr keys, double* vals, uint64_t* occ, int64_t* 
             delta = -1;
             break;
         case PB_NEWCOL: {                                          // new column + its first element: two inserts in order (see k_plan)
-            const int64_t p1 = pl.pos, ne1 = pl.aux, hmax = pl.count & 0xff, capacity = ctl->capacity;
+            const int64_t p1 = pl.pos, ne1 = pl.aux, hmax = pl.count & 0x7f, capacity = ctl->capacity;
+            // (flag 0x80, tight hull: the leaf accepts both scans whatever the other ops of the round do to its count — the loop below stops at
+            // level 0 on any count it can read; footprint widened by the resolve step: the window is this op's alone, the scan sees the planned state)
+            const int64_t flo = pl.lo < pl.ws ? pl.lo : pl.ws, fhi = pl.hi > pl.we ? pl.hi : pl.we;
             // ids are labels: the next free table entry, whatever the key order (merged by the sequencer: Ctl::n_pending)
             int64_t idx = 0;
             if (lane == 0) {
@@ -675,7 +731,7 @@ __device__ void pb_apply_one(KeyArr keys, double* vals, uint64_t* occ, int64_t* 
             const int64_t s1 = moved ? __hip_atomic_load(sems + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : p1 + 1;
             // setindex!(pcsc, value, key, partition) into the empty partition: find() returns the semaphore, insert behind it
             const int64_t ne2 = pb_next_empty_live(occ, s1, capacity);
-            if (ne2 == 0 || ne2 > pl.hi || s1 < pl.lo || s1 >= pl.hi) {
+            if (ne2 == 0 || ne2 > fhi || s1 < flo || s1 >= fhi) {
                 // cannot happen (see k_plan); if it ever does, fail loudly instead of writing outside the footprint
                 if (lane == 0) atomicExch(fault, 1);      // RoundState::pad = fault flag, read by the host after every burst
                 break;
@@ -766,10 +822,10 @@ __global__ __launch_bounds__(LR_BLOCK) void k_local_rounds(const DevBufs* bufs, 
             int dd = G;
             for (int j = 0; j < G && dd == G; ++j) {
                 if (sPlan[j].action == PB_BARRIER) { dd = j; break; }
-                // (leaf-only ops carry their tight hull: widened to the leaf here — no count bookkeeping in the mini-rounds)
+                // (leaf-only ops carry their tight hull: widened to their window here — no count bookkeeping in the mini-rounds)
                 auto full = [&](const Plan& q, int64_t& lo_, int64_t& hi_) {
                     lo_ = q.lo; hi_ = q.hi;
-                    if (lo_ <= hi_ && pb_is_leaf_only(q.action, q.ws, q.we, ctl->segment_capacity)) { if (q.ws < lo_) lo_ = q.ws; if (q.we > hi_) hi_ = q.we; }
+                    if (lo_ <= hi_ && pb_is_leaf_only(q.action, q.ws, q.we, ctl->segment_capacity, q.count)) { if (q.ws < lo_) lo_ = q.ws; if (q.we > hi_) hi_ = q.we; }
                 };
                 int64_t lo, hi;
                 full(sPlan[j], lo, hi);

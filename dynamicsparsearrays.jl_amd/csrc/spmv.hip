@@ -472,6 +472,7 @@ hipError_t launch_scatter_x(const int64_t* xi, const double* xv, int64_t nx, dou
     return hipGetLastError();
 }
 
+#include <algorithm>
 #include <cstdlib>
 // ---- what the gather launch may assume about one orientation (host cache: SpmvMeta in dsa_host.hip) --------------------
 // out[0] = longest partition extent in slots (semaphore .. slot in front of the next semaphore / end of the array),
@@ -486,15 +487,29 @@ __global__ __launch_bounds__(256) void k_spmv_meta(const int64_t* __restrict__ s
     __shared__ unsigned long long sE[4], sG[4], sB[4];
     __shared__ unsigned int sLast;
     unsigned long long ext = 0, gap = 0, bad = 0;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < table_len; i += (int64_t)gridDim.x * 256) {
-        const int64_t s0 = sems[i];
-        const int64_t s1 = i + 1 < table_len ? sems[i + 1] : capacity + 1;
-        if (s0 <= 0 || s1 <= s0) bad = 1;
-        else { const unsigned long long e = (unsigned long long)(s1 - s0); ext = e > ext ? e : ext; }
-        if (i + 1 < table_len) {
-            const int64_t k0 = part_keys[i], k1 = part_keys[i + 1];
-            if (k1 <= k0) bad = 1;
-            else { const unsigned long long g = (unsigned long long)(k1 - k0); gap = g > gap ? g : gap; }
+    // chunks of 1024 entries per workgroup and step, the 16 loads of a thread's four entries issued together (indices clamped, not
+    // predicated): one memory round trip per step instead of four
+    constexpr int U = 4;
+    for (int64_t c = (int64_t)blockIdx.x * (256 * U); c < table_len; c += (int64_t)gridDim.x * (256 * U)) {
+        int64_t s0[U], s1[U], k0[U], k1[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t i = c + u * 256 + threadIdx.x;
+            const int64_t ic = i < table_len ? i : table_len - 1, in = ic + 1 < table_len ? ic + 1 : ic;
+            s0[u] = sems[ic]; s1[u] = sems[in]; k0[u] = part_keys[ic]; k1[u] = part_keys[in];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t i = c + u * 256 + threadIdx.x;
+            if (i >= table_len) continue;
+            const bool last = i + 1 >= table_len;
+            const int64_t e1 = last ? capacity + 1 : s1[u];
+            if (s0[u] <= 0 || e1 <= s0[u]) bad = 1;
+            else { const unsigned long long e = (unsigned long long)(e1 - s0[u]); ext = e > ext ? e : ext; }
+            if (!last) {
+                if (k1[u] <= k0[u]) bad = 1;
+                else { const unsigned long long g = (unsigned long long)(k1[u] - k0[u]); gap = g > gap ? g : gap; }
+            }
         }
     }
 #pragma unroll
@@ -504,6 +519,8 @@ __global__ __launch_bounds__(256) void k_spmv_meta(const int64_t* __restrict__ s
     }
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     if (lane == 0) { sE[wv] = ext; sG[wv] = gap; sB[wv] = bad; }
+    // the first and the last key of the result: requested by everybody's thread 0 now rather than by the last workgroup at the very end
+    const int64_t key_first = threadIdx.x == 0 ? part_keys[0] : 0, key_last = threadIdx.x == 0 ? part_keys[table_len - 1] : 0;
     __syncthreads();
     unsigned long long* ticket = scratch + 3 * SPMV_META_BLOCKS;
     if (threadIdx.x == 0) {
@@ -511,19 +528,29 @@ __global__ __launch_bounds__(256) void k_spmv_meta(const int64_t* __restrict__ s
         __hip_atomic_store(scratch + 3 * blockIdx.x + 0, ext, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(scratch + 3 * blockIdx.x + 1, gap, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(scratch + 3 * blockIdx.x + 2, bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __threadfence();
-        const unsigned long long t = atomicAdd(ticket, 1ull);
+        // device-scope (write-through) stores, acknowledged before the ticket is taken: a release FENCE here would write back this
+        // XCD's whole L2 once per workgroup (cf. k_plan)
+        __builtin_amdgcn_s_waitcnt(0);
+        const unsigned long long t = __hip_atomic_fetch_add(ticket, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         sLast = (t == (unsigned long long)gridDim.x - 1) ? 1u : 0u;
     }
     __syncthreads();
     if (!sLast) return;
-    // the last workgroup: fold the partials (every other workgroup's stores are visible: fence + ticket)
+    // the last workgroup: fold the partials (every other workgroup's stores were acknowledged at device scope before it took its ticket)
     ext = 0; gap = 0; bad = 0;
-    for (int b = threadIdx.x; b < (int)gridDim.x; b += 256) {
-        const unsigned long long e = __hip_atomic_load(scratch + 3 * b + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned long long g = __hip_atomic_load(scratch + 3 * b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        bad |= __hip_atomic_load(scratch + 3 * b + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        ext = e > ext ? e : ext; gap = g > gap ? g : gap;
+    {   // all partials of a thread requested in one round (device-scope loads cross to another XCD's data: ~2 us per dependent round)
+        constexpr int R = SPMV_META_BLOCKS / 256;
+        unsigned long long pe[R], pg[R], pb[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int b = threadIdx.x + r * 256;
+            const int bc = b < (int)gridDim.x ? b : 0;
+            pe[r] = __hip_atomic_load(scratch + 3 * bc + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            pg[r] = __hip_atomic_load(scratch + 3 * bc + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            pb[r] = __hip_atomic_load(scratch + 3 * bc + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) { ext = pe[r] > ext ? pe[r] : ext; gap = pg[r] > gap ? pg[r] : gap; bad |= pb[r]; }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -537,7 +564,7 @@ __global__ __launch_bounds__(256) void k_spmv_meta(const int64_t* __restrict__ s
         for (int w = 1; w < 4; ++w) { ext = sE[w] > ext ? sE[w] : ext; gap = sG[w] > gap ? sG[w] : gap; bad |= sB[w]; }
         // `out` is PINNED HOST memory: the five words, a system-scope release fence, then the sequence number the host polls for —
         // no copy command, no event, no driver call on the host side of the hand-over
-        const unsigned long long r[5] = {ext, gap, (unsigned long long)part_keys[0], (unsigned long long)part_keys[table_len - 1], bad ? 1ull : 0ull};
+        const unsigned long long r[5] = {ext, gap, (unsigned long long)key_first, (unsigned long long)key_last, bad ? 1ull : 0ull};
         for (int q = 0; q < 5; ++q) __hip_atomic_store(out + q, r[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __atomic_thread_fence(__ATOMIC_RELEASE);
         __hip_atomic_store(out + 5, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -547,8 +574,11 @@ __global__ __launch_bounds__(256) void k_spmv_meta(const int64_t* __restrict__ s
 hipError_t launch_spmv_meta(const int64_t* sems, const int64_t* part_keys, int64_t table_len, int64_t capacity,
                             unsigned long long* scratch, unsigned long long* out6_pinned, unsigned long long seq, hipStream_t stream) {
     if (table_len <= 0) return hipErrorInvalidValue;
-    int64_t blocks = (table_len + 255) / 256;                 // one entry per thread, grid-stride beyond SPMV_META_BLOCKS workgroups
-    if (blocks > SPMV_META_BLOCKS) blocks = SPMV_META_BLOCKS;
+    // four entries per thread and step; beyond 256 workgroups the count grows with the table only slowly (1 M entries: 256 workgroups
+    // x 4 steps 12-15 us, 977 x 1 step 18-20 us, 64 x 16 steps 26-33 us: every workgroup costs a partial + a ticket at device scope)
+    int64_t blocks = (table_len + 1023) / 1024;
+    if (blocks > 256) blocks = std::max<int64_t>(256, std::min<int64_t>(SPMV_META_BLOCKS, table_len >> 12));
+    { static const char* e = getenv("DSA_META_BLOCKS"); if (e && atoi(e) > 0 && blocks > atoi(e)) blocks = atoi(e); }
     hipLaunchKernelGGL(k_spmv_meta, dim3((unsigned)blocks), dim3(256), 0, stream, sems, part_keys, table_len, capacity, scratch, out6_pinned, seq);
     return hipGetLastError();
 }

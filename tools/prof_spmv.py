@@ -26,4 +26,9 @@ y = torch.zeros(m, dtype=torch.float64, device=dev)
 for nx in (ncl, ncl, ncl, 0, 0, 0):
     hip.call("mat_spmv_dense_dev", A.h, 0, 0, C.c_void_p(x.data_ptr()), nx, C.c_void_p(y.data_ptr()), m)
     torch.cuda.synchronize()
+# k_spmv_meta alone at 1 M table entries: a one-element write batch re-arms the prefetch on both orientations (the two launches
+# above ran beside the other orientation's bulk build)
+for _ in range(3):
+    A.set_batch([1], [1], [2.5])
+    hip.call("mat_sync", A.h)
 print("cap", A.info(1)["capacity"])
