@@ -135,6 +135,7 @@ struct Move2Args {
     int64_t ntiles;
     unsigned long long* fault;     // raised by a workgroup that gave up waiting for a status word (see M2_SPIN_MAX)
     double cells_to_gaps;          // E / m: starting guess of #gaps in front of a rank
+    double geom_f, geom_inv_f;     // SpreadGeom::f / inv_f of (Wd, m), divided once on the host (IEEE: the same doubles as on the device)
     int dbg;                       // DSA_DBG_MOVE2 ablation knob (dev only): 1 = no waiting for status words, 2 = no write phase, 4 = closed-form P
 };
 
@@ -172,7 +173,8 @@ __global__ __launch_bounds__(BLOCK) void k_move2(Move2Args a) {
     __shared__ uint32_t sSum[NW];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int64_t t = blockIdx.x;
-    const SpreadGeom g = make_geom(a.Wd, a.m);
+    SpreadGeom g;
+    g.W = a.Wd; g.E = a.Wd - a.m; g.f = a.geom_f; g.inv_f = a.geom_inv_f;
     int64_t P;      // cells in front of this tile
     int c;          // cells of this tile
     if (PACKED) {
@@ -190,10 +192,16 @@ __global__ __launch_bounds__(BLOCK) void k_move2(Move2Args a) {
             const int64_t gw0 = (a.src_lo0 >> 6) + t * (64 * M2_WORDS);
             constexpr int WPT = 64 * M2_WORDS / BLOCK;               // words per thread (8 at 256 threads); NW threads per tile
             uint32_t pc = 0;
+            if (gw0 + 64 * M2_WORDS - 1 < wlast) {                   // the whole group lies inside the window: no range masks (every group but the last)
+                const uint64_t* __restrict__ wp = a.src_occ + gw0 + tid * WPT;
 #pragma unroll
-            for (int u = 0; u < WPT; ++u) {
-                const int64_t w = gw0 + (int64_t)tid * WPT + u;
-                if (w <= wlast) pc += popc64(a.src_occ[w] & range_mask_for_word(w, a.src_lo0, a.src_hi0));
+                for (int u = 0; u < WPT; ++u) pc += popc64(wp[u]);
+            } else {
+#pragma unroll
+                for (int u = 0; u < WPT; ++u) {
+                    const int64_t w = gw0 + (int64_t)tid * WPT + u;
+                    if (w <= wlast) pc += popc64(a.src_occ[w] & range_mask_for_word(w, a.src_lo0, a.src_hi0));
+                }
             }
 #pragma unroll
             for (int o = 1; o < NW; o <<= 1) pc += __shfl_xor(pc, o, 64);      // lanes NW*i .. NW*i + NW-1 hold one tile
@@ -212,15 +220,30 @@ __global__ __launch_bounds__(BLOCK) void k_move2(Move2Args a) {
         //         waiting for them, the slots of this wave's 8 words — lane <-> slot, occupied or not: the lines are fetched
         //         whole anyway, and the loads do not depend on the occupancy word.  16 loads in flight per lane.
         uint64_t myword = 0;
-        if (lane < M2_WORDS && w0 + lane <= wlast) myword = a.src_occ[w0 + lane] & range_mask_for_word(w0 + lane, a.src_lo0, a.src_hi0);
         constexpr int WPW = M2_WORDS / NW;     // 8 at 256 threads
         key_t kk[WPW]; double vv[WPW];
+        if (w0 + M2_WORDS - 1 < wlast) {
+            // a tile inside the window (every tile but the last): no range masks, no clamping, 32-bit offsets from a scalar base —
+            // at 2^20 slots this kernel is bound by instruction issue (the 64-bit index arithmetic of the general form was ~150
+            // instructions per wave)
+            if (lane < M2_WORDS) myword = a.src_occ[w0 + lane];
+            const key_t* __restrict__ kp = srck + (w0 << 6);
+            const double* __restrict__ vp = a.src_vals + (w0 << 6);
+            const unsigned off = (unsigned)(wv * (WPW * 64) + lane);
 #pragma unroll
-        for (int u = 0; u < WPW; ++u) {
-            int64_t sidx = ((w0 + wv * WPW + u) << 6) + lane;
-            if (sidx > a.src_hi0) sidx = a.src_hi0;               // a tile that ends behind the source range
-            kk[u] = __builtin_nontemporal_load(srck + sidx);
-            vv[u] = __builtin_nontemporal_load(a.src_vals + sidx);
+            for (int u = 0; u < WPW; ++u) {
+                kk[u] = __builtin_nontemporal_load(kp + (off + u * 64));
+                vv[u] = __builtin_nontemporal_load(vp + (off + u * 64));
+            }
+        } else {
+            if (lane < M2_WORDS && w0 + lane <= wlast) myword = a.src_occ[w0 + lane] & range_mask_for_word(w0 + lane, a.src_lo0, a.src_hi0);
+#pragma unroll
+            for (int u = 0; u < WPW; ++u) {
+                int64_t sidx = ((w0 + wv * WPW + u) << 6) + lane;
+                if (sidx > a.src_hi0) sidx = a.src_hi0;               // a tile that ends behind the source range
+                kk[u] = __builtin_nontemporal_load(srck + sidx);
+                vv[u] = __builtin_nontemporal_load(a.src_vals + sidx);
+            }
         }
         // ---- 2. ask for the prefix: the tile's entry (wave 0) and the totals of the groups in front (waves 1-3); in the
         //         steady state the table is long complete and the answers arrive with the slots
@@ -235,12 +258,14 @@ __global__ __launch_bounds__(BLOCK) void k_move2(Move2Args a) {
         // ---- compact into LDS by in-tile rank ---------------------------------------------------------------------------------
         const uint32_t mypc = popc64(myword);
         const uint32_t myex = wave_excl_scan(mypc);
-        c = (int)__shfl(myex + mypc, M2_WORDS - 1, 64);
+        c = (int)__builtin_amdgcn_readlane((int)(myex + mypc), M2_WORDS - 1);
+        const int wv_s = __builtin_amdgcn_readfirstlane(wv);       // (wave-uniform: the word of another lane comes by v_readlane, not through the LDS crossbar)
 #pragma unroll
         for (int u = 0; u < WPW; ++u) {
-            const int j = wv * WPW + u;
-            const uint64_t wm = __shfl(myword, j, 64);
-            const uint32_t wb = __shfl(myex, j, 64);
+            const int j = wv_s * WPW + u;
+            const uint64_t wm = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(myword >> 32), j) << 32) |
+                                (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)myword, j);
+            const uint32_t wb = (uint32_t)__builtin_amdgcn_readlane((int)myex, j);
             if ((wm >> lane) & 1ull) {
                 const int r = (int)wb + popc64(wm & mask_lt(lane));
                 sK[r] = kk[u]; sV[r] = vv[u];
@@ -271,60 +296,93 @@ __global__ __launch_bounds__(BLOCK) void k_move2(Move2Args a) {
         if (a.dbg & 5) P = (int64_t)((double)t * (double)a.m / (double)a.ntiles);
     }
     // ---- 4. owned destination offsets (Q0, Q1] ------------------------------------------------------------------------------
-    const int64_t Q0 = P == 0 ? 0 : dest_of_rank(g, (int)P, a.cells_to_gaps);
-    const int64_t Q1 = t == a.ntiles - 1 ? a.Wd : (c == 0 ? Q0 : dest_of_rank(g, (int)(P + c), a.cells_to_gaps));
+    // At 2^20 slots the kernel is bound by instruction issue, not by memory (ablations, round 3: without the stores of this phase
+    // 9-10 us of 10.7, without the phase 4.9): offsets are 32-bit, and a group of 128 offsets that the tile owns completely — all
+    // but the first and the last one — takes a path without ownership tests, with one gather per occupancy word instead of
+    // four bit interleaves.
+    const int Q0 = P == 0 ? 0 : dest_of_rank(g, (int)P, a.cells_to_gaps);
+    const int Q1 = t == a.ntiles - 1 ? (int)a.Wd : (c == 0 ? Q0 : dest_of_rank(g, (int)(P + c), a.cells_to_gaps));
     if (Q1 <= Q0 || (a.dbg & 2)) return;
-    const int64_t g_first = Q0 & ~(int64_t)127, g_last = (Q1 - 1) & ~(int64_t)127;
-    for (int64_t gq = g_first + (int64_t)wv * 128; gq <= g_last; gq += NW * 128) {
-        const int64_t qa = gq + 2 * lane + 1;                         // 1-based offsets qa, qa+1
+    const int Wd = (int)a.Wd, Pi = (int)P;
+    key_t* __restrict__ dk = dstk + a.dst_lo0;                       // offset q (1-based) lives in dk[q - 1]
+    double* __restrict__ dv = a.dst_vals + a.dst_lo0;
+    uint64_t* __restrict__ dw = a.dst_occ + (a.dst_lo0 >> 6);        // (windows of this kernel start on an occupancy word)
+    const key_t* __restrict__ pk = srck + a.src_lo0;                 // PACKED: the cell of rank r is pk[r - 1]
+    const double* __restrict__ pv = a.src_vals + a.src_lo0;
+    typedef double d2v __attribute__((ext_vector_type(2)));
+    typedef key_t k2v __attribute__((ext_vector_type(2)));
+    const int g_first = Q0 & ~127, g_last = (Q1 - 1) & ~127;
+    for (int gq = g_first + wv * 128; gq <= g_last; gq += NW * 128) {
+        const int qa = gq + 2 * lane + 1;                             // 1-based offsets qa, qa + 1
+        if (gq >= Q0 && gq + 128 <= Q1) {
+            // ---- every offset of the group is owned (and inside the window)
+            int k; bool gp0, gp1;
+            gap_pair(g, qa, &k, &gp0, &gp1);      // (a straight-line form with one predicated step each way was slower: 9.0 vs 8.8 us at 2^20)
+            const int r0 = qa - k, r1 = qa + 1 - k;                   // 1-based ranks of the cells on qa / qa + 1 (when not gaps)
+            key_t k0 = 0, k1 = 0;
+            double v0 = 0.0, v1 = 0.0;
+            if (PACKED) {
+                if (!gp0) { k0 = pk[r0 - 1]; v0 = pv[r0 - 1]; }
+                if (!gp1) { k1 = pk[r1 - 1]; v1 = pv[r1 - 1]; }
+            } else {
+                if (!gp0) { k0 = sK[r0 - Pi - 1]; v0 = sV[r0 - Pi - 1]; }
+                if (!gp1) { k1 = sK[r1 - Pi - 1]; v1 = sV[r1 - Pi - 1]; }
+            }
+            if (a.sems != nullptr) {                                  // spread! with semaphores  src/moves.jl:160-166
+                if (!gp0 && k0 == SEM_KEY) a.sems[(int64_t)v0 - 1] = a.dst_lo0 + qa;
+                if (!gp1 && k1 == SEM_KEY) a.sems[(int64_t)v1 - 1] = a.dst_lo0 + qa + 1;
+            }
+            k2v kv; kv.x = k0; kv.y = k1;
+            d2v vv2; vv2.x = v0; vv2.y = v1;
+            __builtin_nontemporal_store(kv, reinterpret_cast<k2v*>(dk + qa - 1));
+            __builtin_nontemporal_store(vv2, reinterpret_cast<d2v*>(dv + qa - 1));
+            // occupancy words: bit i of a word = lane i >> 1 of the half, even offset for even i
+            const int occ01 = (gp0 ? 0 : 1) | (gp1 ? 0 : 2);
+            const int lo = __shfl(occ01, lane >> 1, 64), hi = __shfl(occ01, 32 + (lane >> 1), 64);
+            const uint64_t w0 = __ballot((lo >> (lane & 1)) & 1), w1 = __ballot((hi >> (lane & 1)) & 1);
+            if (lane == 0) { dw[gq >> 6] = w0; dw[(gq >> 6) + 1] = w1; }
+            continue;
+        }
+        // ---- the first / the last group of the tile: offsets of the neighbours, the end of the window
         key_t k2[2] = {0, 0};
         double v2[2] = {0.0, 0.0};
         bool o2[2] = {false, false};
-        if (qa <= a.Wd) {
+        if (qa <= Wd) {
             int k; bool gp[2];
-            gap_pair(g, (int)qa, &k, &gp[0], &gp[1]);
+            gap_pair(g, qa, &k, &gp[0], &gp[1]);
             bool own[2];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const bool gap = gp[j];
-                if (j == 1 && gap) ++k;
-                own[j] = qa + j > Q0 && qa + j <= Q1;
-                o2[j] = !gap && qa + j <= a.Wd;
-                if (o2[j] && own[j]) {
-                    const int64_t rank = qa + j - k;
-                    if (PACKED) {
-                        k2[j] = srck[a.src_lo0 + rank - 1];
-                        v2[j] = a.src_vals[a.src_lo0 + rank - 1];
-                    } else {
-                        k2[j] = sK[rank - P - 1];
-                        v2[j] = sV[rank - P - 1];
-                    }
-                    if (a.sems != nullptr && k2[j] == SEM_KEY) a.sems[(int64_t)v2[j] - 1] = a.dst_lo0 + qa + j;   // 1-based slot
+            for (int jj = 0; jj < 2; ++jj) {
+                const bool gap = gp[jj];
+                if (jj == 1 && gap) ++k;
+                own[jj] = qa + jj > Q0 && qa + jj <= Q1;
+                o2[jj] = !gap && qa + jj <= Wd;
+                if (o2[jj] && own[jj]) {
+                    const int rank = qa + jj - k;
+                    if (PACKED) { k2[jj] = pk[rank - 1]; v2[jj] = pv[rank - 1]; }
+                    else { k2[jj] = sK[rank - Pi - 1]; v2[jj] = sV[rank - Pi - 1]; }
+                    if (a.sems != nullptr && k2[jj] == SEM_KEY) a.sems[(int64_t)v2[jj] - 1] = a.dst_lo0 + qa + jj;   // 1-based slot
                 }
             }
-            const int64_t d = a.dst_lo0 + qa - 1;
             if (own[0] && own[1]) {
-                typedef double d2v __attribute__((ext_vector_type(2)));
-                d2v vv2; vv2.x = v2[0]; vv2.y = v2[1];
-                typedef key_t k2v __attribute__((ext_vector_type(2)));
                 k2v kv; kv.x = k2[0]; kv.y = k2[1];
-                __builtin_nontemporal_store(kv, reinterpret_cast<k2v*>(dstk + d));
-                __builtin_nontemporal_store(vv2, reinterpret_cast<d2v*>(a.dst_vals + d));
+                d2v vv2; vv2.x = v2[0]; vv2.y = v2[1];
+                __builtin_nontemporal_store(kv, reinterpret_cast<k2v*>(dk + qa - 1));
+                __builtin_nontemporal_store(vv2, reinterpret_cast<d2v*>(dv + qa - 1));
             } else if (own[0]) {
-                dstk[d] = k2[0]; a.dst_vals[d] = v2[0];
+                dk[qa - 1] = k2[0]; dv[qa - 1] = v2[0];
             } else if (own[1]) {
-                dstk[d + 1] = k2[1]; a.dst_vals[d + 1] = v2[1];
+                dk[qa] = k2[1]; dv[qa] = v2[1];
             }
         }
         // occupancy words are closed-form: written by the owner of their first offset
         const uint64_t be = __ballot(o2[0]);
         const uint64_t bo = __ballot(o2[1]);
         if (lane == 0) {
-            const int64_t w = (a.dst_lo0 + gq) >> 6;
             if (gq + 1 > Q0 && gq + 1 <= Q1)
-                a.dst_occ[w] = spread_bits32((uint32_t)be) | (spread_bits32((uint32_t)bo) << 1);
-            if (gq + 64 < a.Wd && gq + 65 > Q0 && gq + 65 <= Q1)
-                a.dst_occ[w + 1] = spread_bits32((uint32_t)(be >> 32)) | (spread_bits32((uint32_t)(bo >> 32)) << 1);
+                dw[gq >> 6] = spread_bits32((uint32_t)be) | (spread_bits32((uint32_t)bo) << 1);
+            if (gq + 64 < Wd && gq + 65 > Q0 && gq + 65 <= Q1)
+                dw[(gq >> 6) + 1] = spread_bits32((uint32_t)(be >> 32)) | (spread_bits32((uint32_t)(bo >> 32)) << 1);
         }
     }
 }
@@ -657,6 +715,7 @@ hipError_t launch_rebalance(KeyArr src_keys, const double* src_vals, const uint6
         a.Wd = dst_we - dst_ws + 1; a.m = m;
         a.sems = sems;
         a.cells_to_gaps = m > 0 ? (double)(a.Wd - m) / (double)m : 0.0;
+        { const SpreadGeom hg = make_geom(a.Wd, m); a.geom_f = hg.f; a.geom_inv_f = hg.inv_f; }
         { static const char* e = getenv("DSA_DBG_MOVE2"); a.dbg = e ? atoi(e) : 0; }
         if (((src_ws - 1) & 63) != 0 && !src_packed) return hipErrorInvalidValue;     // source windows start on an occupancy word
         // ranks, gap indices and offsets inside a window are 32-bit in the kernel (dest_of_rank, gap_pair: single-instruction
@@ -670,9 +729,10 @@ hipError_t launch_rebalance(KeyArr src_keys, const double* src_vals, const uint6
             return hipGetLastError();
         }
         const int64_t Ws = src_we - src_ws + 1;
-        // few tiles (windows up to 2^22 slots): the chain occupancy -> table -> write is latency, not bandwidth: 8 waves per tile; above: 4.
+        // up to 2^24 slots: 8 waves per tile; above: 4.
         // Tiles of 1024 slots (twice the workgroups, half the write phase each; DSA_MOVE2_TILE=1024) were measured in round 3 and LOSE:
-        // 2^20 slots 11.1 vs 10.1 us, 2^21 18.0 vs 15.0, 2^22 26.1 vs 25.2, 2^24 76.7 vs 77.7 — more status words to publish and poll
+        // 2^20 slots 11.1 vs 10.1 us, 2^21 18.0 vs 15.0, 2^22 26.1 vs 25.2, 2^24 76.7 vs 77.7 — more status words to publish and poll.  Tiles of
+        // 4096 slots (half the per-tile fixed work) bought nothing either: 8.6 vs 8.2 us at 2^20 with 512 threads, 8.0 with 1024 (and 72.6 vs 69 at 2^24)
         static const int force_block = [] { const char* e = getenv("DSA_MOVE2_BLOCK"); return e ? atoi(e) : 0; }();
         static const int force_tile = [] { const char* e = getenv("DSA_MOVE2_TILE"); return e ? atoi(e) : 0; }();
         const int tile = force_tile == M2_TILE_SMALL ? M2_TILE_SMALL : M2_TILE_BIG;
@@ -685,7 +745,9 @@ hipError_t launch_rebalance(KeyArr src_keys, const double* src_vals, const uint6
         }
         a.status = work->status; a.gen = work->gen;
         a.fault = work->status + work->status_cap - 1;              // the last word of the table is not a status word (alloc_work)
-        const int block = force_block ? force_block : (a.ntiles <= 2048 ? 512 : 256);      // measured 512 vs 256 threads: 2^20 9.9 vs 11.5 us, 2^22 27.2 vs 29.3, 2^24 83.5 vs 77.4 (1024 threads: 12.9 / 41 / 152)
+        // measured, 512 vs 256 threads (after the write phase lost two thirds of its instructions): 2^20 8.8 vs 10.4 us, 2^22 22.7 vs 25.0,
+        // 2^23 38.5 vs 41.4, 2^24 69.2-70.8 vs 72.6-75.3, 2^25 135-141 vs 136-139, 2^26 285-296 vs 270-281 (1024 threads lose everywhere)
+        const int block = force_block ? force_block : (a.ntiles <= 8192 ? 512 : 256);
 #define DSA_MOVE2_LAUNCH(W_, B_, T_) hipLaunchKernelGGL((k_move2<false, W_, B_, T_>), dim3((unsigned)a.ntiles), dim3(B_), 0, stream, a)
         const bool wide = a.src_keys.wide != 0;
         if (tile == M2_TILE_SMALL) {
