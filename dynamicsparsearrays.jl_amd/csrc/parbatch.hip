@@ -275,7 +275,8 @@ __global__ __launch_bounds__(PL_BLOCK) void k_plan(const DevBufs* bufs, const Ct
     // ---- resolve, by the workgroup that finishes last (a ticket; no second and third launch per round): folds the previous round's
     //      prefix into the cursor and decides this round's prefix d = min(first BARRIER, smallest j whose footprint overlaps the footprint
     //      of an earlier op): ops [0, d) are pairwise disjoint, each sees exactly the state it was planned on.  k_apply works on (cursor, d).
-    __shared__ int sLast, sC, sB;
+    __shared__ int sLast, sC, sB, sSumDn, sSumRebN;
+    __shared__ unsigned int sSumRebW;
     // footprints as 32-bit pairs (arrays beyond 2^31 slots: in units of 2^shift slots, rounded outwards — conservative)
     struct alignas(8) Iv { int32_t lo, hi; };
     __shared__ Iv sIv[PB_GMAX + 8];
@@ -284,7 +285,7 @@ __global__ __launch_bounds__(PL_BLOCK) void k_plan(const DevBufs* bufs, const Ct
     if (threadIdx.x == 0) {
         const unsigned t = __hip_atomic_fetch_add(&rs->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         sLast = t == gridDim.x - 1 ? 1 : 0;
-        sC = G; sB = G;
+        sC = G; sB = G; sSumDn = 0; sSumRebN = 0; sSumRebW = 0u;
     }
     __syncthreads();
     if (!sLast) return;
@@ -304,6 +305,8 @@ __global__ __launch_bounds__(PL_BLOCK) void k_plan(const DevBufs* bufs, const Ct
     __shared__ int32_t sChg2[PB_GMAX];                                 // the second gap a leaf-accepted new column fills (0: none)
     __shared__ signed char sDl[PB_GMAX];                               // +1 insert, -1 delete, 0 otherwise
     __shared__ unsigned char sLvl[PB_GMAX];                            // level of the window a leaf-only op falls back to (0 unless a new column)
+    __shared__ signed char sDn[PB_GMAX];                               // what an insert / delete adds to Ctl::nb_elements (a new column counts for itself in k_apply)
+    __shared__ unsigned short sRebW[PB_GMAX];                          // slots of the window an insert / delete rebalances (0: none)
     __shared__ signed char sCnt02[PB_GMAX];                            // cells of the NEXT leaf if the op needs that one to accept as well (-1: no)
     __shared__ int32_t sLeafLo[PB_GMAX];                               // first slot of the op's leaf if it is leaf-only, else 0
     __shared__ int32_t sCnt0[PB_GMAX];                                 // cells of that leaf before the round
@@ -329,6 +332,9 @@ __global__ __launch_bounds__(PL_BLOCK) void k_plan(const DevBufs* bufs, const Ct
             sChg[j] = (dl != 0 && shift == 0) ? (int32_t)chg : 0;
             sChg2[j] = (newcol && leaf_only && shift == 0) ? (int32_t)hi : 0;
             sLvl[j] = newcol ? (unsigned char)(cnt & 0x7f) : 0;
+            const bool insdel = act == PB_INS_R || act == PB_INS_L || act == PB_DELETE;
+            sDn[j] = insdel ? (signed char)(act == PB_DELETE ? -1 : 1) : (signed char)0;
+            sRebW[j] = (insdel && we - ws + 1 != seg) ? (unsigned short)(we - ws + 1) : (unsigned short)0;      // (<= PB_MAX_W)
             int64_t flo = lo, fhi = hi;
             if (leaf_only && shift == 0) {
                 sLeafLo[j] = newcol ? (int32_t)((pos / seg) * seg + 1) : (int32_t)ws;      // (new column: the leaf of pos + 1, its semaphore)
@@ -447,6 +453,18 @@ __global__ __launch_bounds__(PL_BLOCK) void k_plan(const DevBufs* bufs, const Ct
         }
     }
     __syncthreads();
+    {   // what the prefix's inserts / deletes do to the element count and the rebalance statistics: added to the control block ONCE, here
+        // (k_apply's waves used to add them one by one: ~500 atomics per round on the same words)
+        int dd = sC < sB ? sC : sB;
+        if (dd > G) dd = G;
+        int dn = 0, rn = 0;
+        unsigned int rw = 0u;
+        for (int j = tid; j < dd; j += PL_BLOCK) { dn += sDn[j]; const unsigned int w = sRebW[j]; if (w) { ++rn; rw += w; } }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { dn += __shfl_xor(dn, o, 64); rn += __shfl_xor(rn, o, 64); rw += __shfl_xor(rw, o, 64); }
+        if ((tid & 63) == 0 && (dn != 0 || rn != 0)) { atomicAdd(&sSumDn, dn); atomicAdd(&sSumRebN, rn); atomicAdd(&sSumRebW, rw); }
+    }
+    __syncthreads();
     if (tid == 0) {
 #ifdef DSA_PB_PROF
         printf("resolve: G %d sB %d sC %d load %lld clk conflicts %lld clk\n", G, sB, sC, tr1 - tr0, (long long)clock64() - tr1);
@@ -479,6 +497,15 @@ __global__ __launch_bounds__(PL_BLOCK) void k_plan(const DevBufs* bufs, const Ct
             rs->stop = 1; rs->d = 0; return;
         }
         rs->d = d;
+        if (d > 0) {
+            Ctl* c = const_cast<Ctl*>(ctl);
+            if (sSumDn != 0) atomicAdd((unsigned long long*)&c->nb_elements, (unsigned long long)(long long)sSumDn);
+            if (sSumRebN != 0) {
+                atomicAdd((unsigned long long*)&c->stat_rebalances, (unsigned long long)sSumRebN);
+                atomicAdd((unsigned long long*)&c->stat_window_slots, (unsigned long long)sSumRebW);
+                atomicAdd((unsigned long long*)&c->stat_small_rebalances, (unsigned long long)sSumRebN);
+            }
+        }
         int Gn = d + (d >> 1) + 32;                                      // the next window: half as much again as what ran (the resolve step costs per planned op)
         if (Gn < 64) Gn = 64;
         if (Gn > PB_GMAX) Gn = PB_GMAX;
@@ -671,8 +698,10 @@ __device__ bool pb_scan_and_rebalance_live(KeyArr keys, double* vals, uint64_t* 
 
 // ONE planned op applied by one wave: shift, write, occupancy update, then the small-window pack + spread through the wave's LDS slice
 // (sK / sV).  fault: raised if an op leaves its planned footprint (cannot happen, checked by the host).
+// counted: the caller has already added the element delta of inserts / deletes and the statistics of their rebalances to the control
+// block (k_plan's resolve step, once per round: one atomic per op on the same three or four words cost 4 us per round of ~500 ops).
 __device__ void pb_apply_one(KeyArr keys, double* vals, uint64_t* occ, int64_t* sems, int64_t* col_keys, uint8_t* col_live, Ctl* ctl,
-                             int32_t* fault, const Op op, const Plan pl, int64_t* sK, double* sV) {
+                             int32_t* fault, const Op op, const Plan pl, int64_t* sK, double* sV, const bool counted) {
     const int lane = lane_id();
     const int64_t seg = ctl->segment_capacity;
     int64_t delta = 0;
@@ -746,12 +775,12 @@ __device__ void pb_apply_one(KeyArr keys, double* vals, uint64_t* occ, int64_t* 
             break;
     }
     if (delta != 0) {
-        if (lane == 0) atomicAdd((unsigned long long*)&ctl->nb_elements, (unsigned long long)delta);
+        if (lane == 0 && !counted) atomicAdd((unsigned long long*)&ctl->nb_elements, (unsigned long long)delta);
         const int64_t W = pl.we - pl.ws + 1;
         if (W != seg) {                                            // _even_rebalance!  src/pma.jl:94-103
             __builtin_amdgcn_s_waitcnt(0);                         // the op's own stores / atomics are complete
             pb_wave_rebalance(keys, vals, occ, sems, pl.ws, pl.we, pl.count, sK, sV);
-            if (lane == 0) {
+            if (lane == 0 && !counted) {
                 atomicAdd((unsigned long long*)&ctl->stat_rebalances, 1ull);
                 atomicAdd((unsigned long long*)&ctl->stat_window_slots, (unsigned long long)W);
                 atomicAdd((unsigned long long*)&ctl->stat_small_rebalances, 1ull);
@@ -777,7 +806,7 @@ __global__ __launch_bounds__(PB_BLOCK) void k_apply(const DevBufs* bufs, Ctl* ct
     double* sV = reinterpret_cast<double*>(pb_lds + (size_t)(PB_BLOCK / 64) * PB_MAX_W * sizeof(int64_t)) + (size_t)wv * PB_MAX_W;
     const Plan pl = plans[w];
     const Op op = ops[i0 + w];
-    pb_apply_one(keys, vals, occ, sems, col_keys, col_live, ctl, &const_cast<RoundState*>(rs)->pad, op, pl, sK, sV);
+    pb_apply_one(keys, vals, occ, sems, col_keys, col_live, ctl, &const_cast<RoundState*>(rs)->pad, op, pl, sK, sV, true);
 }
 
 // ---- local rounds: the same plan / resolve / apply, by ONE workgroup, for phases with little parallelism --------------------------
@@ -841,7 +870,7 @@ __global__ __launch_bounds__(LR_BLOCK) void k_local_rounds(const DevBufs* bufs, 
         __syncthreads();
         const int dd = sD;
         if (dd == 0) { stop = 1; why = sPlan[0].count & 7; break; }       // the op at the cursor cannot be planned: the sequencer's
-        if (wv < dd) pb_apply_one(keys, vals, occ, sems, col_keys, col_live, ctl, &rs->pad, ops[cursor + wv], sPlan[wv], sK, sV);
+        if (wv < dd) pb_apply_one(keys, vals, occ, sems, col_keys, col_live, ctl, &rs->pad, ops[cursor + wv], sPlan[wv], sK, sV, false);
         cursor += dd; par_ops += dd; ++rounds;
         full_streak = dd == LR_WAVES ? full_streak + 1 : 0;
         single_streak = (dd == 1 && G > 1) ? single_streak + 1 : 0;
