@@ -245,6 +245,7 @@ __device__ __forceinline__ int pb_delta(int32_t action, bool leaf_only = false) 
 
 __global__ __launch_bounds__(PL_BLOCK) void k_plan(const DevBufs* bufs, const Ctl* ctl, const Op* ops, RoundState* rs, Plan* plans) {
     // the round's window of ops comes from the device-resident cursor: rounds are enqueued back to back without host syncs
+    [[maybe_unused]] const long long tk0 = clock64();      // dev profile, -DDSA_PB_PROF
     if (rs->stop) return;
     const DevBufs db = *bufs;
     const KeyArr keys{db.keys, db.wide, 0};
@@ -281,6 +282,7 @@ __global__ __launch_bounds__(PL_BLOCK) void k_plan(const DevBufs* bufs, const Ct
     struct alignas(8) Iv { int32_t lo, hi; };
     __shared__ Iv sIv[PB_GMAX + 8];
     __builtin_amdgcn_s_waitcnt(0);                                     // the plan stores of this wave have been acknowledged at device scope
+    [[maybe_unused]] const long long tk1 = clock64();
     __syncthreads();
     if (threadIdx.x == 0) {
         const unsigned t = __hip_atomic_fetch_add(&rs->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -467,7 +469,8 @@ __global__ __launch_bounds__(PL_BLOCK) void k_plan(const DevBufs* bufs, const Ct
     __syncthreads();
     if (tid == 0) {
 #ifdef DSA_PB_PROF
-        printf("resolve: G %d sB %d sC %d load %lld clk conflicts %lld clk\n", G, sB, sC, tr1 - tr0, (long long)clock64() - tr1);
+        printf("resolve: G %d sB %d sC %d load %lld clk conflicts %lld clk | this workgroup: entry -> planned %lld clk, -> ticket %lld clk\n", G, sB, sC, tr1 - tr0,
+               (long long)clock64() - tr1, tk1 - tk0, tr0 - tk1);
         if (sC < G && sC <= sB) {      // who cut the prefix: the op at sC and the first earlier op it overlaps (actions, levels, footprints)
             const Iv me = sIv[sC];
             for (int i = 0; i < sC; ++i) {
