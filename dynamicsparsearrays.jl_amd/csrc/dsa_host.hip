@@ -1274,6 +1274,8 @@ void prefetch_spmv_meta(Pma& P) {
         std::memset(P.h_meta, 0, 8 * sizeof(int64_t));
         P.meta_seq = 0;
     }
+    { static const char* dbg = getenv("DSA_DBG_SPMV_META"); if (dbg) fprintf(stderr, "prefetch_spmv_meta: launch for epoch %lld (cached %lld, in flight %lld)\n",
+                                                                               (long long)P.layout_epoch, (long long)P.spmv_meta.epoch, (long long)P.meta_inflight_epoch); }
     // the kernel writes its five words and then the sequence number straight into pinned host memory
     hipError_t e = launch_spmv_meta(P.sems, P.col_keys, P.h_ctl->table_len, P.h_ctl->capacity, P.d_meta,
                                     reinterpret_cast<unsigned long long*>(P.h_meta), ++P.meta_seq, P.stream);

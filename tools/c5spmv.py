@@ -18,6 +18,8 @@ t_call = t_sync = t_second = 0.0; n = 0
 for c0 in range(0, ncols5, every):
     sl = slice(c0 * per5, (c0 + every) * per5)
     B.set_batch(I5[sl], J5[sl], V5[sl])
+    if "--sync" in sys.argv:      # like bench.py's config-5 leg: the batch's trailing device work (table merge, meta prefetch) is waited for first
+        hip.call("mat_sync", B.h)
     t0 = time.perf_counter()
     hip.call("mat_spmv_dense_dev", B.h, 0, 0, C.c_void_p(xd.data_ptr()), c0 + every, C.c_void_p(yd.data_ptr()), m5)
     t1 = time.perf_counter()
