@@ -350,8 +350,12 @@ struct RoundState {
     int64_t rounds, par_ops;
     int64_t why[8];        // dev: what cut the prefixes (index = Plan::count of the first BARRIER op; 7 = a conflict)
     int32_t tight;         // tight footprints (parbatch.hip): bit 0 leaf-accepted inserts / deletes, bit 1 leaf-accepted new columns (dev knob DSA_TIGHT, default 3)
-    int32_t pad2;
+    int32_t seq;           // number of the burst (set by the host): k_publish hands it back with the state
 };
+// where a burst leaves its result for the host: the pinned mirrors of the round state and of the control block, and the word the
+// host polls (the burst number) — written by k_publish, the last kernel of a burst, with system-scope stores: no copy commands, no
+// stream synchronisation on the host side (nullptr: the host copies and synchronises itself)
+struct BurstPublish { RoundState* host_rs; Ctl* host_ctl; unsigned long long* host_seq; };
 constexpr int ROUND_GMAX = 1024;       // ops planned per round at most (parbatch.hip: one wave each; the host sizes the plan array)
 struct BurstGraph {        // cached hipGraph of one burst of rounds (host-side)
     hipGraphExec_t exec = nullptr; hipGraph_t graph = nullptr; hipStream_t stream = nullptr;
@@ -364,11 +368,11 @@ struct BurstGraph {        // cached hipGraph of one burst of rounds (host-side)
 // _extend! cost ~1 ms a time while an array was growing)
 struct DevBufs { void* keys; double* vals; uint64_t* occ; int64_t* sems; int64_t* col_keys; uint8_t* col_live; int32_t wide, pad; };
 hipError_t launch_burst(const DevBufs* bufs, Ctl* ctl, const Op* ops, RoundState* rs, Plan* plans, int rounds, BurstGraph* cache,
-                        hipStream_t stream);
+                        BurstPublish pub, hipStream_t stream);
 void burst_graph_destroy(BurstGraph* cache);
 // the same rounds by one persistent workgroup (phases with short conflict-free prefixes); leaves with RoundState::stop = 0 (max_rounds
 // used up), 1 (the op at the cursor needs the sequencer), 2 (batch finished) or 3 (full prefixes: back to the grid rounds)
-hipError_t launch_local_rounds(const DevBufs* bufs, Ctl* ctl, const Op* ops, RoundState* rs, int max_rounds, hipStream_t stream);
+hipError_t launch_local_rounds(const DevBufs* bufs, Ctl* ctl, const Op* ops, RoundState* rs, int max_rounds, BurstPublish pub, hipStream_t stream);
 
 // batched read-only lookups.  mode 0: getindex(pma, key) ; 1: getindex(pcsc, key, partition) ;
 // 2: getindex(mpcsc, row, col).  err_out: first error code (0 if none)

@@ -116,6 +116,7 @@ struct Pma {
     int64_t stat_par_rounds = 0, stat_par_ops = 0, stat_seq_ops = 0, stat_seq_launches = 0;      // batch-parallel instrumentation
     BurstGraph burst, burst_short;      // cached graphs of a full burst of rounds and of a short one (conflict-heavy phases)
     Plan* d_plans = nullptr; RoundState* d_rs = nullptr; RoundState* h_rs = nullptr;   // batch-parallel writes
+    unsigned long long* h_pub = nullptr; unsigned int pub_seq = 0;      // pinned word k_publish writes the burst number to, and the last number handed out
     DevBufs* d_bufs = nullptr; DevBufs* h_bufs = nullptr;      // the arrays the rounds work on, read from device memory (pinned mirror)
     TableMerge tmerge{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; int64_t tmerge_cap = 0;   // scratch of the grid-wide table merge (tables.hip)
     int64_t stat_table_merges = 0;
@@ -173,6 +174,7 @@ void pma_destroy(Pma& P) {
     if (P.h_bufs) hipHostFree(P.h_bufs);
     if (P.d_rs) hipFree(P.d_rs);
     if (P.h_rs) hipHostFree(P.h_rs);
+    pinned_free(P.h_pub);
     pool_free(P.d_small);
     pinned_free(P.h_small);
     if (P.d_meta) hipFree(P.d_meta);
@@ -671,6 +673,8 @@ int64_t run_ops_parallel(Pma& P, const std::vector<Op>& ops, int32_t* err) {
         std::memset(P.h_bufs, 0, sizeof(DevBufs));
         HIPCHK(hipMalloc(&P.d_rs, sizeof(RoundState)));
         HIPCHK(hipHostMalloc(&P.h_rs, sizeof(RoundState), hipHostMallocDefault));
+        HIPCHK(pinned_alloc(reinterpret_cast<void**>(&P.h_pub), sizeof(unsigned long long)));
+        *P.h_pub = 0ull; P.pub_seq = 0;
     }
     P.h_ctl->next_op = 0; P.h_ctl->status = 0; P.h_ctl->err = 0; P.h_ctl->no_run_at = -1;
     upload_ctl(P);
@@ -697,6 +701,12 @@ int64_t run_ops_parallel(Pma& P, const std::vector<Op>& ops, int32_t* err) {
         std::memset(&rs, 0, sizeof(rs));
         static const int tight = [] { const char* e = getenv("DSA_TIGHT"); return e ? atoi(e) : 3; }();
         rs.cursor = i; rs.limit = n; rs.G = G; rs.min_prefix = MIN_PREFIX; rs.ema = ema; rs.tight = tight;
+        // the burst hands its result back through pinned memory (k_publish) and the host polls for the burst number; DSA_PUBLISH=0: two
+        // device-to-host copies and a stream synchronisation instead
+        static const bool publish = [] { const char* e = getenv("DSA_PUBLISH"); return !(e && e[0] == '0'); }();
+        if (++P.pub_seq == 0) P.pub_seq = 1;
+        rs.seq = (int32_t)P.pub_seq;
+        const BurstPublish pub = publish ? BurstPublish{P.h_rs, P.h_ctl, P.h_pub} : BurstPublish{nullptr, nullptr, nullptr};
         HIPCHK(hipMemcpyAsync(P.d_rs, P.h_rs, sizeof(RoundState), hipMemcpyHostToDevice, P.stream));
         {
             ++P.layout_epoch;
@@ -708,14 +718,28 @@ int64_t run_ops_parallel(Pma& P, const std::vector<Op>& ops, int32_t* err) {
                 HIPCHK(hipMemcpyAsync(P.d_bufs, P.h_bufs, sizeof(DevBufs), hipMemcpyHostToDevice, P.stream));
             }
             // short conflict-free prefixes (a small array, colliding ops): the rounds of one persistent workgroup, no launch per round
-            hipError_t e = use_local ? launch_local_rounds(P.d_bufs, P.d_ctl, P.d_ops, P.d_rs, LOCAL_ROUNDS, P.stream)
+            hipError_t e = use_local ? launch_local_rounds(P.d_bufs, P.d_ctl, P.d_ops, P.d_rs, LOCAL_ROUNDS, pub, P.stream)
                                      : launch_burst(P.d_bufs, P.d_ctl, P.d_ops, P.d_rs, P.d_plans,
-                                                    burst_rounds, burst_rounds == ROUNDS_PER_SYNC ? &P.burst : &P.burst_short, P.stream);
+                                                    burst_rounds, burst_rounds == ROUNDS_PER_SYNC ? &P.burst : &P.burst_short, pub, P.stream);
             if (e != hipSuccess) fail(DSA_EHIP, std::string("burst launch: ") + hipGetErrorString(e));
         }
-        HIPCHK(hipMemcpyAsync(P.h_rs, P.d_rs, sizeof(RoundState), hipMemcpyDeviceToHost, P.stream));
-        HIPCHK(hipMemcpyAsync(P.h_ctl, P.d_ctl, sizeof(Ctl), hipMemcpyDeviceToHost, P.stream));      // table_len, n_pending, counts of the burst
-        HIPCHK(hipStreamSynchronize(P.stream));
+        if (publish) {
+            // poll for the burst number; the stream is asked now and then so that a failed launch or a faulted kernel cannot hang the host
+            volatile unsigned long long* seqp = P.h_pub;
+            const auto tp0 = std::chrono::steady_clock::now();
+            auto next_query = tp0 + std::chrono::milliseconds(2);
+            while ((unsigned int)__atomic_load_n(seqp, __ATOMIC_ACQUIRE) != P.pub_seq) {
+                if (std::chrono::steady_clock::now() < next_query) continue;
+                const hipError_t q = hipStreamQuery(P.stream);
+                if (q == hipErrorNotReady) { next_query = std::chrono::steady_clock::now() + std::chrono::milliseconds(2); continue; }
+                if (q != hipSuccess) fail(DSA_EHIP, std::string("burst: ") + hipGetErrorString(q));
+                if ((unsigned int)__atomic_load_n(seqp, __ATOMIC_ACQUIRE) != P.pub_seq) fail(DSA_EHIP, "burst finished without publishing its state");
+            }
+        } else {
+            HIPCHK(hipMemcpyAsync(P.h_rs, P.d_rs, sizeof(RoundState), hipMemcpyDeviceToHost, P.stream));
+            HIPCHK(hipMemcpyAsync(P.h_ctl, P.d_ctl, sizeof(Ctl), hipMemcpyDeviceToHost, P.stream));      // table_len, n_pending, counts of the burst
+            HIPCHK(hipStreamSynchronize(P.stream));
+        }
         t_burst += ms(tb0, now()); ++n_burst;
         if (use_local) { t_local += ms(tb0, now()); ++n_local; r_local += rs.rounds; o_local += rs.par_ops; }
         // the prefix of the last round of the burst has been applied but is folded into the cursor only by the next round's resolve step
