@@ -254,7 +254,11 @@ __global__ __launch_bounds__(PL_BLOCK) void k_plan(const DevBufs* bufs, const Ct
     // scalars of the control block the resolve step needs: requested now, so that the last workgroup does not start with a dependent
     // round trip to memory (~2 us across XCDs)
     const int64_t cap0 = ctl->capacity, seg0 = ctl->segment_capacity, lo00 = ctl->lo[0], hi00 = ctl->hi[0];
-    const int64_t i0 = rs->cursor + rs->d;            // the resolve step of this round folds the previous prefix into the cursor
+    // (the fields of the round state the resolve step folds at its very end: read now, scalar loads, instead of as dependent round trips of one
+    // thread behind the last barrier — nobody writes them while this kernel runs)
+    const int d_prev = rs->d, ema_prev = rs->ema, min_prefix = rs->min_prefix;
+    const int64_t rounds_prev = rs->rounds, par_ops_prev = rs->par_ops;
+    const int64_t i0 = rs->cursor + d_prev;           // the resolve step of this round folds the previous prefix into the cursor
     const int64_t left = rs->limit - i0;
     const int G = (int)(left < rs->G ? left : rs->G);
     const int w = blockIdx.x * (PL_BLOCK / 64) + (threadIdx.x >> 6);
@@ -313,6 +317,14 @@ __global__ __launch_bounds__(PL_BLOCK) void k_plan(const DevBufs* bufs, const Ct
     __shared__ int32_t sLeafLo[PB_GMAX];                               // first slot of the op's leaf if it is leaf-only, else 0
     __shared__ int32_t sCnt0[PB_GMAX];                                 // cells of that leaf before the round
     const int64_t seg = seg0;
+    // (spatial hash of the overlap test below; emptied here, under the latency of the plan loads, behind the same barrier)
+    constexpr int CS = PB_MAX_W_LOG2 + 1, NB = 4096;
+    __shared__ int sHead[NB];
+    __shared__ int sNext[2 * PB_GMAX];
+    __shared__ int sWide[PB_GMAX];
+    __shared__ int sNWide;
+    for (int k = tid; k < NB; k += PL_BLOCK) sHead[k] = -1;
+    if (tid == 0) sNWide = 0;
     for (int j = tid; j < G + 8; j += PL_BLOCK) {
         Iv iv{INT32_MAX, INT32_MIN};                                   // an empty footprint overlaps nothing
         if (j < G) {
@@ -356,14 +368,6 @@ __global__ __launch_bounds__(PL_BLOCK) void k_plan(const DevBufs* bufs, const Ct
     // Cells of 2 * PB_MAX_W slots; a footprint of up to that many slots lies in one or two cells and is chained into their buckets, then every op
     // walks the chains of its own cells and tests the earlier ops it meets there exactly.  The (rare) longer footprints are tested
     // against everybody.  Ops at or behind the first BARRIER do not matter.
-    constexpr int CS = PB_MAX_W_LOG2 + 1, NB = 4096;
-    __shared__ int sHead[NB];
-    __shared__ int sNext[2 * PB_GMAX];
-    __shared__ int sWide[PB_GMAX];
-    __shared__ int sNWide;
-    for (int k = tid; k < NB; k += PL_BLOCK) sHead[k] = -1;
-    if (tid == 0) sNWide = 0;
-    __syncthreads();
     const int Gc = sB < G ? sB : G;
     auto bucket = [](int cell) { return (int)(((uint32_t)cell * 0x9E3779B1u) >> 20) & (NB - 1); };
     for (int j = tid; j < Gc; j += PL_BLOCK) {
@@ -483,19 +487,18 @@ __global__ __launch_bounds__(PL_BLOCK) void k_plan(const DevBufs* bufs, const Ct
             }
         } else if (sB < G) printf("  cut: barrier why %d\n", plans[sB].count & 7);
 #endif
-        const int d_prev = rs->d;
         rs->ticket = 0u;                                               // re-armed for the next round
         rs->cursor = i0;
-        if (d_prev > 0) { rs->rounds += 1; rs->par_ops += d_prev; }
+        if (d_prev > 0) { rs->rounds = rounds_prev + 1; rs->par_ops = par_ops_prev + d_prev; }
         if (left <= 0) { rs->stop = 2; rs->d = 0; return; }           // finished
         int d = sC < sB ? sC : sB;
         if (d > G) d = G;
         // short prefixes one after the other mean the ops around the cursor collide (appends, one hot key): hand over to the
         // sequencer.  A single short prefix between long ones (a small array, where windows are wide) is still cheaper as a round
         // of d >= 1 ops than as a sequencer launch.
-        const int ema = (3 * rs->ema + 16 * d) >> 2;
+        const int ema = (3 * ema_prev + 16 * d) >> 2;
         rs->ema = ema;
-        if (d < rs->min_prefix && d < G && (d == 0 || ema < 16 * rs->min_prefix)) {
+        if (d < min_prefix && d < G && (d == 0 || ema < 16 * min_prefix)) {
             rs->why[sB <= sC ? (__hip_atomic_load(&plans[sB < G ? sB : 0].count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 7) : 7] += 1;
             rs->stop = 1; rs->d = 0; return;
         }
