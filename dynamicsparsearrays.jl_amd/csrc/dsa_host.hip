@@ -2071,7 +2071,12 @@ int32_t dsa_mat_spmv_dense(dsa_mat_t* h, int32_t transpose, const double* x, int
 int32_t dsa_mat_spmv_sparse(dsa_mat_t* h, int32_t transpose, const int64_t* xi, const double* xv, int64_t nx,
                             int64_t* yi, double* yv, int64_t cap, int64_t* n_out) {
     API_TRY
+    static const bool dbg_time = getenv("DSA_DBG_TIME") != nullptr;
+    const auto tq0 = std::chrono::steady_clock::now();
+    auto tq = [&](const char* what) { if (dbg_time) fprintf(stderr, "  [spmv_sparse] %s at %.1f us\n", what, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tq0).count()); };
+    if (dbg_time) fprintf(stderr, "  [spmv_sparse] enter at %.1f us (steady clock)\n", std::chrono::duration<double, std::micro>(tq0.time_since_epoch()).count());
     mat_flush(h);
+    tq("flushed");
     if (!h->has_major) fail(DSA_EMODE, "matrix is in fill mode");
     const int64_t ny = transpose ? h->n : h->m;
     const int64_t ncols = transpose ? h->m : h->n;
@@ -2124,6 +2129,7 @@ int32_t dsa_mat_spmv_sparse(dsa_mat_t* h, int32_t transpose, const int64_t* xi, 
             h->sp_pin_bytes = need + need / 2;
         }
     }
+    tq("scratch ready");
     char* pin = static_cast<char*>(h->sp_pin);
     std::memcpy(pin, xi, (size_t)nx * 8);
     std::memcpy(pin + (size_t)nx * 8, xv, (size_t)nx * 8);
@@ -2143,6 +2149,7 @@ int32_t dsa_mat_spmv_sparse(dsa_mat_t* h, int32_t transpose, const int64_t* xi, 
         e = launch_touched_compact(nullptr, h->d_y + ny, h->d_y, ny, d_bm, d_oi, d_ov, &h->sp_work, &cnt, s);
     }
     if (e != hipSuccess) fail(DSA_EHIP, std::string("touched-row compaction: ") + hipGetErrorString(e));
+    tq("product + count back");
     if (cnt > cap) { HIPCHK(hipStreamSynchronize(s)); fail(DSA_ECAP, "output buffers too small"); }
     if (cnt > 0) {
         HIPCHK(hipMemcpyAsync(pin, d_oi, (size_t)cnt * 8, hipMemcpyDeviceToHost, s));
@@ -2154,6 +2161,7 @@ int32_t dsa_mat_spmv_sparse(dsa_mat_t* h, int32_t transpose, const int64_t* xi, 
         std::memcpy(yv, pin + (size_t)cnt * 8, (size_t)cnt * 8);
     }
     *n_out = cnt;
+    tq("done");
     API_CATCH
 }
 

@@ -1,13 +1,26 @@
-import sys, time
-sys.path.insert(0,'/root/repo')
+#!/usr/bin/env python3
+"""Sparse-x product through the host-pointer entry point on the C3 matrix (dev tool): 100 / 10 k / 500 k stored entries, per-call times."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 import numpy as np
 import bench, dsa_loader
 dsa = dsa_loader.load(); hip = dsa.product()
-I,J,V = bench.c3_triplets(1000000, 1000000, 10, 0, 5, 6)
+I, J, V = bench.c3_triplets(1000000, 1000000, 10, 0, 5, 6)
 A = dsa.dynamicsparse(I, J, V, 1000000, 1000000, binding=hip)
 n3 = 1000000
-xi = np.unique(1 + (bench.splitmix_array(50 + 500000, 500000) % np.uint64(n3)).astype(np.int64))
-xv = bench.unit12(51, len(xi))
-for k in range(8):
-    t = time.perf_counter(); yi, yv = A.mul((xi, xv)); dt = time.perf_counter() - t
-    print("call %d: %.2f ms  touched %d" % (k, dt*1e3, len(yi)))
+if "--torch-stream" in sys.argv:      # like bench.py: the matrix bound to torch's current stream
+    import ctypes as C
+    import torch
+    hip.call("mat_set_stream", A.h, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    print("bound to torch stream", torch.cuda.current_stream().cuda_stream)
+if "--rebalance-first" in sys.argv:   # like bench.py: root rebalances of the colmajor orientation before the products
+    for _ in range(5):
+        A.rebalance_root(dsa.COLMAJOR)
+for nxs in (100, 10_000, 500_000):
+    xi = np.unique(1 + (bench.splitmix_array(50 + nxs, nxs) % np.uint64(n3)).astype(np.int64))
+    xv = bench.unit12(51, len(xi))
+    ts = []
+    for k in range(6):
+        t = time.perf_counter(); yi, yv = A.mul((xi, xv)); ts.append((time.perf_counter() - t) * 1e3)
+    print("stored %d touched %d: calls [%s] ms" % (len(xi), len(yi), ", ".join("%.3f" % x for x in ts)))
