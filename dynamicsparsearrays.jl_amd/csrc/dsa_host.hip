@@ -533,6 +533,31 @@ struct SeqRun {
     bool defer_merge = false; // leave pending table entries to the caller (a batch that goes on with more launches)
 };
 
+// Hand-over of a launch's result through pinned memory (parbatch.hip: k_publish / k_publish_ctl): the last kernel of the launch
+// writes the control block (and the round state) into the host's pinned mirrors and then a number into P.h_pub; the host polls for
+// that number instead of issuing device-to-host copies and synchronising the stream.  DSA_PUBLISH=0: copies + synchronisation.
+bool publish_enabled() { static const bool on = [] { const char* e = getenv("DSA_PUBLISH"); return !(e && e[0] == '0'); }(); return on; }
+unsigned int next_publish_seq(Pma& P) {
+    if (!P.h_pub) {
+        HIPCHK(pinned_alloc(reinterpret_cast<void**>(&P.h_pub), sizeof(unsigned long long)));
+        *P.h_pub = 0ull; P.pub_seq = 0;
+    }
+    if (++P.pub_seq == 0) P.pub_seq = 1;
+    return P.pub_seq;
+}
+void wait_published(Pma& P) {
+    // the stream is asked now and then so that a failed launch or a faulted kernel cannot hang the host
+    volatile unsigned long long* seqp = P.h_pub;
+    auto next_query = std::chrono::steady_clock::now() + std::chrono::milliseconds(2);
+    while ((unsigned int)__atomic_load_n(seqp, __ATOMIC_ACQUIRE) != P.pub_seq) {
+        if (std::chrono::steady_clock::now() < next_query) continue;
+        const hipError_t q = hipStreamQuery(P.stream);
+        if (q == hipErrorNotReady) { next_query = std::chrono::steady_clock::now() + std::chrono::milliseconds(2); continue; }
+        if (q != hipSuccess) fail(DSA_EHIP, std::string("device work failed: ") + hipGetErrorString(q));
+        if ((unsigned int)__atomic_load_n(seqp, __ATOMIC_ACQUIRE) != P.pub_seq) fail(DSA_EHIP, "device work finished without publishing its state");
+    }
+}
+
 void seq_launch(SeqRun& r, bool upload = true) {
     Pma& P = *r.P;
     // pinned h_ctl: H2D, kernel and D2H are stream-ordered; the host does not touch h_ctl until the next synchronize
@@ -542,7 +567,13 @@ void seq_launch(SeqRun& r, bool upload = true) {
                                     P.has_cols ? P.col_live : nullptr, P.d_ctl, P.d_ops, r.n, std::max(r.n, r.n_avail),
                                     g_append_runs && P.occ_old != nullptr, P.stream);
     if (e != hipSuccess) fail(DSA_EHIP, std::string("sequencer launch: ") + hipGetErrorString(e));
-    HIPCHK(hipMemcpyAsync(P.h_ctl, P.d_ctl, sizeof(Ctl), hipMemcpyDeviceToHost, P.stream));
+    if (publish_enabled()) {
+        const unsigned int seq = next_publish_seq(P);
+        e = launch_publish_ctl(P.d_ctl, P.h_ctl, P.h_pub, seq, P.stream);
+        if (e != hipSuccess) fail(DSA_EHIP, std::string("publish launch: ") + hipGetErrorString(e));
+    } else {
+        HIPCHK(hipMemcpyAsync(P.h_ctl, P.d_ctl, sizeof(Ctl), hipMemcpyDeviceToHost, P.stream));
+    }
 }
 
 void seq_start(SeqRun& r, Pma& P, const std::vector<Op>& ops) {
@@ -561,7 +592,7 @@ void seq_start(SeqRun& r, Pma& P, const std::vector<Op>& ops) {
 bool seq_step(SeqRun& r) {
     if (!r.active) return false;
     Pma& P = *r.P;
-    HIPCHK(hipStreamSynchronize(P.stream));
+    if (publish_enabled()) wait_published(P); else HIPCHK(hipStreamSynchronize(P.stream));
     Ctl& c = *P.h_ctl;
     switch (c.status) {
         case SEQ_DONE:
@@ -673,8 +704,6 @@ int64_t run_ops_parallel(Pma& P, const std::vector<Op>& ops, int32_t* err) {
         std::memset(P.h_bufs, 0, sizeof(DevBufs));
         HIPCHK(hipMalloc(&P.d_rs, sizeof(RoundState)));
         HIPCHK(hipHostMalloc(&P.h_rs, sizeof(RoundState), hipHostMallocDefault));
-        HIPCHK(pinned_alloc(reinterpret_cast<void**>(&P.h_pub), sizeof(unsigned long long)));
-        *P.h_pub = 0ull; P.pub_seq = 0;
     }
     P.h_ctl->next_op = 0; P.h_ctl->status = 0; P.h_ctl->err = 0; P.h_ctl->no_run_at = -1;
     upload_ctl(P);
@@ -703,9 +732,8 @@ int64_t run_ops_parallel(Pma& P, const std::vector<Op>& ops, int32_t* err) {
         rs.cursor = i; rs.limit = n; rs.G = G; rs.min_prefix = MIN_PREFIX; rs.ema = ema; rs.tight = tight;
         // the burst hands its result back through pinned memory (k_publish) and the host polls for the burst number; DSA_PUBLISH=0: two
         // device-to-host copies and a stream synchronisation instead
-        static const bool publish = [] { const char* e = getenv("DSA_PUBLISH"); return !(e && e[0] == '0'); }();
-        if (++P.pub_seq == 0) P.pub_seq = 1;
-        rs.seq = (int32_t)P.pub_seq;
+        const bool publish = publish_enabled();
+        rs.seq = (int32_t)next_publish_seq(P);
         const BurstPublish pub = publish ? BurstPublish{P.h_rs, P.h_ctl, P.h_pub} : BurstPublish{nullptr, nullptr, nullptr};
         HIPCHK(hipMemcpyAsync(P.d_rs, P.h_rs, sizeof(RoundState), hipMemcpyHostToDevice, P.stream));
         {
@@ -724,17 +752,7 @@ int64_t run_ops_parallel(Pma& P, const std::vector<Op>& ops, int32_t* err) {
             if (e != hipSuccess) fail(DSA_EHIP, std::string("burst launch: ") + hipGetErrorString(e));
         }
         if (publish) {
-            // poll for the burst number; the stream is asked now and then so that a failed launch or a faulted kernel cannot hang the host
-            volatile unsigned long long* seqp = P.h_pub;
-            const auto tp0 = std::chrono::steady_clock::now();
-            auto next_query = tp0 + std::chrono::milliseconds(2);
-            while ((unsigned int)__atomic_load_n(seqp, __ATOMIC_ACQUIRE) != P.pub_seq) {
-                if (std::chrono::steady_clock::now() < next_query) continue;
-                const hipError_t q = hipStreamQuery(P.stream);
-                if (q == hipErrorNotReady) { next_query = std::chrono::steady_clock::now() + std::chrono::milliseconds(2); continue; }
-                if (q != hipSuccess) fail(DSA_EHIP, std::string("burst: ") + hipGetErrorString(q));
-                if ((unsigned int)__atomic_load_n(seqp, __ATOMIC_ACQUIRE) != P.pub_seq) fail(DSA_EHIP, "burst finished without publishing its state");
-            }
+            wait_published(P);
         } else {
             HIPCHK(hipMemcpyAsync(P.h_rs, P.d_rs, sizeof(RoundState), hipMemcpyDeviceToHost, P.stream));
             HIPCHK(hipMemcpyAsync(P.h_ctl, P.d_ctl, sizeof(Ctl), hipMemcpyDeviceToHost, P.stream));      // table_len, n_pending, counts of the burst
