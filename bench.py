@@ -529,6 +529,13 @@ def extras(dsa, hip, torch, A, dev):
     #     element by element into an empty matrix — both orientations —, SpMV every 1000 columns.  Parity of this loop vs the
     #     oracle: tests/test_hip_parity.py::test_matrix_from_empty_streaming_columns_c5_scaled
     res["c5_streaming"] = c5_streaming(dsa, hip, torch, dev, *C5_FULL)
+    # --- an EXTRA: the same stream as column generation does it — after every batch 5 % of its columns are deleted again
+    #     (deletecolumn!, src/matrix.jl:95-102: tombstones in the colmajor tables).  A batch of new, larger column ids cannot fail, so the two
+    #     orientations keep running side by side (dsa_host.hip: mat_apply_sets); parity: test_column_generation_with_deletions_matches_oracle
+    try:
+        res["c5_streaming_with_deletions"] = c5_streaming(dsa, hip, torch, dev, *C5_FULL, delete_every=20)
+    except Exception as e:
+        res["c5_streaming_with_deletions"] = {"error": str(e)[:200]}
     # --- buffered writes: the C3 triples through the fill buffer in ten batches of 1 M, then
     #     closefillmode! (the flush = two bulk builds); and dynamicsparse(I, J, V) from caller memory.  Second of two passes (the
     #     first one pays the pinned staging chunks, which are kept).
@@ -567,7 +574,7 @@ def c5_columns(m5, ncols5, per5):
     return I[order], J[order], V
 
 
-def c5_streaming(dsa, hip, torch, dev, m5, ncols5, per5, every, binding=None, stop_after=None):
+def c5_streaming(dsa, hip, torch, dev, m5, ncols5, per5, every, binding=None, stop_after=None, delete_every=None):
     B = dsa.dynamicsparse(fill_mode=False, binding=binding or hip)     # keeps its two own streams: the orientations update concurrently
     I5, J5, V5 = c5_columns(m5, ncols5, per5)
     x5 = unit12(13, ncols5)
@@ -575,6 +582,7 @@ def c5_streaming(dsa, hip, torch, dev, m5, ncols5, per5, every, binding=None, st
         xd = torch.from_numpy(x5).to(dev)
         yd = torch.zeros(m5, dtype=torch.float64, device=dev)
     t_w, t_s, nsp, t_first = 0.0, 0.0, 0, None
+    t_del, n_del = 0.0, 0
     for c0 in range(0, ncols5, every):
         sl = slice(c0 * per5, (c0 + every) * per5)
         t = time.perf_counter()
@@ -590,12 +598,21 @@ def c5_streaming(dsa, hip, torch, dev, m5, ncols5, per5, every, binding=None, st
             B.mul(x5[: c0 + every])
         t_s += time.perf_counter() - t
         nsp += 1
+        if delete_every:
+            t = time.perf_counter()
+            for j in range(c0 + 1, c0 + every + 1, delete_every):
+                B.deletecolumn(j); n_del += 1
+            t_del += time.perf_counter() - t
         if c0 + every == 10_000:
             t_first = t_w
         if stop_after is not None and c0 + every >= stop_after:
             break
     ncols_done = min(ncols5, (nsp * every))
     nw = ncols_done * per5
+    if delete_every:
+        return {"columns": ncols_done, "columns_per_s": round(ncols_done / t_w, 1), "write_s": round(t_w, 3), "deleted_columns": n_del,
+                "deletecolumn_us_each": round(t_del / max(n_del, 1) * 1e6, 1), "spmv_ms_avg": round(t_s / nsp * 1e3, 4),
+                "note": "config 5 with 1 of %d streamed columns deleted again after every batch of %d" % (delete_every, every)}
     return {"columns": ncols_done, "rows": m5, "element_writes": nw, "columns_per_s": round(ncols_done / t_w, 1),
             "element_writes_per_s": round(nw / t_w, 1), "write_s": round(t_w, 3), "first_10k_columns_write_s": None if t_first is None else round(t_first, 3),
             "spmv_ms_avg": round(t_s / nsp * 1e3, 4), "spmv_every_columns": every,

@@ -327,6 +327,67 @@ def test_matrix_from_empty_streaming_columns_c5_scaled(dsa, hip, oracle):
         np.testing.assert_allclose(ya, yb, rtol=RTOL, atol=0)
 
 
+@pytest.mark.gpu
+def test_column_generation_with_deletions_matches_oracle(dsa, hip, oracle):
+    """Column generation with deletions (Coluna's pattern: new columns get new, larger ids while old ones are deleted): batches of new
+    columns streamed into a matrix whose colmajor tables hold tombstones.  A batch whose column keys never decrease and start at or
+    behind the last LIVE table entry cannot fail, so both orientations are updated side by side (mat_apply_sets: cannot_fail); deleting
+    the last column, writing to an older column, or a deleted row make the batch take the reference's statement order instead — same
+    state and same error codes as the oracle either way."""
+    m_rows, per, step = 400, 6, 60              # 360 element writes per batch (>= 128: the batch-parallel branch)
+    a = dsa.dynamicsparse(fill_mode=False, binding=hip)
+    b = dsa.dynamicsparse(fill_mode=False, binding=oracle)
+    g = SplitMix64(71)
+    gv = SplitMix64(72)
+
+    def both(fn):
+        ea = eb = None
+        try:
+            fn(a)
+        except dsa.DsaError as e:
+            ea = e.code
+        try:
+            fn(b)
+        except dsa.DsaError as e:
+            eb = e.code
+        assert ea == eb, (ea, eb)
+        return ea
+
+    next_col = 1
+    for rnd in range(9):
+        I, J, V = [], [], []
+        for j in range(next_col, next_col + step):
+            rows = set()
+            while len(rows) < per:
+                rows.add(1 + g.next() % m_rows)
+            for r in sorted(rows):
+                I.append(r); J.append(j); V.append(gv.unit12())
+        if rnd == 2:                            # one write to an older column in front: keys decrease -> the sequential orientation order
+            I.insert(0, 7); J.insert(0, next_col - 10); V.insert(0, 3.25)
+        if rnd == 4:                            # a zero-valued write creates an (empty) column too: appended like the others
+            I.append(3); J.append(next_col + step); V.append(0.0)
+        err = both(lambda mtx: mtx.set_batch(I, J, V))
+        if err is not None:
+            assert rnd == 7, rnd                # the reference's crash path after deleting the LAST column (round 6): same code on both sides;
+            return                              # the state behind it is a documented divergence
+        assert_mat_equal(a, b)
+        next_col += step + (1 if rnd == 4 else 0)
+        # deletions between the batches: old columns, sometimes the LAST one (then the next batch must not take the side-by-side branch),
+        # once a row (a tombstone in the rowmajor tables)
+        for j in range(next_col - step, next_col - 1, 7):
+            both(lambda mtx: mtx.deletecolumn(j))
+        if rnd == 6:
+            both(lambda mtx: mtx.deletecolumn(next_col - 1))
+        if rnd == 3:
+            both(lambda mtx: mtx.deleterow(11))
+        assert_mat_equal(a, b)
+        if rnd == 5:
+            n = a.size()[1]
+            x = unit12_array(73, max(n, 1))
+            np.testing.assert_allclose(a.mul(x[:n]), b.mul(x[:n]), rtol=RTOL, atol=0)
+    raise AssertionError("the batch behind a deleted last column was expected to take the reference's error path")
+
+
 @pytest.mark.parametrize("seed,nkeys,batch,span", [(31, 3000, 3000, 10**6), (32, 2500, 700, 5000), (33, 400, 90, 600)])
 def test_new_columns_in_random_key_order_deferred_table_inserts(dsa, hip, oracle, seed, nkeys, batch, span):
     """Writes that create rows AND columns in random key order (middle inserts of addpartition!, src/pcsr.jl:114-146): the
