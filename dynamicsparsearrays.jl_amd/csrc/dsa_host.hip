@@ -122,6 +122,7 @@ struct Pma {
     int64_t stat_table_merges = 0;
     int64_t* d_small = nullptr;                     // 8 x int64 scratch
     int64_t* h_small = nullptr;                     // its pinned host mirror (small read-backs without a pageable staging copy)
+    int64_t* h_view = nullptr; unsigned long long view_seq = 0;      // pinned landing area of column views: meta words, sequence number, first cells (col_view_of)
     // bumped by every launch that can move cells or change the tables; SpmvMeta is recomputed when it differs
     int device = 0;              // the device the handle lives on: re-selected at every API entry (a Julia task / finalizer thread or a
                                  // second Python thread calls in with whatever device its thread last selected)
@@ -177,6 +178,7 @@ void pma_destroy(Pma& P) {
     pinned_free(P.h_pub);
     pool_free(P.d_small);
     pinned_free(P.h_small);
+    pinned_free(P.h_view);
     if (P.d_meta) hipFree(P.d_meta);
     pinned_free(P.h_meta);
     if (P.tmerge.sems2) hipFree(P.tmerge.sems2);
@@ -1291,15 +1293,44 @@ void col_view_of(Pma& P, int64_t col, std::vector<int64_t>& ks, std::vector<doub
     ks.clear(); vs.clear();
     const int alt = 1 - P.cur;
     const int64_t out_cap = std::min<int64_t>(P.cap_alloc, 16384);
-    hipError_t e = launch_view_small(P.K(), P.V(), P.O(), P.sems, P.col_keys, P.col_live, P.h_ctl->table_len, P.capacity(), col,
-                                     P.KA(alt), P.vals[alt], out_cap, P.d_small, P.stream);
-    if (e != hipSuccess) fail(DSA_EHIP, std::string("view launch: ") + hipGetErrorString(e));
-    int64_t r[5] = {0, 0, 0, 0, 0};
     const int64_t spec = std::min<int64_t>(SPEC, out_cap);
-    ks.resize((size_t)spec); vs.resize((size_t)spec);
-    HIPCHK(hipMemcpyAsync(r, P.d_small, sizeof(r), hipMemcpyDeviceToHost, P.stream));
-    HIPCHK(hipMemcpyAsync(vs.data(), P.vals[alt], (size_t)spec * sizeof(double), hipMemcpyDeviceToHost, P.stream));
-    download_keys(P, ks.data(), P.keys[alt], spec);       // synchronises
+    int64_t r[5] = {0, 0, 0, 0, 0};
+    if (publish_enabled()) {
+        // the kernel writes the meta words and the first SPEC cells straight into a pinned landing area and then a sequence number: the host
+        // polls for it — no copy command, no stream synchronisation (60 -> 20 us per view; DSA_PUBLISH=0 = copies + synchronisation)
+        if (!P.h_view) {
+            HIPCHK(pinned_alloc(reinterpret_cast<void**>(&P.h_view), (size_t)(8 + 2 * SPEC) * sizeof(int64_t)));
+            std::memset(P.h_view, 0, (size_t)(8 + 2 * SPEC) * sizeof(int64_t));
+            P.view_seq = 0;
+        }
+        const unsigned long long seq = ++P.view_seq;
+        hipError_t e = launch_view_small(P.K(), P.V(), P.O(), P.sems, P.col_keys, P.col_live, P.h_ctl->table_len, P.capacity(), col,
+                                         P.KA(alt), P.vals[alt], out_cap, P.d_small, P.h_view, SPEC, seq, P.stream);
+        if (e != hipSuccess) fail(DSA_EHIP, std::string("view launch: ") + hipGetErrorString(e));
+        volatile int64_t* seqp = P.h_view + 5;
+        auto next_query = std::chrono::steady_clock::now() + std::chrono::milliseconds(2);
+        while ((unsigned long long)__atomic_load_n(seqp, __ATOMIC_ACQUIRE) != seq) {
+            if (std::chrono::steady_clock::now() < next_query) continue;
+            const hipError_t q = hipStreamQuery(P.stream);
+            if (q == hipErrorNotReady) { next_query = std::chrono::steady_clock::now() + std::chrono::milliseconds(2); continue; }
+            if (q != hipSuccess) fail(DSA_EHIP, std::string("view: ") + hipGetErrorString(q));
+            if ((unsigned long long)__atomic_load_n(seqp, __ATOMIC_ACQUIRE) != seq) fail(DSA_EHIP, "view kernel finished without publishing its result");
+        }
+        for (int q = 0; q < 5; ++q) r[q] = P.h_view[q];
+        const int64_t have = std::max<int64_t>(0, std::min<int64_t>(r[4], spec));
+        ks.assign(P.h_view + 8, P.h_view + 8 + have);
+        vs.resize((size_t)have);
+        std::memcpy(vs.data(), P.h_view + 8 + SPEC, (size_t)have * sizeof(double));
+        ks.resize((size_t)spec); vs.resize((size_t)spec);
+    } else {
+        hipError_t e = launch_view_small(P.K(), P.V(), P.O(), P.sems, P.col_keys, P.col_live, P.h_ctl->table_len, P.capacity(), col,
+                                         P.KA(alt), P.vals[alt], out_cap, P.d_small, nullptr, 0, 0ull, P.stream);
+        if (e != hipSuccess) fail(DSA_EHIP, std::string("view launch: ") + hipGetErrorString(e));
+        ks.resize((size_t)spec); vs.resize((size_t)spec);
+        HIPCHK(hipMemcpyAsync(r, P.d_small, sizeof(r), hipMemcpyDeviceToHost, P.stream));
+        HIPCHK(hipMemcpyAsync(vs.data(), P.vals[alt], (size_t)spec * sizeof(double), hipMemcpyDeviceToHost, P.stream));
+        download_keys(P, ks.data(), P.keys[alt], spec);       // synchronises
+    }
     if (r[2] != 0) { ks.clear(); vs.clear(); fail((int32_t)r[2], "partition has no semaphore"); }
     if (r[0] == 0) { ks.clear(); vs.clear(); return; }       // empty view: the column does not exist (src/views.jl:17,24)
     const int64_t cnt = r[4];
@@ -1975,11 +2006,16 @@ int32_t dsa_mat_deletecolumn(dsa_mat_t* h, int64_t col) {      // src/matrix.jl:
     API_TRY
     mat_flush(h);
     if (h->fillmode) fail(DSA_EMODE, "Cannot delete a column in fill mode");
+    static const bool dbg_time = getenv("DSA_DBG_TIME") != nullptr;
+    const auto td0 = std::chrono::steady_clock::now();
     std::vector<int64_t> rows; std::vector<double> vals;
     col_view_of(h->col, col, rows, vals);
+    const auto td1 = std::chrono::steady_clock::now();
     std::vector<Op> ops;
     for (int64_t r : rows) ops.push_back(make_op(OP_MPCSC_SET, col, r, 0.0));     // rowmajor[col, row] = 0
     std::vector<Op> del{make_op(OP_MPCSC_DELETECOLUMN, 0, col, 0.0)};
+    struct Report { bool on; std::chrono::steady_clock::time_point a, b; size_t n; ~Report() { if (on) fprintf(stderr, "[deletecolumn] view %.1f us, %zu twin deletes + deletepartition %.1f us\n",
+        std::chrono::duration<double, std::micro>(b - a).count(), n, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - b).count()); } } report{dbg_time, td0, td1, rows.size()};
     // the element deletes of the twin cannot fail and touch the other structure: both sequencers run side by side
     if (h->col.stream != h->row.stream) {
         SeqRun rr, rc;

@@ -2075,7 +2075,11 @@ constexpr int64_t VIEW_SMALL_SLOTS = 16384;
 __global__ __launch_bounds__(64) void k_view_small(KeyArr keys, const double* __restrict__ vals,
                                                    const uint64_t* __restrict__ occ, const int64_t* sems, const int64_t* col_keys,
                                                    const uint8_t* col_live, int64_t table_len, int64_t capacity, int64_t col,
-                                                   KeyArr out_k, double* __restrict__ out_v, int64_t out_cap, int64_t* meta) {
+                                                   KeyArr out_k, double* __restrict__ out_v, int64_t out_cap, int64_t* meta,
+                                                   int64_t* host, int64_t host_cells, unsigned long long seq) {
+    // host (pinned, may be null): [0..4] the meta words, [5] the sequence number the host polls for, then host_cells keys and host_cells
+    // values — the first cells of the view go straight to the host with the meta words: one launch and no copy command for a short
+    // column (a D2H copy into the caller's pageable vectors + a stream synchronisation cost 60 us per view; 20 us this way)
     const int lane = threadIdx.x;
     int64_t from = 0, to = 0, err = 0, pid = 0;
     const DFoundKey f = d_find_table(col_keys, col_live, table_len, col);
@@ -2098,7 +2102,14 @@ __global__ __launch_bounds__(64) void k_view_small(KeyArr keys, const double* __
                 const uint64_t mask = occ[w] & word_range_mask(w, lo0, hi0);
                 if ((mask >> lane) & 1ull) {
                     const int64_t r = cnt + popc64(mask & mask_lt(lane));
-                    if (r < out_cap) { out_k[r] = keys[(w << 6) + lane]; out_v[r] = vals[(w << 6) + lane]; }
+                    if (r < out_cap) {
+                        const int64_t kk = keys[(w << 6) + lane]; const double vv = vals[(w << 6) + lane];
+                        out_k[r] = kk; out_v[r] = vv;
+                        if (host != nullptr && r < host_cells) {
+                            __hip_atomic_store(host + 8 + r, kk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                            __hip_atomic_store(host + 8 + host_cells + r, __double_as_longlong(vv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        }
+                    }
                 }
                 cnt += popc64(mask);
             }
@@ -2106,12 +2117,22 @@ __global__ __launch_bounds__(64) void k_view_small(KeyArr keys, const double* __
         }
     }
     if (lane == 0) { meta[0] = from; meta[1] = to; meta[2] = err; meta[3] = pid; meta[4] = cnt; }
+    if (host != nullptr) {
+        __builtin_amdgcn_s_waitcnt(0);                 // every lane's cells have left
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) {
+            const int64_t m5[5] = {from, to, err, pid, cnt};
+            for (int q = 0; q < 5; ++q) __hip_atomic_store(host + q, m5[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __atomic_thread_fence(__ATOMIC_RELEASE);
+            __hip_atomic_store(reinterpret_cast<unsigned long long*>(host) + 5, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 }
 hipError_t launch_view_small(KeyArr keys, const double* vals, const uint64_t* occ, const int64_t* sems, const int64_t* col_keys,
                              const uint8_t* col_live, int64_t table_len, int64_t capacity, int64_t col, KeyArr out_k, double* out_v,
-                             int64_t out_cap, int64_t* meta, hipStream_t stream) {
+                             int64_t out_cap, int64_t* meta, int64_t* host, int64_t host_cells, unsigned long long seq, hipStream_t stream) {
     hipLaunchKernelGGL(k_view_small, dim3(1), dim3(64), 0, stream, keys, vals, occ, sems, col_keys, col_live, table_len, capacity, col, out_k,
-                       out_v, out_cap, meta);
+                       out_v, out_cap, meta, host, host_cells, seq);
     return hipGetLastError();
 }
 
