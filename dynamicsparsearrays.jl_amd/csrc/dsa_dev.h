@@ -381,6 +381,10 @@ hipError_t launch_get_batch(int mode, KeyArr keys, const double* vals, const uin
                             const int64_t* sems, const int64_t* col_keys, const uint8_t* col_live, int64_t table_len,
                             const int64_t* qa, const int64_t* qb, int64_t n, double* out, int32_t* err_out,
                             hipStream_t stream);
+// up to 64 lookups through a pinned landing area (no copy commands; see k_get_small)
+hipError_t launch_get_small(int mode, KeyArr keys, const double* vals, const uint64_t* occ, int64_t capacity, const int64_t* sems,
+                            const int64_t* col_keys, const uint8_t* col_live, int64_t table_len, int64_t* io, int n, unsigned long long seq,
+                            hipStream_t stream);
 // parity hooks (include/dsa.h: dsa_dbg_raw_*): ONE slot-array primitive on a raw slot array of `len` slots; out = 6 x int64 device
 // scratch {error, position, flag, found key, found value bits, cells purged}.  _block: the sequencer's workgroup primitives
 // (sequencer.hip), _wave: the wave-level primitives of the batch-parallel rounds (parbatch.hip).  *_FAST: K-find in its

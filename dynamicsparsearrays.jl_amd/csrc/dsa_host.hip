@@ -122,6 +122,7 @@ struct Pma {
     int64_t stat_table_merges = 0;
     int64_t* d_small = nullptr;                     // 8 x int64 scratch
     int64_t* h_small = nullptr;                     // its pinned host mirror (small read-backs without a pageable staging copy)
+    int64_t* h_get = nullptr; unsigned long long get_seq = 0;        // pinned landing area of small lookups (get_batch: keys, partitions, answers, error, sequence number)
     int64_t* h_view = nullptr; unsigned long long view_seq = 0;      // pinned landing area of column views: meta words, sequence number, first cells (col_view_of)
     // bumped by every launch that can move cells or change the tables; SpmvMeta is recomputed when it differs
     int device = 0;              // the device the handle lives on: re-selected at every API entry (a Julia task / finalizer thread or a
@@ -179,6 +180,7 @@ void pma_destroy(Pma& P) {
     pool_free(P.d_small);
     pinned_free(P.h_small);
     pinned_free(P.h_view);
+    pinned_free(P.h_get);
     if (P.d_meta) hipFree(P.d_meta);
     pinned_free(P.h_meta);
     if (P.tmerge.sems2) hipFree(P.tmerge.sems2);
@@ -901,6 +903,32 @@ void ensure_q(Pma& P, int64_t n) {
 // batched getindex on the device; mode as in launch_get_batch
 void get_batch(Pma& P, int mode, const int64_t* qa, const int64_t* qb, int64_t n, double* out) {
     if (n <= 0) return;
+    if (n <= 64 && publish_enabled()) {
+        // a scalar getindex or a handful of them: one launch that reads its queries from, and writes its answers to, pinned memory
+        if (!P.h_get) {
+            HIPCHK(pinned_alloc(reinterpret_cast<void**>(&P.h_get), 256 * sizeof(int64_t)));
+            std::memset(P.h_get, 0, 256 * sizeof(int64_t));
+            P.get_seq = 0;
+        }
+        for (int64_t i = 0; i < n; ++i) { P.h_get[i] = qa[i]; P.h_get[64 + i] = qb ? qb[i] : 0; }
+        const unsigned long long seq = ++P.get_seq;
+        __atomic_thread_fence(__ATOMIC_RELEASE);
+        hipError_t e = launch_get_small(mode, P.K(), P.V(), P.O(), P.capacity(), P.sems, P.col_keys, P.col_live, P.h_ctl->table_len, P.h_get, (int)n, seq, P.stream);
+        if (e != hipSuccess) fail(DSA_EHIP, std::string("get launch: ") + hipGetErrorString(e));
+        volatile int64_t* seqp = P.h_get + 193;
+        auto next_query = std::chrono::steady_clock::now() + std::chrono::milliseconds(2);
+        while ((unsigned long long)__atomic_load_n(seqp, __ATOMIC_ACQUIRE) != seq) {
+            if (std::chrono::steady_clock::now() < next_query) continue;
+            const hipError_t q = hipStreamQuery(P.stream);
+            if (q == hipErrorNotReady) { next_query = std::chrono::steady_clock::now() + std::chrono::milliseconds(2); continue; }
+            if (q != hipSuccess) fail(DSA_EHIP, std::string("get: ") + hipGetErrorString(q));
+            if ((unsigned long long)__atomic_load_n(seqp, __ATOMIC_ACQUIRE) != seq) fail(DSA_EHIP, "lookup kernel finished without publishing its result");
+        }
+        std::memcpy(out, P.h_get + 128, (size_t)n * sizeof(double));
+        const int32_t err = (int32_t)P.h_get[192];
+        if (err) fail(err, err == DSA_EBOUNDS ? "partition index out of range" : "partition has no semaphore");
+        return;
+    }
     ensure_q(P, n);
     int64_t* d_qa = reinterpret_cast<int64_t*>(P.d_q);
     int64_t* d_qb = d_qa + P.q_cap;

@@ -1945,28 +1945,66 @@ hipError_t launch_sequencer(KeyArr keys, double* vals, uint64_t* occ, int64_t* s
 // ---- batched read-only lookups -----------------------------------------------------------------------
 // getindex(pma,key) src/pma.jl:189-193 ; getindex(pcsc,key,partition) src/pcsr.jl:222-232 ;
 // getindex(mpcsc,row,col) src/pcsr.jl:261-267.  One lane per query; each lane replays the reference's bisection.
+// one lookup by one lane; *err receives E_BOUNDS / E_ASSERT (0: none)
+__device__ double get_one(int mode, KeyArr keys, const double* vals, const uint64_t* occ, int64_t capacity, const int64_t* sems,
+                          const int64_t* col_keys, const uint8_t* col_live, int64_t table_len, int64_t key, int64_t qb, int32_t* err) {
+    int64_t from = 1, to = capacity;
+    if (mode != 0) {
+        int64_t partition = qb;
+        if (mode == 2) {
+            const DFoundKey f = d_find_table(col_keys, col_live, table_len, qb);
+            if (!(f.has && f.key == qb)) return 0.0;
+            partition = f.pos;
+        }
+        if (partition < 1 || partition > table_len) { *err = E_BOUNDS; return 0.0; }
+        from = sems[partition - 1];
+        if (from == 0) { *err = E_ASSERT; return 0.0; }   // _pos_of_partition_start @assert
+        const int64_t next = d_next_live_sem(sems, partition, table_len);
+        to = next != 0 ? sems[next - 1] - 1 : capacity;
+    }
+    const DFound f = d_find(keys, vals, occ, key, from, to);
+    return (f.has && f.key == key) ? f.val : 0.0;
+}
 __global__ void k_get_batch(int mode, KeyArr keys, const double* vals, const uint64_t* occ, int64_t capacity,
                             const int64_t* sems, const int64_t* col_keys, const uint8_t* col_live, int64_t table_len,
                             const int64_t* qa, const int64_t* qb, int64_t n, double* out, int32_t* err_out) {
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const int64_t key = qa[i];
-    int64_t from = 1, to = capacity;
-    if (mode != 0) {
-        int64_t partition = qb[i];
-        if (mode == 2) {
-            const DFoundKey f = d_find_table(col_keys, col_live, table_len, qb[i]);
-            if (!(f.has && f.key == qb[i])) { out[i] = 0.0; return; }
-            partition = f.pos;
-        }
-        if (partition < 1 || partition > table_len) { atomicCAS(err_out, 0, E_BOUNDS); out[i] = 0.0; return; }
-        from = sems[partition - 1];
-        if (from == 0) { atomicCAS(err_out, 0, E_ASSERT); out[i] = 0.0; return; }   // _pos_of_partition_start @assert
-        const int64_t next = d_next_live_sem(sems, partition, table_len);
-        to = next != 0 ? sems[next - 1] - 1 : capacity;
+    int32_t err = 0;
+    out[i] = get_one(mode, keys, vals, occ, capacity, sems, col_keys, col_live, table_len, qa[i], mode != 0 ? qb[i] : 0, &err);
+    if (err) atomicCAS(err_out, 0, err);
+}
+// Up to 64 lookups without a copy command: the queries are read from, and the answers written to, a pinned landing area of the handle —
+// io[0..63] keys, io[64..127] partitions / columns, io[128..191] answers, io[192] first error, io[193] the sequence number the host polls
+// for.  A scalar getindex (A[i, j], v[k]) is one launch and a poll: ~15 us instead of ~70 (two uploads, a memset, two downloads into pageable
+// memory, a stream synchronisation).
+__global__ __launch_bounds__(64) void k_get_small(int mode, KeyArr keys, const double* vals, const uint64_t* occ, int64_t capacity,
+                                                  const int64_t* sems, const int64_t* col_keys, const uint8_t* col_live, int64_t table_len,
+                                                  int64_t* io, int n, unsigned long long seq) {
+    const int lane = threadIdx.x;
+    int32_t err = 0;
+    if (lane < n) {
+        const int64_t key = __hip_atomic_load(io + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        const int64_t qb = mode != 0 ? __hip_atomic_load(io + 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0;
+        const double v = get_one(mode, keys, vals, occ, capacity, sems, col_keys, col_live, table_len, key, qb, &err);
+        __hip_atomic_store(io + 128 + lane, __double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    const DFound f = d_find(keys, vals, occ, key, from, to);
-    out[i] = (f.has && f.key == key) ? f.val : 0.0;
+    const uint64_t eb = __ballot(err != 0);
+    const int first = eb ? __ffsll((unsigned long long)eb) - 1 : 0;
+    const int32_t e0 = __shfl(err, first, 64);
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {
+        __hip_atomic_store(io + 192, (int64_t)(eb ? e0 : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __atomic_thread_fence(__ATOMIC_RELEASE);
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(io) + 193, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+hipError_t launch_get_small(int mode, KeyArr keys, const double* vals, const uint64_t* occ, int64_t capacity, const int64_t* sems,
+                            const int64_t* col_keys, const uint8_t* col_live, int64_t table_len, int64_t* io, int n, unsigned long long seq,
+                            hipStream_t stream) {
+    hipLaunchKernelGGL(k_get_small, dim3(1), dim3(64), 0, stream, mode, keys, vals, occ, capacity, sems, col_keys, col_live, table_len, io, n, seq);
+    return hipGetLastError();
 }
 
 hipError_t launch_get_batch(int mode, KeyArr keys, const double* vals, const uint64_t* occ, int64_t capacity,
