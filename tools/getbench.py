@@ -19,3 +19,15 @@ print("v[k]          %.1f us" % lat(lambda k=0: v[2 * (k % n0) + 2]))
 print("A[i, j]       %.1f us" % lat(lambda k=0: A[int(I[k]), int(J[k])]))
 print("col view      %.1f us" % lat(lambda k=0: A.col_view(1 + k % 100000)))
 print("get_batch(16) %.1f us" % lat(lambda k=0: A.get_batch(I[k:k + 16], J[k:k + 16])))
+def setget(k=0):
+    A[int(I[k]), int(J[k])] = 2.5          # an overwrite (write-combined), flushed by the read behind it
+    return A[int(I[k]), int(J[k])]
+print("A[i,j]=v; A[i,j]   %.1f us" % lat(setget, 1000))
+def vsetget(k=0):
+    v[2 * (k % n0) + 2] = 3.5
+    return v[2 * (k % n0) + 2]
+print("v[k]=x; v[k]       %.1f us" % lat(vsetget, 1000))
+def newelem(k=0):
+    A[1 + (k * 7919) % 100000, 1 + (k * 104729) % 100000] = 1.5     # mostly new elements of existing columns
+    return A[1 + (k * 7919) % 100000, 1 + (k * 104729) % 100000]
+print("new A[i,j]=v; read %.1f us" % lat(newelem, 1000))
