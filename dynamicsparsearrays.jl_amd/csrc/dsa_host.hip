@@ -1287,6 +1287,31 @@ void mat_apply_sets(dsa_mat* h, const int64_t* I, const int64_t* J, const double
         return;
     }
     if (no_tombstones && h->col.stream != h->row.stream) {
+        // A small batch (a column or a few that arrive together, a row): the orientation in which its writes fall into MANY
+        // partitions takes the local rounds (one wave per op: k_local_rounds), the one in which they share a few partitions — writes
+        // into one column are ordered by nature — its sequencer, side by side.  16 writes of a new column: 218 -> ~120 us.
+        static const bool small_rounds = [] { const char* e = getenv("DSA_SMALL_ROUNDS"); return !(e && e[0] == '0'); }();
+        if (small_rounds && par && n >= 8) {
+            std::vector<int64_t> di(I, I + n), dj(J, J + n);
+            std::sort(di.begin(), di.end()); std::sort(dj.begin(), dj.end());
+            const int64_t ni = std::unique(di.begin(), di.end()) - di.begin(), nj = std::unique(dj.begin(), dj.end()) - dj.begin();
+            Pma* rounds = nullptr; Pma* seq = nullptr; const std::vector<Op>* ro = nullptr; const std::vector<Op>* so = nullptr;
+            if (ni >= 2 * nj && ni >= 8) { rounds = &h->row; ro = &orw; seq = &h->col; so = &oc; }          // many rows, few columns
+            else if (nj >= 2 * ni && nj >= 8) { rounds = &h->col; ro = &oc; seq = &h->row; so = &orw; }     // many columns, few rows
+            if (rounds != nullptr) {
+                SeqRun rs;
+                seq_start(rs, *seq, *so);
+                int32_t er = 0;
+                int64_t dr = 0;
+                try { dr = run_ops_parallel(*rounds, *ro, &er); } catch (...) { while (seq_step(rs)) {} throw; }
+                while (seq_step(rs)) {}
+                const int64_t done = std::min(dr, rs.applied);
+                for (int64_t k = 0; k < std::min(done + 1, n); ++k) if (V[k] != 0.0) { h->m = std::max(h->m, I[k]); h->n = std::max(h->n, J[k]); }
+                if (rs.err) fail(rs.err, err_text(rs.err));
+                if (er) fail(er, err_text(er));
+                return;
+            }
+        }
         SeqRun rc, rr;
         run_ops_pair(h->col, oc, h->row, orw, rc, rr);
         const int64_t done = std::min(rc.applied, rr.applied);

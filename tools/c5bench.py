@@ -8,7 +8,7 @@ import bench, dsa_loader
 dsa = dsa_loader.load(); hip = dsa.product()
 full = '--full' in sys.argv
 m5, ncols5, per5 = (100_000, 50_000, 16) if full else (10_000, 5_000, 16)
-step = 1000 if full else 500
+step = int(os.environ.get('C5_STEP', '1000' if full else '500'))     # columns per write batch (Coluna adds a few columns per iteration)
 if '--cold' not in sys.argv:      # warm the process (code objects, first graph instantiation, allocator) like bench.py's earlier legs do
     W = dsa.dynamicsparse(fill_mode=False, binding=hip)
     Iw, Jw, Vw = bench.c5_columns(5000, 1250, 16)        # the same kind of stream at 1/40 of the size
