@@ -328,6 +328,39 @@ def test_matrix_from_empty_streaming_columns_c5_scaled(dsa, hip, oracle):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("shape", ["column_at_a_time", "row_at_a_time", "mixed"])
+def test_small_matrix_batches_match_oracle(dsa, hip, oracle, shape):
+    """Batches of 8..127 writes (a column or a row that arrives on its own, src/matrix.jl:43-62 once per element): the orientation in
+    which the writes fall into many partitions runs through the local rounds, the other through its sequencer, side by side
+    (mat_apply_sets); mixed batches keep the two sequencers.  State after every batch against the oracle, both orientations."""
+    g = SplitMix64(91)
+    gv = SplitMix64(92)
+    a = dsa.dynamicsparse(fill_mode=False, binding=hip)
+    b = dsa.dynamicsparse(fill_mode=False, binding=oracle)
+    for step in range(60):
+        n = 8 + g.next() % 100
+        I, J, V = [], [], []
+        if shape == "column_at_a_time":
+            j = 1 + step if step % 5 else 1 + g.next() % 40            # a new column, now and then an old one again
+            rows = sorted({1 + g.next() % 300 for _ in range(n)})
+            I = rows; J = [j] * len(rows)
+        elif shape == "row_at_a_time":
+            i = 1 + step if step % 4 else 1 + g.next() % 30
+            cols = sorted({1 + g.next() % 300 for _ in range(n)})
+            J = cols; I = [i] * len(cols)
+        else:
+            for _ in range(n):
+                I.append(1 + g.next() % 25); J.append(1 + g.next() % 25)
+        V = [0.0 if gv.next() % 9 == 0 else gv.unit12() for _ in I]     # some deletes (zero writes) among them
+        a.set_batch(I, J, V)
+        b.set_batch(I, J, V)
+        assert_mat_equal(a, b)
+    n = a.size()[1]
+    x = unit12_array(93, max(n, 1))
+    np.testing.assert_allclose(a.mul(x[:n]), b.mul(x[:n]), rtol=RTOL, atol=0)
+
+
+@pytest.mark.gpu
 def test_column_generation_with_deletions_matches_oracle(dsa, hip, oracle):
     """Column generation with deletions (Coluna's pattern: new columns get new, larger ids while old ones are deleted): batches of new
     columns streamed into a matrix whose colmajor tables hold tombstones.  A batch whose column keys never decrease and start at or
