@@ -176,11 +176,9 @@ void pma_destroy(Pma& P) {
     if (P.h_bufs) hipHostFree(P.h_bufs);
     if (P.d_rs) hipFree(P.d_rs);
     if (P.h_rs) hipHostFree(P.h_rs);
-    pinned_free(P.h_pub);
     pool_free(P.d_small);
     pinned_free(P.h_small);
     pinned_free(P.h_view);
-    pinned_free(P.h_get);
     if (P.d_meta) hipFree(P.d_meta);
     pinned_free(P.h_meta);
     if (P.tmerge.sems2) hipFree(P.tmerge.sems2);
@@ -281,7 +279,13 @@ void pma_init_common(Pma& P, bool sems, bool cols) {
     std::memset(P.h_ctl, 0, sizeof(Ctl));
     HIPCHK(pool_alloc(reinterpret_cast<void**>(&P.d_err), sizeof(int32_t)));
     HIPCHK(pool_alloc(reinterpret_cast<void**>(&P.d_small), 8 * sizeof(int64_t)));
-    HIPCHK(pinned_alloc(reinterpret_cast<void**>(&P.h_small), 8 * sizeof(int64_t)));
+    // one pinned block of 4 KB (the allocator's smallest class) per structure: [0, 64) small read-backs, [64, 72) the word the publish
+    // kernels write their number to, [128, 128 + 2 KB) the landing area of small lookups — a structure costs no further pinned blocks
+    // (a program with 10^5 small vectors pays 4 KB of pinned memory for each, not 12)
+    HIPCHK(pinned_alloc(reinterpret_cast<void**>(&P.h_small), 4096));
+    std::memset(P.h_small, 0, 4096);
+    P.h_pub = reinterpret_cast<unsigned long long*>(P.h_small + 8);
+    P.h_get = P.h_small + 16;
 }
 
 void ensure_tables(Pma& P, int64_t need) {
@@ -542,10 +546,6 @@ struct SeqRun {
 // that number instead of issuing device-to-host copies and synchronising the stream.  DSA_PUBLISH=0: copies + synchronisation.
 bool publish_enabled() { static const bool on = [] { const char* e = getenv("DSA_PUBLISH"); return !(e && e[0] == '0'); }(); return on; }
 unsigned int next_publish_seq(Pma& P) {
-    if (!P.h_pub) {
-        HIPCHK(pinned_alloc(reinterpret_cast<void**>(&P.h_pub), sizeof(unsigned long long)));
-        *P.h_pub = 0ull; P.pub_seq = 0;
-    }
     if (++P.pub_seq == 0) P.pub_seq = 1;
     return P.pub_seq;
 }
@@ -905,11 +905,6 @@ void get_batch(Pma& P, int mode, const int64_t* qa, const int64_t* qb, int64_t n
     if (n <= 0) return;
     if (n <= 64 && publish_enabled()) {
         // a scalar getindex or a handful of them: one launch that reads its queries from, and writes its answers to, pinned memory
-        if (!P.h_get) {
-            HIPCHK(pinned_alloc(reinterpret_cast<void**>(&P.h_get), 256 * sizeof(int64_t)));
-            std::memset(P.h_get, 0, 256 * sizeof(int64_t));
-            P.get_seq = 0;
-        }
         for (int64_t i = 0; i < n; ++i) { P.h_get[i] = qa[i]; P.h_get[64 + i] = qb ? qb[i] : 0; }
         const unsigned long long seq = ++P.get_seq;
         __atomic_thread_fence(__ATOMIC_RELEASE);
