@@ -402,7 +402,8 @@ hipError_t launch_check(KeyArr keys, const double* vals, const uint64_t* occ, in
 // view of one partition in one launch (ranges up to 16384 slots): meta = {from, to, err, partition id, cells or -1 = use the general path}
 hipError_t launch_view_small(KeyArr keys, const double* vals, const uint64_t* occ, const int64_t* sems, const int64_t* col_keys,
                              const uint8_t* col_live, int64_t table_len, int64_t capacity, int64_t col, KeyArr out_k, double* out_v,
-                             int64_t out_cap, int64_t* meta, int64_t* host, int64_t host_cells, unsigned long long seq, hipStream_t stream);
+                             int64_t out_cap, int64_t* meta, int64_t* host, int64_t host_cells, unsigned long long seq, int64_t range_from,
+                             int64_t range_to, hipStream_t stream);
 // partition slot range lookup for views: out[0] = from (first slot after the semaphore), out[1] = to, or 0,0 if missing
 hipError_t launch_partition_range(const int64_t* sems, const int64_t* col_keys, const uint8_t* col_live,
                                   int64_t table_len, int64_t capacity, int64_t col, int64_t* out, hipStream_t stream);

@@ -943,7 +943,15 @@ void get_batch(Pma& P, int mode, const int64_t* qa, const int64_t* qb, int64_t n
 
 // stored cells of the slot range [from, to] in slot order: K-pack on the device into the alternate buffer (free between
 // rebalances), then only the packed cells cross PCIe
+void view_small(Pma& P, int64_t col, int64_t range_from, int64_t range_to, std::vector<int64_t>& ks, std::vector<double>& vs);
+void read_range_general(Pma& P, int64_t from, int64_t to, std::vector<int64_t>& ks, std::vector<double>& vs);
 void read_range(Pma& P, int64_t from, int64_t to, std::vector<int64_t>& ks, std::vector<double>& vs) {
+    // up to 16384 slots (iteration over a small vector, a short slice): one launch that packs the cells and hands the first 512 to the
+    // host through pinned memory (nonzeros() of a 100-entry vector: 80 -> 25 us); longer ranges: tile counts + scan + K-pack
+    if (to >= from && from >= 1 && to - from + 1 <= 16384 && to - from + 1 <= P.cap_alloc && publish_enabled()) { view_small(P, 0, from, to, ks, vs); return; }
+    read_range_general(P, from, to, ks, vs);
+}
+void read_range_general(Pma& P, int64_t from, int64_t to, std::vector<int64_t>& ks, std::vector<double>& vs) {
     ks.clear(); vs.clear();
     if (to < from) return;
     const int alt = 1 - P.cur;
@@ -1334,7 +1342,8 @@ void mat_apply_sets(dsa_mat* h, const int64_t* I, const int64_t* J, const double
     if (err) fail(err, err_text(err));
 }
 
-void col_view_of(Pma& P, int64_t col, std::vector<int64_t>& ks, std::vector<double>& vs) {
+// range_from > 0: the stored cells of the slot range [range_from, range_to] instead of the column `col` (at most 16384 slots)
+void view_small(Pma& P, int64_t col, int64_t range_from, int64_t range_to, std::vector<int64_t>& ks, std::vector<double>& vs) {
     // one launch (partition lookup + K-pack of its slot range into the idle alternate buffer) and one host round trip for
     // partitions of up to 16384 slots; the first SPEC cells travel with the meta words, longer views fetch the rest
     constexpr int64_t SPEC = 512;
@@ -1353,7 +1362,7 @@ void col_view_of(Pma& P, int64_t col, std::vector<int64_t>& ks, std::vector<doub
         }
         const unsigned long long seq = ++P.view_seq;
         hipError_t e = launch_view_small(P.K(), P.V(), P.O(), P.sems, P.col_keys, P.col_live, P.h_ctl->table_len, P.capacity(), col,
-                                         P.KA(alt), P.vals[alt], out_cap, P.d_small, P.h_view, SPEC, seq, P.stream);
+                                         P.KA(alt), P.vals[alt], out_cap, P.d_small, P.h_view, SPEC, seq, range_from, range_to, P.stream);
         if (e != hipSuccess) fail(DSA_EHIP, std::string("view launch: ") + hipGetErrorString(e));
         volatile int64_t* seqp = P.h_view + 5;
         auto next_query = std::chrono::steady_clock::now() + std::chrono::milliseconds(2);
@@ -1372,7 +1381,7 @@ void col_view_of(Pma& P, int64_t col, std::vector<int64_t>& ks, std::vector<doub
         ks.resize((size_t)spec); vs.resize((size_t)spec);
     } else {
         hipError_t e = launch_view_small(P.K(), P.V(), P.O(), P.sems, P.col_keys, P.col_live, P.h_ctl->table_len, P.capacity(), col,
-                                         P.KA(alt), P.vals[alt], out_cap, P.d_small, nullptr, 0, 0ull, P.stream);
+                                         P.KA(alt), P.vals[alt], out_cap, P.d_small, nullptr, 0, 0ull, range_from, range_to, P.stream);
         if (e != hipSuccess) fail(DSA_EHIP, std::string("view launch: ") + hipGetErrorString(e));
         ks.resize((size_t)spec); vs.resize((size_t)spec);
         HIPCHK(hipMemcpyAsync(r, P.d_small, sizeof(r), hipMemcpyDeviceToHost, P.stream));
@@ -1382,13 +1391,15 @@ void col_view_of(Pma& P, int64_t col, std::vector<int64_t>& ks, std::vector<doub
     if (r[2] != 0) { ks.clear(); vs.clear(); fail((int32_t)r[2], "partition has no semaphore"); }
     if (r[0] == 0) { ks.clear(); vs.clear(); return; }       // empty view: the column does not exist (src/views.jl:17,24)
     const int64_t cnt = r[4];
-    if (cnt < 0) { read_range(P, r[0], r[1], ks, vs); return; }   // a long partition: general K-pack path
+    if (cnt < 0) { read_range_general(P, r[0], r[1], ks, vs); return; }   // a long partition: general K-pack path
     ks.resize((size_t)cnt); vs.resize((size_t)cnt);
     if (cnt > spec) {
         HIPCHK(hipMemcpyAsync(vs.data() + spec, P.vals[alt] + spec, (size_t)(cnt - spec) * sizeof(double), hipMemcpyDeviceToHost, P.stream));
         download_keys(P, ks.data() + spec, (char*)P.keys[alt] + (size_t)spec * P.kb(), cnt - spec);
     }
 }
+
+void col_view_of(Pma& P, int64_t col, std::vector<int64_t>& ks, std::vector<double>& vs) { view_small(P, col, 0, 0, ks, vs); }
 
 void ensure_xy(dsa_mat* h, int64_t nx, int64_t ny) {
     if (nx > h->x_cap) { if (h->d_x) hipFree(h->d_x); h->x_cap = std::max<int64_t>(nx, 1024); HIPCHK(hipMalloc(&h->d_x, (size_t)h->x_cap * sizeof(double))); }

@@ -2114,14 +2114,19 @@ __global__ __launch_bounds__(64) void k_view_small(KeyArr keys, const double* __
                                                    const uint64_t* __restrict__ occ, const int64_t* sems, const int64_t* col_keys,
                                                    const uint8_t* col_live, int64_t table_len, int64_t capacity, int64_t col,
                                                    KeyArr out_k, double* __restrict__ out_v, int64_t out_cap, int64_t* meta,
-                                                   int64_t* host, int64_t host_cells, unsigned long long seq) {
+                                                   int64_t* host, int64_t host_cells, unsigned long long seq,
+                                                   int64_t range_from, int64_t range_to) {
     // host (pinned, may be null): [0..4] the meta words, [5] the sequence number the host polls for, then host_cells keys and host_cells
     // values — the first cells of the view go straight to the host with the meta words: one launch and no copy command for a short
     // column (a D2H copy into the caller's pageable vectors + a stream synchronisation cost 60 us per view; 20 us this way)
     const int lane = threadIdx.x;
     int64_t from = 0, to = 0, err = 0, pid = 0;
-    const DFoundKey f = d_find_table(col_keys, col_live, table_len, col);
-    if (f.has && f.key == col) {
+    // range_from > 0: no partition lookup, the stored cells of the slot range [range_from, range_to] (iteration over a small vector,
+    // src/pma.jl:165-180: the same one-launch hand-over as a column view)
+    DFoundKey f{0, 0, false};
+    if (range_from > 0) { from = range_from; to = range_to; }
+    else f = d_find_table(col_keys, col_live, table_len, col);
+    if (range_from <= 0 && f.has && f.key == col) {
         const int64_t sp = sems[f.pos - 1];
         if (sp == 0) err = E_ASSERT;
         else {
@@ -2168,9 +2173,10 @@ __global__ __launch_bounds__(64) void k_view_small(KeyArr keys, const double* __
 }
 hipError_t launch_view_small(KeyArr keys, const double* vals, const uint64_t* occ, const int64_t* sems, const int64_t* col_keys,
                              const uint8_t* col_live, int64_t table_len, int64_t capacity, int64_t col, KeyArr out_k, double* out_v,
-                             int64_t out_cap, int64_t* meta, int64_t* host, int64_t host_cells, unsigned long long seq, hipStream_t stream) {
+                             int64_t out_cap, int64_t* meta, int64_t* host, int64_t host_cells, unsigned long long seq, int64_t range_from,
+                             int64_t range_to, hipStream_t stream) {
     hipLaunchKernelGGL(k_view_small, dim3(1), dim3(64), 0, stream, keys, vals, occ, sems, col_keys, col_live, table_len, capacity, col, out_k,
-                       out_v, out_cap, meta, host, host_cells, seq);
+                       out_v, out_cap, meta, host, host_cells, seq, range_from, range_to);
     return hipGetLastError();
 }
 
