@@ -1598,10 +1598,38 @@ int32_t dsa_vec_nonzeros(dsa_vec_t* h, int64_t* keys, double* vals, int64_t cap,
 // K-pack of the whole vector into its alternate slot buffer (free between rebalances); returns the number of stored cells.
 // The count is known on return, the packed cells are still being written on the vector's OWN stream: a consumer on another stream
 // (the other operand of == / +) must wait for it (wait_for_pack).
+// K-pack of up to 16384 slots by ONE launch, the count handed back through the pinned landing area of `P` (no tile counts, no scan, no
+// copy, no stream synchronisation: 50 -> 15 us); returns -1 when the range does not qualify
+static int64_t pack_small(Pma& P, KeyArr k, const double* v, const uint64_t* occ, int64_t from, int64_t to, KeyArr ok, double* ov, int64_t out_cap) {
+    if (!publish_enabled() || to < from || from < 1 || to - from + 1 > 16384 || to - from + 1 > out_cap) return -1;
+    constexpr int64_t SPEC = 512;
+    if (!P.h_view) {
+        HIPCHK(pinned_alloc(reinterpret_cast<void**>(&P.h_view), (size_t)(8 + 2 * SPEC) * sizeof(int64_t)));
+        std::memset(P.h_view, 0, (size_t)(8 + 2 * SPEC) * sizeof(int64_t));
+        P.view_seq = 0;
+    }
+    const unsigned long long seq = ++P.view_seq;
+    hipError_t e = launch_view_small(k, v, occ, nullptr, nullptr, nullptr, 0, to, 0, ok, ov, out_cap, P.d_small, P.h_view, 0, seq, from, to, P.stream);
+    if (e != hipSuccess) fail(DSA_EHIP, std::string("pack launch: ") + hipGetErrorString(e));
+    volatile int64_t* seqp = P.h_view + 5;
+    auto next_query = std::chrono::steady_clock::now() + std::chrono::milliseconds(2);
+    while ((unsigned long long)__atomic_load_n(seqp, __ATOMIC_ACQUIRE) != seq) {
+        if (std::chrono::steady_clock::now() < next_query) continue;
+        const hipError_t q = hipStreamQuery(P.stream);
+        if (q == hipErrorNotReady) { next_query = std::chrono::steady_clock::now() + std::chrono::milliseconds(2); continue; }
+        if (q != hipSuccess) fail(DSA_EHIP, std::string("pack: ") + hipGetErrorString(q));
+        if ((unsigned long long)__atomic_load_n(seqp, __ATOMIC_ACQUIRE) != seq) fail(DSA_EHIP, "pack kernel finished without publishing its result");
+    }
+    return P.h_view[4];
+}
 static int64_t vec_pack_alt(dsa_vec_t* h) {
     Pma& P = h->P;
     int64_t cnt = 0;
     const int alt = 1 - P.cur;
+    {
+        const int64_t c = pack_small(P, P.K(), P.V(), P.O(), 1, P.capacity(), P.KA(alt), P.vals[alt], P.cap_alloc);
+        if (c >= 0) return c;
+    }
     hipError_t e = launch_compact_range(P.K(), P.V(), P.O(), 1, P.capacity(), P.KA(alt), P.vals[alt], P.cap_alloc, &P.work, &cnt, P.stream);
     if (e != hipSuccess) fail(DSA_EHIP, std::string("compact launch: ") + hipGetErrorString(e));
     return cnt;
@@ -1652,7 +1680,7 @@ int32_t dsa_vec_axpby(dsa_vec_t* a, double alpha, dsa_vec_t* b, double beta, int
     char* scratch = nullptr;
     const size_t off_mv = (size_t)total * 8, off_ok = 2 * off_mv, off_ov = 3 * off_mv, off_keep = 4 * off_mv,
                  off_cnt = off_keep + (size_t)nwords * 8, off_off = off_cnt + (size_t)(ntiles + 8) * 4, bytes = off_off + (size_t)(ntiles + 8) * 4;
-    HIPCHK(hipMalloc(&scratch, bytes));
+    HIPCHK(pool_alloc(reinterpret_cast<void**>(&scratch), bytes));      // (the caching allocator: a hipMalloc + hipFree pair per call cost more than the kernels)
     try {
         int64_t* mk = reinterpret_cast<int64_t*>(scratch);
         double* mv = reinterpret_cast<double*>(scratch + off_mv);
@@ -1664,18 +1692,21 @@ int32_t dsa_vec_axpby(dsa_vec_t* a, double alpha, dsa_vec_t* b, double beta, int
         hipError_t e = launch_merge_axpby(A.KA(1 - A.cur), A.vals[1 - A.cur], na, alpha, B.KA(1 - B.cur), B.vals[1 - B.cur], nb, beta,
                                           mk, mv, keep, A.stream);
         if (e != hipSuccess) fail(DSA_EHIP, std::string("merge launch: ") + hipGetErrorString(e));
-        int64_t cnt = 0;
-        e = launch_compact_range(KeyArr{mk, 1, 0}, mv, keep, 1, total, KeyArr{ok, 1, 0}, ov, total, &work, &cnt, A.stream);
-        if (e != hipSuccess) fail(DSA_EHIP, std::string("compact launch: ") + hipGetErrorString(e));
+        int64_t cnt = pack_small(A, KeyArr{mk, 1, 0}, mv, keep, 1, total, KeyArr{ok, 1, 0}, ov, total);
+        if (cnt < 0) {
+            e = launch_compact_range(KeyArr{mk, 1, 0}, mv, keep, 1, total, KeyArr{ok, 1, 0}, ov, total, &work, &cnt, A.stream);
+            if (e != hipSuccess) fail(DSA_EHIP, std::string("compact launch: ") + hipGetErrorString(e));
+        }
         if (cnt > cap) fail(DSA_ECAP, "output buffers too small");
         if (cnt > 0) {
             HIPCHK(hipMemcpyAsync(keys, ok, (size_t)cnt * 8, hipMemcpyDeviceToHost, A.stream));
             HIPCHK(hipMemcpyAsync(vals, ov, (size_t)cnt * 8, hipMemcpyDeviceToHost, A.stream));
             HIPCHK(hipStreamSynchronize(A.stream));
         }
+        else HIPCHK(hipStreamSynchronize(A.stream));      // the scratch goes back to the pool: nothing may still use it
         *n_out = cnt;
-    } catch (...) { hipFree(scratch); throw; }
-    hipFree(scratch);
+    } catch (...) { (void)hipStreamSynchronize(A.stream); pool_free(scratch); throw; }
+    pool_free(scratch);
     API_CATCH
 }
 int32_t dsa_vec_shrink_size(dsa_vec_t* h) {     // shrink_size!  src/vector.jl:64 (+ _guess_length :7-8)
