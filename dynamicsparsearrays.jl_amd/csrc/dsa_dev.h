@@ -304,6 +304,8 @@ hipError_t build_prepare(const int64_t* d_part, const int64_t* d_key, const doub
 hipError_t build_emit(const double* d_val, int32_t combine, BuildScratch& s, KeyArr out_keys, double* out_vals,
                       int64_t* part_keys, int mode, int64_t nparts_explicit, hipStream_t stream);
 void build_abort(BuildScratch& s);
+// a vector of up to 1024 entries by one launch; io = pinned landing area (see k_build_small_vec)
+hipError_t launch_build_small_vec(int64_t* io, int n, int cap, int32_t combine, KeyArr out_k, double* out_v, unsigned long long seq, hipStream_t stream);
 
 // n_avail >= n_ops: ops resident behind the chunk (an append run may consume them); run_ok enables append-run detection
 hipError_t launch_sequencer(KeyArr keys, double* vals, uint64_t* occ, int64_t* sems, int64_t* col_keys,

@@ -943,6 +943,27 @@ void get_batch(Pma& P, int mode, const int64_t* qa, const int64_t* qb, int64_t n
 
 // stored cells of the slot range [from, to] in slot order: K-pack on the device into the alternate buffer (free between
 // rebalances), then only the packed cells cross PCIe
+// the pinned landing area of views, small packs and small builds: 8 header words (meta [0..4], sequence number [5]) + 2 x 1024 cells
+constexpr int64_t VIEW_AREA_CELLS = 1024;
+void ensure_view_area(Pma& P) {
+    if (P.h_view) return;
+    HIPCHK(pinned_alloc(reinterpret_cast<void**>(&P.h_view), (size_t)(8 + 2 * VIEW_AREA_CELLS) * sizeof(int64_t)));
+    std::memset(P.h_view, 0, (size_t)(8 + 2 * VIEW_AREA_CELLS) * sizeof(int64_t));
+    P.view_seq = 0;
+}
+// polls word [5] of the landing area for `seq` (the stream is asked now and then: a failed launch cannot hang the host)
+void wait_view_seq(Pma& P, unsigned long long seq, const char* what) {
+    volatile int64_t* seqp = P.h_view + 5;
+    auto next_query = std::chrono::steady_clock::now() + std::chrono::milliseconds(2);
+    while ((unsigned long long)__atomic_load_n(seqp, __ATOMIC_ACQUIRE) != seq) {
+        if (std::chrono::steady_clock::now() < next_query) continue;
+        const hipError_t q = hipStreamQuery(P.stream);
+        if (q == hipErrorNotReady) { next_query = std::chrono::steady_clock::now() + std::chrono::milliseconds(2); continue; }
+        if (q != hipSuccess) fail(DSA_EHIP, std::string(what) + ": " + hipGetErrorString(q));
+        if ((unsigned long long)__atomic_load_n(seqp, __ATOMIC_ACQUIRE) != seq) fail(DSA_EHIP, std::string(what) + ": kernel finished without publishing its result");
+    }
+}
+
 void view_small(Pma& P, int64_t col, int64_t range_from, int64_t range_to, std::vector<int64_t>& ks, std::vector<double>& vs);
 void read_range_general(Pma& P, int64_t from, int64_t to, std::vector<int64_t>& ks, std::vector<double>& vs);
 void read_range(Pma& P, int64_t from, int64_t to, std::vector<int64_t>& ks, std::vector<double>& vs) {
@@ -1023,6 +1044,32 @@ void pma_build_dev(Pma& P, const int64_t* d_part, const int64_t* d_key, const do
 // uploads host arrays (any of them may be nullptr) and runs the device builder
 void pma_build_from_host(Pma& P, const int64_t* part, const int64_t* key, const double* val, int64_t nnz, int32_t combine,
                          int mode, int64_t nparts_explicit) {
+    static const bool small_build = [] { const char* e = getenv("DSA_SMALL_BUILD"); return !(e && e[0] == '0'); }();
+    if (small_build && mode == 1 && part == nullptr && nnz >= 1 && nnz <= VIEW_AREA_CELLS && publish_enabled() && getenv("DSA_FAIL_BUILD") == nullptr) {
+        // a small vector: ONE launch sorts, folds and packs the caller's pairs (read from the pinned landing area) in front of the slot
+        // buffers and hands the entry count back; then the spread.  130 -> ~45 us for 50 entries (DSA_SMALL_BUILD=0: the general builder)
+        KeyScan ks; ks.add(key, nnz);
+        P.wide = !ks.fit32();
+        ensure_view_area(P);
+        std::memcpy(P.h_view + 8, key, (size_t)nnz * sizeof(int64_t));
+        std::memcpy(P.h_view + 8 + VIEW_AREA_CELLS, val, (size_t)nnz * sizeof(double));
+        ensure_capacity_alloc(P, 2 * capacity_for(nnz));          // (an upper bound: folding can only shorten the stream)
+        const unsigned long long seq = ++P.view_seq;
+        __atomic_thread_fence(__ATOMIC_RELEASE);
+        hipError_t e = launch_build_small_vec(P.h_view, (int)nnz, (int)VIEW_AREA_CELLS, combine, P.K(), P.V(), seq, P.stream);
+        if (e != hipSuccess) fail(DSA_EHIP, std::string("small build launch: ") + hipGetErrorString(e));
+        wait_view_seq(P, seq, "small build");
+        const int64_t n = P.h_view[0];
+        if (n < 1 || n > nnz) fail(DSA_EASSERT, "small build returned an impossible entry count");
+        const int64_t capacity = capacity_for(n);
+        set_geometry_for_new(P, capacity, n);
+        ++P.layout_epoch;
+        P.h_ctl->stat_rebalances = 0; P.h_ctl->stat_window_slots = 0;
+        if (P.capacity() != P.h_ctl->segment_capacity) { P.h_ctl->stat_rebalances = 1; P.h_ctl->stat_window_slots = P.capacity(); }
+        root_rebalance(P, n, P.capacity(), n, true);
+        upload_ctl(P);
+        return;
+    }
     int64_t *dP = nullptr, *dK = nullptr; double* dV = nullptr;
     auto release = [&] { pool_free(dP); pool_free(dK); pool_free(dV); };
     try {
@@ -1355,11 +1402,7 @@ void view_small(Pma& P, int64_t col, int64_t range_from, int64_t range_to, std::
     if (publish_enabled()) {
         // the kernel writes the meta words and the first SPEC cells straight into a pinned landing area and then a sequence number: the host
         // polls for it — no copy command, no stream synchronisation (60 -> 20 us per view; DSA_PUBLISH=0 = copies + synchronisation)
-        if (!P.h_view) {
-            HIPCHK(pinned_alloc(reinterpret_cast<void**>(&P.h_view), (size_t)(8 + 2 * SPEC) * sizeof(int64_t)));
-            std::memset(P.h_view, 0, (size_t)(8 + 2 * SPEC) * sizeof(int64_t));
-            P.view_seq = 0;
-        }
+        ensure_view_area(P);
         const unsigned long long seq = ++P.view_seq;
         hipError_t e = launch_view_small(P.K(), P.V(), P.O(), P.sems, P.col_keys, P.col_live, P.h_ctl->table_len, P.capacity(), col,
                                          P.KA(alt), P.vals[alt], out_cap, P.d_small, P.h_view, SPEC, seq, range_from, range_to, P.stream);
@@ -1602,12 +1645,7 @@ int32_t dsa_vec_nonzeros(dsa_vec_t* h, int64_t* keys, double* vals, int64_t cap,
 // copy, no stream synchronisation: 50 -> 15 us); returns -1 when the range does not qualify
 static int64_t pack_small(Pma& P, KeyArr k, const double* v, const uint64_t* occ, int64_t from, int64_t to, KeyArr ok, double* ov, int64_t out_cap) {
     if (!publish_enabled() || to < from || from < 1 || to - from + 1 > 16384 || to - from + 1 > out_cap) return -1;
-    constexpr int64_t SPEC = 512;
-    if (!P.h_view) {
-        HIPCHK(pinned_alloc(reinterpret_cast<void**>(&P.h_view), (size_t)(8 + 2 * SPEC) * sizeof(int64_t)));
-        std::memset(P.h_view, 0, (size_t)(8 + 2 * SPEC) * sizeof(int64_t));
-        P.view_seq = 0;
-    }
+    ensure_view_area(P);
     const unsigned long long seq = ++P.view_seq;
     hipError_t e = launch_view_small(k, v, occ, nullptr, nullptr, nullptr, 0, to, 0, ok, ov, out_cap, P.d_small, P.h_view, 0, seq, from, to, P.stream);
     if (e != hipSuccess) fail(DSA_EHIP, std::string("pack launch: ") + hipGetErrorString(e));
