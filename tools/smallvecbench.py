@@ -22,6 +22,10 @@ print("v[k] = x; v[k] on 200 vectors in turn   %.1f us" % us(write_one, 600))
 def batch16():
     i = next(it); vs[i % 200].set_batch(np.arange(5000 + 16 * i, 5016 + 16 * i, dtype=np.int64), v50[:16])
 print("set_batch of 16 new keys                %.1f us" % us(batch16, 400))
+rng = np.random.default_rng(5)
+def batch16r():
+    i = next(it); vs[i % 200].set_batch(rng.integers(1, 10**6, 16), v50[:16])
+print("set_batch of 16 scattered keys          %.1f us" % us(batch16r, 400))
 print("nonzeros() of a ~100-entry vector       %.1f us" % us(lambda: vs[next(it) % 200].nonzeros(), 400))
 a, b = vs[0], vs[1]
 print("v1 + v2                                 %.1f us" % us(lambda: a + b, 200))
