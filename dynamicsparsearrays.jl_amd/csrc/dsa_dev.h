@@ -310,6 +310,7 @@ hipError_t launch_build_small_vec(int64_t* io, int n, int cap, int32_t combine, 
 // n_avail >= n_ops: ops resident behind the chunk (an append run may consume them); run_ok enables append-run detection
 hipError_t launch_sequencer(KeyArr keys, double* vals, uint64_t* occ, int64_t* sems, int64_t* col_keys,
                             uint8_t* col_live, Ctl* ctl, const Op* ops, int64_t n_ops, int64_t n_avail, bool run_ok,
+                            Ctl* host_ctl, unsigned long long* host_seq, unsigned int seq,
                             hipStream_t stream);
 // flags / d_T: cell types and cell count written by k_run_expand (MappedPackedCSC runs), nullptr for a vector run
 // saved_memo: append_run_memo_bytes() of zero-initialised device memory owned by the handle (the replay's memo survives in it from

@@ -567,17 +567,13 @@ void seq_launch(SeqRun& r, bool upload = true) {
     // pinned h_ctl: H2D, kernel and D2H are stream-ordered; the host does not touch h_ctl until the next synchronize
     if (upload) HIPCHK(hipMemcpyAsync(P.d_ctl, P.h_ctl, sizeof(Ctl), hipMemcpyHostToDevice, P.stream));
     ++P.layout_epoch;
+    const bool publish = publish_enabled();
+    const unsigned int seq = publish ? next_publish_seq(P) : 0u;       // the sequencer hands its control block back itself
     hipError_t e = launch_sequencer(P.K(), P.V(), P.O(), P.has_sems ? P.sems : nullptr, P.has_cols ? P.col_keys : nullptr,
                                     P.has_cols ? P.col_live : nullptr, P.d_ctl, P.d_ops, r.n, std::max(r.n, r.n_avail),
-                                    g_append_runs && P.occ_old != nullptr, P.stream);
+                                    g_append_runs && P.occ_old != nullptr, publish ? P.h_ctl : nullptr, publish ? P.h_pub : nullptr, seq, P.stream);
     if (e != hipSuccess) fail(DSA_EHIP, std::string("sequencer launch: ") + hipGetErrorString(e));
-    if (publish_enabled()) {
-        const unsigned int seq = next_publish_seq(P);
-        e = launch_publish_ctl(P.d_ctl, P.h_ctl, P.h_pub, seq, P.stream);
-        if (e != hipSuccess) fail(DSA_EHIP, std::string("publish launch: ") + hipGetErrorString(e));
-    } else {
-        HIPCHK(hipMemcpyAsync(P.h_ctl, P.d_ctl, sizeof(Ctl), hipMemcpyDeviceToHost, P.stream));
-    }
+    if (!publish) HIPCHK(hipMemcpyAsync(P.h_ctl, P.d_ctl, sizeof(Ctl), hipMemcpyDeviceToHost, P.stream));
 }
 
 void seq_start(SeqRun& r, Pma& P, const std::vector<Op>& ops) {

@@ -1853,7 +1853,10 @@ __device__ int d_exec(Seq& S, const Op& op) {
 
 __global__ __launch_bounds__(SEQ_BLOCK) void k_sequencer(KeyArr keys, double* vals, uint64_t* occ, int64_t* sems,
                                                          int64_t* col_keys, uint8_t* col_live, Ctl* ctl,
-                                                         const Op* ops, int64_t n_ops, int64_t n_avail, int run_ok) {
+                                                         const Op* ops, int64_t n_ops, int64_t n_avail, int run_ok,
+                                                         Ctl* host_ctl, unsigned long long* host_seq, unsigned int seq) {
+    // host_ctl / host_seq (pinned, may be null): the kernel hands its control block back itself — every word, then `seq` into the word the
+    // host polls for — instead of a publish launch behind it (parbatch.hip: k_publish_ctl)
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     __shared__ int64_t sRed[SEQ_BLOCK / 64];
     __shared__ uint32_t sWordOff[SMALL_W / 64 + 1];
@@ -1924,11 +1927,25 @@ __global__ __launch_bounds__(SEQ_BLOCK) void k_sequencer(KeyArr keys, double* va
         S.prof[7] = DSA_TICK() - tk0;
         for (int q = 0; q < 16; ++q) ctl->prof[q] += S.prof[q];
     }
+    if (host_seq != nullptr) {
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();                               // thread 0's words are on their way to the L2
+        const unsigned long long* src = reinterpret_cast<const unsigned long long*>(ctl);
+        unsigned long long* dst = reinterpret_cast<unsigned long long*>(host_ctl);
+        for (int q = threadIdx.x; q < (int)(sizeof(Ctl) / 8); q += SEQ_BLOCK)
+            __hip_atomic_store(dst + q, __hip_atomic_load(src + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __atomic_thread_fence(__ATOMIC_RELEASE);
+            __hip_atomic_store(host_seq, (unsigned long long)seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 }
 
 hipError_t launch_sequencer(KeyArr keys, double* vals, uint64_t* occ, int64_t* sems, int64_t* col_keys,
                             uint8_t* col_live, Ctl* ctl, const Op* ops, int64_t n_ops, int64_t n_avail, bool run_ok,
-                            hipStream_t stream) {
+                            Ctl* host_ctl, unsigned long long* host_seq, unsigned int seq, hipStream_t stream) {
     const size_t lds_bytes = (size_t)SMALL_W * (sizeof(int64_t) + sizeof(double));
     static PerDeviceOnce once;
     {
@@ -1938,7 +1955,7 @@ hipError_t launch_sequencer(KeyArr keys, double* vals, uint64_t* occ, int64_t* s
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(k_sequencer, dim3(1), dim3(SEQ_BLOCK), lds_bytes, stream, keys, vals, occ, sems, col_keys, col_live,
-                       ctl, ops, n_ops, n_avail, run_ok ? 1 : 0);
+                       ctl, ops, n_ops, n_avail, run_ok ? 1 : 0, host_ctl, host_seq, seq);
     return hipGetLastError();
 }
 
