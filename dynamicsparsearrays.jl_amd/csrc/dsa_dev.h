@@ -373,7 +373,6 @@ struct DevBufs { void* keys; double* vals; uint64_t* occ; int64_t* sems; int64_t
 hipError_t launch_burst(const DevBufs* bufs, Ctl* ctl, const Op* ops, RoundState* rs, Plan* plans, int rounds, BurstGraph* cache,
                         BurstPublish pub, hipStream_t stream);
 void burst_graph_destroy(BurstGraph* cache);
-hipError_t launch_publish_ctl(const Ctl* ctl, Ctl* host_ctl, unsigned long long* host_seq, unsigned int seq, hipStream_t stream);
 // the same rounds by one persistent workgroup (phases with short conflict-free prefixes); leaves with RoundState::stop = 0 (max_rounds
 // used up), 1 (the op at the cursor needs the sequencer), 2 (batch finished) or 3 (full prefixes: back to the grid rounds)
 hipError_t launch_local_rounds(const DevBufs* bufs, Ctl* ctl, const Op* ops, RoundState* rs, int max_rounds, BurstPublish pub, hipStream_t stream);

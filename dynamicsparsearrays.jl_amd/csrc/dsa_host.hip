@@ -541,7 +541,7 @@ struct SeqRun {
     bool defer_merge = false; // leave pending table entries to the caller (a batch that goes on with more launches)
 };
 
-// Hand-over of a launch's result through pinned memory (parbatch.hip: k_publish / k_publish_ctl): the last kernel of the launch
+// Hand-over of a launch's result through pinned memory (parbatch.hip: k_publish; the sequencer does it in its own epilogue): the last kernel of the launch
 // writes the control block (and the round state) into the host's pinned mirrors and then a number into P.h_pub; the host polls for
 // that number instead of issuing device-to-host copies and synchronising the stream.  DSA_PUBLISH=0: copies + synchronisation.
 bool publish_enabled() { static const bool on = [] { const char* e = getenv("DSA_PUBLISH"); return !(e && e[0] == '0'); }(); return on; }

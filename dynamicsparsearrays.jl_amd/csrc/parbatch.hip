@@ -918,24 +918,6 @@ __global__ __launch_bounds__(256) void k_publish(const RoundState* rs, const Ctl
     }
 }
 
-// the same hand-over behind a sequencer launch (no round state; the number is a launch argument: these launches are not captured)
-__global__ __launch_bounds__(256) void k_publish_ctl(const Ctl* ctl, Ctl* host_ctl, unsigned long long* host_seq, unsigned int seq) {
-    const unsigned long long* src = reinterpret_cast<const unsigned long long*>(ctl);
-    unsigned long long* dst = reinterpret_cast<unsigned long long*>(host_ctl);
-    for (int i = threadIdx.x; i < (int)(sizeof(Ctl) / 8); i += 256)
-        __hip_atomic_store(dst + i, __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __builtin_amdgcn_s_waitcnt(0);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __atomic_thread_fence(__ATOMIC_RELEASE);
-        __hip_atomic_store(host_seq, (unsigned long long)seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-}
-hipError_t launch_publish_ctl(const Ctl* ctl, Ctl* host_ctl, unsigned long long* host_seq, unsigned int seq, hipStream_t stream) {
-    hipLaunchKernelGGL(k_publish_ctl, dim3(1), dim3(256), 0, stream, ctl, host_ctl, host_seq, seq);
-    return hipGetLastError();
-}
-
 hipError_t launch_local_rounds(const DevBufs* bufs, Ctl* ctl, const Op* ops, RoundState* rs, int max_rounds, BurstPublish pub, hipStream_t stream) {
     constexpr size_t lds = (size_t)LR_WAVES * LR_MAX_W * (sizeof(int64_t) + sizeof(double));
     static PerDeviceOnce once;

@@ -1856,7 +1856,7 @@ __global__ __launch_bounds__(SEQ_BLOCK) void k_sequencer(KeyArr keys, double* va
                                                          const Op* ops, int64_t n_ops, int64_t n_avail, int run_ok,
                                                          Ctl* host_ctl, unsigned long long* host_seq, unsigned int seq) {
     // host_ctl / host_seq (pinned, may be null): the kernel hands its control block back itself — every word, then `seq` into the word the
-    // host polls for — instead of a publish launch behind it (parbatch.hip: k_publish_ctl)
+    // host polls for — instead of a publish launch behind it (as parbatch.hip's k_publish does for a burst of rounds)
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     __shared__ int64_t sRed[SEQ_BLOCK / 64];
     __shared__ uint32_t sWordOff[SMALL_W / 64 + 1];
