@@ -696,7 +696,13 @@ int64_t run_ops_parallel(Pma& P, const std::vector<Op>& ops, int32_t* err) {
     constexpr int64_t MERGE_AT = 256;       // pending table entries (of at most 1024) that trigger the grid-wide merge between launches
     ensure_key_width(P, ops);
     ensure_ops(P, n);
-    HIPCHK(hipMemcpyAsync(P.d_ops, ops.data(), (size_t)n * sizeof(Op), hipMemcpyHostToDevice, P.stream));
+    {
+        const auto tu0 = std::chrono::steady_clock::now();
+        HIPCHK(hipMemcpyAsync(P.d_ops, ops.data(), (size_t)n * sizeof(Op), hipMemcpyHostToDevice, P.stream));
+        static const bool dbg_up = getenv("DSA_DBG_SPLIT") != nullptr;
+        if (dbg_up) fprintf(stderr, "  [run_ops_parallel] upload of %lld ops (%.1f MB, pageable): %.3f ms on the host\n", (long long)n, n * sizeof(Op) / 1e6,
+                            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tu0).count());
+    }
     if (!P.d_plans) {
         HIPCHK(hipMalloc(&P.d_plans, (size_t)GMAX * sizeof(Plan)));
         HIPCHK(hipMalloc(&P.d_bufs, sizeof(DevBufs)));
