@@ -192,6 +192,20 @@ __device__ __forceinline__ void gap_pair(const SpreadGeom& g, int q, int* k_out,
     *gap0 = (k > 0 && d0 == q);
     *gap1 = (d1 == q + 1);
 }
+// occupancy of window offsets 64t+1 .. 64t+64 after spread! (bit b <-> offset 64t+1+b)
+__device__ __forceinline__ uint64_t spread_word_bits(const SpreadGeom& g, int t) {
+    uint64_t bits = ~0ull;
+    const int E = (int)g.E;
+    const int lo = 64 * t, hi = lo + 64;
+    int k = gaps_le(g, lo);
+#pragma clang loop vectorize(disable) unroll(disable)
+    for (++k; k <= E; ++k) {
+        const int d = gap_D(g, k);
+        if (d > hi) break;
+        bits &= ~(1ull << (d - lo - 1));
+    }
+    return bits;
+}
 // bit-interleave: bit i of x -> bit 2i
 __device__ __forceinline__ uint64_t spread_bits32(uint32_t x) {
     uint64_t v = x;
@@ -316,8 +330,13 @@ hipError_t launch_sequencer(KeyArr keys, double* vals, uint64_t* occ, int64_t* s
 // saved_memo: append_run_memo_bytes() of zero-initialised device memory owned by the handle (the replay's memo survives in it from
 // run to run while the array's geometry stays the same), or nullptr
 size_t append_run_memo_bytes();
+// m3_out: the 8 words k_append_model3 wrote for this run (cells it placed, status), or nullptr
 hipError_t launch_append_run(uint64_t* occ, Ctl* ctl, int64_t i0, int64_t R, const uint64_t* flags, const int64_t* d_T,
-                             uint64_t* saved_memo, hipStream_t stream);
+                             uint64_t* saved_memo, const int64_t* m3_out, hipStream_t stream);
+// count-only replay of an append run (appendmodel.hip), launched in front of launch_append_run on the same bitmap / control block.
+// out = 8 x int64 device words: [0] cells placed [1] 0 not eligible (nothing changed) / 1 ran / 2 ran and stopped in front of an op
+// that needs _extend! [2] reason when not eligible [3..7] dev counters (events above the tables, table levels, ticks per phase)
+hipError_t launch_append_model3(uint64_t* occ, Ctl* ctl, int64_t R, const uint64_t* flags, const int64_t* d_T, int64_t* out, hipStream_t stream);
 hipError_t launch_run_expand(const Op* ops, int64_t i0, int64_t R, const Ctl* ctl, int64_t* col_keys, uint8_t* col_live, Op* cells,
                              uint64_t* flags, int64_t* out, hipStream_t stream);
 

@@ -656,13 +656,28 @@ bool seq_step(SeqRun& r) {
                 if (e != hipSuccess) fail(DSA_EHIP, std::string("run expand launch: ") + hipGetErrorString(e));
             }
             HIPCHK(hipMemcpyAsync(P.occ_old, P.O(), (size_t)words * sizeof(uint64_t), hipMemcpyDeviceToDevice, P.stream));
-            if (!P.run_memo) {
-                HIPCHK(hipMalloc(&P.run_memo, append_run_memo_bytes()));
-                HIPCHK(hipMemsetAsync(P.run_memo, 0, append_run_memo_bytes(), P.stream));
+            if (!P.run_memo) {                  // the memo of k_append_run, then the 8 result words of k_append_model3
+                HIPCHK(hipMalloc(&P.run_memo, append_run_memo_bytes() + 8 * sizeof(int64_t)));
+                HIPCHK(hipMemsetAsync(P.run_memo, 0, append_run_memo_bytes() + 8 * sizeof(int64_t), P.stream));
             }
-            e = launch_append_run(P.O(), P.d_ctl, i0, R, P.has_cols ? P.run_flags : nullptr, P.has_cols ? P.run_out : nullptr, P.run_memo, P.stream);
+            // the count-only replay first (appendmodel.hip); what it cannot take — short runs, small segments, a tail outside the last
+            // leaf — and whatever it leaves is replayed per op by k_append_run.  DSA_MODEL3=0: per-op replay only (A/B, coverage)
+            static const bool model3 = [] { const char* v = getenv("DSA_MODEL3"); return !(v && v[0] == '0'); }();
+            int64_t* m3_out = model3 ? reinterpret_cast<int64_t*>(reinterpret_cast<char*>(P.run_memo) + append_run_memo_bytes()) : nullptr;
+            if (model3) {
+                e = launch_append_model3(P.O(), P.d_ctl, R, P.has_cols ? P.run_flags : nullptr, P.has_cols ? P.run_out : nullptr, m3_out, P.stream);
+                if (e != hipSuccess) fail(DSA_EHIP, std::string("append model launch: ") + hipGetErrorString(e));
+            }
+            e = launch_append_run(P.O(), P.d_ctl, i0, R, P.has_cols ? P.run_flags : nullptr, P.has_cols ? P.run_out : nullptr, P.run_memo, m3_out, P.stream);
             if (e != hipSuccess) fail(DSA_EHIP, std::string("append run launch: ") + hipGetErrorString(e));
             permute_run(P, P.has_cols ? P.run_cells : P.d_ops, P.has_cols ? 0 : i0, n0);
+            if (m3_out != nullptr && getenv("DSA_DBG_RUN")) {
+                int64_t o[8];
+                HIPCHK(hipMemcpyAsync(o, m3_out, sizeof(o), hipMemcpyDeviceToHost, P.stream));
+                HIPCHK(hipStreamSynchronize(P.stream));
+                fprintf(stderr, "[append model v3] run of %lld ops: placed %lld status %lld reason %lld | events above the tables %lld, table levels %lld | counts %.1f us tables %.1f us driver %.1f us\n",
+                        (long long)R, (long long)o[0], (long long)o[1], (long long)o[2], (long long)o[3], (long long)o[4], o[5] / 100.0, o[6] / 100.0, o[7] / 100.0);
+            }
             if (++r.guard > 4 * r.n + 1000000) fail(DSA_EASSERT, "sequencer made no progress");
             seq_launch(r, false);
             return true;

@@ -278,20 +278,7 @@ constexpr int RUN_BLOCK_LOG2 = 12;
 
 struct RunComm { int64_t idx, L, reb, slots, small; int32_t need, pad; };
 
-// occupancy of window offsets 64t+1 .. 64t+64 after spread! (bit b <-> offset 64t+1+b)
-__device__ __forceinline__ uint64_t spread_word_bits(const SpreadGeom& g, int t) {
-    uint64_t bits = ~0ull;
-    const int E = (int)g.E;
-    const int lo = 64 * t, hi = lo + 64;
-    int k = gaps_le(g, lo);
-#pragma clang loop vectorize(disable) unroll(disable)
-    for (++k; k <= E; ++k) {
-        const int d = gap_D(g, k);
-        if (d > hi) break;
-        bits &= ~(1ull << (d - lo - 1));
-    }
-    return bits;
-}
+// (spread_word_bits: dsa_dev.h)
 // 1-based offset of the last cell after spread! of m >= 1 cells over W slots
 __device__ __forceinline__ int64_t spread_last_cell(const SpreadGeom& g) {
     int q = (int)g.W, k = (int)g.E;
@@ -1258,7 +1245,8 @@ hipError_t launch_run_expand(const Op* ops, int64_t i0, int64_t R, const Ctl* ct
 // updates the control block: next_op, nb_elements, statistics.  A run ends early at an op that needs _extend! /
 // _shrink!; when that is the very first op, no_run_at tells the sequencer to execute it on the normal path.
 __global__ __launch_bounds__(SEQ_BLOCK) void k_append_run(uint64_t* occ, Ctl* ctl, int64_t i0, int64_t R, const uint64_t* flags,
-                                                          const int64_t* d_T, int wide_pos, int no_model, uint64_t* saved_memo) {
+                                                          const int64_t* d_T, int wide_pos, int no_model, uint64_t* saved_memo,
+                                                          const int64_t* m3_out) {
     __shared__ int64_t sRed[SEQ_BLOCK / 64];
     __shared__ RunComm sRun;
     extern __shared__ __attribute__((aligned(16))) unsigned char run_lds[];
@@ -1277,8 +1265,15 @@ __global__ __launch_bounds__(SEQ_BLOCK) void k_append_run(uint64_t* occ, Ctl* ct
     }
     constexpr int MEMO_U4 = (int)(sizeof(RunMemo) / 16);
     static_assert(sizeof(RunMemo) % 16 == 0, "the memo is saved in 16-byte pieces");
-    const bool memo_warm = saved_memo != nullptr && saved_memo[2 * MEMO_U4] == memo_tag;
-    if (memo_warm) {
+    // the count-only replay (appendmodel.hip: k_append_model3, launched in front of this kernel) has placed the first m3_idx cells
+    // on the bitmap and counted them in the control block; m3_ended: it stopped in front of an op that no level accepts
+    const int64_t m3_idx = (m3_out != nullptr && m3_out[1] != 0) ? m3_out[0] : 0;
+    const bool m3_ended = m3_out != nullptr && m3_out[1] == 2;
+    const int64_t end_cells = flags != nullptr ? d_T[0] : R;
+    const bool m3_all = m3_ended || (m3_out != nullptr && m3_out[1] != 0 && m3_idx >= end_cells);      // nothing left for this kernel's replay
+    const bool memo_warm = !m3_all && saved_memo != nullptr && saved_memo[2 * MEMO_U4] == memo_tag;
+    if (m3_all) {
+    } else if (memo_warm) {
         const uint4* src = reinterpret_cast<const uint4*>(saved_memo);
         uint4* dst = reinterpret_cast<uint4*>(run_lds);
         for (int k = threadIdx.x; k < MEMO_U4; k += SEQ_BLOCK) dst[k] = src[k];
@@ -1300,15 +1295,15 @@ __global__ __launch_bounds__(SEQ_BLOCK) void k_append_run(uint64_t* occ, Ctl* ct
     __syncthreads();
     RunComm* rc = &sRun;
     // cells of the run: the ops themselves (vector), or the expanded cell stream of k_run_expand (flags != nullptr)
-    int64_t idx = 0, L = d_prev_occupied(occ, S.capacity, 1);
-    const int64_t end = flags != nullptr ? d_T[0] : R;
+    int64_t idx = m3_idx, L = d_prev_occupied(occ, S.capacity, 1);
+    const int64_t end = end_cells;
     int64_t t_fast = 0, t_slow = 0, n_slow = 0;
     const bool narrow_pos = !wide_pos && S.capacity <= (1ll << 30) && end <= (1ll << 30);
     const int64_t c_begin = clock64(), w_begin = wall_clock64();
     const bool use_v2 = no_model == 0 && S.capacity >= RUN_BLOCK;
     if (threadIdx.x == 0) { sMemo.m2.outside_valid = 0; sMemo.m2.pending = 0; }
     __syncthreads();
-    while (idx < end) {
+    while (idx < end && !m3_ended) {
         if (use_v2 && !sMemo.m2.outside_valid) {
             // model v2: suffix cell counts of the levels wider than the block, without the last block (all threads, uniform)
             for (int j = 0; j <= (int)S.height && j < 64; ++j) {
@@ -1373,7 +1368,7 @@ __global__ __launch_bounds__(SEQ_BLOCK) void k_append_run(uint64_t* occ, Ctl* ct
         nsem = 0;
         for (int k = 0; k < SEQ_BLOCK / 64; ++k) nsem += sRed[k];
     }
-    if (saved_memo != nullptr) {
+    if (saved_memo != nullptr && !m3_all) {
         __syncthreads();
         const uint4* src = reinterpret_cast<const uint4*>(run_lds);
         uint4* dst = reinterpret_cast<uint4*>(saved_memo);
@@ -1396,7 +1391,7 @@ __global__ __launch_bounds__(SEQ_BLOCK) void k_append_run(uint64_t* occ, Ctl* ct
 size_t append_run_memo_bytes() { return sizeof(RunMemo) + 16; }
 
 hipError_t launch_append_run(uint64_t* occ, Ctl* ctl, int64_t i0, int64_t R, const uint64_t* flags, const int64_t* d_T,
-                             uint64_t* saved_memo, hipStream_t stream) {
+                             uint64_t* saved_memo, const int64_t* m3_out, hipStream_t stream) {
     static const int wide_pos = [] { const char* e = getenv("DSA_POS_WIDE"); return (e && e[0] == '1') ? 1 : 0; }();   // dev knob: 64-bit positions
     // dev knob DSA_COUNT_MODEL=0: bitmap replay only (the general per-op path; A/B runs and coverage of that path)
     static const int no_model = [] { const char* e = getenv("DSA_COUNT_MODEL"); return (e && e[0] == '0') ? 1 : 0; }();
@@ -1407,7 +1402,7 @@ hipError_t launch_append_run(uint64_t* occ, Ctl* ctl, int64_t i0, int64_t R, con
         });
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(k_append_run, dim3(1), dim3(SEQ_BLOCK), sizeof(RunMemo), stream, occ, ctl, i0, R, flags, d_T, wide_pos, no_model, saved_memo);
+    hipLaunchKernelGGL(k_append_run, dim3(1), dim3(SEQ_BLOCK), sizeof(RunMemo), stream, occ, ctl, i0, R, flags, d_T, wide_pos, no_model, saved_memo, m3_out);
     return hipGetLastError();
 }
 
