@@ -28,7 +28,7 @@ namespace dsa {
 namespace {
 
 constexpr int M3_THREADS = 1024;
-constexpr int M3_X_ENTRIES = 12288, M3_V_ENTRIES = 6144;        // 96 KB + 48 KB of dynamic LDS
+constexpr int M3_X_ENTRIES = 10240, M3_V_ENTRIES = 5120;        // dynamic LDS: X 80 KB + one level of V 40 KB + the step of every V entry 20 KB
 constexpr int M3_MAX_TABLE_W = 16384;                           // (16-bit times in the entries)
 constexpr int64_t M3_MIN_RUN = 512;                             // shorter runs: the per-op replay is cheaper than filling the tables
 
@@ -67,69 +67,80 @@ __device__ __forceinline__ int m3_suffix_cells(const SpreadGeom& g, int W, int w
 // appends until the leaf rejects (every append visits the leaf): the count leaves [lo, hi]
 __device__ __forceinline__ int m3_leaf_reject(int c0, int lo0, int hi0) { return (c0 + 1 < lo0 || c0 + 1 > hi0) ? 1 : hi0 - c0 + 1; }
 
-// time of the first visit of level `upto` from the suffix counts sh.cnt[0 .. upto-1] (tables of levels 1 .. upto-1); adds the
-// rebalances / window slots of the complete chains below.  REC: per level into tauL / rebL / slL.  Wave-uniform.
+// ---- the driver's state lives in the registers of wave 0, lane <-> level: constants of the level (window, thresholds, table range),
+// its suffix count, the count of its surviving rebalance.  A level's value is broadcast with v_readlane (no memory round trip); the
+// only LDS traffic of a step is the table lookup itself, whose address depends on the time accumulated so far.
+struct M3Lane { int W, lo, hi, cmin, base; };
+__device__ __forceinline__ int rl(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+__device__ __forceinline__ uint64_t rl64(uint64_t v, int l) {
+    return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(v >> 32), l) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)v, l);
+}
+struct M3Rec { int tau; uint32_t reb; uint64_t slots; };      // lane i: time of the first visit of level i, what the complete chains below added
+
+// time of the first visit of level `upto` from the suffix counts of the levels below (tables of levels 1 .. upto-1); adds the
+// rebalances / window slots of the complete chains below.  REC: per level into `rec`.  Wave-uniform.
 template <bool REC>
-__device__ __forceinline__ int m3_descent(M3Shared& sh, const uint64_t* X, int upto, uint32_t& reb, uint64_t& slots) {
-    int tau = m3_leaf_reject(ufl(sh.cnt[0]), ufl(sh.lo[0]), ufl(sh.hi[0]));
-    if (REC) { sh.tauL[1] = tau; sh.rebL[1] = 0; sh.slL[1] = 0; }
+__device__ __forceinline__ int m3_descent(const M3Lane& L, int cnt, const uint64_t* X, int upto, uint32_t& reb, uint64_t& slots, int& bail,
+                                          int lane, M3Rec& rec) {
+    int tau = m3_leaf_reject(rl(cnt, 0), rl(L.lo, 0), rl(L.hi, 0));
+    if (REC && lane == 1) { rec.tau = tau; rec.reb = 0; rec.slots = 0; }
 #pragma clang loop unroll(disable)
     for (int i = 1; i < upto; ++i) {
-        const int ci = ufl(sh.cnt[i]) + tau;
-        if (ci >= ufl(sh.lo[i]) && ci <= ufl(sh.hi[i])) {
-            const int cm = ufl(sh.cmin[i]);
-            if (ci < cm) { sh.bail = 10; return tau; }
-            const uint64_t x = ufl64(X[ufl(sh.base[i]) + ci - cm]);
+        const int ci = rl(cnt, i) + tau;
+        if (ci >= rl(L.lo, i) && ci <= rl(L.hi, i)) {
+            const int cm = rl(L.cmin, i);
+            if (ci < cm) { bail = 10; return tau; }
+            const uint64_t x = ufl64(X[rl(L.base, i) + ci - cm]);
             tau += m3_dt(x); reb += m3_reb(x); slots += m3_slots(x);
         }
-        if (REC) { sh.tauL[i + 1] = tau; sh.rebL[i + 1] = reb; sh.slL[i + 1] = slots; }
+        if (REC && lane == i + 1) { rec.tau = tau; rec.reb = reb; rec.slots = slots; }
     }
     return tau;
 }
 
 // event (k, c): the counts of the levels below k in closed form (lane <-> level); false: the last leaf lost its preconditions
-__device__ __forceinline__ bool m3_reset_below(M3Shared& sh, int k, int c, int lane) {
-    const int Wk = ufl(sh.W[k]);
+__device__ __forceinline__ bool m3_reset_below(const M3Lane& L, int& cnt, int k, int c, int lane, int seg) {
+    const int Wk = rl(L.W, k);
     const SpreadGeom g = make_geom(Wk, c);
-    if (lane < k) sh.cnt[lane] = m3_suffix_cells(g, Wk, sh.W[lane]);
-    wave_lds_sync();
-    const int c0 = ufl(sh.cnt[0]);
-    return c0 >= 1 && c0 <= ufl(sh.seg) - 2;
+    if (lane < k) cnt = m3_suffix_cells(g, Wk, L.W);
+    const int c0 = rl(cnt, 0);
+    return c0 >= 1 && c0 <= seg - 2;
 }
 
-// the last b appends of the run from the counts sh.cnt[0 .. kmax-1]; level kmax is not visited by them.  Records the surviving
-// rebalance of every level below kmax and returns the number of trailing ops that no level >= 1 follows.  Wave 0.
-__device__ int m3_final_descent(M3Shared& sh, const uint64_t* X, int kmax, int b, int lane, uint64_t& reb_tot, uint64_t& slots_tot,
-                                uint64_t& evmask) {
+// the last b appends of the run from the suffix counts of the levels below kmax; level kmax is not visited by them.  Records the
+// surviving rebalance of every level below kmax (evmask / evc) and returns the number of trailing ops that no level >= 1 follows.
+// Per level m that is visited inside the budget: the chain of its events c -> c + V_m[c] is walked with the steps kept from the
+// table fill (Vdt) up to the last event inside the budget; what the complete epochs before it add up to is X_m[first] - X_m[last].
+__device__ int m3_final_descent(const M3Lane& L, int& cnt, const uint64_t* X, const uint16_t* Vdt, int kmax, int b, int lane, int seg,
+                                uint64_t& reb_tot, uint64_t& slots_tot, uint64_t& evmask, int& evc, int& bail) {
     for (;;) {
         uint32_t r = 0; uint64_t s = 0;
-        m3_descent<true>(sh, X, kmax, r, s);
-        wave_lds_sync();
-        if (sh.bail) return 0;
-        if (ufl(sh.tauL[1]) > b) return b;
+        M3Rec rec; rec.tau = 0; rec.reb = 0; rec.slots = 0;
+        m3_descent<true>(L, cnt, X, kmax, r, s, bail, lane, rec);
+        if (bail) return 0;
+        if (rl(rec.tau, 1) > b) return b;
         int m = 1;
-        while (m + 1 <= kmax && ufl(sh.tauL[m + 1]) <= b) ++m;
-        if (m >= kmax) { sh.bail = 11; return 0; }
-        reb_tot += sh.rebL[m]; slots_tot += sh.slL[m];
-        int tt = ufl(sh.tauL[m]);
-        int c = ufl(sh.cnt[m]) + tt;
-        const int lom = ufl(sh.lo[m]), him = ufl(sh.hi[m]), Wm = ufl(sh.W[m]);
-        if (c < lom || c > him) { sh.bail = 12; return 0; }
-        reb_tot += 1; slots_tot += (uint64_t)Wm;
+        while (m + 1 <= kmax && rl(rec.tau, m + 1) <= b) ++m;
+        if (m >= kmax) { bail = 11; return 0; }
+        reb_tot += (uint64_t)(uint32_t)rl((int)rec.reb, m); slots_tot += rl64(rec.slots, m);
+        const int tt = rl(rec.tau, m);
+        const int c0 = rl(cnt, m) + tt;
+        const int lom = rl(L.lo, m), him = rl(L.hi, m), Wm = rl(L.W, m), cm = rl(L.cmin, m), bm = rl(L.base, m);
+        if (c0 < lom || c0 > him || c0 < cm) { bail = 12; return 0; }
+        int c = c0;
         for (;;) {
-            // V_m(c) on the fly: the counts below in closed form, then the descent to level m
-            if (!m3_reset_below(sh, m, c, lane)) { sh.bail = 13; return 0; }
-            r = 0; s = 0;
-            const int tv = m3_descent<false>(sh, X, m, r, s);
-            if (sh.bail) return 0;
-            if (tt + tv > b) break;
-            tt += tv; c += tv;
-            if (c < lom || c > him) { sh.bail = 14; return 0; }
-            reb_tot += 1 + r; slots_tot += (uint64_t)Wm + s;
+            const int dv = ufl((int)Vdt[bm + c - cm]);
+            if (tt + (c - c0) + dv > b) break;
+            c += dv;
+            if (c > him) { bail = 14; return 0; }          // (the chain ends behind the budget: cannot happen)
         }
+        const uint64_t x0 = ufl64(X[bm + c0 - cm]), xf = ufl64(X[bm + c - cm]);
+        reb_tot += (uint64_t)(m3_reb(x0) - m3_reb(xf)) + 1ull;
+        slots_tot += (m3_slots(x0) - m3_slots(xf)) + (uint64_t)Wm;
         evmask = (evmask & ~((1ull << m) - 1ull)) | (1ull << m);
-        if (lane == 0) sh.ev_c[m] = c;
-        b -= tt;
+        if (lane == m) evc = c;
+        if (!m3_reset_below(L, cnt, m, c, lane, seg)) { bail = 13; return 0; }
+        b -= tt + (c - c0);
         kmax = m;
     }
 }
@@ -139,6 +150,7 @@ __global__ __launch_bounds__(M3_THREADS) void k_append_model3(uint64_t* occ, Ctl
     extern __shared__ __attribute__((aligned(16))) unsigned char m3_lds[];
     uint64_t* X = reinterpret_cast<uint64_t*>(m3_lds);
     uint64_t* V = X + M3_X_ENTRIES;
+    uint16_t* Vdt = reinterpret_cast<uint16_t*>(V + M3_V_ENTRIES);
     __shared__ M3Shared sh;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t t_begin = wall_clock64();
@@ -163,21 +175,31 @@ __global__ __launch_bounds__(M3_THREADS) void k_append_model3(uint64_t* occ, Ctl
     if (tid < 40) sh.bk[tid] = 0ull;
     if (tid == 0) { sh.H = H; sh.seg = (int32_t)seg; sh.bail = 0; sh.consumed = 0; sh.leaf_ops = 0; sh.ended = 0; sh.ev_mask = 0ull; sh.reb = 0ull; sh.slots = 0ull; sh.top_events = 0; sh.Lp = 0; }
     __syncthreads();
-    // ---- suffix cell counts of every level: word r from the end falls into bucket bits(r); the suffix of 2^j words is buckets 0..j ----
+    // ---- suffix cell counts of every level: word r from the end falls into bucket bits(r); the suffix of 2^j words is buckets 0..j.
+    //      Words r >= 1024 are read in rows of 1024 (one word per thread: a row lies in ONE bucket), summed per thread while the
+    //      bucket stays the same; the first 1024 words go to their buckets one by one ----
     const int64_t nwords = cap >> 6;
     {
-        int nb = 0;
-        while ((1ll << nb) < nwords) ++nb;                    // nwords = 2^nb
-        for (int b = 0; b <= nb; ++b) {
-            const int64_t r0 = b == 0 ? 0 : (1ll << (b - 1)), r1 = b == 0 ? 1 : (1ll << b);
-            unsigned long long c = 0;
-            for (int64_t r = r0 + tid; r < r1; r += M3_THREADS) c += (unsigned long long)popc64(occ[nwords - 1 - r]);
-            if (r1 - r0 > 1) {
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
-                if (lane == 0 && c) atomicAdd(&sh.bk[b], c);
-            } else if (tid == 0) sh.bk[b] = c;
+        if (tid < nwords) {
+            const int b = tid == 0 ? 0 : 32 - __clz(tid);
+            const unsigned long long c = (unsigned long long)popc64(occ[nwords - 1 - tid]);
+            if (c) atomicAdd(&sh.bk[b], c);
         }
+        unsigned long long acc = 0;
+        int cur_b = 11;
+        for (int64_t row = 1; row * M3_THREADS < nwords; ++row) {
+            const int b = 64 - __clzll((long long)(row * M3_THREADS));           // bits(r) of every r in the row
+            if (b != cur_b) {
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+                if (lane == 0 && acc) atomicAdd(&sh.bk[cur_b], acc);
+                acc = 0; cur_b = b;
+            }
+            acc += (unsigned long long)popc64(occ[nwords - 1 - (row * M3_THREADS + tid)]);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+        if (lane == 0 && acc) atomicAdd(&sh.bk[cur_b], acc);
     }
     __syncthreads();
     if (tid <= H) {
@@ -246,8 +268,9 @@ __global__ __launch_bounds__(M3_THREADS) void k_append_model3(uint64_t* occ, Ctl
                 }
             }
             if (tau < 1 || tau > 0xffff || reb > 0xffffu || slots > 0xffffffffull) bad = true;
-            if (bad) { sh.bail = 6; V[e] = m3_pack(1, 0, 0); }
-            else V[e] = m3_pack((uint32_t)tau, reb, slots);
+            if (bad) { sh.bail = 6; tau = 1; reb = 0; slots = 0; }
+            V[e] = m3_pack((uint32_t)tau, reb, slots);
+            Vdt[sh.base[k] + e] = (uint16_t)tau;
         }
         __syncthreads();
         const int hik = sh.hi[k], bk = sh.base[k];
@@ -273,46 +296,51 @@ __global__ __launch_bounds__(M3_THREADS) void k_append_model3(uint64_t* occ, Ctl
     const int64_t t_tables = wall_clock64();
     // ---- the driver: wave 0 steps the levels above Lp event by event ----
     if (wave == 0) {
-        const int end32 = (int)end;
+        const int end32 = (int)end, seg32 = (int)seg;
+        M3Lane L;
+        L.W = sh.W[lane]; L.lo = sh.lo[lane]; L.hi = sh.hi[lane]; L.cmin = sh.cmin[lane]; L.base = sh.base[lane];
+        int cnt = sh.cnt[lane], evc = 0, bail = 0;
         int t = 0, top = 0;
         uint64_t reb_tot = 0, slots_tot = 0, evmask = 0;
         int leaf_ops = 0, consumed = 0, ended = 0;
+        M3Rec norec; norec.tau = 0; norec.reb = 0; norec.slots = 0;
         for (;;) {
             uint32_t r = 0; uint64_t s = 0;
-            const int tau = m3_descent<false>(sh, X, Lp + 1, r, s);
-            if (sh.bail) break;
+            const int tau = m3_descent<false>(L, cnt, X, Lp + 1, r, s, bail, lane, norec);
+            if (bail) break;
             if (t + tau > end32) {
-                leaf_ops = m3_final_descent(sh, X, Lp + 1, end32 - t, lane, reb_tot, slots_tot, evmask);
+                leaf_ops = m3_final_descent(L, cnt, X, Vdt, Lp + 1, end32 - t, lane, seg32, reb_tot, slots_tot, evmask, evc, bail);
                 consumed = end32;
                 break;
             }
             // the append t + tau visits level Lp + 1: lane <-> level evaluates the thresholds above (src/pma.jl:105-141)
-            const int ck = sh.cnt[lane] + tau;
-            const bool a = lane > Lp && lane <= H && ck >= sh.lo[lane] && ck <= sh.hi[lane];
+            const int ck = cnt + tau;
+            const bool a = lane > Lp && lane <= H && ck >= L.lo && ck <= L.hi;
             const unsigned long long am = __ballot(a);
             if (am == 0ull) {
                 // no level accepts: _extend! (or _shrink!) — the run ends in front of this op
-                leaf_ops = m3_final_descent(sh, X, Lp + 1, tau - 1, lane, reb_tot, slots_tot, evmask);
+                leaf_ops = m3_final_descent(L, cnt, X, Vdt, Lp + 1, tau - 1, lane, seg32, reb_tot, slots_tot, evmask, evc, bail);
                 consumed = t + tau - 1;
                 ended = 1;
                 break;
             }
             const int kacc = __ffsll(am) - 1;
             t += tau;
-            if (lane > Lp && lane <= H) sh.cnt[lane] = ck;
-            wave_lds_sync();
-            const int c = ufl(sh.cnt[kacc]);
-            reb_tot += (uint64_t)r + 1ull; slots_tot += s + (uint64_t)ufl(sh.W[kacc]);
+            if (lane > Lp && lane <= H) cnt = ck;
+            const int c = rl(cnt, kacc);
+            reb_tot += (uint64_t)r + 1ull; slots_tot += s + (uint64_t)rl(L.W, kacc);
             evmask = (evmask & ~((1ull << kacc) - 1ull)) | (1ull << kacc);
-            if (lane == 0) sh.ev_c[kacc] = c;
+            if (lane == kacc) evc = c;
             ++top;
-            if (!m3_reset_below(sh, kacc, c, lane)) { sh.bail = 8; break; }
+            if (!m3_reset_below(L, cnt, kacc, c, lane, seg32)) { bail = 8; break; }
         }
-        wave_lds_sync();
+        sh.ev_c[lane] = evc;
         if (lane == 0) {
             sh.consumed = consumed; sh.leaf_ops = leaf_ops; sh.ended = ended; sh.ev_mask = evmask; sh.reb = reb_tot; sh.slots = slots_tot;
             sh.top_events = top;
+            if (bail) sh.bail = bail;
         }
+        wave_lds_sync();
         // ---- the last word: the narrowest surviving patterns, then the trailing leaf ops bit by bit ----
         if (lane == 0 && !sh.bail) {
             uint64_t lw = occ[nwords - 1];
@@ -380,7 +408,7 @@ __global__ __launch_bounds__(M3_THREADS) void k_append_model3(uint64_t* occ, Ctl
 }  // namespace
 
 hipError_t launch_append_model3(uint64_t* occ, Ctl* ctl, int64_t R, const uint64_t* flags, const int64_t* d_T, int64_t* out, hipStream_t stream) {
-    constexpr size_t LDS = (size_t)(M3_X_ENTRIES + M3_V_ENTRIES) * sizeof(uint64_t);
+    constexpr size_t LDS = (size_t)(M3_X_ENTRIES + M3_V_ENTRIES) * sizeof(uint64_t) + (size_t)M3_X_ENTRIES * sizeof(uint16_t);
     static PerDeviceOnce once;
     {
         hipError_t e = once.run([] {

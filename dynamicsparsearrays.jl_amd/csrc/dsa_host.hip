@@ -562,8 +562,11 @@ void wait_published(Pma& P) {
     }
 }
 
+static thread_local double g_seq_launch_ms = 0;
 void seq_launch(SeqRun& r, bool upload = true) {
     Pma& P = *r.P;
+    struct T { std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+               ~T() { g_seq_launch_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); } } timer;
     // pinned h_ctl: H2D, kernel and D2H are stream-ordered; the host does not touch h_ctl until the next synchronize
     if (upload) HIPCHK(hipMemcpyAsync(P.d_ctl, P.h_ctl, sizeof(Ctl), hipMemcpyHostToDevice, P.stream));
     ++P.layout_epoch;
@@ -589,11 +592,23 @@ void seq_start(SeqRun& r, Pma& P, const std::vector<Op>& ops) {
 }
 
 // waits for the running kernel of `r`, services its yield and relaunches; returns false once the batch is finished
+// dev (DSA_DBG_SPLIT): where a sequencer chunk spends its wall clock — waiting for the device / host work per kind of yield
+static thread_local double g_seq_wait_ms = 0, g_seq_host_ms[8] = {0};
+struct SeqStepTimer {
+    std::chrono::steady_clock::time_point t0; int kind;
+    SeqStepTimer(int k) : t0(std::chrono::steady_clock::now()), kind(k) {}
+    ~SeqStepTimer() { g_seq_host_ms[kind & 7] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+};
 bool seq_step(SeqRun& r) {
     if (!r.active) return false;
     Pma& P = *r.P;
-    if (publish_enabled()) wait_published(P); else HIPCHK(hipStreamSynchronize(P.stream));
+    {
+        const auto tw0 = std::chrono::steady_clock::now();
+        if (publish_enabled()) wait_published(P); else HIPCHK(hipStreamSynchronize(P.stream));
+        g_seq_wait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw0).count();
+    }
     Ctl& c = *P.h_ctl;
+    SeqStepTimer timer(c.status);
     switch (c.status) {
         case SEQ_DONE:
             r.applied = std::max(r.n, c.next_op); r.active = false;
@@ -805,16 +820,24 @@ int64_t run_ops_parallel(Pma& P, const std::vector<Op>& ops, int32_t* err) {
         if (rs.stop != 1) continue;                       // burst used up (0), batch finished (2), or a switch of round kind (3)
         // ---- short prefix at op i: sequential sequencer for ops [i, i + seq_chunk)
         const auto ts0 = now();
-        SeqRun r;
-        r.P = &P; r.ops = &ops; r.n = std::min<int64_t>(n, i + seq_chunk); r.n_avail = n; r.active = true; r.defer_merge = true;
-        P.h_ctl->next_op = i; P.h_ctl->status = 0; P.h_ctl->err = 0; P.h_ctl->no_run_at = -1;
-        seq_launch(r);
-        while (seq_step(r)) ++n_yield;
-        t_seq += ms(ts0, now()); ++n_seq;
-        if (r.err) { if (P.h_ctl->n_pending > 0) merge_tables(P); *err = r.err; return r.applied; }
-        if (P.h_ctl->n_pending >= MERGE_AT) merge_tables(P);
-        P.stat_seq_ops += r.applied - i; P.stat_seq_launches += 1;
-        i = r.applied;
+        int64_t no_run_at = -1;
+        for (;;) {
+            SeqRun r;
+            r.P = &P; r.ops = &ops; r.n = std::min<int64_t>(n, i + seq_chunk); r.n_avail = n; r.active = true; r.defer_merge = true;
+            P.h_ctl->next_op = i; P.h_ctl->status = 0; P.h_ctl->err = 0; P.h_ctl->no_run_at = no_run_at;
+            seq_launch(r);
+            while (seq_step(r)) ++n_yield;
+            ++n_seq;
+            if (r.err) { if (P.h_ctl->n_pending > 0) merge_tables(P); *err = r.err; return r.applied; }
+            if (P.h_ctl->n_pending >= MERGE_AT) merge_tables(P);
+            P.stat_seq_ops += r.applied - i; P.stat_seq_launches += 1;
+            i = r.applied;
+            // an append run that stopped in front of op i (it needs _extend!): that op and what follows stay with the sequencer, which
+            // detects the rest of the run behind it — no detour through a burst of rounds that cannot plan the op either
+            if (i < n && P.h_ctl->no_run_at == i) { no_run_at = i; seq_chunk = std::max<int64_t>(seq_chunk, 8); continue; }
+            break;
+        }
+        t_seq += ms(ts0, now());
         seq_chunk = std::min<int64_t>(seq_chunk * 2, 8192);
         G = 64;
     }
@@ -822,6 +845,12 @@ int64_t run_ops_parallel(Pma& P, const std::vector<Op>& ops, int32_t* err) {
         fprintf(stderr, "  [run_ops_parallel %s] n=%lld: %lld bursts %.2f ms (of which %lld local launches %.2f ms: %lld mini-rounds, %lld ops), %lld sequencer chunks (%lld yields) %.2f ms\n",
                 P.has_cols ? "pcsc" : "vec", (long long)n, (long long)n_burst, t_burst, (long long)n_local, t_local, (long long)r_local, (long long)o_local,
                 (long long)n_seq, (long long)n_yield, t_seq);
+    if (dbg_split) {
+        fprintf(stderr, "    sequencer chunks: waiting for the device %.2f ms; host work by yield kind [done %.2f, rebalance %.2f, extend %.2f, shrink %.2f, table %.2f, error %.2f, run %.2f] ms\n",
+                g_seq_wait_ms, g_seq_host_ms[0], g_seq_host_ms[1], g_seq_host_ms[2], g_seq_host_ms[3], g_seq_host_ms[4], g_seq_host_ms[5], g_seq_host_ms[6]);
+        fprintf(stderr, "    seq_launch calls %.2f ms\n", g_seq_launch_ms);
+        g_seq_wait_ms = 0; g_seq_launch_ms = 0; for (double& x : g_seq_host_ms) x = 0;
+    }
     if (P.h_ctl->n_pending > 0) merge_tables(P);          // the tables leave the batch in key order (the reference's numbering)
     return n;
 }
