@@ -322,10 +322,13 @@ void build_abort(BuildScratch& s);
 hipError_t launch_build_small_vec(int64_t* io, int n, int cap, int32_t combine, KeyArr out_k, double* out_v, unsigned long long seq, hipStream_t stream);
 
 // n_avail >= n_ops: ops resident behind the chunk (an append run may consume them); run_ok enables append-run detection
+// breaks: the bitmap of launch_op_breaks for these ops (run detection reads it instead of the ops), or nullptr
 hipError_t launch_sequencer(KeyArr keys, double* vals, uint64_t* occ, int64_t* sems, int64_t* col_keys,
-                            uint8_t* col_live, Ctl* ctl, const Op* ops, int64_t n_ops, int64_t n_avail, bool run_ok,
+                            uint8_t* col_live, Ctl* ctl, const Op* ops, int64_t n_ops, int64_t n_avail, bool run_ok, const uint64_t* breaks,
                             Ctl* host_ctl, unsigned long long* host_seq, unsigned int seq,
                             hipStream_t stream);
+// one bit per op: op j does not continue an append run from op j-1 (mode 0: vector ops, 1: MappedPackedCSC ops); n/64 + 1 words
+hipError_t launch_op_breaks(const Op* ops, int64_t n, int mode, uint64_t* breaks, hipStream_t stream);
 // flags / d_T: cell types and cell count written by k_run_expand (MappedPackedCSC runs), nullptr for a vector run
 // saved_memo: append_run_memo_bytes() of zero-initialised device memory owned by the handle (the replay's memo survives in it from
 // run to run while the array's geometry stays the same), or nullptr

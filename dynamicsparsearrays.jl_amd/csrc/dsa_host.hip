@@ -111,6 +111,7 @@ struct Pma {
     Op* run_cells = nullptr; uint64_t* run_flags = nullptr; int64_t* run_out = nullptr; int64_t run_cap = 0;   // cell stream of a MappedPackedCSC append run
     uint64_t* run_memo = nullptr;               // the append replay's memo between runs (sequencer.hip: k_append_run)
     Op* d_ops = nullptr; int64_t ops_cap = 0;
+    uint64_t* d_breaks = nullptr; bool breaks_valid = false;      // run-break bitmap of the ops in d_ops (sequencer.hip: k_op_breaks)
     double* d_q = nullptr; int64_t q_cap = 0;      // scratch for lookups (3 arrays of q_cap)
     int32_t* d_err = nullptr;
     int64_t stat_par_rounds = 0, stat_par_ops = 0, stat_seq_ops = 0, stat_seq_launches = 0;      // batch-parallel instrumentation
@@ -167,6 +168,7 @@ void pma_destroy(Pma& P) {
     pool_free(P.d_ctl);
     pinned_free(P.h_ctl);
     if (P.d_ops) hipFree(P.d_ops);
+    if (P.d_breaks) hipFree(P.d_breaks);
     if (P.d_q) hipFree(P.d_q);
     pool_free(P.d_err);
     burst_graph_destroy(&P.burst);
@@ -462,10 +464,23 @@ void permute_run(Pma& P, const Op* cells, int64_t i0, int64_t n0) {
 }
 
 void ensure_ops(Pma& P, int64_t n) {
+    P.breaks_valid = false;
     if (n <= P.ops_cap) return;
     if (P.d_ops) hipFree(P.d_ops);
+    if (P.d_breaks) hipFree(P.d_breaks);
+    P.d_breaks = nullptr;
     P.ops_cap = std::max<int64_t>(n, 1024);
     HIPCHK(hipMalloc(&P.d_ops, (size_t)P.ops_cap * sizeof(Op)));
+    HIPCHK(hipMalloc(&P.d_breaks, (size_t)(P.ops_cap / 64 + 8) * sizeof(uint64_t)));
+}
+// the n ops just uploaded into d_ops: where an append run cannot continue (read by the sequencer's run detection), enqueued behind the
+// upload.  Vectors and MappedPackedCSC only — a plain PackedCSC has no runs
+void enqueue_op_breaks(Pma& P, int64_t n) {
+    P.breaks_valid = false;
+    if (!g_append_runs || P.occ_old == nullptr || n < 64 || (P.has_sems && !P.has_cols)) return;
+    hipError_t e = launch_op_breaks(P.d_ops, n, P.has_cols ? 1 : 0, P.d_breaks, P.stream);
+    if (e != hipSuccess) fail(DSA_EHIP, std::string("op breaks launch: ") + hipGetErrorString(e));
+    P.breaks_valid = true;
 }
 
 int32_t seq_err_to_status(int32_t e) { return e == 0 ? DSA_EASSERT : e; }
@@ -574,7 +589,8 @@ void seq_launch(SeqRun& r, bool upload = true) {
     const unsigned int seq = publish ? next_publish_seq(P) : 0u;       // the sequencer hands its control block back itself
     hipError_t e = launch_sequencer(P.K(), P.V(), P.O(), P.has_sems ? P.sems : nullptr, P.has_cols ? P.col_keys : nullptr,
                                     P.has_cols ? P.col_live : nullptr, P.d_ctl, P.d_ops, r.n, std::max(r.n, r.n_avail),
-                                    g_append_runs && P.occ_old != nullptr, publish ? P.h_ctl : nullptr, publish ? P.h_pub : nullptr, seq, P.stream);
+                                    g_append_runs && P.occ_old != nullptr, P.breaks_valid ? P.d_breaks : nullptr,
+                                    publish ? P.h_ctl : nullptr, publish ? P.h_pub : nullptr, seq, P.stream);
     if (e != hipSuccess) fail(DSA_EHIP, std::string("sequencer launch: ") + hipGetErrorString(e));
     if (!publish) HIPCHK(hipMemcpyAsync(P.h_ctl, P.d_ctl, sizeof(Ctl), hipMemcpyDeviceToHost, P.stream));
 }
@@ -586,6 +602,7 @@ void seq_start(SeqRun& r, Pma& P, const std::vector<Op>& ops) {
     ensure_key_width(P, ops);
     ensure_ops(P, r.n);
     HIPCHK(hipMemcpyAsync(P.d_ops, ops.data(), (size_t)r.n * sizeof(Op), hipMemcpyHostToDevice, P.stream));
+    enqueue_op_breaks(P, r.n);
     P.h_ctl->next_op = 0; P.h_ctl->status = 0; P.h_ctl->err = 0; P.h_ctl->no_run_at = -1;
     r.active = true;
     seq_launch(r);
@@ -729,6 +746,7 @@ int64_t run_ops_parallel(Pma& P, const std::vector<Op>& ops, int32_t* err) {
     {
         const auto tu0 = std::chrono::steady_clock::now();
         HIPCHK(hipMemcpyAsync(P.d_ops, ops.data(), (size_t)n * sizeof(Op), hipMemcpyHostToDevice, P.stream));
+        enqueue_op_breaks(P, n);
         static const bool dbg_up = getenv("DSA_DBG_SPLIT") != nullptr;
         if (dbg_up) fprintf(stderr, "  [run_ops_parallel] upload of %lld ops (%.1f MB, pageable): %.3f ms on the host\n", (long long)n, n * sizeof(Op) / 1e6,
                             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tu0).count());
@@ -759,8 +777,25 @@ int64_t run_ops_parallel(Pma& P, const std::vector<Op>& ops, int32_t* err) {
     double t_burst = 0, t_seq = 0, t_local = 0; int64_t n_burst = 0, n_seq = 0, n_yield = 0, n_local = 0, r_local = 0, o_local = 0;
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    // A batch that starts like an append run — ascending keys (vector) / ascending (column, row) pairs (MappedPackedCSC) — goes to the
+    // sequencer first, which detects the run (or, when the keys are not above the last cell after all, applies a few ops and hands
+    // back to the rounds): a burst of rounds on ascending appends plans and applies one op per round (0.37 ms for nothing at 100 k ops)
+    bool seq_first = false;
+    if (g_append_runs && P.occ_old != nullptr && n >= 64 && (!P.has_sems || P.has_cols)) {
+        const int64_t probe = std::min<int64_t>(n, 256);
+        seq_first = true;
+        for (int64_t j = 0; j < probe && seq_first; ++j) {
+            const Op& o = ops[(size_t)j];
+            if (o.v == 0.0 || o.kind != (P.has_cols ? OP_MPCSC_SET : OP_VEC_SET)) seq_first = false;
+            else if (j > 0) {
+                const Op& q = ops[(size_t)j - 1];
+                seq_first = P.has_cols ? (o.b > q.b || (o.b == q.b && o.a > q.a)) : o.a > q.a;
+            }
+        }
+    }
     while (i < n) {
         const auto tb0 = now();
+        if (!seq_first) {
         // ---- a burst of rounds driven by the device-resident cursor; one host synchronisation per burst
         RoundState& rs = *P.h_rs;
         std::memset(&rs, 0, sizeof(rs));
@@ -818,6 +853,8 @@ int64_t run_ops_parallel(Pma& P, const std::vector<Op>& ops, int32_t* err) {
         if (use_local) { if (rs.stop == 3) { use_local = false; ema = 16 * 64; G = 64; } }   // full prefixes: the grid rounds pay again
         else if (local_ok && rs.rounds > 0 && ema < 16 * LOCAL_BELOW) use_local = true;  // prefixes of a few ops: one workgroup is enough
         if (rs.stop != 1) continue;                       // burst used up (0), batch finished (2), or a switch of round kind (3)
+        }
+        seq_first = false;
         // ---- short prefix at op i: sequential sequencer for ops [i, i + seq_chunk)
         const auto ts0 = now();
         int64_t no_run_at = -1;

@@ -44,6 +44,7 @@ struct Seq {
     int64_t y_ws, y_we, y_m;
     int32_t err;
     bool tail_hint;                // the previous insert went behind the last cell of its range: try that first (append runs)
+    const uint64_t* breaks;        // one bit per op of the batch (k_op_breaks): op j does not continue an append run from op j-1; may be null
     int64_t* sK; double* sV;       // LDS staging for the small-window rebalance
     uint32_t* sWordOff;            // [SMALL_W/64 + 1]
     int64_t* sRed;                 // [SEQ_BLOCK/64] block-reduce scratch
@@ -291,6 +292,31 @@ __device__ __forceinline__ int64_t spread_last_cell(const SpreadGeom& g) {
 //   mode 1 (MappedPackedCSC):  OP_MPCSC_SET, non-zero value, row >= 1, (col, row) lexicographically above the previous
 //                              (col, row) ((pb0, pa0) for the first op; any column when first_any)
 __device__ int64_t blk_run_length(Seq& S, const Op* ops, int64_t i, int64_t n, int mode, int64_t pa0, int64_t pb0, bool first_any) {
+    if (S.breaks != nullptr) {
+        // op i against the state of the array, the ops behind it from the bitmap of the batch (one grid-wide pass when the ops were
+        // uploaded: k_op_breaks) — the scan of 100 k ops by this one workgroup took 0.4 ms per detection
+        const Op o = ops[i];
+        const bool bad0 = mode == 0 ? !(o.kind == OP_VEC_SET && o.v != 0.0 && o.a > pa0)
+                                    : !(o.kind == OP_MPCSC_SET && o.v != 0.0 && o.a >= 1 && (first_any || o.b > pb0 || (o.b == pb0 && o.a > pa0)));
+        if (bad0) return 0;
+        const int64_t w0 = (i + 1) >> 6, w1 = (n - 1) >> 6;          // bits i+1 .. n-1 (bits >= the batch length are set)
+        for (int64_t base = w0; base <= w1; base += SEQ_BLOCK) {
+            const int64_t w = base + threadIdx.x;
+            uint64_t x = w <= w1 ? S.breaks[w] : 0ull;
+            if (w == w0) x &= ~mask_lt((int)((i + 1) & 63));
+            int64_t first = x ? (w << 6) + __ffsll((unsigned long long)x) - 1 : INT64_MAX;
+#pragma unroll
+            for (int o2 = 32; o2 > 0; o2 >>= 1) { const int64_t y = __shfl_xor(first, o2, 64); first = y < first ? y : first; }
+            __syncthreads();
+            if ((threadIdx.x & 63) == 0) S.sRed[threadIdx.x >> 6] = first;
+            __syncthreads();
+            first = S.sRed[0];
+#pragma unroll
+            for (int k = 1; k < SEQ_BLOCK / 64; ++k) first = S.sRed[k] < first ? S.sRed[k] : first;
+            if (first != INT64_MAX) return (first < n ? first : n) - i;
+        }
+        return n - i;
+    }
     int64_t R = 0;
     for (int64_t base = i; base < n; base += SEQ_BLOCK) {
         const int64_t j = base + threadIdx.x;
@@ -316,6 +342,25 @@ __device__ int64_t blk_run_length(Seq& S, const Op* ops, int64_t i, int64_t n, i
         R += lim;
     }
     return R;
+}
+
+// one bit per op of a batch: set when op j does NOT continue an append run from op j-1 (the conditions of blk_run_length; bit 0 and the
+// bits behind the last op are set).  Grid-wide, enqueued behind the upload of the ops.
+__global__ __launch_bounds__(256) void k_op_breaks(const Op* ops, int64_t n, int mode, uint64_t* breaks) {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    bool bad = true;
+    if (j > 0 && j < n) {
+        const Op o = ops[j], q = ops[j - 1];
+        if (mode == 0) bad = !(o.kind == OP_VEC_SET && o.v != 0.0 && o.a > q.a);
+        else bad = !(o.kind == OP_MPCSC_SET && o.v != 0.0 && o.a >= 1 && (o.b > q.b || (o.b == q.b && o.a > q.a)));
+    }
+    const uint64_t b = __ballot(bad);
+    if ((threadIdx.x & 63) == 0) breaks[j >> 6] = b;
+}
+hipError_t launch_op_breaks(const Op* ops, int64_t n, int mode, uint64_t* breaks, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_op_breaks, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, ops, n, mode, breaks);
+    return hipGetLastError();
 }
 
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
@@ -1288,7 +1333,7 @@ __global__ __launch_bounds__(SEQ_BLOCK) void k_append_run(uint64_t* occ, Ctl* ct
     S.nb_elements = ctl->nb_elements; S.nb_partitions = 0; S.table_len = 0; S.table_cap = 0;
     S.stat_window_slots = ctl->stat_window_slots; S.stat_rebalances = ctl->stat_rebalances;
     S.stat_small = ctl->stat_small_rebalances;
-    S.y_ws = S.y_we = S.y_m = 0; S.err = 0; S.tail_hint = false;
+    S.y_ws = S.y_we = S.y_m = 0; S.err = 0; S.tail_hint = false; S.breaks = nullptr;
     S.sK = nullptr; S.sV = nullptr; S.sWordOff = nullptr; S.sRed = sRed;
     if (threadIdx.x < MAX_LEVELS) { sLo[threadIdx.x] = ctl->lo[threadIdx.x]; sHi[threadIdx.x] = ctl->hi[threadIdx.x]; }
     S.lo = sLo; S.hi = sHi;
@@ -1848,7 +1893,7 @@ __device__ int d_exec(Seq& S, const Op& op) {
 
 __global__ __launch_bounds__(SEQ_BLOCK) void k_sequencer(KeyArr keys, double* vals, uint64_t* occ, int64_t* sems,
                                                          int64_t* col_keys, uint8_t* col_live, Ctl* ctl,
-                                                         const Op* ops, int64_t n_ops, int64_t n_avail, int run_ok,
+                                                         const Op* ops, int64_t n_ops, int64_t n_avail, int run_ok, const uint64_t* breaks,
                                                          Ctl* host_ctl, unsigned long long* host_seq, unsigned int seq) {
     // host_ctl / host_seq (pinned, may be null): the kernel hands its control block back itself — every word, then `seq` into the word the
     // host polls for — instead of a publish launch behind it (as parbatch.hip's k_publish does for a burst of rounds)
@@ -1862,7 +1907,7 @@ __global__ __launch_bounds__(SEQ_BLOCK) void k_sequencer(KeyArr keys, double* va
     S.table_len = ctl->table_len; S.table_cap = ctl->table_cap;
     S.stat_window_slots = ctl->stat_window_slots; S.stat_rebalances = ctl->stat_rebalances;
     S.stat_small = ctl->stat_small_rebalances;
-    S.y_ws = S.y_we = S.y_m = 0; S.err = 0; S.tail_hint = false;
+    S.y_ws = S.y_we = S.y_m = 0; S.err = 0; S.tail_hint = false; S.breaks = breaks;
     __shared__ int64_t sPKey[PEND_MAX];
     __shared__ uint32_t sPIdx[PEND_MAX];
     __shared__ uint32_t sPLb[PEND_MAX];
@@ -1939,7 +1984,7 @@ __global__ __launch_bounds__(SEQ_BLOCK) void k_sequencer(KeyArr keys, double* va
 }
 
 hipError_t launch_sequencer(KeyArr keys, double* vals, uint64_t* occ, int64_t* sems, int64_t* col_keys,
-                            uint8_t* col_live, Ctl* ctl, const Op* ops, int64_t n_ops, int64_t n_avail, bool run_ok,
+                            uint8_t* col_live, Ctl* ctl, const Op* ops, int64_t n_ops, int64_t n_avail, bool run_ok, const uint64_t* breaks,
                             Ctl* host_ctl, unsigned long long* host_seq, unsigned int seq, hipStream_t stream) {
     const size_t lds_bytes = (size_t)SMALL_W * (sizeof(int64_t) + sizeof(double));
     static PerDeviceOnce once;
@@ -1950,7 +1995,7 @@ hipError_t launch_sequencer(KeyArr keys, double* vals, uint64_t* occ, int64_t* s
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(k_sequencer, dim3(1), dim3(SEQ_BLOCK), lds_bytes, stream, keys, vals, occ, sems, col_keys, col_live,
-                       ctl, ops, n_ops, n_avail, run_ok ? 1 : 0, host_ctl, host_seq, seq);
+                       ctl, ops, n_ops, n_avail, run_ok ? 1 : 0, breaks, host_ctl, host_seq, seq);
     return hipGetLastError();
 }
 
