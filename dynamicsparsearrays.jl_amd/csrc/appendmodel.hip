@@ -99,19 +99,19 @@ __device__ __forceinline__ int m3_descent(const M3Lane& L, int cnt, const uint64
 }
 
 // event (k, c): the counts of the levels below k in closed form (lane <-> level); false: the last leaf lost its preconditions
-__device__ __forceinline__ bool m3_reset_below(const M3Lane& L, int& cnt, int k, int c, int lane, int seg) {
+__device__ __forceinline__ bool m3_reset_below(const M3Lane& L, int& cnt, int k, int c, int lane, int maxc0) {
     const int Wk = rl(L.W, k);
     const SpreadGeom g = make_geom(Wk, c);
     if (lane < k) cnt = m3_suffix_cells(g, Wk, L.W);
     const int c0 = rl(cnt, 0);
-    return c0 >= 1 && c0 <= seg - 2;
+    return c0 >= 1 && c0 <= maxc0;
 }
 
 // the last b appends of the run from the suffix counts of the levels below kmax; level kmax is not visited by them.  Records the
 // surviving rebalance of every level below kmax (evmask / evc) and returns the number of trailing ops that no level >= 1 follows.
 // Per level m that is visited inside the budget: the chain of its events c -> c + V_m[c] is walked with the steps kept from the
 // table fill (Vdt) up to the last event inside the budget; what the complete epochs before it add up to is X_m[first] - X_m[last].
-__device__ int m3_final_descent(const M3Lane& L, int& cnt, const uint64_t* X, const uint16_t* Vdt, int kmax, int b, int lane, int seg,
+__device__ int m3_final_descent(const M3Lane& L, int& cnt, const uint64_t* X, const uint16_t* Vdt, int kmax, int b, int lane, int maxc0,
                                 uint64_t& reb_tot, uint64_t& slots_tot, uint64_t& evmask, int& evc, int& bail) {
     for (;;) {
         uint32_t r = 0; uint64_t s = 0;
@@ -139,7 +139,7 @@ __device__ int m3_final_descent(const M3Lane& L, int& cnt, const uint64_t* X, co
         slots_tot += (m3_slots(x0) - m3_slots(xf)) + (uint64_t)Wm;
         evmask = (evmask & ~((1ull << m) - 1ull)) | (1ull << m);
         if (lane == m) evc = c;
-        if (!m3_reset_below(L, cnt, m, c, lane, seg)) { bail = 13; return 0; }
+        if (!m3_reset_below(L, cnt, m, c, lane, maxc0)) { bail = 13; return 0; }
         b -= tt + (c - c0);
         kmax = m;
     }
@@ -159,13 +159,19 @@ __global__ __launch_bounds__(M3_THREADS) void k_append_model3(uint64_t* occ, Ctl
     const int64_t end = flags != nullptr ? d_T[0] : R;
     // ---- eligibility (uniform) ----
     int why = 0;
-    if (!(seg == 16 || seg == 32)) why = 1;
+    // segments below 16 slots: a semaphore that finds the last slot as the leaf's only free one shifts cells ACROSS the leaf boundary
+    // (src/writes.jl:34-38 from addpartition!, src/pcsr.jl:99-112) and the leaf count stays — typed runs on such arrays (anything
+    // grown from the empty PMA keeps its 8-slot segments) are not count-only and stay with k_append_run; a vector run is
+    if (!(seg == 16 || seg == 32 || (flags == nullptr && (seg == 8 || seg == 4 || seg == 2)))) why = 1;
     else if (cap < 65536 || cap > (1ll << 30) || (seg << H) != cap || H + 1 > MAX_LEVELS) why = 2;
     else if (end < M3_MIN_RUN || end >= (1ll << 30)) why = 3;
     if (why) {
         if (tid == 0) { out[0] = 0; out[1] = 0; out[2] = why; }
         return;
     }
+    // the last leaf before every insert: at least one cell (the tail is in it) and a free slot besides the last one — two free slots
+    // in a typed run (the semaphore's shift must find one left of the last slot), one in a vector run
+    const int maxc0 = (int)seg - (flags != nullptr ? 2 : 1);
     if (tid < 64) {
         sh.W[tid] = tid <= H ? (int32_t)(seg << tid) : 0;
         sh.lo[tid] = tid <= H ? (int32_t)ctl->lo[tid] : 1;
@@ -217,7 +223,7 @@ __global__ __launch_bounds__(M3_THREADS) void k_append_model3(uint64_t* occ, Ctl
     // ---- table ranges: a count of level i never falls below the lowest suffix density of the levels >= i (minus rounding) ----
     if (tid == 0) {
         int bail = 0;
-        if (sh.cnt[0] < 1 || sh.cnt[0] > (int)seg - 2) bail = 4;
+        if (sh.cnt[0] < 1 || sh.cnt[0] > maxc0) bail = 4;
         double dmin = 2.0;
         int32_t cm[64];
         for (int k = H; k >= 0; --k) {
@@ -255,7 +261,7 @@ __global__ __launch_bounds__(M3_THREADS) void k_append_model3(uint64_t* occ, Ctl
             const int c = cmk + e;
             const SpreadGeom g = make_geom(Wk, c);
             const int s0 = m3_suffix_cells(g, Wk, W0);
-            bool bad = s0 < 1 || s0 > (int)seg - 2;
+            bool bad = s0 < 1 || s0 > maxc0;
             int tau = m3_leaf_reject(s0, lo0, hi0);
             uint32_t reb = 0; uint64_t slots = 0;
 #pragma clang loop unroll(disable)
@@ -296,7 +302,7 @@ __global__ __launch_bounds__(M3_THREADS) void k_append_model3(uint64_t* occ, Ctl
     const int64_t t_tables = wall_clock64();
     // ---- the driver: wave 0 steps the levels above Lp event by event ----
     if (wave == 0) {
-        const int end32 = (int)end, seg32 = (int)seg;
+        const int end32 = (int)end, seg32 = maxc0;
         M3Lane L;
         L.W = sh.W[lane]; L.lo = sh.lo[lane]; L.hi = sh.hi[lane]; L.cmin = sh.cmin[lane]; L.base = sh.base[lane];
         int cnt = sh.cnt[lane], evc = 0, bail = 0;

@@ -1542,6 +1542,70 @@ def test_shard_entry_points_split_spmv_exactly(dsa, hip, oracle):
 
 # ---------------------------------------------------------------- round 2: the replay's memo between runs, grid-wide table merges
 @pytest.mark.gpu
+@pytest.mark.parametrize("n_first,total,runs", [(3, 120000, [40000, 700, 90000, 5000]), (150, 200000, [100000, 100000, 3000]),
+                                                (90000, 90000, [513, 30000, 512, 2000, 250000])])
+def test_append_runs_count_only_model_on_vectors_of_every_segment_size(dsa, hip, oracle, n_first, total, runs):
+    """The count-only replay of long append runs (csrc/appendmodel.hip: tables of per-level epochs, a driver above them, one
+    bitmap write) against sequential setindex! on the oracle: vectors GROWN from a few keys keep segments of 2 / 8 slots for life
+    (_extend! doubles the segment count, src/pma.jl:143-151), a vector built from 90 000 keys has 16-slot segments.  Runs around
+    the model's minimum length, runs that cross one and two _extend!s, layouts / scalars / rebalance statistics after every run."""
+    keys = np.arange(1, total + 1, dtype=np.int64) * 2
+    a = dsa.dynamicsparsevec(keys[:n_first], unit12_array(9, n_first), binding=hip)
+    b = dsa.dynamicsparsevec(keys[:n_first], unit12_array(9, n_first), binding=oracle)
+    if total > n_first:
+        a.set_batch(keys[n_first:], unit12_array(10, total - n_first))
+        b.set_batch(keys[n_first:], unit12_array(10, total - n_first))
+    nxt = int(keys[-1]) + 1
+    for r_i, r in enumerate(runs):
+        ks = np.arange(nxt, nxt + r, dtype=np.int64)
+        nxt += r
+        vs = unit12_array(20 + r_i, r)
+        a.set_batch(ks, vs)
+        b.set_batch(ks, vs)
+        assert_vec_equal(a, b)
+        ia, ib = a.info(), b.info()
+        for k in ("stat_extends", "stat_rebalances", "stat_window_slots"):
+            assert ia[k] == ib[k], (k, r_i, ia[k], ib[k])
+    rep = a.check()
+    assert rep[0] == a.nnz() and not rep[2:7].any(), rep
+
+
+def test_append_runs_count_only_model_on_a_built_matrix_with_ragged_columns(dsa, hip, oracle):
+    """Typed runs (semaphore cells of new columns among the appended cells) on a matrix BUILT from triples — 16-slot segments, the
+    geometry the count-only replay takes for MappedPackedCSC runs: columns of 1..40 rows streamed in ascending column id in batches
+    of several thousand cells, across an _extend! of the colmajor orientation; both orientations slot for slot after every batch."""
+    g = SplitMix64(4242)
+    m, n0 = 40000, 12000
+    I0, J0 = [], []
+    for j in range(1, n0 + 1):
+        for i in sorted({1 + g.next() % m for _ in range(1 + g.next() % 12)}):
+            I0.append(i); J0.append(j)
+    V0 = unit12_array(7, len(I0))
+    A = dsa.dynamicsparse(I0, J0, V0, binding=hip)
+    B = dsa.dynamicsparse(I0, J0, V0, binding=oracle)
+    assert A.info(0)["segment_capacity"] == 16
+    cap0 = A.info(0)["capacity"]
+    col = n0
+    for r_i, ncols in enumerate([300, 1200, 40, 2500, 6000]):
+        I, J = [], []
+        for _ in range(ncols):
+            col += 1
+            for i in sorted({1 + g.next() % m for _ in range(1 + g.next() % 40)}):
+                I.append(i); J.append(col)
+        V = unit12_array(50 + r_i, len(I))
+        A.set_batch(I, J, V)
+        B.set_batch(I, J, V)
+        assert_mat_equal(A, B)
+        for o in (0, 1):
+            ia, ib = A.info(o), B.info(o)
+            for k in ("stat_extends", "stat_rebalances", "stat_window_slots"):
+                assert ia[k] == ib[k], (o, k, r_i, ia[k], ib[k])
+    assert A.info(0)["capacity"] > cap0
+    x = unit12_array(3, col)
+    ya, yb = A.mul(x), B.mul(x)
+    assert np.allclose(ya, yb, rtol=RTOL, atol=0)
+
+
 def test_append_memo_survives_runs_on_one_geometry_and_is_dropped_at_extend(dsa, hip, oracle):
     """Several append runs on the SAME handle: the replay's memo (a pure function of the geometry) is reloaded from HBM while the
     capacity is unchanged and rebuilt after _extend! (csrc/sequencer.hip: k_append_run, saved_memo).  Vector runs and matrix runs

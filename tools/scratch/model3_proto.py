@@ -83,7 +83,7 @@ class Model3:
         key = (k, c)
         if key not in self.Vm:
             cnt = self.S_all(k, c)
-            assert 1 <= cnt[0] <= self.g.seg - 2, ("leaf precondition", k, c, cnt[0])
+            assert 1 <= cnt[0] <= self.g.seg - 1, ("leaf precondition", k, c, cnt[0])
             taus, st = self.taus(cnt, k)
             self.Vm[key] = (taus[k], st[k][0], st[k][1])
         return self.Vm[key]
@@ -158,7 +158,7 @@ class Model3:
         g = self.g
         C, H, Lp = g.C, g.H, min(self.Lp, g.H)
         cnt = [int(occ[C - g.W[k]:].sum()) for k in range(H + 1)]
-        assert 1 <= cnt[0] <= g.seg - 2
+        assert 1 <= cnt[0] <= g.seg - 1
         ev = {}
         stats = [0, 0]
         t = 0
@@ -190,7 +190,7 @@ class Model3:
                 ev.pop(i, None)
             ev[kacc] = c
             low = self.S_all(kacc, c)
-            assert 1 <= low[0] <= g.seg - 2
+            assert 1 <= low[0] <= g.seg - 1
             cnt[:kacc] = low
         out = occ.copy()
         for k in sorted(ev.keys(), reverse=True):
@@ -216,10 +216,14 @@ class Model3:
         return out, t, stats[0], stats[1]
 
 
-def check_vector(dsa, oracle, n0, R, Lp, seed=1):
+def check_vector(dsa, oracle, n0, R, Lp, seed=1, grow_from=None):
     keys0 = np.arange(1, n0 + 1, dtype=np.int64) * 2
     vals0 = np.ones(n0)
-    b = dsa.dynamicsparsevec(keys0, vals0, binding=oracle)
+    if grow_from is not None:          # a vector grown from a few keys keeps its small segments
+        b = dsa.dynamicsparsevec(keys0[:grow_from], vals0[:grow_from], binding=oracle)
+        b.set_batch(keys0[grow_from:], vals0[grow_from:])
+    else:
+        b = dsa.dynamicsparsevec(keys0, vals0, binding=oracle)
     nxt = 2 * n0 + 1
     done = 0
     m3 = None
@@ -254,6 +258,8 @@ def check_vector(dsa, oracle, n0, R, Lp, seed=1):
 if __name__ == "__main__":
     dsa = dsa_loader.load()
     oracle = oracle_binding.load(dsa)
+    for n0, R, Lp in [(50000, 60000, 4), (90000, 40000, 7), (200000, 100000, 9)]:
+        check_vector(dsa, oracle, n0, R, Lp, grow_from=3)
     for n0, R, Lp in [(40000, 30000, 4), (40000, 30000, 99), (40000, 30000, 1), (300000, 200000, 8), (50000, 777, 6), (46000, 5, 3),
                       (46000, 14, 3), (46000, 15, 3), (46000, 16, 3), (46000, 17, 3), (700000, 100000, 8), (30000, 100000, 5)]:
         check_vector(dsa, oracle, n0, R, Lp)
