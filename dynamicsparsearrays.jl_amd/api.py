@@ -121,6 +121,10 @@ class DynamicSparseVector(_Handle):
         self.b.call("vec_check", self.h, r.ctypes.data_as(P_I64))
         return r
 
+    def set_wait_policy(self, policy):
+        """0 (DSA_WAIT_SPIN): blocking calls poll pinned memory; 1 (DSA_WAIT_BLOCK): they park in hipStreamSynchronize first."""
+        self.b.call("vec_set_wait_policy", self.h, int(policy))
+
     def __eq__(self, other):                          # src/vector.jl:85-87, src/pma.jl:236-266
         if not isinstance(other, DynamicSparseVector):
             return NotImplemented
@@ -411,6 +415,10 @@ class DynamicSparseMatrix(_Handle):
         self.b.call("mat_check", self.h, orientation, r.ctypes.data_as(P_I64))
         return r
 
+    def set_wait_policy(self, policy):
+        """0 (DSA_WAIT_SPIN): blocking calls poll pinned memory; 1 (DSA_WAIT_BLOCK): they park in hipStreamSynchronize first."""
+        self.b.call("mat_set_wait_policy", self.h, int(policy))
+
     def transpose(self):
         return Transposed(self)
 
@@ -508,3 +516,15 @@ def deletepartition(pcsc, partition):
 
 def nnz(obj):
     return obj.nnz()
+
+
+def pool_idle_bytes(binding: Binding | None = None) -> int:
+    """idle HBM the library's caching allocator holds for reuse (dsa_pool_idle_bytes)"""
+    out = C.c_int64()
+    _bind(binding).call("pool_idle_bytes", C.byref(out))
+    return out.value
+
+
+def pool_trim(keep_bytes=0, binding: Binding | None = None):
+    """release idle HBM blocks until at most keep_bytes remain (dsa_pool_trim)"""
+    _bind(binding).call("pool_trim", int(keep_bytes))

@@ -514,7 +514,9 @@ static void free_scratch(BuildScratch& s) {
     s = BuildScratch();
 }
 
-#define BCHK(e) do { hipError_t _e = (e); if (_e != hipSuccess) { free_scratch(s); return _e; } } while (0)
+// error path: the scratch comes from the caching allocator (pool.hip), which hands a freed block out again at once — earlier passes
+// may still be in flight on it, so the build stream is drained first (build_abort does the same)
+#define BCHK(e) do { hipError_t _e = (e); if (_e != hipSuccess) { if (s.stream) (void)hipStreamSynchronize(s.stream); free_scratch(s); return _e; } } while (0)
 
 static int bit_width_u64(uint64_t x) { int b = 0; while (x) { ++b; x >>= 1; } return b; }
 
@@ -599,6 +601,7 @@ hipError_t device_key_scan(const int64_t* d_a, const int64_t* d_b, int64_t n, Ke
         ra->lo = h->pmin; ra->hi = h->pmax; rb->lo = h->kmin; rb->hi = h->kmax;
         *a_zero = (h->zeros & 1ull) != 0; *b_zero = (h->zeros & 2ull) != 0;
     }
+    if (e != hipSuccess) (void)hipStreamSynchronize(stream);      // a failed copy / wait: the kernel may still be running on the block
     pinned_ctl_put(pin);
     pool_free(base);
     return e;

@@ -37,7 +37,10 @@ Rccl& rccl() {
     std::call_once(once, [] {
         const char* env = getenv("DSA_RCCL_LIB");
         // a copy that is already mapped into the process (e.g. PyTorch's) first, then the ROCm installation
-        const char* names[] = {env, "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+        // DSA_RCCL_LIB names THE library to use (nothing else is tried: an override that silently falls back is not an override)
+        const bool only_env = env && env[0];
+        const char* names[] = {env, only_env ? nullptr : "librccl.so", only_env ? nullptr : "librccl.so.1",
+                               only_env ? nullptr : "/opt/rocm/lib/librccl.so.1", only_env ? nullptr : "/opt/rocm/lib/librccl.so"};
         for (const char* n : names) {
             if (!n || !n[0]) continue;
             R.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
@@ -48,7 +51,11 @@ Rccl& rccl() {
             if (!n || !n[0]) continue;
             R.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
         }
-        if (!R.lib) { R.why = std::string("librccl.so not found: ") + (dlerror() ? dlerror() : ""); return; }
+        if (!R.lib) {
+            const char* de = dlerror();          // (a second call returns NULL: the first one clears the error)
+            R.why = std::string("librccl.so not found: ") + (de ? de : "");
+            return;
+        }
         R.GetUniqueId = reinterpret_cast<decltype(R.GetUniqueId)>(dlsym(R.lib, "ncclGetUniqueId"));
         R.CommInitRank = reinterpret_cast<decltype(R.CommInitRank)>(dlsym(R.lib, "ncclCommInitRank"));
         R.CommDestroy = reinterpret_cast<decltype(R.CommDestroy)>(dlsym(R.lib, "ncclCommDestroy"));

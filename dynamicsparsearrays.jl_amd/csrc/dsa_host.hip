@@ -77,6 +77,8 @@ struct ApiRange {
 
 int g_device = 0;
 // dev knob: DSA_APPEND_RUNS=0 sends ascending append runs through the per-op sequencer path (A/B measurements)
+// default of Pma::wait_policy (DSA_WAIT_POLICY=1: yield-friendly waits for every new handle)
+const int g_wait_policy_default = [] { const char* e = getenv("DSA_WAIT_POLICY"); return (e && e[0] == '1') ? 1 : 0; }();
 const bool g_append_runs = [] { const char* e = getenv("DSA_APPEND_RUNS"); return !(e && e[0] == '0'); }();
 
 // capacity = 2^ceil(Int, log2(ceil(n / t_h)))   src/pma.jl:64,81,88 (Float64 arithmetic, App. A.1)
@@ -111,6 +113,7 @@ struct Pma {
     Op* run_cells = nullptr; uint64_t* run_flags = nullptr; int64_t* run_out = nullptr; int64_t run_cap = 0;   // cell stream of a MappedPackedCSC append run
     uint64_t* run_memo = nullptr;               // the append replay's memo between runs (sequencer.hip: k_append_run)
     Op* d_ops = nullptr; int64_t ops_cap = 0;
+    int wait_policy = g_wait_policy_default;      // how blocking calls wait for a hand-over: 0 spin on the pinned word, 1 block in hipStreamSynchronize first (dsa_*_set_wait_policy)
     uint64_t* d_breaks = nullptr; bool breaks_valid = false;      // run-break bitmap of the ops in d_ops (sequencer.hip: k_op_breaks)
     double* d_q = nullptr; int64_t q_cap = 0;      // scratch for lookups (3 arrays of q_cap)
     int32_t* d_err = nullptr;
@@ -564,7 +567,15 @@ unsigned int next_publish_seq(Pma& P) {
     if (++P.pub_seq == 0) P.pub_seq = 1;
     return P.pub_seq;
 }
+// Blocking calls wait for a word the last kernel of the launch writes into pinned memory.  Policy 0 polls it (lowest latency; the
+// calling thread spins on a host core for the microseconds to milliseconds the device needs).  Policy 1 parks the thread in
+// hipStreamSynchronize first — the word is there when it returns — for hosts that run many tasks on few threads (a Julia process
+// driving Coluna): the kernels, the hand-over and the results are the same, only the way the host waits differs.
+void wait_policy_block(Pma& P) {
+    if (P.wait_policy == 1) HIPCHK(hipStreamSynchronize(P.stream));
+}
 void wait_published(Pma& P) {
+    wait_policy_block(P);
     // the stream is asked now and then so that a failed launch or a faulted kernel cannot hang the host
     volatile unsigned long long* seqp = P.h_pub;
     auto next_query = std::chrono::steady_clock::now() + std::chrono::milliseconds(2);
@@ -993,6 +1004,7 @@ void get_batch(Pma& P, int mode, const int64_t* qa, const int64_t* qb, int64_t n
         __atomic_thread_fence(__ATOMIC_RELEASE);
         hipError_t e = launch_get_small(mode, P.K(), P.V(), P.O(), P.capacity(), P.sems, P.col_keys, P.col_live, P.h_ctl->table_len, P.h_get, (int)n, seq, P.stream);
         if (e != hipSuccess) fail(DSA_EHIP, std::string("get launch: ") + hipGetErrorString(e));
+        wait_policy_block(P);
         volatile int64_t* seqp = P.h_get + 193;
         auto next_query = std::chrono::steady_clock::now() + std::chrono::milliseconds(2);
         while ((unsigned long long)__atomic_load_n(seqp, __ATOMIC_ACQUIRE) != seq) {
@@ -1031,11 +1043,23 @@ constexpr int64_t VIEW_AREA_CELLS = 1024;
 void ensure_view_area(Pma& P) {
     if (P.h_view) return;
     HIPCHK(pinned_alloc(reinterpret_cast<void**>(&P.h_view), (size_t)(8 + 2 * VIEW_AREA_CELLS) * sizeof(int64_t)));
-    std::memset(P.h_view, 0, (size_t)(8 + 2 * VIEW_AREA_CELLS) * sizeof(int64_t));
-    P.view_seq = 0;
+    std::memset(P.h_view, 0, 8 * sizeof(int64_t));          // header: a stale sequence number of the block's previous user must not match
 }
+// The area is LEASED for one operation and goes back to the pinned pool (pool.hip keeps idle blocks by size class: a lease costs a
+// map lookup) when the operation is over: 10^5 small vectors — Coluna keeps that many — would otherwise pin 32 KB each for life.
+// The sequence numbers stay per handle and start at 1; the header is zeroed at every lease.  When the operation fails with a kernel
+// possibly still in flight the block stays with the handle (released with it) instead of being handed to somebody else.
+struct ViewAreaLease {
+    Pma& P; int exc;
+    explicit ViewAreaLease(Pma& p) : P(p), exc(std::uncaught_exceptions()) { ensure_view_area(P); }
+    ~ViewAreaLease() {
+        if (std::uncaught_exceptions() > exc) return;
+        pinned_free(P.h_view); P.h_view = nullptr;
+    }
+};
 // polls word [5] of the landing area for `seq` (the stream is asked now and then: a failed launch cannot hang the host)
 void wait_view_seq(Pma& P, unsigned long long seq, const char* what) {
+    wait_policy_block(P);
     volatile int64_t* seqp = P.h_view + 5;
     auto next_query = std::chrono::steady_clock::now() + std::chrono::milliseconds(2);
     while ((unsigned long long)__atomic_load_n(seqp, __ATOMIC_ACQUIRE) != seq) {
@@ -1133,7 +1157,7 @@ void pma_build_from_host(Pma& P, const int64_t* part, const int64_t* key, const 
         // buffers and hands the entry count back; then the spread.  130 -> ~45 us for 50 entries (DSA_SMALL_BUILD=0: the general builder)
         KeyScan ks; ks.add(key, nnz);
         P.wide = !ks.fit32();
-        ensure_view_area(P);
+        ViewAreaLease lease(P);
         std::memcpy(P.h_view + 8, key, (size_t)nnz * sizeof(int64_t));
         std::memcpy(P.h_view + 8 + VIEW_AREA_CELLS, val, (size_t)nnz * sizeof(double));
         ensure_capacity_alloc(P, 2 * capacity_for(nnz));          // (an upper bound: folding can only shorten the stream)
@@ -1485,11 +1509,12 @@ void view_small(Pma& P, int64_t col, int64_t range_from, int64_t range_to, std::
     if (publish_enabled()) {
         // the kernel writes the meta words and the first SPEC cells straight into a pinned landing area and then a sequence number: the host
         // polls for it — no copy command, no stream synchronisation (60 -> 20 us per view; DSA_PUBLISH=0 = copies + synchronisation)
-        ensure_view_area(P);
+        ViewAreaLease lease(P);
         const unsigned long long seq = ++P.view_seq;
         hipError_t e = launch_view_small(P.K(), P.V(), P.O(), P.sems, P.col_keys, P.col_live, P.h_ctl->table_len, P.capacity(), col,
                                          P.KA(alt), P.vals[alt], out_cap, P.d_small, P.h_view, SPEC, seq, range_from, range_to, P.stream);
         if (e != hipSuccess) fail(DSA_EHIP, std::string("view launch: ") + hipGetErrorString(e));
+        wait_policy_block(P);
         volatile int64_t* seqp = P.h_view + 5;
         auto next_query = std::chrono::steady_clock::now() + std::chrono::milliseconds(2);
         while ((unsigned long long)__atomic_load_n(seqp, __ATOMIC_ACQUIRE) != seq) {
@@ -1577,6 +1602,7 @@ const Pma::SpmvMeta& spmv_meta(Pma& P) {
     prefetch_spmv_meta(P);                      // no-op when the write batch has already enqueued it
     // wait for the sequence number: normally there already (the kernel was enqueued behind the write batch); a stream wait if it
     // does not show up within a millisecond
+    wait_policy_block(P);
     volatile int64_t* seqp = P.h_meta + 5;
     const auto t0 = std::chrono::steady_clock::now();
     bool synced = false;
@@ -1643,6 +1669,10 @@ int32_t dsa_device_count(int32_t* count) {
     *count = n;
     API_CATCH
 }
+// the caching allocator (pool.hip) keeps up to DSA_POOL_MAX_MB of idle HBM per process: a host that shares the card with another
+// allocator (PyTorch's) asks how much that is and hands it back
+int32_t dsa_pool_idle_bytes(int64_t* bytes) { API_TRY *bytes = (int64_t)pool_idle_bytes(); API_CATCH }
+int32_t dsa_pool_trim(int64_t keep_bytes) { API_TRY pool_trim(keep_bytes > 0 ? (size_t)keep_bytes : 0); API_CATCH }
 int32_t dsa_set_device(int32_t device) {
     API_TRY
     HIPCHK(hipSetDevice(device));
@@ -1728,10 +1758,11 @@ int32_t dsa_vec_nonzeros(dsa_vec_t* h, int64_t* keys, double* vals, int64_t cap,
 // copy, no stream synchronisation: 50 -> 15 us); returns -1 when the range does not qualify
 static int64_t pack_small(Pma& P, KeyArr k, const double* v, const uint64_t* occ, int64_t from, int64_t to, KeyArr ok, double* ov, int64_t out_cap) {
     if (!publish_enabled() || to < from || from < 1 || to - from + 1 > 16384 || to - from + 1 > out_cap) return -1;
-    ensure_view_area(P);
+    ViewAreaLease lease(P);
     const unsigned long long seq = ++P.view_seq;
     hipError_t e = launch_view_small(k, v, occ, nullptr, nullptr, nullptr, 0, to, 0, ok, ov, out_cap, P.d_small, P.h_view, 0, seq, from, to, P.stream);
     if (e != hipSuccess) fail(DSA_EHIP, std::string("pack launch: ") + hipGetErrorString(e));
+    wait_policy_block(P);
     volatile int64_t* seqp = P.h_view + 5;
     auto next_query = std::chrono::steady_clock::now() + std::chrono::milliseconds(2);
     while ((unsigned long long)__atomic_load_n(seqp, __ATOMIC_ACQUIRE) != seq) {
@@ -1891,6 +1922,12 @@ int32_t dsa_vec_set_stream(dsa_vec_t* h, void* s) {
     API_CATCH
 }
 int32_t dsa_vec_sync(dsa_vec_t* h) { API_TRY vec_flush(h); HIPCHK(hipStreamSynchronize(h->P.stream)); API_CATCH }
+int32_t dsa_vec_set_wait_policy(dsa_vec_t* h, int32_t policy) {
+    API_TRY
+    if (policy != DSA_WAIT_SPIN && policy != DSA_WAIT_BLOCK) fail(DSA_EARG, "wait policy must be DSA_WAIT_SPIN or DSA_WAIT_BLOCK");
+    h->P.wait_policy = policy;
+    API_CATCH
+}
 
 // ---------------- PackedCSC ----------------
 int32_t dsa_pcsc_create(const int64_t* colptr, int64_t nparts, const int64_t* row_keys, const double* vals,
@@ -2481,6 +2518,12 @@ int32_t dsa_mat_set_stream(dsa_mat_t* h, void* s) {
         if (P->own_stream) stream_put(P->stream, P->device);
         P->stream = (hipStream_t)s; P->own_stream = false;
     }
+    API_CATCH
+}
+int32_t dsa_mat_set_wait_policy(dsa_mat_t* h, int32_t policy) {
+    API_TRY
+    if (policy != DSA_WAIT_SPIN && policy != DSA_WAIT_BLOCK) fail(DSA_EARG, "wait policy must be DSA_WAIT_SPIN or DSA_WAIT_BLOCK");
+    h->col.wait_policy = policy; h->row.wait_policy = policy;
     API_CATCH
 }
 int32_t dsa_mat_sync(dsa_mat_t* h) {

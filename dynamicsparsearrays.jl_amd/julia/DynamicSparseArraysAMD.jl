@@ -22,7 +22,7 @@ using SparseArrays
 
 export DynamicSparseVector, DynamicSparseMatrix, DynamicMatrixColView, PackedCSC, dynamicsparsevec, dynamicsparse, nbpartitions,
        deletecolumn!, deleterow!, deletepartition!, addrow!, closefillmode!, shrink_size!, set_device!, shard_range, dynamicsparse_shard, comm_unique_id, ShardComm, shard_allreduce!,
-       shard_spmv_allreduce!,
+       shard_spmv_allreduce!, set_wait_policy!, WAIT_SPIN, WAIT_BLOCK, pool_idle_bytes, pool_trim!,
        keyint, keyfrom
 
 const libdsa = get(ENV, "DSA_HIP_LIB", joinpath(@__DIR__, "..", "csrc", "libdsa_hip.so"))
@@ -43,6 +43,16 @@ const COMBINE_LAST = Int32(2)
 
 "one process per GPU: select the device before creating handles (dsa_set_device)"
 set_device!(dev::Integer) = _check(ccall((:dsa_set_device, libdsa), Int32, (Int32,), dev))
+"idle HBM the library's caching allocator holds for reuse — dsa_pool_idle_bytes"
+function pool_idle_bytes()
+    out = Ref{Int64}(0)
+    _check(ccall((:dsa_pool_idle_bytes, libdsa), Int32, (Ptr{Int64},), out))
+    return out[]
+end
+"release idle HBM blocks until at most `keep_bytes` remain — dsa_pool_trim"
+pool_trim!(keep_bytes::Integer = 0) = _check(ccall((:dsa_pool_trim, libdsa), Int32, (Int64,), keep_bytes))
+const WAIT_SPIN = Int32(0)      # blocking calls poll a pinned word (lowest latency, one core busy)
+const WAIT_BLOCK = Int32(1)     # blocking calls park in hipStreamSynchronize first (a Julia process that runs many tasks)
 function device_count()
     n = Ref{Int32}(0)
     _check(ccall((:dsa_device_count, libdsa), Int32, (Ref{Int32},), n))
@@ -104,6 +114,10 @@ mutable struct DynamicSparseVector{K} <: AbstractSparseVector{Float64,K}
         return v
     end
 end
+
+"how the blocking calls of `v` wait for the device: WAIT_SPIN (default) or WAIT_BLOCK — dsa_vec_set_wait_policy"
+set_wait_policy!(v::DynamicSparseVector, policy::Integer) =
+    _check(ccall((:dsa_vec_set_wait_policy, libdsa), Int32, (Ptr{Cvoid}, Int32), v.h, policy))
 
 function dynamicsparsevec(I::AbstractVector{K}, V::AbstractVector, combine::Function = +, n::Integer = -1) where {K}
     length(I) == length(V) || throw(ArgumentError("keys & nonzeros vectors must have same length."))
@@ -205,6 +219,10 @@ mutable struct DynamicSparseMatrix{K,L}
         return m
     end
 end
+
+"how the blocking calls of `m` wait for the device: WAIT_SPIN (default) or WAIT_BLOCK — dsa_mat_set_wait_policy"
+set_wait_policy!(m::DynamicSparseMatrix, policy::Integer) =
+    _check(ccall((:dsa_mat_set_wait_policy, libdsa), Int32, (Ptr{Cvoid}, Int32), m.h, policy))
 
 # dynamicsparse(I, J, V[, m, n][, combine])  src/matrix.jl:15-19 -> dynamicsparsecolmajor(J, I, V, combine) src/pcsr.jl:433-445:
 # the library folds duplicates of (i, j) with +; any other combine is folded here first
@@ -353,8 +371,10 @@ mutable struct ShardComm
         return c
     end
 end
-"y (a device pointer to m Float64 in HBM) <- sum over the ranks, in place, asynchronous on `stream` — dsa_shard_allreduce_dev"
-shard_allreduce!(c::ShardComm, d_y::Ptr{Cvoid}, m::Integer, stream::Ptr{Cvoid} = C_NULL) =
+"y (a device pointer to m Float64 in HBM) <- sum over the ranks, in place, asynchronous on `stream` — dsa_shard_allreduce_dev.
+`stream` has no default: the shard's product runs on the matrix's own non-blocking stream, which is NOT ordered against the legacy
+null stream, so the caller names the stream y was produced on (or uses shard_spmv_allreduce!, which takes the matrix's)."
+shard_allreduce!(c::ShardComm, d_y::Ptr{Cvoid}, m::Integer, stream::Ptr{Cvoid}) =
     _check(ccall((:dsa_shard_allreduce_dev, libdsa), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}), c.h, d_y, m, stream))
 "y = A x of the whole sharded matrix on every rank: local product + all-reduce, x / y device pointers — dsa_shard_spmv_allreduce_dev"
 shard_spmv_allreduce!(a::DynamicSparseMatrix, c::ShardComm, d_x::Ptr{Cvoid}, nx::Integer, d_y::Ptr{Cvoid}, ny::Integer) =

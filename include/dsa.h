@@ -235,6 +235,19 @@ int32_t dsa_mat_set_stream(dsa_mat_t* h, void* hip_stream);
 int32_t dsa_vec_set_stream(dsa_vec_t* h, void* hip_stream);
 int32_t dsa_mat_sync(dsa_mat_t* h);
 int32_t dsa_vec_sync(dsa_vec_t* h);
+/* How the blocking entry points of a handle wait for the device.  No reference counterpart (the reference never waits for anything).
+ * DSA_WAIT_SPIN (default): the calling thread polls a word in pinned memory that the last kernel of the launch writes — lowest
+ * latency, one host core busy for the duration.  DSA_WAIT_BLOCK: the thread is parked in hipStreamSynchronize first — for hosts that
+ * multiplex many tasks on few threads (a Julia process driving Coluna).  Results are identical; DSA_WAIT_POLICY=1 in the environment
+ * makes DSA_WAIT_BLOCK the default of new handles. */
+enum { DSA_WAIT_SPIN = 0, DSA_WAIT_BLOCK = 1 };
+int32_t dsa_vec_set_wait_policy(dsa_vec_t* h, int32_t policy);
+int32_t dsa_mat_set_wait_policy(dsa_mat_t* h, int32_t policy);
+/* The library keeps freed HBM blocks (slot buffers, tables, build scratch) for reuse — up to DSA_POOL_MAX_MB (default 16384) of idle
+ * memory per process.  dsa_pool_idle_bytes reports how much is idle right now, dsa_pool_trim releases idle blocks (largest first)
+ * until at most keep_bytes remain: what a host that shares the card with another allocator calls before that one runs short. */
+int32_t dsa_pool_idle_bytes(int64_t* bytes);
+int32_t dsa_pool_trim(int64_t keep_bytes);
 
 /* ---- parity hooks and snapshots (no reference counterpart as entry points; the primitives they run are the reference's) ----
  * dsa_dbg_raw_*: ONE slot-array primitive of src/finds.jl / src/writes.jl / src/moves.jl executed by the DEVICE code on a

@@ -999,11 +999,12 @@ def test_root_rebalance_at_2_24_slots_from_every_relayout_mode_matches_oracle(ds
     assert not a.check()[2:7].any()
 
 
-def test_c5_full_size_streaming_first_10k_columns_vs_oracle_then_invariants(dsa, hip, oracle):
-    """BASELINE config 5 at FULL size (100 000 rows, 16 rows per column, columns streamed in ascending id, SpMV every 1000
-    columns).  The first 10 000 columns run side by side with the CPU oracle (2-3 s of oracle time): slot layout, tables and
-    y compared after every batch.  The remaining 40 000 columns run on the GPU alone: invariant checker, nnz, and y against
-    scipy on the triples streamed so far (1e-12)."""
+def test_c5_full_size_streaming_all_columns_vs_oracle(dsa, hip, oracle):
+    """BASELINE config 5 at FULL size (100 000 rows, 16 rows per column, 50 000 columns streamed in ascending id, SpMV every 1000
+    columns), ALL of it side by side with the CPU oracle (about 5 s of oracle time on the GPU box): y after every batch, slot layout
+    and tables of both orientations after the first two batches and then every 5000 columns — the steady-state append replay of the
+    colmajor orientation and the batch-parallel rounds of the rowmajor twin included —, rebalance statistics at the end, and y
+    against scipy on all triples (1e-12)."""
     import scipy.sparse as sp
     import bench
     m5, ncols5, per5 = bench.C5_FULL[:3]
@@ -1012,23 +1013,55 @@ def test_c5_full_size_streaming_first_10k_columns_vs_oracle_then_invariants(dsa,
     x5 = bench.unit12(13, ncols5)
     a = dsa.dynamicsparse(fill_mode=False, binding=hip)
     b = dsa.dynamicsparse(fill_mode=False, binding=oracle)
+    ya = None
     for c0 in range(0, ncols5, every):
         sl = slice(c0 * per5, (c0 + every) * per5)
         a.set_batch(I5[sl], J5[sl], V5[sl])
+        b.set_batch(I5[sl], J5[sl], V5[sl])
         nc = c0 + every
         ya = a.mul(x5[:nc], dense_out=m5)
-        if nc <= 10_000:
-            b.set_batch(I5[sl], J5[sl], V5[sl])
-            if nc % 2000 == 0 or nc <= 2000:
-                assert_mat_equal(a, b)
-            np.testing.assert_allclose(ya, b.mul(x5[:nc], dense_out=m5), rtol=RTOL, atol=0)
-        elif nc % 10_000 == 0:
-            for o in (dsa.COLMAJOR, dsa.ROWMAJOR):
-                assert not a.check(o)[2:7].any(), (nc, o)
-            assert a.nnz() == nc * per5
-            A = sp.csr_matrix((V5[: nc * per5], (I5[: nc * per5] - 1, J5[: nc * per5] - 1)), shape=(m5, nc))
-            np.testing.assert_allclose(ya, A @ x5[:nc], rtol=1e-12, atol=0)
+        np.testing.assert_allclose(ya, b.mul(x5[:nc], dense_out=m5), rtol=RTOL, atol=0)
+        if nc <= 2000 or nc % 5000 == 0:
+            assert_mat_equal(a, b)
+    for o in (dsa.COLMAJOR, dsa.ROWMAJOR):
+        assert not a.check(o)[2:7].any(), o
+        ia, ib = a.info(o), b.info(o)
+        for k in ("stat_extends", "stat_rebalances", "stat_window_slots"):
+            assert ia[k] == ib[k], (o, k, ia[k], ib[k])
+    assert a.nnz() == ncols5 * per5
+    A = sp.csr_matrix((V5, (I5 - 1, J5 - 1)), shape=(m5, ncols5))
+    np.testing.assert_allclose(ya, A @ x5, rtol=1e-12, atol=0)
     assert a.size() == (int(I5.max()), ncols5)
+
+
+def test_c5_streaming_with_deletions_20k_columns_vs_oracle(dsa, hip, oracle):
+    """Config 5 with deletions at 20 000 columns (the shape of bench.py's c5_streaming_with_deletions leg): after every batch of 1000
+    streamed columns 1 of 20 of them is deleted again (tombstones in the colmajor tables, purged partitions in the slot array, element
+    deletes in the rowmajor twin), all of it side by side with the oracle: y after every batch, both layouts and tables every 5000
+    columns, statistics at the end."""
+    import bench
+    m5, _, per5 = bench.C5_FULL[:3]
+    ncols, every = 20_000, 1000
+    I5, J5, V5 = bench.c5_columns(m5, ncols, per5)
+    x5 = bench.unit12(13, ncols)
+    a = dsa.dynamicsparse(fill_mode=False, binding=hip)
+    b = dsa.dynamicsparse(fill_mode=False, binding=oracle)
+    for c0 in range(0, ncols, every):
+        sl = slice(c0 * per5, (c0 + every) * per5)
+        a.set_batch(I5[sl], J5[sl], V5[sl])
+        b.set_batch(I5[sl], J5[sl], V5[sl])
+        for j in range(c0 + 1, c0 + every + 1, 20):
+            a.deletecolumn(j)
+            b.deletecolumn(j)
+        nc = c0 + every
+        np.testing.assert_allclose(a.mul(x5[:nc], dense_out=m5), b.mul(x5[:nc], dense_out=m5), rtol=RTOL, atol=0)
+        if nc <= 1000 or nc % 5000 == 0:
+            assert_mat_equal(a, b)
+    for o in (dsa.COLMAJOR, dsa.ROWMAJOR):
+        assert not a.check(o)[2:7].any(), o
+        ia, ib = a.info(o), b.info(o)
+        for k in ("stat_extends", "stat_shrinks", "stat_rebalances", "stat_window_slots"):
+            assert ia[k] == ib[k], (o, k, ia[k], ib[k])
 
 
 # ---------------------------------------------------------------- the reference's functional tests, our RNG, HIP vs oracle
@@ -1694,3 +1727,70 @@ def test_new_partitions_by_the_thousand_merge_between_launches(dsa, hip, oracle,
     assert ea == eb
     if ea is None:
         assert_mat_equal(A, B)
+
+
+# ---------------------------------------------------------------- round 4: wait policy, allocator entry points, landing-area leases
+def test_wait_policy_block_gives_the_same_results(dsa, hip, oracle):
+    """dsa_*_set_wait_policy(DSA_WAIT_BLOCK): blocking calls park in hipStreamSynchronize instead of polling pinned memory — same
+    kernels, same hand-over, same results: a vector and a matrix driven through writes, lookups, views, slices, deletes and products
+    under the blocking policy against the oracle, then back to spinning."""
+    g = SplitMix64(99)
+    keys = sorted({1 + g.next() % 100000 for _ in range(3000)})
+    vals = unit12_array(1, len(keys))
+    a = dsa.dynamicsparsevec(keys, vals, binding=hip)
+    b = dsa.dynamicsparsevec(keys, vals, binding=oracle)
+    a.set_wait_policy(1)
+    ks = [1 + g.next() % 100000 for _ in range(2000)]
+    vs = [float(g.next() % 4) for _ in ks]
+    a.set_batch(ks, vs); b.set_batch(ks, vs)
+    a[77] = 2.5; b[77] = 2.5
+    assert a[77] == b[77] and a[keys[5]] == b[keys[5]]
+    assert_vec_equal(a, b)
+    assert np.array_equal(a.nonzeros()[0], b.nonzeros()[0])
+    with pytest.raises(dsa.DsaArgumentError):
+        a.set_wait_policy(7)
+    a.set_wait_policy(0)
+    a[78] = 1.5; b[78] = 1.5
+    assert_vec_equal(a, b)
+    A = dsa.dynamicsparse(fill_mode=False, binding=hip)
+    B = dsa.dynamicsparse(fill_mode=False, binding=oracle)
+    A.set_wait_policy(1)
+    I = [1 + g.next() % 500 for _ in range(4000)]
+    J = [1 + g.next() % 300 for _ in range(4000)]
+    V = [float(1 + g.next() % 9) for _ in range(4000)]
+    A.set_batch(I, J, V); B.set_batch(I, J, V)
+    A[3, 4] = 0.0; B[3, 4] = 0.0
+    A.deletecolumn(J[0]); B.deletecolumn(J[0])
+    assert_mat_equal(A, B)
+    assert A.col_view(J[1]) == B.col_view(J[1])
+    x = unit12_array(5, 300)
+    np.testing.assert_allclose(A.mul(x, dense_out=500), B.mul(x, dense_out=500), rtol=RTOL, atol=0)
+
+
+def test_pool_idle_bytes_and_trim(dsa, hip):
+    """dsa_pool_idle_bytes / dsa_pool_trim: a destroyed structure leaves its HBM blocks idle in the caching allocator; a trim hands
+    them back to the driver (a host sharing the card with another allocator); a structure built afterwards is none the worse."""
+    keys = np.arange(1, 200001, dtype=np.int64)
+    v = dsa.dynamicsparsevec(keys, unit12_array(2, len(keys)), binding=hip)
+    v.close()
+    idle = dsa.pool_idle_bytes(binding=hip)
+    assert idle >= 2 * 200000 * 12, idle
+    dsa.pool_trim(1 << 20, binding=hip)
+    assert dsa.pool_idle_bytes(binding=hip) <= 1 << 20
+    dsa.pool_trim(0, binding=hip)
+    assert dsa.pool_idle_bytes(binding=hip) == 0
+    w = dsa.dynamicsparsevec(keys, unit12_array(2, len(keys)), binding=hip)
+    assert w.nnz() == len(keys) and w[777] == unit12_array(2, len(keys))[776]
+
+
+def test_many_small_vectors_lease_their_landing_area(dsa, hip):
+    """2000 live small vectors, each built by the one-launch small builder and read once: the pinned landing area of those operations
+    is leased per operation (not held per handle), so values and layouts are right however the leases interleave."""
+    vs = []
+    for i in range(2000):
+        k = np.arange(1, 6, dtype=np.int64) * (i + 1)
+        vs.append(dsa.dynamicsparsevec(k, np.full(5, float(i + 1)), binding=hip))
+    for i in (0, 1, 999, 1999):
+        kk, vv = vs[i].nonzeros()
+        assert np.array_equal(kk, np.arange(1, 6, dtype=np.int64) * (i + 1)) and np.all(vv == float(i + 1))
+        assert vs[i][3 * (i + 1)] == float(i + 1)

@@ -77,6 +77,29 @@ def test_shard_range_matches_the_host_layer(dsa):
         b.call("shard_range", 10, 2, 2, C.byref(c0), C.byref(nc))
 
 
+def test_missing_rccl_is_a_status_code_not_a_crash():
+    """A box without RCCL: dsa_comm_unique_id / dsa_comm_init must come back with DSA_ERCCL and a message (the loader once built that
+    message from two dlerror() calls — the second returns NULL — and took the host process down with it).  DSA_RCCL_LIB names the only
+    library that is tried; run in a child process because the loader binds once per process.  No GPU call is made."""
+    code = r"""
+import ctypes as C, os, sys
+lib = C.CDLL(os.path.join(sys.argv[1], "dynamicsparsearrays.jl_amd", "csrc", "libdsa_hip.so"))
+lib.dsa_last_error_message.restype = C.c_char_p
+buf = (C.c_uint8 * 128)()
+rc = lib.dsa_comm_unique_id(buf)
+msg = lib.dsa_last_error_message().decode()
+assert rc == 10, rc                       # DSA_ERCCL
+assert "librccl.so not found" in msg, msg
+out = C.c_void_p()
+rc = lib.dsa_comm_init(0, 2, buf, C.byref(out))
+assert rc in (10, 7), rc                  # DSA_ERCCL (DSA_EHIP without any device: the current-device query comes first)
+print("ok")
+"""
+    env = dict(os.environ, DSA_RCCL_LIB="/nonexistent/librccl.so")
+    r = subprocess.run([os.sys.executable, "-c", code, ROOT], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "ok" in r.stdout, (r.returncode, r.stdout, r.stderr)
+
+
 def test_julia_wrapper_binds_only_declared_symbols():
     """The Julia wrapper cannot be executed here (no Julia toolchain): at least every symbol it `ccall`s must be declared in
     include/dsa.h, and the argument count of each ccall must match the C prototype."""
