@@ -12,6 +12,7 @@ from . import binding  # noqa: F401
 from .api import (  # noqa: F401
     COLMAJOR, ROWMAJOR, DynamicSparseMatrix, DynamicSparseVector, PackedCSC, Transposed,
     addrow, closefillmode, deletecolumn, deletepartition, deleterow, dynamicsparse,
-    dynamicsparsevec, import_packedcsc_layout, import_vector_layout, nbpartitions, nnz, packedcsc, packedcsc_empty, shrink_size,
+    dynamicsparsevec, import_packedcsc_layout, import_vector_layout, nbpartitions, nnz, packedcsc, packedcsc_empty, pool_idle_bytes,
+    pool_trim, shrink_size,
 )
 from .binding import Binding, DsaArgumentError, DsaBoundsError, DsaError, DsaErrorException, product  # noqa: F401
