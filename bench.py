@@ -65,6 +65,41 @@ def c3_triplets(m, ncols, per, col0, seed_rows, seed_vals):
     return rows, cols_local + 1 + col0, vals
 
 
+def c3_insert_leg(m, n, n_random=100_000, n_new_cols=10_000, per=10):
+    """The writes of the `inserts_on_c3` leg (bench.py) and of its parity test (tests/test_hip_parity.py): n_random uniformly random
+    A[i, j] = v on the m x n matrix, then n_new_cols NEW columns n+1 .. n+n_new_cols with `per` distinct ascending rows each."""
+    ri = 1 + (splitmix_array(61, n_random) % np.uint64(m)).astype(np.int64)
+    rj = 1 + (splitmix_array(62, n_random) % np.uint64(n)).astype(np.int64)
+    rv = unit12(63, n_random)
+    z = 1 + (splitmix_array(64, n_new_cols * per * 2) % np.uint64(m)).astype(np.int64)
+    ai, aj = [], []
+    pos = 0
+    for c in range(n_new_cols):
+        seen = set()
+        while len(seen) < per:
+            seen.add(int(z[pos])); pos += 1
+        ai += sorted(seen); aj += [n + 1 + c] * per
+    return (ri, rj, rv), (np.array(ai, dtype=np.int64), np.array(aj, dtype=np.int64), unit12(65, len(ai)))
+
+
+def cold_launch_us(torch, dev, stream, fn, nrep=8, evict_bytes=1 << 30):
+    """Median time of ONE launch of fn with HIP events around it alone, each launch behind a device write of evict_bytes (1 GiB: four
+    times the 256 MB Infinity Cache, far beyond the 8 x 4 MB L2s) — the operands of the launch come from HBM, not from a cache the
+    previous launch filled."""
+    scr = torch.empty(evict_bytes // 4, dtype=torch.float32, device=dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ts = []
+    for i in range(nrep):
+        scr.fill_(float(i))
+        e0.record(stream)
+        fn()
+        e1.record(stream)
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) * 1e3)
+    del scr
+    return float(np.median(ts))
+
+
 def kernel_source_sha():
     """sha256 over the kernel sources whose traffic the committed PMC summaries describe: a summary made from other
     sources is stale and is not quoted."""
@@ -217,6 +252,14 @@ def main():
     gc.enable()
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
     ms_per_step = elapsed * 1e3 / args.steps
+    # the same launch COLD: the timed steps run back to back on 2 x 203 MB of slot buffers + 8 MB of x, within reach of the 256 MB
+    # Infinity Cache (FETCH_SIZE counts MALL hits as fetches); here every launch follows a 1 GiB device write
+    cold_us = None
+    if world == 1:
+        try:
+            cold_us = cold_launch_us(torch, dev, stream, lambda: shard.spmv_partial(x, ys[0]))
+        except Exception:
+            cold_us = None
 
     # algorithmic bytes of one SpMV launch: 16 B per streamed slot + x read + y written
     bytes_launch = 16 * cap + 8 * ncl + 8 * m
@@ -263,6 +306,10 @@ def main():
         "nnz_per_s": round(world * nnz / (ms_per_step / 1e3), 1),
         "build_s": round(build_s, 3),
     }
+    if cold_us is not None:
+        out["roofline"]["cold_kernel_ms"] = round(cold_us / 1e3, 5)
+        out["roofline"]["cold_frac"] = round(bytes_launch / 1e3 / cold_us / HBM_PEAK_GBS, 4)
+        out["roofline"]["cold_note"] = "median of 8 launches, each behind a 1 GiB device write (caches and Infinity Cache evicted), HIP events around the kernel alone"
 
     # what the access pattern itself costs on this part (tools/gatherbench2.hip through tools/scripts/gather_floor.sh, committed as
     # profiles/gather_floor.json): the slot stream alone, the 11 M gathers from an 8.4 MB x alone, and both in one kernel — the
@@ -358,6 +405,14 @@ def extras(dsa, hip, torch, A, dev):
                                  "kernels": "k_move2<false, WIDE=false> (one launch)",
                                  "physical_bytes": 2 * (12 * cap + cap // 8),
                                  "physical_frac": round(2 * (12 * cap + cap // 8) / 1e9 / (ms / 1e3) / HBM_PEAK_GBS, 4)}
+    try:
+        cus = cold_launch_us(torch, dev, stream, lambda: A.rebalance_root(dsa.COLMAJOR))
+        res["roofline_rebalance"]["cold_ms"] = round(cus / 1e3, 5)
+        res["roofline_rebalance"]["cold_frac"] = round(b / 1e3 / cus / HBM_PEAK_GBS, 4)
+        res["roofline_rebalance"]["cold_physical_frac"] = round(2 * (12 * cap + cap // 8) / 1e3 / cus / HBM_PEAK_GBS, 4)
+        res["roofline_rebalance"]["cold_note"] = "median of 8 launches, each behind a 1 GiB device write, HIP events around the launch alone"
+    except Exception as e:
+        res["roofline_rebalance"]["cold_error"] = str(e)[:120]
     # --- the isolated rebalance on full windows of 2^20 / 2^21 / 2^24 slots at densities 0.35 / 0.70:
     #     a vector's PMA built from n = density * capacity keys, root pack + spread timed back to back
     sweep = []
@@ -561,6 +616,36 @@ def extras(dsa, hip, torch, A, dev):
     fill["kbuild"] = "hand-written LSD radix sort of a (partition, key) composite over its significant bits: 5 passes of 8 bits at this size (csrc/build.hip)"
     del F
     res["buffered_writes"] = fill
+    # --- inserts ON the 10 M-nnz PCSR itself (what BASELINE's metric names): 100 k uniformly random A[i, j] = v, then 10 k NEW columns
+    #     of 10 rows appended — every element write updates both 2^24-slot orientations.  Last leg: it changes the headline matrix.
+    #     Parity of exactly these writes at full size: tests/test_hip_parity.py::test_inserts_on_the_c3_matrix_match_oracle
+    try:
+        m3, n3 = A.size()
+        (ri, rj, rv), (ai, aj, av) = c3_insert_leg(m3, n3)
+
+        def stats():
+            return {o: A.info(o) for o in (dsa.COLMAJOR, dsa.ROWMAJOR)}
+
+        def delta(a, b_):
+            return {name: {k: b_[o][k] - a[o][k] for k in ("stat_window_slots", "stat_rebalances", "stat_grid_rebalances", "stat_extends", "nb_elements")}
+                    for o, name in ((dsa.COLMAJOR, "colmajor"), (dsa.ROWMAJOR, "rowmajor"))}
+        A.set_batch(ri[:256], rj[:256], rv[:256])                  # (first batch on this handle: graph capture, op buffers)
+        s0 = stats()
+        t = time.perf_counter(); A.set_batch(ri[256:], rj[256:], rv[256:]); t_rand = time.perf_counter() - t
+        s1 = stats()
+        t = time.perf_counter(); A.set_batch(ai, aj, av); t_app = time.perf_counter() - t
+        s2 = stats()
+        res["inserts_on_c3"] = {
+            "matrix": "%d x %d, %d nnz before the leg, capacity %d slots per orientation" % (m3, n3, s0[dsa.COLMAJOR]["nb_elements"] - s0[dsa.COLMAJOR]["nb_partitions"], s0[dsa.COLMAJOR]["capacity"]),
+            "random_writes": {"element_writes": int(len(ri) - 256), "ms": round(t_rand * 1e3, 3), "element_writes_per_s": round((len(ri) - 256) / t_rand, 1),
+                              "pcsr_inserts_per_s": round(2 * (len(ri) - 256) / t_rand, 1), "stats": delta(s0, s1)},
+            "appended_columns": {"columns": 10_000, "element_writes": int(len(ai)), "ms": round(t_app * 1e3, 3), "element_writes_per_s": round(len(ai) / t_app, 1),
+                                 "pcsr_inserts_per_s": round(2 * len(ai) / t_app, 1), "stats": delta(s1, s2)},
+            "note": "whole dsa_mat_set_batch calls incl. H2D; stat_grid_rebalances = launches of the grid-wide pack/spread kernel (windows above 8192 "
+                    "slots); the appended columns are one append run per batch in the colmajor orientation (bitmap replay + one K-permute of the "
+                    "array, no per-window launches) and random inserts in the rowmajor twin"}
+    except Exception as e:
+        res["inserts_on_c3"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
     return res
 
 

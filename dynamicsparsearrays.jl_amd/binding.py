@@ -22,11 +22,11 @@ P_U8 = C.POINTER(C.c_uint8)
 P_I32 = C.POINTER(C.c_int32)
 VP = C.c_void_p
 
-INFO_COUNT = 16
+INFO_COUNT = 17
 INFO = dict(capacity=0, segment_capacity=1, nb_segments=2, nb_elements=3, height=4,
             nb_partitions=5, table_len=6, stat_window_slots=7, stat_rebalances=8,
             stat_extends=9, stat_shrinks=10, stat_par_rounds=11, stat_par_ops=12, stat_seq_ops=13,
-            stat_spmv_nomemset=14, hbm_bytes=15)
+            stat_spmv_nomemset=14, hbm_bytes=15, stat_grid_rebalances=16)
 
 OK, EARG, EBOUNDS, EDELETED, EFULL, EMODE, EASSERT, EHIP, ECAP, EKEY, ERCCL = range(11)
 STATUS_NAMES = ["OK", "EARG", "EBOUNDS", "EDELETED", "EFULL", "EMODE", "EASSERT", "EHIP", "ECAP", "EKEY", "ERCCL"]

@@ -124,6 +124,7 @@ struct Pma {
     DevBufs* d_bufs = nullptr; DevBufs* h_bufs = nullptr;      // the arrays the rounds work on, read from device memory (pinned mirror)
     TableMerge tmerge{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; int64_t tmerge_cap = 0;   // scratch of the grid-wide table merge (tables.hip)
     int64_t stat_table_merges = 0;
+    int64_t stat_grid_rebalances = 0;               // launches of the grid-wide rebalance (window_rebalance / root_rebalance)
     int64_t* d_small = nullptr;                     // 8 x int64 scratch
     int64_t* h_small = nullptr;                     // its pinned host mirror (small read-backs without a pageable staging copy)
     int64_t* h_get = nullptr; unsigned long long get_seq = 0;        // pinned landing area of small lookups (get_batch: keys, partitions, answers, error, sequence number)
@@ -388,6 +389,7 @@ void ensure_capacity_alloc(Pma& P, int64_t slots) {
 // pack + spread of the whole array into the other buffer: cells of cur[1..src_cap] -> alt[1..new_cap]
 // (root _even_rebalance!, _extend!, pack! + _shrink!)  src/pma.jl:94-103,135-161
 void root_rebalance(Pma& P, int64_t src_cap, int64_t new_cap, int64_t m, bool src_packed) {
+    ++P.stat_grid_rebalances;
     ensure_capacity_alloc(P, std::max(src_cap, new_cap));
     ++P.layout_epoch;
     const int alt = 1 - P.cur;
@@ -412,6 +414,7 @@ void window_rebalance(Pma& P, int64_t ws, int64_t we, int64_t m) {
     if (ws == 1 && we == P.capacity()) { root_rebalance(P, P.capacity(), P.capacity(), m, false); return; }
     const int alt = 1 - P.cur;
     ++P.layout_epoch;
+    ++P.stat_grid_rebalances;
     if (m <= 0) {                                     // nothing to move: every slot of the window becomes a gap
         hipError_t e0 = launch_clear_occ(P.O(), ws, we, P.stream);
         if (e0 != hipSuccess) fail(DSA_EHIP, std::string("clear launch: ") + hipGetErrorString(e0));
@@ -930,6 +933,7 @@ void pma_info(Pma& P, int64_t nb_partitions_or_len, int64_t* info) {
     info[DSA_INFO_STAT_SHRINKS] = c.stat_shrinks;
     info[11] = P.stat_par_rounds; info[12] = P.stat_par_ops; info[13] = P.stat_seq_ops;
     info[DSA_INFO_STAT_SPMV_NOMEMSET] = P.stat_spmv_nomemset;
+    info[DSA_INFO_STAT_GRID_REBALANCES] = P.stat_grid_rebalances;
     // HBM held by the structure: both slot buffers (keys, values, bitmap), the saved bitmap of append runs, the tables and the merge scratch
     info[DSA_INFO_HBM_BYTES] = 2 * (P.cap_alloc * (int64_t)(P.kb() + sizeof(double)) + P.occ_words * 8) + (P.occ_old ? P.occ_words * 8 : 0) +
                                (P.has_sems ? c.table_cap * 8 : 0) + (P.has_cols ? c.table_cap * 9 : 0) + 2 * P.tmerge_cap * 8;

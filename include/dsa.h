@@ -64,7 +64,8 @@ enum {
     DSA_INFO_STAT_SEQ_OPS = 13,
     DSA_INFO_STAT_SPMV_NOMEMSET = 14, /* instrumentation: gather SpMV launches over this orientation that needed no memset of y */
     DSA_INFO_HBM_BYTES = 15,          /* bytes of HBM the structure holds (slot buffers x 2, bitmaps, tables, merge scratch) */
-    DSA_INFO_COUNT = 16
+    DSA_INFO_STAT_GRID_REBALANCES = 16, /* instrumentation: launches of the grid-wide pack/spread kernel (windows above 8192 slots, root, _extend!, _shrink!) */
+    DSA_INFO_COUNT = 17
 };
 
 typedef struct dsa_vec dsa_vec_t;    /* DynamicSparseVector   src/vector.jl:1-4   */

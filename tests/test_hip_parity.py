@@ -965,6 +965,32 @@ def test_c3_full_size_build_spmv_checker_and_rebalance_idempotence(dsa, hip, ora
     np.testing.assert_allclose(a.mul(x), A @ x, rtol=1e-12, atol=0)
 
 
+def test_inserts_on_the_c3_matrix_match_oracle(dsa, hip, oracle):
+    """The `inserts_on_c3` leg of bench.py at FULL size against the oracle: the 10 M-nnz matrix, 100 000 uniformly random A[i, j] = v
+    (both 2^24-slot orientations take a random insert each), then 10 000 NEW columns of 10 rows (one append run in the colmajor
+    orientation — the count-only replay on 16-slot segments with semaphore cells — and random inserts in the rowmajor twin).  Both
+    orientations slot for slot after each half, the rebalance statistics, the invariant checker and y = A x (1e-12)."""
+    import bench
+    m = n = 1_000_000
+    I, J, V = bench.c3_triplets(m, n, 10, 0, seed_rows=5, seed_vals=6)
+    a = dsa.dynamicsparse(I, J, V, m, n, binding=hip)
+    b = dsa.dynamicsparse(I, J, V, m, n, binding=oracle)
+    (ri, rj, rv), (ai, aj, av) = bench.c3_insert_leg(m, n)
+    for Ii, Jj, Vv in ((ri[:256], rj[:256], rv[:256]), (ri[256:], rj[256:], rv[256:]), (ai, aj, av)):
+        a.set_batch(Ii, Jj, Vv)
+        b.set_batch(Ii, Jj, Vv)
+        assert_mat_equal(a, b)
+        for o in (dsa.COLMAJOR, dsa.ROWMAJOR):
+            ia, ib = a.info(o), b.info(o)
+            for k in ("stat_extends", "stat_rebalances", "stat_window_slots"):
+                assert ia[k] == ib[k], (o, k, ia[k], ib[k])
+    for o in (dsa.COLMAJOR, dsa.ROWMAJOR):
+        assert not a.check(o)[2:7].any(), o
+    assert a.size() == (m, n + 10_000)
+    x = bench.unit12(7, n + 10_000)
+    np.testing.assert_allclose(a.mul(x), b.mul(x), rtol=1e-12, atol=0)
+
+
 def test_root_rebalance_at_2_24_slots_from_every_relayout_mode_matches_oracle(dsa, hip, oracle):
     """The window the north-star roofline is quoted on: 11 M cells in 2^24 slots (the density of config 3).  From a source packed
     to the left (pack!), packed to the right (all gaps at the left), after _extend! (2^25 slots: compared with the oracle's
