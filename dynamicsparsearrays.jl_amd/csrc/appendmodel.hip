@@ -145,6 +145,48 @@ __device__ int m3_final_descent(const M3Lane& L, int& cnt, const uint64_t* X, co
     }
 }
 
+// ---- suffix cell counts of every level into sh.cnt (whole workgroup; sh.bk zeroed by the caller): word r from the end falls into
+//      bucket bits(r); the suffix of 2^j words is buckets 0..j.  Words r >= 1024 are read in rows of 1024 (one word per thread: a row
+//      lies in ONE bucket), summed per thread while the bucket stays the same; the first 1024 words go to their buckets one by one
+__device__ void m3_suffix_counts(M3Shared& sh, const uint64_t* occ, int64_t cap, int64_t seg, int H, int tid, int lane) {
+    const int64_t nwords = cap >> 6;
+    {
+        if (tid < nwords) {
+            const int b = tid == 0 ? 0 : 32 - __clz(tid);
+            const unsigned long long c = (unsigned long long)popc64(occ[nwords - 1 - tid]);
+            if (c) atomicAdd(&sh.bk[b], c);
+        }
+        unsigned long long acc = 0;
+        int cur_b = 11;
+        for (int64_t row = 1; row * (int)blockDim.x < nwords; ++row) {
+            const int b = 64 - __clzll((long long)(row * (int)blockDim.x));           // bits(r) of every r in the row
+            if (b != cur_b) {
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+                if (lane == 0 && acc) atomicAdd(&sh.bk[cur_b], acc);
+                acc = 0; cur_b = b;
+            }
+            acc += (unsigned long long)popc64(occ[nwords - 1 - (row * (int)blockDim.x + tid)]);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+        if (lane == 0 && acc) atomicAdd(&sh.bk[cur_b], acc);
+    }
+    __syncthreads();
+    if (tid <= H) {
+        const int64_t Wk = seg << tid;
+        unsigned long long c = 0;
+        if (Wk < 64) c = (unsigned long long)popc64(occ[nwords - 1] >> (64 - Wk));
+        else {
+            int j = 0;
+            while ((64ll << j) < Wk) ++j;
+            for (int b = 0; b <= j; ++b) c += sh.bk[b];
+        }
+        sh.cnt[tid] = (int32_t)c;
+    }
+    __syncthreads();
+}
+
 __global__ __launch_bounds__(M3_THREADS) void k_append_model3(uint64_t* occ, Ctl* ctl, int64_t R, const uint64_t* flags, const int64_t* d_T,
                                                               int64_t* out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char m3_lds[];
@@ -181,51 +223,14 @@ __global__ __launch_bounds__(M3_THREADS) void k_append_model3(uint64_t* occ, Ctl
     if (tid < 40) sh.bk[tid] = 0ull;
     if (tid == 0) { sh.H = H; sh.seg = (int32_t)seg; sh.bail = 0; sh.consumed = 0; sh.leaf_ops = 0; sh.ended = 0; sh.ev_mask = 0ull; sh.reb = 0ull; sh.slots = 0ull; sh.top_events = 0; sh.Lp = 0; }
     __syncthreads();
-    // ---- suffix cell counts of every level: word r from the end falls into bucket bits(r); the suffix of 2^j words is buckets 0..j.
-    //      Words r >= 1024 are read in rows of 1024 (one word per thread: a row lies in ONE bucket), summed per thread while the
-    //      bucket stays the same; the first 1024 words go to their buckets one by one ----
+    m3_suffix_counts(sh, occ, cap, seg, H, tid, lane);
     const int64_t nwords = cap >> 6;
-    {
-        if (tid < nwords) {
-            const int b = tid == 0 ? 0 : 32 - __clz(tid);
-            const unsigned long long c = (unsigned long long)popc64(occ[nwords - 1 - tid]);
-            if (c) atomicAdd(&sh.bk[b], c);
-        }
-        unsigned long long acc = 0;
-        int cur_b = 11;
-        for (int64_t row = 1; row * M3_THREADS < nwords; ++row) {
-            const int b = 64 - __clzll((long long)(row * M3_THREADS));           // bits(r) of every r in the row
-            if (b != cur_b) {
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-                if (lane == 0 && acc) atomicAdd(&sh.bk[cur_b], acc);
-                acc = 0; cur_b = b;
-            }
-            acc += (unsigned long long)popc64(occ[nwords - 1 - (row * M3_THREADS + tid)]);
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-        if (lane == 0 && acc) atomicAdd(&sh.bk[cur_b], acc);
-    }
-    __syncthreads();
-    if (tid <= H) {
-        const int64_t Wk = seg << tid;
-        unsigned long long c = 0;
-        if (Wk < 64) c = (unsigned long long)popc64(occ[nwords - 1] >> (64 - Wk));
-        else {
-            int j = 0;
-            while ((64ll << j) < Wk) ++j;
-            for (int b = 0; b <= j; ++b) c += sh.bk[b];
-        }
-        sh.cnt[tid] = (int32_t)c;
-    }
-    __syncthreads();
     // ---- table ranges: a count of level i never falls below the lowest suffix density of the levels >= i (minus rounding) ----
     if (tid == 0) {
         int bail = 0;
         if (sh.cnt[0] < 1 || sh.cnt[0] > maxc0) bail = 4;
         double dmin = 2.0;
-        int32_t cm[64];
+        int32_t* cm = sh.tauL;                  // (scratch: the driver's records are not in use yet)
         for (int k = H; k >= 0; --k) {
             const double d = (double)sh.cnt[k] / (double)sh.W[k];
             dmin = d < dmin ? d : dmin;
@@ -411,6 +416,7 @@ __global__ __launch_bounds__(M3_THREADS) void k_append_model3(uint64_t* occ, Ctl
     }
 }
 
+
 }  // namespace
 
 hipError_t launch_append_model3(uint64_t* occ, Ctl* ctl, int64_t R, const uint64_t* flags, const int64_t* d_T, int64_t* out, hipStream_t stream) {
@@ -425,5 +431,6 @@ hipError_t launch_append_model3(uint64_t* occ, Ctl* ctl, int64_t R, const uint64
     hipLaunchKernelGGL(k_append_model3, dim3(1), dim3(M3_THREADS), LDS, stream, occ, ctl, R, flags, d_T, out);
     return hipGetLastError();
 }
+
 
 }  // namespace dsa

@@ -206,6 +206,12 @@ __device__ __forceinline__ uint64_t spread_word_bits(const SpreadGeom& g, int t)
     }
     return bits;
 }
+// 1-based offset of the last cell after spread! of m >= 1 cells over W slots
+__device__ __forceinline__ int64_t spread_last_cell(const SpreadGeom& g) {
+    int q = (int)g.W, k = (int)g.E;
+    while (k > 0 && gap_D(g, k) == q) { --q; --k; }
+    return q;
+}
 // bit-interleave: bit i of x -> bit 2i
 __device__ __forceinline__ uint64_t spread_bits32(uint32_t x) {
     uint64_t v = x;

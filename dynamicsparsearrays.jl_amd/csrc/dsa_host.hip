@@ -709,8 +709,11 @@ bool seq_step(SeqRun& r) {
             // the count-only replay first (appendmodel.hip); what it cannot take — short runs, small segments, a tail outside the last
             // leaf — and whatever it leaves is replayed per op by k_append_run.  DSA_MODEL3=0: per-op replay only (A/B, coverage)
             static const bool model3 = [] { const char* v = getenv("DSA_MODEL3"); return !(v && v[0] == '0'); }();
-            int64_t* m3_out = model3 ? reinterpret_cast<int64_t*>(reinterpret_cast<char*>(P.run_memo) + append_run_memo_bytes()) : nullptr;
-            if (model3) {
+            // (typed runs on segments below 16 slots are not count-only — appendmodel.hip — and runs below its minimum length do not pay:
+            //  no launch for them)
+            const bool m3_takes = model3 && R >= 512 && (P.has_cols ? c.segment_capacity >= 16 : c.segment_capacity >= 2) && c.capacity >= 65536;
+            int64_t* m3_out = m3_takes ? reinterpret_cast<int64_t*>(reinterpret_cast<char*>(P.run_memo) + append_run_memo_bytes()) : nullptr;
+            if (m3_takes) {
                 e = launch_append_model3(P.O(), P.d_ctl, R, P.has_cols ? P.run_flags : nullptr, P.has_cols ? P.run_out : nullptr, m3_out, P.stream);
                 if (e != hipSuccess) fail(DSA_EHIP, std::string("append model launch: ") + hipGetErrorString(e));
             }

@@ -280,12 +280,7 @@ constexpr int RUN_BLOCK_LOG2 = 12;
 struct RunComm { int64_t idx, L, reb, slots, small; int32_t need, pad; };
 
 // (spread_word_bits: dsa_dev.h)
-// 1-based offset of the last cell after spread! of m >= 1 cells over W slots
-__device__ __forceinline__ int64_t spread_last_cell(const SpreadGeom& g) {
-    int q = (int)g.W, k = (int)g.E;
-    while (k > 0 && gap_D(g, k) == q) { --q; --k; }
-    return q;
-}
+// (spread_last_cell: dsa_dev.h)
 
 // number of leading ops of ops[i..n) that continue an append run.
 //   mode 0 (vector):           OP_VEC_SET, non-zero value, key above the previous key (pa0 for the first op)

@@ -23,6 +23,15 @@ dev = torch.device("cuda:0")
 hip.call("mat_set_stream", A.h, C.c_void_p(torch.cuda.current_stream().cuda_stream))
 x = torch.from_numpy(bench.unit12(7, ncl)).to(dev)
 y = torch.zeros(m, dtype=torch.float64, device=dev)
+if "cold" in sys.argv[1:]:
+    # the gather kernel COLD (kernel-trace passes): every launch behind a 1 GiB device write, as bench.py's roofline.cold_* numbers
+    scr = torch.empty((1 << 30) // 4, dtype=torch.float32, device=dev)
+    for i in range(12):
+        scr.fill_(float(i))
+        hip.call("mat_spmv_dense_dev", A.h, 0, 0, C.c_void_p(x.data_ptr()), ncl, C.c_void_p(y.data_ptr()), m)
+        torch.cuda.synchronize()
+    print("cap", A.info(1)["capacity"], "cold launches 12")
+    sys.exit(0)
 for nx in (ncl, ncl, ncl, 0, 0, 0):
     hip.call("mat_spmv_dense_dev", A.h, 0, 0, C.c_void_p(x.data_ptr()), nx, C.c_void_p(y.data_ptr()), m)
     torch.cuda.synchronize()

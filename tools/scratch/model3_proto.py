@@ -255,7 +255,7 @@ def check_vector(dsa, oracle, n0, R, Lp, seed=1, grow_from=None):
     return m3
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and "v4" not in sys.argv:
     dsa = dsa_loader.load()
     oracle = oracle_binding.load(dsa)
     for n0, R, Lp in [(50000, 60000, 4), (90000, 40000, 7), (200000, 100000, 9)]:
@@ -263,3 +263,116 @@ if __name__ == "__main__":
     for n0, R, Lp in [(40000, 30000, 4), (40000, 30000, 99), (40000, 30000, 1), (300000, 200000, 8), (50000, 777, 6), (46000, 5, 3),
                       (46000, 14, 3), (46000, 15, 3), (46000, 16, 3), (46000, 17, 3), (700000, 100000, 8), (30000, 100000, 5)]:
         check_vector(dsa, oracle, n0, R, Lp)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# model v4: typed runs (semaphore cells) on 8-slot segments — leaf state (s, g), cross-leaf shifts, counts above
+def trailing_gaps(W, c):
+    bits = pattern(W, c)
+    nz = np.nonzero(bits)[0]
+    return W - (int(nz[-1]) + 1)
+
+
+def model4_run(geo, occ, types):
+    """types[j] = 1 for a semaphore cell; returns (suffix counts of levels >= 1 at the end, rebalances, slots, stop reason)"""
+    C, H = geo.C, geo.H
+    assert geo.seg == 8 and geo.hi[0] == 7
+    cnt = [int(occ[C - geo.W[k]:].sum()) for k in range(H + 1)]
+    leaf = occ[C - 8:]
+    s = cnt[0]
+    nz = np.nonzero(leaf)[0]
+    g = 8 - (int(nz[-1]) + 1)
+    sems = np.nonzero(types)[0].tolist() + [1 << 60]
+    sp = 0
+    t = 0
+    reb = slots = 0
+    end = len(types)
+    while True:
+        while sems[sp] < t:
+            sp += 1
+        ns = sems[sp]
+        j = 7 - s
+        cross = (s + g == 8) and ns == t + j
+        ln = 8 - s + (1 if cross else 0)
+        if t + ln > end:
+            rest = end - t
+            # the remaining ops stay inside the leaf epoch (a cross-leaf op among them would not count below its level: ignored here,
+            # the caller compares levels >= 4 only)
+            for k in range(1, H + 1):
+                cnt[k] += rest
+            return cnt, reb, slots, "end"
+        kstar = 1
+        if cross:
+            kstar = None
+            for k in range(1, H + 1):
+                if cnt[k] + j < geo.W[k] - 1:
+                    kstar = k
+                    break
+            assert kstar is not None
+        for k in range(1, H + 1):
+            cnt[k] += ln if k >= kstar else ln - 1
+        t += ln
+        kacc = None
+        for k in range(1, H + 1):
+            if geo.acc(k, cnt[k]):
+                kacc = k
+                break
+        if kacc is None:
+            return cnt, reb, slots, "extend"
+        reb += 1; slots += geo.W[kacc]
+        c = cnt[kacc]
+        for i in range(1, kacc):
+            cnt[i] = suffix_cells(geo.W[kacc], c, geo.W[i])
+        s = suffix_cells(geo.W[kacc], c, 8)
+        g = trailing_gaps(geo.W[kacc], c)
+        assert 1 <= s <= 7 and g >= 0, (kacc, c, s, g)       # g == 0: fl(E * fl(W / E)) < W puts the last gap on W - 1 and a cell on the last slot
+
+
+def check_matrix_v4(dsa, oracle, ncols0, batches, per=16, m=5000, seed=3):
+    rng = np.random.default_rng(seed)
+    B = dsa.dynamicsparse(fill_mode=False, binding=oracle)
+    col = 0
+
+    def make(ncols):
+        nonlocal col
+        I, J = [], []
+        for _ in range(ncols):
+            col += 1
+            n = per if per > 0 else int(rng.integers(1, 20))
+            rows = sorted(rng.choice(m, size=n, replace=False) + 1)
+            I += [int(r) for r in rows]; J += [col] * n
+        return np.array(I, dtype=np.int64), np.array(J, dtype=np.int64)
+    I, J = make(ncols0)
+    B.set_batch(I, J, np.ones(len(I)))
+    for nb in batches:
+        L0 = B.export_layout(0)
+        info = L0["info"]
+        geo = Geo(info["capacity"], info["segment_capacity"], info["height"])
+        I, J = make(nb)
+        types = []
+        last = None
+        for j in J:
+            if j != last:
+                types.append(1); last = j
+            types.append(0)
+        types = np.array(types, dtype=np.uint8)
+        cnt, reb, slots, why = model4_run(geo, L0["occ"], types)
+        B.set_batch(I, J, np.ones(len(I)))
+        L1 = B.export_layout(0)
+        if L1["info"]["capacity"] != info["capacity"]:
+            print("  batch of %d columns: extend inside (model said %s) — skipped" % (nb, why))
+            continue
+        occ1 = L1["occ"]
+        real = [int(occ1[geo.C - geo.W[k]:].sum()) for k in range(geo.H + 1)]
+        assert real[4:] == cnt[4:], ("counts", real, cnt)
+        dreb = L1["info"]["stat_rebalances"] - info["stat_rebalances"]
+        dslots = L1["info"]["stat_window_slots"] - info["stat_window_slots"]
+        assert (dreb, dslots) == (reb, slots), ("stats", dreb, reb, dslots, slots)
+        print("  v4: batch of %d columns (%d cells) on cap %d ok: %d rebalances, %d slots" % (nb, len(types), geo.C, reb, slots))
+
+
+if __name__ == "__main__" and "v4" in sys.argv:
+    dsa = dsa_loader.load()
+    oracle = oracle_binding.load(dsa)
+    check_matrix_v4(dsa, oracle, 6000, [500, 1000, 300, 1000], per=16)
+    check_matrix_v4(dsa, oracle, 9000, [700, 1000, 1000], per=0)
