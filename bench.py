@@ -173,6 +173,16 @@ def main():
             dist.init_process_group(backend="nccl", device_id=dev)
         else:
             dist.init_process_group(backend=backend)
+        # start-up self-check: every rank is there and they agree on the world — a sum of ones over the group must give WORLD_SIZE on
+        # every rank (a rank that joined a different rendezvous, or a collective that silently degenerates, shows up here and not as
+        # a wrong throughput); the result is printed in the line as `rccl_ranks`
+        chk = torch.ones(1, dtype=torch.int64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(chk)
+        ranks_seen = int(chk.item())
+        if ranks_seen != world:
+            raise SystemExit(f"rank {rank}: the process group answers with {ranks_seen} ranks, WORLD_SIZE says {world}")
+    else:
+        ranks_seen = 1
 
     import dsa_loader
     dsa = dsa_loader.load()
@@ -190,7 +200,23 @@ def main():
     I, J, V = c3_triplets(m, ncl, per, col0, seed_rows=seeds[0], seed_vals=seeds[1])
     # the shard is the reference-layout PCSR of its own sub-matrix: local column keys 1..ncl (only this rank's columns are generated)
     t0 = time.time()
-    abi_comm = sharding.AbiComm(hip, rank, world) if (world > 1 and args.collective == "abi" and args.schedule == "all_reduce") else None
+    abi_comm = None
+    collective_note = None
+    if world > 1 and args.collective == "abi" and args.schedule == "all_reduce":
+        # every rank must take the same path: the outcome of the (collective) communicator set-up is agreed on before it is used
+        try:
+            abi_comm = sharding.AbiComm(hip, rank, world)
+            ok_local = 1
+        except Exception as e:
+            ok_local = 0
+            collective_note = "ABI communicator failed on rank %d (%s): torch.distributed all_reduce instead" % (rank, str(e)[:120])
+        okt = torch.tensor([ok_local], dtype=torch.int64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        if int(okt.item()) == 0:
+            if abi_comm is not None:
+                abi_comm.close()
+            abi_comm = None
+            collective_note = collective_note or "ABI communicator failed on another rank: torch.distributed all_reduce instead"
     shard = sharding.ColumnShard(dsa, I, np.ascontiguousarray(J - col0), V, m, n_total, rank, world, binding=hip, device=dev,
                                  local_columns=True, comm=abi_comm)      # bulk build of both orientations on the device (incl. the H2D of I, J, V)
     build_s = time.time() - t0
@@ -278,6 +304,7 @@ def main():
         "value": round(value, 2),
         "unit": "GB/s",
         "n_gpus": world,
+        "rccl_ranks": ranks_seen,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 5),
@@ -306,6 +333,8 @@ def main():
         "nnz_per_s": round(world * nnz / (ms_per_step / 1e3), 1),
         "build_s": round(build_s, 3),
     }
+    if collective_note:
+        out["config"]["collective_note"] = collective_note
     if cold_us is not None:
         out["roofline"]["cold_kernel_ms"] = round(cold_us / 1e3, 5)
         out["roofline"]["cold_frac"] = round(bytes_launch / 1e3 / cold_us / HBM_PEAK_GBS, 4)

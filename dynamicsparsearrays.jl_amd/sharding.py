@@ -55,9 +55,15 @@ class AbiComm:
         idb = None
         if world > 1 or with_rccl:
             buf = (C.c_uint8 * 128)()
+            err = None
             if rank == 0:
-                binding.call("comm_unique_id", buf)
-            raw = bytes(buf) if rank == 0 else None
+                # a failure here (no librccl.so) must reach EVERY rank: the others are about to wait for the id, so rank 0 hands them
+                # the error text instead of leaving them in the broadcast
+                try:
+                    binding.call("comm_unique_id", buf)
+                except Exception as e:              # noqa: BLE001 — re-raised on every rank below
+                    err = "rank 0: %s" % e
+            raw = (bytes(buf) if err is None else err.encode()) if rank == 0 else None
             if world > 1:
                 if bcast is None:
                     import torch.distributed as dist
@@ -66,6 +72,8 @@ class AbiComm:
                     raw = box[0]
                 else:
                     raw = bcast(raw)
+            if raw is None or len(raw) != 128:
+                raise RuntimeError("no RCCL unique id: %s" % (raw.decode(errors="replace") if raw else "rank 0 sent nothing"))
             idb = (C.c_uint8 * 128).from_buffer_copy(raw)
         self.h = C.c_void_p()
         binding.call("comm_init", rank, world, idb, C.byref(self.h))      # collective over the ranks

@@ -7,6 +7,7 @@ import socket
 import sys
 
 import numpy as np
+import pytest
 import torch.multiprocessing as mp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -85,3 +86,62 @@ def test_column_sharded_spmv_world2(dsa, oracle, tmp_path):
         cover += list(range(c0 + 1, c0 + nc + 1))
     assert cover == list(range(1, n + 1))
     assert sharding.owner_of_column(400, world, n) == 1 and sharding.owner_of_column(2, world, n) == 0
+
+
+def test_abi_communicator_rank_plumbing_with_a_stub_library_and_a_stub_broadcast(dsa):
+    """sharding.AbiComm without a GPU: the id is drawn on rank 0 only, handed to the other ranks through `bcast` (MPI.Bcast from Julia,
+    torch.distributed's object broadcast in bench.py), and every rank calls comm_init(rank, world, the SAME 128 bytes); a rank 0 that
+    cannot load RCCL hands the error to the others instead of leaving them in the broadcast.  The library is a stub that records
+    the calls; the real calls run in tests/test_hip_parity.py::test_abi_communicator_world_1_rccl_smoke on the GPU."""
+    import ctypes as C
+    from dsa_amd import sharding
+
+    class Stub:
+        def __init__(self, fail_id=False):
+            self.calls, self.fail_id = [], fail_id
+
+        def call(self, name, *args):
+            if name == "comm_unique_id":
+                if self.fail_id:
+                    raise RuntimeError("ERCCL: librccl.so not found")
+                for i in range(128):
+                    args[0][i] = (7 * i + 3) % 256
+            elif name == "comm_init":
+                rank, world, idb, out = args
+                self.calls.append(("comm_init", rank, world, bytes(idb) if idb is not None else None))
+                C.cast(out, C.POINTER(C.c_void_p))[0] = C.c_void_p(0x1000 + rank)
+                return
+            self.calls.append((name,))
+
+    wire = {}
+
+    def bcast_from(rank):
+        def f(raw):
+            if rank == 0:
+                wire["id"] = raw
+            return wire["id"]
+        return f
+
+    world = 4
+    stubs = [Stub() for _ in range(world)]
+    comms = [sharding.AbiComm(stubs[r], r, world, bcast=bcast_from(r)) for r in range(world)]      # rank 0 first, as a broadcast orders it
+    expect = bytes((7 * i + 3) % 256 for i in range(128))
+    for r in range(world):
+        inits = [c for c in stubs[r].calls if c[0] == "comm_init"]
+        assert inits == [("comm_init", r, world, expect)], (r, stubs[r].calls)
+        assert (("comm_unique_id",) in stubs[r].calls) == (r == 0)
+        assert comms[r].h.value == 0x1000 + r
+        comms[r].close()
+        assert ("comm_destroy",) in stubs[r].calls and not comms[r].h
+    # world 1 without RCCL: no id, a communicator without a collective behind it
+    s1 = Stub()
+    c1 = sharding.AbiComm(s1, 0, 1, with_rccl=False)
+    assert s1.calls == [("comm_init", 0, 1, None)]
+    c1.close()
+    # rank 0 cannot draw the id: every rank raises, nobody calls comm_init
+    wire.clear()
+    bad = [Stub(fail_id=(r == 0)) for r in range(2)]
+    for r in range(2):
+        with pytest.raises(RuntimeError, match="no RCCL unique id"):
+            sharding.AbiComm(bad[r], r, 2, bcast=bcast_from(r))
+        assert not [c for c in bad[r].calls if c[0] == "comm_init"]
