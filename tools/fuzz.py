@@ -190,6 +190,74 @@ def run_shared_words(seed):
     return "ok"
 
 
+def run_append_models(seed):
+    """Targeted stress of the count-only append replay (csrc/appendmodel.hip): structures BUILT from data (16-slot segments: the
+    geometry on which typed runs — semaphore cells of new columns — are count-only too) or grown from a few keys (small segments),
+    then append runs of random lengths around the model's minimum (512), across extends, interleaved with random writes, deletes
+    and column deletions that leave tombstones and ragged tails; layouts, tables and rebalance statistics after every batch."""
+    g = SplitMix64(seed)
+    if g.next() % 2 == 0:
+        n0 = [3, 200, 50000, 90000, 400000][g.next() % 5]
+        grown = g.next() % 2 == 0 and n0 >= 50000
+        keys0 = np.arange(1, n0 + 1, dtype=np.int64) * 3
+        first = 3 if grown else n0
+        a = dsa.dynamicsparsevec(keys0[:first], np.ones(first), binding=hip)
+        b = dsa.dynamicsparsevec(keys0[:first], np.ones(first), binding=ora)
+        if grown:
+            a.set_batch(keys0[first:], np.ones(n0 - first)); b.set_batch(keys0[first:], np.ones(n0 - first))
+        top = int(keys0[-1])
+        for step in range(3 + g.next() % 5):
+            r = [300, 511, 512, 513, 3000, 40000, 150000][g.next() % 7]
+            ks = top + np.cumsum(1 + (np.array([g.next() for _ in range(r)], dtype=np.uint64) % np.uint64(3)).astype(np.int64))
+            top = int(ks[-1])
+            pre = np.array([keys0[g.next() % n0], top - 1], dtype=np.int64)          # a breaker in front, an update behind
+            kk = np.concatenate([pre[:1], ks, pre[1:]]); vv = np.concatenate([[0.0 if g.next() % 2 else 2.5], np.full(r, 1.5), [3.5]])
+            a.set_batch(kk, vv); b.set_batch(kk, vv)
+            ka, kb = a.export_layout(), b.export_layout()
+            assert np.array_equal(ka[2], kb[2]), (seed, step, "occ")
+            occ = ka[2].astype(bool)
+            assert np.array_equal(ka[0][occ], kb[0][occ]) and np.array_equal(ka[1][occ], kb[1][occ]), (seed, step, "cells")
+            ia, ib = a.info(), b.info()
+            for k in ("capacity", "stat_extends", "stat_rebalances", "stat_window_slots"):
+                assert ia[k] == ib[k], (seed, step, k, ia[k], ib[k])
+        return "ok"
+    m = [2000, 40000][g.next() % 2]
+    n0 = [3000, 12000][g.next() % 2]
+    I0, J0 = [], []
+    for j in range(1, n0 + 1):
+        for i in sorted({1 + int(g.next() % m) for _ in range(1 + g.next() % 10)}):
+            I0.append(i); J0.append(j)
+    V0 = 1.0 + np.arange(len(I0)) % 9 / 8.0
+    a = dsa.dynamicsparse(I0, J0, V0, binding=hip)
+    b = dsa.dynamicsparse(I0, J0, V0, binding=ora)
+    col = n0
+    for step in range(3 + g.next() % 4):
+        ncols = [40, 60, 700, 5000][g.next() % 4]
+        maxlen = [1, 8, 40][g.next() % 3]
+        I, J = [], []
+        for _ in range(ncols):
+            col += 1
+            for i in sorted({1 + int(g.next() % m) for _ in range(1 + g.next() % maxlen)}):
+                I.append(i); J.append(col)
+        V = 1.0 + np.arange(len(I)) % 7 / 8.0
+        if g.next() % 3 == 0:                 # a write to an old column in front: the run starts behind it
+            I.insert(0, 1 + int(g.next() % m)); J.insert(0, 1 + int(g.next() % n0)); V = np.concatenate([[2.25], V])
+        a.set_batch(I, J, V); b.set_batch(I, J, V)
+        mat_equal(a, b, (seed, step, "append batch"))
+        for o in (0, 1):
+            ia, ib = a.info(o), b.info(o)
+            for k in ("stat_extends", "stat_rebalances", "stat_window_slots"):
+                assert ia[k] == ib[k], (seed, step, o, k, ia[k], ib[k])
+        if g.next() % 2 == 0:                 # delete an older column (never the last: the reference's crash path is a documented divergence)
+            jd = 1 + int(g.next() % (col - 1))
+            try:
+                a.deletecolumn(jd); b.deletecolumn(jd)
+            except dsa.DsaError:
+                pass
+            mat_equal(a, b, (seed, step, "deletecolumn"))
+    return "ok"
+
+
 if __name__ == "__main__":
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
@@ -197,7 +265,10 @@ if __name__ == "__main__":
     n = 0
     res = {}
     while time.time() - t0 < budget:
-        r = run_shared_words(seed) if seed % 8 == 5 else (run_matrix(seed) if seed % 4 else run_vector(seed))
+        if os.environ.get("FUZZ_ONLY") == "append":      # soak of the append-replay scenario alone
+            r = run_append_models(seed)
+        else:
+            r = run_shared_words(seed) if seed % 8 == 5 else (run_append_models(seed) if seed % 8 == 3 else (run_matrix(seed) if seed % 4 else run_vector(seed)))
         res[r] = res.get(r, 0) + 1
         n += 1
         seed += 1
