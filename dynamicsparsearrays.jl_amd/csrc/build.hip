@@ -29,8 +29,6 @@
 #include <cstring>
 #include <mutex>
 #include <vector>
-#include <rocprim/device/device_radix_sort.hpp>
-#include <rocprim/device/device_scan.hpp>
 
 namespace dsa {
 
@@ -439,14 +437,63 @@ __global__ void k_emit_sems(const uint64_t* __restrict__ comp, int kbits, int64_
     out_vals[pos] = (double)p;
 }
 
-// ---- general path (composite wider than 64 bits): two stable 64-bit library sorts carrying the input index ----------------
-__global__ void k_iota(uint32_t* idx, int64_t n) {
-    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (i < n) idx[i] = (uint32_t)i;
+// ---- general path (composite wider than 64 bits): TWO runs of the stable radix sort above, each over 64-bit digits' worth of one
+// component, carrying the input index as the 8-byte payload — by key first, then (stable) by partition: (partition, key, input order),
+// the order the single composite sort produces.  (Round 3 called a library sort here.)
+__global__ void k_wide_key0(const int64_t* __restrict__ key, int64_t kmin, uint64_t* __restrict__ comp, double* __restrict__ payload, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        comp[i] = (uint64_t)key[i] - (uint64_t)kmin;                 // order-preserving: the range fits 64 bits
+        payload[i] = __longlong_as_double((long long)i);              // (moved as raw bits, never computed on)
+    }
 }
-__global__ void k_gather_i64(const int64_t* __restrict__ src, const uint32_t* __restrict__ idx, int64_t* __restrict__ dst, int64_t n) {
-    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (i < n) dst[i] = src[idx[i]];
+// the composites of the second run, in the order the first one left: partition of the element behind each payload
+__global__ void k_wide_part(const int64_t* __restrict__ part, int64_t pmin, const double* __restrict__ payload, uint64_t* __restrict__ comp, int64_t n) {
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x)
+        comp[j] = (uint64_t)part[__double_as_longlong(payload[j])] - (uint64_t)pmin;
+}
+// sorted order -> input index, key and partition of every element
+__global__ void k_wide_finish(const int64_t* __restrict__ part, const int64_t* __restrict__ key, const double* __restrict__ payload,
+                              uint32_t* __restrict__ idx, int64_t* __restrict__ k2, int64_t* __restrict__ p2, int64_t n) {
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = __double_as_longlong(payload[j]);
+        idx[j] = (uint32_t)i;
+        k2[j] = key[i];
+        if (part != nullptr) p2[j] = part[i];
+    }
+}
+// inclusive prefix sums of the two flag arrays: per-tile sums (k_bf_scan turns them into tile offsets and totals), then the tiles
+__global__ __launch_bounds__(RS_BLOCK) void k_flag_tile_sums(const uint32_t* __restrict__ fpart, const uint32_t* __restrict__ fcell, int64_t n,
+                                                             uint32_t* __restrict__ cnt_c, uint32_t* __restrict__ cnt_p) {
+    __shared__ uint32_t sC[RS_WAVES], sP[RS_WAVES];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int64_t tile0 = (int64_t)blockIdx.x * RS_TILE;
+    uint32_t c = 0, p = 0;
+    for (int j = 0; j < RS_ITEMS; ++j) {
+        const int64_t i = tile0 + (int64_t)j * RS_BLOCK + tid;
+        if (i < n) { c += fcell[i]; p += fpart[i]; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { c += __shfl_xor(c, o, 64); p += __shfl_xor(p, o, 64); }
+    if (lane == 0) { sC[wv] = c; sP[wv] = p; }
+    __syncthreads();
+    if (tid == 0) { cnt_c[blockIdx.x] = sC[0] + sC[1] + sC[2] + sC[3]; cnt_p[blockIdx.x] = sP[0] + sP[1] + sP[2] + sP[3]; }
+}
+__global__ __launch_bounds__(RS_BLOCK) void k_flag_scan_apply(const uint32_t* __restrict__ fpart, const uint32_t* __restrict__ fcell, int64_t n,
+                                                              const uint32_t* __restrict__ off_c, const uint32_t* __restrict__ off_p,
+                                                              uint32_t* __restrict__ spart, uint32_t* __restrict__ scell) {
+    __shared__ uint32_t sW[RS_WAVES];
+    const int tid = threadIdx.x;
+    const int64_t tile0 = (int64_t)blockIdx.x * RS_TILE;
+    uint32_t run_c = off_c[blockIdx.x], run_p = off_p[blockIdx.x];
+    for (int j = 0; j < RS_ITEMS; ++j) {                       // RS_BLOCK consecutive elements per step
+        const int64_t i = tile0 + (int64_t)j * RS_BLOCK + tid;
+        const uint32_t fc = i < n ? fcell[i] : 0u, fp = i < n ? fpart[i] : 0u;
+        uint32_t tc, tp;
+        const uint32_t ec = bld_block_excl_scan(fc, sW, &tc);
+        const uint32_t ep = bld_block_excl_scan(fp, sW, &tp);
+        if (i < n) { scell[i] = run_c + ec + fc; spart[i] = run_p + ep + fp; }
+        run_c += tc; run_p += tp;
+    }
 }
 __global__ void k_flags(const int64_t* __restrict__ part, const int64_t* __restrict__ key, uint32_t* __restrict__ fpart,
                         uint32_t* __restrict__ fcell, int64_t n) {
@@ -520,7 +567,8 @@ static void free_scratch(BuildScratch& s) {
 
 static int bit_width_u64(uint64_t x) { int b = 0; while (x) { ++b; x >>= 1; } return b; }
 
-static hipError_t prepare_wide(const int64_t* d_part, const int64_t* d_key, int64_t nnz, BuildScratch& s, int64_t counts[2], hipStream_t stream);
+static hipError_t prepare_wide(const int64_t* d_part, const int64_t* d_key, int64_t nnz, BuildScratch& s, int64_t counts[2], hipStream_t stream,
+                               int64_t kmin, int kbits, int64_t pmin, int pbits);
 
 // value ranges and reserved-key check of two key arrays that are already in HBM (a and b: rows and columns of a triple stream): one
 // pass on the device instead of a host loop over arrays the host would otherwise not touch at all; synchronises the stream
@@ -648,9 +696,11 @@ hipError_t build_prepare(const int64_t* d_part, const int64_t* d_key, const doub
     s.kbits = std::max(1, bit_width_u64((uint64_t)key_range.hi - (uint64_t)key_range.lo));
     s.pbits = d_part ? bit_width_u64((uint64_t)part_range.hi - (uint64_t)part_range.lo) : 0;
     if (s.kbits + s.pbits > 64 || force_wide) {
+        const int64_t kmin = s.kmin, pmin = s.pmin;
+        const int kbits = s.kbits, pbits = s.pbits;
         free_scratch(s);
         s.n = nnz; s.stream = stream; s.wide_path = true;
-        return prepare_wide(d_part, d_key, nnz, s, counts, stream);
+        return prepare_wide(d_part, d_key, nnz, s, counts, stream, kmin, kbits, pmin, pbits);
     }
     // ---- the sort: passes over bits [0, kbits + pbits)
     static PerDeviceOnce once;
@@ -712,47 +762,64 @@ void build_abort(BuildScratch& s) {
 }
 
 // ---- general path, host side ----
-static hipError_t prepare_wide(const int64_t* d_part, const int64_t* d_key, int64_t nnz, BuildScratch& s, int64_t counts[2], hipStream_t stream) {
+// one stable LSD sort of (comp, payload) over `bits` bits with the kernels of the composite path; returns the buffer index of the result
+static hipError_t wide_sort(BuildScratch& s, int& cur, int bits, int64_t nblocks, hipStream_t stream) {
+    const size_t lds_bytes = (size_t)RS_TILE * (sizeof(uint64_t) + sizeof(double));
+    const dim3 grid((unsigned)nblocks), block(RS_BLOCK);
+    const int npass = (bits + 7) / 8;
+    for (int pass = 0; pass < npass; ++pass) {
+        const int shift = 8 * pass;
+        uint32_t* dtot = s.ghist + pass * RS_BINS;
+        hipLaunchKernelGGL(k_rs_hist, grid, block, 0, stream, (const uint64_t*)s.comp[cur], s.n, shift, s.hist, nblocks);
+        hipLaunchKernelGGL(k_rs_scan, dim3(RS_BINS), block, 0, stream, s.hist, dtot, nblocks);
+        hipLaunchKernelGGL(k_rs_scatter, grid, block, lds_bytes, stream, (const uint64_t*)s.comp[cur], (const double*)s.val[cur], s.n, shift,
+                           (const uint32_t*)s.hist, (const uint32_t*)dtot, s.comp[1 - cur], s.val[1 - cur], nblocks);
+        cur = 1 - cur;
+    }
+    return hipGetLastError();
+}
+
+static hipError_t prepare_wide(const int64_t* d_part, const int64_t* d_key, int64_t nnz, BuildScratch& s, int64_t counts[2], hipStream_t stream,
+                               int64_t kmin, int kbits, int64_t pmin, int pbits) {
     const size_t n = (size_t)nnz;
-    size_t t1 = 0, t2 = 0;
-    BCHK(rocprim::radix_sort_pairs(nullptr, t1, d_key, s.k1, s.idx0, s.idx1, n, 0, 64, stream));
-    BCHK(rocprim::inclusive_scan(nullptr, t2, s.fpart, s.spart, n, rocprim::plus<uint32_t>(), stream));
-    s.temp_bytes = t1 > t2 ? t1 : t2;
+    const int64_t nblocks = (nnz + RS_TILE - 1) / RS_TILE;
+    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    BCHK(pinned_ctl_get(&s.h_ctl));
     {
-        auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
-        const size_t a4 = up(n * 4), a8 = up(n * 8);
-        BCHK(pool_alloc(&s.base, 7 * a4 + 4 * a8 + up(s.temp_bytes)));
+        const size_t a4 = up(n * 4), a8 = up(n * 8), b_ctl = up(sizeof(BuildCtl)), b_gh = up(8 * RS_BINS * 4 + 64),
+                     b_hist = up((size_t)RS_BINS * nblocks * 4), b_cnt = up((size_t)(nblocks + 1) * 4);
+        BCHK(pool_alloc(&s.base, b_ctl + b_gh + 6 * a8 + 5 * a4 + b_hist + 2 * b_cnt));
         char* q = static_cast<char*>(s.base);
         auto take = [&q](size_t b) { char* r = q; q += b; return r; };
-        s.idx0 = (uint32_t*)take(a4); s.idx1 = (uint32_t*)take(a4); s.idx2 = (uint32_t*)take(a4);
-        s.fpart = (uint32_t*)take(a4); s.fcell = (uint32_t*)take(a4); s.spart = (uint32_t*)take(a4); s.scell = (uint32_t*)take(a4);
-        s.k1 = (int64_t*)take(a8); s.p1 = (int64_t*)take(a8); s.p2 = (int64_t*)take(a8); s.k2 = (int64_t*)take(a8);
-        s.temp = take(up(s.temp_bytes));
+        s.d_ctl = take(b_ctl); s.ghist = (uint32_t*)take(b_gh);
+        s.comp[0] = (uint64_t*)take(a8); s.comp[1] = (uint64_t*)take(a8); s.val[0] = (double*)take(a8); s.val[1] = (double*)take(a8);
+        s.k2 = (int64_t*)take(a8); s.p2 = (int64_t*)take(a8);
+        s.idx2 = (uint32_t*)take(a4); s.fpart = (uint32_t*)take(a4); s.fcell = (uint32_t*)take(a4); s.spart = (uint32_t*)take(a4); s.scell = (uint32_t*)take(a4);
+        s.hist = (uint32_t*)take(b_hist); s.cnt_c = (uint32_t*)take(b_cnt); s.cnt_p = (uint32_t*)take(b_cnt);
     }
-    const unsigned blocks = (unsigned)((nnz + 255) / 256);
-    hipLaunchKernelGGL(k_iota, dim3(blocks), dim3(256), 0, stream, s.idx0, nnz);
-    size_t tb = s.temp_bytes;
-    BCHK(rocprim::radix_sort_pairs(s.temp, tb, d_key, s.k1, s.idx0, s.idx1, n, 0, 64, stream));           // by key
+    BuildCtl* dctl = static_cast<BuildCtl*>(s.d_ctl);
+    BuildCtl* hctl = static_cast<BuildCtl*>(s.h_ctl);
+    static PerDeviceOnce once;
+    const size_t lds_bytes = (size_t)RS_TILE * (sizeof(uint64_t) + sizeof(double));
+    BCHK(once.run([&] { return hipFuncSetAttribute(reinterpret_cast<const void*>(k_rs_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); }));
+    const unsigned gs = (unsigned)std::min<int64_t>((nnz + 255) / 256, 65535 * 4);
+    int cur = 0;
+    hipLaunchKernelGGL(k_wide_key0, dim3(gs), dim3(256), 0, stream, d_key, kmin, s.comp[0], s.val[0], nnz);
+    BCHK(wide_sort(s, cur, kbits, nblocks, stream));                                                        // by key
     if (d_part != nullptr) {
-        hipLaunchKernelGGL(k_gather_i64, dim3(blocks), dim3(256), 0, stream, d_part, s.idx1, s.p1, nnz);
-        tb = s.temp_bytes;
-        BCHK(rocprim::radix_sort_pairs(s.temp, tb, s.p1, s.p2, s.idx1, s.idx2, n, 0, 64, stream));       // then by partition (stable)
-        hipLaunchKernelGGL(k_gather_i64, dim3(blocks), dim3(256), 0, stream, d_key, s.idx2, s.k2, nnz);
-        hipLaunchKernelGGL(k_flags, dim3(blocks), dim3(256), 0, stream, s.p2, s.k2, s.fpart, s.fcell, nnz);
-    } else {                                                                                               // vector: keys only
-        BCHK(hipMemcpyAsync(s.idx2, s.idx1, n * 4, hipMemcpyDeviceToDevice, stream));
-        BCHK(hipMemcpyAsync(s.k2, s.k1, n * 8, hipMemcpyDeviceToDevice, stream));
-        hipLaunchKernelGGL(k_flags, dim3(blocks), dim3(256), 0, stream, (const int64_t*)nullptr, s.k2, s.fpart, s.fcell, nnz);
+        hipLaunchKernelGGL(k_wide_part, dim3(gs), dim3(256), 0, stream, d_part, pmin, (const double*)s.val[cur], s.comp[cur], nnz);
+        BCHK(wide_sort(s, cur, std::max(pbits, 1), nblocks, stream));                                       // then by partition (stable)
     }
-    tb = s.temp_bytes;
-    BCHK(rocprim::inclusive_scan(s.temp, tb, s.fpart, s.spart, n, rocprim::plus<uint32_t>(), stream));
-    tb = s.temp_bytes;
-    BCHK(rocprim::inclusive_scan(s.temp, tb, s.fcell, s.scell, n, rocprim::plus<uint32_t>(), stream));
-    uint32_t last[2] = {0, 0};
-    BCHK(hipMemcpyAsync(&last[0], s.scell + (n - 1), 4, hipMemcpyDeviceToHost, stream));
-    BCHK(hipMemcpyAsync(&last[1], s.spart + (n - 1), 4, hipMemcpyDeviceToHost, stream));
+    hipLaunchKernelGGL(k_wide_finish, dim3(gs), dim3(256), 0, stream, d_part, d_key, (const double*)s.val[cur], s.idx2, s.k2, s.p2, nnz);
+    const unsigned blocks = (unsigned)((nnz + 255) / 256);
+    hipLaunchKernelGGL(k_flags, dim3(blocks), dim3(256), 0, stream, d_part != nullptr ? (const int64_t*)s.p2 : (const int64_t*)nullptr, s.k2, s.fpart, s.fcell, nnz);
+    hipLaunchKernelGGL(k_flag_tile_sums, dim3((unsigned)nblocks), dim3(RS_BLOCK), 0, stream, (const uint32_t*)s.fpart, (const uint32_t*)s.fcell, nnz, s.cnt_c, s.cnt_p);
+    hipLaunchKernelGGL(k_bf_scan, dim3(1), dim3(1024), 0, stream, s.cnt_c, s.cnt_p, nblocks, dctl);
+    hipLaunchKernelGGL(k_flag_scan_apply, dim3((unsigned)nblocks), dim3(RS_BLOCK), 0, stream, (const uint32_t*)s.fpart, (const uint32_t*)s.fcell, nnz,
+                       (const uint32_t*)s.cnt_c, (const uint32_t*)s.cnt_p, s.spart, s.scell);
+    BCHK(hipMemcpyAsync(hctl, dctl, sizeof(BuildCtl), hipMemcpyDeviceToHost, stream));
     BCHK(hipStreamSynchronize(stream));
-    counts[0] = last[0]; counts[1] = last[1];
+    counts[0] = (int64_t)hctl->ncells; counts[1] = (int64_t)hctl->nparts;
     return hipGetLastError();
 }
 

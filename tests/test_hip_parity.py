@@ -1512,6 +1512,15 @@ def test_forced_64bit_keys_and_replay_variants_in_subprocesses(dsa, hip, oracle)
     env = dict(os.environ, DSA_LOCAL_ROUNDS="0")
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz.py"), "8", "4242"], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "fuzz done" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    # DSA_BUILD_WIDE=1: every bulk build (vectors, PackedCSC, matrices, fill-mode flushes) through the GENERAL path of K-build — two runs
+    # of the hand-written radix sort with the input index as payload, hand-written flag scans (the path composites wider than 64 bits take)
+    env = dict(os.environ, DSA_BUILD_WIDE="1")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz.py"), "10", "9090"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "fuzz done" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    # DSA_MODEL3=0: long append runs on the per-op replay alone (what the count-only model hands back: short runs, small typed segments)
+    env = dict(os.environ, DSA_MODEL3="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "appendbench.py"), "--check"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "append parity ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 @pytest.mark.gpu

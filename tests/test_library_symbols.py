@@ -45,6 +45,17 @@ def test_product_code_object_is_gfx950_only():
         assert targets and all("gfx950" in t for t in targets), targets
 
 
+def test_product_carries_no_library_sort():
+    """Every sort and scan of the bulk builder is hand-written for gfx950 (csrc/build.hip: LSD radix passes, flag scans) — also on the
+    general path for composites wider than 64 bits, which called rocPRIM until round 3: no rocprim symbol in the shared library."""
+    so = os.path.join(ROOT, "dynamicsparsearrays.jl_amd", "csrc", "libdsa_hip.so")
+    out = subprocess.run(["nm", "-C", "--defined-only", so], capture_output=True, text=True, check=True).stdout
+    assert "rocprim" not in out
+    # (the device code objects are embedded in the same file: their kernel names would show up in .hip_fatbin strings)
+    raw = open(so, "rb").read()
+    assert b"rocprim" not in raw
+
+
 def test_product_does_not_reference_the_oracle():
     """The product path must not import, link or execute anything under oracle/."""
     pkg = os.path.join(ROOT, "dynamicsparsearrays.jl_amd")

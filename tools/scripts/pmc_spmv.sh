@@ -1,11 +1,15 @@
+# usage (GPU box, repo root): bash tools/scripts/pmc_spmv.sh [tag]   -> gpurun_out/<tag>_spmv_sq_tcc_counters.json
 set -euo pipefail
+TAG=${1:-r04}
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:?set GRAFT_REPO_ROOT (the repo root on the GPU box)}
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU -d $R/gpurun_out/pmc_sq -o sq --output-format csv -- python3 $R/tools/prof_spmv.py > $R/gpurun_out/pmc_sq.log 2>&1 && \
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum -d $R/gpurun_out/pmc_tc -o tc --output-format csv -- python3 $R/tools/prof_spmv.py > $R/gpurun_out/pmc_tc.log 2>&1
-cd $R && python3 - <<'PY'
+cd $R && TAG=$TAG python3 - <<'PY'
 # per-dispatch sums of every counter for the k_spmv_gather launches: dispatches 0-2 = C3 product, 3-5 = the same with nx = 0 (stream only)
-import csv, glob, collections, json
+import csv, glob, collections, json, os, sys
+sys.path.insert(0, os.getcwd())
+import bench
 out = {}
 for d in ("gpurun_out/pmc_sq", "gpurun_out/pmc_tc"):
     rows = []
@@ -25,6 +29,7 @@ w, wi = out.get("SQ_WAVE_CYCLES", {}).get("C3_product_avg"), out.get("SQ_WAIT_IN
 if w and wi:
     out["wait_inst_any_share_of_wave_cycles"] = round(wi / w, 4)
 json.dump({"note": "rocprofv3 --pmc, two separate passes (SQ_*, TCC/TCP), k_spmv_gather on the C3 matrix; sums over all XCDs / SEs per dispatch",
-           "counters": out}, open("gpurun_out/spmv_sq_tcc_counters.json", "w"), indent=1)
+           "kernel_source_sha": bench.kernel_source_sha(),
+           "counters": out}, open("gpurun_out/%s_spmv_sq_tcc_counters.json" % os.environ.get("TAG", "r04"), "w"), indent=1)
 print(json.dumps(out, indent=1))
 PY
