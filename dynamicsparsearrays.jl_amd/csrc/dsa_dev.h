@@ -335,6 +335,8 @@ hipError_t launch_sequencer(KeyArr keys, double* vals, uint64_t* occ, int64_t* s
                             hipStream_t stream);
 // one bit per op: op j does not continue an append run from op j-1 (mode 0: vector ops, 1: MappedPackedCSC ops); n/64 + 1 words
 hipError_t launch_op_breaks(const Op* ops, int64_t n, int mode, uint64_t* breaks, hipStream_t stream);
+// the op array of a batch from its columns in HBM (a, b or nullptr, v): op k = (a[k], b[k] or 0, v[k], kind)
+hipError_t launch_make_ops(const int64_t* a, const int64_t* b, const double* v, int32_t kind, int64_t n, Op* ops, hipStream_t stream);
 // flags / d_T: cell types and cell count written by k_run_expand (MappedPackedCSC runs), nullptr for a vector run
 // saved_memo: append_run_memo_bytes() of zero-initialised device memory owned by the handle (the replay's memo survives in it from
 // run to run while the array's geometry stays the same), or nullptr

@@ -115,6 +115,7 @@ struct Pma {
     Op* d_ops = nullptr; int64_t ops_cap = 0;
     int wait_policy = g_wait_policy_default;      // how blocking calls wait for a hand-over: 0 spin on the pinned word, 1 block in hipStreamSynchronize first (dsa_*_set_wait_policy)
     uint64_t* d_breaks = nullptr; bool breaks_valid = false;      // run-break bitmap of the ops in d_ops (sequencer.hip: k_op_breaks)
+    int64_t* d_opsrc = nullptr; int64_t opsrc_cap = 0;            // the caller's columns of a batch (a, b, v: 3 x opsrc_cap x 8 B) before k_make_ops expands them
     double* d_q = nullptr; int64_t q_cap = 0;      // scratch for lookups (3 arrays of q_cap)
     int32_t* d_err = nullptr;
     int64_t stat_par_rounds = 0, stat_par_ops = 0, stat_seq_ops = 0, stat_seq_launches = 0;      // batch-parallel instrumentation
@@ -173,6 +174,7 @@ void pma_destroy(Pma& P) {
     pinned_free(P.h_ctl);
     if (P.d_ops) hipFree(P.d_ops);
     if (P.d_breaks) hipFree(P.d_breaks);
+    if (P.d_opsrc) hipFree(P.d_opsrc);
     if (P.d_q) hipFree(P.d_q);
     pool_free(P.d_err);
     burst_graph_destroy(&P.burst);
@@ -469,6 +471,23 @@ void permute_run(Pma& P, const Op* cells, int64_t i0, int64_t n0) {
     P.cur = alt;
 }
 
+// A batch of ops as the host hands it to a structure: a ready-made Op array (small batches, mixed kinds), or the caller's COLUMNS —
+// op k = (a[k], b ? b[k] : 0, v[k]) of one kind — which go up as they are (16 / 24 bytes per op instead of 32, no Op vector built on
+// the host) and are expanded into the op array by a kernel behind the upload (sequencer.hip: k_make_ops).
+struct OpBatch {
+    int64_t n = 0;
+    const Op* ops = nullptr;
+    const int64_t* a = nullptr; const int64_t* b = nullptr; const double* v = nullptr; int32_t kind = 0;
+    OpBatch() = default;
+    OpBatch(const std::vector<Op>& o) : n((int64_t)o.size()), ops(o.data()) {}      // NOLINT: implicit by design
+    OpBatch(int32_t kind_, const int64_t* a_, const int64_t* b_, const double* v_, int64_t n_) : n(n_), a(a_), b(b_), v(v_), kind(kind_) {}
+    Op at(int64_t k) const {
+        if (ops) return ops[k];
+        Op o; o.a = a[k]; o.b = b ? b[k] : 0; o.v = v[k]; o.kind = kind; o.pad = 0; return o;
+    }
+    int64_t key(int64_t k) const { return ops ? ops[k].a : a[k]; }
+};
+
 void ensure_ops(Pma& P, int64_t n) {
     P.breaks_valid = false;
     if (n <= P.ops_cap) return;
@@ -479,6 +498,26 @@ void ensure_ops(Pma& P, int64_t n) {
     HIPCHK(hipMalloc(&P.d_ops, (size_t)P.ops_cap * sizeof(Op)));
     HIPCHK(hipMalloc(&P.d_breaks, (size_t)(P.ops_cap / 64 + 8) * sizeof(uint64_t)));
 }
+// the ops of a batch into d_ops (stream-ordered; the host arrays must stay alive until the batch has finished — every batch waits)
+void upload_batch(Pma& P, const OpBatch& B) {
+    const int64_t n = B.n;
+    if (B.ops != nullptr) {
+        HIPCHK(hipMemcpyAsync(P.d_ops, B.ops, (size_t)n * sizeof(Op), hipMemcpyHostToDevice, P.stream));
+        return;
+    }
+    if (n > P.opsrc_cap) {
+        if (P.d_opsrc) hipFree(P.d_opsrc);
+        P.opsrc_cap = std::max<int64_t>(n, P.ops_cap);
+        HIPCHK(hipMalloc(&P.d_opsrc, (size_t)P.opsrc_cap * 3 * sizeof(int64_t)));
+    }
+    int64_t* da = P.d_opsrc; int64_t* db = P.d_opsrc + P.opsrc_cap; double* dv = reinterpret_cast<double*>(P.d_opsrc + 2 * P.opsrc_cap);
+    HIPCHK(hipMemcpyAsync(da, B.a, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, P.stream));
+    if (B.b) HIPCHK(hipMemcpyAsync(db, B.b, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, P.stream));
+    HIPCHK(hipMemcpyAsync(dv, B.v, (size_t)n * sizeof(double), hipMemcpyHostToDevice, P.stream));
+    hipError_t e = launch_make_ops(da, B.b ? db : nullptr, dv, B.kind, n, P.d_ops, P.stream);
+    if (e != hipSuccess) fail(DSA_EHIP, std::string("make ops launch: ") + hipGetErrorString(e));
+}
+
 // the n ops just uploaded into d_ops: where an append run cannot continue (read by the sequencer's run detection), enqueued behind the
 // upload.  Vectors and MappedPackedCSC only — a plain PackedCSC has no runs
 void enqueue_op_breaks(Pma& P, int64_t n) {
@@ -516,6 +555,17 @@ void widen_keys(Pma& P) {
     }
     for (int b = 0; b < 2; ++b) pool_free(old[b]);
     P.wide = true;
+}
+void ensure_key_width(Pma& P, const OpBatch& B) {
+    if (P.wide) return;
+    if (B.ops != nullptr) {
+        for (int64_t k = 0; k < B.n; ++k) {
+            const Op& o = B.ops[k];
+            if ((o.kind == OP_VEC_SET || o.kind == OP_PCSC_SET || o.kind == OP_MPCSC_SET) && !key_fits32(o.a)) { widen_keys(P); return; }
+        }
+        return;
+    }
+    for (int64_t k = 0; k < B.n; ++k) if (!key_fits32(B.a[k])) { widen_keys(P); return; }
 }
 void ensure_key_width(Pma& P, const std::vector<Op>& ops) {
     if (P.wide) return;
@@ -752,9 +802,9 @@ int64_t run_ops(Pma& P, const std::vector<Op>& ops, int32_t* err) {
 // Batch-parallel execution of vector writes (parbatch.hip): rounds of plan / resolve / apply for the prefix of ops whose
 // footprints are pairwise disjoint; the op that cuts a short prefix (and a growing chunk after it while prefixes stay
 // short: ascending appends, hammering one key) goes through the sequential sequencer.  Same final state as run_ops.
-int64_t run_ops_parallel(Pma& P, const std::vector<Op>& ops, int32_t* err) {
+int64_t run_ops_parallel(Pma& P, const OpBatch& ops, int32_t* err) {
     *err = 0;
-    const int64_t n = (int64_t)ops.size();
+    const int64_t n = ops.n;
     if (n == 0) return 0;
     constexpr int GMAX = ROUND_GMAX, MIN_PREFIX = 4, ROUNDS_PER_SYNC = 12, ROUNDS_SHORT = 3;
     constexpr int64_t MERGE_AT = 256;       // pending table entries (of at most 1024) that trigger the grid-wide merge between launches
@@ -762,7 +812,7 @@ int64_t run_ops_parallel(Pma& P, const std::vector<Op>& ops, int32_t* err) {
     ensure_ops(P, n);
     {
         const auto tu0 = std::chrono::steady_clock::now();
-        HIPCHK(hipMemcpyAsync(P.d_ops, ops.data(), (size_t)n * sizeof(Op), hipMemcpyHostToDevice, P.stream));
+        upload_batch(P, ops);
         enqueue_op_breaks(P, n);
         static const bool dbg_up = getenv("DSA_DBG_SPLIT") != nullptr;
         if (dbg_up) fprintf(stderr, "  [run_ops_parallel] upload of %lld ops (%.1f MB, pageable): %.3f ms on the host\n", (long long)n, n * sizeof(Op) / 1e6,
@@ -802,10 +852,10 @@ int64_t run_ops_parallel(Pma& P, const std::vector<Op>& ops, int32_t* err) {
         const int64_t probe = std::min<int64_t>(n, 256);
         seq_first = true;
         for (int64_t j = 0; j < probe && seq_first; ++j) {
-            const Op& o = ops[(size_t)j];
+            const Op o = ops.at(j);
             if (o.v == 0.0 || o.kind != (P.has_cols ? OP_MPCSC_SET : OP_VEC_SET)) seq_first = false;
             else if (j > 0) {
-                const Op& q = ops[(size_t)j - 1];
+                const Op q = ops.at(j - 1);
                 seq_first = P.has_cols ? (o.b > q.b || (o.b == q.b && o.a > q.a)) : o.a > q.a;
             }
         }
@@ -877,7 +927,7 @@ int64_t run_ops_parallel(Pma& P, const std::vector<Op>& ops, int32_t* err) {
         int64_t no_run_at = -1;
         for (;;) {
             SeqRun r;
-            r.P = &P; r.ops = &ops; r.n = std::min<int64_t>(n, i + seq_chunk); r.n_avail = n; r.active = true; r.defer_merge = true;
+            r.P = &P; r.n = std::min<int64_t>(n, i + seq_chunk); r.n_avail = n; r.active = true; r.defer_merge = true;
             P.h_ctl->next_op = i; P.h_ctl->status = 0; P.h_ctl->err = 0; P.h_ctl->no_run_at = no_run_at;
             seq_launch(r);
             while (seq_step(r)) ++n_yield;
@@ -1368,11 +1418,18 @@ Op make_op(int32_t kind, int64_t a, int64_t b, double v) { Op o; o.a = a; o.b = 
 
 // setindex! on both orientations for ops [0, n)  src/matrix.jl:53-59
 void mat_apply_sets(dsa_mat* h, const int64_t* I, const int64_t* J, const double* V, int64_t n) {
-    std::vector<Op> oc((size_t)n), orw((size_t)n);
-    for (int64_t k = 0; k < n; ++k) {
-        oc[(size_t)k] = make_op(OP_MPCSC_SET, I[k], J[k], V[k]);      // colmajor[row, col] = val
-        orw[(size_t)k] = make_op(OP_MPCSC_SET, J[k], I[k], V[k]);     // rowmajor[col, row] = val
-    }
+    // colmajor[row, col] = val / rowmajor[col, row] = val: the batch-parallel path takes the caller's columns as they are, the other
+    // branches below build the op arrays they need
+    const OpBatch bc(OP_MPCSC_SET, I, J, V, n), br(OP_MPCSC_SET, J, I, V, n);
+    std::vector<Op> oc, orw;
+    auto build_ops = [&] {
+        if (!oc.empty() || n == 0) return;
+        oc.resize((size_t)n); orw.resize((size_t)n);
+        for (int64_t k = 0; k < n; ++k) {
+            oc[(size_t)k] = make_op(OP_MPCSC_SET, I[k], J[k], V[k]);
+            orw[(size_t)k] = make_op(OP_MPCSC_SET, J[k], I[k], V[k]);
+        }
+    };
     // Without tombstones an OP_MPCSC_SET cannot fail (the reference's assert / bounds paths of addpartition! need a
     // deleted partition, App. A.6 (3)), so the two orientations can be updated concurrently; otherwise the colmajor
     // batch runs first and the rowmajor batch is cut at the failing op, like the reference's statement order.
@@ -1415,15 +1472,15 @@ void mat_apply_sets(dsa_mat* h, const int64_t* I, const int64_t* J, const double
         std::thread row_thread;
         if (side_by_side)
             row_thread = std::thread([&] {
-                try { bind_device(h->row); dr = run_ops_parallel(h->row, orw, &er); t_row_done = std::chrono::steady_clock::now(); }
+                try { bind_device(h->row); dr = run_ops_parallel(h->row, br, &er); t_row_done = std::chrono::steady_clock::now(); }
                 catch (...) { row_exc = std::current_exception(); }
             });
         const int64_t rounds0 = h->row.stat_par_rounds;
-        try { dc = run_ops_parallel(h->col, oc, &ec); }
+        try { dc = run_ops_parallel(h->col, bc, &ec); }
         catch (...) { if (row_thread.joinable()) row_thread.join(); throw; }
         const auto t1 = std::chrono::steady_clock::now();
         if (side_by_side) { row_thread.join(); if (row_exc) std::rethrow_exception(row_exc); }
-        else dr = run_ops_parallel(h->row, orw, &er);
+        else dr = run_ops_parallel(h->row, br, &er);
         if (dbg_time)
             fprintf(stderr, "[mat_apply_sets] n=%lld both orientations %.2f ms (colmajor done after %.2f ms, rowmajor after %.2f ms)  colmajor (par %lld seq %lld ext %lld)  "
                     "rowmajor (par %lld seq %lld ext %lld rounds +%lld)\n", (long long)n,
@@ -1450,6 +1507,7 @@ void mat_apply_sets(dsa_mat* h, const int64_t* I, const int64_t* J, const double
         if (er) fail(er, err_text(er));
         return;
     }
+    build_ops();
     if (no_tombstones && h->col.stream != h->row.stream) {
         // A small batch (a column or a few that arrive together, a row): the orientation in which its writes fall into MANY
         // partitions takes the local rounds (one wave per op: k_local_rounds), the one in which they share a few partitions — writes
@@ -1722,11 +1780,15 @@ static void vec_flush(dsa_vec_t* h) {
     vec_apply(h, k.data(), v.data(), (int64_t)k.size());
 }
 static void vec_apply(dsa_vec_t* h, const int64_t* keys, const double* vals, int64_t n) {
-    std::vector<Op> ops((size_t)n);
-    for (int64_t i = 0; i < n; ++i) ops[(size_t)i] = make_op(OP_VEC_SET, keys[i], 0, vals[i]);
     int32_t err = 0;
     static const bool par = [] { const char* e = getenv("DSA_PARBATCH"); return !(e && e[0] == '0'); }();
-    const int64_t done = (par && n >= 128) ? run_ops_parallel(h->P, ops, &err) : run_ops(h->P, ops, &err);
+    int64_t done;
+    if (par && n >= 128) done = run_ops_parallel(h->P, OpBatch(OP_VEC_SET, keys, nullptr, vals, n), &err);      // the caller's columns go up as they are
+    else {
+        std::vector<Op> ops((size_t)n);
+        for (int64_t i = 0; i < n; ++i) ops[(size_t)i] = make_op(OP_VEC_SET, keys[i], 0, vals[i]);
+        done = run_ops(h->P, ops, &err);
+    }
     const int64_t upto = err ? std::min(done + 1, n) : done;          // v.n is updated before the write (src/vector.jl:77-79)
     for (int64_t i = 0; i < upto; ++i) if (vals[i] != 0.0) h->n = std::max(h->n, keys[i]);
     if (err) fail(err, err_text(err));

@@ -352,6 +352,19 @@ __global__ __launch_bounds__(256) void k_op_breaks(const Op* ops, int64_t n, int
     const uint64_t b = __ballot(bad);
     if ((threadIdx.x & 63) == 0) breaks[j >> 6] = b;
 }
+// the op array of a batch from the caller's columns (uploaded as they are): op k = (a[k], b ? b[k] : 0, v[k], kind)
+__global__ __launch_bounds__(256) void k_make_ops(const int64_t* __restrict__ a, const int64_t* __restrict__ b, const double* __restrict__ v,
+                                                  int32_t kind, int64_t n, Op* __restrict__ ops) {
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (int64_t)gridDim.x * 256) {
+        Op o; o.a = a[k]; o.b = b != nullptr ? b[k] : 0; o.v = v[k]; o.kind = kind; o.pad = 0;
+        ops[k] = o;
+    }
+}
+hipError_t launch_make_ops(const int64_t* a, const int64_t* b, const double* v, int32_t kind, int64_t n, Op* ops, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_make_ops, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 65536)), dim3(256), 0, stream, a, b, v, kind, n, ops);
+    return hipGetLastError();
+}
 hipError_t launch_op_breaks(const Op* ops, int64_t n, int mode, uint64_t* breaks, hipStream_t stream) {
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_op_breaks, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, ops, n, mode, breaks);
