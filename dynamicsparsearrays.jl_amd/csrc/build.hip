@@ -106,8 +106,11 @@ __global__ __launch_bounds__(256) void k_minmax(const int64_t* __restrict__ part
 __device__ __forceinline__ int64_t rs_index(int64_t tile0, int wv, int j, int lane) { return tile0 + (int64_t)wv * RS_PER_WAVE + j * 64 + lane; }
 
 // composites from (partition, key) + the histogram of the first pass: hist[d * nblocks + b]
+// ibits > 0: the element's input index rides in the low ibits bits of the word (composite << ibits | index): the sort then moves
+// 8-byte words only — no value payload, values are gathered by index when the cells are emitted — and, being stable over the
+// composite's bits alone (shift starts at ibits), keeps equal composites in input order
 __global__ __launch_bounds__(RS_BLOCK) void k_comp_hist(const int64_t* __restrict__ part, const int64_t* __restrict__ key, int64_t n,
-                                                        int64_t pmin, int64_t kmin, int kbits, uint64_t* __restrict__ comp,
+                                                        int64_t pmin, int64_t kmin, int kbits, int ibits, uint64_t* __restrict__ comp,
                                                         int shift, uint32_t* __restrict__ hist, int64_t nblocks) {
     __shared__ uint32_t h[RS_BINS];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -127,6 +130,7 @@ __global__ __launch_bounds__(RS_BLOCK) void k_comp_hist(const int64_t* __restric
         if (i < n) {
             uint64_t c = (uint64_t)kk[j] - (uint64_t)kmin;
             if (part != nullptr) c |= ((uint64_t)pp[j] - (uint64_t)pmin) << kbits;
+            if (ibits > 0) c = (c << ibits) | (uint64_t)i;
             comp[i] = c;
             atomicAdd(&h[(c >> shift) & (RS_BINS - 1)], 1u);
         }
@@ -195,6 +199,7 @@ __global__ __launch_bounds__(RS_BLOCK) void k_rs_scan(uint32_t* __restrict__ his
     if (tid == 0) tot[d] = total;
 }
 
+template <bool HAS_VAL>
 __global__ __launch_bounds__(RS_BLOCK) void k_rs_scatter(const uint64_t* __restrict__ in_key, const double* __restrict__ in_val, int64_t n, int shift,
                                                          const uint32_t* __restrict__ gbase, const uint32_t* __restrict__ dtot,
                                                          uint64_t* __restrict__ out_key, double* __restrict__ out_val, int64_t nblocks) {
@@ -213,7 +218,7 @@ __global__ __launch_bounds__(RS_BLOCK) void k_rs_scatter(const uint64_t* __restr
         const int64_t i = rs_index(tile0, wv, j, lane);
         const bool valid = i < n;
         k[j] = valid ? __builtin_nontemporal_load(in_key + i) : ~0ull;
-        v[j] = valid ? __builtin_nontemporal_load(in_val + i) : 0.0;
+        v[j] = (HAS_VAL && valid) ? __builtin_nontemporal_load(in_val + i) : 0.0;
     }
     __syncthreads();
     // ranks inside the wave, per digit, in element order: lanes with the same digit find each other with 8 ballots; the lowest
@@ -251,7 +256,8 @@ __global__ __launch_bounds__(RS_BLOCK) void k_rs_scatter(const uint64_t* __restr
         if (rs_index(tile0, wv, j, lane) < n) {
             const uint32_t d = (uint32_t)(k[j] >> shift) & (RS_BINS - 1);
             const uint32_t p = sStart[d] + sCnt[wv][d] + r[j];
-            sKey[p] = k[j]; sVal[p] = v[j];
+            sKey[p] = k[j];
+            if (HAS_VAL) sVal[p] = v[j];
         }
     }
     __syncthreads();
@@ -259,16 +265,17 @@ __global__ __launch_bounds__(RS_BLOCK) void k_rs_scatter(const uint64_t* __restr
     for (int i = tid; i < count; i += RS_BLOCK) {
         const uint64_t kk = sKey[i];
         const uint32_t g = sBase[(uint32_t)(kk >> shift) & (RS_BINS - 1)] + (uint32_t)i;
-        out_key[g] = kk; out_val[g] = sVal[i];
+        out_key[g] = kk;
+        if (HAS_VAL) out_val[g] = sVal[i];
     }
 }
 
 // ---- flags, counts, emit ---------------------------------------------------------------------------------------------
 // new-cell / new-partition flags of one element from its predecessor in the sorted order
 struct BfFlags { uint64_t fc, fp; };      // ballots over the wave's 64 elements of one iteration
-__device__ __forceinline__ BfFlags bf_flags(const uint64_t* __restrict__ comp, int64_t i, int64_t n, uint64_t cur, int kbits, bool has_part, int lane) {
+__device__ __forceinline__ BfFlags bf_flags(const uint64_t* __restrict__ comp, int64_t i, int64_t n, uint64_t cur, int kbits, bool has_part, int lane, int ibits) {
     uint64_t prev = __shfl_up(cur, 1, 64);
-    if (lane == 0 && i > 0 && i < n) prev = comp[i - 1];
+    if (lane == 0 && i > 0 && i < n) prev = comp[i - 1] >> ibits;
     const bool valid = i < n;
     const bool fc = valid && (i == 0 || cur != prev);
     const bool fp = valid && (i == 0 || (has_part && (cur >> kbits) != (prev >> kbits)));
@@ -276,7 +283,7 @@ __device__ __forceinline__ BfFlags bf_flags(const uint64_t* __restrict__ comp, i
     return f;
 }
 
-__global__ __launch_bounds__(RS_BLOCK) void k_bf_count(const uint64_t* __restrict__ comp, int64_t n, int kbits, int has_part,
+__global__ __launch_bounds__(RS_BLOCK) void k_bf_count(const uint64_t* __restrict__ comp, int64_t n, int kbits, int ibits, int has_part,
                                                        uint32_t* __restrict__ cnt_c, uint32_t* __restrict__ cnt_p) {
     __shared__ uint32_t sC[RS_WAVES], sP[RS_WAVES];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -285,8 +292,8 @@ __global__ __launch_bounds__(RS_BLOCK) void k_bf_count(const uint64_t* __restric
 #pragma unroll 4
     for (int j = 0; j < RS_ITEMS; ++j) {
         const int64_t i = rs_index(tile0, wv, j, lane);
-        const uint64_t cur = i < n ? comp[i] : 0ull;
-        const BfFlags f = bf_flags(comp, i, n, cur, kbits, has_part != 0, lane);
+        const uint64_t cur = i < n ? comp[i] >> ibits : 0ull;
+        const BfFlags f = bf_flags(comp, i, n, cur, kbits, has_part != 0, lane, ibits);
         c += (uint32_t)popc64(f.fc); p += (uint32_t)popc64(f.fp);
     }
     if (lane == 0) { sC[wv] = c; sP[wv] = p; }
@@ -325,7 +332,8 @@ __device__ __forceinline__ double bld_combine(double a, double b, int32_t combin
 
 // mode 0: mapped partitions (ids = rank of the distinct partition keys, semaphore emitted by the first cell of a partition)
 // mode 1: plain vector (no semaphores)   mode 2: explicit partition ids 1..P (semaphores by k_emit_sems)
-__global__ __launch_bounds__(RS_BLOCK) void k_bf_emit(const uint64_t* __restrict__ comp, const double* __restrict__ val, int64_t n, int kbits,
+// ibits > 0: the words are composite << ibits | input index and `val` is the caller's value array (gathered by index)
+__global__ __launch_bounds__(RS_BLOCK) void k_bf_emit(const uint64_t* __restrict__ comp, const double* __restrict__ val, int64_t n, int kbits, int ibits,
                                                       int64_t pmin, int64_t kmin, int mode, int32_t combine,
                                                       const uint32_t* __restrict__ off_c, const uint32_t* __restrict__ off_p,
                                                       KeyArr out_keys, double* __restrict__ out_vals, int64_t* __restrict__ part_keys,
@@ -335,19 +343,21 @@ __global__ __launch_bounds__(RS_BLOCK) void k_bf_emit(const uint64_t* __restrict
     const int64_t tile0 = (int64_t)blockIdx.x * RS_TILE;
     const bool has_part = mode != 1;
     const uint64_t kmask = kbits >= 64 ? ~0ull : ((1ull << kbits) - 1ull);
+    const uint64_t imask = ibits > 0 ? ((1ull << ibits) - 1ull) : 0ull;
     uint64_t cur[RS_ITEMS], fcb[RS_ITEMS], fpb[RS_ITEMS];
     double vj[RS_ITEMS];
     uint32_t c = 0, p = 0;
 #pragma unroll
     for (int j = 0; j < RS_ITEMS; ++j) {
         const int64_t i = rs_index(tile0, wv, j, lane);
-        cur[j] = i < n ? __builtin_nontemporal_load(comp + i) : 0ull;
-        vj[j] = i < n ? __builtin_nontemporal_load(val + i) : 0.0;
+        const uint64_t w = i < n ? __builtin_nontemporal_load(comp + i) : 0ull;
+        cur[j] = w >> ibits;
+        vj[j] = i < n ? (ibits > 0 ? val[w & imask] : __builtin_nontemporal_load(val + i)) : 0.0;
     }
 #pragma unroll
     for (int j = 0; j < RS_ITEMS; ++j) {
         const int64_t i = rs_index(tile0, wv, j, lane);
-        const BfFlags f = bf_flags(comp, i, n, cur[j], kbits, has_part, lane);
+        const BfFlags f = bf_flags(comp, i, n, cur[j], kbits, has_part, lane, ibits);
         fcb[j] = f.fc; fpb[j] = f.fp;
         c += (uint32_t)popc64(f.fc); p += (uint32_t)popc64(f.fp);
     }
@@ -362,7 +372,7 @@ __global__ __launch_bounds__(RS_BLOCK) void k_bf_emit(const uint64_t* __restrict
         const uint32_t rank = rc + (uint32_t)popc64(fcb[j] & le);            // 1-based rank of the cell this element belongs to
         const uint32_t pidr = rp + (uint32_t)popc64(fpb[j] & le);            // 1-based rank of its partition
         uint64_t nxt = __shfl_down(cur[j], 1, 64);
-        if (lane == 63) nxt = i + 1 < n ? comp[i + 1] : ~cur[j];
+        if (lane == 63) nxt = i + 1 < n ? comp[i + 1] >> ibits : ~cur[j];
         if (i + 1 >= n) nxt = ~cur[j];
         if (i < n) {
             if (scell != nullptr) scell[i] = rank;
@@ -376,8 +386,10 @@ __global__ __launch_bounds__(RS_BLOCK) void k_bf_emit(const uint64_t* __restrict
                 if (nxt == cc) {                                  // duplicates: left fold in input order  src/pcsr.jl:374-375
                     int64_t t = i + 1;
                     int len = 1;
-                    while (t < n && len < FOLD_INLINE && comp[t] == cc) { acc = bld_combine(acc, val[t], combine); ++t; ++len; }
-                    if (t < n && len == FOLD_INLINE && comp[t] == cc) {      // a long run: a wave finishes it (k_fold_long)
+                    while (t < n && len < FOLD_INLINE && (comp[t] >> ibits) == cc) {
+                        acc = bld_combine(acc, ibits > 0 ? val[comp[t] & imask] : val[t], combine); ++t; ++len;
+                    }
+                    if (t < n && len == FOLD_INLINE && (comp[t] >> ibits) == cc) {      // a long run: a wave finishes it (k_fold_long)
                         const unsigned long long q = atomicAdd(&ctl->nlong, 1ull);
                         LongRun lr; lr.next = t; lr.pos = pos; lr.acc = acc; lr.comp = cc;
                         queue[q] = lr;
@@ -397,8 +409,9 @@ __global__ __launch_bounds__(RS_BLOCK) void k_bf_emit(const uint64_t* __restrict
 }
 
 // the rest of the duplicate runs longer than FOLD_INLINE: one wave per run, 64 values per coalesced load, folded in order
-__global__ __launch_bounds__(64) void k_fold_long(const uint64_t* __restrict__ comp, const double* __restrict__ val, int64_t n, int32_t combine,
+__global__ __launch_bounds__(64) void k_fold_long(const uint64_t* __restrict__ comp, const double* __restrict__ val, int64_t n, int ibits, int32_t combine,
                                                   const BuildCtl* ctl, const LongRun* __restrict__ queue, double* __restrict__ out_vals) {
+    const uint64_t imask = ibits > 0 ? ((1ull << ibits) - 1ull) : 0ull;
     const int lane = threadIdx.x;
     const unsigned long long nl = ctl->nlong;
     for (unsigned long long q = blockIdx.x; q < nl; q += gridDim.x) {
@@ -407,8 +420,9 @@ __global__ __launch_bounds__(64) void k_fold_long(const uint64_t* __restrict__ c
         int64_t t = lr.next;
         while (true) {
             const int64_t i = t + lane;
-            const bool same = i < n && comp[i] == lr.comp;
-            const double v = same ? val[i] : 0.0;
+            const uint64_t w = i < n ? comp[i] : 0ull;
+            const bool same = i < n && (w >> ibits) == lr.comp;
+            const double v = same ? (ibits > 0 ? val[w & imask] : val[i]) : 0.0;
             const uint64_t b = __ballot(same);
             const int cnt = b == ~0ull ? 64 : __ffsll((unsigned long long)~b) - 1;      // leading run of equal composites
             for (int l = 0; l < cnt; ++l) acc = bld_combine(acc, __shfl(v, l, 64), combine);
@@ -421,14 +435,14 @@ __global__ __launch_bounds__(64) void k_fold_long(const uint64_t* __restrict__ c
 
 // mode 2: semaphore cell of every partition p = 1..P (empty partitions included, src/pcsr.jl:36-41):
 // position = (#distinct cells of partitions < p) + p - 1
-__global__ void k_emit_sems(const uint64_t* __restrict__ comp, int kbits, int64_t pmin, const uint32_t* __restrict__ scell, int64_t n,
+__global__ void k_emit_sems(const uint64_t* __restrict__ comp, int kbits, int ibits, int64_t pmin, const uint32_t* __restrict__ scell, int64_t n,
                             int64_t nparts, KeyArr out_keys, double* __restrict__ out_vals) {
     const int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x + 1;
     if (p > nparts) return;
     int64_t lo = 0, hi = n;                     // first index with part >= p
     while (lo < hi) {
         const int64_t mid = (lo + hi) >> 1;
-        const int64_t pm = (int64_t)((kbits >= 64 ? 0ull : (comp[mid] >> kbits)) + (uint64_t)pmin);
+        const int64_t pm = (int64_t)((kbits >= 64 ? 0ull : ((comp[mid] >> ibits) >> kbits)) + (uint64_t)pmin);
         if (pm < p) lo = mid + 1; else hi = mid;
     }
     const int64_t cells_before = lo == 0 ? 0 : (int64_t)scell[lo - 1];
@@ -702,30 +716,38 @@ hipError_t build_prepare(const int64_t* d_part, const int64_t* d_key, const doub
         s.n = nnz; s.stream = stream; s.wide_path = true;
         return prepare_wide(d_part, d_key, nnz, s, counts, stream, kmin, kbits, pmin, pbits);
     }
-    // ---- the sort: passes over bits [0, kbits + pbits)
+    // ---- the sort: passes over bits [0, kbits + pbits).  When composite + input index fit one 64-bit word the passes move 8-byte
+    //      words without a payload (half the bytes, half the LDS per tile) and the values are gathered by index at the emit
     static PerDeviceOnce once;
     const size_t lds_bytes = (size_t)RS_TILE * (sizeof(uint64_t) + sizeof(double));
-    BCHK(once.run([&] { return hipFuncSetAttribute(reinterpret_cast<const void*>(k_rs_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); }));
+    BCHK(once.run([&] { return hipFuncSetAttribute(reinterpret_cast<const void*>(k_rs_scatter<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); }));
     const int total_bits = s.kbits + s.pbits;
+    static const bool idx_sort = [] { const char* e = getenv("DSA_BUILD_IDXSORT"); return !(e && e[0] == '0'); }();      // dev knob: 0 = always carry the values
+    const int ibits_need = std::max(1, bit_width_u64((uint64_t)(nnz - 1)));
+    s.ibits = (idx_sort && total_bits + ibits_need <= 64) ? ibits_need : 0;
     const int npass = (total_bits + 7) / 8;
     const dim3 grid((unsigned)nblocks), block(RS_BLOCK);
     int cur = 0;                                    // comp[cur] holds the current order; values: d_val before the first scatter
     const double* vin = d_val;
     for (int pass = 0; pass < npass; ++pass) {
-        const int shift = 8 * pass;
+        const int shift = s.ibits + 8 * pass;
         uint32_t* dtot = s.ghist + pass * RS_BINS;
-        if (pass == 0) hipLaunchKernelGGL(k_comp_hist, grid, block, 0, stream, s.pbits > 0 ? d_part : (const int64_t*)nullptr, d_key, nnz, s.pmin, s.kmin, s.kbits, s.comp[0], shift, s.hist, nblocks);
+        if (pass == 0) hipLaunchKernelGGL(k_comp_hist, grid, block, 0, stream, s.pbits > 0 ? d_part : (const int64_t*)nullptr, d_key, nnz, s.pmin, s.kmin, s.kbits, s.ibits, s.comp[0], shift, s.hist, nblocks);
         else hipLaunchKernelGGL(k_rs_hist, grid, block, 0, stream, (const uint64_t*)s.comp[cur], nnz, shift, s.hist, nblocks);
         hipLaunchKernelGGL(k_rs_scan, dim3(RS_BINS), block, 0, stream, s.hist, dtot, nblocks);
-        hipLaunchKernelGGL(k_rs_scatter, grid, block, lds_bytes, stream, (const uint64_t*)s.comp[cur], vin, nnz, shift, (const uint32_t*)s.hist,
-                           (const uint32_t*)dtot, s.comp[1 - cur], s.val[1 - cur], nblocks);
+        if (s.ibits > 0)
+            hipLaunchKernelGGL(k_rs_scatter<false>, grid, block, (size_t)RS_TILE * sizeof(uint64_t), stream, (const uint64_t*)s.comp[cur], (const double*)nullptr, nnz, shift,
+                               (const uint32_t*)s.hist, (const uint32_t*)dtot, s.comp[1 - cur], (double*)nullptr, nblocks);
+        else
+            hipLaunchKernelGGL(k_rs_scatter<true>, grid, block, lds_bytes, stream, (const uint64_t*)s.comp[cur], vin, nnz, shift, (const uint32_t*)s.hist,
+                               (const uint32_t*)dtot, s.comp[1 - cur], s.val[1 - cur], nblocks);
         cur = 1 - cur;
-        vin = s.val[cur];
+        if (s.ibits == 0) vin = s.val[cur];
     }
     s.sorted = cur;
-    s.vsorted = vin;
+    s.vsorted = vin;                                // (ibits > 0: still the caller's array)
     // ---- flags: per-tile counts of new cells / new partitions, their prefixes, the totals
-    hipLaunchKernelGGL(k_bf_count, grid, block, 0, stream, (const uint64_t*)s.comp[cur], nnz, s.kbits, d_part ? 1 : 0, s.cnt_c, s.cnt_p);
+    hipLaunchKernelGGL(k_bf_count, grid, block, 0, stream, (const uint64_t*)s.comp[cur], nnz, s.kbits, s.ibits, d_part ? 1 : 0, s.cnt_c, s.cnt_p);
     hipLaunchKernelGGL(k_bf_scan, dim3(1), dim3(1024), 0, stream, s.cnt_c, s.cnt_p, nblocks, dctl);
     BCHK(hipMemcpyAsync(hctl, dctl, sizeof(BuildCtl), hipMemcpyDeviceToHost, stream));
     BCHK(hipStreamSynchronize(stream));
@@ -742,13 +764,13 @@ hipError_t build_emit(const double* d_val, int32_t combine, BuildScratch& s, Key
     const int64_t nblocks = (s.n + RS_TILE - 1) / RS_TILE;
     BuildCtl* dctl = static_cast<BuildCtl*>(s.d_ctl);
     const uint64_t* comp = s.comp[s.sorted];
-    hipLaunchKernelGGL(k_bf_emit, dim3((unsigned)nblocks), dim3(RS_BLOCK), 0, stream, comp, s.vsorted, s.n, s.kbits, s.pmin, s.kmin, mode, combine,
+    hipLaunchKernelGGL(k_bf_emit, dim3((unsigned)nblocks), dim3(RS_BLOCK), 0, stream, comp, s.vsorted, s.n, s.kbits, s.ibits, s.pmin, s.kmin, mode, combine,
                        (const uint32_t*)s.cnt_c, (const uint32_t*)s.cnt_p, out_keys, out_vals, part_keys, mode == 2 ? s.scell : (uint32_t*)nullptr,
                        dctl, static_cast<LongRun*>(s.queue));
-    hipLaunchKernelGGL(k_fold_long, dim3(256), dim3(64), 0, stream, comp, s.vsorted, s.n, combine, (const BuildCtl*)dctl,
+    hipLaunchKernelGGL(k_fold_long, dim3(256), dim3(64), 0, stream, comp, s.vsorted, s.n, s.ibits, combine, (const BuildCtl*)dctl,
                        (const LongRun*)s.queue, out_vals);
     if (mode == 2 && nparts_explicit > 0)
-        hipLaunchKernelGGL(k_emit_sems, dim3((unsigned)((nparts_explicit + 255) / 256)), dim3(256), 0, stream, comp, s.kbits, s.pmin,
+        hipLaunchKernelGGL(k_emit_sems, dim3((unsigned)((nparts_explicit + 255) / 256)), dim3(256), 0, stream, comp, s.kbits, s.ibits, s.pmin,
                            (const uint32_t*)s.scell, s.n, nparts_explicit, out_keys, out_vals);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(stream);
@@ -772,7 +794,7 @@ static hipError_t wide_sort(BuildScratch& s, int& cur, int bits, int64_t nblocks
         uint32_t* dtot = s.ghist + pass * RS_BINS;
         hipLaunchKernelGGL(k_rs_hist, grid, block, 0, stream, (const uint64_t*)s.comp[cur], s.n, shift, s.hist, nblocks);
         hipLaunchKernelGGL(k_rs_scan, dim3(RS_BINS), block, 0, stream, s.hist, dtot, nblocks);
-        hipLaunchKernelGGL(k_rs_scatter, grid, block, lds_bytes, stream, (const uint64_t*)s.comp[cur], (const double*)s.val[cur], s.n, shift,
+        hipLaunchKernelGGL(k_rs_scatter<true>, grid, block, lds_bytes, stream, (const uint64_t*)s.comp[cur], (const double*)s.val[cur], s.n, shift,
                            (const uint32_t*)s.hist, (const uint32_t*)dtot, s.comp[1 - cur], s.val[1 - cur], nblocks);
         cur = 1 - cur;
     }
@@ -801,7 +823,7 @@ static hipError_t prepare_wide(const int64_t* d_part, const int64_t* d_key, int6
     BuildCtl* hctl = static_cast<BuildCtl*>(s.h_ctl);
     static PerDeviceOnce once;
     const size_t lds_bytes = (size_t)RS_TILE * (sizeof(uint64_t) + sizeof(double));
-    BCHK(once.run([&] { return hipFuncSetAttribute(reinterpret_cast<const void*>(k_rs_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); }));
+    BCHK(once.run([&] { return hipFuncSetAttribute(reinterpret_cast<const void*>(k_rs_scatter<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); }));
     const unsigned gs = (unsigned)std::min<int64_t>((nnz + 255) / 256, 65535 * 4);
     int cur = 0;
     hipLaunchKernelGGL(k_wide_key0, dim3(gs), dim3(256), 0, stream, d_key, kmin, s.comp[0], s.val[0], nnz);

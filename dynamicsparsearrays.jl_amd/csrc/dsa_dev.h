@@ -304,6 +304,7 @@ struct BuildScratch {
     uint64_t* comp[2] = {nullptr, nullptr}; double* val[2] = {nullptr, nullptr};
     void* queue = nullptr;
     int64_t kmin = 0, pmin = 0; int kbits = 0, pbits = 0, sorted = 0; const double* vsorted = nullptr;
+    int ibits = 0;                                           // > 0: the sorted words are composite << ibits | input index, values are gathered from the caller's array
     // general path (composite wider than 64 bits)
     bool wide_path = false;
     uint32_t *idx0 = nullptr, *idx1 = nullptr, *idx2 = nullptr, *fpart = nullptr, *fcell = nullptr, *spart = nullptr, *scell = nullptr;
