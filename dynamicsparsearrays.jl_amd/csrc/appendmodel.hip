@@ -29,7 +29,7 @@ namespace {
 
 constexpr int M3_THREADS = 1024;
 constexpr int M3_X_ENTRIES = 10240, M3_V_ENTRIES = 5120;        // dynamic LDS: X 80 KB + one level of V 40 KB + the step of every V entry 20 KB
-constexpr int M3_MAX_TABLE_W = 16384;                           // (16-bit times in the entries)
+constexpr int M3_MAX_TABLE_W = 65536;                           // (16-bit times in the entries: checked when they are packed)
 constexpr int64_t M3_MIN_RUN = 512;                             // shorter runs: the per-op replay is cheaper than filling the tables
 
 // entry: [15:0] appends  [31:16] rebalances  [63:32] window slots
@@ -101,7 +101,10 @@ __device__ __forceinline__ int m3_descent(const M3Lane& L, int cnt, const uint64
 // event (k, c): the counts of the levels below k in closed form (lane <-> level); false: the last leaf lost its preconditions
 __device__ __forceinline__ bool m3_reset_below(const M3Lane& L, int& cnt, int k, int c, int lane, int maxc0) {
     const int Wk = rl(L.W, k);
-    const SpreadGeom g = make_geom(Wk, c);
+    SpreadGeom g;                                           // make_geom(Wk, c); E / W — only gaps_le's starting guess — by a multiply
+    g.W = Wk; g.E = Wk - c;                                 // (W is a power of two: exact either way)
+    g.f = g.E > 0 ? (double)Wk / (double)(Wk - c) : 0.0;
+    g.inv_f = (double)(Wk - c) * (1.0 / (double)Wk);
     if (lane < k) cnt = m3_suffix_cells(g, Wk, L.W);
     const int c0 = rl(cnt, 0);
     return c0 >= 1 && c0 <= maxc0;

@@ -305,11 +305,10 @@ struct BuildScratch {
     void* queue = nullptr;
     int64_t kmin = 0, pmin = 0; int kbits = 0, pbits = 0, sorted = 0; const double* vsorted = nullptr;
     int ibits = 0;                                           // > 0: the sorted words are composite << ibits | input index, values are gathered from the caller's array
-    // general path (composite wider than 64 bits)
+    // general path (composite wider than 64 bits): sorted input index, keys and partitions, flags and their inclusive prefix sums
     bool wide_path = false;
-    uint32_t *idx0 = nullptr, *idx1 = nullptr, *idx2 = nullptr, *fpart = nullptr, *fcell = nullptr, *spart = nullptr, *scell = nullptr;
-    int64_t *k1 = nullptr, *p1 = nullptr, *p2 = nullptr, *k2 = nullptr;
-    void* temp = nullptr; size_t temp_bytes = 0;
+    uint32_t *idx2 = nullptr, *fpart = nullptr, *fcell = nullptr, *spart = nullptr, *scell = nullptr;
+    int64_t *p2 = nullptr, *k2 = nullptr;
 };
 // bounds of the values of a key array (closed; need not be tight): they fix how many bits of the composite are sorted.  The host has
 // seen every key it uploads (it scans them for their storage width anyway); unknown() ranges cost one min / max pass on the device.
