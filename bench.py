@@ -642,7 +642,8 @@ def extras(dsa, hip, torch, A, dev):
     capF = F.info(dsa.COLMAJOR)["capacity"] + F.info(dsa.ROWMAJOR)["capacity"]
     fill["closefillmode_stream_bound_ms"] = round((24 * len(I3) + 16 * capF) / (HBM_PEAK_GBS * 1e9) * 1e3, 4)
     fill["closefillmode_frac_of_stream_bound"] = round(fill["closefillmode_stream_bound_ms"] / fill["closefillmode_ms"], 4)
-    fill["kbuild"] = "hand-written LSD radix sort of a (partition, key) composite over its significant bits: 5 passes of 8 bits at this size (csrc/build.hip)"
+    fill["kbuild"] = ("hand-written LSD radix sort of (partition, key) composite << 24 | input index: 5 passes of 8 bits over 8-byte words at this size, "
+                      "values gathered by index at the emit (csrc/build.hip)")
     del F
     res["buffered_writes"] = fill
     # --- inserts ON the 10 M-nnz PCSR itself (what BASELINE's metric names): 100 k uniformly random A[i, j] = v, then 10 k NEW columns
