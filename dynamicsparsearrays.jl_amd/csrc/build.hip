@@ -101,6 +101,45 @@ __global__ __launch_bounds__(256) void k_minmax(const int64_t* __restrict__ part
     }
 }
 
+// the same ranges for a STREAM of triples that arrives in pieces (the device-resident fill buffer): every piece is folded into five
+// running words acc = {amin, amax, bmin, bmax, zero flags} behind its upload — a handful of workgroups, one atomic per workgroup and
+// word — so that closefillmode! finds the ranges of everything appended without another pass over 160 MB of keys
+__global__ __launch_bounds__(256) void k_minmax_acc(const int64_t* __restrict__ a, const int64_t* __restrict__ b, int64_t n, long long* __restrict__ acc) {
+    __shared__ long long sM[4][4];
+    __shared__ unsigned int sZ;
+    long long m[4] = {INT64_MAX, INT64_MIN, INT64_MAX, INT64_MIN};
+    unsigned int z = 0;
+    if (threadIdx.x == 0) sZ = 0u;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const long long x = a[i], y = b[i];
+        m[0] = x < m[0] ? x : m[0]; m[1] = x > m[1] ? x : m[1];
+        m[2] = y < m[2] ? y : m[2]; m[3] = y > m[3] ? y : m[3];
+        if (x == 0) z |= 1u;
+        if (y == 0) z |= 2u;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const long long t = __shfl_xor(m[q], o, 64); m[q] = (q & 1) ? (t > m[q] ? t : m[q]) : (t < m[q] ? t : m[q]); }
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) for (int q = 0; q < 4; ++q) sM[wv][q] = m[q];
+    if (z) atomicOr(&sZ, z);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) for (int q = 0; q < 4; ++q) m[q] = (q & 1) ? (sM[w][q] > m[q] ? sM[w][q] : m[q]) : (sM[w][q] < m[q] ? sM[w][q] : m[q]);
+        atomicMin(acc + 0, m[0]); atomicMax(acc + 1, m[1]); atomicMin(acc + 2, m[2]); atomicMax(acc + 3, m[3]);
+        if (sZ) atomicOr(reinterpret_cast<unsigned long long*>(acc + 4), (unsigned long long)sZ);
+    }
+}
+hipError_t launch_key_scan_acc(const int64_t* d_a, const int64_t* d_b, int64_t n, long long* d_acc, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    const unsigned blocks = (unsigned)std::min<int64_t>((n + 4095) / 4096, 64);
+    hipLaunchKernelGGL(k_minmax_acc, dim3(blocks), dim3(256), 0, stream, d_a, d_b, n, d_acc);
+    return hipGetLastError();
+}
+
 // ---- the radix pass ---------------------------------------------------------------------------------------------------
 // element order inside a tile: wave w owns RS_PER_WAVE consecutive elements, iteration j of the wave 64 consecutive ones
 __device__ __forceinline__ int64_t rs_index(int64_t tile0, int wv, int j, int lane) { return tile0 + (int64_t)wv * RS_PER_WAVE + j * 64 + lane; }

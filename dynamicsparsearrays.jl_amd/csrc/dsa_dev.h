@@ -315,6 +315,9 @@ struct BuildScratch {
 struct KeyRange { int64_t lo = 0, hi = -1; bool known() const { return hi >= lo; } };
 hipError_t device_key_scan(const int64_t* d_a, const int64_t* d_b, int64_t n, KeyRange* ra, KeyRange* rb, bool* a_zero, bool* b_zero,
                            hipStream_t stream);
+// the same for a stream that arrives in pieces: folds n more entries into d_acc = {a min, a max, b min, b max, zero flags} (5 x int64 in
+// HBM, initialised to {INT64_MAX, INT64_MIN, INT64_MAX, INT64_MIN, 0}); stream-ordered, no host wait
+hipError_t launch_key_scan_acc(const int64_t* d_a, const int64_t* d_b, int64_t n, long long* d_acc, hipStream_t stream);
 // phase 1: sort by (partition, key, input order), flags, counts; counts[0] = distinct cells, counts[1] = partitions
 hipError_t build_prepare(const int64_t* d_part, const int64_t* d_key, const double* d_val, int64_t nnz, KeyRange part_range, KeyRange key_range,
                          BuildScratch& s, int64_t counts[2], hipStream_t stream);

@@ -1279,10 +1279,14 @@ struct FillBuffer {
     int64_t* hI[2] = {nullptr, nullptr}; int64_t* hJ[2] = {nullptr, nullptr}; double* hV[2] = {nullptr, nullptr};
     hipEvent_t uploaded[2] = {nullptr, nullptr};
     bool in_flight[2] = {false, false};
+    static constexpr int64_t PIECE = 1 << 18;            // a chunk goes up in pieces of this many triples, behind the memcpy that stages them
     int cur = 0;
     int64_t fill = 0;                                     // triples in the current pinned chunk
+    int64_t sent = 0;                                     // ... of which already on their way to HBM
     int64_t *dI = nullptr, *dJ = nullptr; double* dV = nullptr;
     int64_t dcap = 0, dlen = 0;                           // triples allocated / resident in HBM
+    long long* d_acc = nullptr;                           // running value ranges of the resident triples (build.hip: k_minmax_acc), 5 words
+    long long* h_acc = nullptr;                           // pinned read-back of them
     hipStream_t stream = nullptr;
     int64_t length = 0;
     int device = 0;
@@ -1317,6 +1321,7 @@ static void fill_release(FillBuffer& b) {
         if (b.uploaded[k]) hipEventDestroy(b.uploaded[k]);
     }
     pool_free(b.dI); pool_free(b.dJ); pool_free(b.dV);
+    pool_free(b.d_acc); pinned_free(b.h_acc);
     if (b.stream) stream_put(b.stream, b.device);
     b = FillBuffer();
 }
@@ -2151,6 +2156,14 @@ static void fill_init(FillBuffer& b) {
         if (g_fill_cache.hI[0] != nullptr && g_fill_cache.device == b.device)
             for (int k = 0; k < 2; ++k) { b.hI[k] = g_fill_cache.hI[k]; b.hJ[k] = g_fill_cache.hJ[k]; b.hV[k] = g_fill_cache.hV[k]; g_fill_cache.hI[k] = nullptr; g_fill_cache.hJ[k] = nullptr; g_fill_cache.hV[k] = nullptr; }
     }
+    {
+        void* p = nullptr;
+        HIPCHK(pool_alloc(&p, 64)); b.d_acc = static_cast<long long*>(p);
+        HIPCHK(pinned_alloc(&p, 64)); b.h_acc = static_cast<long long*>(p);
+        b.h_acc[0] = INT64_MAX; b.h_acc[1] = INT64_MIN; b.h_acc[2] = INT64_MAX; b.h_acc[3] = INT64_MIN; b.h_acc[4] = 0;
+        HIPCHK(hipMemcpyAsync(b.d_acc, b.h_acc, 5 * sizeof(long long), hipMemcpyHostToDevice, b.stream));
+        HIPCHK(hipStreamSynchronize(b.stream));             // (h_acc is reused as the read-back target)
+    }
     for (int k = 0; k < 2; ++k) {
         HIPCHK(hipEventCreateWithFlags(&b.uploaded[k], hipEventDisableTiming));
         if (b.hI[k]) continue;
@@ -2159,33 +2172,45 @@ static void fill_init(FillBuffer& b) {
         HIPCHK(hipHostMalloc(&b.hV[k], (size_t)FillBuffer::CHUNK * sizeof(double), hipHostMallocDefault));
     }
 }
-// ships the current pinned chunk (b.fill triples) to HBM, asynchronously; the other chunk becomes current
-static void fill_upload_chunk(FillBuffer& b) {
+// ships what is staged in the current pinned chunk and not yet sent (triples [b.sent, b.fill)) to HBM, asynchronously; a chunk that
+// is full (or `finish`: the end of a batch) is closed — its event recorded — and the other chunk becomes current.  Pieces go up
+// while the caller's memcpy fills the rest of the chunk, so that closefillmode! waits for one piece (6 MB), not for a chunk (24 MB).
+static void fill_upload_chunk(FillBuffer& b, bool finish = true) {
     if (b.fill == 0) return;
     HIPCHK(hipSetDevice(b.device));
-    if (b.dlen + b.fill > b.dcap) {          // grow geometrically: new arrays, device-to-device copy of what is resident
-        const int64_t ncap = std::max<int64_t>(2 * b.dcap, std::max<int64_t>(b.dlen + b.fill, 4 * FillBuffer::CHUNK));
-        int64_t *nI = nullptr, *nJ = nullptr; double* nV = nullptr;
-        HIPCHK(pool_alloc(reinterpret_cast<void**>(&nI), (size_t)ncap * sizeof(int64_t)));
-        HIPCHK(pool_alloc(reinterpret_cast<void**>(&nJ), (size_t)ncap * sizeof(int64_t)));
-        HIPCHK(pool_alloc(reinterpret_cast<void**>(&nV), (size_t)ncap * sizeof(double)));
-        if (b.dlen > 0) {
-            HIPCHK(hipMemcpyAsync(nI, b.dI, (size_t)b.dlen * sizeof(int64_t), hipMemcpyDeviceToDevice, b.stream));
-            HIPCHK(hipMemcpyAsync(nJ, b.dJ, (size_t)b.dlen * sizeof(int64_t), hipMemcpyDeviceToDevice, b.stream));
-            HIPCHK(hipMemcpyAsync(nV, b.dV, (size_t)b.dlen * sizeof(double), hipMemcpyDeviceToDevice, b.stream));
+    const int64_t npiece = b.fill - b.sent;
+    if (npiece > 0) {
+        if (b.dlen + npiece > b.dcap) {          // grow geometrically: new arrays, device-to-device copy of what is resident
+            const int64_t ncap = std::max<int64_t>(2 * b.dcap, std::max<int64_t>(b.dlen + npiece, 4 * FillBuffer::CHUNK));
+            int64_t *nI = nullptr, *nJ = nullptr; double* nV = nullptr;
+            HIPCHK(pool_alloc(reinterpret_cast<void**>(&nI), (size_t)ncap * sizeof(int64_t)));
+            HIPCHK(pool_alloc(reinterpret_cast<void**>(&nJ), (size_t)ncap * sizeof(int64_t)));
+            HIPCHK(pool_alloc(reinterpret_cast<void**>(&nV), (size_t)ncap * sizeof(double)));
+            if (b.dlen > 0) {
+                HIPCHK(hipMemcpyAsync(nI, b.dI, (size_t)b.dlen * sizeof(int64_t), hipMemcpyDeviceToDevice, b.stream));
+                HIPCHK(hipMemcpyAsync(nJ, b.dJ, (size_t)b.dlen * sizeof(int64_t), hipMemcpyDeviceToDevice, b.stream));
+                HIPCHK(hipMemcpyAsync(nV, b.dV, (size_t)b.dlen * sizeof(double), hipMemcpyDeviceToDevice, b.stream));
+            }
+            HIPCHK(hipStreamSynchronize(b.stream));       // earlier uploads into the old arrays have landed
+            pool_free(b.dI); pool_free(b.dJ); pool_free(b.dV);
+            b.dI = nI; b.dJ = nJ; b.dV = nV; b.dcap = ncap;
         }
-        HIPCHK(hipStreamSynchronize(b.stream));       // earlier uploads into the old arrays have landed
-        pool_free(b.dI); pool_free(b.dJ); pool_free(b.dV);
-        b.dI = nI; b.dJ = nJ; b.dV = nV; b.dcap = ncap;
+        const int c = b.cur;
+        HIPCHK(hipMemcpyAsync(b.dI + b.dlen, b.hI[c] + b.sent, (size_t)npiece * sizeof(int64_t), hipMemcpyHostToDevice, b.stream));
+        HIPCHK(hipMemcpyAsync(b.dJ + b.dlen, b.hJ[c] + b.sent, (size_t)npiece * sizeof(int64_t), hipMemcpyHostToDevice, b.stream));
+        HIPCHK(hipMemcpyAsync(b.dV + b.dlen, b.hV[c] + b.sent, (size_t)npiece * sizeof(double), hipMemcpyHostToDevice, b.stream));
+        {   // the value ranges of the piece, folded into the running ones behind its upload
+            hipError_t e = launch_key_scan_acc(b.dI + b.dlen, b.dJ + b.dlen, npiece, b.d_acc, b.stream);
+            if (e != hipSuccess) fail(DSA_EHIP, std::string("key range launch: ") + hipGetErrorString(e));
+        }
+        b.dlen += npiece;
+        b.sent = b.fill;
     }
+    if (!finish && b.fill < FillBuffer::CHUNK) return;
     const int c = b.cur;
-    HIPCHK(hipMemcpyAsync(b.dI + b.dlen, b.hI[c], (size_t)b.fill * sizeof(int64_t), hipMemcpyHostToDevice, b.stream));
-    HIPCHK(hipMemcpyAsync(b.dJ + b.dlen, b.hJ[c], (size_t)b.fill * sizeof(int64_t), hipMemcpyHostToDevice, b.stream));
-    HIPCHK(hipMemcpyAsync(b.dV + b.dlen, b.hV[c], (size_t)b.fill * sizeof(double), hipMemcpyHostToDevice, b.stream));
     HIPCHK(hipEventRecord(b.uploaded[c], b.stream));
     b.in_flight[c] = true;
-    b.dlen += b.fill;
-    b.fill = 0;
+    b.fill = 0; b.sent = 0;
     b.cur = 1 - c;
     if (b.in_flight[b.cur]) { HIPCHK(hipEventSynchronize(b.uploaded[b.cur])); b.in_flight[b.cur] = false; }   // its pinned memory is free again
 }
@@ -2194,17 +2219,17 @@ static void fill_append(FillBuffer& b, const int64_t* I, const int64_t* J, const
     fill_init(b);
     int64_t k = 0;
     while (k < n) {
-        const int64_t room = FillBuffer::CHUNK - b.fill;
+        const int64_t room = std::min(FillBuffer::CHUNK - b.fill, FillBuffer::PIECE - (b.fill - b.sent));      // up to the end of the chunk / of the piece
         const int64_t take = std::min(room, n - k);
         std::memcpy(b.hI[b.cur] + b.fill, I + k, (size_t)take * sizeof(int64_t));
         std::memcpy(b.hJ[b.cur] + b.fill, J + k, (size_t)take * sizeof(int64_t));
         std::memcpy(b.hV[b.cur] + b.fill, V + k, (size_t)take * sizeof(double));
         b.fill += take; k += take;
-        if (b.fill == FillBuffer::CHUNK) fill_upload_chunk(b);
+        if (b.fill == FillBuffer::CHUNK || b.fill - b.sent >= FillBuffer::PIECE) fill_upload_chunk(b, false);
     }
     // a batch of appends has ended: what is staged goes up now (asynchronously), so that closefillmode! finds almost nothing left
     // in pinned memory — single-element appends (setindex! in fill mode) only ship whole quarter chunks
-    if (b.fill >= (n > 1 ? FillBuffer::EAGER : FillBuffer::CHUNK / 4)) fill_upload_chunk(b);
+    if (b.fill - b.sent >= (n > 1 ? FillBuffer::EAGER : FillBuffer::CHUNK / 4)) fill_upload_chunk(b, false);
     b.length += n;
 }
 
@@ -2289,20 +2314,20 @@ int32_t dsa_mat_closefillmode(dsa_mat_t* h) {     // closefillmode!  src/matrix.
     bool wr = false, wc = false;
     static const bool dbg_time = getenv("DSA_DBG_TIME") != nullptr;
     const auto tc0 = std::chrono::steady_clock::now();
+    // value ranges of everything appended (K-build's composite, the storage width of the keys): every uploaded piece was folded into
+    // five running words on the device (k_minmax_acc) — they come back with the wait for the last piece; the appends themselves never
+    // look at a key twice
+    KeyRange rows, cols;
     if (b.stream) {
         fill_upload_chunk(b);
+        HIPCHK(hipMemcpyAsync(b.h_acc, b.d_acc, 5 * sizeof(long long), hipMemcpyDeviceToHost, b.stream));
         HIPCHK(hipStreamSynchronize(b.stream));
         nnz = b.dlen;
-    }
-    // value ranges of everything appended (K-build's composite, the storage width of the keys): one pass on the device over the
-    // resident triples — the appends themselves never look at a key twice
-    KeyRange rows, cols;
-    if (nnz > 0) {
-        bool zr = false, zc = false;
-        hipError_t e = device_key_scan(b.dI, b.dJ, nnz, &rows, &cols, &zr, &zc, b.stream);
-        if (e != hipSuccess) fail(DSA_EHIP, std::string("key scan: ") + hipGetErrorString(e));
-        wr = g_force_wide || !(key_fits32(rows.lo) && key_fits32(rows.hi));
-        wc = g_force_wide || !(key_fits32(cols.lo) && key_fits32(cols.hi));
+        if (nnz > 0) {
+            rows.lo = b.h_acc[0]; rows.hi = b.h_acc[1]; cols.lo = b.h_acc[2]; cols.hi = b.h_acc[3];
+            wr = g_force_wide || !(key_fits32(rows.lo) && key_fits32(rows.hi));
+            wc = g_force_wide || !(key_fits32(cols.lo) && key_fits32(cols.hi));
+        }
     }
     // a failed build (out of memory, a HIP error) leaves the matrix what it was: in fill mode, with all of its triples — the
     // builder only reads them — so the caller may free memory and close again, or keep appending
