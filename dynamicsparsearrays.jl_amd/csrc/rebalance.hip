@@ -74,8 +74,39 @@ __global__ __launch_bounds__(256) void k_tile_count(const uint64_t* __restrict__
     }
 }
 
-// one workgroup: exclusive prefix of n counts, 4096 per round (4 consecutive counts per thread, one barrier pair per round)
-__global__ __launch_bounds__(1024) void k_tile_scan(const uint32_t* __restrict__ cnt, uint32_t* __restrict__ off, int64_t n) {
+// the same for TWO bitmaps in one launch (K-permute needs the tile prefixes of the old and of the new bitmap): workgroups [0, nbA)
+// count A, the rest B
+__global__ __launch_bounds__(256) void k_tile_count2(const uint64_t* __restrict__ occA, int64_t hiA, int64_t nwordsA, int64_t ntilesA,
+                                                     uint32_t* __restrict__ cntA, int nbA,
+                                                     const uint64_t* __restrict__ occB, int64_t hiB, int64_t nwordsB, int64_t ntilesB,
+                                                     uint32_t* __restrict__ cntB) {
+    const bool second = (int)blockIdx.x >= nbA;
+    const uint64_t* __restrict__ occ = second ? occB : occA;
+    const int64_t hi0 = second ? hiB : hiA, nwords = second ? nwordsB : nwordsA, ntiles = second ? ntilesB : ntilesA;
+    uint32_t* __restrict__ tile_cnt = second ? cntB : cntA;
+    const int64_t blk = second ? (int64_t)blockIdx.x - nbA : (int64_t)blockIdx.x;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t pc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t t = blk * CNT_TILES + wv * 4 + i;
+        const int64_t w = t * SRC_TILE_WORDS + lane;
+        pc[i] = 0;
+        if (t < ntiles && w < nwords) pc[i] = popc64(occ[w] & range_mask_for_word(w, 0, hi0));
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t t = blk * CNT_TILES + wv * 4 + i;
+        const uint32_t r = wave_reduce_add(pc[i]);
+        if (lane == 0 && t < ntiles) tile_cnt[t] = r;
+    }
+}
+
+// one workgroup: exclusive prefix of n counts, 4096 per round (4 consecutive counts per thread, one barrier pair per round); a second
+// workgroup (blockIdx 1) scans a second array in the same launch
+__global__ __launch_bounds__(1024) void k_tile_scan(const uint32_t* __restrict__ cnt, uint32_t* __restrict__ off, int64_t n,
+                                                    const uint32_t* __restrict__ cnt2 = nullptr, uint32_t* __restrict__ off2 = nullptr, int64_t n2 = 0) {
+    if (blockIdx.x == 1) { cnt = cnt2; off = off2; n = n2; }
     __shared__ uint32_t wsum[16];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     uint32_t carry = 0;
@@ -643,12 +674,12 @@ hipError_t launch_permute(KeyArr src_keys, const double* src_vals, const uint64_
     a.src_tiles = (a.src_words + SRC_TILE_WORDS - 1) / SRC_TILE_WORDS;
     a.dst_tiles = (a.dst_words + SRC_TILE_WORDS - 1) / SRC_TILE_WORDS;
     if (a.src_tiles + 1 > wsrc->tiles_cap || a.dst_tiles + 1 > wdst->tiles_cap) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_tile_count, dim3((unsigned)((a.src_tiles + CNT_TILES - 1) / CNT_TILES)), dim3(256), 0, stream, src_occ, (int64_t)0,
-                       src_cap - 1, (int64_t)0, a.src_words, a.src_tiles, wsrc->tile_cnt);
-    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, stream, wsrc->tile_cnt, wsrc->tile_off, a.src_tiles);
-    hipLaunchKernelGGL(k_tile_count, dim3((unsigned)((a.dst_tiles + CNT_TILES - 1) / CNT_TILES)), dim3(256), 0, stream, dst_occ, (int64_t)0,
-                       dst_cap - 1, (int64_t)0, a.dst_words, a.dst_tiles, wdst->tile_cnt);
-    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, stream, wdst->tile_cnt, wdst->tile_off, a.dst_tiles);
+    // tile prefixes of both bitmaps: one count launch and one scan launch for the two of them
+    const int nbA = (int)((a.src_tiles + CNT_TILES - 1) / CNT_TILES), nbB = (int)((a.dst_tiles + CNT_TILES - 1) / CNT_TILES);
+    hipLaunchKernelGGL(k_tile_count2, dim3((unsigned)(nbA + nbB)), dim3(256), 0, stream, src_occ, src_cap - 1, a.src_words, a.src_tiles, wsrc->tile_cnt, nbA,
+                       dst_occ, dst_cap - 1, a.dst_words, a.dst_tiles, wdst->tile_cnt);
+    hipLaunchKernelGGL(k_tile_scan, dim3(2), dim3(1024), 0, stream, (const uint32_t*)wsrc->tile_cnt, wsrc->tile_off, a.src_tiles,
+                       (const uint32_t*)wdst->tile_cnt, wdst->tile_off, a.dst_tiles);
     a.src_off = wsrc->tile_off; a.dst_off = wdst->tile_off;
     a.n0 = n0; a.ops = ops; a.i0 = i0; a.sems = sems;
     const size_t lds = (size_t)PERM_TILE * 16;
