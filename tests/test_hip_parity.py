@@ -1829,3 +1829,27 @@ def test_many_small_vectors_lease_their_landing_area(dsa, hip):
         kk, vv = vs[i].nonzeros()
         assert np.array_equal(kk, np.arange(1, 6, dtype=np.int64) * (i + 1)) and np.all(vv == float(i + 1))
         assert vs[i][3 * (i + 1)] == float(i + 1)
+
+
+def test_pool_cap_from_the_environment_is_honoured(dsa, hip):
+    """DSA_POOL_MAX_MB (read when the library is loaded) caps the idle HBM the caching allocator keeps: in a child process with a
+    64 MB cap a destroyed 200 MB structure leaves at most 64 MB behind."""
+    import subprocess
+    code = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+import dsa_loader
+dsa = dsa_loader.load(); hip = dsa.product()
+keys = np.arange(1, 6_000_001, dtype=np.int64)
+v = dsa.dynamicsparsevec(keys, np.ones(len(keys)), binding=hip)          # 2 x 2^24 slots x 12 B = 400 MB of slot buffers
+held = v.info()["hbm_bytes"]
+v.close()
+idle = dsa.pool_idle_bytes(binding=hip)
+assert held > 300e6, held
+assert idle <= 64 << 20, (idle, held)
+print("ok", idle)
+"""
+    env = dict(os.environ, DSA_POOL_MAX_MB="64")
+    r = subprocess.run([sys.executable, "-c", code, ROOT], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
