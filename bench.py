@@ -232,16 +232,12 @@ def main():
     ys = [shard.new_y() for _ in range(2 if overlap else 1)]
     pending = [None] * len(ys)
 
-    def step(k, events=None):
+    def step(k):
         b = k % len(ys)
         if pending[b] is not None:
             pending[b].wait()                     # the collective that last used this buffer (two steps ago)
             pending[b] = None
-        if events is not None:
-            events[0].record(stream)
         shard.spmv_partial(x, ys[b])             # dsa_shard_spmv_dev: HIP kernel on torch's stream, y written in HBM
-        if events is not None:
-            events[1].record(stream)
         if world > 1:
             pending[b] = shard.reduce(ys[b], args.schedule, async_op=overlap)
 
@@ -267,17 +263,41 @@ def main():
     for k in range(args.warmup):
         step(k)
     barrier()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    # ONE pair of HIP events brackets the timed region on the stream the kernel is launched on.  (Rounds 1-4 recorded a pair around every
+    # launch inside the region: the two event packets cost ~10 us of device time per step — 132.9 us per step for a 122.9 us kernel — and
+    # each interval came out ~3 us longer than the kernel trace's duration of the same launch.)
+    ev_region = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
     import gc
     gc.collect(); gc.disable()          # a collector pass of the host interpreter (~3 ms with torch loaded) is not part of a step
     t1 = time.perf_counter()
+    ev_region[0].record(stream)
     for k in range(args.steps):
-        step(k, ev[k])
+        step(k)
+    ev_region[1].record(stream)
     barrier()
     elapsed = max_over_ranks(time.perf_counter() - t1)
     gc.enable()
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
     ms_per_step = elapsed * 1e3 / args.steps
+    region_ms = ev_region[0].elapsed_time(ev_region[1]) / args.steps
+    # the kernel's average launch duration: at N = 1 the region holds nothing but the K launches, back to back on one stream, so the
+    # bracket / K is it (idle gaps between launches, if the host fell behind, are charged to the kernel); at N > 1 the stream also
+    # waits for collectives inside the region, so the launches are timed again right behind it, K of them alone between one pair
+    if world == 1:
+        kern_ms = region_ms
+    else:
+        ev_k = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev_k[0].record(stream)
+        for k in range(args.steps):
+            shard.spmv_partial(x, ys[0])
+        ev_k[1].record(stream)
+        torch.cuda.synchronize()
+        kern_ms = ev_k[0].elapsed_time(ev_k[1]) / args.steps
+    # cross-check in the old form (a pair of events around single launches, outside the timed region)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(min(args.steps, 20))]
+    for a, b in ev:
+        a.record(stream); shard.spmv_partial(x, ys[0]); b.record(stream)
+    torch.cuda.synchronize()
+    kern_pair_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
     # the same launch COLD: the timed steps run back to back on 2 x 203 MB of slot buffers + 8 MB of x, within reach of the 256 MB
     # Infinity Cache (FETCH_SIZE counts MALL hits as fetches); here every launch follows a 1 GiB device write
     cold_us = None
@@ -323,6 +343,9 @@ def main():
                      "kernel": "dsa::k_spmv_gather" + (" (no memset of y: the kernel zero-fills rows without a partition)" if nomemset else " (+ memset of y)"),
                      "algorithmic_bytes": bytes_launch,
                      "kernel_ms": round(kern_ms, 5),
+                     "kernel_ms_source": ("one HIP event pair around the %d launches of the timed region / %d" % (args.steps, args.steps)) if world == 1 else
+                                         ("one HIP event pair around %d launches alone, right behind the timed region / %d" % (args.steps, args.steps)),
+                     "kernel_ms_event_pair_per_launch": round(kern_pair_ms, 5),
                      "physical_bytes": physical_bytes,
                      "physical_gbps": round(physical_bytes / 1e9 / (kern_ms / 1e3), 2),
                      "physical_frac": round(physical_bytes / 1e9 / (kern_ms / 1e3) / HBM_PEAK_GBS, 4),
@@ -340,9 +363,11 @@ def main():
         out["roofline"]["cold_frac"] = round(bytes_launch / 1e3 / cold_us / HBM_PEAK_GBS, 4)
         out["roofline"]["cold_note"] = "median of 8 launches, each behind a 1 GiB device write (caches and Infinity Cache evicted), HIP events around the kernel alone"
 
-    # what the access pattern itself costs on this part (tools/gatherbench2.hip through tools/scripts/gather_floor.sh, committed as
-    # profiles/gather_floor.json): the slot stream alone, the 11 M gathers from an 8.4 MB x alone, and both in one kernel — the
-    # ceiling a single-pass kernel on uniformly random columns has, in the record next to the fraction it explains
+    # what the access pattern itself costs on this part (tools/gatherbench3.hip through tools/scripts/gather_floor3.sh, committed as
+    # profiles/gather_floor.json): the slot stream alone, the 10 M gathers from an 8 MB x alone, both in one kernel, and the minimal
+    # key-driven kernel (no rows, no semaphores, no y) — the floor a single-pass kernel on uniformly random columns has,
+    # in the record next to the fraction it explains.  (Rounds 3-4 quoted gatherbench2's 11 M gathers from an 8.4 MB table: 10 % more
+    # gathers than the product issues — semaphores do not read x.)
     if cfg == "c3" and m == 1_000_000 and ncl == 1_000_000 and per == 10:
         try:
             with open(os.path.join(ROOT, "profiles", "gather_floor.json")) as f:
@@ -350,7 +375,11 @@ def main():
             out["roofline"]["stream_only_us"] = gf["stream_only_us"]
             out["roofline"]["gather_only_floor_us"] = gf["gather_only_us"]
             out["roofline"]["stream_and_gather_one_kernel_us"] = gf["stream_and_gather_one_kernel_us"]
-            out["roofline"]["frac_ceiling_single_pass"] = round(bytes_launch / 1e9 / (gf["gather_only_us"] / 1e6) / HBM_PEAK_GBS, 4)
+            if "keyed_single_pass_us" in gf:
+                out["roofline"]["keyed_single_pass_floor_us"] = gf["keyed_single_pass_us"]
+                out["roofline"]["kernel_over_floor"] = round(kern_ms * 1e3 / gf["keyed_single_pass_us"], 3)
+            floor_us = gf.get("keyed_single_pass_us", gf["gather_only_us"])
+            out["roofline"]["frac_ceiling_single_pass"] = round(bytes_launch / 1e9 / (floor_us / 1e6) / HBM_PEAK_GBS, 4)
             out["roofline"]["floor_source"] = gf["source"]
         except (OSError, KeyError, ValueError):
             out["roofline"]["floor_source"] = "none: profiles/gather_floor.json missing"
@@ -517,6 +546,14 @@ def extras(dsa, hip, torch, A, dev):
                                 "algorithmic_bytes": b4, "gbps": round(b4 / 1e9 / (ms4 / 1e3), 1),
                                 "frac": round(b4 / 1e9 / (ms4 / 1e3) / HBM_PEAK_GBS, 4),
                                 "note": "local SpMV of one of the 8 column-range shards of BASELINE config 4 (the 80 MB all-reduce of y is not included)"}
+        try:      # the measured cost of this shard's slot stream + x gathers alone (tools/scripts/gather_floor3.sh): no 80 MB y, no row keys
+            with open(os.path.join(ROOT, "profiles", "gather_floor_c4shard.json")) as f:
+                g4 = json.load(f)
+            res["c4_shard_spmv"]["stream_and_gather_floor_us"] = g4["keyed_single_pass_us"]
+            res["c4_shard_spmv"]["frac_ceiling_stream_and_gathers_only"] = round(b4 / 1e9 / (g4["keyed_single_pass_us"] / 1e6) / HBM_PEAK_GBS, 4)
+            res["c4_shard_spmv"]["floor_source"] = g4["source"]
+        except (OSError, KeyError, ValueError):
+            pass
         del A4, x4, y4
     except Exception as e:           # an extra must never cost the headline line
         res["c4_shard_spmv"] = {"error": str(e)[:200]}

@@ -201,7 +201,13 @@ __device__ __forceinline__ void zero_fill_front(double* __restrict__ y, int64_t 
     if (tail) for (int64_t r = (row > 0 ? row : 0) + 1; r <= ny; ++r) y[r - 1] = 0.0;
 }
 
-template <bool WIDE, bool NT, bool ZFILL>
+// SHARE: the four waves of a workgroup hold four CONSECUTIVE spans, so the word behind the span of waves 0..2 is the first word of the
+//     next wave, whose products are in LDS anyway: after one workgroup barrier a wave walks on into its neighbour's slice instead of
+//     loading (and gathering for) a ninth word of its own, and learns from the neighbour in front whether that span holds a semaphore
+//     instead of loading the keys of the word in front.  Only wave 3 loads a ninth word, only wave 0 the word in front: 33 + 1 words
+//     of requests per workgroup instead of 36 + 4.  Needs every wave of the grid alive at the barrier: capacity a multiple of SP_TILE
+//     (decided by launch_spmv).  Same sums in the same order as without it.
+template <bool WIDE, bool NT, bool ZFILL, bool SHARE>
 __global__ __launch_bounds__(SP_BLOCK) void k_spmv_gather(KeyArr keys, const double* __restrict__ vals,
                                                           const uint64_t* __restrict__ occ, int64_t capacity,
                                                           const int64_t* __restrict__ sems,
@@ -212,9 +218,17 @@ __global__ __launch_bounds__(SP_BLOCK) void k_spmv_gather(KeyArr keys, const dou
     const key_t* __restrict__ kp = static_cast<const key_t*>(keys.p);
     __shared__ double sPw[SP_WAVES][SW_SLOTS + 1];      // [SW_SLOTS]: ZFILL, key of the partition in front of the span's first semaphore
     __shared__ uint16_t sListw[SP_WAVES][SW_SLOTS];
+    __shared__ uint64_t sSb0[SP_WAVES];                 // SHARE: semaphore ballot of a wave's first word, number of semaphores of its span
+    __shared__ int sNsem[SP_WAVES];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    double* sP = sPw[wv];
+    // SHARE: one flat product array over the same storage — wave w's slots at [w * SW_WORDS * 64, ...), running on into wave w + 1's; behind
+    // the four spans the ninth word of wave 3, then the four front keys
+    constexpr int SPAN = SW_WORDS * 64;
+    double* sP = SHARE ? &sPw[0][0] + wv * SPAN : sPw[wv];
+    const int front_idx = SHARE ? SP_WAVES * SPAN + 64 + wv - wv * SPAN : SW_SLOTS;
+    static_assert(SP_WAVES * (SW_SLOTS + 1) >= SP_WAVES * SW_WORDS * 64 + 64 + SP_WAVES, "flat product array fits the per-wave slices");
+    const bool ninth = !SHARE || wv == SP_WAVES - 1;    // this wave loads the word behind its span itself
     uint16_t* sList = sListw[wv];
     // XCD-aware tile mapping (see k_spmv): XCD g streams the g-th contiguous eighth of the slot array
     const int64_t ntiles = (capacity + SP_TILE - 1) / SP_TILE;
@@ -235,14 +249,19 @@ __global__ __launch_bounds__(SP_BLOCK) void k_spmv_gather(KeyArr keys, const dou
     double v[SW_WORDS + 1];
 #pragma unroll
     for (int j = 0; j <= SW_WORDS; ++j) {
+        if (SHARE && j == SW_WORDS && !ninth) { k[j] = 0; v[j] = 0.0; continue; }
         const int64_t w = w0 + j < nwords ? w0 + j : nwords - 1;
         k[j] = (int64_t)(NT ? __builtin_nontemporal_load(kp + (w << 6) + lane) : kp[(w << 6) + lane]);
         v[j] = NT ? __builtin_nontemporal_load(vals + (w << 6) + lane) : vals[(w << 6) + lane];
     }
-    // the word in front: does the previous span own the cells before our first semaphore?
+    // the word in front: does the previous span own the cells before our first semaphore?  (SHARE: waves 1..3 ask their neighbour)
     const int64_t pw = w0 > 0 ? w0 - 1 : 0;
-    const uint64_t pword = w0 > 0 ? occ[pw] : 0ull;
-    const int64_t pk = (int64_t)kp[(pw << 6) + lane];
+    uint64_t pword = 0ull;
+    int64_t pk = 0;
+    if (!SHARE || wv == 0) {
+        pword = w0 > 0 ? occ[pw] : 0ull;
+        pk = (int64_t)kp[(pw << 6) + lane];
+    }
 
     // ---- semaphore ballots, one gather per lane and word -----------------------------------------------------------------
     uint64_t sb[SW_WORDS + 1], cm[SW_WORDS + 1];
@@ -252,6 +271,7 @@ __global__ __launch_bounds__(SP_BLOCK) void k_spmv_gather(KeyArr keys, const dou
     const uint32_t tlen = table_len < 0x7fffffff ? (uint32_t)table_len : 0x7fffffffu;
 #pragma unroll
     for (int j = 0; j <= SW_WORDS; ++j) {
+        if (SHARE && j == SW_WORDS && !ninth) { sb[j] = 0; cm[j] = 0; q[j] = 0; continue; }
         const uint64_t word = w0 + j < nwords ? occ[w0 + j] : 0ull;
         const bool bit = (word >> lane) & 1ull;
         const bool issem = bit && k[j] == SEM_KEY;
@@ -277,10 +297,11 @@ __global__ __launch_bounds__(SP_BLOCK) void k_spmv_gather(KeyArr keys, const dou
         }
     }
     // ---- products and semaphore rows -> LDS ; compact the semaphores of the span ---------------------------------------
-    if (ZFILL && front_mine) sP[SW_SLOTS] = __longlong_as_double(front_key);
+    if (ZFILL && front_mine) sP[front_idx] = __longlong_as_double(front_key);
     int nsem = 0;
 #pragma unroll
     for (int j = 0; j <= SW_WORDS; ++j) {
+        if (SHARE && j == SW_WORDS && !ninth) continue;
         const bool cell = (cm[j] >> lane) & 1ull;
         const bool issem = (sb[j] >> lane) & 1ull;
         const double p = product_of(v[j], __longlong_as_double(q[j]), count_pass);
@@ -293,9 +314,14 @@ __global__ __launch_bounds__(SP_BLOCK) void k_spmv_gather(KeyArr keys, const dou
     const int own_words = (int)(nwords - w0 < SW_WORDS ? nwords - w0 : SW_WORDS);
     // end of the row that is open at the end of the span, as far as the 9 words show it
     const bool behind_valid = w0 + SW_WORDS < nwords;
+    if (SHARE) {
+        if (lane == 0) { sSb0[wv] = sb[0]; sNsem[wv] = nsem; }
+        __syncthreads();
+        if (!ninth) sb[SW_WORDS] = sSb0[wv + 1];
+    }
     const int endpos = !behind_valid ? own_words * 64 : (sb[SW_WORDS] ? SW_WORDS * 64 + __ffsll((unsigned long long)sb[SW_WORDS]) - 1 : SW_SLOTS);
     bool closed = !behind_valid || sb[SW_WORDS] != 0;
-    __builtin_amdgcn_wave_barrier();
+    if (!SHARE) __builtin_amdgcn_wave_barrier();
 
     double open_sum = 0.0;         // last row of the span (wave-uniform after the walk)
     int64_t open_row = 0;
@@ -306,7 +332,7 @@ __global__ __launch_bounds__(SP_BLOCK) void k_spmv_gather(KeyArr keys, const dou
             const bool is_last = e == nsem - 1;
             const int end = is_last ? endpos : (int)sList[e + 1];
             const int64_t row = __double_as_longlong(sP[a]);
-            if (ZFILL) zero_fill_front(y, ny, __double_as_longlong(sP[e > 0 ? (int)sList[e - 1] : SW_SLOTS]), row, is_last && has_last);
+            if (ZFILL) zero_fill_front(y, ny, __double_as_longlong(sP[e > 0 ? (int)sList[e - 1] : front_idx]), row, is_last && has_last);
             double sum = 0.0;
             int t = a + 1;
             for (; t + 3 < end; t += 4) {
@@ -330,7 +356,7 @@ __global__ __launch_bounds__(SP_BLOCK) void k_spmv_gather(KeyArr keys, const dou
             const bool is_last = e == nsem - 1;
             const int end = is_last ? endpos : (int)sList[e + 1];
             const int64_t row = __double_as_longlong(sP[a]);
-            if (ZFILL && lane == 0) zero_fill_front(y, ny, __double_as_longlong(sP[e > 0 ? (int)sList[e - 1] : SW_SLOTS]), row, is_last && has_last);
+            if (ZFILL && lane == 0) zero_fill_front(y, ny, __double_as_longlong(sP[e > 0 ? (int)sList[e - 1] : front_idx]), row, is_last && has_last);
             double sum = 0.0;
             for (int t = a + 1 + lane; t < end; t += 64) sum += sP[t];
             sum = wave_reduce_add_f64(sum);
@@ -365,7 +391,8 @@ __global__ __launch_bounds__(SP_BLOCK) void k_spmv_gather(KeyArr keys, const dou
     if (w0 > 0) {
         const bool pbit = (pword >> lane) & 1ull;
         bool covered = __ballot(pbit && pk == SEM_KEY) != 0;
-        for (int64_t w = w0 - 2; !covered && w >= 0 && w >= w0 - SW_WORDS; --w) {
+        if (SHARE && wv > 0) covered = sNsem[wv - 1] > 0;          // the span in front is the neighbour's: it counted its semaphores
+        for (int64_t w = w0 - 2; (!SHARE || wv == 0) && !covered && w >= 0 && w >= w0 - SW_WORDS; --w) {
             const uint64_t wd = occ[w];
             bool issem = false;
             if ((wd >> lane) & 1ull) issem = keys[(w << 6) + lane] == SEM_KEY;
@@ -587,8 +614,14 @@ template <bool WIDE, bool NT, bool ZFILL>
 static void launch_gather_t(int64_t grid, hipStream_t stream, KeyArr keys, const double* vals, const uint64_t* occ, int64_t capacity,
                             const int64_t* sems, const int64_t* part_keys, int64_t table_len, const double* x, int64_t nx, double* y,
                             int64_t ny, int pattern) {
-    hipLaunchKernelGGL((k_spmv_gather<WIDE, NT, ZFILL>), dim3((unsigned)grid), dim3(SP_BLOCK), 0, stream, keys, vals, occ, capacity, sems,
-                       part_keys, table_len, x, nx, y, ny, pattern);
+    // SHARE needs every wave of every workgroup at its barrier: whole tiles only (DSA_SPMV_SHARE=0: the form without the barrier)
+    static const bool share_ok = [] { const char* e = getenv("DSA_SPMV_SHARE"); return !(e && e[0] == '0'); }();
+    if (share_ok && capacity >= SP_TILE && capacity % SP_TILE == 0)
+        hipLaunchKernelGGL((k_spmv_gather<WIDE, NT, ZFILL, true>), dim3((unsigned)grid), dim3(SP_BLOCK), 0, stream, keys, vals, occ, capacity, sems,
+                           part_keys, table_len, x, nx, y, ny, pattern);
+    else
+        hipLaunchKernelGGL((k_spmv_gather<WIDE, NT, ZFILL, false>), dim3((unsigned)grid), dim3(SP_BLOCK), 0, stream, keys, vals, occ, capacity, sems,
+                           part_keys, table_len, x, nx, y, ny, pattern);
 }
 
 // mode bit 0 (SPMV_ZFILL): skip the memset of y, the kernel zeroes the rows without a partition itself (see k_spmv_gather);
