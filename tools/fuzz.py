@@ -119,11 +119,15 @@ def run_matrix(seed):
                 pass
             live = [(p, q) for (p, q) in live if q != j]
             mat_equal(a, b, (seed, step, "deletecolumn"))
-    n = a.size()[1]
+    m, n = a.size()
     if n >= 1:
         x = 1.0 + np.arange(n) % 7 / 8.0
         ya, yb = a.mul(x), b.mul(x)
         assert np.allclose(ya, yb, rtol=1e-12, atol=0), (seed, "spmv")
+    if m >= 1 and n >= 1:                  # transpose(mat) * v walks the other orientation with the same kernel
+        xt = 1.0 + np.arange(m) % 5 / 4.0
+        ya, yb = dsa.Transposed(a).mul(xt), dsa.Transposed(b).mul(xt)
+        assert np.allclose(ya, yb, rtol=1e-12, atol=0), (seed, "spmv transposed")
     return "ok"
 
 
