@@ -47,3 +47,18 @@ def test_committed_pmc_summary_matches_the_kernel_sources():
     if path is None:      # kernel sources edited since the last profile round: bench.py then reports traffic = null (never a stale number)
         pytest.skip("no profiles/*_pmc_summary.json was made from the current spmv.hip + rebalance.hip + dsa_dev.h: re-run tools/scripts/profile_round.sh")
     assert pm["kernel_source_sha"] == bench.kernel_source_sha()
+
+
+def test_committed_kernel_trace_agrees_with_the_bench_line():
+    """The rocprofv3 --kernel-trace --stats summary of the same command (profiles/<tag>_spmv_only_kernel_stats.csv) must give the
+    duration bench.py measured with HIP events for the dominant kernel: within 4 % of each other."""
+    import csv
+    d, path = latest_line()
+    stats = path.replace("_bench.json", "_spmv_only_kernel_stats.csv")
+    assert os.path.exists(stats), stats
+    rows = [r for r in csv.DictReader(open(stats)) if "k_spmv_gather" in r["Name"]]
+    assert rows, "no k_spmv_gather row in " + stats
+    top = max(rows, key=lambda r: int(r["Calls"]))
+    trace_ms = float(top["AverageNs"]) / 1e6
+    bench_ms = d["roofline"]["kernel_ms"]
+    assert abs(trace_ms - bench_ms) / bench_ms < 0.04, (trace_ms, bench_ms)
