@@ -1853,3 +1853,37 @@ print("ok", idle)
     env = dict(os.environ, DSA_POOL_MAX_MB="64")
     r = subprocess.run([sys.executable, "-c", code, ROOT], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+
+
+@pytest.mark.gpu
+def test_spmv_shared_words_form_is_bit_identical_to_the_plain_form(dsa, hip, tmp_path):
+    """k_spmv_gather<SHARE> (waves of a workgroup read the word behind their span from the neighbour's LDS slice, csrc/spmv.hip) adds the
+    same terms in the same order as the form without the barrier (DSA_SPMV_SHARE=0): every product of tools/spmv_sharecheck.py's
+    matrices with rows shorter than a span must be bit-identical between the two, both orientations, also after deletions; the ragged
+    and very long rows (partial sums joined by fp64 atomics in either form) agree to the tolerance of the path."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for share in ("1", "0"):
+        f = str(tmp_path / ("y_share%s.npz" % share))
+        env = dict(os.environ, DSA_SPMV_SHARE=share)
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "spmv_sharecheck.py"), f], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "sharecheck wrote" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+        outs.append(np.load(f))
+    a, b = outs
+    assert sorted(a.files) == sorted(b.files) and len(a.files) >= 28
+    shared_used = False
+    for k in a.files:
+        assert a[k].dtype == b[k].dtype and a[k].shape == b[k].shape, k
+        if a[k].dtype != np.float64:
+            assert np.array_equal(a[k], b[k]), k
+        elif k.startswith(("uniform0", "uniform1", "uniform2", "uniform3")):
+            assert np.array_equal(a[k].view(np.uint64), b[k].view(np.uint64)), k      # every row shorter than a span: one writer, fixed order
+        else:
+            # rows longer than a 512-slot span are joined with fp64 atomics in either form: equal up to the order of those additions
+            np.testing.assert_allclose(a[k], b[k], rtol=RTOL, atol=0, err_msg=k)
+        if k.endswith("_cap"):
+            shared_used = shared_used or bool((a[k] % 2048 == 0).any())
+    assert shared_used          # at least one capacity of whole 2048-slot tiles: the SHARE instantiation ran in the first child
