@@ -398,13 +398,22 @@ __global__ __launch_bounds__(PL_BLOCK) void k_plan(const DevBufs* bufs, const Ct
             auto accepts = [&](int32_t a, int64_t c) {
                 const int32_t b = a + (int32_t)seg - 1;
                 int ins = 0, del = 0;
-                const int cl = a >> CS;                                 // the cell of the leaf (= one of the hull's cells: the op writes into the leaf)
-                for (int e = sHead[bucket(cl)]; e >= 0; e = sNext[e]) {
-                    const int i = e >> 1;
-                    if ((e & 1) && (sIv[i].lo >> CS) == cl) continue;   // an op chained twice into this bucket's cell is counted once
-                    const int32_t ch = sChg[i], ch2 = sChg2[i];
-                    if (ch >= a && ch <= b) { if (sDl[i] > 0) ++ins; else ++del; }
-                    if (ch2 >= a && ch2 <= b) ++ins;
+                // The cells the leaf lies in.  Slots are 1-based, leaves start at k * seg + 1: the LAST slot of a leaf is a multiple of seg
+                // and, once in 2^CS / seg leaves, the first slot of the next cell — an op that changes that slot is chained THERE, not in
+                // the cell of the leaf's first slot (round 2-4 walked only that one: two deletes from one leaf, one of them of its last
+                // slot 237568 = 116 * 2048, ran in one round and left the leaf empty without the rebalance; tools/fuzz.py, FUZZ_BIG seed 91098).
+                const int cl0 = a >> CS, cl1 = b >> CS;
+                for (int cl = cl0; cl <= cl1; ++cl) {
+                    if (cl != cl0 && bucket(cl) == bucket(cl0)) break;      // the same chain again
+                    for (int e = sHead[bucket(cl)]; e >= 0; e = sNext[e]) {
+                        const int i = e >> 1;
+                        const int first = sIv[i].lo >> CS;
+                        if ((e & 1) && first == cl) continue;               // an op chained twice into this bucket's cell is counted once
+                        if (cl != cl0 && first == cl0) continue;            // ... and so is an op whose hull lies in both cells of the leaf
+                        const int32_t ch = sChg[i], ch2 = sChg2[i];
+                        if (ch >= a && ch <= b) { if (sDl[i] > 0) ++ins; else ++del; }
+                        if (ch2 >= a && ch2 <= b) ++ins;
+                    }
                 }
                 for (int w2 = 0; w2 < nwide0; ++w2) {
                     const int i = sWide[w2];

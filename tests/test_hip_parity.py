@@ -1887,3 +1887,40 @@ def test_spmv_shared_words_form_is_bit_identical_to_the_plain_form(dsa, hip, tmp
         if k.endswith("_cap"):
             shared_used = shared_used or bool((a[k] % 2048 == 0).any())
     assert shared_used          # at least one capacity of whole 2048-slot tiles: the SHARE instantiation ran in the first child
+
+
+@pytest.mark.gpu
+def test_two_deletes_from_a_leaf_whose_last_slot_starts_a_hash_cell(dsa, hip, oracle):
+    """Regression (tools/fuzz.py, FUZZ_BIG seed 91098): slots are 1-based, so the LAST slot of a leaf is a multiple of the segment size and —
+    for the leaf that ends at slot 12288 — the first slot of the next 4096-slot cell of the resolver's spatial hash (csrc/parbatch.hip).  An op
+    that deletes that slot is chained in the next cell; the count bookkeeping of tight footprints walked only the cell of the leaf's FIRST
+    slot, let two deletes from that leaf into one round, and the leaf went below its threshold without the rebalance of src/pma.jl:105-141."""
+    n = 60007
+    keys = np.arange(1, n + 1, dtype=np.int64) * 2
+    vals = unit12_array(77, n)
+    a = dsa.dynamicsparsevec(keys, vals, binding=hip)
+    b = dsa.dynamicsparsevec(keys, vals, binding=oracle)
+    assert_vec_equal(a, b)
+    K, V, O = b.export_layout()
+    inf = b.info()
+    assert inf["capacity"] == 131072 and inf["segment_capacity"] == 16        # (above 2^16 slots: the grid rounds, not the one-workgroup rounds)
+    leaf = slice(12288 - 16, 12288)
+    in_leaf = [int(x) for x in K[leaf][O[leaf].astype(bool)]]
+    assert O[12287] == 1 and in_leaf == [11238, 11240, 11242, 11244, 11246, 11248, 11250, 11252]
+    for k in in_leaf[:5]:                                                      # 8 -> 3 cells, one call each: the leaf accepts (>= 2), nothing moves
+        for v in (a, b):
+            v[k] = 0.0
+    assert_vec_equal(a, b)
+    K, V, O = b.export_layout()
+    assert [int(x) for x in K[leaf][O[leaf].astype(bool)]] == [11248, 11250, 11252] and O[12287] == 1
+    # one batch = one round of the batch-parallel path: value updates far away (no footprint in common with anything) around the two deletes
+    far = np.arange(40000, 40000 + 2 * 298, 2, dtype=np.int64)
+    bk = np.concatenate([far[:50], [11250], far[50:150], [11252], far[150:]])
+    bv = np.concatenate([unit12_array(78, 50), [0.0], unit12_array(79, 100), [0.0], unit12_array(80, len(far) - 150)])
+    reb0 = b.info()["stat_rebalances"]
+    for v in (a, b):
+        v.set_batch(bk, bv)
+    assert b.info()["stat_rebalances"] == reb0 + 1          # the second delete leaves 1 cell < 2: the reference rebalances a wider window
+    assert a.info()["stat_par_ops"] >= len(bk) - 8            # ... and the HIP library took the batch through the parallel rounds
+    assert_vec_equal(a, b)
+    assert a.info()["stat_rebalances"] == b.info()["stat_rebalances"] and a.info()["stat_window_slots"] == b.info()["stat_window_slots"]
