@@ -438,7 +438,10 @@ __global__ __launch_bounds__(PL_BLOCK) void k_plan(const DevBufs* bufs, const Ct
                 const int32_t a = ((sLeafLo[j] - 1) / W) * W + 1, b = a + W - 1;
                 if (a < me.lo) me.lo = a;
                 if (b > me.hi) me.hi = b;
-                sIv[j] = me;                                           // (still inside the cells it is chained in: an aligned window of up to PB_MAX_W slots never straddles a cell)
+                // (The widened interval can reach ONE slot into the next cell — slots are 1-based, an aligned window ends on a multiple of its
+                // size — where the op is not chained.  That is fine: the op WRITES only its tight hull, which it is chained by; the widening
+                // stands for the counts it READ, and a later op looks for the earlier writers in the cells of its own, widened, interval.)
+                sIv[j] = me;
             }
         }
     }
