@@ -186,7 +186,10 @@ __device__ Plan pb_plan_one(KeyArr keys, const double* vals, const uint64_t* occ
                 if (ne != 0) { pl.action = PB_INS_R; ip = p + 1; changed = ne; wlo = p + 1; whi = ne; pl.aux = ne; scan = true; }
                 else {
                     const int64_t pe = d_prev_empty(occ, p);
-                    if (pe != 0) { pl.action = PB_INS_L; ip = p; changed = pe; wlo = pe; whi = p; pl.aux = pe; scan = true; }
+                    // (the left branch is taken because NO slot behind p is free up to the end of the array: the plan has read all of them —
+                    // an earlier delete anywhere behind p would have sent this insert to the right instead.  Rounds 2-4 kept rhi = p + 1: an
+                    // insert near the end of a full tail and a delete of the last cell ran in one round, tools/fuzz.py run_same_leaf seed 2000.)
+                    if (pe != 0) { pl.action = PB_INS_L; ip = p; changed = pe; wlo = pe; whi = p; pl.aux = pe; scan = true; rhi = capacity; }
                 }
                 pl.pos = p; delta = 1;
             }

@@ -1924,3 +1924,21 @@ def test_two_deletes_from_a_leaf_whose_last_slot_starts_a_hash_cell(dsa, hip, or
     assert a.info()["stat_par_ops"] >= len(bk) - 8            # ... and the HIP library took the batch through the parallel rounds
     assert_vec_equal(a, b)
     assert a.info()["stat_rebalances"] == b.info()["stat_rebalances"] and a.info()["stat_window_slots"] == b.info()["stat_window_slots"]
+
+
+@pytest.mark.gpu
+def test_same_leaf_fuzz_scenarios_that_found_resolver_bugs(dsa, hip, oracle):
+    """tools/fuzz.py run_same_leaf (several count-changing ops per leaf and round, half of them in leaves that end on a hash-cell boundary)
+    around the two seeds that exposed resolver bugs of rounds 2-4: 712 (two deletes from a leaf whose last slot starts the next 4096-slot
+    hash cell: the count bookkeeping walked one cell only) and 2000 (an insert that falls back to the LEFT because nothing behind it is free
+    has read every slot up to the end of the array; its footprint ended at p + 1, so a delete of the last cell shared its round)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FUZZ_ONLY="leaf")
+    for first in (700, 1990):
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz.py"), "6", str(first)], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and "fuzz done" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+        done = int(r.stdout.strip().splitlines()[-1].split("scenarios")[0].split()[-1])
+        assert done >= 15, r.stdout[-500:]          # the named seed lies within the first 13 scenarios of each run

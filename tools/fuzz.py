@@ -194,6 +194,70 @@ def run_shared_words(seed):
     return "ok"
 
 
+def run_same_leaf(seed):
+    """Targeted stress of the resolver's count bookkeeping (csrc/parbatch.hip, tight footprints): several inserts / deletes of ONE batch in
+    the SAME leaf — chosen from the oracle's layout, half of them in leaves that end on a multiple of 4096 slots (the cells of the resolver's
+    spatial hash; a leaf's last slot is the first slot of the next cell) — spread over a batch of far-away value updates so that they meet
+    in one round.  Vectors above 2^16 slots (grid rounds, 16-slot segments) and, for 8-slot segments at that size, grown matrices are covered
+    by run_matrix; here the geometry is the built one."""
+    g = SplitMix64(seed)
+    n0 = [50000, 60007, 100000, 180000, 300000][g.next() % 5]
+    stride = 4 + 2 * (g.next() % 3)
+    keys0 = np.arange(1, n0 + 1, dtype=np.int64) * stride
+    a = dsa.dynamicsparsevec(keys0, np.ones(n0), binding=hip)
+    b = dsa.dynamicsparsevec(keys0, np.ones(n0), binding=ora)
+    for step in range(5):
+        K, V, O = b.export_layout()
+        inf = b.info()
+        cap, seg = inf["capacity"], inf["segment_capacity"]
+        occ = O.astype(bool)
+        ops = []                                   # (key, value) of the leaf ops, in the order they must keep
+        nleaves = 6 + g.next() % 20
+        for _ in range(nleaves):
+            if g.next() % 2 == 0:
+                kcell = 1 + g.next() % max(1, cap // 4096 - 1)
+                last = 4096 * kcell + seg * (int(g.next() % 3) - 1)      # the boundary leaf or a neighbour (1-based last slot)
+            else:
+                last = seg * (1 + g.next() % (cap // seg))
+            lo0, hi0 = last - seg, last                                   # 0-based slice of the leaf
+            cells = [int(x) for x in K[lo0:hi0][occ[lo0:hi0]]]
+            if not cells:
+                continue
+            nops = 2 + g.next() % 4
+            for _ in range(nops):
+                r = g.next() % 10
+                if r < 6 and cells:                                      # delete (the last cell of the leaf more often than not)
+                    c = cells.pop(-1 if g.next() % 2 else int(g.next() % len(cells)))
+                    ops.append((c, 0.0))
+                else:                                                     # insert between / behind the cells of the leaf
+                    base = cells[int(g.next() % len(cells))] if cells else int(K[lo0:hi0].max())
+                    ops.append((base + 1 + int(g.next() % (stride - 1)), 3.25))
+        # far-away fillers: value updates of existing keys (no footprint in common with anything), a few hundred around the leaf ops
+        nfill = [150, 400, 900][g.next() % 3]
+        pool_keys = K[occ]
+        fill = pool_keys[(np.array([g.next() for _ in range(nfill)], dtype=np.uint64) % np.uint64(len(pool_keys))).astype(np.int64)]
+        touched = {k for k, _ in ops}
+        fill = [int(k) for k in fill if int(k) not in touched]
+        keys, vals = [], []
+        slots = sorted(int(g.next() % (len(fill) + 1)) for _ in ops)
+        it = iter(zip(slots, ops)); nxt = next(it, None)
+        for idx, fk in enumerate(fill + [None]):
+            while nxt is not None and nxt[0] == idx:
+                keys.append(nxt[1][0]); vals.append(nxt[1][1]); nxt = next(it, None)
+            if fk is not None:
+                keys.append(fk); vals.append(1.0 + (idx % 7) / 8.0)
+        keys = np.array(keys, dtype=np.int64); vals = np.array(vals)
+        a.set_batch(keys, vals); b.set_batch(keys, vals)
+        ka, kb = a.export_layout(), b.export_layout()
+        assert a.info()["capacity"] == b.info()["capacity"], (seed, step, "capacity")
+        assert np.array_equal(ka[2], kb[2]), (seed, step, "occ")
+        o2 = ka[2].astype(bool)
+        assert np.array_equal(ka[0][o2], kb[0][o2]) and np.array_equal(ka[1][o2], kb[1][o2]), (seed, step, "cells")
+        ia, ib = a.info(), b.info()
+        assert ia["stat_rebalances"] == ib["stat_rebalances"] and ia["stat_window_slots"] == ib["stat_window_slots"], (seed, step, "statistics")
+    return "ok"
+
+
 def run_append_models(seed):
     """Targeted stress of the count-only append replay (csrc/appendmodel.hip): structures BUILT from data (16-slot segments: the
     geometry on which typed runs — semaphore cells of new columns — are count-only too) or grown from a few keys (small segments),
@@ -271,6 +335,8 @@ if __name__ == "__main__":
     while time.time() - t0 < budget:
         if os.environ.get("FUZZ_ONLY") == "append":      # soak of the append-replay scenario alone
             r = run_append_models(seed)
+        elif os.environ.get("FUZZ_ONLY") == "leaf" or (os.environ.get("FUZZ_ONLY") is None and seed % 16 == 7):
+            r = run_same_leaf(seed)                         # several count-changing ops per leaf and round
         else:
             r = run_shared_words(seed) if seed % 8 == 5 else (run_append_models(seed) if seed % 8 == 3 else (run_matrix(seed) if seed % 4 else run_vector(seed)))
         res[r] = res.get(r, 0) + 1
