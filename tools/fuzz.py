@@ -258,6 +258,78 @@ def run_same_leaf(seed):
     return "ok"
 
 
+def run_same_leaf_matrix(seed):
+    """run_same_leaf for a MATRIX: element inserts / deletes, NEW columns (their semaphore lands in front of an existing column's) and
+    writes that empty a column, several per leaf of the colmajor orientation and per batch, leaves picked from the oracle's layout (half of
+    them ending on a multiple of 4096 slots), between far-away overwrites.  The rowmajor twin receives the transposed ops."""
+    g = SplitMix64(seed)
+    m = [3000, 40000][g.next() % 2]
+    ncols = [12000, 30000, 70000][g.next() % 3]
+    per = 1 + g.next() % 4
+    cols = np.repeat(np.arange(1, ncols + 1, dtype=np.int64) * 4, per)
+    rows = 2 + 2 * (np.array([g.next() for _ in range(len(cols))], dtype=np.uint64) % np.uint64(m // 2)).astype(np.int64)      # even rows: odd ones are free
+    a = dsa.dynamicsparse(rows, cols, np.ones(len(cols)), binding=hip)
+    b = dsa.dynamicsparse(rows, cols, np.ones(len(cols)), binding=ora)
+    mat_equal(a, b, (seed, "build"))
+    colset = set(int(c) for c in cols)
+    for step in range(4):
+        L = b.export_layout(0)
+        K, Vv, O = L["keys"], L["vals"], L["occ"].astype(bool)
+        cap, seg = L["info"]["capacity"], L["info"]["segment_capacity"]
+        sem_pos = L["semaphores"]; ck = L["col_keys"]; live = L["col_live"].astype(bool)
+        order = np.argsort(np.where(live, sem_pos, np.iinfo(np.int64).max))
+        spos_sorted = sem_pos[order][: int(live.sum())]            # 1-based slots of the live semaphores, ascending
+        def column_of_slot(slot1):                                  # column key of the partition that holds 1-based slot `slot1`
+            q = int(np.searchsorted(spos_sorted, slot1, side="right")) - 1
+            return int(ck[order[q]]) if q >= 0 else None
+        ops = []
+        for _ in range(6 + g.next() % 16):
+            if g.next() % 2 == 0:
+                kcell = 1 + g.next() % max(1, cap // 4096 - 1)
+                last = 4096 * kcell + seg * (int(g.next() % 3) - 1)
+            else:
+                last = seg * (1 + g.next() % (cap // seg))
+            lo0, hi0 = last - seg, last
+            slots = [lo0 + int(x) for x in np.nonzero(O[lo0:hi0])[0]]
+            if not slots:
+                continue
+            for _ in range(2 + g.next() % 4):
+                s0 = slots[int(g.next() % len(slots))] if g.next() % 3 else slots[-1]
+                col = column_of_slot(s0 + 1)
+                if col is None:
+                    continue
+                r = g.next() % 10
+                if K[s0] == 0:                                            # a semaphore cell
+                    if r < 5:
+                        newc = col - 1 - int(g.next() % 3)
+                        if newc >= 1 and newc not in colset:
+                            colset.add(newc); ops.append((1 + 2 * int(g.next() % (m // 2)), newc, 2.5)); continue
+                    ops.append((1 + 2 * int(g.next() % 8), col, 2.75))    # a small odd row: right behind the semaphore
+                elif r < 5:
+                    ops.append((int(K[s0]), col, 0.0))                    # delete the element
+                else:
+                    ops.append((max(1, int(K[s0]) + (1 if g.next() % 2 else -1)), col, 3.25))      # a row next to it (never 0: the semaphore key)
+        nfill = [150, 400, 900][g.next() % 3]
+        pick = (np.array([g.next() for _ in range(nfill)], dtype=np.uint64) % np.uint64(len(cols))).astype(np.int64)
+        touched = {(i, j) for i, j, _ in ops}
+        fill = [(int(rows[t]), int(cols[t])) for t in pick if (int(rows[t]), int(cols[t])) not in touched]
+        I, J, V = [], [], []
+        where = sorted(int(g.next() % (len(fill) + 1)) for _ in ops)
+        it = iter(zip(where, ops)); nxt = next(it, None)
+        for idx, f in enumerate(fill + [None]):
+            while nxt is not None and nxt[0] == idx:
+                I.append(nxt[1][0]); J.append(nxt[1][1]); V.append(nxt[1][2]); nxt = next(it, None)
+            if f is not None:
+                I.append(f[0]); J.append(f[1]); V.append(1.0 + (idx % 7) / 8.0)
+        # (a filler may address an element an earlier leaf op deleted: it then re-inserts it — same on both sides)
+        a.set_batch(I, J, V); b.set_batch(I, J, V)
+        mat_equal(a, b, (seed, step, "same leaf matrix", len(I)))
+        for o in (0, 1):
+            ia, ib = a.info(o), b.info(o)
+            assert ia["stat_rebalances"] == ib["stat_rebalances"] and ia["stat_window_slots"] == ib["stat_window_slots"], (seed, step, o, "statistics")
+    return "ok"
+
+
 def run_append_models(seed):
     """Targeted stress of the count-only append replay (csrc/appendmodel.hip): structures BUILT from data (16-slot segments: the
     geometry on which typed runs — semaphore cells of new columns — are count-only too) or grown from a few keys (small segments),
@@ -337,6 +409,8 @@ if __name__ == "__main__":
             r = run_append_models(seed)
         elif os.environ.get("FUZZ_ONLY") == "leaf" or (os.environ.get("FUZZ_ONLY") is None and seed % 16 == 7):
             r = run_same_leaf(seed)                         # several count-changing ops per leaf and round
+        elif os.environ.get("FUZZ_ONLY") == "leafmat" or (os.environ.get("FUZZ_ONLY") is None and seed % 16 == 15):
+            r = run_same_leaf_matrix(seed)                  # ... in a matrix: elements, new columns, emptied columns
         else:
             r = run_shared_words(seed) if seed % 8 == 5 else (run_append_models(seed) if seed % 8 == 3 else (run_matrix(seed) if seed % 4 else run_vector(seed)))
         res[r] = res.get(r, 0) + 1
