@@ -201,7 +201,7 @@ def run_same_leaf(seed):
     in one round.  Vectors above 2^16 slots (grid rounds, 16-slot segments) and, for 8-slot segments at that size, grown matrices are covered
     by run_matrix; here the geometry is the built one."""
     g = SplitMix64(seed)
-    n0 = [50000, 60007, 100000, 180000, 300000][g.next() % 5]
+    n0 = [3000, 12000, 50000, 60007, 100000, 180000, 300000][g.next() % 7]      # (the two small ones: the one-workgroup rounds)
     stride = 4 + 2 * (g.next() % 3)
     keys0 = np.arange(1, n0 + 1, dtype=np.int64) * stride
     a = dsa.dynamicsparsevec(keys0, np.ones(n0), binding=hip)
@@ -214,9 +214,14 @@ def run_same_leaf(seed):
         ops = []                                   # (key, value) of the leaf ops, in the order they must keep
         nleaves = 6 + g.next() % 20
         for _ in range(nleaves):
-            if g.next() % 2 == 0:
+            pick = g.next() % 8
+            if pick < 3 and cap >= 8192:
                 kcell = 1 + g.next() % max(1, cap // 4096 - 1)
                 last = 4096 * kcell + seg * (int(g.next() % 3) - 1)      # the boundary leaf or a neighbour (1-based last slot)
+            elif pick == 3:
+                last = cap - seg * int(g.next() % 3)                     # the end of the array (left-falling inserts)
+            elif pick == 4:
+                last = seg * (1 + int(g.next() % 3))                     # ... and its start
             else:
                 last = seg * (1 + g.next() % (cap // seg))
             lo0, hi0 = last - seg, last                                   # 0-based slice of the leaf
@@ -284,9 +289,14 @@ def run_same_leaf_matrix(seed):
             return int(ck[order[q]]) if q >= 0 else None
         ops = []
         for _ in range(6 + g.next() % 16):
-            if g.next() % 2 == 0:
+            pick = g.next() % 8
+            if pick < 3:
                 kcell = 1 + g.next() % max(1, cap // 4096 - 1)
                 last = 4096 * kcell + seg * (int(g.next() % 3) - 1)
+            elif pick == 3:
+                last = cap - seg * int(g.next() % 3)
+            elif pick == 4:
+                last = seg * (1 + int(g.next() % 3))
             else:
                 last = seg * (1 + g.next() % (cap // seg))
             lo0, hi0 = last - seg, last
