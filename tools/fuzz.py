@@ -340,6 +340,127 @@ def run_same_leaf_matrix(seed):
     return "ok"
 
 
+def _both(fa, fb):
+    """runs the same call on both libraries; returns the (equal) error code or None"""
+    ea = eb = None
+    try:
+        fa()
+    except dsa.DsaError as e:
+        ea = e.code
+    try:
+        fb()
+    except dsa.DsaError as e:
+        eb = e.code
+    assert ea == eb, ("error codes", ea, eb)
+    return ea
+
+
+def run_tombstones(seed):
+    """Targeted stress of the partition tables: deletecolumn! / deleterow! leave tombstones (src/pcsr.jl:188-212, src/matrix.jl:95-111), then
+    batches create columns NEXT to tombstoned ids, re-create deleted ones (addpartition!(pcsc, prev) reuses a tombstoned id or shifts the
+    tables, src/pcsr.jl:114-146) and write into the survivors; both orientations compared after every call."""
+    g = SplitMix64(seed)
+    m = [400, 5000][g.next() % 2]
+    ncols = [300, 3000, 20000][g.next() % 3]
+    per = 1 + g.next() % 3
+    cols = np.repeat(np.arange(1, ncols + 1, dtype=np.int64) * 3, per)
+    rows = 1 + (np.array([g.next() for _ in range(len(cols))], dtype=np.uint64) % np.uint64(m)).astype(np.int64)
+    a = dsa.dynamicsparse(rows, cols, np.ones(len(cols)), binding=hip)
+    b = dsa.dynamicsparse(rows, cols, np.ones(len(cols)), binding=ora)
+    mat_equal(a, b, (seed, "build"))
+    alive = sorted(set(int(c) for c in cols)); dead = []
+    top_id = 3 * ncols
+    for step in range(6):
+        for _ in range(1 + g.next() % 6):                      # tombstones
+            if not alive:
+                break
+            j = alive.pop(int(g.next() % len(alive))); dead.append(j)
+            if _both(lambda: a.deletecolumn(j), lambda: b.deletecolumn(j)) is not None:
+                return "err"
+            mat_equal(a, b, (seed, step, "deletecolumn", j))
+        if g.next() % 3 == 0:
+            i = 1 + int(g.next() % m)
+            if _both(lambda: a.deleterow(i), lambda: b.deleterow(i)) is not None:
+                return "err"
+            mat_equal(a, b, (seed, step, "deleterow", i))
+        I, J, V = [], [], []
+        for _ in range([3, 40, 300, 2000][g.next() % 4]):
+            # (a column created BETWEEN two live ones while a tombstone sits further up the table runs into the reference's @assert,
+            # src/pcsr.jl:132 — a crash path, the scenario would end there: every tombstone is used once, by its own id or a neighbour,
+            # which lands ON it; new ids beyond the last column take the push branch)
+            r = g.next() % 10
+            v = 0.0 if g.next() % 6 == 0 else 1.5
+            if r < 4 and dead and v != 0.0:
+                d = dead.pop(int(g.next() % len(dead)))
+                j = max(1, d + int(g.next() % 3) - 1)
+                alive.append(j)
+            elif r == 4 and v != 0.0:
+                top_id += 1 + int(g.next() % 3); j = top_id; alive.append(j)
+            elif alive:
+                j = alive[int(g.next() % len(alive))]
+            else:
+                continue
+            I.append(1 + int(g.next() % m)); J.append(j); V.append(v)
+        e = _both(lambda: a.set_batch(I, J, V), lambda: b.set_batch(I, J, V))
+        if e is not None:
+            return "err%d" % e          # state after a reference crash path is a documented divergence
+        mat_equal(a, b, (seed, step, "batch", len(I)))
+        alive = sorted(set(alive))
+    n = a.size()[1]
+    if n >= 1:
+        x = 1.0 + np.arange(n) % 7 / 8.0
+        assert np.allclose(a.mul(x), b.mul(x), rtol=1e-12, atol=0), (seed, "spmv")
+    return "ok"
+
+
+def run_packedcsc(seed):
+    """The PackedCSC API on its own (explicit partition ids, src/pcsr.jl:26-63, 171-232, 294-339): writes, deletes, trailing partitions
+    created by a write behind the last one, deletepartition! and the error paths behind it, lookups; layout compared after every step."""
+    g = SplitMix64(seed)
+    nparts = [3, 40, 600][g.next() % 3]
+    span = [30, 500, 20000][g.next() % 3]
+    rk, vv = [], []
+    for _ in range(nparts):
+        ks = sorted({1 + int(g.next() % span) for _ in range(int(g.next() % 12))})
+        rk.append(ks); vv.append([1.0 + (k % 9) / 8.0 for k in ks])
+    a = dsa.packedcsc(rk, vv, binding=hip)
+    b = dsa.packedcsc(rk, vv, binding=ora)
+    def same():
+        La, Lb = a.export_layout(), b.export_layout()
+        assert a.info()["capacity"] == b.info()["capacity"] and a.nbpartitions() == b.nbpartitions() and a.nnz() == b.nnz()
+        assert np.array_equal(La[2], Lb[2]), (seed, "occ")
+        o = La[2].astype(bool)
+        assert np.array_equal(La[0][o], Lb[0][o]) and np.array_equal(La[1][o], Lb[1][o]) and np.array_equal(La[3], Lb[3]), (seed, "cells / semaphores")
+    same()
+    top = nparts
+    for step in range(30 + int(g.next() % 200)):
+        r = g.next() % 20
+        if r == 0 and top >= 1:
+            p = 1 + int(g.next() % (top + 1))
+            e = _both(lambda: a.deletepartition(p), lambda: b.deletepartition(p))
+        else:
+            p = 1 + int(g.next() % (top + (2 if r < 3 else 0)))            # now and then a write behind the last partition: trailing partitions
+            k = 1 + int(g.next() % span)
+            v = 0.0 if g.next() % 5 == 0 else 2.0 + (step % 5) / 4.0
+            def wa(): a[k, p] = v
+            def wb(): b[k, p] = v
+            e = _both(wa, wb)
+            if e is None and v != 0.0:
+                top = max(top, p)
+        if e is not None and e not in (dsa.binding.EDELETED, dsa.binding.EBOUNDS):
+            return "err%d" % e
+        same()
+        if step % 7 == 0:
+            p = 1 + int(g.next() % max(top, 1)); k = 1 + int(g.next() % span)
+            ga = gb = None
+            try: ga = a[k, p]
+            except dsa.DsaError as e2: ga = ("err", e2.code)
+            try: gb = b[k, p]
+            except dsa.DsaError as e2: gb = ("err", e2.code)
+            assert ga == gb, (seed, step, "get", ga, gb)
+    return "ok"
+
+
 def run_append_models(seed):
     """Targeted stress of the count-only append replay (csrc/appendmodel.hip): structures BUILT from data (16-slot segments: the
     geometry on which typed runs — semaphore cells of new columns — are count-only too) or grown from a few keys (small segments),
@@ -421,6 +542,10 @@ if __name__ == "__main__":
             r = run_same_leaf(seed)                         # several count-changing ops per leaf and round
         elif os.environ.get("FUZZ_ONLY") == "leafmat" or (os.environ.get("FUZZ_ONLY") is None and seed % 16 == 15):
             r = run_same_leaf_matrix(seed)                  # ... in a matrix: elements, new columns, emptied columns
+        elif os.environ.get("FUZZ_ONLY") == "tomb" or (os.environ.get("FUZZ_ONLY") is None and seed % 16 == 11):
+            r = run_tombstones(seed)                        # deletecolumn! / deleterow! and columns next to the tombstones
+        elif os.environ.get("FUZZ_ONLY") == "pcsc" or (os.environ.get("FUZZ_ONLY") is None and seed % 16 == 13):
+            r = run_packedcsc(seed)                         # the PackedCSC API with explicit partition ids
         else:
             r = run_shared_words(seed) if seed % 8 == 5 else (run_append_models(seed) if seed % 8 == 3 else (run_matrix(seed) if seed % 4 else run_vector(seed)))
         res[r] = res.get(r, 0) + 1
