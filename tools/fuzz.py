@@ -461,6 +461,98 @@ def run_packedcsc(seed):
     return "ok"
 
 
+def run_fill(seed):
+    """Fill mode (src/buffer.jl, src/matrix.jl:113-134): addrow! (a second addrow! of a row is rejected), element appends through setindex!
+    (duplicates of (i, j) are accumulated with +: integer-valued values, the fold order is the reference's unstable sort), closefillmode!,
+    then ordinary writes and slices / views on the flushed matrix."""
+    g = SplitMix64(seed)
+    m = [50, 2000, 60000][g.next() % 3]
+    n = [40, 3000, 50000][g.next() % 3]
+    a = dsa.dynamicsparse(fill_mode=True, binding=hip)
+    b = dsa.dynamicsparse(fill_mode=True, binding=ora)
+    for _ in range(int(g.next() % 400)):
+        r = 1 + int(g.next() % m)
+        k = int(g.next() % 12)
+        cs = sorted({1 + int(g.next() % n) for _ in range(k)})
+        vs = [float(1 + g.next() % 5) for _ in cs]
+        e = _both(lambda: a.addrow(r, cs, vs), lambda: b.addrow(r, cs, vs))
+        if e not in (None, dsa.binding.EMODE):          # EMODE: "Row already written in dynamic sparse matrix buffer." (src/buffer.jl:13) — the call is rejected, the buffer unchanged
+            return "err%d addrow" % e
+    ne = [0, 50, 3000, 40000][g.next() % 4]
+    if ne:
+        I = 1 + (np.array([g.next() for _ in range(ne)], dtype=np.uint64) % np.uint64(m)).astype(np.int64)
+        J = 1 + (np.array([g.next() for _ in range(ne)], dtype=np.uint64) % np.uint64(n)).astype(np.int64)
+        V = (1 + np.array([g.next() % 4 for _ in range(ne)])).astype(np.float64)
+        e = _both(lambda: a.set_batch(I, J, V), lambda: b.set_batch(I, J, V))
+        if e is not None:
+            return "err%d appends" % e
+    e = _both(lambda: a.closefillmode(), lambda: b.closefillmode())
+    if e is not None:
+        return "err%d closefillmode" % e
+    mat_equal(a, b, (seed, "closefillmode"))
+    assert a.nnz() == b.nnz()
+    for step in range(3):
+        nb = [5, 200, 4000][g.next() % 3]
+        I = 1 + (np.array([g.next() for _ in range(nb)], dtype=np.uint64) % np.uint64(m)).astype(np.int64)
+        J = 1 + (np.array([g.next() for _ in range(nb)], dtype=np.uint64) % np.uint64(n)).astype(np.int64)
+        V = np.where(np.array([g.next() % 4 for _ in range(nb)]) == 0, 0.0, 2.5)
+        e = _both(lambda: a.set_batch(I, J, V), lambda: b.set_batch(I, J, V))
+        if e is not None:
+            return "err%d" % e
+        mat_equal(a, b, (seed, step, "writes behind the flush"))
+        j0, i0 = int(J[0]), int(I[0])
+        assert a.col_view(j0) == b.col_view(j0) and a.row_view(i0) == b.row_view(i0), (seed, step, "views")
+    return "ok"
+
+
+def run_shrink_grow(seed):
+    """_shrink! and _extend! back to back (src/pma.jl:135-161): a vector or a matrix is emptied in batches — ascending, descending or random
+    key order — down to a handful of cells (several halvings), then filled again past its old size; layouts compared after every batch."""
+    g = SplitMix64(seed)
+    n0 = [3000, 40000, 250000 if BIG else 90000][g.next() % 3]
+    keys = np.arange(1, n0 + 1, dtype=np.int64) * 3
+    order = g.next() % 3
+    if g.next() % 2 == 0:
+        a = dsa.dynamicsparsevec(keys, np.ones(n0), binding=hip); b = dsa.dynamicsparsevec(keys, np.ones(n0), binding=ora)
+        def same(ctx):
+            ka, kb = a.export_layout(), b.export_layout()
+            assert a.info()["capacity"] == b.info()["capacity"], (ctx, "capacity", a.info()["capacity"], b.info()["capacity"])
+            assert np.array_equal(ka[2], kb[2]), (ctx, "occ")
+            o = ka[2].astype(bool)
+            assert np.array_equal(ka[0][o], kb[0][o]) and np.array_equal(ka[1][o], kb[1][o]), (ctx, "cells")
+        def write(ks, vs):
+            a.set_batch(ks, vs); b.set_batch(ks, vs)
+    else:
+        per = 1 + g.next() % 3
+        cols = np.repeat(np.arange(1, n0 // per + 1, dtype=np.int64), per)
+        rows = 1 + (np.array([g.next() for _ in range(len(cols))], dtype=np.uint64) % np.uint64(5000)).astype(np.int64)
+        a = dsa.dynamicsparse(rows, cols, np.ones(len(cols)), binding=hip); b = dsa.dynamicsparse(rows, cols, np.ones(len(cols)), binding=ora)
+        keys = np.arange(len(cols), dtype=np.int64)                 # indices of the triples
+        def same(ctx):
+            mat_equal(a, b, ctx)
+        def write(ks, vs):
+            a.set_batch(rows[ks], cols[ks], vs); b.set_batch(rows[ks], cols[ks], vs)
+    same((seed, "build"))
+    perm = keys.copy()
+    if order == 1:
+        perm = perm[::-1].copy()
+    elif order == 2:
+        rnd = np.array([g.next() for _ in range(len(perm))], dtype=np.uint64)
+        perm = perm[np.argsort(rnd, kind="stable")]
+    keep = 3 + int(g.next() % 40)
+    pos = 0
+    while pos < len(perm) - keep:
+        nb = min(len(perm) - keep - pos, [200, 3000, 30000][g.next() % 3])
+        write(perm[pos:pos + nb], np.zeros(nb)); pos += nb
+        same((seed, "emptying", pos))
+    pos = 0
+    while pos < len(perm):
+        nb = min(len(perm) - pos, [500, 8000, 60000][g.next() % 3])
+        write(perm[pos:pos + nb], np.full(nb, 2.0)); pos += nb
+        same((seed, "refilling", pos))
+    return "ok"
+
+
 def run_append_models(seed):
     """Targeted stress of the count-only append replay (csrc/appendmodel.hip): structures BUILT from data (16-slot segments: the
     geometry on which typed runs — semaphore cells of new columns — are count-only too) or grown from a few keys (small segments),
@@ -546,6 +638,10 @@ if __name__ == "__main__":
             r = run_tombstones(seed)                        # deletecolumn! / deleterow! and columns next to the tombstones
         elif os.environ.get("FUZZ_ONLY") == "pcsc" or (os.environ.get("FUZZ_ONLY") is None and seed % 16 == 13):
             r = run_packedcsc(seed)                         # the PackedCSC API with explicit partition ids
+        elif os.environ.get("FUZZ_ONLY") == "fill" or (os.environ.get("FUZZ_ONLY") is None and seed % 16 == 9):
+            r = run_fill(seed)                              # fill mode: addrow!, element appends, closefillmode!, writes behind it
+        elif os.environ.get("FUZZ_ONLY") == "shrink" or (os.environ.get("FUZZ_ONLY") is None and seed % 32 == 17):
+            r = run_shrink_grow(seed)                       # emptied through several _shrink!s, refilled through _extend!s
         else:
             r = run_shared_words(seed) if seed % 8 == 5 else (run_append_models(seed) if seed % 8 == 3 else (run_matrix(seed) if seed % 4 else run_vector(seed)))
         res[r] = res.get(r, 0) + 1
