@@ -553,6 +553,54 @@ def run_shrink_grow(seed):
     return "ok"
 
 
+def run_hot_keys(seed):
+    """A few HOT keys written over and over inside one batch — insert, delete, overwrite of the same key and of its direct neighbours, in
+    every order — between ordinary writes: identical and adjacent footprints, prefixes of one or two ops, hand-overs between the rounds
+    and the sequencer in both directions.  Sequential semantics: the last write of a key wins, every intermediate state decides the
+    rebalances in between."""
+    g = SplitMix64(seed)
+    n0 = [200, 5000, 70000][g.next() % 3]
+    stride = 5
+    keys0 = np.arange(1, n0 + 1, dtype=np.int64) * stride
+    if g.next() % 2 == 0:
+        a = dsa.dynamicsparsevec(keys0, np.ones(n0), binding=hip); b = dsa.dynamicsparsevec(keys0, np.ones(n0), binding=ora)
+        def write(ks, vs):
+            a.set_batch(ks, vs); b.set_batch(ks, vs)
+        def same(ctx):
+            ka, kb = a.export_layout(), b.export_layout()
+            assert a.info()["capacity"] == b.info()["capacity"], (ctx, "capacity")
+            assert np.array_equal(ka[2], kb[2]), (ctx, "occ")
+            o = ka[2].astype(bool)
+            assert np.array_equal(ka[0][o], kb[0][o]) and np.array_equal(ka[1][o], kb[1][o]), (ctx, "cells")
+            assert a.info()["stat_rebalances"] == b.info()["stat_rebalances"], (ctx, "rebalances")
+    else:
+        ncol = max(4, n0 // 6)
+        cols0 = 1 + (np.arange(n0) % ncol).astype(np.int64) * 2
+        a = dsa.dynamicsparse(keys0, cols0, np.ones(n0), binding=hip); b = dsa.dynamicsparse(keys0, cols0, np.ones(n0), binding=ora)
+        hot_col = [int(c) for c in cols0[:8]]
+        def write(ks, vs):
+            cs = np.array([hot_col[int(k) % 8] for k in ks], dtype=np.int64)      # a key always goes to the same column
+            a.set_batch(ks, cs, vs); b.set_batch(ks, cs, vs)
+        def same(ctx):
+            mat_equal(a, b, ctx)
+    for step in range(5):
+        nhot = 1 + int(g.next() % 6)
+        hot = [int(keys0[int(g.next() % n0)]) + int(g.next() % 3) - 1 for _ in range(nhot)]
+        hot = [h for h in hot if h >= 1] or [3]
+        nb = [20, 300, 3000][g.next() % 3]
+        ks, vs = [], []
+        for _ in range(nb):
+            r = g.next() % 10
+            if r < 7:
+                h = hot[int(g.next() % len(hot))] + (int(g.next() % 3) - 1 if g.next() % 4 == 0 else 0)
+                ks.append(max(1, h)); vs.append(0.0 if g.next() % 2 else 1.0 + (g.next() % 8) / 8.0)
+            else:
+                ks.append(1 + int(g.next() % (n0 * stride))); vs.append(0.0 if g.next() % 5 == 0 else 4.5)
+        write(np.array(ks, dtype=np.int64), np.array(vs))
+        same((seed, step, "hot keys", nb))
+    return "ok"
+
+
 def run_append_models(seed):
     """Targeted stress of the count-only append replay (csrc/appendmodel.hip): structures BUILT from data (16-slot segments: the
     geometry on which typed runs — semaphore cells of new columns — are count-only too) or grown from a few keys (small segments),
@@ -638,6 +686,8 @@ if __name__ == "__main__":
             r = run_tombstones(seed)                        # deletecolumn! / deleterow! and columns next to the tombstones
         elif os.environ.get("FUZZ_ONLY") == "pcsc" or (os.environ.get("FUZZ_ONLY") is None and seed % 16 == 13):
             r = run_packedcsc(seed)                         # the PackedCSC API with explicit partition ids
+        elif os.environ.get("FUZZ_ONLY") == "hot" or (os.environ.get("FUZZ_ONLY") is None and seed % 32 == 1):
+            r = run_hot_keys(seed)                          # the same few keys written over and over inside one batch
         elif os.environ.get("FUZZ_ONLY") == "fill" or (os.environ.get("FUZZ_ONLY") is None and seed % 16 == 9):
             r = run_fill(seed)                              # fill mode: addrow!, element appends, closefillmode!, writes behind it
         elif os.environ.get("FUZZ_ONLY") == "shrink" or (os.environ.get("FUZZ_ONLY") is None and seed % 32 == 17):
