@@ -1508,6 +1508,7 @@ void mat_apply_sets(dsa_mat* h, const int64_t* I, const int64_t* J, const double
         }
         const int64_t done = std::min(dc, dr);
         for (int64_t k = 0; k < std::min(done + 1, n); ++k) if (V[k] != 0.0) { h->m = std::max(h->m, I[k]); h->n = std::max(h->n, J[k]); }
+        if (ec && er && dr < dc) fail(er, err_text(er));      // both halves failed: the rowmajor half of the EARLIER write comes first
         if (ec) fail(ec, err_text(ec));
         if (er) fail(er, err_text(er));
         return;
@@ -1553,15 +1554,20 @@ void mat_apply_sets(dsa_mat* h, const int64_t* I, const int64_t* J, const double
     const bool par_seq = par && n >= 128;
     int32_t err = 0;
     const int64_t done = par_seq ? run_ops_parallel(h->col, oc, &err) : run_ops(h->col, oc, &err);
-    for (int64_t k = 0; k < done; ++k) if (V[k] != 0.0) { h->m = std::max(h->m, I[k]); h->n = std::max(h->n, J[k]); }
     if (err) {
-        // the failing write had already updated size(m) in the reference (src/matrix.jl:44-47)
-        if (V[done] != 0.0) { h->m = std::max(h->m, I[done]); h->n = std::max(h->n, J[done]); }
         orw.resize((size_t)done);
         int32_t e2 = 0;
-        if (par_seq) run_ops_parallel(h->row, orw, &e2); else run_ops(h->row, orw, &e2);
+        const int64_t d2 = par_seq ? run_ops_parallel(h->row, orw, &e2) : run_ops(h->row, orw, &e2);
+        // Which write fails FIRST in the reference's order (colmajor then rowmajor of write 0, of write 1, ...): the rowmajor half of an
+        // earlier write d2 < done comes before the colmajor half of write `done`.  (Rounds 1-4 reported the colmajor error regardless:
+        // tools/fuzz.py run_tombstones seed 503707, EBOUNDS where the reference throws the AssertionError of src/pcsr.jl:132 three writes earlier.)
+        const int64_t fail_at = e2 ? d2 : done;
+        // the failing write had already updated size(m) in the reference (src/matrix.jl:44-47)
+        for (int64_t k = 0; k <= fail_at && k < n; ++k) if (V[k] != 0.0) { h->m = std::max(h->m, I[k]); h->n = std::max(h->n, J[k]); }
+        if (e2) fail(e2, err_text(e2));
         fail(err, err_text(err));
     }
+    for (int64_t k = 0; k < done; ++k) if (V[k] != 0.0) { h->m = std::max(h->m, I[k]); h->n = std::max(h->n, J[k]); }
     if (par_seq) run_ops_parallel(h->row, orw, &err); else run_ops(h->row, orw, &err);
     if (err) fail(err, err_text(err));
 }

@@ -1931,7 +1931,8 @@ def test_same_leaf_fuzz_scenarios_that_found_resolver_bugs(dsa, hip, oracle):
     """tools/fuzz.py run_same_leaf (several count-changing ops per leaf and round, half of them in leaves that end on a hash-cell boundary)
     around the two seeds that exposed resolver bugs of rounds 2-4: 712 (two deletes from a leaf whose last slot starts the next 4096-slot
     hash cell: the count bookkeeping walked one cell only) and 2000 (an insert that falls back to the LEFT because nothing behind it is free
-    has read every slot up to the end of the array; its footprint ended at p + 1, so a delete of the last cell shared its round)."""
+    has read every slot up to the end of the array; its footprint ended at p + 1, so a delete of the last cell shared its round); and the
+    seed of run_tombstones that exposed the wrong error code of a batch whose two orientations fail at different writes."""
     import os
     import subprocess
     import sys
@@ -1942,3 +1943,9 @@ def test_same_leaf_fuzz_scenarios_that_found_resolver_bugs(dsa, hip, oracle):
         assert r.returncode == 0 and "fuzz done" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
         done = int(r.stdout.strip().splitlines()[-1].split("scenarios")[0].split()[-1])
         assert done >= 15, r.stdout[-500:]          # the named seed lies within the first 13 scenarios of each run
+    # run_tombstones seed 503707: a batch on a matrix with tombstones in BOTH orientations whose rowmajor half fails (the @assert of
+    # src/pcsr.jl:132) three writes before its colmajor half does (BoundsError): the reference throws the earlier one
+    env = dict(os.environ, FUZZ_ONLY="tomb")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz.py"), "4", "503700"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "fuzz done" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    assert int(r.stdout.strip().splitlines()[-1].split("scenarios")[0].split()[-1]) >= 10, r.stdout[-500:]
