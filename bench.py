@@ -310,7 +310,7 @@ def main():
     # algorithmic bytes of one SpMV launch: 16 B per streamed slot + x read + y written
     bytes_launch = 16 * cap + 8 * ncl + 8 * m
     useful_bytes = 16 * nnz + 8 * ncl + 8 * m
-    slot_bytes = 16 if os.environ.get("DSA_KEYS_WIDE") == "1" else 12      # int32 keys in HBM while every key fits Int32 (KeyArr)
+    slot_bytes = 16 if (os.environ.get("DSA_KEYS_WIDE") == "1" and os.environ.get("DSA_DEV") == "1") else 12      # int32 keys in HBM while every key fits Int32 (KeyArr)
     physical_bytes = slot_bytes * cap + cap // 8 + 8 * ncl + 8 * m            # what the kernel has to move at least: slots + bitmap + x + y
     value = world * bytes_launch / 1e9 / (ms_per_step / 1e3)
     achieved = bytes_launch / 1e9 / (kern_ms / 1e3)

@@ -13,6 +13,6 @@ from .api import (  # noqa: F401
     COLMAJOR, ROWMAJOR, DynamicSparseMatrix, DynamicSparseVector, PackedCSC, Transposed,
     addrow, closefillmode, deletecolumn, deletepartition, deleterow, dynamicsparse,
     dynamicsparsevec, import_packedcsc_layout, import_vector_layout, nbpartitions, nnz, packedcsc, packedcsc_empty, pool_idle_bytes,
-    pool_trim, shrink_size,
+    pool_trim, shrink_size, dev_switches,
 )
 from .binding import Binding, DsaArgumentError, DsaBoundsError, DsaError, DsaErrorException, product  # noqa: F401

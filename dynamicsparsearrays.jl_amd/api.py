@@ -528,3 +528,12 @@ def pool_idle_bytes(binding: Binding | None = None) -> int:
 def pool_trim(keep_bytes=0, binding: Binding | None = None):
     """release idle HBM blocks until at most keep_bytes remain (dsa_pool_trim)"""
     _bind(binding).call("pool_trim", int(keep_bytes))
+
+
+def dev_switches(binding: Binding | None = None):
+    """(names, enabled): the library's table of development switches and whether this process honours them
+    (only with DSA_DEV=1 in the environment: a release process ignores them — dsa_dev_switches)"""
+    buf = C.create_string_buffer(2048)
+    on = C.c_int32()
+    _bind(binding).call("dev_switches", buf, 2048, C.byref(on))
+    return buf.value.decode().split(), bool(on.value)

@@ -139,6 +139,7 @@ _DEVICE_SIGS = {
     "mat_set_wait_policy": [VP, I32],
     "pool_idle_bytes": [P_I64],
     "pool_trim": [I64],
+    "dev_switches": [C.c_char_p, I64, P_I32],
     # parity hooks: device slot-array primitives on raw slot arrays (include/dsa.h)
     "dbg_raw_find": [P_I64, P_F64, P_U8, I64, I64, I64, I64, I32, I32, P_I64, P_I32, P_I64, P_F64],
     "dbg_raw_insert": [P_I64, P_F64, P_U8, I64, I64, F64, I64, I64, P_I64, I64, I32, I32, P_I64, P_I32],

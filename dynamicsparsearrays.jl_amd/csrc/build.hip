@@ -716,8 +716,8 @@ hipError_t build_prepare(const int64_t* d_part, const int64_t* d_key, const doub
     s = BuildScratch();
     s.n = nnz; s.stream = stream;
     const size_t n = (size_t)nnz;
-    static const bool force_wide = [] { const char* e = getenv("DSA_BUILD_WIDE"); return e && e[0] == '1'; }();
-    static const bool force_minmax = [] { const char* e = getenv("DSA_BUILD_MINMAX"); return e && e[0] == '1'; }();      // dev: ignore the caller's ranges
+    static const bool force_wide = [] { const char* e = dev_env("DSA_BUILD_WIDE"); return e && e[0] == '1'; }();
+    static const bool force_minmax = [] { const char* e = dev_env("DSA_BUILD_MINMAX"); return e && e[0] == '1'; }();      // dev: ignore the caller's ranges
     auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
     const int64_t nblocks = (nnz + RS_TILE - 1) / RS_TILE;
     BCHK(pinned_ctl_get(&s.h_ctl));
@@ -761,7 +761,7 @@ hipError_t build_prepare(const int64_t* d_part, const int64_t* d_key, const doub
     const size_t lds_bytes = (size_t)RS_TILE * (sizeof(uint64_t) + sizeof(double));
     BCHK(once.run([&] { return hipFuncSetAttribute(reinterpret_cast<const void*>(k_rs_scatter<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); }));
     const int total_bits = s.kbits + s.pbits;
-    static const bool idx_sort = [] { const char* e = getenv("DSA_BUILD_IDXSORT"); return !(e && e[0] == '0'); }();      // dev knob: 0 = always carry the values
+    static const bool idx_sort = [] { const char* e = dev_env("DSA_BUILD_IDXSORT"); return !(e && e[0] == '0'); }();      // dev knob: 0 = always carry the values
     const int ibits_need = std::max(1, bit_width_u64((uint64_t)(nnz - 1)));
     s.ibits = (idx_sort && total_bits + ibits_need <= 64) ? ibits_need : 0;
     const int npass = (total_bits + 7) / 8;

@@ -224,7 +224,13 @@ __device__ __forceinline__ uint64_t spread_bits32(uint32_t x) {
 }
 #endif  // __HIPCC__
 
-void set_last_error(const char* msg);      // text behind dsa_last_error_message() for entry points outside dsa_host.hip
+void set_last_error(const char* msg);
+// Development switches (A/B runs, fault injection, coverage of alternative code paths).  A RELEASE process ignores every one of them:
+// dev_env() returns nullptr unless DSA_DEV=1 is set in the environment, so that a parity-critical path cannot be selected by whatever
+// the host application happens to inherit.  The names are one table in dsa_host.hip (dsa_dev_switches lists it); a name that is
+// not in the table aborts in the debug build.  Configuration that is NOT a development switch keeps plain getenv: DSA_POOL_MAX_MB,
+// DSA_RCCL_LIB, DSA_WAIT_POLICY, DSA_ROCTX.
+const char* dev_env(const char* name);      // text behind dsa_last_error_message() for entry points outside dsa_host.hip
 
 // one-time kernel attribute setup (hipFuncSetAttribute is per device): thread-safe — the two orientations of a matrix are driven
 // from two host threads (dsa_host.hip: mat_apply_sets) — and repeated for every device a process uses

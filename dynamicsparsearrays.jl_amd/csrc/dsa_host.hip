@@ -76,10 +76,58 @@ struct ApiRange {
     return DSA_OK;
 
 int g_device = 0;
+}  // namespace
+
+// ---- the one table of development switches (dsa_dev.h: dev_env) --------------------------------------------------------------------
+namespace dsa {
+static const char* const k_dev_switches[] = {
+    "DSA_APPEND_RUNS",    // 0: no append runs (per-op sequencer)
+    "DSA_BARRIER_CHUNK",  // n: first sequencer chunk after a stop at an op that cannot be planned
+    "DSA_BUILD_IDXSORT",  // 0: K-build always carries the values through the sort
+    "DSA_BUILD_MINMAX",   // 1: key ranges by the device scan even when the host knows them
+    "DSA_BUILD_WIDE",     // 1: K-build through the general (> 64-bit composite) path
+    "DSA_BURST_GRAPH",    // 0: rounds as eager launches instead of a cached graph
+    "DSA_COUNT_MODEL",    // 0: bitmap-only append replay (no model v2)
+    "DSA_DBG_BURST", "DSA_DBG_RUN", "DSA_DBG_SPLIT", "DSA_DBG_SPMV", "DSA_DBG_SPMV_META", "DSA_DBG_TIME",      // timing / trace prints
+    "DSA_DBG_MOVE2",      // ablations of the rebalance kernel (wrong results, timed)
+    "DSA_FAIL_BUILD",     // 1: fails the next bulk build (fault injection, tests)
+    "DSA_FP_MODE",        // footprint-check build (-DDSA_FP_CHECK): 1 recorded read / write sets, 2 sequential shadow re-plan (parbatch.hip)
+    "DSA_KEYS_WIDE",      // 1: 64-bit physical keys everywhere
+    "DSA_LOCAL_ROUNDS",   // 0: no local rounds (grid rounds only)
+    "DSA_META_BLOCKS",    // workgroups of k_spmv_meta
+    "DSA_MODEL3",         // 0: no count-only append replay
+    "DSA_MODEL5",         // 0: no typed multi-level replay of 8-slot-segment append runs
+    "DSA_MOVE2_BLOCK", "DSA_MOVE2_TILE",      // workgroup / tile size of k_move2
+    "DSA_PARBATCH",       // 0: no batch-parallel rounds
+    "DSA_POS_WIDE",       // 1: 64-bit positions in the append replay
+    "DSA_PUBLISH",        // 0: device-to-host copies + stream synchronisation instead of the pinned hand-overs
+    "DSA_SEQ_CHUNK",      // n: first sequencer chunk after a stop by short prefixes
+    "DSA_SMALL_BUILD",    // 0: small vectors through the general builder
+    "DSA_SMALL_ROUNDS",   // 0: small matrix batches on two sequencers
+    "DSA_SPMV_SHARE", "DSA_SPMV_STREAM", "DSA_SPMV_ZFILL", "DSA_SPMV_COMPACT",     // variants of the gather kernel
+    "DSA_TIGHT",          // 0..3: tight footprints of leaf-accepted ops
+    "DSA_TOMBSTONE_PAR",  // 0: orientations one after the other whenever tombstones exist
+    "DSA_TWIN_ROUNDS",    // 0: the twin's deletes of deletecolumn! on a second sequencer
+};
+const char* dev_env(const char* name) {
+#ifndef NDEBUG
+    bool known = false;
+    for (const char* s : k_dev_switches) known = known || std::strcmp(s, name) == 0;
+    if (!known) { fprintf(stderr, "dev_env: %s is not in the table of development switches\n", name); abort(); }
+#endif
+#ifndef DSA_DEV
+    const char* on = getenv("DSA_DEV");
+    if (!(on && on[0] == '1')) return nullptr;
+#endif
+    return getenv(name);
+}
+}  // namespace dsa
+
+namespace {
 // dev knob: DSA_APPEND_RUNS=0 sends ascending append runs through the per-op sequencer path (A/B measurements)
 // default of Pma::wait_policy (DSA_WAIT_POLICY=1: yield-friendly waits for every new handle)
 const int g_wait_policy_default = [] { const char* e = getenv("DSA_WAIT_POLICY"); return (e && e[0] == '1') ? 1 : 0; }();
-const bool g_append_runs = [] { const char* e = getenv("DSA_APPEND_RUNS"); return !(e && e[0] == '0'); }();
+const bool g_append_runs = [] { const char* e = dev_env("DSA_APPEND_RUNS"); return !(e && e[0] == '0'); }();
 
 // capacity = 2^ceil(Int, log2(ceil(n / t_h)))   src/pma.jl:64,81,88 (Float64 arithmetic, App. A.1)
 int64_t capacity_for(int64_t n) {
@@ -219,7 +267,7 @@ void download_keys(Pma& P, int64_t* dst, const void* src, int64_t n) {      // s
 }
 
 // dev knob: DSA_KEYS_WIDE=1 keeps every structure in 64-bit keys (A/B measurements, coverage of the wide kernels)
-const bool g_force_wide = [] { const char* e = getenv("DSA_KEYS_WIDE"); return e && e[0] == '1'; }();
+const bool g_force_wide = [] { const char* e = dev_env("DSA_KEYS_WIDE"); return e && e[0] == '1'; }();
 bool keys_fit32(const int64_t* k, int64_t n) {
     if (g_force_wide) return false;
     for (int64_t i = 0; i < n; ++i) if (!key_fits32(k[i])) return false;
@@ -615,7 +663,7 @@ struct SeqRun {
 // Hand-over of a launch's result through pinned memory (parbatch.hip: k_publish; the sequencer does it in its own epilogue): the last kernel of the launch
 // writes the control block (and the round state) into the host's pinned mirrors and then a number into P.h_pub; the host polls for
 // that number instead of issuing device-to-host copies and synchronising the stream.  DSA_PUBLISH=0: copies + synchronisation.
-bool publish_enabled() { static const bool on = [] { const char* e = getenv("DSA_PUBLISH"); return !(e && e[0] == '0'); }(); return on; }
+bool publish_enabled() { static const bool on = [] { const char* e = dev_env("DSA_PUBLISH"); return !(e && e[0] == '0'); }(); return on; }
 unsigned int next_publish_seq(Pma& P) {
     if (++P.pub_seq == 0) P.pub_seq = 1;
     return P.pub_seq;
@@ -722,13 +770,13 @@ bool seq_step(SeqRun& r) {
             ensure_tables(P, c.table_len + 1);
             break;
         case SEQ_Y_APPEND_RUN: {
-            if (getenv("DSA_DBG_RUN") && c.dbg[4])
+            if (dev_env("DSA_DBG_RUN") && c.dbg[4])
                 fprintf(stderr, "[previous append run] ops=%lld slow=%lld fast=%.1fus slow=%.1fus shader clock %.0f MHz | model v2: entries %lld ops %lld wide events %lld "
                         "pattern misses %lld exits [end %lld, word full %lld, word empty %lld, wider level %lld]\n", (long long)c.dbg[4],
                         (long long)c.dbg[0], c.dbg[2] / 100.0, c.dbg[3] / 100.0, c.dbg[5] ? 100.0 * c.dbg[1] / c.dbg[5] : 0.0,
                         (long long)c.prof[8], (long long)c.prof[9], (long long)c.prof[10], (long long)c.prof[11], (long long)c.prof[12], (long long)c.prof[13],
                         (long long)c.prof[14], (long long)c.prof[15]);
-            if (getenv("DSA_DBG_RUN") && c.dbg[4])
+            if (dev_env("DSA_DBG_RUN") && c.dbg[4])
                 fprintf(stderr, "    model v2: %lld in-word ops simulated one by one; %lld epoch jumps; %lld wide events computed (not memoised) in %.1f us; whole model %.1f us (shader clock)\n", (long long)c.prof[3], (long long)c.prof[4],
                         (long long)c.prof[5], c.prof[6] / 2400.0, c.prof[7] / 2400.0);
             // save the bitmap, replay the run on the live bitmap, move the cells; all stream-ordered, no host wait.  The
@@ -758,7 +806,7 @@ bool seq_step(SeqRun& r) {
             }
             // the count-only replay first (appendmodel.hip); what it cannot take — short runs, small segments, a tail outside the last
             // leaf — and whatever it leaves is replayed per op by k_append_run.  DSA_MODEL3=0: per-op replay only (A/B, coverage)
-            static const bool model3 = [] { const char* v = getenv("DSA_MODEL3"); return !(v && v[0] == '0'); }();
+            static const bool model3 = [] { const char* v = dev_env("DSA_MODEL3"); return !(v && v[0] == '0'); }();
             // (typed runs on segments below 16 slots are not count-only — appendmodel.hip — and runs below its minimum length do not pay:
             //  no launch for them)
             const bool m3_takes = model3 && R >= 512 && (P.has_cols ? c.segment_capacity >= 16 : c.segment_capacity >= 2) && c.capacity >= 65536;
@@ -770,7 +818,7 @@ bool seq_step(SeqRun& r) {
             e = launch_append_run(P.O(), P.d_ctl, i0, R, P.has_cols ? P.run_flags : nullptr, P.has_cols ? P.run_out : nullptr, P.run_memo, m3_out, P.stream);
             if (e != hipSuccess) fail(DSA_EHIP, std::string("append run launch: ") + hipGetErrorString(e));
             permute_run(P, P.has_cols ? P.run_cells : P.d_ops, P.has_cols ? 0 : i0, n0);
-            if (m3_out != nullptr && getenv("DSA_DBG_RUN")) {
+            if (m3_out != nullptr && dev_env("DSA_DBG_RUN")) {
                 int64_t o[8];
                 HIPCHK(hipMemcpyAsync(o, m3_out, sizeof(o), hipMemcpyDeviceToHost, P.stream));
                 HIPCHK(hipStreamSynchronize(P.stream));
@@ -814,7 +862,7 @@ int64_t run_ops_parallel(Pma& P, const OpBatch& ops, int32_t* err) {
         const auto tu0 = std::chrono::steady_clock::now();
         upload_batch(P, ops);
         enqueue_op_breaks(P, n);
-        static const bool dbg_up = getenv("DSA_DBG_SPLIT") != nullptr;
+        static const bool dbg_up = dev_env("DSA_DBG_SPLIT") != nullptr;
         if (dbg_up) fprintf(stderr, "  [run_ops_parallel] upload of %lld ops (%.1f MB, pageable): %.3f ms on the host\n", (long long)n, n * sizeof(Op) / 1e6,
                             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tu0).count());
     }
@@ -828,19 +876,19 @@ int64_t run_ops_parallel(Pma& P, const OpBatch& ops, int32_t* err) {
     }
     P.h_ctl->next_op = 0; P.h_ctl->status = 0; P.h_ctl->err = 0; P.h_ctl->no_run_at = -1;
     upload_ctl(P);
-    static const int64_t SEQ_CHUNK0 = [] { const char* e = getenv("DSA_SEQ_CHUNK"); return e ? (int64_t)atoi(e) : (int64_t)8; }();
-    static const int64_t BARRIER_CHUNK0 = [] { const char* e = getenv("DSA_BARRIER_CHUNK"); return e ? (int64_t)atoi(e) : (int64_t)1; }();
+    static const int64_t SEQ_CHUNK0 = [] { const char* e = dev_env("DSA_SEQ_CHUNK"); return e ? (int64_t)atoi(e) : (int64_t)8; }();
+    static const int64_t BARRIER_CHUNK0 = [] { const char* e = dev_env("DSA_BARRIER_CHUNK"); return e ? (int64_t)atoi(e) : (int64_t)1; }();
     int64_t i = 0, seq_chunk = SEQ_CHUNK0;
     int G = 256;
     int ema = 16 * 16;                      // RoundState::ema, carried across the bursts of the batch
     // local rounds (parbatch.hip: k_local_rounds) while the prefixes are short; a small array starts with them
-    static const bool local_ok = [] { const char* e = getenv("DSA_LOCAL_ROUNDS"); return !(e && e[0] == '0'); }();
+    static const bool local_ok = [] { const char* e = dev_env("DSA_LOCAL_ROUNDS"); return !(e && e[0] == '0'); }();
     constexpr int LOCAL_ROUNDS = 2048, LOCAL_BELOW = 6;
     bool use_local = local_ok && (P.h_ctl->capacity <= (1 << 16) || n <= 64);      // (a handful of ops: one launch of the persistent workgroup, not a burst graph)
     // a burst that stops in its first rounds (short conflict-free prefix, barrier op) leaves the rest of its graph as no-op
     // launches (~2.5 us each, four per round): after such a stop the next burst is a short one, until one runs to its end
     int burst_rounds = ROUNDS_PER_SYNC;
-    static const bool dbg_split = getenv("DSA_DBG_SPLIT") != nullptr;
+    static const bool dbg_split = dev_env("DSA_DBG_SPLIT") != nullptr;
     double t_burst = 0, t_seq = 0, t_local = 0; int64_t n_burst = 0, n_seq = 0, n_yield = 0, n_local = 0, r_local = 0, o_local = 0;
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
@@ -866,7 +914,7 @@ int64_t run_ops_parallel(Pma& P, const OpBatch& ops, int32_t* err) {
         // ---- a burst of rounds driven by the device-resident cursor; one host synchronisation per burst
         RoundState& rs = *P.h_rs;
         std::memset(&rs, 0, sizeof(rs));
-        static const int tight = [] { const char* e = getenv("DSA_TIGHT"); return e ? atoi(e) : 3; }();
+        static const int tight = [] { const char* e = dev_env("DSA_TIGHT"); return e ? atoi(e) : 3; }();
         rs.cursor = i; rs.limit = n; rs.G = G; rs.min_prefix = MIN_PREFIX; rs.ema = ema; rs.tight = tight;
         // the burst hands its result back through pinned memory (k_publish) and the host polls for the burst number; DSA_PUBLISH=0: two
         // device-to-host copies and a stream synchronisation instead
@@ -900,7 +948,7 @@ int64_t run_ops_parallel(Pma& P, const OpBatch& ops, int32_t* err) {
         if (use_local) { t_local += ms(tb0, now()); ++n_local; r_local += rs.rounds; o_local += rs.par_ops; }
         // the prefix of the last round of the burst has been applied but is folded into the cursor only by the next round's resolve step
         if (rs.pad != 0) fail(DSA_EASSERT, "batch-parallel column creation left its footprint (internal invariant)");
-        static const bool dbg_burst = getenv("DSA_DBG_BURST") != nullptr;
+        static const bool dbg_burst = dev_env("DSA_DBG_BURST") != nullptr;
         if (dbg_burst)
             fprintf(stderr, "    burst%s: rounds %lld ops %lld (+ last prefix %d) stop %d G %d ema %.1f pending %lld table %lld/%lld cap %lld\n", use_local ? " (local)" : "",
                     (long long)rs.rounds, (long long)rs.par_ops, rs.d, rs.stop, rs.G, rs.ema / 16.0, (long long)P.h_ctl->n_pending,
@@ -1161,7 +1209,7 @@ void pma_build_dev(Pma& P, const int64_t* d_part, const int64_t* d_key, const do
                    int mode, int64_t nparts_explicit, bool wide, KeyRange part_range = KeyRange(), KeyRange key_range = KeyRange()) {
     P.wide = wide;                     // decided by the caller from the host copy of the keys, before anything is allocated
     // fault injection for the error paths of the builders (tests): DSA_FAIL_BUILD=1 fails every build while it is set
-    if (const char* fe = getenv("DSA_FAIL_BUILD")) if (fe[0] == '1') fail(DSA_EHIP, "injected build failure (DSA_FAIL_BUILD)");
+    if (const char* fe = dev_env("DSA_FAIL_BUILD")) if (fe[0] == '1') fail(DSA_EHIP, "injected build failure (DSA_FAIL_BUILD)");
     if (nnz == 0) {
         std::vector<int64_t> ks; std::vector<double> vs;
         const int64_t np = mode == 2 ? nparts_explicit : 0;
@@ -1172,7 +1220,7 @@ void pma_build_dev(Pma& P, const int64_t* d_part, const int64_t* d_key, const do
     }
     BuildScratch sc;
     int64_t counts[2] = {0, 0};
-    static const bool dbg_time = getenv("DSA_DBG_TIME") != nullptr;
+    static const bool dbg_time = dev_env("DSA_DBG_TIME") != nullptr;
     const auto tp0 = std::chrono::steady_clock::now();
     hipError_t e = build_prepare(d_part, d_key, d_val, nnz, part_range, key_range, sc, counts, P.stream);
     const auto tp1 = std::chrono::steady_clock::now();
@@ -1208,8 +1256,8 @@ void pma_build_dev(Pma& P, const int64_t* d_part, const int64_t* d_key, const do
 // uploads host arrays (any of them may be nullptr) and runs the device builder
 void pma_build_from_host(Pma& P, const int64_t* part, const int64_t* key, const double* val, int64_t nnz, int32_t combine,
                          int mode, int64_t nparts_explicit) {
-    static const bool small_build = [] { const char* e = getenv("DSA_SMALL_BUILD"); return !(e && e[0] == '0'); }();
-    if (small_build && mode == 1 && part == nullptr && nnz >= 1 && nnz <= VIEW_AREA_CELLS && publish_enabled() && getenv("DSA_FAIL_BUILD") == nullptr) {
+    static const bool small_build = [] { const char* e = dev_env("DSA_SMALL_BUILD"); return !(e && e[0] == '0'); }();
+    if (small_build && mode == 1 && part == nullptr && nnz >= 1 && nnz <= VIEW_AREA_CELLS && publish_enabled() && dev_env("DSA_FAIL_BUILD") == nullptr) {
         // a small vector: ONE launch sorts, folds and packs the caller's pairs (read from the pinned landing area) in front of the slot
         // buffers and hands the entry count back; then the spread.  130 -> ~45 us for 50 entries (DSA_SMALL_BUILD=0: the general builder)
         KeyScan ks; ks.add(key, nnz);
@@ -1345,7 +1393,7 @@ namespace {
 void mat_build_major_dev(dsa_mat* h, const int64_t* dI, const int64_t* dJ, const double* dV, int64_t nnz, bool wide_rows, bool wide_cols,
                          KeyRange rows = KeyRange(), KeyRange cols = KeyRange()) {
     try {
-        static const bool dbg_time = getenv("DSA_DBG_TIME") != nullptr;
+        static const bool dbg_time = dev_env("DSA_DBG_TIME") != nullptr;
         const auto ti0 = std::chrono::steady_clock::now();
         pma_init_common(h->col, true, true);
         pma_init_common(h->row, true, true);
@@ -1401,7 +1449,7 @@ void mat_build_major(dsa_mat* h, const int64_t* I, const int64_t* J, const doubl
             hipError_t e = device_key_scan(dI, dJ, nnz, &rows, &cols, &zr, &zc, nullptr);
             if (e != hipSuccess) fail(DSA_EHIP, std::string("key scan: ") + hipGetErrorString(e));
         }
-        static const bool dbg_time = getenv("DSA_DBG_TIME") != nullptr;
+        static const bool dbg_time = dev_env("DSA_DBG_TIME") != nullptr;
         if (dbg_time) fprintf(stderr, "[mat_build_major] upload of %lld triples from caller memory + key scan %.1f ms\n", (long long)nnz,
                               std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tup0).count());
         if (rows_out) *rows_out = rows;
@@ -1440,7 +1488,7 @@ void mat_apply_sets(dsa_mat* h, const int64_t* I, const int64_t* J, const double
     // batch runs first and the rowmajor batch is cut at the failing op, like the reference's statement order.
     const bool no_tombstones = h->col.h_ctl->nb_partitions == h->col.h_ctl->table_len &&
                                h->row.h_ctl->nb_partitions == h->row.h_ctl->table_len;
-    static const bool par = [] { const char* e = getenv("DSA_PARBATCH"); return !(e && e[0] == '0'); }();
+    static const bool par = [] { const char* e = dev_env("DSA_PARBATCH"); return !(e && e[0] == '0'); }();
     // With tombstones a write can only fail while it CREATES a partition in the middle of the table (addpartition!(pcsc, prev),
     // src/pcsr.jl:114-146: the two asserts, and the lookup behind a tombstoned tail).  A batch whose partition keys never decrease and start
     // at or behind the last table entry — which must be live — only ever writes to that entry or appends behind it (find() returns the
@@ -1460,13 +1508,13 @@ void mat_apply_sets(dsa_mat* h, const int64_t* I, const int64_t* J, const double
         for (int64_t k = 0; k < n; ++k) { if (part_keys_of_ops[k] < running) return false; running = part_keys_of_ops[k]; }
         return true;
     };
-    static const bool tomb_par = [] { const char* e = getenv("DSA_TOMBSTONE_PAR"); return !(e && e[0] == '0'); }();
+    static const bool tomb_par = [] { const char* e = dev_env("DSA_TOMBSTONE_PAR"); return !(e && e[0] == '0'); }();
     const bool side_by_side_ok = no_tombstones || (tomb_par && n >= 128 && cannot_fail(h->col, J) && cannot_fail(h->row, I));
     if (par && side_by_side_ok && n >= 128) {
         // batch-parallel rounds per orientation (writes to existing columns with disjoint footprints run concurrently; new
         // columns and anything else fall back to the sequential sequencer inside run_ops_parallel)
         int32_t ec = 0, er = 0;
-        static const bool dbg_time = getenv("DSA_DBG_TIME") != nullptr;
+        static const bool dbg_time = dev_env("DSA_DBG_TIME") != nullptr;
         // the two orientations are independent structures on their own streams: their round / sequencer loops (host-driven)
         // run side by side, the rowmajor one on a helper thread
         const auto t0 = std::chrono::steady_clock::now();
@@ -1518,7 +1566,7 @@ void mat_apply_sets(dsa_mat* h, const int64_t* I, const int64_t* J, const double
         // A small batch (a column or a few that arrive together, a row): the orientation in which its writes fall into MANY
         // partitions takes the local rounds (one wave per op: k_local_rounds), the one in which they share a few partitions — writes
         // into one column are ordered by nature — its sequencer, side by side.  16 writes of a new column: 218 -> ~120 us.
-        static const bool small_rounds = [] { const char* e = getenv("DSA_SMALL_ROUNDS"); return !(e && e[0] == '0'); }();
+        static const bool small_rounds = [] { const char* e = dev_env("DSA_SMALL_ROUNDS"); return !(e && e[0] == '0'); }();
         if (small_rounds && par && n >= 8) {
             std::vector<int64_t> di(I, I + n), dj(J, J + n);
             std::sort(di.begin(), di.end()); std::sort(dj.begin(), dj.end());
@@ -1654,7 +1702,7 @@ void prefetch_spmv_meta(Pma& P) {
         std::memset(P.h_meta, 0, 8 * sizeof(int64_t));
         P.meta_seq = 0;
     }
-    { static const char* dbg = getenv("DSA_DBG_SPMV_META"); if (dbg) fprintf(stderr, "prefetch_spmv_meta: launch for epoch %lld (cached %lld, in flight %lld)\n",
+    { static const char* dbg = dev_env("DSA_DBG_SPMV_META"); if (dbg) fprintf(stderr, "prefetch_spmv_meta: launch for epoch %lld (cached %lld, in flight %lld)\n",
                                                                                (long long)P.layout_epoch, (long long)P.spmv_meta.epoch, (long long)P.meta_inflight_epoch); }
     // the kernel writes its five words and then the sequence number straight into pinned host memory
     hipError_t e = launch_spmv_meta(P.sems, P.col_keys, P.h_ctl->table_len, P.h_ctl->capacity, P.d_meta,
@@ -1667,7 +1715,7 @@ const Pma::SpmvMeta& spmv_meta(Pma& P) {
     if (M.epoch == P.layout_epoch) return M;
     M = Pma::SpmvMeta();
     M.epoch = P.layout_epoch;
-    static const char* dbg = getenv("DSA_DBG_SPMV_META");
+    static const char* dbg = dev_env("DSA_DBG_SPMV_META");
     if (!spmv_meta_applicable(P)) {     // tombstones: memset path
         const Ctl& c = *P.h_ctl;
         if (dbg) fprintf(stderr, "spmv_meta: has_cols %d table_len %lld nb_partitions %lld n_pending %lld\n", (int)P.has_cols, (long long)c.table_len,
@@ -1749,6 +1797,22 @@ int32_t dsa_device_count(int32_t* count) {
 // allocator (PyTorch's) asks how much that is and hands it back
 int32_t dsa_pool_idle_bytes(int64_t* bytes) { API_TRY *bytes = (int64_t)pool_idle_bytes(); API_CATCH }
 int32_t dsa_pool_trim(int64_t keep_bytes) { API_TRY pool_trim(keep_bytes > 0 ? (size_t)keep_bytes : 0); API_CATCH }
+int32_t dsa_dev_switches(char* buf, int64_t cap, int32_t* enabled) {
+    API_TRY
+    std::string all;
+    for (const char* s : dsa::k_dev_switches) { if (!all.empty()) all += ' '; all += s; }
+    if (buf == nullptr || cap < (int64_t)all.size() + 1) fail(DSA_ECAP, "buffer too small for the list of development switches");
+    std::memcpy(buf, all.c_str(), all.size() + 1);
+    if (enabled) {
+#ifdef DSA_DEV
+        *enabled = 1;
+#else
+        const char* on = getenv("DSA_DEV");
+        *enabled = (on && on[0] == '1') ? 1 : 0;
+#endif
+    }
+    API_CATCH
+}
 int32_t dsa_set_device(int32_t device) {
     API_TRY
     HIPCHK(hipSetDevice(device));
@@ -1792,7 +1856,7 @@ static void vec_flush(dsa_vec_t* h) {
 }
 static void vec_apply(dsa_vec_t* h, const int64_t* keys, const double* vals, int64_t n) {
     int32_t err = 0;
-    static const bool par = [] { const char* e = getenv("DSA_PARBATCH"); return !(e && e[0] == '0'); }();
+    static const bool par = [] { const char* e = dev_env("DSA_PARBATCH"); return !(e && e[0] == '0'); }();
     int64_t done;
     if (par && n >= 128) done = run_ops_parallel(h->P, OpBatch(OP_VEC_SET, keys, nullptr, vals, n), &err);      // the caller's columns go up as they are
     else {
@@ -2318,7 +2382,7 @@ int32_t dsa_mat_closefillmode(dsa_mat_t* h) {     // closefillmode!  src/matrix.
     FillBuffer& b = h->buf;
     int64_t nnz = 0;
     bool wr = false, wc = false;
-    static const bool dbg_time = getenv("DSA_DBG_TIME") != nullptr;
+    static const bool dbg_time = dev_env("DSA_DBG_TIME") != nullptr;
     const auto tc0 = std::chrono::steady_clock::now();
     // value ranges of everything appended (K-build's composite, the storage width of the keys): every uploaded piece was folded into
     // five running words on the device (k_minmax_acc) — they come back with the wait for the last piece; the appends themselves never
@@ -2354,7 +2418,7 @@ int32_t dsa_mat_deletecolumn(dsa_mat_t* h, int64_t col) {      // src/matrix.jl:
     API_TRY
     mat_flush(h);
     if (h->fillmode) fail(DSA_EMODE, "Cannot delete a column in fill mode");
-    static const bool dbg_time = getenv("DSA_DBG_TIME") != nullptr;
+    static const bool dbg_time = dev_env("DSA_DBG_TIME") != nullptr;
     const auto td0 = std::chrono::steady_clock::now();
     std::vector<int64_t> rows; std::vector<double> vals;
     col_view_of(h->col, col, rows, vals);
@@ -2367,7 +2431,7 @@ int32_t dsa_mat_deletecolumn(dsa_mat_t* h, int64_t col) {      // src/matrix.jl:
     // the element deletes of the twin cannot fail and touch the other structure: the deletepartition! of the own orientation is launched
     // on its sequencer, the twin's deletes — different partitions, mostly disjoint footprints — go through the local rounds meanwhile
     // (one wave per op instead of one op after the other: 105 -> 60 us for a column of 16)
-    static const bool twin_rounds = [] { const char* e = getenv("DSA_TWIN_ROUNDS"); return !(e && e[0] == '0'); }();
+    static const bool twin_rounds = [] { const char* e = dev_env("DSA_TWIN_ROUNDS"); return !(e && e[0] == '0'); }();
     if (h->col.stream != h->row.stream && twin_rounds && !ops.empty()) {
         SeqRun rc;
         seq_start(rc, h->col, del);
@@ -2399,7 +2463,7 @@ int32_t dsa_mat_deleterow(dsa_mat_t* h, int64_t row) {         // src/matrix.jl:
     std::vector<Op> ops;
     for (int64_t c : cols) ops.push_back(make_op(OP_MPCSC_SET, row, c, 0.0));     // colmajor[row, col] = 0
     std::vector<Op> del{make_op(OP_MPCSC_DELETECOLUMN, 0, row, 0.0)};
-    static const bool twin_rounds = [] { const char* e = getenv("DSA_TWIN_ROUNDS"); return !(e && e[0] == '0'); }();
+    static const bool twin_rounds = [] { const char* e = dev_env("DSA_TWIN_ROUNDS"); return !(e && e[0] == '0'); }();
     if (h->col.stream != h->row.stream && twin_rounds && !ops.empty()) {       // (as in deletecolumn!)
         SeqRun rr;
         seq_start(rr, h->row, del);
@@ -2514,7 +2578,7 @@ int32_t dsa_mat_spmv_dense(dsa_mat_t* h, int32_t transpose, const double* x, int
 int32_t dsa_mat_spmv_sparse(dsa_mat_t* h, int32_t transpose, const int64_t* xi, const double* xv, int64_t nx,
                             int64_t* yi, double* yv, int64_t cap, int64_t* n_out) {
     API_TRY
-    static const bool dbg_time = getenv("DSA_DBG_TIME") != nullptr;
+    static const bool dbg_time = dev_env("DSA_DBG_TIME") != nullptr;
     const auto tq0 = std::chrono::steady_clock::now();
     auto tq = [&](const char* what) { if (dbg_time) fprintf(stderr, "  [spmv_sparse] %s at %.1f us\n", what, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tq0).count()); };
     if (dbg_time) fprintf(stderr, "  [spmv_sparse] enter at %.1f us (steady clock)\n", std::chrono::duration<double, std::micro>(tq0.time_since_epoch()).count());

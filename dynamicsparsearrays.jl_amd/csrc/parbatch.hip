@@ -972,7 +972,7 @@ hipError_t launch_burst(const DevBufs* bufs, Ctl* ctl, const Op* ops, RoundState
     bool same = cache->exec != nullptr && cache->stream == stream;
     for (int k = 0; k < 12 && same; ++k) same = cache->key[k] == key[k];
     if (cache->disabled && cache->failed_on != stream) cache->disabled = false;      // another stream: capture may work there
-    static const bool no_graph = [] { const char* v = getenv("DSA_BURST_GRAPH"); return v && v[0] == '0'; }();       // dev knob: eager launches
+    static const bool no_graph = [] { const char* v = dev_env("DSA_BURST_GRAPH"); return v && v[0] == '0'; }();       // dev knob: eager launches
     if (no_graph) { cache->disabled = true; cache->failed_on = stream; }
     if (!same && !cache->disabled) {
         if (cache->exec) { (void)hipGraphExecDestroy(cache->exec); cache->exec = nullptr; }

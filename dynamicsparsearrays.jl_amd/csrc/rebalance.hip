@@ -747,7 +747,7 @@ hipError_t launch_rebalance(KeyArr src_keys, const double* src_vals, const uint6
         a.sems = sems;
         a.cells_to_gaps = m > 0 ? (double)(a.Wd - m) / (double)m : 0.0;
         { const SpreadGeom hg = make_geom(a.Wd, m); a.geom_f = hg.f; a.geom_inv_f = hg.inv_f; }
-        { static const char* e = getenv("DSA_DBG_MOVE2"); a.dbg = e ? atoi(e) : 0; }
+        { static const char* e = dev_env("DSA_DBG_MOVE2"); a.dbg = e ? atoi(e) : 0; }
         if (((src_ws - 1) & 63) != 0 && !src_packed) return hipErrorInvalidValue;     // source windows start on an occupancy word
         // ranks, gap indices and offsets inside a window are 32-bit in the kernel (dest_of_rank, gap_pair: single-instruction
         // int <-> double conversions): windows of 2^31 slots or more are refused, not wrapped
@@ -764,8 +764,8 @@ hipError_t launch_rebalance(KeyArr src_keys, const double* src_vals, const uint6
         // Tiles of 1024 slots (twice the workgroups, half the write phase each; DSA_MOVE2_TILE=1024) were measured in round 3 and LOSE:
         // 2^20 slots 11.1 vs 10.1 us, 2^21 18.0 vs 15.0, 2^22 26.1 vs 25.2, 2^24 76.7 vs 77.7 — more status words to publish and poll.  Tiles of
         // 4096 slots (half the per-tile fixed work) bought nothing either: 8.6 vs 8.2 us at 2^20 with 512 threads, 8.0 with 1024 (and 72.6 vs 69 at 2^24)
-        static const int force_block = [] { const char* e = getenv("DSA_MOVE2_BLOCK"); return e ? atoi(e) : 0; }();
-        static const int force_tile = [] { const char* e = getenv("DSA_MOVE2_TILE"); return e ? atoi(e) : 0; }();
+        static const int force_block = [] { const char* e = dev_env("DSA_MOVE2_BLOCK"); return e ? atoi(e) : 0; }();
+        static const int force_tile = [] { const char* e = dev_env("DSA_MOVE2_TILE"); return e ? atoi(e) : 0; }();
         const int tile = force_tile == M2_TILE_SMALL ? M2_TILE_SMALL : M2_TILE_BIG;
         a.ntiles = (Ws + tile - 1) / tile;
         if (a.ntiles + (a.ntiles >> 6) + 2 > work->status_cap || work->status == nullptr) return hipErrorInvalidValue;

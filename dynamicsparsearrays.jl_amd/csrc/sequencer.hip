@@ -1445,9 +1445,9 @@ size_t append_run_memo_bytes() { return sizeof(RunMemo) + 16; }
 
 hipError_t launch_append_run(uint64_t* occ, Ctl* ctl, int64_t i0, int64_t R, const uint64_t* flags, const int64_t* d_T,
                              uint64_t* saved_memo, const int64_t* m3_out, hipStream_t stream) {
-    static const int wide_pos = [] { const char* e = getenv("DSA_POS_WIDE"); return (e && e[0] == '1') ? 1 : 0; }();   // dev knob: 64-bit positions
+    static const int wide_pos = [] { const char* e = dev_env("DSA_POS_WIDE"); return (e && e[0] == '1') ? 1 : 0; }();   // dev knob: 64-bit positions
     // dev knob DSA_COUNT_MODEL=0: bitmap replay only (the general per-op path; A/B runs and coverage of that path)
-    static const int no_model = [] { const char* e = getenv("DSA_COUNT_MODEL"); return (e && e[0] == '0') ? 1 : 0; }();
+    static const int no_model = [] { const char* e = dev_env("DSA_COUNT_MODEL"); return (e && e[0] == '0') ? 1 : 0; }();
     static PerDeviceOnce once;
     {
         hipError_t e = once.run([] {

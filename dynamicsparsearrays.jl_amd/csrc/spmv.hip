@@ -605,7 +605,7 @@ hipError_t launch_spmv_meta(const int64_t* sems, const int64_t* part_keys, int64
     // x 4 steps 12-15 us, 977 x 1 step 18-20 us, 64 x 16 steps 26-33 us: every workgroup costs a partial + a ticket at device scope)
     int64_t blocks = (table_len + 1023) / 1024;
     if (blocks > 256) blocks = std::max<int64_t>(256, std::min<int64_t>(SPMV_META_BLOCKS, table_len >> 12));
-    { static const char* e = getenv("DSA_META_BLOCKS"); if (e && atoi(e) > 0 && blocks > atoi(e)) blocks = atoi(e); }
+    { static const char* e = dev_env("DSA_META_BLOCKS"); if (e && atoi(e) > 0 && blocks > atoi(e)) blocks = atoi(e); }
     hipLaunchKernelGGL(k_spmv_meta, dim3((unsigned)blocks), dim3(256), 0, stream, sems, part_keys, table_len, capacity, scratch, out6_pinned, seq);
     return hipGetLastError();
 }
@@ -615,7 +615,7 @@ static void launch_gather_t(int64_t grid, hipStream_t stream, KeyArr keys, const
                             const int64_t* sems, const int64_t* part_keys, int64_t table_len, const double* x, int64_t nx, double* y,
                             int64_t ny, int pattern) {
     // SHARE needs every wave of every workgroup at its barrier: whole tiles only (DSA_SPMV_SHARE=0: the form without the barrier)
-    static const bool share_ok = [] { const char* e = getenv("DSA_SPMV_SHARE"); return !(e && e[0] == '0'); }();
+    static const bool share_ok = [] { const char* e = dev_env("DSA_SPMV_SHARE"); return !(e && e[0] == '0'); }();
     if (share_ok && capacity >= SP_TILE && capacity % SP_TILE == 0)
         hipLaunchKernelGGL((k_spmv_gather<WIDE, NT, ZFILL, true>), dim3((unsigned)grid), dim3(SP_BLOCK), 0, stream, keys, vals, occ, capacity, sems,
                            part_keys, table_len, x, nx, y, ny, pattern);
@@ -629,10 +629,10 @@ static void launch_gather_t(int64_t grid, hipStream_t stream, KeyArr keys, const
 static hipError_t launch_spmv(bool scatter, int pattern, int mode, KeyArr keys, const double* vals, const uint64_t* occ, int64_t capacity,
                               const int64_t* sems, const int64_t* part_keys, int64_t table_len, const double* x, int64_t nx,
                               double* y, int64_t ny, hipStream_t stream) {
-    { static const char* dbg = getenv("DSA_DBG_SPMV"); if (dbg && pattern == 0) pattern = atoi(dbg) & 4; }
+    { static const char* dbg = dev_env("DSA_DBG_SPMV"); if (dbg && pattern == 0) pattern = atoi(dbg) & 4; }
     {   // dev knobs: DSA_SPMV_ZFILL=0 keeps the memset, DSA_SPMV_STREAM=nt|plain forces the stream policy
-        static const char* z = getenv("DSA_SPMV_ZFILL"); if (z && z[0] == '0') mode &= ~1;
-        static const char* st = getenv("DSA_SPMV_STREAM"); if (st) mode = (mode & ~2) | (st[0] == 'p' ? 2 : 0);
+        static const char* z = dev_env("DSA_SPMV_ZFILL"); if (z && z[0] == '0') mode &= ~1;
+        static const char* st = dev_env("DSA_SPMV_STREAM"); if (st) mode = (mode & ~2) | (st[0] == 'p' ? 2 : 0);
     }
     if (scatter) mode = 0;
     const bool zfill = (mode & 1) && table_len > 0;

@@ -51,6 +51,12 @@ function pool_idle_bytes()
 end
 "release idle HBM blocks until at most `keep_bytes` remain — dsa_pool_trim"
 pool_trim!(keep_bytes::Integer = 0) = _check(ccall((:dsa_pool_trim, libdsa), Int32, (Int64,), keep_bytes))
+"(names, enabled): the library's development switches and whether this process honours them (only with ENV[\"DSA_DEV\"] = \"1\") — dsa_dev_switches"
+function dev_switches()
+    buf = Vector{UInt8}(undef, 2048); on = Ref{Int32}(0)
+    _check(ccall((:dsa_dev_switches, libdsa), Int32, (Ptr{UInt8}, Int64, Ref{Int32}), buf, 2048, on))
+    return split(unsafe_string(pointer(buf))), on[] != 0
+end
 const WAIT_SPIN = Int32(0)      # blocking calls poll a pinned word (lowest latency, one core busy)
 const WAIT_BLOCK = Int32(1)     # blocking calls park in hipStreamSynchronize first (a Julia process that runs many tasks)
 function device_count()

@@ -249,6 +249,12 @@ int32_t dsa_mat_set_wait_policy(dsa_mat_t* h, int32_t policy);
  * until at most keep_bytes remain: what a host that shares the card with another allocator calls before that one runs short. */
 int32_t dsa_pool_idle_bytes(int64_t* bytes);
 int32_t dsa_pool_trim(int64_t keep_bytes);
+/* Release configuration.  The library has development switches (environment variables DSA_TIGHT, DSA_PARBATCH, DSA_MODEL3, ... that
+ * select alternative — parity-tested, slower or instrumented — code paths for A/B runs and fault injection).  A release process IGNORES
+ * all of them: they are honoured only when DSA_DEV=1 is set in the environment (or the library was built with -DDSA_DEV).  What stays
+ * configurable without it is not a code-path switch: DSA_POOL_MAX_MB, DSA_RCCL_LIB, DSA_WAIT_POLICY, DSA_ROCTX.
+ * dsa_dev_switches: the space-separated table of switch names (cap >= 1024 suffices) and whether this process honours them. */
+int32_t dsa_dev_switches(char* buf, int64_t cap, int32_t* enabled);
 
 /* ---- parity hooks and snapshots (no reference counterpart as entry points; the primitives they run are the reference's) ----
  * dsa_dbg_raw_*: ONE slot-array primitive of src/finds.jl / src/writes.jl / src/moves.jl executed by the DEVICE code on a

@@ -1254,6 +1254,7 @@ def test_failed_closefillmode_leaves_a_usable_fill_mode_matrix(dsa, hip, oracle)
     b = dsa.dynamicsparse(fill_mode=True, binding=oracle)
     for m_ in (a, b):
         m_.set_batch(row[:4000], col[:4000], val[:4000])
+    os.environ["DSA_DEV"] = "1"          # development switches are honoured only with DSA_DEV=1 (include/dsa.h)
     os.environ["DSA_FAIL_BUILD"] = "1"
     try:
         for _ in range(2):
@@ -1264,6 +1265,7 @@ def test_failed_closefillmode_leaves_a_usable_fill_mode_matrix(dsa, hip, oracle)
             dsa.dynamicsparse(row, col, val, binding=hip)
     finally:
         del os.environ["DSA_FAIL_BUILD"]
+        del os.environ["DSA_DEV"]
     with pytest.raises(dsa.DsaError):           # still in fill mode: no lookups
         a[1, 1]
     for m_ in (a, b):
@@ -1496,29 +1498,29 @@ def test_forced_64bit_keys_and_replay_variants_in_subprocesses(dsa, hip, oracle)
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     # DSA_POS_WIDE=1 additionally selects the 64-bit-position instantiation of the append-run replay (used for capacities > 2^30)
-    env = dict(os.environ, DSA_KEYS_WIDE="1", DSA_POS_WIDE="1")
+    env = dict(os.environ, DSA_DEV="1", DSA_KEYS_WIDE="1", DSA_POS_WIDE="1")
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz.py"), "12", "12345"], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "fuzz done" in r.stdout
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "appendbench.py"), "--check"], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "append parity ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
     # DSA_COUNT_MODEL=0: the bitmap-only append replay (the path every op takes outside the count model's regime) on a whole batch
-    env = dict(os.environ, DSA_COUNT_MODEL="0")
+    env = dict(os.environ, DSA_DEV="1", DSA_COUNT_MODEL="0")
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "appendbench.py"), "--check"], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "append parity ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz.py"), "8", "777"], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "fuzz done" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
     # DSA_LOCAL_ROUNDS=0: small structures through the grid rounds only (the suite itself runs them on the local rounds)
-    env = dict(os.environ, DSA_LOCAL_ROUNDS="0")
+    env = dict(os.environ, DSA_DEV="1", DSA_LOCAL_ROUNDS="0")
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz.py"), "8", "4242"], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "fuzz done" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
     # DSA_BUILD_WIDE=1: every bulk build (vectors, PackedCSC, matrices, fill-mode flushes) through the GENERAL path of K-build — two runs
     # of the hand-written radix sort with the input index as payload, hand-written flag scans (the path composites wider than 64 bits take)
-    env = dict(os.environ, DSA_BUILD_WIDE="1")
+    env = dict(os.environ, DSA_DEV="1", DSA_BUILD_WIDE="1")
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz.py"), "10", "9090"], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "fuzz done" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
     # DSA_MODEL3=0: long append runs on the per-op replay alone (what the count-only model hands back: short runs, small typed segments)
-    env = dict(os.environ, DSA_MODEL3="0")
+    env = dict(os.environ, DSA_DEV="1", DSA_MODEL3="0")
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "appendbench.py"), "--check"], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "append parity ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
@@ -1868,7 +1870,7 @@ def test_spmv_shared_words_form_is_bit_identical_to_the_plain_form(dsa, hip, tmp
     outs = []
     for share in ("1", "0"):
         f = str(tmp_path / ("y_share%s.npz" % share))
-        env = dict(os.environ, DSA_SPMV_SHARE=share)
+        env = dict(os.environ, DSA_DEV="1", DSA_SPMV_SHARE=share)
         r = subprocess.run([sys.executable, os.path.join(root, "tools", "spmv_sharecheck.py"), f], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0 and "sharecheck wrote" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
         outs.append(np.load(f))

@@ -188,3 +188,32 @@ def test_julia_modules_export_the_reference_surface():
         assert needed in amd, needed
     # an unsupported combine is never silently mapped to +
     assert "get(COMBINE, combine, Int32(0))" not in amd
+
+
+def test_development_switches_are_one_table_and_off_by_default(dsa):
+    """Release configuration (include/dsa.h: dsa_dev_switches).  Every DSA_* environment variable the library reads is either one of
+    the four documented configuration variables or a development switch listed in the ONE table of csrc/dsa_host.hip, and those are
+    read through dev_env(), which returns nothing unless DSA_DEV=1: no plain getenv of a switch is left in the sources.  No GPU call."""
+    csrc = os.path.join(ROOT, "dynamicsparsearrays.jl_amd", "csrc")
+    names, enabled = dsa.dev_switches(dsa.product())
+    assert enabled == (os.environ.get("DSA_DEV") == "1")
+    assert "DSA_TIGHT" in names and "DSA_PARBATCH" in names and len(names) == len(set(names))
+    config = {"DSA_POOL_MAX_MB", "DSA_RCCL_LIB", "DSA_WAIT_POLICY", "DSA_ROCTX", "DSA_DEV"}
+    used_dev, used_plain = set(), set()
+    for f in os.listdir(csrc):
+        if f.endswith((".hip", ".h")):
+            txt = open(os.path.join(csrc, f)).read()
+            used_dev |= set(re.findall(r'dev_env\("([A-Z0-9_]+)"\)', txt))
+            used_plain |= set(re.findall(r'(?<![a-z_])getenv\("([A-Z0-9_]+)"\)', txt))
+    assert used_plain <= config, used_plain - config
+    assert used_dev <= set(names), used_dev - set(names)
+    assert not (set(names) & config)
+    # a child process without DSA_DEV reports the switches as ignored, one with DSA_DEV=1 as honoured
+    code = ("import sys; sys.path.insert(0, %r); import dsa_loader; d = dsa_loader.load(); print(d.dev_switches(d.product())[1])" % ROOT)
+    for dev, want in ((None, "False"), ("1", "True"), ("0", "False")):
+        env = {k: v for k, v in os.environ.items() if k != "DSA_DEV"}
+        env["DSA_TIGHT"] = "0"
+        if dev is not None:
+            env["DSA_DEV"] = dev
+        r = subprocess.run([os.sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0 and r.stdout.strip().endswith(want), (dev, r.stdout, r.stderr)

@@ -8,6 +8,7 @@ import ctypes as C
 import os
 import sys
 
+os.environ["DSA_DEV"] = "1"
 os.environ["DSA_SPMV_STREAM"] = "nt"      # the nx = 0 calibration launches must be the SAME kernel instantiation (non-temporal stream loads)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -5,6 +5,7 @@ import ctypes as C
 import os
 import sys
 
+os.environ["DSA_DEV"] = "1"
 os.environ["DSA_SPMV_STREAM"] = "nt"      # the nx = 0 launches must be the SAME kernel instantiation as the real ones
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

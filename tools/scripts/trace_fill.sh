@@ -5,7 +5,7 @@ TAG=${1:-fill}
 R=${GRAFT_REPO_ROOT:?set GRAFT_REPO_ROOT (the repo root on the GPU box)}
 mkdir -p $R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
-DSA_DBG_TIME=1 python3 $R/tools/fillbench.py > $R/gpurun_out/${TAG}_fillbench.log 2>&1
+DSA_DEV=1 DSA_DBG_TIME=1 python3 $R/tools/fillbench.py > $R/gpurun_out/${TAG}_fillbench.log 2>&1
 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${TAG}_kt -o kt --output-format csv -- python3 $R/tools/fillbench.py > $R/gpurun_out/${TAG}_kt.log 2>&1
 cd $R && python3 - <<PY
 import csv, glob
