@@ -83,21 +83,27 @@ def c3_insert_leg(m, n, n_random=100_000, n_new_cols=10_000, per=10):
 
 
 def cold_launch_us(torch, dev, stream, fn, nrep=8, evict_bytes=1 << 30):
-    """Median time of ONE launch of fn with HIP events around it alone, each launch behind a device write of evict_bytes (1 GiB: four
-    times the 256 MB Infinity Cache, far beyond the 8 x 4 MB L2s) — the operands of the launch come from HBM, not from a cache the
-    previous launch filled."""
+    """Time of ONE launch of fn from cold caches: ONE pair of HIP events around nrep x (a device write of evict_bytes, the launch),
+    minus ONE pair around nrep x (the same write) alone, divided by nrep.  The write — 1 GiB: four times the 256 MB Infinity Cache,
+    far beyond the 8 x 4 MB L2s — makes the operands of every launch come from HBM; no event packet sits next to a launch (a pair
+    around every single launch read ~4 us longer than the kernel trace's duration of the same launch: rounds 3-4)."""
     scr = torch.empty(evict_bytes // 4, dtype=torch.float32, device=dev)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    ts = []
+    e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    for i in range(2):                      # warm both sequences once
+        scr.fill_(float(i)); fn()
+    torch.cuda.synchronize()
+    e[0].record(stream)
     for i in range(nrep):
         scr.fill_(float(i))
-        e0.record(stream)
         fn()
-        e1.record(stream)
-        torch.cuda.synchronize()
-        ts.append(e0.elapsed_time(e1) * 1e3)
+    e[1].record(stream)
+    e[2].record(stream)
+    for i in range(nrep):
+        scr.fill_(float(i + 1))
+    e[3].record(stream)
+    torch.cuda.synchronize()
     del scr
-    return float(np.median(ts))
+    return float((e[0].elapsed_time(e[1]) - e[2].elapsed_time(e[3])) * 1e3 / nrep)
 
 
 def kernel_source_sha():
@@ -147,6 +153,9 @@ def main():
                     help="N > 1: who issues the all-reduce of y — torch.distributed (RCCL through PyTorch; default) or the C ABI of the library "
                          "itself (dsa_comm_* / dsa_shard_allreduce_dev: RCCL bound inside libdsa_hip.so, the path a Julia host uses; "
                          "stream-ordered behind the SpMV, all_reduce schedule only)")
+    ap.add_argument("--dump-y", default=None,
+                    help="rank 0 writes y = A x of every reduction schedule (after the timed steps) to this .npz file: what a test compares with "
+                         "the CPU oracle (tests/test_hip_parity.py::test_bench_two_ranks_on_one_gpu_gloo_rehearsal)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the inserts/s and rebalance legs")
     args = ap.parse_args()
@@ -361,7 +370,7 @@ def main():
     if cold_us is not None:
         out["roofline"]["cold_kernel_ms"] = round(cold_us / 1e3, 5)
         out["roofline"]["cold_frac"] = round(bytes_launch / 1e3 / cold_us / HBM_PEAK_GBS, 4)
-        out["roofline"]["cold_note"] = "median of 8 launches, each behind a 1 GiB device write (caches and Infinity Cache evicted), HIP events around the kernel alone"
+        out["roofline"]["cold_note"] = "8 launches, each behind a 1 GiB device write (caches and Infinity Cache evicted): one event pair around the 8 (write, launch) pairs minus one around 8 writes alone, / 8"
 
     # what the access pattern itself costs on this part (tools/gatherbench3.hip through tools/scripts/gather_floor3.sh, committed as
     # profiles/gather_floor.json): the slot stream alone, the 10 M gathers from an 8 MB x alone, both in one kernel, and the minimal
@@ -419,6 +428,22 @@ def main():
                 sched[name + "_ms"] = "failed: %s" % str(e)[:120]
         out["collective_schedules"] = sched
         out["end_to_end_ms"] = {"local_spmv": sched["local_spmv_ms"], "step_overlapped": round(ms_per_step, 5)}
+    if args.dump_y:
+        ydump = {}
+        for name in sharding.SCHEDULES:
+            yy = shard.new_y()
+            shard.spmv_partial(x, yy)
+            shard.reduce(yy, name)
+            torch.cuda.synchronize()
+            ydump[name] = yy.cpu().numpy()
+        if abi_comm is not None:
+            yy = shard.new_y()
+            shard.spmv_partial(x, yy)
+            shard.reduce(yy, "all_reduce")
+            torch.cuda.synchronize()
+            ydump["abi_all_reduce"] = yy.cpu().numpy()
+        if rank == 0:
+            np.savez(args.dump_y, **ydump)
     if rank == 0 and world == 1 and not args.no_extras:          # the extra legs and the CPU baseline belong to the N = 1 line
         try:
             out.update(extras(dsa, hip, torch, A, dev))
@@ -468,7 +493,7 @@ def extras(dsa, hip, torch, A, dev):
         res["roofline_rebalance"]["cold_ms"] = round(cus / 1e3, 5)
         res["roofline_rebalance"]["cold_frac"] = round(b / 1e3 / cus / HBM_PEAK_GBS, 4)
         res["roofline_rebalance"]["cold_physical_frac"] = round(2 * (12 * cap + cap // 8) / 1e3 / cus / HBM_PEAK_GBS, 4)
-        res["roofline_rebalance"]["cold_note"] = "median of 8 launches, each behind a 1 GiB device write, HIP events around the launch alone"
+        res["roofline_rebalance"]["cold_note"] = "8 launches, each behind a 1 GiB device write: one event pair around the 8 (write, launch) pairs minus one around 8 writes alone, / 8"
     except Exception as e:
         res["roofline_rebalance"]["cold_error"] = str(e)[:120]
     # --- the isolated rebalance on full windows of 2^20 / 2^21 / 2^24 slots at densities 0.35 / 0.70:
@@ -649,12 +674,32 @@ def extras(dsa, hip, torch, A, dev):
     # --- C5 (BASELINE config 5, full size): stream 50k new columns (16 distinct rows each, ascending inside a column, 100k rows)
     #     element by element into an empty matrix — both orientations —, SpMV every 1000 columns.  Parity of this loop vs the
     #     oracle: tests/test_hip_parity.py::test_matrix_from_empty_streaming_columns_c5_scaled
-    res["c5_streaming"] = c5_streaming(dsa, hip, torch, dev, *C5_FULL)
+    def median_of(runs, key):
+        runs = sorted(runs, key=lambda r: r[key])
+        mid = dict(runs[len(runs) // 2])
+        mid["runs_" + key] = [r[key] for r in runs]
+        mid["protocol"] = "median of %d full runs (each on a fresh empty matrix) after one warm-up run" % len(runs)
+        return mid
+
+    c5_streaming(dsa, hip, torch, dev, *C5_FULL, stop_after=5000)            # warm-up: code objects, graphs, pools of this process
+    res["c5_streaming"] = median_of([c5_streaming(dsa, hip, torch, dev, *C5_FULL) for _ in range(3)], "write_s")
+    # --- the same stream as 800 000 single dsa_mat_set calls ("written element by element"): a C client of include/dsa.h
+    #     (tools/percall/percall_bench.c, built by __graft_entry__.build) in a child process — one ccall-shaped call per element through
+    #     the library's write-combining queue, the matrix observed after every 1000 columns; median of 3 repeats after a warm-up repeat
+    try:
+        import subprocess
+        exe = os.path.join(ROOT, "tools", "percall", "percall_bench")
+        r = subprocess.run([exe, str(C5_FULL[0]), str(C5_FULL[1]), str(C5_FULL[2]), str(C5_FULL[3]), "3"], capture_output=True, text=True, timeout=300)
+        res["c5_per_call"] = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else {"error": (r.stderr or r.stdout)[-300:]}
+        res["c5_per_call"]["note"] = ("config 5 as single dsa_mat_set(A, v, i, j) calls from a plain-C client (what a Julia `A[i, j] = v` ccall costs): the "
+                                      "library queues each write on the host and applies the queue in order before the next observing call")
+    except Exception as e:
+        res["c5_per_call"] = {"error": str(e)[:200]}
     # --- an EXTRA: the same stream as column generation does it — after every batch 5 % of its columns are deleted again
     #     (deletecolumn!, src/matrix.jl:95-102: tombstones in the colmajor tables).  A batch of new, larger column ids cannot fail, so the two
     #     orientations keep running side by side (dsa_host.hip: mat_apply_sets); parity: test_column_generation_with_deletions_matches_oracle
     try:
-        res["c5_streaming_with_deletions"] = c5_streaming(dsa, hip, torch, dev, *C5_FULL, delete_every=20)
+        res["c5_streaming_with_deletions"] = median_of([c5_streaming(dsa, hip, torch, dev, *C5_FULL, delete_every=20) for _ in range(3)], "write_s")
     except Exception as e:
         res["c5_streaming_with_deletions"] = {"error": str(e)[:200]}
     # --- buffered writes: the C3 triples through the fill buffer in ten batches of 1 M, then
@@ -696,18 +741,37 @@ def extras(dsa, hip, torch, A, dev):
         def delta(a, b_):
             return {name: {k: b_[o][k] - a[o][k] for k in ("stat_window_slots", "stat_rebalances", "stat_grid_rebalances", "stat_extends", "nb_elements")}
                     for o, name in ((dsa.COLMAJOR, "colmajor"), (dsa.ROWMAJOR, "rowmajor"))}
-        A.set_batch(ri[:256], rj[:256], rv[:256])                  # (first batch on this handle: graph capture, op buffers)
-        s0 = stats()
-        t = time.perf_counter(); A.set_batch(ri[256:], rj[256:], rv[256:]); t_rand = time.perf_counter() - t
-        s1 = stats()
-        t = time.perf_counter(); A.set_batch(ai, aj, av); t_app = time.perf_counter() - t
-        s2 = stats()
+        # median of 3 passes, each on a freshly built copy of the C3 matrix (the leg changes the matrix it runs on), after one warm-up
+        # pass that takes the first-launch costs of this process (the first append run / count-only model launch on a new hardware
+        # queue costs 1.4-2.3 ms on this runtime: round 4's single shot had it inside the 'appended_columns' time)
+        passes = []
+        Aw = A
+        for rep in range(4):
+            Aw.set_batch(ri[:256], rj[:256], rv[:256])              # (first batch on this handle: graph capture, op buffers)
+            s0 = {o: Aw.info(o) for o in (dsa.COLMAJOR, dsa.ROWMAJOR)}
+            t = time.perf_counter(); Aw.set_batch(ri[256:], rj[256:], rv[256:]); t_rand = time.perf_counter() - t
+            s1 = {o: Aw.info(o) for o in (dsa.COLMAJOR, dsa.ROWMAJOR)}
+            t = time.perf_counter(); Aw.set_batch(ai, aj, av); t_app = time.perf_counter() - t
+            s2 = {o: Aw.info(o) for o in (dsa.COLMAJOR, dsa.ROWMAJOR)}
+            if rep > 0:
+                passes.append((t_rand, t_app, s0, s1, s2))
+            if rep < 3:
+                if Aw is not A:
+                    del Aw
+                Aw = dsa.dynamicsparse(I3, J3, V3, 1_000_000, 1_000_000, binding=hip)
+        if Aw is not A:
+            del Aw
+        rand_runs = [p[0] for p in passes]; app_runs = [p[1] for p in passes]
+        t_rand = float(np.median(rand_runs)); t_app = float(np.median(app_runs))
+        s0, s1, s2 = passes[0][2], passes[0][3], passes[0][4]
         res["inserts_on_c3"] = {
             "matrix": "%d x %d, %d nnz before the leg, capacity %d slots per orientation" % (m3, n3, s0[dsa.COLMAJOR]["nb_elements"] - s0[dsa.COLMAJOR]["nb_partitions"], s0[dsa.COLMAJOR]["capacity"]),
             "random_writes": {"element_writes": int(len(ri) - 256), "ms": round(t_rand * 1e3, 3), "element_writes_per_s": round((len(ri) - 256) / t_rand, 1),
                               "pcsr_inserts_per_s": round(2 * (len(ri) - 256) / t_rand, 1), "stats": delta(s0, s1)},
             "appended_columns": {"columns": 10_000, "element_writes": int(len(ai)), "ms": round(t_app * 1e3, 3), "element_writes_per_s": round(len(ai) / t_app, 1),
                                  "pcsr_inserts_per_s": round(2 * len(ai) / t_app, 1), "stats": delta(s1, s2)},
+            "random_writes_ms_runs": [round(x * 1e3, 3) for x in rand_runs], "appended_columns_ms_runs": [round(x * 1e3, 3) for x in app_runs],
+            "protocol": "medians of 3 passes, each on a freshly built copy of the C3 matrix, after one warm-up pass",
             "note": "whole dsa_mat_set_batch calls incl. H2D; stat_grid_rebalances = launches of the grid-wide pack/spread kernel (windows above 8192 "
                     "slots); the appended columns are one append run per batch in the colmajor orientation (bitmap replay + one K-permute of the "
                     "array, no per-window launches) and random inserts in the rowmajor twin"}

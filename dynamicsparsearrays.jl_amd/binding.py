@@ -193,6 +193,11 @@ _PRODUCT = None
 
 
 def product_library_path() -> str:
+    """csrc/libdsa_hip.so; DSA_LIBRARY names another build of the SAME sources (the footprint-check build
+    csrc/libdsa_hip_fpcheck.so: tools/fuzz.py, the suite's check test) — a path that does not exist fails loudly like the default."""
+    override = os.environ.get("DSA_LIBRARY")
+    if override:
+        return os.path.abspath(override)
     return os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libdsa_hip.so")
 
 

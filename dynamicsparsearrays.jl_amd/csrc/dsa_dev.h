@@ -398,6 +398,10 @@ struct RoundState {
 // host polls (the burst number) — written by k_publish, the last kernel of a burst, with system-scope stores: no copy commands, no
 // stream synchronisation on the host side (nullptr: the host copies and synchronises itself)
 struct BurstPublish { RoundState* host_rs; Ctl* host_ctl; unsigned long long* host_seq; };
+// footprint-check build (parbatch.hip, -DDSA_FP_CHECK): bits of RoundState::tight that select the check, and the bytes per op the
+// plan array carries behind the plans for the recorded read / touch sets and the final footprints
+constexpr int FP_MODE_SETS = 0x100, FP_MODE_SHADOW = 0x200;
+constexpr size_t FP_BYTES_PER_OP = 160;
 constexpr int ROUND_GMAX = 1024;       // ops planned per round at most (parbatch.hip: one wave each; the host sizes the plan array)
 struct BurstGraph {        // cached hipGraph of one burst of rounds (host-side)
     hipGraphExec_t exec = nullptr; hipGraph_t graph = nullptr; hipStream_t stream = nullptr;

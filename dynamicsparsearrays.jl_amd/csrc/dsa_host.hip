@@ -867,7 +867,12 @@ int64_t run_ops_parallel(Pma& P, const OpBatch& ops, int32_t* err) {
                             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tu0).count());
     }
     if (!P.d_plans) {
+#ifdef DSA_FP_CHECK
+        HIPCHK(hipMalloc(&P.d_plans, (size_t)GMAX * (sizeof(Plan) + FP_BYTES_PER_OP)));      // + the recorded sets of the footprint check (parbatch.hip)
+        HIPCHK(hipMemsetAsync(P.d_plans, 0, (size_t)GMAX * (sizeof(Plan) + FP_BYTES_PER_OP), P.stream));
+#else
         HIPCHK(hipMalloc(&P.d_plans, (size_t)GMAX * sizeof(Plan)));
+#endif
         HIPCHK(hipMalloc(&P.d_bufs, sizeof(DevBufs)));
         HIPCHK(hipHostMalloc(&P.h_bufs, sizeof(DevBufs), hipHostMallocDefault));
         std::memset(P.h_bufs, 0, sizeof(DevBufs));
@@ -916,6 +921,12 @@ int64_t run_ops_parallel(Pma& P, const OpBatch& ops, int32_t* err) {
         std::memset(&rs, 0, sizeof(rs));
         static const int tight = [] { const char* e = dev_env("DSA_TIGHT"); return e ? atoi(e) : 3; }();
         rs.cursor = i; rs.limit = n; rs.G = G; rs.min_prefix = MIN_PREFIX; rs.ema = ema; rs.tight = tight;
+#ifdef DSA_FP_CHECK
+        {   // the footprint-check build: DSA_FP_MODE = 1 recorded read / touch sets (default), 2 sequential shadow re-plan, 0 neither
+            static const int fp_mode = [] { const char* e = dev_env("DSA_FP_MODE"); return e ? atoi(e) : 1; }();
+            rs.tight |= fp_mode == 2 ? FP_MODE_SHADOW : (fp_mode == 1 ? FP_MODE_SETS : 0);
+        }
+#endif
         // the burst hands its result back through pinned memory (k_publish) and the host polls for the burst number; DSA_PUBLISH=0: two
         // device-to-host copies and a stream synchronisation instead
         const bool publish = publish_enabled();
@@ -947,6 +958,7 @@ int64_t run_ops_parallel(Pma& P, const OpBatch& ops, int32_t* err) {
         t_burst += ms(tb0, now()); ++n_burst;
         if (use_local) { t_local += ms(tb0, now()); ++n_local; r_local += rs.rounds; o_local += rs.par_ops; }
         // the prefix of the last round of the burst has been applied but is folded into the cursor only by the next round's resolve step
+        if (rs.pad >= 10) fail(DSA_EASSERT, "DSA_FP_CHECK: a round of the batch-parallel writes is not equivalent to the sequential order (code " + std::to_string(rs.pad) + ", details on stdout)");
         if (rs.pad != 0) fail(DSA_EASSERT, "batch-parallel column creation left its footprint (internal invariant)");
         static const bool dbg_burst = dev_env("DSA_DBG_BURST") != nullptr;
         if (dbg_burst)

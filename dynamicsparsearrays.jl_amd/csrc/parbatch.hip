@@ -32,6 +32,59 @@ constexpr int PB_GMAX = ROUND_GMAX;           // ops planned per round at most (
 enum : int32_t { PB_NOOP = 0, PB_OVERWRITE = 1, PB_INS_R = 2, PB_INS_L = 3, PB_DELETE = 4, PB_BARRIER = 5, PB_NEWCOL = 6 };
 constexpr int64_t PB_PEND_MAX = TABLE_PEND_MAX;  // the sequencer imports, tables.hip merges the pending table entries
 
+// ---- footprint-check build (-DDSA_FP_CHECK; make libdsa_hip_fpcheck.so) -------------------------------------------------------------
+// The resolve step lets ops run side by side on the strength of their DECLARED footprints.  Three footprint-class defects hid behind green
+// suites for two rounds (Oracle and parity); this build makes the soundness of a round mechanical instead of argued:
+//   mode 1 (recorded sets)  the plan records what it literally scanned for its shift target (the occupancy runs of _nextemptypos /
+//            _previousemptypos) and every window whose cell count it consulted; the apply records the hull of every slot it wrote or
+//            re-read live.  k_fp_pre then re-derives the resolver's verdict by BRUTE FORCE, without its spatial hash: the final footprints of
+//            the prefix are pairwise disjoint, every scanned run lies inside the op's footprint, every counted window either lies inside it
+//            (and no other op of the prefix changes a bit there) or is the leaf of a leaf-accepted op whose thresholds hold for the count
+//            recounted from the bitmap plus / minus ALL changes the prefix makes in that leaf.  k_fp_post: what the apply touched lies inside
+//            the footprint.
+//   mode 2 (sequential shadow)  the prefix is applied one op after the other by ONE wave; before each op its plan is recomputed on the
+//            LIVE state and must equal the plan the round was resolved on (action, positions, accepted window, count when a rebalance
+//            follows): "each op sees exactly the state it was planned on", checked, for every semantic dependency at once (also the ones
+//            of the 64-ary find, whose literal probes are far outside any footprint).
+// A violation prints its details and raises RoundState::pad (the host fails the batch).  DSA_FP_REGRESS=1 / 2 re-introduce the two
+// resolver bugs of round 4 (the leaf walk of ONE hash cell; the footprint of a left-falling insert ending at p + 1): the check must fire.
+#ifdef DSA_FP_CHECK
+constexpr int FP_MAXCNT = 12;
+struct FpRec {                                    // what ONE op of a round literally read (plan) and touched (apply)
+    int64_t rlo, rhi;                             // occupancy runs scanned for the shift target (1-based, inclusive; rlo > rhi: none)
+    int64_t tlo, thi;                             // slots written, bits changed, cells re-read live by the apply
+    int32_t ncnt, pad;
+    int32_t cnt[FP_MAXCNT][2];                    // windows whose cell count the plan consulted
+};
+struct FpIv { int32_t lo, hi; };                  // the FINAL footprint the resolve step used (after widening)
+static_assert(sizeof(FpRec) + sizeof(FpIv) <= FP_BYTES_PER_OP, "the host sizes the plan array for the records behind it");
+__shared__ FpRec g_fpw[16];                       // one recorder per wave of the workgroup (k_plan: 16, k_apply: 4, k_local_rounds: 8)
+__device__ __forceinline__ void fp_reset() {
+    if (lane_id() == 0) { FpRec& f = g_fpw[threadIdx.x >> 6]; f.rlo = INT64_MAX; f.rhi = 0; f.tlo = INT64_MAX; f.thi = 0; f.ncnt = 0; f.pad = 0; }
+}
+__device__ __forceinline__ void fp_pos(int64_t a, int64_t b) {
+    if (lane_id() == 0 && a <= b) { FpRec& f = g_fpw[threadIdx.x >> 6]; if (a < f.rlo) f.rlo = a; if (b > f.rhi) f.rhi = b; }
+}
+__device__ __forceinline__ void fp_touch(int64_t a, int64_t b) {
+    if (lane_id() == 0 && a <= b) { FpRec& f = g_fpw[threadIdx.x >> 6]; if (a < f.tlo) f.tlo = a; if (b > f.thi) f.thi = b; }
+}
+__device__ __forceinline__ void fp_cnt(int64_t a, int64_t b) {
+    if (lane_id() == 0) {
+        FpRec& f = g_fpw[threadIdx.x >> 6];
+        if (f.ncnt < FP_MAXCNT) { f.cnt[f.ncnt][0] = (int32_t)a; f.cnt[f.ncnt][1] = (int32_t)b; }
+        f.ncnt += 1;
+    }
+}
+#else
+__device__ __forceinline__ void fp_reset() {}
+__device__ __forceinline__ void fp_pos(int64_t, int64_t) {}
+__device__ __forceinline__ void fp_touch(int64_t, int64_t) {}
+__device__ __forceinline__ void fp_cnt(int64_t, int64_t) {}
+#endif
+#ifndef DSA_FP_REGRESS
+#define DSA_FP_REGRESS 0
+#endif
+
 __device__ __forceinline__ int64_t pb_wave_sum(int64_t v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -53,10 +106,11 @@ __device__ int64_t pb_wave_count(const uint64_t* occ, int64_t ws, int64_t we, bo
 // Plan of ONE op by one wave (read-only): what the op would do on the current state, and its footprint.  w = index of the op in its
 // round (new columns take table entries in that order), max_w = largest window one wave of the caller rebalances.
 __device__ Plan pb_plan_one(KeyArr keys, const double* vals, const uint64_t* occ, const int64_t* sems, const int64_t* col_keys,
-                            const uint8_t* col_live, const Ctl* ctl, const Op op, int w, int max_w) {
+                            const uint8_t* col_live, const Ctl* ctl, const Op op, int w, int max_w, const bool tight_only = false) {
     const int64_t capacity = ctl->capacity, seg = ctl->segment_capacity, height = ctl->height;
     Plan pl;
     pl.lo = 1; pl.hi = 0; pl.pos = 0; pl.aux = 0; pl.ws = 0; pl.we = 0; pl.count = 0; pl.action = PB_BARRIER;
+    fp_reset();
     int why = 0;           // dev: reason of a BARRIER (kept in pl.count): 0 not plannable, 1 new column w/o successor or v == 0, 2 limits, 3 shifts, 4 sem leaf, 5 window, 6 scan
     // search range of the write: the whole array for a vector (src/pma.jl:196-213); for setindex!(mpcsc, v, row, col) on an
     // EXISTING live column, semaphore+1 .. end of partition for the insert path and semaphore .. end for the delete path
@@ -123,48 +177,61 @@ __device__ Plan pb_plan_one(KeyArr keys, const double* vals, const uint64_t* occ
             const int64_t ip1 = p1 + 1;
             const int64_t ne1 = d_next_empty(occ, p1, capacity);
             const int64_t ne2 = ne1 != 0 ? d_next_empty(occ, ne1, capacity) : 0;
+            fp_pos(p1 + 1, ne2 != 0 ? ne2 : capacity);
             why = 3;
             if (p1 >= 1 && ne1 != 0 && ne2 != 0) {
                 why = 5;
+                // the fallback window: the first level H whose aligned window holds both gaps and accepts the count after one and after two new cells
+                int64_t H = -1, A = 0, B = 0, cnt = 0;
                 for (int64_t h = 0; h <= height; ++h) {
                     const int64_t W = seg << h;
                     if (W > max_w) break;
-                    const int64_t A = ((ip1 - 1) / W) * W + 1, B = A + W - 1;
+                    A = ((ip1 - 1) / W) * W + 1; B = A + W - 1;
                     if (ne2 > B || ip1 >= B) continue;
-                    const int64_t cnt = pb_wave_count(occ, A, B, false);
-                    if (ctl->lo[h] <= cnt + 1 && cnt + 2 <= ctl->hi[h]) {
+                    cnt = pb_wave_count(occ, A, B, false);
+                    fp_cnt(A, B);
+                    if (ctl->lo[h] <= cnt + 1 && cnt + 2 <= ctl->hi[h]) { H = h; break; }
+                }
+                // (tight_only: the footprint-check build's sequential shadow asks whether the op, on the LIVE state, is still a leaf-accepted
+                // new column with the same two gaps — the fallback window only matters to the resolve step of a round)
+                if (H >= 0 || tight_only) {
+                    const int32_t lvl = H >= 0 ? (int32_t)H : 0x7f;
+                    if (H >= 0) {
                         pl.action = PB_NEWCOL; pl.pos = p1; pl.aux = ne1;
-                        pl.ws = A; pl.we = B; pl.count = (int32_t)h | ((int32_t)cnt << 8);      // level, and the cells of [A, B] before the round
+                        pl.ws = A; pl.we = B; pl.count = lvl | ((int32_t)cnt << 8);      // level, and the cells of [A, B] before the round
                         pl.lo = p1 < A ? p1 : A; pl.hi = B;
-                        // Both scans accepted by the LEAF of the new semaphore (the element lands in the same leaf): neither insert is
-                        // followed by a rebalance, the two shifted runs [p1 + 1, ne1] and [p1 + 2, ne2] are all that moves — wherever
-                        // the two gaps are inside [A, B] (a run that leaves the leaf pushes one cell out for the one that comes in).
-                        // The plan then carries that TIGHT hull, flag 0x80 and the leaf's cell count; the resolve step widens it to
-                        // [A, B] unless the leaf accepts every order of the window's ops that change its count (pb_is_leaf_only).
-                        const int64_t l0 = ((ip1 - 1) / seg) * seg + 1, l1 = l0 + seg - 1;
-                        if (seg > 64) {
-                            // (counts travel in 7 bits)
-                        } else if (ip1 < l1) {
-                            const int64_t cl = h == 0 ? cnt : pb_wave_count(occ, l0, l1, false);
-                            const int64_t c1 = cl + (ne1 <= l1 ? 1 : 0), c2 = c1 + (ne2 <= l1 ? 1 : 0);
-                            if (ctl->lo[0] <= c1 && c2 <= ctl->hi[0]) {
-                                pl.lo = p1; pl.hi = ne2;
-                                pl.count = (int32_t)h | 0x80 | ((int32_t)cl << 8);
-                            }
-                        } else if (l1 + seg <= capacity) {
-                            // The semaphore lands on the LAST slot of its leaf (the successor's semaphore moves on into the next one), the
-                            // element on the first slot of the next leaf: the first scan reads this leaf — its count unchanged —, the
-                            // second the next one, which receives whatever gaps of its own the two runs fill.  Two leaves to accept
-                            // (flag 0x8000 + the second count); without this a semaphore on slot 512 k needed a window of 1024 slots.
-                            const int64_t m1 = l1 + seg;
-                            const int64_t cl = pb_wave_count(occ, l0, l1, false), cm = pb_wave_count(occ, l1 + 1, m1, false);
-                            const int64_t c2 = cm + (ne1 <= m1 ? 1 : 0) + (ne2 <= m1 ? 1 : 0);
-                            if (ctl->lo[0] <= cl && cl <= ctl->hi[0] && ctl->lo[0] <= cm && c2 <= ctl->hi[0]) {
-                                pl.lo = p1; pl.hi = ne2;
-                                pl.count = (int32_t)h | 0x80 | ((int32_t)cl << 8) | 0x8000 | ((int32_t)cm << 16);
-                            }
+                    }
+                    // Both scans accepted by the LEAF of the new semaphore (the element lands in the same leaf): neither insert is
+                    // followed by a rebalance, the two shifted runs [p1 + 1, ne1] and [p1 + 2, ne2] are all that moves — wherever
+                    // the two gaps are inside [A, B] (a run that leaves the leaf pushes one cell out for the one that comes in).
+                    // The plan then carries that TIGHT hull, flag 0x80 and the leaf's cell count; the resolve step widens it to
+                    // [A, B] unless the leaf accepts every order of the window's ops that change its count (pb_is_leaf_only).
+                    const int64_t l0 = ((ip1 - 1) / seg) * seg + 1, l1 = l0 + seg - 1;
+                    bool tight = false;
+                    int32_t tcount = 0;
+                    if (seg > 64) {
+                        // (counts travel in 7 bits)
+                    } else if (ip1 < l1) {
+                        const int64_t cl = H == 0 ? cnt : pb_wave_count(occ, l0, l1, false);
+                        fp_cnt(l0, l1);
+                        const int64_t c1 = cl + (ne1 <= l1 ? 1 : 0), c2 = c1 + (ne2 <= l1 ? 1 : 0);
+                        if (ctl->lo[0] <= c1 && c2 <= ctl->hi[0]) { tight = true; tcount = lvl | 0x80 | ((int32_t)cl << 8); }
+                    } else if (l1 + seg <= capacity) {
+                        // The semaphore lands on the LAST slot of its leaf (the successor's semaphore moves on into the next one), the
+                        // element on the first slot of the next leaf: the first scan reads this leaf — its count unchanged —, the
+                        // second the next one, which receives whatever gaps of its own the two runs fill.  Two leaves to accept
+                        // (flag 0x8000 + the second count); without this a semaphore on slot 512 k needed a window of 1024 slots.
+                        const int64_t m1 = l1 + seg;
+                        const int64_t cl = pb_wave_count(occ, l0, l1, false), cm = pb_wave_count(occ, l1 + 1, m1, false);
+                        fp_cnt(l0, l1); fp_cnt(l1 + 1, m1);
+                        const int64_t c2 = cm + (ne1 <= m1 ? 1 : 0) + (ne2 <= m1 ? 1 : 0);
+                        if (ctl->lo[0] <= cl && cl <= ctl->hi[0] && ctl->lo[0] <= cm && c2 <= ctl->hi[0]) {
+                            tight = true; tcount = lvl | 0x80 | ((int32_t)cl << 8) | 0x8000 | ((int32_t)cm << 16);
                         }
-                        break;
+                    }
+                    if (tight) {
+                        pl.action = PB_NEWCOL; pl.pos = p1; pl.aux = ne1;
+                        pl.lo = p1; pl.hi = ne2; pl.count = tcount;
                     }
                 }
             }
@@ -182,14 +249,16 @@ __device__ Plan pb_plan_one(KeyArr keys, const double* vals, const uint64_t* occ
             } else {
                 const int64_t p = f.pos;
                 const int64_t ne = d_next_empty(occ, p, capacity);
+                fp_pos(p + 1, ne != 0 ? ne : capacity);
                 rlo = p >= 1 ? p : 1; rhi = p + 1 <= capacity ? p + 1 : capacity;
                 if (ne != 0) { pl.action = PB_INS_R; ip = p + 1; changed = ne; wlo = p + 1; whi = ne; pl.aux = ne; scan = true; }
                 else {
                     const int64_t pe = d_prev_empty(occ, p);
+                    fp_pos(pe != 0 ? pe : 1, p - 1);
                     // (the left branch is taken because NO slot behind p is free up to the end of the array: the plan has read all of them —
                     // an earlier delete anywhere behind p would have sent this insert to the right instead.  Rounds 2-4 kept rhi = p + 1: an
                     // insert near the end of a full tail and a delete of the last cell ran in one round, tools/fuzz.py run_same_leaf seed 2000.)
-                    if (pe != 0) { pl.action = PB_INS_L; ip = p; changed = pe; wlo = pe; whi = p; pl.aux = pe; scan = true; rhi = capacity; }
+                    if (pe != 0) { pl.action = PB_INS_L; ip = p; changed = pe; wlo = pe; whi = p; pl.aux = pe; scan = true; rhi = DSA_FP_REGRESS == 2 ? rhi : capacity; }
                 }
                 pl.pos = p; delta = 1;
             }
@@ -212,6 +281,7 @@ __device__ Plan pb_plan_one(KeyArr keys, const double* vals, const uint64_t* occ
                 ws = ((ip - 1) / W) * W + 1;
                 we = ws + W - 1;
                 c = pb_wave_count(occ, ws, we, false) + ((changed >= ws && changed <= we) ? delta : 0);
+                fp_cnt(ws, we);
                 if (ctl->lo[h] <= c && c <= ctl->hi[h]) { accepted = true; break; }
             }
             if (!accepted) {
@@ -278,6 +348,10 @@ __global__ __launch_bounds__(PL_BLOCK) void k_plan(const DevBufs* bufs, const Ct
                               : (int64_t)((uint64_t)(uint32_t)pl.count | ((uint64_t)(uint32_t)pl.action << 32));
             __hip_atomic_store(reinterpret_cast<int64_t*>(plans + w) + l, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+#ifdef DSA_FP_CHECK
+        __builtin_amdgcn_wave_barrier();
+        if (l == 0) reinterpret_cast<FpRec*>(plans + PB_GMAX)[w] = g_fpw[threadIdx.x >> 6];      // read by k_fp_pre, the next kernel of the round
+#endif
     }
     }
     // ---- resolve, by the workgroup that finishes last (a ticket; no second and third launch per round): folds the previous round's
@@ -405,7 +479,7 @@ __global__ __launch_bounds__(PL_BLOCK) void k_plan(const DevBufs* bufs, const Ct
                 // and, once in 2^CS / seg leaves, the first slot of the next cell — an op that changes that slot is chained THERE, not in
                 // the cell of the leaf's first slot (round 2-4 walked only that one: two deletes from one leaf, one of them of its last
                 // slot 237568 = 116 * 2048, ran in one round and left the leaf empty without the rebalance; tools/fuzz.py, FUZZ_BIG seed 91098).
-                const int cl0 = a >> CS, cl1 = b >> CS;
+                const int cl0 = a >> CS, cl1 = DSA_FP_REGRESS == 1 ? cl0 : b >> CS;
                 for (int cl = cl0; cl <= cl1; ++cl) {
                     if (cl != cl0 && bucket(cl) == bucket(cl0)) break;      // the same chain again
                     for (int e = sHead[bucket(cl)]; e >= 0; e = sNext[e]) {
@@ -474,6 +548,12 @@ __global__ __launch_bounds__(PL_BLOCK) void k_plan(const DevBufs* bufs, const Ct
         }
     }
     __syncthreads();
+#ifdef DSA_FP_CHECK
+    {   // the final footprints, for the brute-force re-derivation of this verdict (k_fp_pre)
+        FpIv* fiv = reinterpret_cast<FpIv*>(reinterpret_cast<FpRec*>(plans + PB_GMAX) + PB_GMAX);
+        for (int j = tid; j < Gc; j += PL_BLOCK) { fiv[j].lo = sIv[j].lo; fiv[j].hi = sIv[j].hi; }
+    }
+#endif
     {   // what the prefix's inserts / deletes do to the element count and the rebalance statistics: added to the control block ONCE, here
         // (k_apply's waves used to add them one by one: ~500 atomics per round on the same words)
         int dd = sC < sB ? sC : sB;
@@ -537,6 +617,7 @@ __global__ __launch_bounds__(PL_BLOCK) void k_plan(const DevBufs* bufs, const Ct
 // ---- apply ----------------------------------------------------------------------------------------------------------
 __device__ void pb_shift_right(KeyArr keys, double* vals, int64_t* sems, int64_t a, int64_t b) {      // cells [a, b-1] -> +1
     const int lane = lane_id();
+    fp_touch(a, b);
     for (int64_t hi = b - 1; hi >= a; hi -= 64) {
         const int64_t p = hi - lane;
         const bool act = p >= a;
@@ -551,6 +632,7 @@ __device__ void pb_shift_right(KeyArr keys, double* vals, int64_t* sems, int64_t
 // cells [a, b-1] -> +dist, highest chunk first (a chunk's stores land above every cell that is still to be read)
 __device__ void pb_shift_right_by(KeyArr keys, double* vals, int64_t* sems, int64_t a, int64_t b, int dist) {
     const int lane = lane_id();
+    fp_touch(a, b - 1 + dist);
     for (int64_t hi = b - 1; hi >= a; hi -= 64) {
         const int64_t p = hi - lane;
         const bool act = p >= a;
@@ -564,6 +646,7 @@ __device__ void pb_shift_right_by(KeyArr keys, double* vals, int64_t* sems, int6
 }
 __device__ void pb_shift_left(KeyArr keys, double* vals, int64_t* sems, int64_t a, int64_t b, bool last_occ) {   // cells [a+1, b] -> -1
     const int lane = lane_id();
+    fp_touch(a, b);
     for (int64_t lo = a + 1; lo <= b; lo += 64) {
         const int64_t p = lo + lane;
         const bool act = p <= b && (p < b || last_occ);
@@ -576,9 +659,11 @@ __device__ void pb_shift_left(KeyArr keys, double* vals, int64_t* sems, int64_t 
     }
 }
 __device__ __forceinline__ void pb_bit_set(uint64_t* occ, int64_t pos) {
+    fp_touch(pos, pos);
     atomicOr((unsigned long long*)(occ + ((pos - 1) >> 6)), 1ull << ((pos - 1) & 63));
 }
 __device__ __forceinline__ void pb_bit_clear(uint64_t* occ, int64_t pos) {
+    fp_touch(pos, pos);
     atomicAnd((unsigned long long*)(occ + ((pos - 1) >> 6)), ~(1ull << ((pos - 1) & 63)));
 }
 __device__ __forceinline__ uint32_t pb_wave_excl_scan(uint32_t v) {
@@ -598,6 +683,7 @@ __device__ void pb_wave_rebalance(KeyArr keys, double* vals, uint64_t* occ, int6
     const int lane = lane_id();
     const int64_t W = we - ws + 1, lo0 = ws - 1, w0 = lo0 >> 6;
     const SpreadGeom g = make_geom(W, m);
+    fp_touch(ws, we);
     if (W >= 64) {
         const int nwords = (int)(W >> 6);                          // <= 16
         const uint64_t myword = lane < nwords ? pb_occ_load(occ, w0 + lane) : 0ull;
@@ -673,13 +759,14 @@ __device__ int64_t pb_next_empty_live(const uint64_t* occ, int64_t from, int64_t
     uint64_t word = ~pb_occ_load(occ, w) & ~mask_lt((int)(from & 63));
     const int64_t lastw = (capacity - 1) >> 6;
     while (true) {
-        if (word) { const int64_t p = (w << 6) + __ffsll((unsigned long long)word); return p <= capacity ? p : 0; }
-        if (++w > lastw) return 0;
+        if (word) { const int64_t p = (w << 6) + __ffsll((unsigned long long)word); fp_touch(from + 1, p <= capacity ? p : capacity); return p <= capacity ? p : 0; }
+        if (++w > lastw) { fp_touch(from + 1, capacity); return 0; }
         word = ~pb_occ_load(occ, w);
     }
 }
 __device__ void pb_shift_right_live(KeyArr keys, double* vals, int64_t* sems, int64_t a, int64_t b) {      // cells [a, b-1] -> +1
     const int lane = lane_id();
+    fp_touch(a, b);
     for (int64_t hi = b - 1; hi >= a; hi -= 64) {
         const int64_t p = hi - lane;
         const bool act = p >= a;
@@ -726,8 +813,10 @@ __device__ void pb_apply_one(KeyArr keys, double* vals, uint64_t* occ, int64_t* 
     const int lane = lane_id();
     const int64_t seg = ctl->segment_capacity;
     int64_t delta = 0;
+    fp_reset();
     switch (pl.action) {
         case PB_OVERWRITE:
+            fp_touch(pl.pos, pl.pos);
             if (lane == 0) vals[pl.pos - 1] = op.v;
             break;
         case PB_INS_R: {                                           // _insert!, right branch  src/writes.jl:29-32
@@ -827,8 +916,181 @@ __global__ __launch_bounds__(PB_BLOCK) void k_apply(const DevBufs* bufs, Ctl* ct
     double* sV = reinterpret_cast<double*>(pb_lds + (size_t)(PB_BLOCK / 64) * PB_MAX_W * sizeof(int64_t)) + (size_t)wv * PB_MAX_W;
     const Plan pl = plans[w];
     const Op op = ops[i0 + w];
+#ifdef DSA_FP_CHECK
+    if (rs->tight & FP_MODE_SHADOW) return;                       // (the prefix was applied one op after the other by k_fp_pre)
+#endif
     pb_apply_one(keys, vals, occ, sems, col_keys, col_live, ctl, &const_cast<RoundState*>(rs)->pad, op, pl, sK, sV, true);
+#ifdef DSA_FP_CHECK
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {
+        FpRec* rec = reinterpret_cast<FpRec*>(const_cast<Plan*>(plans) + PB_GMAX) + w;
+        rec->tlo = g_fpw[wv].tlo; rec->thi = g_fpw[wv].thi;
+    }
+#endif
 }
+
+#ifdef DSA_FP_CHECK
+// do two plans of one op describe the same effect?  (footprints and the leaf counts carried for the resolver may differ)
+__device__ bool fp_same_plan(const Plan& a, const Plan& b, int64_t seg) {
+    if (a.action != b.action) return false;
+    switch (a.action) {
+        case PB_NOOP: case PB_BARRIER: return true;
+        case PB_OVERWRITE: return a.pos == b.pos;
+        case PB_NEWCOL: {
+            if (a.pos != b.pos || a.aux != b.aux) return false;
+            const bool ta = (a.count & 0x80) != 0, tb = (b.count & 0x80) != 0;
+            if (ta && tb) return a.hi == b.hi;                                      // both leaf-accepted: the same two gaps
+            return ta == tb && a.ws == b.ws && a.we == b.we && (a.count & 0x7f) == (b.count & 0x7f);
+        }
+        default:
+            if (a.pos != b.pos || a.aux != b.aux || a.ws != b.ws || a.we != b.we) return false;
+            return (a.we - a.ws + 1 == seg) || a.count == b.count;                  // a rebalance follows: it spreads `count` cells
+    }
+}
+__device__ __forceinline__ void fp_fault(RoundState* rs, int code) { atomicMax(&rs->pad, code); }
+
+// Between k_plan (+ resolve) and k_apply.  Mode 1: the brute-force re-derivation described at the top of this file.  Mode 2: the
+// sequential shadow — wave 0 re-plans every op of the prefix on the live state, compares, applies it.
+__global__ __launch_bounds__(PL_BLOCK) void k_fp_pre(const DevBufs* bufs, Ctl* ctl, const Op* ops, RoundState* rs, Plan* plans) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char pb_lds[];
+    if (rs->stop) return;
+    const int d = rs->d;
+    if (d <= 0) return;
+    const int mode = rs->tight;
+    const DevBufs db = *bufs;
+    const KeyArr keys{db.keys, db.wide, 0};
+    double* vals = db.vals; uint64_t* occ = db.occ;
+    int64_t* sems = db.sems; int64_t* col_keys = db.col_keys; uint8_t* col_live = db.col_live;
+    const int64_t i0 = rs->cursor, seg = ctl->segment_capacity;
+    const int tid = threadIdx.x;
+    if (mode & FP_MODE_SHADOW) {
+        if (tid >= 64) return;
+        int64_t* sK = reinterpret_cast<int64_t*>(pb_lds);
+        double* sV = reinterpret_cast<double*>(pb_lds + (size_t)PB_MAX_W * sizeof(int64_t));
+        for (int j = 0; j < d; ++j) {
+            const Op op = ops[i0 + j];
+            const Plan want = plans[j];
+            // (w = 0: the table entries of the earlier new columns exist by now; a leaf-accepted new column need not find its fallback window again)
+            const Plan live = pb_plan_one(keys, vals, occ, sems, col_keys, col_live, ctl, op, 0, PB_MAX_W, want.action == PB_NEWCOL && (want.count & 0x80));
+            if (!fp_same_plan(want, live, seg)) {
+                if (tid == 0) {
+                    printf("DSA_FP_CHECK shadow: op %lld (round op %d of %d; a %lld b %lld v %g) planned act %d pos %lld aux %lld win [%lld,%lld] count %d fp [%lld,%lld]"
+                           " | on the state left by the earlier ops of its round: act %d pos %lld aux %lld win [%lld,%lld] count %d fp [%lld,%lld]\n",
+                           (long long)(i0 + j), j, d, (long long)op.a, (long long)op.b, op.v, want.action, (long long)want.pos, (long long)want.aux,
+                           (long long)want.ws, (long long)want.we, want.count, (long long)want.lo, (long long)want.hi, live.action, (long long)live.pos,
+                           (long long)live.aux, (long long)live.ws, (long long)live.we, live.count, (long long)live.lo, (long long)live.hi);
+                    fp_fault(rs, 12);
+                }
+                return;                                              // nothing more is applied: the host fails the batch
+            }
+            pb_apply_one(keys, vals, occ, sems, col_keys, col_live, ctl, &rs->pad, op, want, sK, sV, true);
+            __builtin_amdgcn_s_waitcnt(0);                           // this wave's stores and atomics have been acknowledged (they are at the L2) ...
+            __builtin_amdgcn_s_dcache_inv();                         // ... and the next plan reads neither through a stale scalar cache
+            asm volatile("buffer_inv sc0" ::: "memory");            // nor through this CU's vector L1
+        }
+        return;
+    }
+    if (!(mode & FP_MODE_SETS)) return;
+    const FpRec* recs = reinterpret_cast<const FpRec*>(plans + PB_GMAX);
+    const FpIv* fiv = reinterpret_cast<const FpIv*>(recs + PB_GMAX);
+    __shared__ int32_t sLo[PB_GMAX], sHi[PB_GMAX], sC1[PB_GMAX], sC2[PB_GMAX], sWs[PB_GMAX], sWe[PB_GMAX], sTLo[PB_GMAX], sTHi[PB_GMAX];
+    __shared__ signed char sD1[PB_GMAX];
+    __shared__ unsigned char sTight[PB_GMAX];
+    for (int j = tid; j < d; j += PL_BLOCK) {
+        const Plan q = plans[j];
+        const bool leaf_only = pb_is_leaf_only(q.action, q.ws, q.we, seg, q.count);
+        const int dl = pb_delta(q.action, leaf_only);
+        sLo[j] = fiv[j].lo; sHi[j] = fiv[j].hi;
+        sD1[j] = (signed char)dl;
+        sC1[j] = dl != 0 ? (int32_t)pb_changed_slot(q.action, q.pos, q.aux) : 0;
+        sC2[j] = (q.action == PB_NEWCOL && leaf_only) ? (int32_t)q.hi : 0;
+        // an op that rebalances (or a new column that may) changes any bit of its window
+        const bool reb = (q.action == PB_NEWCOL && !leaf_only) ||
+                         ((q.action == PB_INS_R || q.action == PB_INS_L || q.action == PB_DELETE) && q.we - q.ws + 1 != seg);
+        sWs[j] = reb ? (int32_t)q.ws : 1; sWe[j] = reb ? (int32_t)q.we : 0;
+        sTight[j] = leaf_only ? 1 : 0;
+        // what the apply may WRITE or re-read live: a leaf-accepted insert / delete moves nothing but its shifted run — its tight hull,
+        // also when the resolve step widened the footprint to the leaf (the widening stands for the COUNT the plan read) —, everybody
+        // else anything inside the final footprint (a new column that was widened scans and rebalances live inside its window)
+        const bool hull_only = leaf_only && q.action != PB_NEWCOL;
+        sTLo[j] = hull_only ? (int32_t)q.lo : fiv[j].lo; sTHi[j] = hull_only ? (int32_t)q.hi : fiv[j].hi;
+    }
+    __syncthreads();
+    const int64_t lo0 = ctl->lo[0], hi0 = ctl->hi[0];
+    for (int j = tid; j < d; j += PL_BLOCK) {
+        const int32_t lo = sLo[j], hi = sHi[j];
+        const FpRec r = recs[j];
+        // (a) nothing an EARLIER op of the prefix writes lies in the final footprint of a later one (which holds everything that one read for
+        //     its decisions and everything it writes) — all pairs, no hash.  The converse — a later op writing where an earlier one only
+        //     COUNTED — is allowed: the earlier plan was made on the pre-round state either way, as the sequential order has it.
+        if (lo <= hi)
+            for (int i = 0; i < j; ++i)
+                if (sTLo[i] <= sTHi[i] && sTLo[i] <= hi && lo <= sTHi[i]) {
+                    printf("DSA_FP_CHECK sets: op %d of a prefix of %d writes inside [%d,%d] (footprint [%d,%d]); the later op %d has the footprint [%d,%d]\n", i, d,
+                           sTLo[i], sTHi[i], sLo[i], sHi[i], j, lo, hi);
+                    fp_fault(rs, 13);
+                }
+        if (sTLo[j] < lo || sTHi[j] > hi) { printf("DSA_FP_CHECK sets: op %d: write set [%d,%d] outside its footprint [%d,%d]\n", j, sTLo[j], sTHi[j], lo, hi); fp_fault(rs, 13); }
+        // (b) the occupancy runs the plan scanned for its shift target lie inside the footprint
+        if (r.rlo <= r.rhi && (r.rlo < lo || r.rhi > hi)) {
+            printf("DSA_FP_CHECK sets: op %d (act %d) scanned the occupancy of [%lld,%lld] for its shift target, its footprint is [%d,%d]\n", j, plans[j].action,
+                   (long long)r.rlo, (long long)r.rhi, lo, hi);
+            fp_fault(rs, 14);
+        }
+        // (c) every window whose count the plan consulted: inside the footprint and untouched by the others, or the leaf of a leaf-accepted
+        //     op whose thresholds hold whatever subset of the prefix's changes has happened
+        if (r.ncnt > FP_MAXCNT) { printf("DSA_FP_CHECK sets: op %d consulted %d windows (recorder holds %d)\n", j, r.ncnt, FP_MAXCNT); fp_fault(rs, 15); }
+        for (int c = 0; c < r.ncnt && c < FP_MAXCNT; ++c) {
+            const int32_t a = r.cnt[c][0], b = r.cnt[c][1];
+            const bool inside = a >= lo && b <= hi;
+            int ins = 0, del = 0, foreign = 0;
+            for (int i = 0; i < d; ++i) {
+                if (i != j && sWs[i] <= sWe[i] && sWs[i] <= b && a <= sWe[i]) ++foreign;       // somebody else's rebalance window reaches in
+                const int32_t c1 = sC1[i], c2 = sC2[i];
+                if (c1 >= a && c1 <= b) { if (sD1[i] > 0) ++ins; else ++del; if (i != j && inside) ++foreign; }
+                if (c2 >= a && c2 <= b) { ++ins; if (i != j && inside) ++foreign; }
+            }
+            if (inside) {
+                if (foreign) { printf("DSA_FP_CHECK sets: op %d counted [%d,%d] inside its footprint [%d,%d]; %d other ops of the prefix change it\n", j, a, b, lo, hi, foreign); fp_fault(rs, 16); }
+                continue;
+            }
+            if (sTight[j] && plans[j].action == PB_NEWCOL && b - a + 1 != seg) continue;      // the fallback window of a leaf-accepted new column: only consulted if the resolve step widens the op to it — then it is inside
+            if (!sTight[j] || b - a + 1 != seg) {
+                printf("DSA_FP_CHECK sets: op %d (act %d) counted [%d,%d] outside its footprint [%d,%d] and is not leaf-accepted\n", j, plans[j].action, a, b, lo, hi);
+                fp_fault(rs, 17);
+                continue;
+            }
+            if (foreign) { printf("DSA_FP_CHECK sets: leaf [%d,%d] of op %d lies in another op's rebalance window\n", a, b, j); fp_fault(rs, 18); continue; }
+            int64_t cnt = 0;                                                   // recounted from the pre-round bitmap
+            for (int64_t w = (a - 1) >> 6; w <= (b - 1) >> 6; ++w) cnt += popc64(occ[w] & word_range_mask(w, a - 1, b - 1));
+            if (!(cnt + ins <= hi0 && cnt - del >= lo0)) {
+                printf("DSA_FP_CHECK sets: leaf [%d,%d] of leaf-accepted op %d (act %d, footprint [%d,%d]) holds %lld cells; the prefix of %d ops inserts %d and deletes %d "
+                       "there: thresholds [%lld,%lld] do not hold for every order\n", a, b, j, plans[j].action, lo, hi, (long long)cnt, d, ins, del, (long long)lo0, (long long)hi0);
+                fp_fault(rs, 19);
+            }
+        }
+    }
+}
+// behind k_apply (mode 1): what every op of the prefix wrote, changed or re-read live lies inside its final footprint
+__global__ __launch_bounds__(PL_BLOCK) void k_fp_post(RoundState* rs, const Plan* plans, const Ctl* ctl) {
+    if (rs->stop || !(rs->tight & FP_MODE_SETS) || (rs->tight & FP_MODE_SHADOW)) return;
+    const int d = rs->d;
+    const int64_t seg = ctl->segment_capacity;
+    const FpRec* recs = reinterpret_cast<const FpRec*>(plans + PB_GMAX);
+    const FpIv* fiv = reinterpret_cast<const FpIv*>(recs + PB_GMAX);
+    for (int j = threadIdx.x; j < d; j += PL_BLOCK) {
+        const FpRec r = recs[j];
+        const Plan q = plans[j];
+        const bool hull_only = q.action != PB_NEWCOL && pb_is_leaf_only(q.action, q.ws, q.we, seg, q.count);      // (see k_fp_pre)
+        const int64_t tlo = hull_only ? q.lo : (int64_t)fiv[j].lo, thi = hull_only ? q.hi : (int64_t)fiv[j].hi;
+        if (r.tlo <= r.thi && (r.tlo < tlo || r.thi > thi)) {
+            printf("DSA_FP_CHECK sets: op %d (act %d) touched [%lld,%lld], it may write [%lld,%lld] (footprint [%d,%d])\n", j, q.action, (long long)r.tlo, (long long)r.thi,
+                   (long long)tlo, (long long)thi, fiv[j].lo, fiv[j].hi);
+            fp_fault(rs, 20);
+        }
+    }
+}
+#endif
 
 // ---- local rounds: the same plan / resolve / apply, by ONE workgroup, for phases with little parallelism --------------------------
 // A grid round costs two launches (~15 us) whatever it applies; while the conflict-free prefixes are short — a small, fast-growing
@@ -891,7 +1153,59 @@ __global__ __launch_bounds__(LR_BLOCK) void k_local_rounds(const DevBufs* bufs, 
         __syncthreads();
         const int dd = sD;
         if (dd == 0) { stop = 1; why = sPlan[0].count & 7; break; }       // the op at the cursor cannot be planned: the sequencer's
+#ifdef DSA_FP_CHECK
+        if (rs->tight & FP_MODE_SHADOW) {
+            // sequential shadow of the mini-round: op j is planned again on the state the ops before it left, compared, applied
+            for (int j = 0; j < dd; ++j) {
+                if (wv == j) {
+                    const Op op = ops[cursor + j];
+                    const Plan live = pb_plan_one(keys, vals, occ, sems, col_keys, col_live, ctl, op, 0, LR_MAX_W, sPlan[j].action == PB_NEWCOL && (sPlan[j].count & 0x80));
+                    if (!fp_same_plan(sPlan[j], live, ctl->segment_capacity)) {
+                        if (lane == 0) {
+                            printf("DSA_FP_CHECK shadow (local rounds): op %lld (%d of %d) planned act %d pos %lld aux %lld win [%lld,%lld] | live act %d pos %lld aux %lld win [%lld,%lld]\n",
+                                   (long long)(cursor + j), j, dd, sPlan[j].action, (long long)sPlan[j].pos, (long long)sPlan[j].aux, (long long)sPlan[j].ws, (long long)sPlan[j].we,
+                                   live.action, (long long)live.pos, (long long)live.aux, (long long)live.ws, (long long)live.we);
+                            fp_fault(rs, 22);
+                        }
+                    } else pb_apply_one(keys, vals, occ, sems, col_keys, col_live, ctl, &rs->pad, op, sPlan[j], sK, sV, false);
+                }
+                __builtin_amdgcn_s_waitcnt(0);
+                __syncthreads();
+                __builtin_amdgcn_s_dcache_inv();
+                asm volatile("buffer_inv sc0" ::: "memory");
+            }
+        } else {
+            // recorded sets: the run the plan scanned and what the apply touched lie inside the op's FULL footprint (what this kernel's
+            // all-pairs test works on), and those are pairwise disjoint
+            __shared__ FpRec sRec[LR_WAVES];
+            if (wv < dd && lane == 0) sRec[wv] = g_fpw[wv];
+            if (wv < dd) pb_apply_one(keys, vals, occ, sems, col_keys, col_live, ctl, &rs->pad, ops[cursor + wv], sPlan[wv], sK, sV, false);
+            __builtin_amdgcn_wave_barrier();
+            if (wv < dd && lane == 0) { sRec[wv].tlo = g_fpw[wv].tlo; sRec[wv].thi = g_fpw[wv].thi; }
+            __syncthreads();
+            if ((rs->tight & FP_MODE_SETS) && threadIdx.x == 0) {
+                const int64_t segc = ctl->segment_capacity;
+                int64_t flo[LR_WAVES], fhi[LR_WAVES];
+                for (int j = 0; j < dd; ++j) {
+                    const Plan& q = sPlan[j];
+                    flo[j] = q.lo; fhi[j] = q.hi;
+                    if (flo[j] <= fhi[j] && pb_is_leaf_only(q.action, q.ws, q.we, segc, q.count)) { if (q.ws < flo[j]) flo[j] = q.ws; if (q.we > fhi[j]) fhi[j] = q.we; }
+                    for (int i = 0; i < j; ++i)
+                        if (flo[i] <= fhi[i] && flo[j] <= fhi[j] && flo[i] <= fhi[j] && flo[j] <= fhi[i]) { printf("DSA_FP_CHECK sets (local rounds): ops %d and %d share slots\n", i, j); fp_fault(rs, 23); }
+                    const FpRec& r = sRec[j];
+                    if ((r.rlo <= r.rhi && (r.rlo < flo[j] || r.rhi > fhi[j])) || (r.tlo <= r.thi && (r.tlo < flo[j] || r.thi > fhi[j]))) {
+                        printf("DSA_FP_CHECK sets (local rounds): op %d (act %d) scanned [%lld,%lld] touched [%lld,%lld], footprint [%lld,%lld]\n", j, q.action,
+                               (long long)r.rlo, (long long)r.rhi, (long long)r.tlo, (long long)r.thi, (long long)flo[j], (long long)fhi[j]);
+                        fp_fault(rs, 24);
+                    }
+                    for (int c = 0; c < r.ncnt && c < FP_MAXCNT; ++c)
+                        if (r.cnt[c][0] < flo[j] || r.cnt[c][1] > fhi[j]) { printf("DSA_FP_CHECK sets (local rounds): op %d counted [%d,%d] outside [%lld,%lld]\n", j, r.cnt[c][0], r.cnt[c][1], (long long)flo[j], (long long)fhi[j]); fp_fault(rs, 25); }
+                }
+            }
+        }
+#else
         if (wv < dd) pb_apply_one(keys, vals, occ, sems, col_keys, col_live, ctl, &rs->pad, ops[cursor + wv], sPlan[wv], sK, sV, false);
+#endif
         cursor += dd; par_ops += dd; ++rounds;
         full_streak = dd == LR_WAVES ? full_streak + 1 : 0;
         single_streak = (dd == 1 && G > 1) ? single_streak + 1 : 0;
@@ -956,7 +1270,13 @@ static hipError_t configure_apply() {
 static hipError_t enqueue_round(const DevBufs* bufs, Ctl* ctl, const Op* ops, RoundState* rs, Plan* plans, hipStream_t stream) {
     const size_t lds = (size_t)(PB_BLOCK / 64) * PB_MAX_W * (sizeof(int64_t) + sizeof(double));
     hipLaunchKernelGGL(k_plan, dim3(PB_GMAX / (PL_BLOCK / 64)), dim3(PL_BLOCK), 0, stream, bufs, ctl, ops, rs, plans);
+#ifdef DSA_FP_CHECK
+    hipLaunchKernelGGL(k_fp_pre, dim3(1), dim3(PL_BLOCK), (size_t)PB_MAX_W * (sizeof(int64_t) + sizeof(double)), stream, bufs, ctl, ops, rs, plans);
+#endif
     hipLaunchKernelGGL(k_apply, dim3(PB_GMAX / 4), dim3(PB_BLOCK), lds, stream, bufs, ctl, ops, rs, plans);
+#ifdef DSA_FP_CHECK
+    hipLaunchKernelGGL(k_fp_post, dim3(1), dim3(PL_BLOCK), 0, stream, rs, plans, ctl);
+#endif
     return hipGetLastError();
 }
 

@@ -55,25 +55,28 @@ class AbiComm:
         idb = None
         if world > 1 or with_rccl:
             buf = (C.c_uint8 * 128)()
-            err = None
+            payload = None                      # (ok, bytes): the id, or the text of rank 0's failure — tagged, never told apart by length
             if rank == 0:
                 # a failure here (no librccl.so) must reach EVERY rank: the others are about to wait for the id, so rank 0 hands them
-                # the error text instead of leaving them in the broadcast
+                # the error text instead of leaving them in the broadcast (a single rank has nobody to tell: its error keeps its type)
                 try:
                     binding.call("comm_unique_id", buf)
+                    payload = (True, bytes(buf))
                 except Exception as e:              # noqa: BLE001 — re-raised on every rank below
-                    err = "rank 0: %s" % e
-            raw = (bytes(buf) if err is None else err.encode()) if rank == 0 else None
+                    if world == 1:
+                        raise
+                    payload = (False, ("rank 0: %s" % e).encode())
             if world > 1:
                 if bcast is None:
                     import torch.distributed as dist
-                    box = [raw]
+                    box = [payload]
                     dist.broadcast_object_list(box, src=0)
-                    raw = box[0]
+                    payload = box[0]
                 else:
-                    raw = bcast(raw)
-            if raw is None or len(raw) != 128:
-                raise RuntimeError("no RCCL unique id: %s" % (raw.decode(errors="replace") if raw else "rank 0 sent nothing"))
+                    payload = bcast(payload)
+            ok, raw = payload if payload is not None else (False, b"rank 0 sent nothing")
+            if not ok or len(raw) != 128:
+                raise RuntimeError("no RCCL unique id: %s" % (raw.decode(errors="replace") if not ok else "%d bytes instead of 128" % len(raw)))
             idb = (C.c_uint8 * 128).from_buffer_copy(raw)
         self.h = C.c_void_p()
         binding.call("comm_init", rank, world, idb, C.byref(self.h))      # collective over the ranks

@@ -1951,3 +1951,117 @@ def test_same_leaf_fuzz_scenarios_that_found_resolver_bugs(dsa, hip, oracle):
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz.py"), "4", "503700"], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "fuzz done" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
     assert int(r.stdout.strip().splitlines()[-1].split("scenarios")[0].split()[-1]) >= 10, r.stdout[-500:]
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_on_one_gpu_gloo_rehearsal(dsa, hip, oracle, tmp_path):
+    """The N > 1 branch of bench.py — the only code the driver's 8-GPU run executes that no multi-GPU box has ever run — as two fresh child
+    processes on the ONE GPU of the test box (DSA_BENCH_SAME_GPU=1: both ranks on cuda:0; DSA_BENCH_BACKEND=gloo: the process group
+    without RCCL, which needs one device per rank): config-4-shaped shards (200 000 rows, 25 000 columns per rank), the overlapped timed
+    steps, all three reduction schedules of the sum of y.  Checks the JSON line (rccl_ranks, collective_schedules, metric / config) and
+    y of every schedule against the CPU oracle's product of the whole matrix.  What stays unmeasured: RCCL itself and xGMI."""
+    import socket
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    ydump = str(tmp_path / "y.npz")
+    env = dict(os.environ, DSA_BENCH_SAME_GPU="1", DSA_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    rows, cpg, world = 200_000, 25_000, 2
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", str(world), "--config", "c4", "--rows", str(rows),
+           "--cols-per-gpu", str(cpg), "--steps", "3", "--warmup", "1", "--all-schedules", "--dump-y", ydump]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1, r.stdout[-2000:]               # rank 0 prints ONE line
+    d = json.loads(lines[0])
+    assert d["metric"] == "spmv_gbps_10M_nnz_pcsr" and d["n_gpus"] == world and d["rccl_ranks"] == world and d["steps"] == 3
+    assert d["scaling"] == "weak" and d["config"]["name"] == "c4" and d["config"]["sharding"] == "column-range x2"
+    assert d["value"] > 0 and d["roofline"]["frac"] > 0 and d["ms_per_step"] >= d["roofline"]["kernel_ms"] * 0.98
+    cs = d["collective_schedules"]
+    assert cs["local_spmv_ms"] > 0
+    for name in ("all_reduce", "rs_ag", "direct"):
+        assert isinstance(cs[name + "_ms"], float) and cs[name + "_ms"] > 0, (name, cs)
+    # y of every schedule == the oracle's product of the WHOLE matrix on the same inputs (the ranks' column ranges side by side)
+    n_total = world * cpg
+    I, J, V = [], [], []
+    for rk in range(world):
+        i_, j_, v_ = bench.c3_triplets(rows, cpg, 10, rk * cpg, seed_rows=8, seed_vals=9)
+        I.append(i_); J.append(j_); V.append(v_)
+    I, J, V = np.concatenate(I), np.concatenate(J), np.concatenate(V)
+    x = bench.unit12(10, n_total)
+    ref = dsa.dynamicsparse(I, J, V, rows, n_total, binding=oracle).mul(x, dense_out=rows)
+    got = np.load(ydump)
+    assert set(got.files) >= {"all_reduce", "rs_ag", "direct"}
+    for name in got.files:
+        np.testing.assert_allclose(got[name], ref, rtol=1e-12, atol=0, err_msg=name)
+
+
+@pytest.mark.gpu
+def test_release_library_ignores_development_switches(dsa, hip, oracle):
+    """include/dsa.h, release configuration: DSA_TIGHT=0 (no tight footprints: ~twice the rounds for uniformly random inserts) changes
+    nothing unless DSA_DEV=1 is set as well — a parity-critical path cannot be selected by whatever environment the host inherits."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import dsa_loader
+from util import splitmix_array, unit12_array
+dsa = dsa_loader.load(); hip = dsa.product()
+n0 = 700000
+v = dsa.dynamicsparsevec(np.arange(1, n0 + 1, dtype=np.int64) * 2, unit12_array(3, n0), binding=hip)
+odd = np.unique(1 + 2 * (np.array(splitmix_array(4, 60000), dtype=np.uint64) % np.uint64(700000)).astype(np.int64))[:50000]
+np.random.default_rng(4).shuffle(odd)
+v.set_batch(odd, unit12_array(4, len(odd)))
+inf = v.info()
+print("ROUNDS", inf["stat_par_rounds"], inf["nb_elements"], dsa.dev_switches(hip)[1])
+"""
+    res = {}
+    for tag, extra in (("default", {}), ("tight0_release", {"DSA_TIGHT": "0"}), ("tight0_dev", {"DSA_TIGHT": "0", "DSA_DEV": "1"})):
+        env = {k: v for k, v in os.environ.items() if k not in ("DSA_DEV", "DSA_TIGHT")}
+        env.update(extra)
+        r = subprocess.run([sys.executable, "-c", code, root], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+        f = [ln for ln in r.stdout.splitlines() if ln.startswith("ROUNDS")][0].split()
+        res[tag] = (int(f[1]), int(f[2]), f[3])
+    assert res["default"][0] == res["tight0_release"][0] and res["tight0_release"][2] == "False", res
+    assert res["tight0_dev"][0] > 1.3 * res["default"][0] and res["tight0_dev"][2] == "True", res
+    assert res["default"][1] == res["tight0_dev"][1]
+
+
+def _run_child(cmd, env, timeout=600):
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout, cwd=root)
+
+
+@pytest.mark.gpu
+def test_footprint_check_build_fires_on_the_two_resolver_bugs_of_round_4_and_is_clean_on_the_tree(dsa, hip, oracle):
+    """csrc/parbatch.hip, -DDSA_FP_CHECK (libdsa_hip_fpcheck.so): the soundness of a round of the batch-parallel writes checked mechanically —
+    mode 1 re-derives the resolver's verdict by brute force from what every plan literally scanned and counted and every apply touched, mode 2
+    applies the prefix one op after the other and requires each op's plan, recomputed on the live state, to equal the plan the round was
+    resolved on.  (a) Both modes FAIL on the two libraries that re-introduce the resolver defects of round 4 (DSA_FP_REGRESS=1: the leaf
+    walk of one hash cell — two deletes from one leaf in one round; =2: the footprint of a left-falling insert ending at p + 1), on the
+    scenarios that found them.  (b) Both modes are clean on the tree: the same scenarios, the default fuzzer mix, the same-leaf scenarios."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "dynamicsparsearrays.jl_amd", "csrc")
+    fuzz = [sys.executable, os.path.join(root, "tools", "fuzz.py")]
+    leaf_test = [sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_hip_parity.py"), "-m", "gpu", "-x", "-q", "-k", "two_deletes_from_a_leaf"]
+    for mode in ("1", "2"):
+        env = dict(os.environ, DSA_LIBRARY=os.path.join(csrc, "libdsa_hip_fpcheck_bug1.so"), DSA_FP_MODE=mode)
+        r = _run_child(leaf_test, env)
+        assert r.returncode != 0 and "DSA_FP_CHECK" in r.stdout + r.stderr, (mode, r.stdout[-1500:])
+        env = dict(os.environ, DSA_LIBRARY=os.path.join(csrc, "libdsa_hip_fpcheck_bug2.so"), DSA_FP_MODE=mode, FUZZ_ONLY="leaf")
+        r = _run_child(fuzz + ["8", "1990"], env)
+        assert r.returncode != 0 and "DSA_FP_CHECK" in r.stdout + r.stderr, (mode, r.stdout[-1500:])
+        env = dict(os.environ, DSA_LIBRARY=os.path.join(csrc, "libdsa_hip_fpcheck.so"), DSA_FP_MODE=mode)
+        r = _run_child(leaf_test, env)
+        assert r.returncode == 0, (mode, r.stdout[-2500:])
+        r = _run_child(fuzz + ["6", "1990"], dict(env, FUZZ_ONLY="leaf"))
+        assert r.returncode == 0 and "fuzz done" in r.stdout and "DSA_FP_CHECK" not in r.stdout, (mode, r.stdout[-2500:] + r.stderr[-1500:])
+        r = _run_child(fuzz + ["15", str(31000 + int(mode))], env)
+        assert r.returncode == 0 and "fuzz done" in r.stdout and "DSA_FP_CHECK" not in r.stdout, (mode, r.stdout[-2500:] + r.stderr[-1500:])
