@@ -420,6 +420,374 @@ __global__ __launch_bounds__(M3_THREADS) void k_append_model3(uint64_t* occ, Ctl
 }
 
 
+// =====================================================================================================================================
+// Model v5: TYPED append runs (semaphore cells) on 8-slot segments — BASELINE config 5's colmajor orientation: a matrix grown from the
+// empty one keeps its 8-slot segments for life (_extend! doubles the segment COUNT, src/pma.jl:143-151).
+//
+// Why the count-only tables above do not apply.  The leaf threshold of an 8-slot segment leaves ONE free slot (hi[0] = 7).  When that
+// slot is the last one of the array and the next cell is a semaphore — which always goes to the last slot, with a shift to the left
+// (addpartition!, src/pcsr.jl:99-112 -> _insert!, src/writes.jl:34-38) — the shift finds its gap OUTSIDE the leaf: one cell crosses the
+// leaf boundary, the leaf keeps its 7 cells and accepts, no level is scanned ("cross" below).  So the time a leaf epoch takes depends on
+// the cell types, and so does everything above it.  What stays true (tools/scratch/model5_proto.py, checked bit for bit against the
+// oracle on columns of 1..20 cells): the state is the suffix cell count of every level plus the leaf state (s cells, g free slots behind
+// the tail); an epoch is the ops until the leaf holds 8 cells — 8 - s of them, one more when all free slots are behind the tail
+// (s + g == 8) and the op that meets the leaf at 7 cells is a semaphore —; it ends with the rebalance of the first level >= 1 that
+// accepts its count (every level below is full), which resets counts and leaf state to the closed form of spread!; a cross op adds a
+// cell to every suffix window that holds the gap it fills (level >= kstar) and to none below.
+//
+// At the densities of an append run the suffix sits at its thresholds: 12 800 epochs per 17 000 cells, spread over ALL levels
+// (13 / 21 / 26 / 20 / 8 / 5 / 3 % at levels 1..7).  Tables over (level, count) do not skip them — the epoch sequence IS the process —
+// so this kernel makes the epoch cheap instead: ONE wave, lane <-> level, every loop-carried value in registers, ~45 instructions and
+// one LDS read per epoch and no divergent branch on the common path:
+//   * counts: one v_add; the accepting level: two compares + a ballot + s_ff1; its count: one v_readlane;
+//   * the reset below the accepting level: ONE ds_read_u16 per lane from a table row R[k][c] = (s | g << 8, count of level 1, ...,
+//     count of level k - 1) — rows for every level whose windows fit the table (<= 4096 slots: 99.9 % of the events), filled by the
+//     whole workgroup in front of the loop (a row = one fp64 division + k closed-form counts); wider events compute their row by lanes;
+//   * the semaphores of the run as a list of cell indices in LDS (one read per semaphore, issued an epoch ahead).
+// Nothing is committed before the loop has ended: the surviving rebalance of every level (the last one no wider one followed) is written
+// as its spread! pattern, widest first, like the count-only model.  The trailing partial epoch — and an epoch that ends in _extend! —
+// is NOT consumed: k_append_run replays those < 9 cells on the bitmap.
+constexpr int M5_TAB_U16 = 56 * 1024;            // 112 KB of table entries
+constexpr int M5_MAX_SEMS = 8192;                // 32 KB: semaphore cells of the run (a longer run is consumed up to that one)
+constexpr int64_t M5_MIN_RUN = 64;
+
+__device__ __forceinline__ uint32_t m5_block_excl_scan(uint32_t v, uint32_t* wsum, int tid, int lane, int wave, uint32_t* total) {
+    uint32_t x = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
+    if (lane == 63) wsum[wave] = x;
+    __syncthreads();
+    uint32_t woff = 0, tot = 0;
+    for (int k = 0; k < M3_THREADS / 64; ++k) { const uint32_t w = wsum[k]; if (k < wave) woff += w; tot += w; }
+    __syncthreads();
+    *total = tot;
+    return woff + x - v;
+}
+
+__global__ __launch_bounds__(M3_THREADS) void k_append_model5(uint64_t* occ, Ctl* ctl, int64_t R, const uint64_t* flags, const int64_t* d_T,
+                                                              int64_t* out, const int use_asm) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char m3_lds[];
+    uint16_t* Tab = reinterpret_cast<uint16_t*>(m3_lds);
+    uint32_t* Sem = reinterpret_cast<uint32_t*>(Tab + M5_TAB_U16);
+    __shared__ M3Shared sh;
+    __shared__ uint32_t sWsum[M3_THREADS / 64];
+    __shared__ int32_t sOff[64];                 // rowbase[k] - lo[k] * k (u16 units): the row of (k, c) starts at sOff[k] + c * k
+    __shared__ int32_t sNSem, sKT, sEndEff;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t t_begin = wall_clock64();
+    const int64_t cap = ctl->capacity, seg = ctl->segment_capacity;
+    const int H = (int)ctl->height;
+    const int64_t end = flags != nullptr ? d_T[0] : R;
+    int why = 0;
+    if (flags == nullptr || seg != 8 || ctl->lo[0] != 1 || ctl->hi[0] != 7) why = 1;
+    else if (cap < 256 || cap > (1ll << 30) || (seg << H) != cap || H + 1 > MAX_LEVELS || H < 2) why = 2;
+    else if (end < M5_MIN_RUN || end >= (1ll << 30)) why = 3;
+    if (why) {
+        if (tid == 0) { out[0] = 0; out[1] = 0; out[2] = why; }
+        return;
+    }
+    if (tid < 64) {
+        sh.W[tid] = tid <= H ? (int32_t)(seg << tid) : 0;
+        sh.lo[tid] = tid <= H ? (int32_t)ctl->lo[tid] : 1;
+        sh.hi[tid] = tid <= H ? (int32_t)ctl->hi[tid] : 0;
+        sh.cnt[tid] = 0; sh.ev_c[tid] = 0; sh.n[tid] = 0; sh.base[tid] = 0; sh.cmin[tid] = 0; sOff[tid] = 0;
+    }
+    if (tid < 40) sh.bk[tid] = 0ull;
+    if (tid == 0) { sh.H = H; sh.seg = 8; sh.bail = 0; sh.consumed = 0; sh.leaf_ops = 0; sh.ended = 0; sh.ev_mask = 0ull; sh.reb = 0ull; sh.slots = 0ull; sh.top_events = 0; sh.Lp = 0; }
+    __syncthreads();
+    m3_suffix_counts(sh, occ, cap, seg, H, tid, lane);
+    const int64_t nwords = cap >> 6;
+    // ---- which levels get table rows: a row of level k = k entries, one row per accepted count ----
+    if (tid == 0) {
+        int KT = 0, sum = 0;
+        for (int k = 1; k <= H; ++k) {
+            const int nk = sh.hi[k] >= sh.lo[k] ? sh.hi[k] - sh.lo[k] + 1 : 0;
+            if (sum + nk * k > M5_TAB_U16) break;
+            sh.base[k] = sum; sh.n[k] = nk; sOff[k] = sum - sh.lo[k] * k;
+            sum += nk * k;
+            KT = k;
+        }
+        sKT = KT;
+        if (sh.cnt[0] < 1 || sh.cnt[0] > 7) sh.bail = 4;         // the tail is not in the last leaf (or the leaf is full): not this model's run
+    }
+    __syncthreads();
+    if (sh.bail) {
+        if (tid == 0) { out[0] = 0; out[1] = 0; out[2] = sh.bail; }
+        return;
+    }
+    const int KT = sKT;
+    const int64_t t_counts = wall_clock64();
+    // ---- the table rows: one thread per row — make_geom (the one fp64 division), the leaf state, the counts of the levels below ----
+    for (int k = 1; k <= KT; ++k) {
+        const int nk = sh.n[k], lok = sh.lo[k], Wk = sh.W[k], bk = sh.base[k];
+        for (int r = tid; r < nk; r += M3_THREADS) {
+            const int c = lok + r;
+            const SpreadGeom g = make_geom(Wk, c);
+            const int s0 = m3_suffix_cells(g, Wk, 8);
+            const int g0 = (int)(Wk - spread_last_cell(g));
+            uint16_t* row = Tab + bk + r * k;
+            row[0] = (uint16_t)((8 - s0) | ((s0 + g0 == 8 ? 8 - s0 : 0) << 4));      // the leaf state as the epoch loop reads it (see e0 there)
+            if (s0 < 1 || s0 > 7 || g0 < 0 || g0 > 8 - s0) sh.bail = 6;         // (cannot happen: the last gap of spread! lies on one of the last two slots)
+            for (int i = 1; i < k; ++i) row[i] = (uint16_t)m3_suffix_cells(g, Wk, sh.W[i]);
+        }
+    }
+    // ---- the semaphore cells of the run: their cell indices, ascending, as a list ----
+    {
+        const int64_t fwords = (end + 63) >> 6;
+        uint32_t base_n = 0;
+        int32_t end_eff = (int32_t)end;
+        for (int64_t w0 = 0; w0 < fwords; w0 += M3_THREADS) {
+            const int64_t w = w0 + tid;
+            uint64_t f = w < fwords ? flags[w] : 0ull;
+            if (w < fwords && ((w + 1) << 6) > end) f &= mask_lt((int)(end - (w << 6)));
+            uint32_t tot = 0;
+            const uint32_t at = base_n + m5_block_excl_scan((uint32_t)popc64(f), sWsum, tid, lane, wave, &tot);
+            uint32_t q = at;
+            while (f) {
+                const int b = __ffsll((unsigned long long)f) - 1;
+                f &= f - 1;
+                if (q < (uint32_t)M5_MAX_SEMS) Sem[q] = (uint32_t)((w << 6) + b);
+                ++q;
+            }
+            base_n += tot;
+            if (base_n > (uint32_t)M5_MAX_SEMS) break;            // (uniform: base_n is the same in every thread)
+        }
+        __syncthreads();
+        if (tid == 0) {
+            // more semaphores than the list holds: the run is consumed up to the first one that did not fit
+            if (base_n > (uint32_t)M5_MAX_SEMS) { end_eff = (int32_t)Sem[M5_MAX_SEMS - 1]; base_n = M5_MAX_SEMS - 1; }
+            sNSem = (int32_t)base_n; sEndEff = end_eff;
+        }
+    }
+    __syncthreads();
+    if (sh.bail) {
+        if (tid == 0) { out[0] = 0; out[1] = 0; out[2] = sh.bail; }
+        return;
+    }
+    const int64_t t_tables = wall_clock64();
+    // ---- the epochs: wave 0, lane <-> level ----
+    if (wave == 0) {
+        const int end32 = ufl(sEndEff), nsem = ufl(sNSem), KTu = ufl(KT);
+        // per-lane constants of the level; lanes that are no level (0, > H) never accept and never hold a gap
+        const bool lvl = lane >= 1 && lane <= H;
+        const int lol = lvl ? sh.lo[lane] : 0x7fffffff;
+        const unsigned rngl = lvl ? (unsigned)(sh.hi[lane] - sh.lo[lane]) : 0u;
+        const int Wm1 = lvl ? sh.W[lane] - 1 : (int)0x80000000;
+        const int Wl = sh.W[lane];
+        const int off2 = 2 * sOff[lane] + (int)(reinterpret_cast<uintptr_t>(Tab) & 0xffffffffu);      // byte address of "row 0" of the level (LDS)
+        const int lane2 = 2 * lane;
+        int cnt = sh.cnt[lane], evc = 0, evt = -1;
+        unsigned nev = 0;                                  // events of the level (lane <-> level): rebalances and window slots at the end
+        // leaf state as the table rows carry it: e0 = (8 - s) | (jx + 1) << 4, jx = 7 - s when every free slot is behind the tail (a semaphore
+        // that meets the leaf at 7 cells then shifts across the leaf boundary), jx + 1 = 0 otherwise
+        int e0;
+        {
+            const int s0 = sh.cnt[0];
+            const uint32_t leafbits = (uint32_t)(occ[nwords - 1] >> 56);
+            const int g0 = __clz((int)leafbits) - 24;
+            e0 = ufl((8 - s0) | ((s0 + g0 == 8 ? 8 - s0 : 0) << 4));
+        }
+        int t = 0, sp = 0, bail = 0;
+        constexpr int NOSEM = 0x7fffffff;
+        const int semb = ufl((int)(reinterpret_cast<uintptr_t>(Sem) & 0xffffffffu));      // LDS byte address of the semaphore list
+        int ns = nsem > 0 ? ufl((int)Sem[0]) : NOSEM;
+        int ns_next = nsem > 1 ? ufl((int)Sem[1]) : NOSEM;
+        // The common epoch — no cross-leaf shift, a level with a table row accepts, the next semaphore still ahead — is a hand-scheduled
+        // block of 36 instructions (the compiler's version of the same loop: 55, with its exits merged through mask registers; measured
+        // 165 ns per epoch against ~90): one LDS read per epoch, issued as early as its address is known, the bookkeeping of the
+        // rebalanced level under its latency.  Everything else leaves the block with a status and takes ONE epoch of the generic C++
+        // path below: 1 cross-leaf shift, 2 event above the tables; 0 = the run's end or _extend!.  The next semaphore is taken from the list inside the block.
+        // Registers: lane <-> level in cnt / evc / evt / nev; e0, t, ns wave-uniform in SGPRs.  Hazards (gfx950): lane selects of
+        // v_readlane come from SALU results, every VALU-written SGPR is consumed by SALU or after >= 2 instructions.
+        for (;;) {
+            // the next semaphore at or behind cell t (semaphores are at least two cells apart — a new column comes with its first
+            // element —, epochs at most 9 cells long: a step or two)
+            while (ns < t) {
+                ++sp;
+                ns = ns_next;
+                ns_next = sp + 1 < nsem ? ufl((int)Sem[sp + 1]) : NOSEM;
+            }
+            int status = 4;
+            if (use_asm) {
+                int r_ln, r_tmp, r_tn, r_k, r_c, r_ra;
+                int v_cn, v_t, v_nv;
+                asm volatile(
+                    "L_m5_top_%=:\n\t"
+                    "s_and_b32 %[ln], %[e0], 15\n\t"
+                    "s_lshr_b32 %[tmp], %[e0], 4\n\t"
+                    "s_sub_i32 %[tn], %[ns], %[t]\n\t"
+                    "s_add_i32 %[tn], %[tn], 1\n\t"
+                    "s_cmp_eq_u32 %[tn], %[tmp]\n\t"
+                    "s_cbranch_scc1 L_m5_x1_%=\n\t"
+                    "s_add_i32 %[tn], %[t], %[ln]\n\t"
+                    "s_cmp_gt_i32 %[tn], %[end]\n\t"
+                    "s_cbranch_scc1 L_m5_x0_%=\n\t"
+                    "v_add_u32_e32 %[cn], %[ln], %[cnt]\n\t"
+                    "v_sub_u32_e32 %[vt], %[cn], %[lol]\n\t"
+                    "v_cmp_le_u32_e32 vcc, %[vt], %[rng]\n\t"
+                    "s_cbranch_vccz L_m5_x0_%=\n\t"
+                    "s_ff1_i32_b64 %[k], vcc\n\t"
+                    "s_cmp_gt_i32 %[k], %[kt]\n\t"
+                    "s_cbranch_scc1 L_m5_x2_%=\n\t"
+                    "v_readlane_b32 %[c], %[cn], %[k]\n\t"
+                    "v_readlane_b32 %[ra], %[off2], %[k]\n\t"
+                    "s_lshl_b32 %[tmp], %[k], 1\n\t"
+                    "s_mul_i32 %[tmp], %[tmp], %[c]\n\t"
+                    "s_add_i32 %[ra], %[ra], %[tmp]\n\t"
+                    "v_add_u32_e32 %[vt], %[ra], %[lane2]\n\t"
+                    "ds_read_u16 %[nv], %[vt]\n\t"
+                    "v_cmp_eq_u32_e32 vcc, %[k], %[lane]\n\t"
+                    "v_mov_b32_e32 %[vt], %[c]\n\t"
+                    "v_cndmask_b32_e32 %[evc], %[evc], %[vt], vcc\n\t"
+                    "v_mov_b32_e32 %[vt], %[tn]\n\t"
+                    "v_cndmask_b32_e32 %[evt], %[evt], %[vt], vcc\n\t"
+                    "v_addc_co_u32_e32 %[nev], vcc, 0, %[nev], vcc\n\t"
+                    "v_cmp_gt_u32_e32 vcc, %[k], %[lane]\n\t"
+                    "s_mov_b32 %[t], %[tn]\n\t"
+                    "s_waitcnt lgkmcnt(0)\n\t"
+                    "v_cndmask_b32_e32 %[cnt], %[cn], %[nv], vcc\n\t"
+                    "v_readfirstlane_b32 %[e0], %[nv]\n\t"
+                    "s_cmp_lt_i32 %[ns], %[t]\n\t"
+                    "s_cbranch_scc0 L_m5_top_%=\n"
+                    // the semaphore has been passed: the next one from the list (one LDS read per semaphore, one in 13 epochs)
+                    "L_m5_adv_%=:\n\t"
+                    "s_mov_b32 %[ns], %[nsn]\n\t"
+                    "s_add_i32 %[sp], %[sp], 1\n\t"
+                    "s_add_i32 %[tmp], %[sp], 1\n\t"
+                    "s_mov_b32 %[nsn], 0x7fffffff\n\t"
+                    "s_cmp_lt_i32 %[tmp], %[nsem]\n\t"
+                    "s_cbranch_scc0 L_m5_chk_%=\n\t"
+                    "s_lshl_b32 %[tmp], %[tmp], 2\n\t"
+                    "s_add_i32 %[tmp], %[tmp], %[semb]\n\t"
+                    "v_mov_b32_e32 %[vt], %[tmp]\n\t"
+                    "ds_read_b32 %[vt], %[vt]\n\t"
+                    "s_waitcnt lgkmcnt(0)\n\t"
+                    "v_readfirstlane_b32 %[nsn], %[vt]\n"
+                    "L_m5_chk_%=:\n\t"
+                    "s_cmp_lt_i32 %[ns], %[t]\n\t"
+                    "s_cbranch_scc1 L_m5_adv_%=\n\t"
+                    "s_branch L_m5_top_%=\n"
+                    "L_m5_x0_%=:\n\t"
+                    "s_mov_b32 %[st], 0\n\t"
+                    "s_branch L_m5_out_%=\n"
+                    "L_m5_x1_%=:\n\t"
+                    "s_mov_b32 %[st], 1\n\t"
+                    "s_branch L_m5_out_%=\n"
+                    "L_m5_x2_%=:\n\t"
+                    "s_mov_b32 %[st], 2\n"
+                    "L_m5_out_%=:\n\t"
+                    : [st] "=&s"(status), [e0] "+s"(e0), [t] "+s"(t), [ns] "+s"(ns), [nsn] "+s"(ns_next), [sp] "+s"(sp), [cnt] "+v"(cnt), [evc] "+v"(evc), [evt] "+v"(evt), [nev] "+v"(nev),
+                      [ln] "=&s"(r_ln), [tmp] "=&s"(r_tmp), [tn] "=&s"(r_tn), [k] "=&s"(r_k), [c] "=&s"(r_c), [ra] "=&s"(r_ra),
+                      [cn] "=&v"(v_cn), [vt] "=&v"(v_t), [nv] "=&v"(v_nv)
+                    : [nsem] "s"(nsem), [semb] "s"(semb), [end] "s"(end32), [kt] "s"(KTu), [lol] "v"(lol), [rng] "v"(rngl), [off2] "v"(off2), [lane2] "v"(lane2), [lane] "v"(lane)
+                    : "vcc", "scc", "memory");
+                if (status == 0) break;                  // (the generic path would break at the same test: the trailing epoch / _extend! is k_append_run's)
+            }
+            // ---- one epoch, every case ----
+            const int ln0 = e0 & 15, jxp1 = e0 >> 4;
+            const bool cross = ns - t + 1 == jxp1;                   // (jx + 1 = 0: never — ns >= t)
+            const int ln = ln0 + (cross ? 1 : 0);
+            const int tn = t + ln;
+            if (tn > end32) break;                                   // the trailing partial epoch: k_append_run's
+            int cn = cnt + ln;
+            if (__builtin_expect(cross, 0)) {
+                // the gap the shift fills: the first level whose suffix window has a free slot besides the last one; the windows below
+                // it lose the cell that crosses their left boundary for the one that comes in
+                const unsigned long long fm = __builtin_amdgcn_ballot_w64(cnt + (jxp1 - 1) < Wm1);
+                if (fm == 0ull) { bail = 8; break; }
+                const int kstar = __ffsll(fm) - 1;
+                if (lane < kstar) cn -= 1;
+            }
+            const unsigned long long am = __builtin_amdgcn_ballot_w64((unsigned)(cn - lol) <= rngl);
+            if (am == 0ull) break;                                   // no level accepts: _extend! — the epoch is k_append_run's too
+            const int kacc = __ffsll(am) - 1;
+            const int c = rl(cn, kacc);
+            int nv;
+            if (__builtin_expect(kacc <= KTu, 1)) {
+                const int rowaddr = rl(off2, kacc) + c * (kacc << 1);
+                nv = (int)*reinterpret_cast<const __attribute__((address_space(3))) uint16_t*>((uintptr_t)(unsigned)(rowaddr + lane2));
+            } else {
+                // an event above the tables (windows beyond 4096 slots: one in a thousand): its row by lanes
+                const int Wk = rl(Wl, kacc);
+                const SpreadGeom gg = make_geom(Wk, c);
+                const int s1 = m3_suffix_cells(gg, Wk, 8), g1 = (int)(Wk - spread_last_cell(gg));
+                nv = lane == 0 ? ((8 - s1) | ((s1 + g1 == 8 ? 8 - s1 : 0) << 4)) : (lane < kacc ? m3_suffix_cells(gg, Wk, Wl) : 0);
+            }
+            t = tn;
+            {   // bookkeeping of the level that was rebalanced (independent of the table read: issued under its latency)
+                const bool me = lane == kacc;
+                evc = me ? c : evc;
+                evt = me ? tn : evt;
+                nev += me ? 1u : 0u;
+            }
+            cnt = lane < kacc ? nv : cn;
+            e0 = ufl(nv);
+        }
+        // rebalances and window slots: per level, summed over the lanes
+        unsigned long long slots = (unsigned long long)nev * (unsigned long long)(lvl ? Wl : 0);
+        unsigned epochs = nev;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { slots += __shfl_xor(slots, o, 64); epochs += __shfl_xor(epochs, o, 64); }
+        sh.ev_c[lane] = evc;
+        // the surviving rebalance of every level: no wider one came later
+        int later = -1;
+        for (int k = H; k >= 1; --k) {
+            const int e = rl(evt, k);
+            if (lane == 0 && e > later) sh.ev_mask |= 1ull << k;
+            later = e > later ? e : later;
+        }
+        if (lane == 0) {
+            sh.consumed = t; sh.leaf_ops = 0; sh.ended = 0; sh.reb = (unsigned long long)epochs; sh.slots = slots; sh.top_events = epochs;
+            if (bail) sh.bail = bail;
+        }
+        wave_lds_sync();
+        // ---- the last word: the narrowest surviving patterns (no trailing ops: they were not consumed) ----
+        if (lane == 0 && !sh.bail) {
+            const unsigned long long evmask = sh.ev_mask;
+            uint64_t lw = occ[nwords - 1];
+            for (int k = H; k >= 1; --k) {
+                if (!((evmask >> k) & 1ull)) continue;
+                const int Wk = sh.W[k];
+                const SpreadGeom gk = make_geom(Wk, sh.ev_c[k]);
+                if (Wk >= 64) lw = spread_word_bits(gk, (Wk >> 6) - 1);
+                else {
+                    const uint64_t m = (1ull << Wk) - 1ull;
+                    lw = (lw & ~(m << (64 - Wk))) | ((spread_word_bits(gk, 0) & m) << (64 - Wk));
+                }
+            }
+            sh.last_word = lw;
+        }
+    }
+    __syncthreads();
+    if (sh.bail || sh.consumed == 0) {
+        if (tid == 0) { out[0] = 0; out[1] = 0; out[2] = sh.bail ? sh.bail : 9; }
+        return;
+    }
+    const int64_t t_driver = wall_clock64();
+    // ---- commit: the surviving rebalance of every level, each up to where the next narrower one (or the last word) takes over ----
+    {
+        const unsigned long long evmask = sh.ev_mask;
+        int64_t w_low = 64;
+        for (int k = 1; k <= H; ++k) {
+            if (!((evmask >> k) & 1ull)) continue;
+            const int64_t Wk = sh.W[k];
+            if (Wk <= 64) continue;
+            const SpreadGeom g = make_geom(Wk, sh.ev_c[k]);
+            const int64_t w0 = (cap - Wk) >> 6, nw = (Wk - w_low) >> 6;
+            for (int64_t tw = tid; tw < nw; tw += M3_THREADS) occ[w0 + tw] = spread_word_bits(g, (int)tw);
+            w_low = Wk;
+        }
+        if (tid == 0) {
+            occ[nwords - 1] = sh.last_word;
+            ctl->nb_elements += sh.consumed;
+            ctl->stat_rebalances += (int64_t)sh.reb; ctl->stat_window_slots += (int64_t)sh.slots; ctl->stat_small_rebalances += (int64_t)sh.reb;
+            out[0] = sh.consumed; out[1] = 1; out[2] = 0;
+            out[3] = sh.top_events; out[4] = KT; out[5] = t_counts - t_begin; out[6] = t_tables - t_counts; out[7] = t_driver - t_tables;
+        }
+    }
+}
+
+
 }  // namespace
 
 hipError_t launch_append_model3(uint64_t* occ, Ctl* ctl, int64_t R, const uint64_t* flags, const int64_t* d_T, int64_t* out, hipStream_t stream) {
@@ -435,5 +803,20 @@ hipError_t launch_append_model3(uint64_t* occ, Ctl* ctl, int64_t R, const uint64
     return hipGetLastError();
 }
 
+
+hipError_t launch_append_model5(uint64_t* occ, Ctl* ctl, int64_t R, const uint64_t* flags, const int64_t* d_T, int64_t* out, hipStream_t stream) {
+    constexpr size_t LDS = (size_t)M5_TAB_U16 * sizeof(uint16_t) + (size_t)M5_MAX_SEMS * sizeof(uint32_t);
+    static PerDeviceOnce once;
+    {
+        hipError_t e = once.run([] {
+            return hipFuncSetAttribute(reinterpret_cast<const void*>(k_append_model5), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
+        });
+        if (e != hipSuccess) return e;
+    }
+    // dev knob DSA_MODEL5=2: every epoch through the generic C++ path (A/B against the hand-scheduled block, coverage of that path)
+    static const int use_asm = [] { const char* e = dev_env("DSA_MODEL5"); return (e && e[0] == '2') ? 0 : 1; }();
+    hipLaunchKernelGGL(k_append_model5, dim3(1), dim3(M3_THREADS), LDS, stream, occ, ctl, R, flags, d_T, out, use_asm);
+    return hipGetLastError();
+}
 
 }  // namespace dsa

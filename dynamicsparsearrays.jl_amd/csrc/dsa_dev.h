@@ -357,6 +357,9 @@ hipError_t launch_append_run(uint64_t* occ, Ctl* ctl, int64_t i0, int64_t R, con
 // out = 8 x int64 device words: [0] cells placed [1] 0 not eligible (nothing changed) / 1 ran / 2 ran and stopped in front of an op
 // that needs _extend! [2] reason when not eligible [3..7] dev counters (events above the tables, table levels, ticks per phase)
 hipError_t launch_append_model3(uint64_t* occ, Ctl* ctl, int64_t R, const uint64_t* flags, const int64_t* d_T, int64_t* out, hipStream_t stream);
+// typed replay of an append run WITH semaphore cells on 8-slot segments (appendmodel.hip: k_append_model5; a matrix grown from the empty
+// one — BASELINE config 5); same hand-over words as launch_append_model3; consumes whole leaf epochs, the rest is launch_append_run's
+hipError_t launch_append_model5(uint64_t* occ, Ctl* ctl, int64_t R, const uint64_t* flags, const int64_t* d_T, int64_t* out, hipStream_t stream);
 hipError_t launch_run_expand(const Op* ops, int64_t i0, int64_t R, const Ctl* ctl, int64_t* col_keys, uint8_t* col_live, Op* cells,
                              uint64_t* flags, int64_t* out, hipStream_t stream);
 

@@ -810,10 +810,17 @@ bool seq_step(SeqRun& r) {
             // (typed runs on segments below 16 slots are not count-only — appendmodel.hip — and runs below its minimum length do not pay:
             //  no launch for them)
             const bool m3_takes = model3 && R >= 512 && (P.has_cols ? c.segment_capacity >= 16 : c.segment_capacity >= 2) && c.capacity >= 65536;
-            int64_t* m3_out = m3_takes ? reinterpret_cast<int64_t*>(reinterpret_cast<char*>(P.run_memo) + append_run_memo_bytes()) : nullptr;
+            // typed runs on 8-slot segments (a matrix grown from the empty one: BASELINE config 5) are not count-only; their replay is the
+            // per-epoch model of appendmodel.hip (k_append_model5).  DSA_MODEL5=0: per-op replay only (A/B, coverage)
+            static const bool model5 = [] { const char* v = dev_env("DSA_MODEL5"); return !(v && v[0] == '0'); }();
+            const bool m5_takes = model5 && !m3_takes && P.has_cols && c.segment_capacity == 8 && R >= 64 && c.capacity >= 256;
+            int64_t* m3_out = (m3_takes || m5_takes) ? reinterpret_cast<int64_t*>(reinterpret_cast<char*>(P.run_memo) + append_run_memo_bytes()) : nullptr;
             if (m3_takes) {
                 e = launch_append_model3(P.O(), P.d_ctl, R, P.has_cols ? P.run_flags : nullptr, P.has_cols ? P.run_out : nullptr, m3_out, P.stream);
                 if (e != hipSuccess) fail(DSA_EHIP, std::string("append model launch: ") + hipGetErrorString(e));
+            } else if (m5_takes) {
+                e = launch_append_model5(P.O(), P.d_ctl, R, P.run_flags, P.run_out, m3_out, P.stream);
+                if (e != hipSuccess) fail(DSA_EHIP, std::string("typed append model launch: ") + hipGetErrorString(e));
             }
             e = launch_append_run(P.O(), P.d_ctl, i0, R, P.has_cols ? P.run_flags : nullptr, P.has_cols ? P.run_out : nullptr, P.run_memo, m3_out, P.stream);
             if (e != hipSuccess) fail(DSA_EHIP, std::string("append run launch: ") + hipGetErrorString(e));
@@ -822,8 +829,8 @@ bool seq_step(SeqRun& r) {
                 int64_t o[8];
                 HIPCHK(hipMemcpyAsync(o, m3_out, sizeof(o), hipMemcpyDeviceToHost, P.stream));
                 HIPCHK(hipStreamSynchronize(P.stream));
-                fprintf(stderr, "[append model v3] run of %lld ops: placed %lld status %lld reason %lld | events above the tables %lld, table levels %lld | counts %.1f us tables %.1f us driver %.1f us\n",
-                        (long long)R, (long long)o[0], (long long)o[1], (long long)o[2], (long long)o[3], (long long)o[4], o[5] / 100.0, o[6] / 100.0, o[7] / 100.0);
+                fprintf(stderr, "[append model %s] run of %lld ops: placed %lld status %lld reason %lld | events above the tables %lld, table levels %lld | counts %.1f us tables %.1f us driver %.1f us\n",
+                        m5_takes ? "v5 (typed epochs)" : "v3", (long long)R, (long long)o[0], (long long)o[1], (long long)o[2], (long long)o[3], (long long)o[4], o[5] / 100.0, o[6] / 100.0, o[7] / 100.0);
             }
             if (++r.guard > 4 * r.n + 1000000) fail(DSA_EASSERT, "sequencer made no progress");
             seq_launch(r, false);
@@ -895,6 +902,7 @@ int64_t run_ops_parallel(Pma& P, const OpBatch& ops, int32_t* err) {
     int burst_rounds = ROUNDS_PER_SYNC;
     static const bool dbg_split = dev_env("DSA_DBG_SPLIT") != nullptr;
     double t_burst = 0, t_seq = 0, t_local = 0; int64_t n_burst = 0, n_seq = 0, n_yield = 0, n_local = 0, r_local = 0, o_local = 0;
+    int64_t dbg_detour[32] = {0};
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
     // A batch that starts like an append run — ascending keys (vector) / ascending (column, row) pairs (MappedPackedCSC) — goes to the
@@ -989,11 +997,18 @@ int64_t run_ops_parallel(Pma& P, const OpBatch& ops, int32_t* err) {
             SeqRun r;
             r.P = &P; r.n = std::min<int64_t>(n, i + seq_chunk); r.n_avail = n; r.active = true; r.defer_merge = true;
             P.h_ctl->next_op = i; P.h_ctl->status = 0; P.h_ctl->err = 0; P.h_ctl->no_run_at = no_run_at;
+            const int64_t dbg_slots0 = P.h_ctl->stat_window_slots, dbg_reb0 = P.h_ctl->stat_rebalances, dbg_ext0 = P.h_ctl->stat_extends;
             seq_launch(r);
             while (seq_step(r)) ++n_yield;
             ++n_seq;
             if (r.err) { if (P.h_ctl->n_pending > 0) merge_tables(P); *err = r.err; return r.applied; }
             if (P.h_ctl->n_pending >= MERGE_AT) merge_tables(P);
+            if (dbg_split && r.applied - i <= 2) {      // dev: what a one-op detour through the sequencer rebalanced (slots of its windows, log2 buckets)
+                const int64_t ds = P.h_ctl->stat_window_slots - dbg_slots0;
+                int b = 0; while ((1ll << b) < ds && b < 31) ++b;
+                dbg_detour[P.h_ctl->stat_extends != dbg_ext0 ? 31 : b] += 1;
+                (void)dbg_reb0;
+            }
             P.stat_seq_ops += r.applied - i; P.stat_seq_launches += 1;
             i = r.applied;
             // an append run that stopped in front of op i (it needs _extend!): that op and what follows stay with the sequencer, which
@@ -1010,6 +1025,9 @@ int64_t run_ops_parallel(Pma& P, const OpBatch& ops, int32_t* err) {
                 P.has_cols ? "pcsc" : "vec", (long long)n, (long long)n_burst, t_burst, (long long)n_local, t_local, (long long)r_local, (long long)o_local,
                 (long long)n_seq, (long long)n_yield, t_seq);
     if (dbg_split) {
+        fprintf(stderr, "    one-op detours by window slots (log2 bucket: count; 31 = with _extend!):");
+        for (int b = 0; b < 32; ++b) if (dbg_detour[b]) fprintf(stderr, " %d:%lld", b, (long long)dbg_detour[b]);
+        fprintf(stderr, "\n");
         fprintf(stderr, "    sequencer chunks: waiting for the device %.2f ms; host work by yield kind [done %.2f, rebalance %.2f, extend %.2f, shrink %.2f, table %.2f, error %.2f, run %.2f] ms\n",
                 g_seq_wait_ms, g_seq_host_ms[0], g_seq_host_ms[1], g_seq_host_ms[2], g_seq_host_ms[3], g_seq_host_ms[4], g_seq_host_ms[5], g_seq_host_ms[6]);
         fprintf(stderr, "    seq_launch calls %.2f ms\n", g_seq_launch_ms);

@@ -47,7 +47,8 @@ constexpr int64_t PB_PEND_MAX = TABLE_PEND_MAX;  // the sequencer imports, table
 //            follows): "each op sees exactly the state it was planned on", checked, for every semantic dependency at once (also the ones
 //            of the 64-ary find, whose literal probes are far outside any footprint).
 // A violation prints its details and raises RoundState::pad (the host fails the batch).  DSA_FP_REGRESS=1 / 2 re-introduce the two
-// resolver bugs of round 4 (the leaf walk of ONE hash cell; the footprint of a left-falling insert ending at p + 1): the check must fire.
+// resolver bugs of round 4 (the leaf walk of ONE hash cell; the footprint of a left-falling insert ending at p + 1), = 3 the one this build
+// found itself (a widened new column whose window ends on a hash-cell boundary is not chained in the next cell): the check must fire.
 #ifdef DSA_FP_CHECK
 constexpr int FP_MAXCNT = 12;
 struct FpRec {                                    // what ONE op of a round literally read (plan) and touched (apply)
@@ -103,10 +104,66 @@ __device__ int64_t pb_wave_count(const uint64_t* occ, int64_t ws, int64_t we, bo
     return pb_wave_sum(c);
 }
 
+// ---- a window of the occupancy bitmap in registers --------------------------------------------------------------------------------
+// The plan of an op is a chain of DEPENDENT memory round trips (~0.6 us each under load): table search, semaphores, find, shift target,
+// one count per level of the density scan — and every step after the find re-read the same one or two occupancy words through its own
+// helper (_nextemptypos, the walk-left loops of find, _nbcells).  One wave-wide load puts 64 words — the 2048-slot aligned block around an
+// anchor position and the block behind it: every window a wave may rebalance around the anchor, and any shift target nearby — into one
+// register per lane; the bit scans and counts behind it are ballots and v_readlane, no memory.  Words at or beyond the end of the array
+// read as FULL (no free slot is ever reported there; windows never reach there).
+__device__ __forceinline__ int pb_ufl(int v) { return __builtin_amdgcn_readfirstlane(v); }
+struct OccWin {
+    uint64_t w;            // lane l: occupancy word wbase + l
+    int64_t wbase;         // 0-based word index of lane 0 (wave-uniform); -1: no window
+    __device__ __forceinline__ bool covers(int64_t a, int64_t b) const {      // 1-based positions a <= b
+        return wbase >= 0 && ((a - 1) >> 6) >= wbase && ((b - 1) >> 6) < wbase + 64;
+    }
+    __device__ __forceinline__ uint64_t word(int i) const {                   // i wave-uniform, 0 <= i < 64
+        const int iu = pb_ufl(i);
+        return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(w >> 32), iu) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)w, iu);
+    }
+    // _nextemptypos(array, from) inside the window: smallest free position > from, or -1 when the window holds none (the caller asks the bitmap)
+    __device__ __forceinline__ int64_t next_empty(int64_t from) const {
+        const int li = (int)((from >> 6) - wbase), lane = lane_id();
+        uint64_t z = ~w;
+        if (lane == li) z &= ~mask_lt((int)(from & 63));
+        if (lane < li) z = 0ull;
+        const unsigned long long any = __builtin_amdgcn_ballot_w64(z != 0ull);
+        if (any == 0ull) return -1;
+        const int fl = __ffsll(any) - 1;
+        const uint64_t zz = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(z >> 32), fl) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)z, fl);
+        return ((wbase + fl) << 6) + __ffsll((unsigned long long)zz);
+    }
+    // occupied cells of [ws, we] (inside the window)
+    __device__ __forceinline__ int64_t count(int64_t ws, int64_t we) const {
+        const int64_t lo0 = ws - 1, hi0 = we - 1;
+        if ((lo0 >> 6) == (hi0 >> 6)) return popc64(word((int)((lo0 >> 6) - wbase)) & word_range_mask(lo0 >> 6, lo0, hi0));      // a leaf, a small window: one word
+        return pb_wave_sum((int64_t)popc64(w & word_range_mask(wbase + lane_id(), lo0, hi0)));
+    }
+    // occupancy of the 64 positions p0 .. p0 + 63 (bit l <-> position p0 + l); inside the window
+    __device__ __forceinline__ uint64_t bits64(int64_t p0) const {
+        const int i0 = (int)(((p0 - 1) >> 6) - wbase), sh = (int)((p0 - 1) & 63);
+        const uint64_t w0 = word(i0);
+        if (sh == 0) return w0;
+        const uint64_t w1 = i0 + 1 < 64 ? word(i0 + 1) : ~0ull;
+        return (w0 >> sh) | (w1 << (64 - sh));
+    }
+};
+__device__ __forceinline__ OccWin pb_occwin_load(const uint64_t* occ, int64_t anchor, int64_t capacity) {
+    OccWin win;
+    win.wbase = -1; win.w = ~0ull;
+    if (anchor >= 1 && anchor <= capacity) {
+        win.wbase = ((anchor - 1) >> 11) << 5;
+        const int64_t wi = win.wbase + lane_id(), lastw = (capacity - 1) >> 6;
+        win.w = wi <= lastw ? occ[wi] : ~0ull;
+    }
+    return win;
+}
+
 // Plan of ONE op by one wave (read-only): what the op would do on the current state, and its footprint.  w = index of the op in its
 // round (new columns take table entries in that order), max_w = largest window one wave of the caller rebalances.
 __device__ Plan pb_plan_one(KeyArr keys, const double* vals, const uint64_t* occ, const int64_t* sems, const int64_t* col_keys,
-                            const uint8_t* col_live, const Ctl* ctl, const Op op, int w, int max_w, const bool tight_only = false) {
+                            const uint8_t* col_live, const Ctl* ctl, const Op op, int w, int max_w) {
     const int64_t capacity = ctl->capacity, seg = ctl->segment_capacity, height = ctl->height;
     Plan pl;
     pl.lo = 1; pl.hi = 0; pl.pos = 0; pl.aux = 0; pl.ws = 0; pl.we = 0; pl.count = 0; pl.action = PB_BARRIER;
@@ -175,9 +232,13 @@ __device__ Plan pb_plan_one(KeyArr keys, const double* vals, const uint64_t* occ
             // semaphore, or nothing was rebalanced, the second empty slot of the pre-round state (ne2 <= B) is still free.
             const int64_t p1 = sems[sidx] - 1;                        // _insert! after p1: the new semaphore lands on p1 + 1
             const int64_t ip1 = p1 + 1;
-            const int64_t ne1 = d_next_empty(occ, p1, capacity);
-            const int64_t ne2 = ne1 != 0 ? d_next_empty(occ, ne1, capacity) : 0;
+            const OccWin win = pb_occwin_load(occ, ip1, capacity);      // the bitmap around the insertion point: both gaps and every count below come from it
+            int64_t ne1 = win.wbase >= 0 ? win.next_empty(p1) : -1;
+            if (ne1 < 0) ne1 = d_next_empty(occ, p1, capacity);
+            int64_t ne2 = ne1 != 0 ? ((win.wbase >= 0 && win.covers(ne1, ne1)) ? win.next_empty(ne1) : -1) : 0;
+            if (ne2 < 0) ne2 = d_next_empty(occ, ne1, capacity);
             fp_pos(p1 + 1, ne2 != 0 ? ne2 : capacity);
+            auto cells_of = [&](int64_t a, int64_t b) { return win.covers(a, b) ? win.count(a, b) : pb_wave_count(occ, a, b, false); };
             why = 3;
             if (p1 >= 1 && ne1 != 0 && ne2 != 0) {
                 why = 5;
@@ -188,13 +249,15 @@ __device__ Plan pb_plan_one(KeyArr keys, const double* vals, const uint64_t* occ
                     if (W > max_w) break;
                     A = ((ip1 - 1) / W) * W + 1; B = A + W - 1;
                     if (ne2 > B || ip1 >= B) continue;
-                    cnt = pb_wave_count(occ, A, B, false);
+                    cnt = cells_of(A, B);
                     fp_cnt(A, B);
                     if (ctl->lo[h] <= cnt + 1 && cnt + 2 <= ctl->hi[h]) { H = h; break; }
                 }
-                // (tight_only: the footprint-check build's sequential shadow asks whether the op, on the LIVE state, is still a leaf-accepted
-                // new column with the same two gaps — the fallback window only matters to the resolve step of a round)
-                if (H >= 0 || tight_only) {
+                // No window of a wave's size accepts (a small, fast-growing array sits between the thresholds of its middle levels and
+                // the leaf's — config 5's first batches: 283 such new rows, each a detour through the sequencer although its leaf accepted and
+                // nothing was rebalanced): the op can still be planned when its LEAF accepts — level 0x7f = "no fallback": the resolve step
+                // cuts the prefix in front of it instead of widening it.
+                {
                     const int32_t lvl = H >= 0 ? (int32_t)H : 0x7f;
                     if (H >= 0) {
                         pl.action = PB_NEWCOL; pl.pos = p1; pl.aux = ne1;
@@ -212,7 +275,7 @@ __device__ Plan pb_plan_one(KeyArr keys, const double* vals, const uint64_t* occ
                     if (seg > 64) {
                         // (counts travel in 7 bits)
                     } else if (ip1 < l1) {
-                        const int64_t cl = H == 0 ? cnt : pb_wave_count(occ, l0, l1, false);
+                        const int64_t cl = H == 0 ? cnt : cells_of(l0, l1);
                         fp_cnt(l0, l1);
                         const int64_t c1 = cl + (ne1 <= l1 ? 1 : 0), c2 = c1 + (ne2 <= l1 ? 1 : 0);
                         if (ctl->lo[0] <= c1 && c2 <= ctl->hi[0]) { tight = true; tcount = lvl | 0x80 | ((int32_t)cl << 8); }
@@ -222,7 +285,7 @@ __device__ Plan pb_plan_one(KeyArr keys, const double* vals, const uint64_t* occ
                         // second the next one, which receives whatever gaps of its own the two runs fill.  Two leaves to accept
                         // (flag 0x8000 + the second count); without this a semaphore on slot 512 k needed a window of 1024 slots.
                         const int64_t m1 = l1 + seg;
-                        const int64_t cl = pb_wave_count(occ, l0, l1, false), cm = pb_wave_count(occ, l1 + 1, m1, false);
+                        const int64_t cl = cells_of(l0, l1), cm = cells_of(l1 + 1, m1);
                         fp_cnt(l0, l1); fp_cnt(l1 + 1, m1);
                         const int64_t c2 = cm + (ne1 <= m1 ? 1 : 0) + (ne2 <= m1 ? 1 : 0);
                         if (ctl->lo[0] <= cl && cl <= ctl->hi[0] && ctl->lo[0] <= cm && c2 <= ctl->hi[0]) {
@@ -238,7 +301,41 @@ __device__ Plan pb_plan_one(KeyArr keys, const double* vals, const uint64_t* occ
         }
     }
     if (plannable) {
-        const DFound f = op.v != 0.0 ? d_find_fast(keys, vals, occ, op.a, from, to) : d_find_fast(keys, vals, occ, op.a, del_from, to);
+        OccWin win;
+        win.wbase = -1; win.w = ~0ull;
+        DFound f;
+        const int64_t lo_s = op.v != 0.0 ? from : del_from;      // first slot of the searched range
+        if (op.kind == OP_MPCSC_SET && to - del_from <= 61 && lo_s <= to) {
+            // A partition of up to 62 slots (a column of config 5's twin, a row of a sparse matrix): lane l <-> position sp + l, sp the
+            // semaphore.  ONE load of the bitmap window and ONE of the keys of the occupied slots replace the probes of the 64-ary find
+            // (occupancy word, key, next occupied, key, previous occupied, key: dependent round trips each).  Same answer as d_find_fast
+            // on a key-partitioned range: the cell holding the key if present, else the last cell of the range with a smaller key, else
+            // the nearest occupied cell left of the range — the semaphore on slot sp (src/finds.jl:29-57).
+            const int64_t sp = del_from;
+            win = pb_occwin_load(occ, sp, capacity);
+            const int lane = lane_id();
+            const uint64_t bits = win.bits64(sp);
+            const int64_t pl_ = sp + lane;
+            const bool inr = pl_ >= lo_s && pl_ <= to && ((bits >> lane) & 1ull);
+            const int64_t kk = inr ? (int64_t)keys[pl_ - 1] : 0;
+            const unsigned long long viol = __builtin_amdgcn_ballot_w64(inr && kk >= op.a);
+            const int fv = viol ? __ffsll(viol) - 1 : (int)(to - sp + 1);                    // first cell of the range with a key >= the target (or one past the range)
+            const bool hit = viol != 0ull && __builtin_amdgcn_ballot_w64(inr && kk == op.a && lane == fv) != 0ull;
+            if (hit) { f.pos = sp + fv; f.key = op.a; f.val = 0.0; f.has = true; }
+            else {
+                const uint64_t below = bits & mask_lt(fv);                                   // occupied cells in front of it — the semaphore (lane 0) among them
+                if (below != 0ull) {
+                    const int pv = 63 - __clzll((long long)below);
+                    f.pos = sp + pv; f.has = true; f.val = 0.0;
+                    // its key decides nothing below unless it equals the target, which only a cell INSIDE the range can (those were compared)
+                    f.key = (sp + pv >= lo_s) ? op.a - 1 : SEM_KEY - (op.a == SEM_KEY ? 1 : 0);
+                } else f = d_find_fast(keys, vals, occ, op.a, lo_s, to);                     // (cannot happen: slot sp holds the semaphore)
+            }
+        } else {
+            f = op.v != 0.0 ? d_find_fast(keys, vals, occ, op.a, from, to) : d_find_fast(keys, vals, occ, op.a, del_from, to);
+            win = pb_occwin_load(occ, f.has ? f.pos : 1, capacity);      // the shift target and the counts around the predecessor: one more load, then registers
+        }
+        auto cells_of = [&](int64_t a, int64_t b) { return win.covers(a, b) ? win.count(a, b) : pb_wave_count(occ, a, b, false); };
         const bool exists = op.v != 0.0 ? (f.has && f.key == op.a && from <= f.pos && f.pos <= to)      // src/writes.jl:16
                                         : (f.has && f.key == op.a);                                     // src/writes.jl:59
         int64_t ip = 0, changed = 0, delta = 0, wlo = 1, whi = 0, rlo = 1, rhi = 0;
@@ -248,7 +345,8 @@ __device__ Plan pb_plan_one(KeyArr keys, const double* vals, const uint64_t* occ
                 pl.action = PB_OVERWRITE; pl.pos = f.pos; pl.lo = f.pos; pl.hi = f.pos;
             } else {
                 const int64_t p = f.pos;
-                const int64_t ne = d_next_empty(occ, p, capacity);
+                int64_t ne = (p + 1 <= capacity && win.covers(p + 1, p + 1)) ? win.next_empty(p) : -1;
+                if (ne < 0) ne = d_next_empty(occ, p, capacity);
                 fp_pos(p + 1, ne != 0 ? ne : capacity);
                 rlo = p >= 1 ? p : 1; rhi = p + 1 <= capacity ? p + 1 : capacity;
                 if (ne != 0) { pl.action = PB_INS_R; ip = p + 1; changed = ne; wlo = p + 1; whi = ne; pl.aux = ne; scan = true; }
@@ -280,7 +378,7 @@ __device__ Plan pb_plan_one(KeyArr keys, const double* vals, const uint64_t* occ
                 if (W > max_w && h > 0) break;
                 ws = ((ip - 1) / W) * W + 1;
                 we = ws + W - 1;
-                c = pb_wave_count(occ, ws, we, false) + ((changed >= ws && changed <= we) ? delta : 0);
+                c = cells_of(ws, we) + ((changed >= ws && changed <= we) ? delta : 0);
                 fp_cnt(ws, we);
                 if (ctl->lo[h] <= c && c <= ctl->hi[h]) { accepted = true; break; }
             }
@@ -503,6 +601,9 @@ __global__ __launch_bounds__(PL_BLOCK) void k_plan(const DevBufs* bufs, const Ct
             bool ok = accepts(l0, sCnt0[j]);
             if (ok && sCnt02[j] >= 0) ok = accepts(l0 + (int32_t)seg, sCnt02[j]);
             widen[u] = !ok || !((tight_mask >> (sChg2[j] != 0 ? 1 : 0)) & 1);
+            // a new column without a fallback window (level 0x7f) cannot be widened: the prefix ends in front of it (alone at the head
+            // of the next round it is handed to the sequencer — d = 0 stops the rounds)
+            if (widen[u] && sLvl[j] == 0x7f) { widen[u] = false; atomicMin(&sC, j); }
         }
         __syncthreads();                                               // every walk has read the tight hulls
 #pragma unroll
@@ -513,11 +614,17 @@ __global__ __launch_bounds__(PL_BLOCK) void k_plan(const DevBufs* bufs, const Ct
                 // back to the window the plan was accepted in: the leaf, or the level-H window of a new column
                 const int32_t W = (int32_t)seg << sLvl[j];
                 const int32_t a = ((sLeafLo[j] - 1) / W) * W + 1, b = a + W - 1;
+                const int oc0 = me.lo >> CS, oc1 = me.hi >> CS;                  // the cells the op is chained in (its tight hull)
                 if (a < me.lo) me.lo = a;
                 if (b > me.hi) me.hi = b;
-                // (The widened interval can reach ONE slot into the next cell — slots are 1-based, an aligned window ends on a multiple of its
-                // size — where the op is not chained.  That is fine: the op WRITES only its tight hull, which it is chained by; the widening
-                // stands for the counts it READ, and a later op looks for the earlier writers in the cells of its own, widened, interval.)
+                // The widened interval can reach into a cell the op is not chained in — slots are 1-based, an aligned window ends on a multiple
+                // of its size, e.g. [516081, 516096] with 516096 = 126 * 4096 the first slot of the next cell.  For a leaf-accepted insert /
+                // delete that is harmless (it writes only its tight hull; the widening stands for the count it read), but a widened NEW COLUMN
+                // scans and REBALANCES its whole window when it is applied: a later op that starts on that last slot walked only its own cell
+                // and ran in the same round (rounds 3-4; found by the footprint-check build of round 5, tools/fuzz.py run_same_leaf_matrix,
+                // first seed 9101: "op 52 writes inside [516081,516096]; the later op 54 has the footprint [516096,516098]").  Such an op is
+                // tested against everybody, like the footprints longer than two cells.
+                if (DSA_FP_REGRESS != 3 && ((me.lo >> CS) != oc0 || (me.hi >> CS) != oc1)) sWide[atomicAdd(&sNWide, 1)] = j;
                 sIv[j] = me;
             }
         }
@@ -844,7 +951,8 @@ __device__ void pb_apply_one(KeyArr keys, double* vals, uint64_t* occ, int64_t* 
             delta = -1;
             break;
         case PB_NEWCOL: {                                          // new column + its first element: two inserts in order (see k_plan)
-            const int64_t p1 = pl.pos, ne1 = pl.aux, hmax = pl.count & 0x7f, capacity = ctl->capacity;
+            const int64_t p1 = pl.pos, ne1 = pl.aux, capacity = ctl->capacity;
+            const int64_t hmax = (pl.count & 0x7f) <= ctl->height ? (pl.count & 0x7f) : ctl->height;      // (0x7f: leaf-accepted without a fallback window — both scans stop at the leaf)
             // (flag 0x80, tight hull: the leaf accepts both scans whatever the other ops of the round do to its count — the loop below stops at
             // level 0 on any count it can read; footprint widened by the resolve step: the window is this op's alone, the scan sees the planned state)
             const int64_t flo = pl.lo < pl.ws ? pl.lo : pl.ws, fhi = pl.hi > pl.we ? pl.hi : pl.we;
@@ -970,8 +1078,8 @@ __global__ __launch_bounds__(PL_BLOCK) void k_fp_pre(const DevBufs* bufs, Ctl* c
         for (int j = 0; j < d; ++j) {
             const Op op = ops[i0 + j];
             const Plan want = plans[j];
-            // (w = 0: the table entries of the earlier new columns exist by now; a leaf-accepted new column need not find its fallback window again)
-            const Plan live = pb_plan_one(keys, vals, occ, sems, col_keys, col_live, ctl, op, 0, PB_MAX_W, want.action == PB_NEWCOL && (want.count & 0x80));
+            // (w = 0: the table entries of the earlier new columns exist by now)
+            const Plan live = pb_plan_one(keys, vals, occ, sems, col_keys, col_live, ctl, op, 0, PB_MAX_W);
             if (!fp_same_plan(want, live, seg)) {
                 if (tid == 0) {
                     printf("DSA_FP_CHECK shadow: op %lld (round op %d of %d; a %lld b %lld v %g) planned act %d pos %lld aux %lld win [%lld,%lld] count %d fp [%lld,%lld]"
@@ -1137,7 +1245,10 @@ __global__ __launch_bounds__(LR_BLOCK) void k_local_rounds(const DevBufs* bufs, 
                 // (leaf-only ops carry their tight hull: widened to their window here — no count bookkeeping in the mini-rounds)
                 auto full = [&](const Plan& q, int64_t& lo_, int64_t& hi_) {
                     lo_ = q.lo; hi_ = q.hi;
-                    if (lo_ <= hi_ && pb_is_leaf_only(q.action, q.ws, q.we, ctl->segment_capacity, q.count)) { if (q.ws < lo_) lo_ = q.ws; if (q.we > hi_) hi_ = q.we; }
+                    if (lo_ <= hi_ && pb_is_leaf_only(q.action, q.ws, q.we, ctl->segment_capacity, q.count)) {
+                        if (q.action == PB_NEWCOL && (q.count & 0x7f) == 0x7f) { lo_ = 1; hi_ = ctl->capacity; }      // no fallback window to widen to: alone in its mini-round
+                        else { if (q.ws < lo_) lo_ = q.ws; if (q.we > hi_) hi_ = q.we; }
+                    }
                 };
                 int64_t lo, hi;
                 full(sPlan[j], lo, hi);
@@ -1159,7 +1270,7 @@ __global__ __launch_bounds__(LR_BLOCK) void k_local_rounds(const DevBufs* bufs, 
             for (int j = 0; j < dd; ++j) {
                 if (wv == j) {
                     const Op op = ops[cursor + j];
-                    const Plan live = pb_plan_one(keys, vals, occ, sems, col_keys, col_live, ctl, op, 0, LR_MAX_W, sPlan[j].action == PB_NEWCOL && (sPlan[j].count & 0x80));
+                    const Plan live = pb_plan_one(keys, vals, occ, sems, col_keys, col_live, ctl, op, 0, LR_MAX_W);
                     if (!fp_same_plan(sPlan[j], live, ctl->segment_capacity)) {
                         if (lane == 0) {
                             printf("DSA_FP_CHECK shadow (local rounds): op %lld (%d of %d) planned act %d pos %lld aux %lld win [%lld,%lld] | live act %d pos %lld aux %lld win [%lld,%lld]\n",
@@ -1189,7 +1300,10 @@ __global__ __launch_bounds__(LR_BLOCK) void k_local_rounds(const DevBufs* bufs, 
                 for (int j = 0; j < dd; ++j) {
                     const Plan& q = sPlan[j];
                     flo[j] = q.lo; fhi[j] = q.hi;
-                    if (flo[j] <= fhi[j] && pb_is_leaf_only(q.action, q.ws, q.we, segc, q.count)) { if (q.ws < flo[j]) flo[j] = q.ws; if (q.we > fhi[j]) fhi[j] = q.we; }
+                    if (flo[j] <= fhi[j] && pb_is_leaf_only(q.action, q.ws, q.we, segc, q.count)) {
+                        if (q.action == PB_NEWCOL && (q.count & 0x7f) == 0x7f) { flo[j] = 1; fhi[j] = ctl->capacity; }
+                        else { if (q.ws < flo[j]) flo[j] = q.ws; if (q.we > fhi[j]) fhi[j] = q.we; }
+                    }
                     for (int i = 0; i < j; ++i)
                         if (flo[i] <= fhi[i] && flo[j] <= fhi[j] && flo[i] <= fhi[j] && flo[j] <= fhi[i]) { printf("DSA_FP_CHECK sets (local rounds): ops %d and %d share slots\n", i, j); fp_fault(rs, 23); }
                     const FpRec& r = sRec[j];

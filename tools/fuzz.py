@@ -634,13 +634,24 @@ def run_append_models(seed):
         return "ok"
     m = [2000, 40000][g.next() % 2]
     n0 = [3000, 12000][g.next() % 2]
+    grown_m = g.next() % 2 == 0
+    if grown_m:
+        # a matrix GROWN from the empty one keeps 8-slot segments for life: its typed runs take the per-epoch replay (k_append_model5:
+        # cross-leaf shifts of semaphores, surviving-event reconstruction, trailing epochs handed to the per-op replay)
+        n0 = [1, 40, 700, 4000, 9000][g.next() % 5]
     I0, J0 = [], []
     for j in range(1, n0 + 1):
         for i in sorted({1 + int(g.next() % m) for _ in range(1 + g.next() % 10)}):
             I0.append(i); J0.append(j)
     V0 = 1.0 + np.arange(len(I0)) % 9 / 8.0
-    a = dsa.dynamicsparse(I0, J0, V0, binding=hip)
-    b = dsa.dynamicsparse(I0, J0, V0, binding=ora)
+    if grown_m:
+        a = dsa.dynamicsparse(fill_mode=False, binding=hip)
+        b = dsa.dynamicsparse(fill_mode=False, binding=ora)
+        a.set_batch(I0, J0, V0); b.set_batch(I0, J0, V0)
+        mat_equal(a, b, (seed, "grown"))
+    else:
+        a = dsa.dynamicsparse(I0, J0, V0, binding=hip)
+        b = dsa.dynamicsparse(I0, J0, V0, binding=ora)
     col = n0
     for step in range(3 + g.next() % 4):
         ncols = [40, 60, 700, 5000][g.next() % 4]
