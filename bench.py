@@ -106,6 +106,16 @@ def cold_launch_us(torch, dev, stream, fn, nrep=8, evict_bytes=1 << 30):
     return float((e[0].elapsed_time(e[1]) - e[2].elapsed_time(e[3])) * 1e3 / nrep)
 
 
+def banded_floor(us):
+    """the L2-hit floor of the banded extra (tools/scripts/gather_floor3.sh: 2^24 slots streamed, 10 M gathers from a 1 MB table)"""
+    try:
+        with open(os.path.join(ROOT, "profiles", "gather_floor_banded.json")) as f:
+            g = json.load(f)
+        return {"keyed_single_pass_floor_us": g["keyed_single_pass_us"], "kernel_over_floor": round(us / g["keyed_single_pass_us"], 3), "floor_source": g["source"]}
+    except (OSError, KeyError, ValueError):
+        return {}
+
+
 def kernel_source_sha():
     """sha256 over the kernel sources whose traffic the committed PMC summaries describe: a summary made from other
     sources is stale and is not quoted."""
@@ -601,6 +611,7 @@ def extras(dsa, hip, torch, A, dev):
         bb = 16 * capb + 8 * nb + 8 * mb
         res["spmv_banded_extra"] = {"rows": mb, "columns": nb, "nnz": int(len(firstb)), "band": "+-4096", "capacity_slots": capb, "us": round(usb, 2),
                                     "algorithmic_bytes": bb, "gbps": round(bb / usb / 1e3, 1), "frac": round(bb / usb / 1e3 / HBM_PEAK_GBS, 4),
+                                    **banded_floor(usb),
                                     "note": "NOT the headline workload: a banded variant of config 3, reported to show what the kernel does when x has locality"}
         del Ab, xb, yb
     except Exception as e:
@@ -825,13 +836,41 @@ def c5_streaming(dsa, hip, torch, dev, m5, ncols5, per5, every, binding=None, st
             break
     ncols_done = min(ncols5, (nsp * every))
     nw = ncols_done * per5
+    final_spmv = None
+    if binding is None and not delete_every and stop_after is None:
+        # the product on the FINAL matrix (x = 50 k doubles = 400 KB: L2-resident on every XCD — the regime column generation runs in),
+        # 20 launches between one pair of HIP events on the matrix's own stream order (torch's current stream: set for the product)
+        st = torch.cuda.current_stream()
+        hip.call("mat_set_stream", B.h, C.c_void_p(st.cuda_stream))
+        for _ in range(3):
+            hip.call("mat_spmv_dense_dev", B.h, 0, 0, C.c_void_p(xd.data_ptr()), ncols_done, C.c_void_p(yd.data_ptr()), m5)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(st)
+        for _ in range(20):
+            hip.call("mat_spmv_dense_dev", B.h, 0, 0, C.c_void_p(xd.data_ptr()), ncols_done, C.c_void_p(yd.data_ptr()), m5)
+        e1.record(st)
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / 20 * 1e3
+        capr = B.info(dsa.ROWMAJOR)["capacity"]
+        bb = 16 * capr + 8 * ncols_done + 8 * m5
+        final_spmv = {"us": round(us, 2), "capacity_slots": capr, "algorithmic_bytes": bb, "gbps": round(bb / us / 1e3, 1),
+                      "frac": round(bb / us / 1e3 / HBM_PEAK_GBS, 4)}
+        try:
+            with open(os.path.join(ROOT, "profiles", "gather_floor_c5.json")) as f:
+                g5 = json.load(f)
+            final_spmv["keyed_single_pass_floor_us"] = g5["keyed_single_pass_us"]
+            final_spmv["kernel_over_floor"] = round(us / g5["keyed_single_pass_us"], 3)
+            final_spmv["floor_source"] = g5["source"]
+        except (OSError, KeyError, ValueError):
+            pass
     if delete_every:
         return {"columns": ncols_done, "columns_per_s": round(ncols_done / t_w, 1), "write_s": round(t_w, 3), "deleted_columns": n_del,
                 "deletecolumn_us_each": round(t_del / max(n_del, 1) * 1e6, 1), "spmv_ms_avg": round(t_s / nsp * 1e3, 4),
                 "note": "config 5 with 1 of %d streamed columns deleted again after every batch of %d" % (delete_every, every)}
     return {"columns": ncols_done, "rows": m5, "element_writes": nw, "columns_per_s": round(ncols_done / t_w, 1),
             "element_writes_per_s": round(nw / t_w, 1), "write_s": round(t_w, 3), "first_10k_columns_write_s": None if t_first is None else round(t_first, 3),
-            "spmv_ms_avg": round(t_s / nsp * 1e3, 4), "spmv_every_columns": every,
+            "spmv_ms_avg": round(t_s / nsp * 1e3, 4), "spmv_every_columns": every, "final_spmv": final_spmv,
             "note": "each element write updates both orientations (2 PCSR inserts); new rows arrive in random key order "
                     "(middle inserts of addpartition!, src/pcsr.jl:114-146)"}
 

@@ -428,7 +428,7 @@ __global__ __launch_bounds__(M3_THREADS) void k_append_model3(uint64_t* occ, Ctl
 // slot is the last one of the array and the next cell is a semaphore — which always goes to the last slot, with a shift to the left
 // (addpartition!, src/pcsr.jl:99-112 -> _insert!, src/writes.jl:34-38) — the shift finds its gap OUTSIDE the leaf: one cell crosses the
 // leaf boundary, the leaf keeps its 7 cells and accepts, no level is scanned ("cross" below).  So the time a leaf epoch takes depends on
-// the cell types, and so does everything above it.  What stays true (tools/scratch/model5_proto.py, checked bit for bit against the
+// the cell types, and so does everything above it.  What stays true (tests/repro/model5_proto.py, checked bit for bit against the
 // oracle on columns of 1..20 cells): the state is the suffix cell count of every level plus the leaf state (s cells, g free slots behind
 // the tail); an epoch is the ops until the leaf holds 8 cells — 8 - s of them, one more when all free slots are behind the tail
 // (s + g == 8) and the op that meets the leaf at 7 cells is a semaphore —; it ends with the rebalance of the first level >= 1 that

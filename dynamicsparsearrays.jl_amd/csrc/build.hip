@@ -610,6 +610,7 @@ static void pinned_ctl_put(void* p) {
 }
 static void free_scratch(BuildScratch& s) {
     if (s.base) pool_free(s.base);
+    if (s.base_val) pool_free(s.base_val);
     if (s.h_ctl) pinned_ctl_put(s.h_ctl);
     s = BuildScratch();
 }
@@ -724,11 +725,13 @@ hipError_t build_prepare(const int64_t* d_part, const int64_t* d_key, const doub
     const size_t b_ctl = up(sizeof(BuildCtl)), b_gh = up(8 * RS_BINS * 4 + 4 * MM_BLOCKS * 8 + 64), b_comp = up(n * 8),
                  b_hist = up((size_t)RS_BINS * nblocks * 4), b_cnt = up((size_t)(nblocks + 1) * 4),
                  b_queue = up((n / FOLD_INLINE + 2) * sizeof(LongRun)), b_scell = up(n * 4);
-    BCHK(pool_alloc(&s.base, b_ctl + b_gh + 4 * b_comp + b_hist + 2 * b_cnt + b_queue + b_scell));
+    // (the two value arrays — 16 bytes per triple — are a block of their own, taken further down only when the values really travel
+    // with the sorted words: the index-in-word sort of config 3 never touches them, and the block used to be held, untouched, all the same)
+    BCHK(pool_alloc(&s.base, b_ctl + b_gh + 2 * b_comp + b_hist + 2 * b_cnt + b_queue + b_scell));
     char* q = static_cast<char*>(s.base);
     auto take = [&q](size_t b) { char* r = q; q += b; return r; };
     s.d_ctl = take(b_ctl); s.ghist = (uint32_t*)take(b_gh);
-    s.comp[0] = (uint64_t*)take(b_comp); s.comp[1] = (uint64_t*)take(b_comp); s.val[0] = (double*)take(b_comp); s.val[1] = (double*)take(b_comp);
+    s.comp[0] = (uint64_t*)take(b_comp); s.comp[1] = (uint64_t*)take(b_comp);
     s.hist = (uint32_t*)take(b_hist); s.cnt_c = (uint32_t*)take(b_cnt); s.cnt_p = (uint32_t*)take(b_cnt);
     s.queue = take(b_queue); s.scell = (uint32_t*)take(b_scell);
     BuildCtl* dctl = static_cast<BuildCtl*>(s.d_ctl);
@@ -764,6 +767,10 @@ hipError_t build_prepare(const int64_t* d_part, const int64_t* d_key, const doub
     static const bool idx_sort = [] { const char* e = dev_env("DSA_BUILD_IDXSORT"); return !(e && e[0] == '0'); }();      // dev knob: 0 = always carry the values
     const int ibits_need = std::max(1, bit_width_u64((uint64_t)(nnz - 1)));
     s.ibits = (idx_sort && total_bits + ibits_need <= 64) ? ibits_need : 0;
+    if (s.ibits == 0) {
+        BCHK(pool_alloc(&s.base_val, 2 * b_comp));
+        s.val[0] = static_cast<double*>(s.base_val); s.val[1] = reinterpret_cast<double*>(static_cast<char*>(s.base_val) + b_comp);
+    }
     const int npass = (total_bits + 7) / 8;
     const dim3 grid((unsigned)nblocks), block(RS_BLOCK);
     int cur = 0;                                    // comp[cur] holds the current order; values: d_val before the first scatter

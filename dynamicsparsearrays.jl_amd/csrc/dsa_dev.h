@@ -303,7 +303,8 @@ void stream_put(hipStream_t s, int device);             // (the caller has synch
 // ---- K-build (build.hip): device bulk constructor of one orientation ---------------------------------------------
 struct BuildScratch {
     int64_t n = 0;
-    void* base = nullptr; hipStream_t stream = nullptr;      // the one block (pool.hip) all device arrays below are carved from
+    void* base = nullptr; hipStream_t stream = nullptr;      // the block (pool.hip) the device arrays below are carved from
+    void* base_val = nullptr;                                // ... except val[0..1], allocated only when the values travel with the sorted words (ibits == 0)
     // composite path: comp = (partition - pmin) << kbits | (key - kmin), sorted with its value (build.hip)
     void* d_ctl = nullptr; void* h_ctl = nullptr;            // BuildCtl on the device / its pinned mirror
     uint32_t* ghist = nullptr; uint32_t* hist = nullptr; uint32_t* cnt_c = nullptr; uint32_t* cnt_p = nullptr;

@@ -13,6 +13,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <chrono>
@@ -76,6 +77,7 @@ struct ApiRange {
     return DSA_OK;
 
 int g_device = 0;
+std::atomic<bool> g_models_off{false};      // an append-replay model kernel could not be launched on this device (LDS): per-op replay only from then on
 }  // namespace
 
 // ---- the one table of development switches (dsa_dev.h: dev_env) --------------------------------------------------------------------
@@ -220,9 +222,7 @@ void pma_destroy(Pma& P) {
     pool_free(P.sems); pool_free(P.col_keys); pool_free(P.col_live);
     pool_free(P.d_ctl);
     pinned_free(P.h_ctl);
-    if (P.d_ops) hipFree(P.d_ops);
-    if (P.d_breaks) hipFree(P.d_breaks);
-    if (P.d_opsrc) hipFree(P.d_opsrc);
+    pool_free(P.d_ops); pool_free(P.d_breaks); pool_free(P.d_opsrc);      // (from the caching allocator since round 5: counted in DSA_INFO_HBM_BYTES)
     if (P.d_q) hipFree(P.d_q);
     pool_free(P.d_err);
     burst_graph_destroy(&P.burst);
@@ -539,12 +539,12 @@ struct OpBatch {
 void ensure_ops(Pma& P, int64_t n) {
     P.breaks_valid = false;
     if (n <= P.ops_cap) return;
-    if (P.d_ops) hipFree(P.d_ops);
-    if (P.d_breaks) hipFree(P.d_breaks);
-    P.d_breaks = nullptr;
+    HIPCHK(hipStreamSynchronize(P.stream));                  // (a pooled block is handed out again at once: nothing may still read the old one)
+    pool_free(P.d_ops); pool_free(P.d_breaks);
+    P.d_ops = nullptr; P.d_breaks = nullptr;
     P.ops_cap = std::max<int64_t>(n, 1024);
-    HIPCHK(hipMalloc(&P.d_ops, (size_t)P.ops_cap * sizeof(Op)));
-    HIPCHK(hipMalloc(&P.d_breaks, (size_t)(P.ops_cap / 64 + 8) * sizeof(uint64_t)));
+    HIPCHK(pool_alloc(reinterpret_cast<void**>(&P.d_ops), (size_t)P.ops_cap * sizeof(Op)));
+    HIPCHK(pool_alloc(reinterpret_cast<void**>(&P.d_breaks), (size_t)(P.ops_cap / 64 + 8) * sizeof(uint64_t)));
 }
 // the ops of a batch into d_ops (stream-ordered; the host arrays must stay alive until the batch has finished — every batch waits)
 void upload_batch(Pma& P, const OpBatch& B) {
@@ -554,9 +554,10 @@ void upload_batch(Pma& P, const OpBatch& B) {
         return;
     }
     if (n > P.opsrc_cap) {
-        if (P.d_opsrc) hipFree(P.d_opsrc);
+        HIPCHK(hipStreamSynchronize(P.stream));
+        pool_free(P.d_opsrc); P.d_opsrc = nullptr;
         P.opsrc_cap = std::max<int64_t>(n, P.ops_cap);
-        HIPCHK(hipMalloc(&P.d_opsrc, (size_t)P.opsrc_cap * 3 * sizeof(int64_t)));
+        HIPCHK(pool_alloc(reinterpret_cast<void**>(&P.d_opsrc), (size_t)P.opsrc_cap * 3 * sizeof(int64_t)));
     }
     int64_t* da = P.d_opsrc; int64_t* db = P.d_opsrc + P.opsrc_cap; double* dv = reinterpret_cast<double*>(P.d_opsrc + 2 * P.opsrc_cap);
     HIPCHK(hipMemcpyAsync(da, B.a, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, P.stream));
@@ -809,18 +810,23 @@ bool seq_step(SeqRun& r) {
             static const bool model3 = [] { const char* v = dev_env("DSA_MODEL3"); return !(v && v[0] == '0'); }();
             // (typed runs on segments below 16 slots are not count-only — appendmodel.hip — and runs below its minimum length do not pay:
             //  no launch for them)
-            const bool m3_takes = model3 && R >= 512 && (P.has_cols ? c.segment_capacity >= 16 : c.segment_capacity >= 2) && c.capacity >= 65536;
+            const bool m3_takes = model3 && !g_models_off.load() && R >= 512 && (P.has_cols ? c.segment_capacity >= 16 : c.segment_capacity >= 2) && c.capacity >= 65536;
             // typed runs on 8-slot segments (a matrix grown from the empty one: BASELINE config 5) are not count-only; their replay is the
             // per-epoch model of appendmodel.hip (k_append_model5).  DSA_MODEL5=0: per-op replay only (A/B, coverage)
             static const bool model5 = [] { const char* v = dev_env("DSA_MODEL5"); return !(v && v[0] == '0'); }();
-            const bool m5_takes = model5 && !m3_takes && P.has_cols && c.segment_capacity == 8 && R >= 64 && c.capacity >= 256;
+            const bool m5_takes = model5 && !g_models_off.load() && !m3_takes && P.has_cols && c.segment_capacity == 8 && R >= 64 && c.capacity >= 256;
             int64_t* m3_out = (m3_takes || m5_takes) ? reinterpret_cast<int64_t*>(reinterpret_cast<char*>(P.run_memo) + append_run_memo_bytes()) : nullptr;
             if (m3_takes) {
                 e = launch_append_model3(P.O(), P.d_ctl, R, P.has_cols ? P.run_flags : nullptr, P.has_cols ? P.run_out : nullptr, m3_out, P.stream);
-                if (e != hipSuccess) fail(DSA_EHIP, std::string("append model launch: ") + hipGetErrorString(e));
             } else if (m5_takes) {
                 e = launch_append_model5(P.O(), P.d_ctl, R, P.run_flags, P.run_out, m3_out, P.stream);
-                if (e != hipSuccess) fail(DSA_EHIP, std::string("typed append model launch: ") + hipGetErrorString(e));
+            }
+            if ((m3_takes || m5_takes) && e != hipSuccess) {
+                // The models need 140 KB of LDS per workgroup (gfx950 has 160): on a part that refuses the launch (hipFuncSetAttribute /
+                // launch error) the run is not lost — the per-op replay takes all of it, and the models stay off for the process.
+                (void)hipGetLastError();
+                g_models_off.store(true);
+                m3_out = nullptr;
             }
             e = launch_append_run(P.O(), P.d_ctl, i0, R, P.has_cols ? P.run_flags : nullptr, P.has_cols ? P.run_out : nullptr, P.run_memo, m3_out, P.stream);
             if (e != hipSuccess) fail(DSA_EHIP, std::string("append run launch: ") + hipGetErrorString(e));
@@ -1067,7 +1073,8 @@ void pma_info(Pma& P, int64_t nb_partitions_or_len, int64_t* info) {
     info[DSA_INFO_STAT_GRID_REBALANCES] = P.stat_grid_rebalances;
     // HBM held by the structure: both slot buffers (keys, values, bitmap), the saved bitmap of append runs, the tables and the merge scratch
     info[DSA_INFO_HBM_BYTES] = 2 * (P.cap_alloc * (int64_t)(P.kb() + sizeof(double)) + P.occ_words * 8) + (P.occ_old ? P.occ_words * 8 : 0) +
-                               (P.has_sems ? c.table_cap * 8 : 0) + (P.has_cols ? c.table_cap * 9 : 0) + 2 * P.tmerge_cap * 8;
+                               (P.has_sems ? c.table_cap * 8 : 0) + (P.has_cols ? c.table_cap * 9 : 0) + 2 * P.tmerge_cap * 8 +
+                               (P.d_ops ? P.ops_cap * (int64_t)sizeof(Op) + (P.ops_cap / 64 + 8) * 8 : 0) + (P.d_opsrc ? P.opsrc_cap * 24 : 0);      // op array, run-break bitmap, batch columns
 }
 
 void export_slots(Pma& P, int64_t* keys, double* vals, uint8_t* occ, int64_t cap) {

@@ -104,62 +104,6 @@ __device__ int64_t pb_wave_count(const uint64_t* occ, int64_t ws, int64_t we, bo
     return pb_wave_sum(c);
 }
 
-// ---- a window of the occupancy bitmap in registers --------------------------------------------------------------------------------
-// The plan of an op is a chain of DEPENDENT memory round trips (~0.6 us each under load): table search, semaphores, find, shift target,
-// one count per level of the density scan — and every step after the find re-read the same one or two occupancy words through its own
-// helper (_nextemptypos, the walk-left loops of find, _nbcells).  One wave-wide load puts 64 words — the 2048-slot aligned block around an
-// anchor position and the block behind it: every window a wave may rebalance around the anchor, and any shift target nearby — into one
-// register per lane; the bit scans and counts behind it are ballots and v_readlane, no memory.  Words at or beyond the end of the array
-// read as FULL (no free slot is ever reported there; windows never reach there).
-__device__ __forceinline__ int pb_ufl(int v) { return __builtin_amdgcn_readfirstlane(v); }
-struct OccWin {
-    uint64_t w;            // lane l: occupancy word wbase + l
-    int64_t wbase;         // 0-based word index of lane 0 (wave-uniform); -1: no window
-    __device__ __forceinline__ bool covers(int64_t a, int64_t b) const {      // 1-based positions a <= b
-        return wbase >= 0 && ((a - 1) >> 6) >= wbase && ((b - 1) >> 6) < wbase + 64;
-    }
-    __device__ __forceinline__ uint64_t word(int i) const {                   // i wave-uniform, 0 <= i < 64
-        const int iu = pb_ufl(i);
-        return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(w >> 32), iu) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)w, iu);
-    }
-    // _nextemptypos(array, from) inside the window: smallest free position > from, or -1 when the window holds none (the caller asks the bitmap)
-    __device__ __forceinline__ int64_t next_empty(int64_t from) const {
-        const int li = (int)((from >> 6) - wbase), lane = lane_id();
-        uint64_t z = ~w;
-        if (lane == li) z &= ~mask_lt((int)(from & 63));
-        if (lane < li) z = 0ull;
-        const unsigned long long any = __builtin_amdgcn_ballot_w64(z != 0ull);
-        if (any == 0ull) return -1;
-        const int fl = __ffsll(any) - 1;
-        const uint64_t zz = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(z >> 32), fl) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)z, fl);
-        return ((wbase + fl) << 6) + __ffsll((unsigned long long)zz);
-    }
-    // occupied cells of [ws, we] (inside the window)
-    __device__ __forceinline__ int64_t count(int64_t ws, int64_t we) const {
-        const int64_t lo0 = ws - 1, hi0 = we - 1;
-        if ((lo0 >> 6) == (hi0 >> 6)) return popc64(word((int)((lo0 >> 6) - wbase)) & word_range_mask(lo0 >> 6, lo0, hi0));      // a leaf, a small window: one word
-        return pb_wave_sum((int64_t)popc64(w & word_range_mask(wbase + lane_id(), lo0, hi0)));
-    }
-    // occupancy of the 64 positions p0 .. p0 + 63 (bit l <-> position p0 + l); inside the window
-    __device__ __forceinline__ uint64_t bits64(int64_t p0) const {
-        const int i0 = (int)(((p0 - 1) >> 6) - wbase), sh = (int)((p0 - 1) & 63);
-        const uint64_t w0 = word(i0);
-        if (sh == 0) return w0;
-        const uint64_t w1 = i0 + 1 < 64 ? word(i0 + 1) : ~0ull;
-        return (w0 >> sh) | (w1 << (64 - sh));
-    }
-};
-__device__ __forceinline__ OccWin pb_occwin_load(const uint64_t* occ, int64_t anchor, int64_t capacity) {
-    OccWin win;
-    win.wbase = -1; win.w = ~0ull;
-    if (anchor >= 1 && anchor <= capacity) {
-        win.wbase = ((anchor - 1) >> 11) << 5;
-        const int64_t wi = win.wbase + lane_id(), lastw = (capacity - 1) >> 6;
-        win.w = wi <= lastw ? occ[wi] : ~0ull;
-    }
-    return win;
-}
-
 // Plan of ONE op by one wave (read-only): what the op would do on the current state, and its footprint.  w = index of the op in its
 // round (new columns take table entries in that order), max_w = largest window one wave of the caller rebalances.
 __device__ Plan pb_plan_one(KeyArr keys, const double* vals, const uint64_t* occ, const int64_t* sems, const int64_t* col_keys,
@@ -232,13 +176,9 @@ __device__ Plan pb_plan_one(KeyArr keys, const double* vals, const uint64_t* occ
             // semaphore, or nothing was rebalanced, the second empty slot of the pre-round state (ne2 <= B) is still free.
             const int64_t p1 = sems[sidx] - 1;                        // _insert! after p1: the new semaphore lands on p1 + 1
             const int64_t ip1 = p1 + 1;
-            const OccWin win = pb_occwin_load(occ, ip1, capacity);      // the bitmap around the insertion point: both gaps and every count below come from it
-            int64_t ne1 = win.wbase >= 0 ? win.next_empty(p1) : -1;
-            if (ne1 < 0) ne1 = d_next_empty(occ, p1, capacity);
-            int64_t ne2 = ne1 != 0 ? ((win.wbase >= 0 && win.covers(ne1, ne1)) ? win.next_empty(ne1) : -1) : 0;
-            if (ne2 < 0) ne2 = d_next_empty(occ, ne1, capacity);
+            const int64_t ne1 = d_next_empty(occ, p1, capacity);
+            const int64_t ne2 = ne1 != 0 ? d_next_empty(occ, ne1, capacity) : 0;
             fp_pos(p1 + 1, ne2 != 0 ? ne2 : capacity);
-            auto cells_of = [&](int64_t a, int64_t b) { return win.covers(a, b) ? win.count(a, b) : pb_wave_count(occ, a, b, false); };
             why = 3;
             if (p1 >= 1 && ne1 != 0 && ne2 != 0) {
                 why = 5;
@@ -249,7 +189,7 @@ __device__ Plan pb_plan_one(KeyArr keys, const double* vals, const uint64_t* occ
                     if (W > max_w) break;
                     A = ((ip1 - 1) / W) * W + 1; B = A + W - 1;
                     if (ne2 > B || ip1 >= B) continue;
-                    cnt = cells_of(A, B);
+                    cnt = pb_wave_count(occ, A, B, false);
                     fp_cnt(A, B);
                     if (ctl->lo[h] <= cnt + 1 && cnt + 2 <= ctl->hi[h]) { H = h; break; }
                 }
@@ -275,7 +215,7 @@ __device__ Plan pb_plan_one(KeyArr keys, const double* vals, const uint64_t* occ
                     if (seg > 64) {
                         // (counts travel in 7 bits)
                     } else if (ip1 < l1) {
-                        const int64_t cl = H == 0 ? cnt : cells_of(l0, l1);
+                        const int64_t cl = H == 0 ? cnt : pb_wave_count(occ, l0, l1, false);
                         fp_cnt(l0, l1);
                         const int64_t c1 = cl + (ne1 <= l1 ? 1 : 0), c2 = c1 + (ne2 <= l1 ? 1 : 0);
                         if (ctl->lo[0] <= c1 && c2 <= ctl->hi[0]) { tight = true; tcount = lvl | 0x80 | ((int32_t)cl << 8); }
@@ -285,7 +225,7 @@ __device__ Plan pb_plan_one(KeyArr keys, const double* vals, const uint64_t* occ
                         // second the next one, which receives whatever gaps of its own the two runs fill.  Two leaves to accept
                         // (flag 0x8000 + the second count); without this a semaphore on slot 512 k needed a window of 1024 slots.
                         const int64_t m1 = l1 + seg;
-                        const int64_t cl = cells_of(l0, l1), cm = cells_of(l1 + 1, m1);
+                        const int64_t cl = pb_wave_count(occ, l0, l1, false), cm = pb_wave_count(occ, l1 + 1, m1, false);
                         fp_cnt(l0, l1); fp_cnt(l1 + 1, m1);
                         const int64_t c2 = cm + (ne1 <= m1 ? 1 : 0) + (ne2 <= m1 ? 1 : 0);
                         if (ctl->lo[0] <= cl && cl <= ctl->hi[0] && ctl->lo[0] <= cm && c2 <= ctl->hi[0]) {
@@ -301,41 +241,7 @@ __device__ Plan pb_plan_one(KeyArr keys, const double* vals, const uint64_t* occ
         }
     }
     if (plannable) {
-        OccWin win;
-        win.wbase = -1; win.w = ~0ull;
-        DFound f;
-        const int64_t lo_s = op.v != 0.0 ? from : del_from;      // first slot of the searched range
-        if (op.kind == OP_MPCSC_SET && to - del_from <= 61 && lo_s <= to) {
-            // A partition of up to 62 slots (a column of config 5's twin, a row of a sparse matrix): lane l <-> position sp + l, sp the
-            // semaphore.  ONE load of the bitmap window and ONE of the keys of the occupied slots replace the probes of the 64-ary find
-            // (occupancy word, key, next occupied, key, previous occupied, key: dependent round trips each).  Same answer as d_find_fast
-            // on a key-partitioned range: the cell holding the key if present, else the last cell of the range with a smaller key, else
-            // the nearest occupied cell left of the range — the semaphore on slot sp (src/finds.jl:29-57).
-            const int64_t sp = del_from;
-            win = pb_occwin_load(occ, sp, capacity);
-            const int lane = lane_id();
-            const uint64_t bits = win.bits64(sp);
-            const int64_t pl_ = sp + lane;
-            const bool inr = pl_ >= lo_s && pl_ <= to && ((bits >> lane) & 1ull);
-            const int64_t kk = inr ? (int64_t)keys[pl_ - 1] : 0;
-            const unsigned long long viol = __builtin_amdgcn_ballot_w64(inr && kk >= op.a);
-            const int fv = viol ? __ffsll(viol) - 1 : (int)(to - sp + 1);                    // first cell of the range with a key >= the target (or one past the range)
-            const bool hit = viol != 0ull && __builtin_amdgcn_ballot_w64(inr && kk == op.a && lane == fv) != 0ull;
-            if (hit) { f.pos = sp + fv; f.key = op.a; f.val = 0.0; f.has = true; }
-            else {
-                const uint64_t below = bits & mask_lt(fv);                                   // occupied cells in front of it — the semaphore (lane 0) among them
-                if (below != 0ull) {
-                    const int pv = 63 - __clzll((long long)below);
-                    f.pos = sp + pv; f.has = true; f.val = 0.0;
-                    // its key decides nothing below unless it equals the target, which only a cell INSIDE the range can (those were compared)
-                    f.key = (sp + pv >= lo_s) ? op.a - 1 : SEM_KEY - (op.a == SEM_KEY ? 1 : 0);
-                } else f = d_find_fast(keys, vals, occ, op.a, lo_s, to);                     // (cannot happen: slot sp holds the semaphore)
-            }
-        } else {
-            f = op.v != 0.0 ? d_find_fast(keys, vals, occ, op.a, from, to) : d_find_fast(keys, vals, occ, op.a, del_from, to);
-            win = pb_occwin_load(occ, f.has ? f.pos : 1, capacity);      // the shift target and the counts around the predecessor: one more load, then registers
-        }
-        auto cells_of = [&](int64_t a, int64_t b) { return win.covers(a, b) ? win.count(a, b) : pb_wave_count(occ, a, b, false); };
+        const DFound f = op.v != 0.0 ? d_find_fast(keys, vals, occ, op.a, from, to) : d_find_fast(keys, vals, occ, op.a, del_from, to);
         const bool exists = op.v != 0.0 ? (f.has && f.key == op.a && from <= f.pos && f.pos <= to)      // src/writes.jl:16
                                         : (f.has && f.key == op.a);                                     // src/writes.jl:59
         int64_t ip = 0, changed = 0, delta = 0, wlo = 1, whi = 0, rlo = 1, rhi = 0;
@@ -345,8 +251,7 @@ __device__ Plan pb_plan_one(KeyArr keys, const double* vals, const uint64_t* occ
                 pl.action = PB_OVERWRITE; pl.pos = f.pos; pl.lo = f.pos; pl.hi = f.pos;
             } else {
                 const int64_t p = f.pos;
-                int64_t ne = (p + 1 <= capacity && win.covers(p + 1, p + 1)) ? win.next_empty(p) : -1;
-                if (ne < 0) ne = d_next_empty(occ, p, capacity);
+                const int64_t ne = d_next_empty(occ, p, capacity);
                 fp_pos(p + 1, ne != 0 ? ne : capacity);
                 rlo = p >= 1 ? p : 1; rhi = p + 1 <= capacity ? p + 1 : capacity;
                 if (ne != 0) { pl.action = PB_INS_R; ip = p + 1; changed = ne; wlo = p + 1; whi = ne; pl.aux = ne; scan = true; }
@@ -378,7 +283,7 @@ __device__ Plan pb_plan_one(KeyArr keys, const double* vals, const uint64_t* occ
                 if (W > max_w && h > 0) break;
                 ws = ((ip - 1) / W) * W + 1;
                 we = ws + W - 1;
-                c = cells_of(ws, we) + ((changed >= ws && changed <= we) ? delta : 0);
+                c = pb_wave_count(occ, ws, we, false) + ((changed >= ws && changed <= we) ? delta : 0);
                 fp_cnt(ws, we);
                 if (ctl->lo[h] <= c && c <= ctl->hi[h]) { accepted = true; break; }
             }

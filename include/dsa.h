@@ -64,7 +64,9 @@ enum {
     DSA_INFO_STAT_SEQ_OPS = 13,
     DSA_INFO_STAT_SPMV_NOMEMSET = 14, /* instrumentation: gather SpMV launches over this orientation that needed no memset of y */
     DSA_INFO_HBM_BYTES = 15,          /* bytes of HBM the structure holds (slot buffers x 2, bitmaps, tables, merge scratch) */
-    DSA_INFO_STAT_GRID_REBALANCES = 16, /* instrumentation: launches of the grid-wide pack/spread kernel (windows above 8192 slots, root, _extend!, _shrink!) */
+    DSA_INFO_STAT_GRID_REBALANCES = 16, /* instrumentation: launches of the grid-wide pack/spread kernel (windows above 8192 slots, root, _extend!, _shrink!).
+                                         * Windows an append run rebalances are replayed on the bitmap (csrc/appendmodel.hip) and moved by ONE K-permute
+                                         * at the end of the run, whatever their size: they count in STAT_REBALANCES / STAT_WINDOW_SLOTS, not here. */
     DSA_INFO_COUNT = 17
 };
 
@@ -152,7 +154,12 @@ int32_t dsa_mat_destroy(dsa_mat_t* h);
  * dsa_vec_set (size(m) is updated immediately); when the matrix holds deleted columns/rows — the only state in which a write
  * can fail in the reference — the write is applied before the call returns so the error surfaces here. */
 int32_t dsa_mat_set(dsa_mat_t* h, double val, int64_t row, int64_t col);
-/* n sequential setindex! calls in order */
+/* n sequential setindex! calls in order.  On success the state equals that of the n calls.  When write k fails (only possible while
+ * the matrix holds deleted columns / rows) the status and size(m) are those of the reference at its exception; the
+ * contents are a documented divergence: with tombstones the library applies the colmajor orientation of the batch first, so colmajor may
+ * already hold writes behind k that the reference never reaches (the reference itself leaves its two orientations inconsistent at that
+ * point: src/matrix.jl:43-62 updates colmajor, then throws in rowmajor).  A host that catches the error should treat the matrix as the
+ * reference's caller would: not usable for further column generation. */
 int32_t dsa_mat_set_batch(dsa_mat_t* h, const int64_t* I, const int64_t* J, const double* V, int64_t n);
 /* getindex(m, row, col)  src/matrix.jl:64-68 */
 int32_t dsa_mat_get(dsa_mat_t* h, int64_t row, int64_t col, double* out);

@@ -1,7 +1,7 @@
 """Prototype of the count-only append replay ("model v3"), checked against the CPU oracle.  Development scratch: validates the
 theory (tables V / X, descent, final reconstruction) before the HIP implementation in csrc/sequencer.hip.
 
-    python tools/scratch/model3_proto.py
+    python tests/repro/model3_proto.py
 """
 import math
 import os

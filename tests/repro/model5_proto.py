@@ -3,7 +3,7 @@ bit for bit against the CPU oracle.  Development scratch: validates the state ab
 cross-leaf shifts), the surviving-event reconstruction of the bitmap and the hand-back of the trailing partial epoch before the HIP
 implementation in csrc/appendmodel.hip (k_append_model5).
 
-    python tools/scratch/model5_proto.py
+    python tests/repro/model5_proto.py
 """
 import os
 import sys

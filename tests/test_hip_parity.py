@@ -2065,3 +2065,72 @@ def test_footprint_check_build_fires_on_the_two_resolver_bugs_of_round_4_and_is_
         assert r.returncode == 0 and "fuzz done" in r.stdout and "DSA_FP_CHECK" not in r.stdout, (mode, r.stdout[-2500:] + r.stderr[-1500:])
         r = _run_child(fuzz + ["15", str(31000 + int(mode))], env)
         assert r.returncode == 0 and "fuzz done" in r.stdout and "DSA_FP_CHECK" not in r.stdout, (mode, r.stdout[-2500:] + r.stderr[-1500:])
+
+
+@pytest.mark.gpu
+def test_concurrent_grid_rebalances_on_the_twin_streams_and_other_handles(dsa, hip, oracle):
+    """k_move2 (csrc/rebalance.hip) lets a workgroup wait for status words of LOWER block indices of its own launch — deadlock-free as long as
+    the workgroups of a launch start in index order, whatever else runs on the chip.  Here up to six launches of it are in flight at once:
+    one orientation each of two 2^21-slot matrices (every handle on its own streams, one host thread per handle) and two 2^20-slot vectors on theirs, 25
+    root rebalances each, while a third thread keeps a write batch running — then every layout must still equal the oracle's (a root rebalance
+    is layout-idempotent) and no launch may have raised its fault word (dsa_*_check turns it into DSA_EHIP)."""
+    import threading
+    m = n = 200_000
+    I = 1 + (np.array(splitmix_array(91, 1_000_000), dtype=np.uint64) % np.uint64(m)).astype(np.int64)
+    J = 1 + (np.array(splitmix_array(92, 1_000_000), dtype=np.uint64) % np.uint64(n)).astype(np.int64)
+    V = unit12_array(93, 1_000_000)
+    a = dsa.dynamicsparse(I, J, V, m, n, binding=hip)
+    a2 = dsa.dynamicsparse(I, J, V, m, n, binding=hip)          # (a handle is single-writer: one thread per handle)
+    b = dsa.dynamicsparse(I, J, V, m, n, binding=oracle)
+    assert a.info(dsa.COLMAJOR)["capacity"] >= 1 << 21
+    kv = np.arange(1, 700_001, dtype=np.int64) * 2
+    vecs = [dsa.dynamicsparsevec(kv, unit12_array(94 + q, len(kv)), binding=hip) for q in range(2)]
+    vref = [dsa.dynamicsparsevec(kv, unit12_array(94 + q, len(kv)), binding=oracle) for q in range(2)]
+    w = dsa.dynamicsparsevec(kv[:200_000], np.ones(200_000), binding=hip)
+    errors = []
+
+    def guard(fn):
+        def run():
+            try:
+                fn()
+            except Exception as e:      # noqa: BLE001 — reported by the main thread
+                errors.append(repr(e))
+        return run
+
+    def reb_mat(o):
+        for _ in range(25):
+            (a if o == dsa.COLMAJOR else a2).rebalance_root(o)
+
+    def reb_vec(v):
+        for _ in range(25):
+            v.rebalance_root()
+
+    def writer():
+        odd = 1 + 2 * (np.array(splitmix_array(97, 60_000), dtype=np.uint64) % np.uint64(200_000)).astype(np.int64)
+        for q in range(6):
+            w.set_batch(odd[q * 10_000:(q + 1) * 10_000], np.full(10_000, 2.0))
+
+    threads = [threading.Thread(target=guard(lambda o=o: reb_mat(o))) for o in (dsa.COLMAJOR, dsa.ROWMAJOR)]
+    threads += [threading.Thread(target=guard(lambda v=v: reb_vec(v))) for v in vecs]
+    threads.append(threading.Thread(target=guard(writer)))
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for o in (dsa.COLMAJOR, dsa.ROWMAJOR):
+        b.rebalance_root(o)
+    a.rebalance_root(dsa.ROWMAJOR); a2.rebalance_root(dsa.COLMAJOR)
+    assert_mat_equal(a, b)
+    assert_mat_equal(a2, b)
+    for v, r in zip(vecs, vref):
+        r.rebalance_root()
+        assert_vec_equal(v, r)
+    import ctypes as C
+    rep = (C.c_int64 * 8)()
+    for o in (dsa.COLMAJOR, dsa.ROWMAJOR):
+        hip.call("mat_check", a.h, o, rep)
+        assert list(rep)[2:7] == [0, 0, 0, 0, 0], list(rep)
+    for v in vecs + [w]:
+        hip.call("vec_check", v.h, rep)
+        assert list(rep)[2:7] == [0, 0, 0, 0, 0], list(rep)
