@@ -216,8 +216,11 @@ __global__ __launch_bounds__(SP_BLOCK) void k_spmv_gather(KeyArr keys, const dou
                                                           double* __restrict__ y, int64_t ny, int pattern) {
     typedef typename std::conditional<WIDE, int64_t, int32_t>::type key_t;      // physical key width, fixed at compile time for the streams
     const key_t* __restrict__ kp = static_cast<const key_t*>(keys.p);
-    __shared__ double sPw[SP_WAVES][SW_SLOTS + 1];      // [SW_SLOTS]: ZFILL, key of the partition in front of the span's first semaphore
-    __shared__ uint16_t sListw[SP_WAVES][SW_SLOTS];
+    // Products: with SHARE the 4 spans + the word behind the last one, FLAT (wave w at w * 512, running on into wave w + 1's slice);
+    // without it every wave keeps its own ninth word.  ~21 KB per workgroup: 7 workgroups per CU (8 were measured with a shorter
+    // semaphore list: no difference, the kernel is not occupancy-bound).
+    __shared__ double sPw[SHARE ? SP_WAVES * SW_WORDS * 64 + 64 : SP_WAVES * SW_SLOTS];
+    __shared__ uint16_t sListw[SP_WAVES][SW_WORDS * 64];
     __shared__ uint64_t sSb0[SP_WAVES];                 // SHARE: semaphore ballot of a wave's first word, number of semaphores of its span
     __shared__ int sNsem[SP_WAVES];
     const int lane = threadIdx.x & 63;
@@ -225,9 +228,7 @@ __global__ __launch_bounds__(SP_BLOCK) void k_spmv_gather(KeyArr keys, const dou
     // SHARE: one flat product array over the same storage — wave w's slots at [w * SW_WORDS * 64, ...), running on into wave w + 1's; behind
     // the four spans the ninth word of wave 3, then the four front keys
     constexpr int SPAN = SW_WORDS * 64;
-    double* sP = SHARE ? &sPw[0][0] + wv * SPAN : sPw[wv];
-    const int front_idx = SHARE ? SP_WAVES * SPAN + 64 + wv - wv * SPAN : SW_SLOTS;
-    static_assert(SP_WAVES * (SW_SLOTS + 1) >= SP_WAVES * SW_WORDS * 64 + 64 + SP_WAVES, "flat product array fits the per-wave slices");
+    double* sP = SHARE ? sPw + wv * SPAN : sPw + wv * SW_SLOTS;
     const bool ninth = !SHARE || wv == SP_WAVES - 1;    // this wave loads the word behind its span itself
     uint16_t* sList = sListw[wv];
     // XCD-aware tile mapping (see k_spmv): XCD g streams the g-th contiguous eighth of the slot array
@@ -242,72 +243,70 @@ __global__ __launch_bounds__(SP_BLOCK) void k_spmv_gather(KeyArr keys, const dou
     const int64_t w0 = tile * (SP_TILE / 64) + (int64_t)wv * SW_WORDS;
     if (w0 >= nwords) return;
     const bool count_pass = (pattern & 3) == 1;
-    const int64_t* other = table_len > 0 ? part_keys : (const int64_t*)occ;     // what idle lanes and semaphores read
 
     // ---- one round of requests (straight-line: word indices are clamped, not predicated) ---------------------------------
-    int64_t k[SW_WORDS + 1];
+    // the occupancy words of the span and of the word behind it: uniform loads, all of them issued before anything waits for one
+    // (round 4 loaded them one by one in front of each word's gathers: nine dependent scalar round trips per wave)
+    uint64_t ow[SW_WORDS + 1];
+#pragma unroll
+    for (int j = 0; j <= SW_WORDS; ++j) ow[j] = occ[w0 + j < nwords ? w0 + j : nwords - 1];
+    key_t k[SW_WORDS + 1];
     double v[SW_WORDS + 1];
 #pragma unroll
     for (int j = 0; j <= SW_WORDS; ++j) {
         if (SHARE && j == SW_WORDS && !ninth) { k[j] = 0; v[j] = 0.0; continue; }
         const int64_t w = w0 + j < nwords ? w0 + j : nwords - 1;
-        k[j] = (int64_t)(NT ? __builtin_nontemporal_load(kp + (w << 6) + lane) : kp[(w << 6) + lane]);
+        k[j] = NT ? __builtin_nontemporal_load(kp + (w << 6) + lane) : kp[(w << 6) + lane];
         v[j] = NT ? __builtin_nontemporal_load(vals + (w << 6) + lane) : vals[(w << 6) + lane];
     }
     // the word in front: does the previous span own the cells before our first semaphore?  (SHARE: waves 1..3 ask their neighbour)
     const int64_t pw = w0 > 0 ? w0 - 1 : 0;
     uint64_t pword = 0ull;
-    int64_t pk = 0;
+    key_t pk = 0;
     if (!SHARE || wv == 0) {
         pword = w0 > 0 ? occ[pw] : 0ull;
-        pk = (int64_t)kp[(pw << 6) + lane];
+        pk = kp[(pw << 6) + lane];
     }
+#pragma unroll
+    for (int j = 0; j <= SW_WORDS; ++j) if (w0 + j >= nwords) ow[j] = 0ull;
 
-    // ---- semaphore ballots, one gather per lane and word -----------------------------------------------------------------
+    // ---- cell / semaphore masks (wave-uniform 64-bit words), one x gather per lane and word ----------------------------------
+    // Everything a lane decides comes from a compare whose result IS the mask (v_cmp -> SGPR pair); the occupancy bit of a lane is
+    // the inverse ballot of the uniform word (no per-lane shifts).  Semaphores do not gather here: the row key of a partition is
+    // fetched once per ROW by the lane that sums it (below), together with the key of the partition in front of it (ZFILL).
     uint64_t sb[SW_WORDS + 1], cm[SW_WORDS + 1];
-    bool has_last = false;         // ZFILL: the last partition of the table has its semaphore in this span
-    int64_t front_key = 0; bool front_mine = false;
-    int64_t q[SW_WORDS + 1];       // cell: bits of x[key] ; semaphore: row key of its partition
+    double xq[SW_WORDS + 1];
+    const double* xs = nx > 0 ? x : (const double*)occ;          // what idle lanes read: the first 8 bytes of something that exists
+    const uint32_t nx32 = nx < 0x7fffffff ? (uint32_t)(nx > 0 ? nx : 0) : 0x7fffffffu;
     const uint32_t tlen = table_len < 0x7fffffff ? (uint32_t)table_len : 0x7fffffffu;
 #pragma unroll
     for (int j = 0; j <= SW_WORDS; ++j) {
-        if (SHARE && j == SW_WORDS && !ninth) { sb[j] = 0; cm[j] = 0; q[j] = 0; continue; }
-        const uint64_t word = w0 + j < nwords ? occ[w0 + j] : 0ull;
-        const bool bit = (word >> lane) & 1ull;
-        const bool issem = bit && k[j] == SEM_KEY;
-        sb[j] = __ballot(issem);
-        bool cell = bit && (uint64_t)(k[j] - 1) < (uint64_t)nx;           // 1 <= key <= nx (a semaphore wraps to 2^64-1)
+        if (SHARE && j == SW_WORDS && !ninth) { sb[j] = 0; cm[j] = 0; xq[j] = 0.0; continue; }
+        uint64_t inr;
+        if (WIDE) inr = __ballot((uint64_t)((int64_t)k[j] - 1) < (uint64_t)(nx > 0 ? nx : 0));      // 1 <= key <= nx (a semaphore wraps around)
+        else inr = __ballot((uint32_t)k[j] - 1u < nx32);
+        sb[j] = __ballot(k[j] == SEM_KEY) & ow[j];
+        cm[j] = inr & ow[j];
         // the word behind the span: only the cells in front of its first semaphore matter
-        if (j == SW_WORDS) cell = cell && lane < (sb[j] ? __ffsll((unsigned long long)sb[j]) - 1 : 64);
-        cm[j] = __ballot(cell);
-        const uint32_t id1 = (uint32_t)((int)v[j] - 1);                     // partition ids are stored as Float64 (src/pcsr.jl:104)
-        const bool semrow = issem && id1 < tlen;
-        const int64_t* base = cell ? (const int64_t*)x : other;
-        const int64_t idx = cell ? k[j] - 1 : (semrow ? (int64_t)id1 : 0);
-        q[j] = base[idx];
-        if (issem && !semrow) q[j] = 0;
-        if (ZFILL && j < SW_WORDS) {
-            // the first semaphore of the span fetches the key of the partition in front of it (ids ascend along the array);
-            // the last partition of the table is remembered: its owner zeroes the tail of y
-            bool earlier = (sb[j] & mask_lt(lane)) != 0;
-#pragma unroll
-            for (int i = 0; i < j; ++i) earlier = earlier || sb[i] != 0;
-            if (semrow && !earlier) { front_key = id1 > 0 ? part_keys[id1 - 1] : 0; front_mine = true; }
-            has_last = has_last || __ballot(semrow && id1 + 1 == tlen) != 0;
-        }
+        if (j == SW_WORDS) cm[j] &= sb[j] ? ((sb[j] & (0ull - sb[j])) - 1ull) : ~0ull;
+        const bool cell = __builtin_amdgcn_inverse_ballot_w64(cm[j]);
+        if (WIDE) { const int64_t idx = cell ? (int64_t)k[j] - 1 : 0; xq[j] = xs[idx]; }
+        else { const uint32_t idx = cell ? (uint32_t)k[j] - 1u : 0u; xq[j] = xs[idx]; }
     }
-    // ---- products and semaphore rows -> LDS ; compact the semaphores of the span ---------------------------------------
-    if (ZFILL && front_mine) sP[front_idx] = __longlong_as_double(front_key);
+    // ---- products -> LDS ; the semaphores of the span are compacted, their slot keeps the partition id (the stored Float64) -------
     int nsem = 0;
 #pragma unroll
     for (int j = 0; j <= SW_WORDS; ++j) {
         if (SHARE && j == SW_WORDS && !ninth) continue;
-        const bool cell = (cm[j] >> lane) & 1ull;
-        const bool issem = (sb[j] >> lane) & 1ull;
-        const double p = product_of(v[j], __longlong_as_double(q[j]), count_pass);
-        sP[j * 64 + lane] = issem ? __longlong_as_double(q[j]) : (cell ? p : 0.0);
-        if (j < SW_WORDS) {
-            if (issem) sList[nsem + popc64(sb[j] & mask_lt(lane))] = (uint16_t)(j * 64 + lane);
+        const bool cell = __builtin_amdgcn_inverse_ballot_w64(cm[j]);
+        const double p = product_of(v[j], xq[j], count_pass);
+        sP[j * 64 + lane] = cell ? p : 0.0;
+        if (j < SW_WORDS && sb[j] != 0ull) {
+            if (__builtin_amdgcn_inverse_ballot_w64(sb[j])) {
+                const int r = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(sb[j] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)sb[j], 0u));
+                sP[j * 64 + lane] = v[j];            // partition ids are stored as Float64 (src/pcsr.jl:104)
+                sList[nsem + r] = (uint16_t)(j * 64 + lane);
+            }
             nsem += popc64(sb[j]);
         }
     }
@@ -323,16 +322,29 @@ __global__ __launch_bounds__(SP_BLOCK) void k_spmv_gather(KeyArr keys, const dou
     bool closed = !behind_valid || sb[SW_WORDS] != 0;
     if (!SHARE) __builtin_amdgcn_wave_barrier();
 
+    // row key of the partition whose id sits in slot a of the span (0: no such partition) and — ZFILL — the key of the partition in
+    // front of it (ids ascend along the array and the tables are in key order there) and whether it is the last of the table
+    struct SemRow { int64_t row, prev; bool last; };
+    auto sem_row = [&](int a) -> SemRow {
+        const uint32_t id1 = (uint32_t)((int)sP[a] - 1);
+        const bool ok = id1 < tlen;
+        SemRow r;
+        r.row = part_keys[ok ? id1 : 0u];
+        r.prev = 0; r.last = false;
+        if (ZFILL) { r.prev = part_keys[ok && id1 > 0 ? id1 - 1u : 0u]; if (!(ok && id1 > 0)) r.prev = 0; r.last = ok && id1 + 1u == tlen; }
+        if (!ok) r.row = 0;
+        return r;
+    };
+
     double open_sum = 0.0;         // last row of the span (wave-uniform after the walk)
     int64_t open_row = 0;
     if (nsem > SW_COOP) {
-        // one lane per semaphore, left to right
+        // one lane per semaphore, left to right; the row key is requested first and needed last
         for (int e = lane; e < nsem; e += 64) {
             const int a = sList[e];
             const bool is_last = e == nsem - 1;
             const int end = is_last ? endpos : (int)sList[e + 1];
-            const int64_t row = __double_as_longlong(sP[a]);
-            if (ZFILL) zero_fill_front(y, ny, __double_as_longlong(sP[e > 0 ? (int)sList[e - 1] : front_idx]), row, is_last && has_last);
+            const SemRow sr = sem_row(a);
             double sum = 0.0;
             int t = a + 1;
             for (; t + 3 < end; t += 4) {
@@ -340,11 +352,12 @@ __global__ __launch_bounds__(SP_BLOCK) void k_spmv_gather(KeyArr keys, const dou
                 sum = sum + t0; sum = sum + t1; sum = sum + t2; sum = sum + t3;
             }
             for (; t < end; ++t) sum = sum + sP[t];
-            if (!is_last || closed) { if (row >= 1 && row <= ny) y[row - 1] = sum; }
+            if (ZFILL) zero_fill_front(y, ny, sr.prev, sr.row, is_last && sr.last);
+            if (!is_last || closed) { if (sr.row >= 1 && sr.row <= ny) y[sr.row - 1] = sum; }
         }
         if (!closed) {        // re-sum the open row cooperatively for the slow path below
             const int a = sList[nsem - 1];
-            open_row = __double_as_longlong(sP[a]);
+            open_row = sem_row(a).row;
             double sum = 0.0;
             for (int t = a + 1 + lane; t < endpos; t += 64) sum += sP[t];
             open_sum = wave_reduce_add_f64(sum);
@@ -355,13 +368,13 @@ __global__ __launch_bounds__(SP_BLOCK) void k_spmv_gather(KeyArr keys, const dou
             const int a = sList[e];
             const bool is_last = e == nsem - 1;
             const int end = is_last ? endpos : (int)sList[e + 1];
-            const int64_t row = __double_as_longlong(sP[a]);
-            if (ZFILL && lane == 0) zero_fill_front(y, ny, __double_as_longlong(sP[e > 0 ? (int)sList[e - 1] : front_idx]), row, is_last && has_last);
+            const SemRow sr = sem_row(a);
+            if (ZFILL && lane == 0) zero_fill_front(y, ny, sr.prev, sr.row, is_last && sr.last);
             double sum = 0.0;
             for (int t = a + 1 + lane; t < end; t += 64) sum += sP[t];
             sum = wave_reduce_add_f64(sum);
-            if (!is_last || closed) { if (lane == 0 && row >= 1 && row <= ny) y[row - 1] = sum; }
-            else { open_row = row; open_sum = sum; }
+            if (!is_last || closed) { if (lane == 0 && sr.row >= 1 && sr.row <= ny) y[sr.row - 1] = sum; }
+            else { open_row = sr.row; open_sum = sum; }
         }
     }
 
@@ -616,7 +629,9 @@ static void launch_gather_t(int64_t grid, hipStream_t stream, KeyArr keys, const
                             int64_t ny, int pattern) {
     // SHARE needs every wave of every workgroup at its barrier: whole tiles only (DSA_SPMV_SHARE=0: the form without the barrier)
     static const bool share_ok = [] { const char* e = dev_env("DSA_SPMV_SHARE"); return !(e && e[0] == '0'); }();
-    if (share_ok && capacity >= SP_TILE && capacity % SP_TILE == 0)
+    // SHARE pays where the gathers miss (config 3: 118.1 vs 121.2 us without it); where x is L2-resident the barrier costs more than the
+    // ninth word saves (banded shape: 90.9 vs 86.9 us), so the plain-stream instantiations run without it
+    if (NT && share_ok && capacity >= SP_TILE && capacity % SP_TILE == 0)
         hipLaunchKernelGGL((k_spmv_gather<WIDE, NT, ZFILL, true>), dim3((unsigned)grid), dim3(SP_BLOCK), 0, stream, keys, vals, occ, capacity, sems,
                            part_keys, table_len, x, nx, y, ny, pattern);
     else

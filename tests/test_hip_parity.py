@@ -1870,7 +1870,7 @@ def test_spmv_shared_words_form_is_bit_identical_to_the_plain_form(dsa, hip, tmp
     outs = []
     for share in ("1", "0"):
         f = str(tmp_path / ("y_share%s.npz" % share))
-        env = dict(os.environ, DSA_DEV="1", DSA_SPMV_SHARE=share)
+        env = dict(os.environ, DSA_DEV="1", DSA_SPMV_SHARE=share, DSA_SPMV_STREAM="nt")      # (SHARE is the form of the non-temporal instantiations)
         r = subprocess.run([sys.executable, os.path.join(root, "tools", "spmv_sharecheck.py"), f], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0 and "sharecheck wrote" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
         outs.append(np.load(f))
