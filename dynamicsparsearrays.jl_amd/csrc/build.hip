@@ -24,6 +24,7 @@
 // stable 64-bit sorts by key then by partition (rocPRIM) carrying the input index.
 // Bound: HBM (sort passes: 40 B per triple and pass).
 #include "dsa_dev.h"
+#include <functional>
 
 #include <algorithm>
 #include <cstring>
@@ -713,7 +714,7 @@ hipError_t device_key_scan(const int64_t* d_a, const int64_t* d_b, int64_t n, Ke
 // Returns the number of distinct cells and of partitions through counts[0..1] (host).  The scratch stays alive for phase 2
 // (build_emit), which writes counts[0] + #partitions stream cells.
 hipError_t build_prepare(const int64_t* d_part, const int64_t* d_key, const double* d_val, int64_t nnz, KeyRange part_range, KeyRange key_range,
-                         BuildScratch& s, int64_t counts[2], hipStream_t stream) {
+                         BuildScratch& s, int64_t counts[2], hipStream_t stream, const std::function<void()>* while_sorting) {
     s = BuildScratch();
     s.n = nnz; s.stream = stream;
     const size_t n = (size_t)nnz;
@@ -796,6 +797,10 @@ hipError_t build_prepare(const int64_t* d_part, const int64_t* d_key, const doub
     hipLaunchKernelGGL(k_bf_count, grid, block, 0, stream, (const uint64_t*)s.comp[cur], nnz, s.kbits, s.ibits, d_part ? 1 : 0, s.cnt_c, s.cnt_p);
     hipLaunchKernelGGL(k_bf_scan, dim3(1), dim3(1024), 0, stream, s.cnt_c, s.cnt_p, nblocks, dctl);
     BCHK(hipMemcpyAsync(hctl, dctl, sizeof(BuildCtl), hipMemcpyDeviceToHost, stream));
+    // everything above is in flight: host work of the caller that does not need the counts (allocations) goes here
+    if (while_sorting && *while_sorting) {
+        try { (*while_sorting)(); } catch (...) { (void)hipStreamSynchronize(stream); throw; }
+    }
     BCHK(hipStreamSynchronize(stream));
     counts[0] = (int64_t)hctl->ncells; counts[1] = (int64_t)hctl->nparts;
     return hipGetLastError();
@@ -805,7 +810,7 @@ static hipError_t emit_wide(const double* d_val, int32_t combine, BuildScratch& 
                             int64_t nparts_explicit, hipStream_t stream);
 
 hipError_t build_emit(const double* d_val, int32_t combine, BuildScratch& s, KeyArr out_keys, double* out_vals,
-                      int64_t* part_keys, int mode, int64_t nparts_explicit, hipStream_t stream) {
+                      int64_t* part_keys, int mode, int64_t nparts_explicit, hipStream_t stream, bool wait_and_free) {
     if (s.wide_path) return emit_wide(d_val, combine, s, out_keys, out_vals, part_keys, mode, nparts_explicit, stream);
     const int64_t nblocks = (s.n + RS_TILE - 1) / RS_TILE;
     BuildCtl* dctl = static_cast<BuildCtl*>(s.d_ctl);
@@ -819,6 +824,7 @@ hipError_t build_emit(const double* d_val, int32_t combine, BuildScratch& s, Key
         hipLaunchKernelGGL(k_emit_sems, dim3((unsigned)((nparts_explicit + 255) / 256)), dim3(256), 0, stream, comp, s.kbits, s.ibits, s.pmin,
                            (const uint32_t*)s.scell, s.n, nparts_explicit, out_keys, out_vals);
     hipError_t e = hipGetLastError();
+    if (!wait_and_free) return e;            // the caller enqueues more behind the emit and calls build_abort(s) after its own stream wait
     if (e == hipSuccess) e = hipStreamSynchronize(stream);
     free_scratch(s);
     return e;

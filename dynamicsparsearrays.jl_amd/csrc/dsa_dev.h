@@ -12,6 +12,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <functional>
 #include <mutex>
 
 namespace dsa {
@@ -326,13 +327,15 @@ hipError_t device_key_scan(const int64_t* d_a, const int64_t* d_b, int64_t n, Ke
 // HBM, initialised to {INT64_MAX, INT64_MIN, INT64_MAX, INT64_MIN, 0}); stream-ordered, no host wait
 hipError_t launch_key_scan_acc(const int64_t* d_a, const int64_t* d_b, int64_t n, long long* d_acc, hipStream_t stream);
 // phase 1: sort by (partition, key, input order), flags, counts; counts[0] = distinct cells, counts[1] = partitions
+// while_sorting (or nullptr): called once the sort kernels and the copy of the counts are in flight, before the wait for them
 hipError_t build_prepare(const int64_t* d_part, const int64_t* d_key, const double* d_val, int64_t nnz, KeyRange part_range, KeyRange key_range,
-                         BuildScratch& s, int64_t counts[2], hipStream_t stream);
+                         BuildScratch& s, int64_t counts[2], hipStream_t stream, const std::function<void()>* while_sorting = nullptr);
 // phase 2: emit the ordered cell stream [sem(0,id), entries...] (counts[0]+counts[1] cells) and the partition keys
 // mode 0: mapped partitions (semaphores + partition keys) ; 1: plain vector (d_part was nullptr) ; 2: explicit partition
 // ids 1..nparts_explicit in d_part (PackedCSC: empty partitions keep their semaphore)
+// wait_and_free = false: the kernels are only enqueued; the caller waits for the stream itself and releases the scratch with build_abort
 hipError_t build_emit(const double* d_val, int32_t combine, BuildScratch& s, KeyArr out_keys, double* out_vals,
-                      int64_t* part_keys, int mode, int64_t nparts_explicit, hipStream_t stream);
+                      int64_t* part_keys, int mode, int64_t nparts_explicit, hipStream_t stream, bool wait_and_free = true);
 void build_abort(BuildScratch& s);
 // a vector of up to 1024 entries by one launch; io = pinned landing area (see k_build_small_vec)
 hipError_t launch_build_small_vec(int64_t* io, int n, int cap, int32_t combine, KeyArr out_k, double* out_v, unsigned long long seq, hipStream_t stream);

@@ -20,6 +20,7 @@
 #include <cstddef>
 #include <cstring>
 #include <numeric>
+#include <functional>
 #include <mutex>
 #include <exception>
 #include <string>
@@ -364,7 +365,9 @@ void ensure_tables(Pma& P, int64_t need) {
             HIPCHK(hipMemcpyAsync(nl, P.col_live, (size_t)len, hipMemcpyDeviceToDevice, P.stream));
         }
     }
-    HIPCHK(hipStreamSynchronize(P.stream));
+    // (fresh tables: the memsets above are stream-ordered in front of whatever uses them — no wait; the K-build sizes its tables while
+    //  its sort kernels run on this stream, and a wait here would be a wait for the sort)
+    if (P.sems || P.col_keys || P.col_live) HIPCHK(hipStreamSynchronize(P.stream));
     pool_free(P.sems); pool_free(P.col_keys); pool_free(P.col_live);
     P.sems = ns; P.col_keys = nk; P.col_live = nl;
     P.h_ctl->table_cap = ncap;
@@ -428,7 +431,7 @@ void ensure_capacity_alloc(Pma& P, int64_t slots) {
         HIPCHK(hipMemcpyAsync(P.vals[P.cur], ov[P.cur], (size_t)old_slots * sizeof(double), hipMemcpyDeviceToDevice, P.stream));
         HIPCHK(hipMemcpyAsync(P.occ[P.cur], oo[P.cur], (size_t)old_words * sizeof(uint64_t), hipMemcpyDeviceToDevice, P.stream));
     }
-    HIPCHK(hipStreamSynchronize(P.stream));
+    if (ok[0] || ok[1]) HIPCHK(hipStreamSynchronize(P.stream));      // (old buffers: copied out of and about to be freed; a fresh array waits for nobody)
     for (int b = 0; b < 2; ++b) { pool_free(ok[b]); pool_free(ov[b]); pool_free(oo[b]); }
     P.occ_dirty[1 - P.cur] = 0;                       // fresh, zero-filled; occ_dirty[cur] keeps its value
     P.cap_alloc = n;
@@ -1237,6 +1240,10 @@ void read_range_general(Pma& P, int64_t from, int64_t to, std::vector<int64_t>& 
 // ------------------------------------------------------------------------------------------------
 // bulk builders (K-build): everything but the staging of the caller's arrays runs on the device
 // ------------------------------------------------------------------------------------------------
+// order of the emit + spread phases of concurrent K-builds on one device (see pma_build_dev)
+constexpr int MAX_EMIT_DEVICES = 16;
+static std::mutex g_emit_mu;
+static hipEvent_t g_emit_done[MAX_EMIT_DEVICES] = {};
 // K-build from device-resident triples: sort / combine / emit on the device (build.hip), then the full-array spread;
 // semaphores[] positions are written by the spread kernel.
 //   mode 0: one orientation of a matrix (MappedPackedCSC: partitions = distinct values of d_part)
@@ -1259,7 +1266,20 @@ void pma_build_dev(Pma& P, const int64_t* d_part, const int64_t* d_key, const do
     int64_t counts[2] = {0, 0};
     static const bool dbg_time = dev_env("DSA_DBG_TIME") != nullptr;
     const auto tp0 = std::chrono::steady_clock::now();
-    hipError_t e = build_prepare(d_part, d_key, d_val, nnz, part_range, key_range, sc, counts, P.stream);
+    // While the sort kernels run (build_prepare calls this between enqueueing them and waiting for the counts): tables and slot buffers
+    // for the UPPER bounds — every triple a cell of its own, every partition of the key range present.  The exact sizes are known only
+    // from the counts, but capacity_for is monotone and the allocations (13 of them, a dozen memsets) used to sit between the sort and
+    // the emit with the GPU idle: 180 of the 1500 us of config 3's closefillmode!.  Duplicates folded later only leave the buffers
+    // larger than needed (as after a _shrink!).  Only for a structure that holds nothing yet: growing an existing one waits for
+    // the stream (old contents are copied).
+    const std::function<void()> prealloc = [&] {
+        if (P.cap_alloc != 0 || P.sems != nullptr) return;
+        int64_t np_ub = mode == 2 ? nparts_explicit : 0;
+        if (mode == 0) np_ub = part_range.known() ? std::min<int64_t>(nnz, (int64_t)std::min<uint64_t>((uint64_t)part_range.hi - (uint64_t)part_range.lo, (uint64_t)nnz) + 1) : nnz;
+        if (P.has_sems) ensure_tables(P, std::max<int64_t>(2 * np_ub, 64));
+        ensure_capacity_alloc(P, 2 * capacity_for(nnz + np_ub));
+    };
+    hipError_t e = build_prepare(d_part, d_key, d_val, nnz, part_range, key_range, sc, counts, P.stream, &prealloc);
     const auto tp1 = std::chrono::steady_clock::now();
     if (e != hipSuccess) fail(DSA_EHIP, std::string("K-build prepare: ") + hipGetErrorString(e));
     const int64_t np = mode == 0 ? counts[1] : (mode == 2 ? nparts_explicit : 0);
@@ -1276,13 +1296,31 @@ void pma_build_dev(Pma& P, const int64_t* d_part, const int64_t* d_key, const do
     } catch (...) { build_abort(sc); throw; }
     const auto tp2 = std::chrono::steady_clock::now();
     ++P.layout_epoch;
-    e = build_emit(d_val, combine, sc, P.K(), P.V(), P.has_cols ? P.col_keys : nullptr, mode, nparts_explicit, P.stream);
-    if (e != hipSuccess) fail(DSA_EHIP, std::string("K-build emit: ") + hipGetErrorString(e));
+    // (the emit kernels are only enqueued: the spread goes in right behind them, the scratch of the sort is released after the one
+    //  stream wait of upload_ctl instead of after a wait of its own)
+    // The two orientations of a matrix are built side by side on two streams.  Their sort passes share the chip well; their emits — ten
+    // million 8-byte gathers of the values by input index each — and spreads do not: 293 + 263 us side by side against 100 us each alone,
+    // the spreads 118 + 78 against 54.  So the emit + spread of one build waits (on the device: an event, no host wait) for the emit +
+    // spread of the build enqueued before it.
+    std::unique_lock<std::mutex> emit_order(g_emit_mu);
+    const bool ordered = P.device >= 0 && P.device < MAX_EMIT_DEVICES;      // (events belong to a device: one slot per device)
+    if (ordered) {
+        hipEvent_t& ev = g_emit_done[P.device];
+        if (ev == nullptr) HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        else HIPCHK(hipStreamWaitEvent(P.stream, ev, 0));
+    }
+    e = build_emit(d_val, combine, sc, P.K(), P.V(), P.has_cols ? P.col_keys : nullptr, mode, nparts_explicit, P.stream, false);
+    if (e != hipSuccess) { emit_order.unlock(); build_abort(sc); fail(DSA_EHIP, std::string("K-build emit: ") + hipGetErrorString(e)); }
     const auto tp3 = std::chrono::steady_clock::now();
     P.h_ctl->stat_rebalances = 0; P.h_ctl->stat_window_slots = 0;
     if (P.capacity() != P.h_ctl->segment_capacity) { P.h_ctl->stat_rebalances = 1; P.h_ctl->stat_window_slots = P.capacity(); }
-    root_rebalance(P, n, P.capacity(), n, true);
-    upload_ctl(P);
+    try {
+        root_rebalance(P, n, P.capacity(), n, true);
+        if (ordered) HIPCHK(hipEventRecord(g_emit_done[P.device], P.stream));
+        emit_order.unlock();
+        upload_ctl(P);
+    } catch (...) { if (emit_order.owns_lock()) emit_order.unlock(); build_abort(sc); throw; }
+    build_abort(sc);          // (stream already waited for: releases the scratch)
     if (dbg_time) {
         auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
         fprintf(stderr, "  [pma_build_dev] prepare (alloc + sorts + scans) %.1f ms  tables/slot alloc %.1f ms  emit (+ free) %.1f ms  spread + ctl %.1f ms\n",

@@ -211,6 +211,23 @@ __global__ __launch_bounds__(BLOCK) void k_move2(Move2Args a) {
     if (PACKED) {
         P = t * M2_TILE < a.m ? t * M2_TILE : a.m;
         c = (int)(a.m - P < M2_TILE ? a.m - P : M2_TILE);
+        // the tile's cells, staged through LDS like those of a general source: ONE round of coalesced loads per thread (round 4 read
+        // each destination pair's cells from global memory inside the write loop: one dependent round trip per 128 offsets and wave —
+        // 148 us for the 10 M cells of config 3's build, twice the time of the general source that reads 70 % more)
+        constexpr int CPT = M2_TILE / BLOCK;
+        const key_t* __restrict__ kp = srck + a.src_lo0 + P;
+        const double* __restrict__ vp = a.src_vals + a.src_lo0 + P;
+        key_t kk[CPT]; double vv[CPT];
+#pragma unroll
+        for (int u = 0; u < CPT; ++u) {
+            const int i = tid + u * BLOCK;
+            const int ic = i < c ? i : (c > 0 ? c - 1 : 0);
+            kk[u] = __builtin_nontemporal_load(kp + ic);
+            vv[u] = __builtin_nontemporal_load(vp + ic);
+        }
+#pragma unroll
+        for (int u = 0; u < CPT; ++u) { const int i = tid + u * BLOCK; sK[i] = kk[u]; sV[i] = vv[u]; }
+        __syncthreads();
     } else {
         const int64_t w0 = (a.src_lo0 >> 6) + t * M2_WORDS;
         const int64_t wlast = a.src_hi0 >> 6;
@@ -338,8 +355,6 @@ __global__ __launch_bounds__(BLOCK) void k_move2(Move2Args a) {
     key_t* __restrict__ dk = dstk + a.dst_lo0;                       // offset q (1-based) lives in dk[q - 1]
     double* __restrict__ dv = a.dst_vals + a.dst_lo0;
     uint64_t* __restrict__ dw = a.dst_occ + (a.dst_lo0 >> 6);        // (windows of this kernel start on an occupancy word)
-    const key_t* __restrict__ pk = srck + a.src_lo0;                 // PACKED: the cell of rank r is pk[r - 1]
-    const double* __restrict__ pv = a.src_vals + a.src_lo0;
     typedef double d2v __attribute__((ext_vector_type(2)));
     typedef key_t k2v __attribute__((ext_vector_type(2)));
     const int g_first = Q0 & ~127, g_last = (Q1 - 1) & ~127;
@@ -352,13 +367,8 @@ __global__ __launch_bounds__(BLOCK) void k_move2(Move2Args a) {
             const int r0 = qa - k, r1 = qa + 1 - k;                   // 1-based ranks of the cells on qa / qa + 1 (when not gaps)
             key_t k0 = 0, k1 = 0;
             double v0 = 0.0, v1 = 0.0;
-            if (PACKED) {
-                if (!gp0) { k0 = pk[r0 - 1]; v0 = pv[r0 - 1]; }
-                if (!gp1) { k1 = pk[r1 - 1]; v1 = pv[r1 - 1]; }
-            } else {
-                if (!gp0) { k0 = sK[r0 - Pi - 1]; v0 = sV[r0 - Pi - 1]; }
-                if (!gp1) { k1 = sK[r1 - Pi - 1]; v1 = sV[r1 - Pi - 1]; }
-            }
+            if (!gp0) { k0 = sK[r0 - Pi - 1]; v0 = sV[r0 - Pi - 1]; }
+            if (!gp1) { k1 = sK[r1 - Pi - 1]; v1 = sV[r1 - Pi - 1]; }
             if (a.sems != nullptr) {                                  // spread! with semaphores  src/moves.jl:160-166
                 if (!gp0 && k0 == SEM_KEY) a.sems[(int64_t)v0 - 1] = a.dst_lo0 + qa;
                 if (!gp1 && k1 == SEM_KEY) a.sems[(int64_t)v1 - 1] = a.dst_lo0 + qa + 1;
@@ -390,8 +400,7 @@ __global__ __launch_bounds__(BLOCK) void k_move2(Move2Args a) {
                 o2[jj] = !gap && qa + jj <= Wd;
                 if (o2[jj] && own[jj]) {
                     const int rank = qa + jj - k;
-                    if (PACKED) { k2[jj] = pk[rank - 1]; v2[jj] = pv[rank - 1]; }
-                    else { k2[jj] = sK[rank - Pi - 1]; v2[jj] = sV[rank - Pi - 1]; }
+                    k2[jj] = sK[rank - Pi - 1]; v2[jj] = sV[rank - Pi - 1];
                     if (a.sems != nullptr && k2[jj] == SEM_KEY) a.sems[(int64_t)v2[jj] - 1] = a.dst_lo0 + qa + jj;   // 1-based slot
                 }
             }
@@ -755,8 +764,16 @@ hipError_t launch_rebalance(KeyArr src_keys, const double* src_vals, const uint6
         if (src_packed) {
             a.ntiles = std::max<int64_t>(1, (m + M2_TILE_BIG - 1) / M2_TILE_BIG);
             a.status = nullptr; a.gen = 0; a.fault = nullptr;
-            if (a.src_keys.wide) hipLaunchKernelGGL((k_move2<true, true, 256, M2_TILE_BIG>), dim3((unsigned)a.ntiles), dim3(256), 0, stream, a);
-            else hipLaunchKernelGGL((k_move2<true, false, 256, M2_TILE_BIG>), dim3((unsigned)a.ntiles), dim3(256), 0, stream, a);
+            // (512 threads up to 8192 tiles like the general source)
+            static const int force_block_p = [] { const char* e = dev_env("DSA_MOVE2_BLOCK"); return e ? atoi(e) : 0; }();
+            const int block = force_block_p ? force_block_p : (a.ntiles <= 8192 ? 512 : 256);
+            if (block == 512) {
+                if (a.src_keys.wide) hipLaunchKernelGGL((k_move2<true, true, 512, M2_TILE_BIG>), dim3((unsigned)a.ntiles), dim3(512), 0, stream, a);
+                else hipLaunchKernelGGL((k_move2<true, false, 512, M2_TILE_BIG>), dim3((unsigned)a.ntiles), dim3(512), 0, stream, a);
+            } else {
+                if (a.src_keys.wide) hipLaunchKernelGGL((k_move2<true, true, 256, M2_TILE_BIG>), dim3((unsigned)a.ntiles), dim3(256), 0, stream, a);
+                else hipLaunchKernelGGL((k_move2<true, false, 256, M2_TILE_BIG>), dim3((unsigned)a.ntiles), dim3(256), 0, stream, a);
+            }
             return hipGetLastError();
         }
         const int64_t Ws = src_we - src_ws + 1;
