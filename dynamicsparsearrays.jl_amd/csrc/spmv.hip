@@ -248,27 +248,52 @@ __global__ __launch_bounds__(SP_BLOCK) void k_spmv_gather(KeyArr keys, const dou
     // the occupancy words of the span and of the word behind it: uniform loads, all of them issued before anything waits for one
     // (round 4 loaded them one by one in front of each word's gathers: nine dependent scalar round trips per wave)
     uint64_t ow[SW_WORDS + 1];
-#pragma unroll
-    for (int j = 0; j <= SW_WORDS; ++j) ow[j] = occ[w0 + j < nwords ? w0 + j : nwords - 1];
     key_t k[SW_WORDS + 1];
     double v[SW_WORDS + 1];
-#pragma unroll
-    for (int j = 0; j <= SW_WORDS; ++j) {
-        if (SHARE && j == SW_WORDS && !ninth) { k[j] = 0; v[j] = 0.0; continue; }
-        const int64_t w = w0 + j < nwords ? w0 + j : nwords - 1;
-        k[j] = NT ? __builtin_nontemporal_load(kp + (w << 6) + lane) : kp[(w << 6) + lane];
-        v[j] = NT ? __builtin_nontemporal_load(vals + (w << 6) + lane) : vals[(w << 6) + lane];
-    }
-    // the word in front: does the previous span own the cells before our first semaphore?  (SHARE: waves 1..3 ask their neighbour)
-    const int64_t pw = w0 > 0 ? w0 - 1 : 0;
     uint64_t pword = 0ull;
     key_t pk = 0;
-    if (!SHARE || wv == 0) {
-        pword = w0 > 0 ? occ[pw] : 0ull;
-        pk = kp[(pw << 6) + lane];
-    }
+    if (!NT && w0 > 0 && w0 + SW_WORDS < nwords) {
+        // a span inside the array (all but the first and the last one): no clamping, ONE base address per stream and constant offsets —
+        // the general form below spends ~100 scalar and vector instructions per wave on index arithmetic.  Only where x is L2-resident
+        // (plain streams): the final config-5 product 8.2 -> 7.7 us; on config 3, whose gathers miss, the tighter burst of stream
+        // loads is the SLOWER form (118.5 vs 117.8 us, same box, twice)
+        const uint64_t* __restrict__ op = occ + w0;
+        const key_t* __restrict__ kb = kp + (w0 << 6) + lane;
+        const double* __restrict__ vb = vals + (w0 << 6) + lane;
 #pragma unroll
-    for (int j = 0; j <= SW_WORDS; ++j) if (w0 + j >= nwords) ow[j] = 0ull;
+        for (int j = 0; j <= SW_WORDS; ++j) ow[j] = op[j];
+        // keys first: the gathers wait for them, the values are not needed before the products
+#pragma unroll
+        for (int j = 0; j <= SW_WORDS; ++j) {
+            if (SHARE && j == SW_WORDS && !ninth) { k[j] = 0; continue; }
+            k[j] = NT ? __builtin_nontemporal_load(kb + j * 64) : kb[j * 64];
+        }
+        if (!SHARE || wv == 0) { pword = op[-1]; pk = kb[-64]; }
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int j = 0; j <= SW_WORDS; ++j) {
+            if (SHARE && j == SW_WORDS && !ninth) { v[j] = 0.0; continue; }
+            v[j] = NT ? __builtin_nontemporal_load(vb + j * 64) : vb[j * 64];
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j <= SW_WORDS; ++j) ow[j] = occ[w0 + j < nwords ? w0 + j : nwords - 1];
+#pragma unroll
+        for (int j = 0; j <= SW_WORDS; ++j) {
+            if (SHARE && j == SW_WORDS && !ninth) { k[j] = 0; v[j] = 0.0; continue; }
+            const int64_t w = w0 + j < nwords ? w0 + j : nwords - 1;
+            k[j] = NT ? __builtin_nontemporal_load(kp + (w << 6) + lane) : kp[(w << 6) + lane];
+            v[j] = NT ? __builtin_nontemporal_load(vals + (w << 6) + lane) : vals[(w << 6) + lane];
+        }
+        // the word in front: does the previous span own the cells before our first semaphore?  (SHARE: waves 1..3 ask their neighbour)
+        const int64_t pw = w0 > 0 ? w0 - 1 : 0;
+        if (!SHARE || wv == 0) {
+            pword = w0 > 0 ? occ[pw] : 0ull;
+            pk = kp[(pw << 6) + lane];
+        }
+#pragma unroll
+        for (int j = 0; j <= SW_WORDS; ++j) if (w0 + j >= nwords) ow[j] = 0ull;
+    }
 
     // ---- cell / semaphore masks (wave-uniform 64-bit words), one x gather per lane and word ----------------------------------
     // Everything a lane decides comes from a compare whose result IS the mask (v_cmp -> SGPR pair); the occupancy bit of a lane is
