@@ -223,6 +223,12 @@ __global__ __launch_bounds__(SP_BLOCK) void k_spmv_gather(KeyArr keys, const dou
     __shared__ uint16_t sListw[SP_WAVES][SW_WORDS * 64];
     __shared__ uint64_t sSb0[SP_WAVES];                 // SHARE: semaphore ballot of a wave's first word, number of semaphores of its span
     __shared__ int sNsem[SP_WAVES];
+    // Occupancy limiter of the non-temporal instantiations: 16 KB of LDS nobody uses make it 4 workgroups per CU instead of 7.  The kernel
+    // does not live on occupancy (2 per CU run config 3 within 2 %): fewer waves queueing in front of the CU's texture addresser were
+    // measured FASTER where the gathers hit (banded shape 84-87 vs 90 us, same box, twice) and equal on config 3 (117.6 vs 117.8).
+    // 3 per CU: config 3 +2 %; 5 per CU: no gain.
+    __shared__ double sPad[NT ? 2048 : 1];
+    if (capacity == -2) { sPad[threadIdx.x] = 1.0; __syncthreads(); y[0] = sPad[0]; }        // (never true: keeps the array allocated)
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // SHARE: one flat product array over the same storage — wave w's slots at [w * SW_WORDS * 64, ...), running on into wave w + 1's; behind
