@@ -361,6 +361,44 @@ def test_small_matrix_batches_match_oracle(dsa, hip, oracle, shape):
 
 
 @pytest.mark.gpu
+def test_kbuild_buffers_sized_for_the_upper_bound_then_duplicates_fold(dsa, hip, oracle):
+    """K-build allocates tables and slot buffers while its sort runs, for the UPPER bounds (every triple a cell of its own, every key of the
+    partition range a partition: csrc/dsa_host.hip, pma_build_dev) — the exact counts are known only after the sort.  When most triples are
+    duplicates, and when the partition keys are few but far apart, the structure ends up far smaller than its buffers: geometry, layout and
+    tables must still be the reference's (capacity from the FOLDED count, src/pma.jl:42-55), and the structure must keep working (writes,
+    _extend!, product) in buffers it did not size itself."""
+    g = np.random.default_rng(2025)
+    base_i = g.integers(1, 400, 3000)
+    base_j = g.integers(1, 300, 3000) * 100003                     # 300 distinct column keys spread over a range of 3 * 10^7
+    I = np.tile(base_i, 40)                                           # every (i, j) forty times: 120 000 triples, <= 3 000 cells
+    J = np.tile(base_j, 40)
+    V = 1.0 + g.random(len(I))
+    perm = g.permutation(len(I))
+    I, J, V = I[perm], J[perm], V[perm]
+    a = dsa.dynamicsparse(I, J, V, binding=hip)
+    b = dsa.dynamicsparse(I, J, V, binding=oracle)
+    assert_mat_equal(a, b)
+    for o in (0, 1):
+        assert a.info(o)["capacity"] == b.info(o)["capacity"] <= 8192      # (the upper bound would have been 2^18 slots)
+    I2 = g.integers(1, 2000, 20000)
+    J2 = g.integers(1, 300, 20000) * 100003 + g.integers(0, 2, 20000)
+    V2 = np.where(g.random(20000) < 0.2, 0.0, 1.0 + g.random(20000))
+    for m_ in (a, b):
+        m_.set_batch(I2, J2, V2)
+    assert_mat_equal(a, b)
+    assert a.info(0)["stat_extends"] == b.info(0)["stat_extends"] >= 1
+    x = 1.0 + g.random(a.size()[1])
+    np.testing.assert_allclose(a.mul(x), b.mul(x), rtol=RTOL, atol=0)
+    # the same through fill mode (closefillmode! -> the same builder on the device-resident buffer)
+    c = dsa.dynamicsparse(fill_mode=True, binding=hip)
+    d = dsa.dynamicsparse(fill_mode=True, binding=oracle)
+    for m_ in (c, d):
+        m_.set_batch(I, J, V)
+        m_.closefillmode()
+    assert_mat_equal(c, d)
+
+
+@pytest.mark.gpu
 def test_column_generation_with_deletions_matches_oracle(dsa, hip, oracle):
     """Column generation with deletions (Coluna's pattern: new columns get new, larger ids while old ones are deleted): batches of new
     columns streamed into a matrix whose colmajor tables hold tombstones.  A batch whose column keys never decrease and start at or
