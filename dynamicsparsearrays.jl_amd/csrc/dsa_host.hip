@@ -1279,7 +1279,9 @@ void pma_build_dev(Pma& P, const int64_t* d_part, const int64_t* d_key, const do
         if (P.has_sems) ensure_tables(P, std::max<int64_t>(2 * np_ub, 64));
         ensure_capacity_alloc(P, 2 * capacity_for(nnz + np_ub));
     };
-    hipError_t e = build_prepare(d_part, d_key, d_val, nnz, part_range, key_range, sc, counts, P.stream, &prealloc);
+    hipError_t e;
+    try { e = build_prepare(d_part, d_key, d_val, nnz, part_range, key_range, sc, counts, P.stream, &prealloc); }
+    catch (...) { build_abort(sc); throw; }          // (an allocation of `prealloc` failed: the scratch of the sort is released here)
     const auto tp1 = std::chrono::steady_clock::now();
     if (e != hipSuccess) fail(DSA_EHIP, std::string("K-build prepare: ") + hipGetErrorString(e));
     const int64_t np = mode == 0 ? counts[1] : (mode == 2 ? nparts_explicit : 0);

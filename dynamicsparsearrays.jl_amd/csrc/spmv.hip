@@ -272,14 +272,14 @@ __global__ __launch_bounds__(SP_BLOCK) void k_spmv_gather(KeyArr keys, const dou
 #pragma unroll
         for (int j = 0; j <= SW_WORDS; ++j) {
             if (SHARE && j == SW_WORDS && !ninth) { k[j] = 0; continue; }
-            k[j] = NT ? __builtin_nontemporal_load(kb + j * 64) : kb[j * 64];
+            k[j] = kb[j * 64];
         }
         if (!SHARE || wv == 0) { pword = op[-1]; pk = kb[-64]; }
         asm volatile("" ::: "memory");
 #pragma unroll
         for (int j = 0; j <= SW_WORDS; ++j) {
             if (SHARE && j == SW_WORDS && !ninth) { v[j] = 0.0; continue; }
-            v[j] = NT ? __builtin_nontemporal_load(vb + j * 64) : vb[j * 64];
+            v[j] = vb[j * 64];
         }
     } else {
 #pragma unroll
@@ -360,10 +360,9 @@ __global__ __launch_bounds__(SP_BLOCK) void k_spmv_gather(KeyArr keys, const dou
         const uint32_t id1 = (uint32_t)((int)sP[a] - 1);
         const bool ok = id1 < tlen;
         SemRow r;
-        r.row = part_keys[ok ? id1 : 0u];
-        r.prev = 0; r.last = false;
-        if (ZFILL) { r.prev = part_keys[ok && id1 > 0 ? id1 - 1u : 0u]; if (!(ok && id1 > 0)) r.prev = 0; r.last = ok && id1 + 1u == tlen; }
-        if (!ok) r.row = 0;
+        r.row = 0; r.prev = 0; r.last = false;
+        if (ok) r.row = part_keys[id1];              // (an id outside the table — there is none in a consistent structure — reads nothing)
+        if (ZFILL) { if (ok && id1 > 0) r.prev = part_keys[id1 - 1u]; r.last = ok && id1 + 1u == tlen; }
         return r;
     };
 
