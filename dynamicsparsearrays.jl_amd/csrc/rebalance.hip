@@ -167,7 +167,8 @@ struct Move2Args {
     unsigned long long* fault;     // raised by a workgroup that gave up waiting for a status word (see M2_SPIN_MAX)
     double cells_to_gaps;          // E / m: starting guess of #gaps in front of a rank
     double geom_f, geom_inv_f;     // SpreadGeom::f / inv_f of (Wd, m), divided once on the host (IEEE: the same doubles as on the device)
-    int dbg;                       // DSA_DBG_MOVE2 ablation knob (dev only): 1 = no waiting for status words, 2 = no write phase, 4 = closed-form P
+    int dbg;                       // DSA_DBG_MOVE2 ablation knob (dev only): 1 = no waiting for status words, 2 = no write phase, 4 = closed-form P,
+                                   // 8 = the group totals are NOT published, 16 = give up after 4096 polls (8 + 16: the fault path, tests)
 };
 
 // 1-based destination offset of the cell of rank r (1 <= r <= m)
@@ -261,7 +262,7 @@ __global__ __launch_bounds__(BLOCK) void k_move2(Move2Args a) {
                 const uint32_t ex = wave_excl_scan(tc);
                 const int64_t tt = (t << 6) + lane;
                 if (tt < a.ntiles) __hip_atomic_store(a.status + tt, (a.gen << 34) | (unsigned long long)ex, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (lane == 63) __hip_atomic_store(gstatus + t, (a.gen << 34) | (unsigned long long)(ex + tc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (lane == 63 && !(a.dbg & 8)) __hip_atomic_store(gstatus + t, (a.gen << 34) | (unsigned long long)(ex + tc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
         // ---- 1. ONE round of loads: the 32 occupancy words of the tile (every wave reads them: no barrier) and, without
@@ -320,8 +321,9 @@ __global__ __launch_bounds__(BLOCK) void k_move2(Move2Args a) {
             }
         }
         // ---- 3. cells in front of the tile ------------------------------------------------------------------------------------
+        const unsigned int spin_max = (a.dbg & 16) ? 4096u : M2_SPIN_MAX;
         for (unsigned int spin = 0; (st0 >> 34) != a.gen; ++spin) {
-            if (spin == M2_SPIN_MAX) { atomicExch(a.fault, 1ull); break; }
+            if (spin == spin_max) { atomicExch(a.fault, 1ull); break; }
             __builtin_amdgcn_s_sleep(1); st0 = __hip_atomic_load(poll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         uint32_t part = (uint32_t)st0;
@@ -329,7 +331,7 @@ __global__ __launch_bounds__(BLOCK) void k_move2(Move2Args a) {
             for (int64_t j = tid - 64 + (BLOCK - 64); j < grp; j += BLOCK - 64) {
                 unsigned long long st = __hip_atomic_load(gstatus + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 for (unsigned int spin = 0; (st >> 34) != a.gen; ++spin) {
-                    if (spin == M2_SPIN_MAX) { atomicExch(a.fault, 1ull); break; }
+                    if (spin == spin_max) { atomicExch(a.fault, 1ull); break; }
                     __builtin_amdgcn_s_sleep(1); st = __hip_atomic_load(gstatus + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 part += (uint32_t)st;

@@ -2106,6 +2106,45 @@ def test_footprint_check_build_fires_on_the_two_resolver_bugs_of_round_4_and_is_
 
 
 @pytest.mark.gpu
+def test_grid_rebalance_that_never_gets_its_prefix_raises_ehip_instead_of_hanging():
+    """k_move2 (csrc/rebalance.hip) lets a workgroup wait for prefix words published by workgroups with a lower index — deadlock-free as
+    long as the hardware dispatches a 1-D grid in order.  The wait is bounded all the same: a workgroup that gives up raises a fault word
+    and carries on, and the next check of the structure reports DSA_EHIP.  Provoked here with the development switches (group totals
+    never published, 4096 polls instead of 2^24): the launch must come back, the checker must raise EHIP, the process must live on and
+    a fresh structure must still work."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1])
+import dsa_loader
+dsa = dsa_loader.load(); hip = dsa.product()
+n = 1_300_000                                   # capacity 2^21: 1024 tiles, 16 groups of 64 — every tile behind the first group waits
+keys = np.arange(1, n + 1, dtype=np.int64) * 3
+v = dsa.dynamicsparsevec(keys, np.ones(n), binding=hip)
+assert v.info()["capacity"] == 1 << 21
+v.check()                                       # the build spreads a PACKED source: closed-form prefixes, nobody waits
+v.rebalance_root()                              # a general source: the prefix table is needed and never completed
+try:
+    v.check()
+    print("no error raised")
+except dsa.DsaError as e:
+    print("raised", e.code)
+    assert e.code == 7          # DSA_EHIP (include/dsa.h)
+del v
+w = dsa.dynamicsparsevec(np.arange(1, 5001, dtype=np.int64), np.ones(5000), binding=hip)      # small: one workgroup per window, no table
+w.set_batch(np.arange(5001, 6001, dtype=np.int64), np.ones(1000))
+w.check()
+print("ok")
+"""
+    env = dict(os.environ, DSA_DEV="1", DSA_DBG_MOVE2="24")
+    r = subprocess.run([sys.executable, "-c", code, root], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "raised" in r.stdout and r.stdout.strip().endswith("ok"), r.stdout[-1500:] + r.stderr[-1500:]
+
+
+@pytest.mark.gpu
 def test_concurrent_grid_rebalances_on_the_twin_streams_and_other_handles(dsa, hip, oracle):
     """k_move2 (csrc/rebalance.hip) lets a workgroup wait for status words of LOWER block indices of its own launch — deadlock-free as long as
     the workgroups of a launch start in index order, whatever else runs on the chip.  Here up to six launches of it are in flight at once:
