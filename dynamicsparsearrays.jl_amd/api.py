@@ -361,6 +361,22 @@ class DynamicSparseMatrix(_Handle):
     def row_view(self, row):                          # @view m[row, :]  src/matrix.jl:70-81
         return self._view("mat_row_view", row)
 
+    def _view_dev(self, name, key, d_keys, d_vals, cap):
+        """the view delivered into HBM: d_keys / d_vals are device addresses (int64 / float64 arrays of cap entries, e.g.
+        tensor.data_ptr()); returns the number of cells; the copy is enqueued on the orientation's stream (sync())"""
+        n = C.c_int64()
+        self.b.call(name, self.h, int(key), C.c_void_p(int(d_keys)), C.c_void_p(int(d_vals)), int(cap), C.byref(n))
+        return n.value
+
+    def sync(self):                                   # dsa_mat_sync: everything enqueued on the handle's streams has finished
+        self.b.call("mat_sync", self.h)
+
+    def col_view_dev(self, col, d_rows, d_vals, cap):  # @view m[:, col] into device memory
+        return self._view_dev("mat_col_view_dev", col, d_rows, d_vals, cap)
+
+    def row_view_dev(self, row, d_cols, d_vals, cap):  # @view m[row, :] into device memory
+        return self._view_dev("mat_row_view_dev", row, d_cols, d_vals, cap)
+
     def col_slice(self, col):                         # m[:, col]  src/pcsr.jl:285-291
         h = VP()
         self.b.call("mat_col_slice", self.h, int(col), C.byref(h))

@@ -23,6 +23,8 @@ constexpr int MAX_LEVELS = 48;
 // partition-table entries a batch may leave unmerged at the END of the tables (Ctl::n_pending): the one limit the sequencer's LDS
 // list (sequencer.hip), the batch-parallel rounds (parbatch.hip) and the grid-wide merge (tables.hip) share
 constexpr int TABLE_PEND_MAX = 1024;
+// slot ranges up to this size are packed by ONE launch of one workgroup (sequencer.hip: k_view_small): column views, slices, small vectors
+constexpr int64_t VIEW_SMALL_SLOTS = 65536;
 
 // ---- physical key storage ---------------------------------------------------------------------------
 // K = Int64 at the API; in HBM a slot array keeps its keys in 32 bits as long as every key ever written fits Int32
@@ -287,6 +289,10 @@ hipError_t launch_packed_equal(KeyArr ka, const double* va, KeyArr kb, const dou
 hipError_t launch_merge_axpby(KeyArr ka, const double* va, int64_t na, double alpha, KeyArr kb, const double* vb, int64_t nb,
                               double beta, int64_t* mk, double* mv, uint64_t* keep, hipStream_t stream);
 hipError_t launch_widen_keys(const void* src32, void* dst64, int64_t n, hipStream_t stream);
+// a structure made of fresh (uninitialised) blocks in ONE launch: both occupancy bitmaps and the status table of the grid rebalance
+// zeroed, the control block written from the argument (no copy command)
+hipError_t launch_init_fresh(uint64_t* occ0, uint64_t* occ1, int64_t occ_words, unsigned long long* status, int64_t status_words,
+                             Ctl* d_ctl, const Ctl& ctl, hipStream_t stream);
 // clears occupancy bits of slots [from, to] (1-based, inclusive); from/to word-aligned or inside one word
 hipError_t launch_clear_occ(uint64_t* occ, int64_t from, int64_t to, hipStream_t stream);
 

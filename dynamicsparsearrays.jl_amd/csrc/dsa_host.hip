@@ -181,6 +181,7 @@ struct Pma {
     int64_t* h_small = nullptr;                     // its pinned host mirror (small read-backs without a pageable staging copy)
     int64_t* h_get = nullptr; unsigned long long get_seq = 0;        // pinned landing area of small lookups (get_batch: keys, partitions, answers, error, sequence number)
     int64_t* h_view = nullptr; unsigned long long view_seq = 0;      // pinned landing area of column views: meta words, sequence number, first cells (col_view_of)
+    hipEvent_t ev_handoff = nullptr;      // recorded on `stream` behind work another handle's stream must wait for (a slice built from this structure)
     // bumped by every launch that can move cells or change the tables; SpmvMeta is recomputed when it differs
     int device = 0;              // the device the handle lives on: re-selected at every API entry (a Julia task / finalizer thread or a
                                  // second Python thread calls in with whatever device its thread last selected)
@@ -206,14 +207,11 @@ void pma_free_buffers(Pma& P) {
         pool_free(P.keys[b]); pool_free(P.vals[b]); pool_free(P.occ[b]);     // (the caller has synchronised the stream)
         P.keys[b] = nullptr; P.vals[b] = nullptr; P.occ[b] = nullptr;
     }
-    if (P.work.tile_cnt) hipFree(P.work.tile_cnt);
-    if (P.work.tile_off) hipFree(P.work.tile_off);
-    if (P.work.status) hipFree(P.work.status);
+    pool_free(P.work.tile_cnt); pool_free(P.work.tile_off); pool_free(P.work.status);
     P.work = RebalanceWork{nullptr, nullptr, 0};
-    if (P.work2.tile_cnt) hipFree(P.work2.tile_cnt);
-    if (P.work2.tile_off) hipFree(P.work2.tile_off);
+    pool_free(P.work2.tile_cnt); pool_free(P.work2.tile_off);
     P.work2 = RebalanceWork{nullptr, nullptr, 0};
-    if (P.occ_old) hipFree(P.occ_old);
+    pool_free(P.occ_old);
     P.occ_old = nullptr;
 }
 
@@ -236,6 +234,7 @@ void pma_destroy(Pma& P) {
     pool_free(P.d_small);
     pinned_free(P.h_small);
     pinned_free(P.h_view);
+    if (P.ev_handoff) (void)hipEventDestroy(P.ev_handoff);
     if (P.d_meta) hipFree(P.d_meta);
     pinned_free(P.h_meta);
     if (P.tmerge.sems2) hipFree(P.tmerge.sems2);
@@ -296,29 +295,33 @@ int64_t occ_words_for(int64_t slots) {
 
 // slot buffers come from the caching allocator (pool.hip): a structure built after another one of the same size was destroyed
 // finds its ~100 MB blocks again without a driver call
-void alloc_one_buffer(Pma& P, int b, int64_t slots) {
+void alloc_one_buffer(Pma& P, int b, int64_t slots, bool zero = true) {
     HIPCHK(pool_alloc(&P.keys[b], (size_t)slots * P.kb()));
     HIPCHK(pool_alloc(reinterpret_cast<void**>(&P.vals[b]), (size_t)slots * sizeof(double)));
     const int64_t words = occ_words_for(slots);
     HIPCHK(pool_alloc(reinterpret_cast<void**>(&P.occ[b]), (size_t)words * sizeof(uint64_t)));
-    HIPCHK(hipMemsetAsync(P.occ[b], 0, (size_t)words * sizeof(uint64_t), P.stream));
+    if (zero) HIPCHK(hipMemsetAsync(P.occ[b], 0, (size_t)words * sizeof(uint64_t), P.stream));
 }
 
-void alloc_work(Pma& P, int64_t slots) {
-    if (P.work.tile_cnt) { hipFree(P.work.tile_cnt); hipFree(P.work.tile_off); }
+// zero = false: the caller zeroes the bitmaps and the status table itself (launch_init_fresh: one launch for all of them)
+void alloc_work(Pma& P, int64_t slots, bool zero = true) {
+    // (from the caching allocator since round 6: five driver allocations per new structure were a third of what a small vector — a
+    //  slice, a filter result — costs to create; the caller has waited for the stream before an existing table is replaced)
+    pool_free(P.work.tile_cnt); pool_free(P.work.tile_off); pool_free(P.work.status);
+    P.work = RebalanceWork{nullptr, nullptr, 0};
     P.work.tiles_cap = slots / 4096 + 8;
-    HIPCHK(hipMalloc(&P.work.tile_cnt, (size_t)P.work.tiles_cap * sizeof(uint32_t)));
-    HIPCHK(hipMalloc(&P.work.tile_off, (size_t)P.work.tiles_cap * sizeof(uint32_t)));
-    if (P.work.status) hipFree(P.work.status);
+    HIPCHK(pool_alloc(reinterpret_cast<void**>(&P.work.tile_cnt), (size_t)P.work.tiles_cap * sizeof(uint32_t)));
+    HIPCHK(pool_alloc(reinterpret_cast<void**>(&P.work.tile_off), (size_t)P.work.tiles_cap * sizeof(uint32_t)));
     P.work.status_cap = slots / 1024 + slots / (1024 * 64) + 16; P.work.gen = 0;      // one word per 1024-slot tile + one per 64 tiles + the fault word
-    HIPCHK(hipMalloc(&P.work.status, (size_t)P.work.status_cap * sizeof(unsigned long long)));
-    HIPCHK(hipMemsetAsync(P.work.status, 0, (size_t)P.work.status_cap * sizeof(unsigned long long), P.stream));
-    if (P.work2.tile_cnt) { hipFree(P.work2.tile_cnt); hipFree(P.work2.tile_off); }
+    HIPCHK(pool_alloc(reinterpret_cast<void**>(&P.work.status), (size_t)P.work.status_cap * sizeof(unsigned long long)));
+    if (zero) HIPCHK(hipMemsetAsync(P.work.status, 0, (size_t)P.work.status_cap * sizeof(unsigned long long), P.stream));
+    pool_free(P.work2.tile_cnt); pool_free(P.work2.tile_off);
+    P.work2 = RebalanceWork{nullptr, nullptr, 0};
     P.work2.tiles_cap = P.work.tiles_cap;
-    HIPCHK(hipMalloc(&P.work2.tile_cnt, (size_t)P.work2.tiles_cap * sizeof(uint32_t)));
-    HIPCHK(hipMalloc(&P.work2.tile_off, (size_t)P.work2.tiles_cap * sizeof(uint32_t)));
-    if (P.occ_old) hipFree(P.occ_old);
-    HIPCHK(hipMalloc(&P.occ_old, (size_t)occ_words_for(slots) * sizeof(uint64_t)));
+    HIPCHK(pool_alloc(reinterpret_cast<void**>(&P.work2.tile_cnt), (size_t)P.work2.tiles_cap * sizeof(uint32_t)));
+    HIPCHK(pool_alloc(reinterpret_cast<void**>(&P.work2.tile_off), (size_t)P.work2.tiles_cap * sizeof(uint32_t)));
+    pool_free(P.occ_old); P.occ_old = nullptr;
+    HIPCHK(pool_alloc(reinterpret_cast<void**>(&P.occ_old), (size_t)occ_words_for(slots) * sizeof(uint64_t)));
 }
 
 void bind_device(const Pma& P) { HIPCHK(hipSetDevice(P.device)); }
@@ -413,7 +416,7 @@ void download_ctl(Pma& P) {
 }
 
 // grow both slot buffers to at least `slots` (contents of the current buffer are preserved)
-void ensure_capacity_alloc(Pma& P, int64_t slots) {
+void ensure_capacity_alloc(Pma& P, int64_t slots, bool zero = true) {
     if (slots <= P.cap_alloc) return;
     // growth in steps of 4x (at least 64k slots once the first 4096 are outgrown): a growing array re-allocates its two buffers
     // (13 hipMalloc / hipFree and a stream wait each time) 4 times on the way to 4M slots instead of 10; HBM is not the scarce resource
@@ -425,7 +428,7 @@ void ensure_capacity_alloc(Pma& P, int64_t slots) {
     void* ok[2] = {P.keys[0], P.keys[1]}; double* ov[2] = {P.vals[0], P.vals[1]}; uint64_t* oo[2] = {P.occ[0], P.occ[1]};
     const int64_t old_words = P.occ_words, old_slots = P.cap_alloc;
     for (int b = 0; b < 2; ++b) { P.keys[b] = nullptr; P.vals[b] = nullptr; P.occ[b] = nullptr; }
-    for (int b = 0; b < 2; ++b) alloc_one_buffer(P, b, n);
+    for (int b = 0; b < 2; ++b) alloc_one_buffer(P, b, n, zero);
     if (ok[P.cur] != nullptr && old_slots > 0) {
         HIPCHK(hipMemcpyAsync(P.keys[P.cur], ok[P.cur], (size_t)old_slots * P.kb(), hipMemcpyDeviceToDevice, P.stream));
         HIPCHK(hipMemcpyAsync(P.vals[P.cur], ov[P.cur], (size_t)old_slots * sizeof(double), hipMemcpyDeviceToDevice, P.stream));
@@ -436,7 +439,7 @@ void ensure_capacity_alloc(Pma& P, int64_t slots) {
     P.occ_dirty[1 - P.cur] = 0;                       // fresh, zero-filled; occ_dirty[cur] keeps its value
     P.cap_alloc = n;
     P.occ_words = occ_words_for(n);
-    alloc_work(P, n);
+    alloc_work(P, n, zero);
 }
 
 // pack + spread of the whole array into the other buffer: cells of cur[1..src_cap] -> alt[1..new_cap]
@@ -1219,9 +1222,9 @@ void wait_view_seq(Pma& P, unsigned long long seq, const char* what) {
 void view_small(Pma& P, int64_t col, int64_t range_from, int64_t range_to, std::vector<int64_t>& ks, std::vector<double>& vs);
 void read_range_general(Pma& P, int64_t from, int64_t to, std::vector<int64_t>& ks, std::vector<double>& vs);
 void read_range(Pma& P, int64_t from, int64_t to, std::vector<int64_t>& ks, std::vector<double>& vs) {
-    // up to 16384 slots (iteration over a small vector, a short slice): one launch that packs the cells and hands the first 512 to the
+    // up to VIEW_SMALL_SLOTS slots (iteration over a small vector, a short slice): one launch that packs the cells and hands the first 512 to the
     // host through pinned memory (nonzeros() of a 100-entry vector: 80 -> 25 us); longer ranges: tile counts + scan + K-pack
-    if (to >= from && from >= 1 && to - from + 1 <= 16384 && to - from + 1 <= P.cap_alloc && publish_enabled()) { view_small(P, 0, from, to, ks, vs); return; }
+    if (to >= from && from >= 1 && to - from + 1 <= VIEW_SMALL_SLOTS && to - from + 1 <= P.cap_alloc && publish_enabled()) { view_small(P, 0, from, to, ks, vs); return; }
     read_range_general(P, from, to, ks, vs);
 }
 void read_range_general(Pma& P, int64_t from, int64_t to, std::vector<int64_t>& ks, std::vector<double>& vs) {
@@ -1697,14 +1700,14 @@ void mat_apply_sets(dsa_mat* h, const int64_t* I, const int64_t* J, const double
     if (err) fail(err, err_text(err));
 }
 
-// range_from > 0: the stored cells of the slot range [range_from, range_to] instead of the column `col` (at most 16384 slots)
+// range_from > 0: the stored cells of the slot range [range_from, range_to] instead of the column `col` (at most VIEW_SMALL_SLOTS slots)
 void view_small(Pma& P, int64_t col, int64_t range_from, int64_t range_to, std::vector<int64_t>& ks, std::vector<double>& vs) {
     // one launch (partition lookup + K-pack of its slot range into the idle alternate buffer) and one host round trip for
-    // partitions of up to 16384 slots; the first SPEC cells travel with the meta words, longer views fetch the rest
+    // partitions of up to VIEW_SMALL_SLOTS slots; the first SPEC cells travel with the meta words, longer views fetch the rest
     constexpr int64_t SPEC = 512;
     ks.clear(); vs.clear();
     const int alt = 1 - P.cur;
-    const int64_t out_cap = std::min<int64_t>(P.cap_alloc, 16384);
+    const int64_t out_cap = std::min<int64_t>(P.cap_alloc, VIEW_SMALL_SLOTS);
     const int64_t spec = std::min<int64_t>(SPEC, out_cap);
     int64_t r[5] = {0, 0, 0, 0, 0};
     if (publish_enabled()) {
@@ -1752,6 +1755,49 @@ void view_small(Pma& P, int64_t col, int64_t range_from, int64_t range_to, std::
 }
 
 void col_view_of(Pma& P, int64_t col, std::vector<int64_t>& ks, std::vector<double>& vs) { view_small(P, col, 0, 0, ks, vs); }
+
+// view(mpcsc, :, col) (src/views.jl:15-35) that stays in HBM: the stored cells of the column packed, in slot order, at the front of
+// P's idle alternate buffer (P.KA(1 - P.cur), P.vals[1 - P.cur]); only the meta words reach the host (through the pinned landing area:
+// no copy command).  cnt = number of cells, last_key = key of the last one (the largest: a partition is key-ordered).
+struct DevView { int64_t cnt = 0, last_key = 0; };
+DevView view_dev(Pma& P, int64_t col) {
+    DevView dv;
+    const int alt = 1 - P.cur;
+    const int64_t out_cap = std::min<int64_t>(P.cap_alloc, VIEW_SMALL_SLOTS);
+    int64_t r[6] = {0, 0, 0, 0, 0, 0};
+    if (publish_enabled()) {
+        ViewAreaLease lease(P);
+        const unsigned long long seq = ++P.view_seq;
+        hipError_t e = launch_view_small(P.K(), P.V(), P.O(), P.sems, P.col_keys, P.col_live, P.h_ctl->table_len, P.capacity(), col,
+                                         P.KA(alt), P.vals[alt], out_cap, P.d_small, P.h_view, 0, seq, 0, 0, P.stream);
+        if (e != hipSuccess) fail(DSA_EHIP, std::string("view launch: ") + hipGetErrorString(e));
+        wait_view_seq(P, seq, "view");
+        for (int q = 0; q < 5; ++q) r[q] = P.h_view[q];
+        r[5] = P.h_view[6];
+    } else {
+        hipError_t e = launch_view_small(P.K(), P.V(), P.O(), P.sems, P.col_keys, P.col_live, P.h_ctl->table_len, P.capacity(), col,
+                                         P.KA(alt), P.vals[alt], out_cap, P.d_small, nullptr, 0, 0ull, 0, 0, P.stream);
+        if (e != hipSuccess) fail(DSA_EHIP, std::string("view launch: ") + hipGetErrorString(e));
+        HIPCHK(hipMemcpyAsync(P.h_small, P.d_small, sizeof(r), hipMemcpyDeviceToHost, P.stream));
+        HIPCHK(hipStreamSynchronize(P.stream));
+        for (int q = 0; q < 6; ++q) r[q] = P.h_small[q];
+    }
+    if (r[2] != 0) fail((int32_t)r[2], "partition has no semaphore");
+    if (r[0] == 0) return dv;                                  // the column does not exist (src/views.jl:17,24)
+    dv.cnt = r[4]; dv.last_key = r[5];
+    if (dv.cnt < 0) {                                          // a long partition: tile counts + scan + K-pack; the count and one key come back
+        int64_t cnt = 0;
+        hipError_t e = launch_compact_range(P.K(), P.V(), P.O(), r[0], r[1], P.KA(alt), P.vals[alt], P.cap_alloc, &P.work, &cnt, P.stream);
+        if (e != hipSuccess) fail(DSA_EHIP, std::string("compact launch: ") + hipGetErrorString(e));
+        dv.cnt = cnt; dv.last_key = 0;
+        if (cnt > 0) {
+            HIPCHK(hipMemcpyAsync(P.h_small, (const char*)P.keys[alt] + (size_t)(cnt - 1) * P.kb(), P.kb(), hipMemcpyDeviceToHost, P.stream));
+            HIPCHK(hipStreamSynchronize(P.stream));
+            dv.last_key = P.wide ? P.h_small[0] : (int64_t) * reinterpret_cast<const int32_t*>(P.h_small);
+        }
+    }
+    return dv;
+}
 
 void ensure_xy(dsa_mat* h, int64_t nx, int64_t ny) {
     if (nx > h->x_cap) { if (h->d_x) hipFree(h->d_x); h->x_cap = std::max<int64_t>(nx, 1024); HIPCHK(hipMalloc(&h->d_x, (size_t)h->x_cap * sizeof(double))); }
@@ -1975,10 +2021,10 @@ int32_t dsa_vec_nonzeros(dsa_vec_t* h, int64_t* keys, double* vals, int64_t cap,
 // K-pack of the whole vector into its alternate slot buffer (free between rebalances); returns the number of stored cells.
 // The count is known on return, the packed cells are still being written on the vector's OWN stream: a consumer on another stream
 // (the other operand of == / +) must wait for it (wait_for_pack).
-// K-pack of up to 16384 slots by ONE launch, the count handed back through the pinned landing area of `P` (no tile counts, no scan, no
+// K-pack of up to VIEW_SMALL_SLOTS slots by ONE launch, the count handed back through the pinned landing area of `P` (no tile counts, no scan, no
 // copy, no stream synchronisation: 50 -> 15 us); returns -1 when the range does not qualify
 static int64_t pack_small(Pma& P, KeyArr k, const double* v, const uint64_t* occ, int64_t from, int64_t to, KeyArr ok, double* ov, int64_t out_cap) {
-    if (!publish_enabled() || to < from || from < 1 || to - from + 1 > 16384 || to - from + 1 > out_cap) return -1;
+    if (!publish_enabled() || to < from || from < 1 || to - from + 1 > VIEW_SMALL_SLOTS || to - from + 1 > out_cap) return -1;
     ViewAreaLease lease(P);
     const unsigned long long seq = ++P.view_seq;
     hipError_t e = launch_view_small(k, v, occ, nullptr, nullptr, nullptr, 0, to, 0, ok, ov, out_cap, P.d_small, P.h_view, 0, seq, from, to, P.stream);
@@ -2585,16 +2631,88 @@ int32_t dsa_mat_row_view(dsa_mat_t* h, int64_t row, int64_t* cols, double* vals,
 }
 // m[:, col] (src/pcsr.jl:285-291 -> :247-259) and m[row, :] (src/pcsr.jl:269-283; served from the rowmajor twin, whose
 // partition `row` holds exactly the (col, value) pairs the reference collects by scanning the colmajor array)
+// PackedMemoryArray(elements) (src/pma.jl:69-84) of the n cells packed at the front of S's alternate buffer (view_dev: ascending,
+// distinct keys — nothing to sort or fold): geometry on the host, then ONE k_move2<PACKED> from S's buffer straight into the new
+// vector's slot array.  The cells never leave HBM.  Everything is enqueued on S's stream (the pack that produced the cells runs
+// there); the new vector gets its own stream back before it is handed out, after the one wait of upload_ctl.
+static dsa_vec* vec_from_packed_dev(Pma& S, int64_t n, int64_t len) {
+    auto* v = new dsa_vec();
+    hipStream_t own = nullptr;
+    try {
+        pma_init_common(v->P, false, false);
+        Pma& P = v->P;
+        own = P.stream; P.stream = S.stream;
+        P.wide = S.wide;
+        const int64_t capacity = capacity_for(n);
+        set_geometry_for_new(P, capacity, n);
+        ensure_capacity_alloc(P, 2 * capacity, false);
+        ++P.layout_epoch; ++P.stat_grid_rebalances;
+        P.h_ctl->stat_rebalances = 0; P.h_ctl->stat_window_slots = 0;
+        if (capacity != P.h_ctl->segment_capacity) { P.h_ctl->stat_rebalances = 1; P.h_ctl->stat_window_slots = capacity; }
+        // TWO launches make the vector: (1) both bitmaps, the status table of the grid rebalance and the control block (passed by value:
+        // no copy command, the pinned mirror is not a DMA source) — five stream commands and a wait until round 6; (2) the spread
+        hipError_t e = launch_init_fresh(P.occ[0], P.occ[1], P.occ_words, P.work.status, P.work.status_cap, P.d_ctl, *P.h_ctl, P.stream);
+        if (e != hipSuccess) fail(DSA_EHIP, std::string("init launch: ") + hipGetErrorString(e));
+        const int salt = 1 - S.cur;
+        // (root_rebalance of P with a foreign source: cells of S.alt[1..n] -> P.cur[1..capacity])
+        e = launch_rebalance(S.KA(salt), S.vals[salt], S.occ[salt], 1, n, true, P.K(), P.V(), P.O(), 1, capacity, n,
+                             nullptr, &P.work, P.stream);
+        if (e != hipSuccess) fail(DSA_EHIP, std::string("rebalance launch: ") + hipGetErrorString(e));
+        P.occ_dirty[P.cur] = (capacity + 63) / 64;
+        // the vector's own stream waits (on the device) for what was enqueued on S's; whatever S does next with its alternate buffer is
+        // stream-ordered behind the spread.  No host wait.
+        if (S.ev_handoff == nullptr) HIPCHK(hipEventCreateWithFlags(&S.ev_handoff, hipEventDisableTiming));
+        HIPCHK(hipEventRecord(S.ev_handoff, S.stream));
+        HIPCHK(hipStreamWaitEvent(own, S.ev_handoff, 0));
+        P.stream = own;
+    } catch (...) {
+        if (own) { (void)hipStreamSynchronize(v->P.stream); v->P.stream = own; }
+        pma_destroy(v->P); delete v; throw;
+    }
+    v->n = len;
+    return v;
+}
 static int32_t slice_impl(dsa_mat_t* h, int32_t o, int64_t key, dsa_vec_t** out) {
     API_TRY
     mat_flush(h);
     if (h->fillmode) fail(DSA_EMODE, "slices are not available in fill mode");
-    std::vector<int64_t> k; std::vector<double> v;
-    col_view_of(orient(h, o), key, k, v);
-    int64_t len = 0;
-    for (int64_t x : k) len = std::max(len, x);          // _guess_length(pma)  src/vector.jl:7-8
-    _check_status(dsa_vec_create(k.data(), v.data(), (int64_t)k.size(), DSA_COMBINE_ADD, len, out));
+    Pma& S = orient(h, o);
+    static const bool dbg_time = dev_env("DSA_DBG_TIME") != nullptr;
+    const auto ts0 = std::chrono::steady_clock::now();
+    const DevView dv = view_dev(S, key);
+    const auto ts1 = std::chrono::steady_clock::now();
+    if (dv.cnt <= 0) { _check_status(dsa_vec_create(nullptr, nullptr, 0, DSA_COMBINE_ADD, 0, out)); return DSA_OK; }      // PackedMemoryArray(L, T)  src/pcsr.jl:288
+    *out = vec_from_packed_dev(S, dv.cnt, std::max<int64_t>(dv.last_key, 0));          // _guess_length(pma)  src/vector.jl:7-8
+    if (dbg_time) fprintf(stderr, "[slice] %lld cells: view %.1f us, new vector %.1f us\n", (long long)dv.cnt,
+                          std::chrono::duration<double, std::micro>(ts1 - ts0).count(), std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - ts1).count());
     API_CATCH
+}
+// @view m[:, col] / @view m[row, :] with the cells delivered into HBM: d_keys / d_vals are DEVICE arrays of `cap` entries; the copy is
+// enqueued on the orientation's stream (dsa_mat_set_stream / dsa_mat_sync), the count is known on return
+static int32_t view_dev_impl(dsa_mat_t* h, int32_t o, int64_t key, int64_t* d_keys, double* d_vals, int64_t cap, int64_t* n_out) {
+    API_TRY
+    mat_flush(h);
+    if (h->fillmode) fail(DSA_EMODE, "View not available in fill mode.");
+    Pma& S = orient(h, o);
+    const DevView dv = view_dev(S, key);
+    *n_out = 0;
+    if (dv.cnt <= 0) return DSA_OK;
+    if (dv.cnt > cap) fail(DSA_ECAP, "output buffers too small");
+    const int salt = 1 - S.cur;
+    if (S.wide) HIPCHK(hipMemcpyAsync(d_keys, S.keys[salt], (size_t)dv.cnt * sizeof(int64_t), hipMemcpyDeviceToDevice, S.stream));
+    else {
+        hipError_t e = launch_widen_keys(S.keys[salt], d_keys, dv.cnt, S.stream);
+        if (e != hipSuccess) fail(DSA_EHIP, std::string("view copy-out: ") + hipGetErrorString(e));
+    }
+    HIPCHK(hipMemcpyAsync(d_vals, S.vals[salt], (size_t)dv.cnt * sizeof(double), hipMemcpyDeviceToDevice, S.stream));
+    *n_out = dv.cnt;
+    API_CATCH
+}
+int32_t dsa_mat_col_view_dev(dsa_mat_t* h, int64_t col, int64_t* d_rows, double* d_vals, int64_t cap, int64_t* n_out) {
+    return view_dev_impl(h, DSA_COLMAJOR, col, d_rows, d_vals, cap, n_out);
+}
+int32_t dsa_mat_row_view_dev(dsa_mat_t* h, int64_t row, int64_t* d_cols, double* d_vals, int64_t cap, int64_t* n_out) {
+    return view_dev_impl(h, DSA_ROWMAJOR, row, d_cols, d_vals, cap, n_out);
 }
 int32_t dsa_mat_col_slice(dsa_mat_t* h, int64_t col, dsa_vec_t** out) { return slice_impl(h, DSA_COLMAJOR, col, out); }
 int32_t dsa_mat_row_slice(dsa_mat_t* h, int64_t row, dsa_vec_t** out) { return slice_impl(h, DSA_ROWMAJOR, row, out); }

@@ -714,6 +714,27 @@ hipError_t launch_widen_keys(const void* src32, void* dst64, int64_t n, hipStrea
     return hipGetLastError();
 }
 
+struct FreshInit { uint64_t* occ0; uint64_t* occ1; int64_t occ_words; unsigned long long* status; int64_t status_words; Ctl* d_ctl; Ctl ctl; };
+__global__ __launch_bounds__(256) void k_init_fresh(FreshInit a) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.occ_words; i += stride) { a.occ0[i] = 0ull; a.occ1[i] = 0ull; }
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.status_words; i += stride) a.status[i] = 0ull;
+    if (blockIdx.x == 0) {
+        static_assert(sizeof(Ctl) % 8 == 0, "Ctl is copied in 8-byte words");
+        const int64_t* src = reinterpret_cast<const int64_t*>(&a.ctl);
+        int64_t* dst = reinterpret_cast<int64_t*>(a.d_ctl);
+        for (int i = threadIdx.x; i < (int)(sizeof(Ctl) / 8); i += blockDim.x) dst[i] = src[i];
+    }
+}
+hipError_t launch_init_fresh(uint64_t* occ0, uint64_t* occ1, int64_t occ_words, unsigned long long* status, int64_t status_words,
+                             Ctl* d_ctl, const Ctl& ctl, hipStream_t stream) {
+    FreshInit a{occ0, occ1, occ_words, status, status_words, d_ctl, ctl};
+    const int64_t n = std::max(occ_words, status_words);
+    const int blocks = (int)std::min<int64_t>(std::max<int64_t>((n + 255) / 256, 1), 1024);
+    hipLaunchKernelGGL(k_init_fresh, dim3(blocks), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
 __global__ void k_clear_occ(uint64_t* occ, int64_t lo0, int64_t hi0) {
     const int64_t w0 = lo0 >> 6, w1 = hi0 >> 6;
     for (int64_t w = w0 + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; w <= w1; w += (int64_t)gridDim.x * blockDim.x)

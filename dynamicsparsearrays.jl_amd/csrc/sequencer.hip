@@ -2171,26 +2171,34 @@ __global__ void k_partition_range(const int64_t* sems, const int64_t* col_keys, 
     out[3] = f.pos;
 }
 // view(mpcsc, :, col) (src/views.jl:15-35) in ONE launch for partitions of up to VIEW_SMALL_SLOTS slots: partition lookup, then the
-// occupied cells of its slot range packed in slot order into out_k / out_v (one wave, ballot-style ranks).  meta[0] = from,
-// meta[1] = to, meta[2] = error code, meta[3] = partition id, meta[4] = number of cells or -1 when the range is longer (the
-// caller then takes the general K-pack path).  Column views and deletecolumn! / deleterow! need one host round trip this way.
-constexpr int64_t VIEW_SMALL_SLOTS = 16384;
-__global__ __launch_bounds__(64) void k_view_small(KeyArr keys, const double* __restrict__ vals,
+// occupied cells of its slot range packed in slot order into out_k / out_v.  meta[0] = from, meta[1] = to, meta[2] = error code,
+// meta[3] = partition id, meta[4] = number of cells or -1 when the range is longer (the caller then takes the general K-pack path),
+// meta[5] = key of the last cell packed (host word [6]).  Column views, slices and deletecolumn! / deleterow! need one host round trip
+// this way.  One workgroup of VIEW_BLOCK threads (round 6; one wave until then: a 10 000-cell column took 115 us of dependent word after
+// word): (1) every thread counts its share of the occupancy words, all loads in flight at once; (2) exclusive prefix per word in LDS;
+// (3) the waves take the words round-robin, lane <-> slot, and store rank-addressed — coalesced reads, independent of each other.
+constexpr int VIEW_BLOCK = 1024;
+constexpr int VIEW_WORDS = (int)(VIEW_SMALL_SLOTS / 64) + 1;          // a range of VIEW_SMALL_SLOTS slots touches at most this many words
+__global__ __launch_bounds__(VIEW_BLOCK) void k_view_small(KeyArr keys, const double* __restrict__ vals,
                                                    const uint64_t* __restrict__ occ, const int64_t* sems, const int64_t* col_keys,
                                                    const uint8_t* col_live, int64_t table_len, int64_t capacity, int64_t col,
                                                    KeyArr out_k, double* __restrict__ out_v, int64_t out_cap, int64_t* meta,
                                                    int64_t* host, int64_t host_cells, unsigned long long seq,
                                                    int64_t range_from, int64_t range_to) {
-    // host (pinned, may be null): [0..4] the meta words, [5] the sequence number the host polls for, then host_cells keys and host_cells
-    // values — the first cells of the view go straight to the host with the meta words: one launch and no copy command for a short
-    // column (a D2H copy into the caller's pageable vectors + a stream synchronisation cost 60 us per view; 20 us this way)
-    const int lane = threadIdx.x;
+    // host (pinned, may be null): [0..4] the meta words, [5] the sequence number the host polls for, [6] the last key, then host_cells
+    // keys and host_cells values — the first cells of the view go straight to the host with the meta words: one launch and no copy
+    // command for a short column (a D2H copy into the caller's pageable vectors + a stream synchronisation cost 60 us per view; 20 us this way)
+    __shared__ uint64_t sMask[VIEW_WORDS];
+    __shared__ uint32_t sPref[VIEW_WORDS];
+    __shared__ uint32_t sWave[VIEW_BLOCK / 64];
+    __shared__ int64_t sLast;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int64_t from = 0, to = 0, err = 0, pid = 0;
     // range_from > 0: no partition lookup, the stored cells of the slot range [range_from, range_to] (iteration over a small vector,
-    // src/pma.jl:165-180: the same one-launch hand-over as a column view)
+    // src/pma.jl:165-180: the same one-launch hand-over as a column view).  The lookup is executed by every wave (uniform result).
     DFoundKey f{0, 0, false};
     if (range_from > 0) { from = range_from; to = range_to; }
-    else f = d_find_table(col_keys, col_live, table_len, col);
+    else f = d_find_table_fast(col_keys, col_live, table_len, col);
     if (range_from <= 0 && f.has && f.key == col) {
         const int64_t sp = sems[f.pos - 1];
         if (sp == 0) err = E_ASSERT;
@@ -2202,35 +2210,76 @@ __global__ __launch_bounds__(64) void k_view_small(KeyArr keys, const double* __
         }
     }
     int64_t cnt = 0;
+    if (threadIdx.x == 0) sLast = 0;
     if (from != 0 && to >= from) {
         if (to - from + 1 > VIEW_SMALL_SLOTS) cnt = -1;
         else {
             const int64_t lo0 = from - 1, hi0 = to - 1;
-            for (int64_t w = lo0 >> 6; w <= (hi0 >> 6); ++w) {
-                const uint64_t mask = occ[w] & word_range_mask(w, lo0, hi0);
-                if ((mask >> lane) & 1ull) {
-                    const int64_t r = cnt + popc64(mask & mask_lt(lane));
-                    if (r < out_cap) {
-                        const int64_t kk = keys[(w << 6) + lane]; const double vv = vals[(w << 6) + lane];
-                        out_k[r] = kk; out_v[r] = vv;
-                        if (host != nullptr && r < host_cells) {
-                            __hip_atomic_store(host + 8 + r, kk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                            __hip_atomic_store(host + 8 + host_cells + r, __double_as_longlong(vv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            const int64_t w0 = lo0 >> 6;
+            const int nw = (int)((hi0 >> 6) - w0) + 1;                      // <= VIEW_WORDS
+            const int per = (nw + VIEW_BLOCK - 1) / VIEW_BLOCK;             // words per thread, contiguous
+            const int t0 = threadIdx.x * per;
+            uint32_t mine = 0;
+            for (int q = t0; q < t0 + per && q < nw; ++q) {
+                const uint64_t m = occ[w0 + q] & word_range_mask(w0 + q, lo0, hi0);
+                sMask[q] = m;
+                mine += (uint32_t)popc64(m);
+            }
+            // exclusive scan of the per-thread counts: inside the wave by shuffles, across the waves through LDS
+            uint32_t inc = mine;
+            for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(inc, o, 64); if (lane >= o) inc += y; }
+            if (lane == 63) sWave[wave] = inc;
+            __syncthreads();
+            uint32_t base = 0, total = 0;
+            for (int v = 0; v < VIEW_BLOCK / 64; ++v) { const uint32_t c = sWave[v]; if (v < wave) base += c; total += c; }
+            uint32_t run = base + inc - mine;
+            for (int q = t0; q < t0 + per && q < nw; ++q) { sPref[q] = run; run += (uint32_t)popc64(sMask[q]); }
+            __syncthreads();
+            cnt = (int64_t)total;
+            if (cnt > out_cap) cnt = -1;
+            else {
+                // four words per wave and step: the loads of all four are in flight before the first store (the stores may alias the
+                // loads as far as the compiler knows: word after word, every iteration waited for its own loads — 35 us for 366 words)
+                constexpr int NWAVES = VIEW_BLOCK / 64, U = 4;
+                for (int q0 = wave; q0 < nw; q0 += NWAVES * U) {
+                    int64_t kk[U]; double vv[U]; int64_t r[U]; bool on[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const int q = q0 + u * NWAVES;
+                        on[u] = false; r[u] = 0; kk[u] = 0; vv[u] = 0.0;
+                        if (q < nw) {
+                            const uint64_t mask = sMask[q];
+                            if ((mask >> lane) & 1ull) {
+                                on[u] = true;
+                                r[u] = (int64_t)sPref[q] + popc64(mask & mask_lt(lane));
+                                const int64_t slot = ((w0 + q) << 6) + lane;
+                                kk[u] = keys[slot]; vv[u] = vals[slot];
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        if (!on[u]) continue;
+                        out_k[r[u]] = kk[u]; out_v[r[u]] = vv[u];
+                        if (r[u] == cnt - 1) sLast = kk[u];
+                        if (host != nullptr && r[u] < host_cells) {
+                            __hip_atomic_store(host + 8 + r[u], kk[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                            __hip_atomic_store(host + 8 + host_cells + r[u], __double_as_longlong(vv[u]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                         }
                     }
                 }
-                cnt += popc64(mask);
             }
-            if (cnt > out_cap) cnt = -1;
         }
     }
-    if (lane == 0) { meta[0] = from; meta[1] = to; meta[2] = err; meta[3] = pid; meta[4] = cnt; }
-    if (host != nullptr) {
-        __builtin_amdgcn_s_waitcnt(0);                 // every lane's cells have left
-        __builtin_amdgcn_wave_barrier();
-        if (lane == 0) {
+    __builtin_amdgcn_s_waitcnt(0);                     // every lane's cells have left
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int64_t last_key = cnt > 0 ? sLast : 0;
+        meta[0] = from; meta[1] = to; meta[2] = err; meta[3] = pid; meta[4] = cnt; meta[5] = last_key;
+        if (host != nullptr) {
             const int64_t m5[5] = {from, to, err, pid, cnt};
             for (int q = 0; q < 5; ++q) __hip_atomic_store(host + q, m5[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(host + 6, last_key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __atomic_thread_fence(__ATOMIC_RELEASE);
             __hip_atomic_store(reinterpret_cast<unsigned long long*>(host) + 5, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
@@ -2240,7 +2289,7 @@ hipError_t launch_view_small(KeyArr keys, const double* vals, const uint64_t* oc
                              const uint8_t* col_live, int64_t table_len, int64_t capacity, int64_t col, KeyArr out_k, double* out_v,
                              int64_t out_cap, int64_t* meta, int64_t* host, int64_t host_cells, unsigned long long seq, int64_t range_from,
                              int64_t range_to, hipStream_t stream) {
-    hipLaunchKernelGGL(k_view_small, dim3(1), dim3(64), 0, stream, keys, vals, occ, sems, col_keys, col_live, table_len, capacity, col, out_k,
+    hipLaunchKernelGGL(k_view_small, dim3(1), dim3(VIEW_BLOCK), 0, stream, keys, vals, occ, sems, col_keys, col_live, table_len, capacity, col, out_k,
                        out_v, out_cap, meta, host, host_cells, seq, range_from, range_to);
     return hipGetLastError();
 }

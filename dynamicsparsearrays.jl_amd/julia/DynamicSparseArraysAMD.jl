@@ -23,7 +23,7 @@ using SparseArrays
 export DynamicSparseVector, DynamicSparseMatrix, DynamicMatrixColView, PackedCSC, dynamicsparsevec, dynamicsparse, nbpartitions,
        deletecolumn!, deleterow!, deletepartition!, addrow!, closefillmode!, shrink_size!, set_device!, shard_range, dynamicsparse_shard, comm_unique_id, ShardComm, shard_allreduce!,
        shard_spmv_allreduce!, set_wait_policy!, WAIT_SPIN, WAIT_BLOCK, pool_idle_bytes, pool_trim!,
-       keyint, keyfrom
+       keyint, keyfrom, col_view_dev!, row_view_dev!
 
 const libdsa = get(ENV, "DSA_HIP_LIB", joinpath(@__DIR__, "..", "csrc", "libdsa_hip.so"))
 
@@ -339,6 +339,19 @@ for (fname, sym) in ((:_col_slice, :dsa_mat_col_slice), (:_row_slice, :dsa_mat_r
         return out[]
     end
 end
+"`@view A[:, col]` delivered into HBM: `d_rows` / `d_vals` are device pointers to `cap` Int64 / Float64 entries (mapped key integers, see
+keyint); returns the number of cells; the copy is enqueued on the colmajor stream — dsa_mat_col_view_dev (the row form: dsa_mat_row_view_dev)"
+function col_view_dev!(a::DynamicSparseMatrix, col, d_rows::Ptr{Cvoid}, d_vals::Ptr{Cvoid}, cap::Integer)
+    n = Ref{Int64}(0)
+    _check(ccall((:dsa_mat_col_view_dev, libdsa), Int32, (Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ref{Int64}), a.h, _in(a.cols, col), d_rows, d_vals, cap, n))
+    return n[]
+end
+function row_view_dev!(a::DynamicSparseMatrix, row, d_cols::Ptr{Cvoid}, d_vals::Ptr{Cvoid}, cap::Integer)
+    n = Ref{Int64}(0)
+    _check(ccall((:dsa_mat_row_view_dev, libdsa), Int32, (Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ref{Int64}), a.h, _in(a.rows, row), d_cols, d_vals, cap, n))
+    return n[]
+end
+# A[:, col] / A[row, :]: the new vector is built device to device (view kernel -> one spread launch); nothing but its handle comes back
 Base.getindex(a::DynamicSparseMatrix{K,L}, ::Colon, col) where {K,L} = DynamicSparseVector{K}(_col_slice(a, _in(a.cols, col)), a.rows)
 Base.getindex(a::DynamicSparseMatrix{K,L}, row, ::Colon) where {K,L} = DynamicSparseVector{L}(_row_slice(a, _in(a.rows, row)), a.cols)
 "n getindex calls in one ccall"

@@ -174,8 +174,14 @@ int32_t dsa_mat_deleterow(dsa_mat_t* h, int64_t row);
 /* @view m[:, col] / @view m[row, :] iteration  src/matrix.jl:70-93, src/views.jl:15-35 */
 int32_t dsa_mat_col_view(dsa_mat_t* h, int64_t col, int64_t* rows, double* vals, int64_t cap, int64_t* n_out);
 int32_t dsa_mat_row_view(dsa_mat_t* h, int64_t row, int64_t* cols, double* vals, int64_t cap, int64_t* n_out);
+/* the same views delivered into HBM: d_rows / d_vals are DEVICE arrays of cap entries; the cells are packed on the device and copied
+ * device-to-device on the orientation's stream (dsa_mat_set_stream / dsa_mat_sync); *n_out is valid on return.  No cell crosses PCIe. */
+int32_t dsa_mat_col_view_dev(dsa_mat_t* h, int64_t col, int64_t* d_rows, double* d_vals, int64_t cap, int64_t* n_out);
+int32_t dsa_mat_row_view_dev(dsa_mat_t* h, int64_t row, int64_t* d_cols, double* d_vals, int64_t cap, int64_t* n_out);
 /* m[:, col] / m[row, :] as a NEW dynamic sparse vector  (getindex(mpcsc, :, col) src/pcsr.jl:285-291 -> :247-259 ;
- * getindex(mpcsc, row, :) src/pcsr.jl:269-283): the stored entries of the column / row, length = largest key */
+ * getindex(mpcsc, row, :) src/pcsr.jl:269-283): the stored entries of the column / row, length = largest key.  Device to device: the
+ * view kernel packs the partition into the orientation's idle slot buffer and ONE spread launch writes the new vector's slot array
+ * from there (PackedMemoryArray(elements), src/pma.jl:69-84); only the entry count and the largest key reach the host. */
 int32_t dsa_mat_col_slice(dsa_mat_t* h, int64_t col, dsa_vec_t** out);
 int32_t dsa_mat_row_slice(dsa_mat_t* h, int64_t row, dsa_vec_t** out);
 /* nnz(m) src/matrix.jl:91 ; size(m) :92 ; nbpartitions(orientation) src/pcsr.jl:21-22 */

@@ -1345,6 +1345,58 @@ def test_row_and_column_slices_match_oracle(dsa, hip, oracle):
         assert_vec_equal(a.row_slice(key), b.row_slice(key))
 
 
+def test_slices_and_views_stay_on_the_device(dsa, hip, oracle):
+    """m[:, j] / m[i, :] are built device to device (view kernel -> ONE spread launch from the orientation's idle slot
+    buffer; csrc/dsa_host.hip vec_from_packed_dev) and dsa_mat_*_view_dev deliver a view into caller-owned HBM.  Short partitions
+    (one wave), partitions above 16384 slots (tile counts + scan + K-pack), 64-bit keys, empty and missing columns; the new vectors slot
+    for slot against the oracle's (src/pcsr.jl:247-291, src/pma.jl:69-84), the matrix untouched and writable afterwards."""
+    import torch
+    rng = np.random.default_rng(77)
+    # column 5 holds 30 000 rows (a partition of > 16384 slots), row 3 holds 2000 columns, the rest is sparse
+    I = np.concatenate([rng.choice(200000, 30000, replace=False) + 1, np.full(2000, 3), rng.integers(1, 200001, 5000)])
+    J = np.concatenate([np.full(30000, 5), rng.choice(40000, 2000, replace=False) + 1, rng.integers(1, 40001, 5000)])
+    V = rng.integers(1, 100, len(I)).astype(np.float64)
+    for wide in (False, True):
+        if wide:
+            I = I.copy(); J = J.copy()
+            I[I == 77] = 2 ** 40 + 7; J[J == 9] = 2 ** 36
+            I[0] = 2 ** 40 + 9                       # (column 5 holds a 64-bit row key: its slice is a wide vector)
+        a = dsa.dynamicsparse(I, J, V, binding=hip)
+        b = dsa.dynamicsparse(I, J, V, binding=oracle)
+        cols = [5, 1, 2, int(J[-1]), 2 ** 36, 40001, 123456789]
+        rows = [3, 1, int(I[-1]), 2 ** 40 + 7, 2 ** 40 + 9, 200001]
+        for key in cols:
+            assert_vec_equal(a.col_slice(key), b.col_slice(key))
+        for key in rows:
+            assert_vec_equal(a.row_slice(key), b.row_slice(key))
+        dk = torch.empty(40000, dtype=torch.int64, device="cuda"); dv = torch.empty(40000, dtype=torch.float64, device="cuda")
+        for key in cols:
+            n = a.col_view_dev(key, dk.data_ptr(), dv.data_ptr(), 40000)
+            a.sync()
+            want = b.col_view(key)
+            assert n == len(want)
+            assert list(zip(dk[:n].cpu().tolist(), dv[:n].cpu().tolist())) == want
+        for key in rows:
+            n = a.row_view_dev(key, dk.data_ptr(), dv.data_ptr(), 40000)
+            a.sync()
+            want = b.row_view(key)
+            assert n == len(want) and list(zip(dk[:n].cpu().tolist(), dv[:n].cpu().tolist())) == want
+        with pytest.raises(dsa.DsaError):
+            a.col_view_dev(5, dk.data_ptr(), dv.data_ptr(), 100)        # DSA_ECAP
+        # a slice is a vector of its own: writes to it leave the matrix alone, and the matrix keeps working
+        va, vb = a.col_slice(5), b.col_slice(5)
+        for v in (va, vb):
+            v.set_batch(np.arange(1, 3001, dtype=np.int64) * 7, np.ones(3000))
+        assert_vec_equal(va, vb)
+        assert_mat_equal(a, b)
+        I2 = rng.integers(1, 200001, 3000); J2 = rng.integers(1, 40001, 3000); V2 = rng.integers(0, 5, 3000).astype(np.float64)
+        for m in (a, b):
+            m.set_batch(I2, J2, V2)
+        assert_mat_equal(a, b)
+        assert_vec_equal(a.col_slice(5), b.col_slice(5))
+        assert_vec_equal(a.row_slice(3), b.row_slice(3))
+
+
 def test_c4_shard_scale_build_spmv_and_root_rebalance(dsa, hip, oracle):
     """One shard of BASELINE config 4 at full size: 1.25 M columns x 10 M rows, 12.5 M nnz -> capacity 2^25 in both
     orientations (colmajor density 0.41, rowmajor 0.67).  Both orientations SLOT FOR SLOT against the oracle's build of the
