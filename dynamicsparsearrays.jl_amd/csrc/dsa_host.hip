@@ -1549,6 +1549,71 @@ Pma& orient(dsa_mat* h, int32_t o) {
 
 Op make_op(int32_t kind, int64_t a, int64_t b, double v) { Op o; o.a = a; o.b = b; o.v = v; o.kind = kind; o.pad = 0; return o; }
 
+// Host replay of ONE partition table (MappedPackedCSC.col_keys + which ids are tombstones) through a batch of writes: which write is
+// the first one the reference refuses?  Control logic like the integer density bounds — no slot is read or written here; the device
+// executes (and judges) every write.  Follows find(col_keys, col) + addcolumn! + the table half of addpartition!(pcsc, prev)
+// (src/pcsr.jl:341-351, 148-169, 114-146): a key that is present changes nothing; a key behind the last entry is pushed; a key whose
+// table slot prev+1 is a tombstone reuses it, unless no live id follows (semaphores[0]: BoundsError, :121-125); a key in front of an
+// occupied slot shifts the tail of the tables, which asserts on the first tombstone it meets (:129-133).
+struct TableReplay {
+    std::vector<int64_t> ck; std::vector<uint8_t> live;
+    int64_t last_tomb = 0, last_live = 0;          // 1-based index of the last tombstone / the last live entry (0: none)
+    void load(Pma& P) {
+        const int64_t len = P.h_ctl->table_len;
+        ck.resize((size_t)len); live.resize((size_t)len);
+        if (len > 0) {
+            HIPCHK(hipMemcpyAsync(ck.data(), P.col_keys, (size_t)len * sizeof(int64_t), hipMemcpyDeviceToHost, P.stream));
+            HIPCHK(hipMemcpyAsync(live.data(), P.col_live, (size_t)len, hipMemcpyDeviceToHost, P.stream));
+            HIPCHK(hipStreamSynchronize(P.stream));
+        }
+        rescan();
+    }
+    void rescan() {
+        last_tomb = 0; last_live = 0;
+        for (int64_t i = (int64_t)live.size(); i >= 1 && (last_tomb == 0 || last_live == 0); --i) {
+            if (live[(size_t)i - 1]) { if (last_live == 0) last_live = i; } else if (last_tomb == 0) last_tomb = i;
+        }
+    }
+    // find(col_keys, key) with tombstones (the host twin of d_find_table, csrc/find_dev.h): position of the key or of its predecessor
+    int64_t find(int64_t key, bool* exact) const {
+        int64_t from = 1, to = (int64_t)ck.size();
+        *exact = false;
+        while (from <= to) {
+            const int64_t mid = (from + to) >> 1;
+            int64_t i = mid;
+            while (i >= from && !live[(size_t)i - 1]) --i;
+            if (i < from) from = mid + 1;
+            else {
+                const int64_t c = ck[(size_t)i - 1];
+                if (c > key) to = i - 1;
+                else if (c < key) from = mid + 1;
+                else { *exact = true; return i; }
+            }
+        }
+        int64_t i = to;
+        while (i > 0 && !live[(size_t)i - 1]) --i;
+        return i;
+    }
+    // a write into partition `key`: 0 when the table accepts it (and the table as it is afterwards), else the reference's error
+    int32_t touch(int64_t key) {
+        bool exact = false;
+        const int64_t prev = find(key, &exact);
+        if (exact) return 0;
+        const int64_t len = (int64_t)ck.size();
+        if (prev == len) { ck.push_back(key); live.push_back(1); last_live = len + 1; return 0; }
+        if (!live[(size_t)prev]) {                                  // entry prev + 1 is a tombstone: reuse it
+            if (last_live <= prev + 1) return DSA_EBOUNDS;
+            ck[(size_t)prev] = key; live[(size_t)prev] = 1;
+            if (last_tomb == prev + 1) rescan();
+            return 0;
+        }
+        if (last_tomb >= prev + 1) return DSA_EASSERT;               // the shift of the tail meets a tombstone
+        ck.insert(ck.begin() + prev, key); live.insert(live.begin() + prev, (uint8_t)1);
+        last_live = len + 1;
+        return 0;
+    }
+};
+
 // setindex! on both orientations for ops [0, n)  src/matrix.jl:53-59
 void mat_apply_sets(dsa_mat* h, const int64_t* I, const int64_t* J, const double* V, int64_t n) {
     // colmajor[row, col] = val / rowmajor[col, row] = val: the batch-parallel path takes the caller's columns as they are, the other
@@ -1678,26 +1743,53 @@ void mat_apply_sets(dsa_mat* h, const int64_t* I, const int64_t* J, const double
     }
     // tombstones present: a write that creates a column can fail (src/pcsr.jl:124,132), so the colmajor batch runs first and the
     // rowmajor batch is cut at the failing op, like the reference's statement order — still through the batch-parallel
-    // rounds for everything that is plannable (writes to existing columns); new columns take the sequencer's literal path
+    // rounds for everything that is plannable (writes to existing columns); new columns take the sequencer's literal path.
+    //
+    // The state after a FAILED batch is the reference's too (round 6; until then colmajor could hold writes behind the failing one):
+    // the reference stops at write k with colmajor holding writes [0, k] when its rowmajor statement threw, [0, k) when the colmajor one
+    // did, rowmajor [0, k) either way (src/matrix.jl:43-62).  Colmajor running ahead of rowmajor is only wrong when ROWMAJOR fails, and
+    // whether a write fails depends on nothing but the partition table (which ids are tombstones: src/pcsr.jl:114-162).  So when the
+    // rowmajor table holds tombstones the first write it will refuse is found up front by replaying the table — not the slots — on the
+    // host (TableReplay), and colmajor is not run beyond it.  The device stays the judge: the error code comes from the device, and
+    // when the device accepts what the replay predicted to fail the loop simply goes on behind it.
     const bool par_seq = par && n >= 128;
-    int32_t err = 0;
-    const int64_t done = par_seq ? run_ops_parallel(h->col, oc, &err) : run_ops(h->col, oc, &err);
-    if (err) {
-        orw.resize((size_t)done);
+    int64_t pos = 0;
+    while (pos < n) {
+        const int64_t rem = n - pos;
+        int64_t f = n;                                                  // first write the rowmajor table refuses (n: none)
+        const Ctl& rc = *h->row.h_ctl;
+        if (rem > 1 && rc.nb_partitions != rc.table_len) {
+            TableReplay tr;
+            tr.load(h->row);
+            for (int64_t k = pos; k < n; ++k) if (tr.touch(I[k]) != 0) { f = k; break; }
+        }
+        const int64_t end = std::min(n, f + 1);
+        std::vector<Op> pc(oc.begin() + pos, oc.begin() + end), pr(orw.begin() + pos, orw.begin() + end);
+        int32_t err = 0;
+        const int64_t done = (par_seq ? run_ops_parallel(h->col, pc, &err) : run_ops(h->col, pc, &err)) + pos;
+        if (err) {
+            // colmajor refused write `done` (<= f): rowmajor gets the writes in front of it — none of which its table refuses
+            pr.resize((size_t)(done - pos));
+            int32_t e2 = 0;
+            const int64_t d2 = (par_seq ? run_ops_parallel(h->row, pr, &e2) : run_ops(h->row, pr, &e2)) + pos;
+            // Which write fails FIRST in the reference's order (colmajor then rowmajor of write 0, of write 1, ...): the rowmajor half of an
+            // earlier write d2 < done comes before the colmajor half of write `done`.  (Rounds 1-4 reported the colmajor error regardless:
+            // tools/fuzz.py run_tombstones seed 503707, EBOUNDS where the reference throws the AssertionError of src/pcsr.jl:132 three writes earlier.)
+            const int64_t fail_at = e2 ? d2 : done;
+            // the failing write had already updated size(m) in the reference (src/matrix.jl:44-47)
+            for (int64_t k = 0; k <= fail_at && k < n; ++k) if (V[k] != 0.0) { h->m = std::max(h->m, I[k]); h->n = std::max(h->n, J[k]); }
+            if (e2) fail(e2, err_text(e2));
+            fail(err, err_text(err));
+        }
         int32_t e2 = 0;
-        const int64_t d2 = par_seq ? run_ops_parallel(h->row, orw, &e2) : run_ops(h->row, orw, &e2);
-        // Which write fails FIRST in the reference's order (colmajor then rowmajor of write 0, of write 1, ...): the rowmajor half of an
-        // earlier write d2 < done comes before the colmajor half of write `done`.  (Rounds 1-4 reported the colmajor error regardless:
-        // tools/fuzz.py run_tombstones seed 503707, EBOUNDS where the reference throws the AssertionError of src/pcsr.jl:132 three writes earlier.)
-        const int64_t fail_at = e2 ? d2 : done;
-        // the failing write had already updated size(m) in the reference (src/matrix.jl:44-47)
-        for (int64_t k = 0; k <= fail_at && k < n; ++k) if (V[k] != 0.0) { h->m = std::max(h->m, I[k]); h->n = std::max(h->n, J[k]); }
-        if (e2) fail(e2, err_text(e2));
-        fail(err, err_text(err));
+        const int64_t d2 = (par_seq ? run_ops_parallel(h->row, pr, &e2) : run_ops(h->row, pr, &e2)) + pos;
+        if (e2) {
+            for (int64_t k = 0; k <= d2 && k < n; ++k) if (V[k] != 0.0) { h->m = std::max(h->m, I[k]); h->n = std::max(h->n, J[k]); }
+            fail(e2, err_text(e2));
+        }
+        for (int64_t k = pos; k < end; ++k) if (V[k] != 0.0) { h->m = std::max(h->m, I[k]); h->n = std::max(h->n, J[k]); }
+        pos = end;
     }
-    for (int64_t k = 0; k < done; ++k) if (V[k] != 0.0) { h->m = std::max(h->m, I[k]); h->n = std::max(h->n, J[k]); }
-    if (par_seq) run_ops_parallel(h->row, orw, &err); else run_ops(h->row, orw, &err);
-    if (err) fail(err, err_text(err));
 }
 
 // range_from > 0: the stored cells of the slot range [range_from, range_to] instead of the column `col` (at most VIEW_SMALL_SLOTS slots)

@@ -155,11 +155,10 @@ int32_t dsa_mat_destroy(dsa_mat_t* h);
  * can fail in the reference — the write is applied before the call returns so the error surfaces here. */
 int32_t dsa_mat_set(dsa_mat_t* h, double val, int64_t row, int64_t col);
 /* n sequential setindex! calls in order.  On success the state equals that of the n calls.  When write k fails (only possible while
- * the matrix holds deleted columns / rows) the status and size(m) are those of the reference at its exception; the
- * contents are a documented divergence: with tombstones the library applies the colmajor orientation of the batch first, so colmajor may
- * already hold writes behind k that the reference never reaches (the reference itself leaves its two orientations inconsistent at that
- * point: src/matrix.jl:43-62 updates colmajor, then throws in rowmajor).  A host that catches the error should treat the matrix as the
- * reference's caller would: not usable for further column generation. */
+ * the matrix holds deleted columns / rows) the status, size(m) and the contents are those of the reference at its
+ * exception (src/matrix.jl:43-62 updates colmajor, then rowmajor): both orientations hold writes [0, k), colmajor also holds write k when
+ * it was the rowmajor statement that threw.  (The orientation that refused the write keeps its partition tables as they were; the
+ * reference leaves them half shifted — a state nothing can continue from.) */
 int32_t dsa_mat_set_batch(dsa_mat_t* h, const int64_t* I, const int64_t* J, const double* V, int64_t n);
 /* getindex(m, row, col)  src/matrix.jl:64-68 */
 int32_t dsa_mat_get(dsa_mat_t* h, int64_t row, int64_t col, double* out);

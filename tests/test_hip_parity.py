@@ -683,6 +683,85 @@ def test_error_codes_match_reference_sites(dsa, hip):
         p.deletepartition(7)                    # src/pcsr.jl:190
 
 
+def _orientation_equal(a, b, o):
+    try:
+        La, Lb = a.export_layout(o), b.export_layout(o)
+    except Exception:
+        return False
+    if any(La["info"][k] != Lb["info"][k] for k in ("capacity", "segment_capacity", "nb_segments", "nb_elements", "height", "nb_partitions", "table_len")):
+        return False
+    live = La["col_live"].astype(bool)
+    return bool(layouts_equal((La["keys"], La["vals"], La["occ"]), (Lb["keys"], Lb["vals"], Lb["occ"])) and np.array_equal(La["semaphores"], Lb["semaphores"])
+                and np.array_equal(La["col_live"], Lb["col_live"]) and np.array_equal(La["col_keys"][live], Lb["col_keys"][live]))
+
+
+@pytest.mark.parametrize("pad", [0, 300])
+def test_state_after_a_failed_batch_is_the_references(dsa, hip, oracle, pad):
+    """src/matrix.jl:43-62 writes colmajor, then rowmajor: when write k of a batch throws, both orientations hold writes [0, k) and colmajor
+    also holds write k if it was the rowmajor statement that threw.  Until round 6 the library ran the colmajor half of the batch first and
+    could hold writes BEHIND k.  Crash paths of addpartition!(pcsc, prev) (src/pcsr.jl:114-146) provoked in the rowmajor
+    table, in the colmajor table, by both kinds of error, with writes queued behind the failing one; `pad` harmless writes in front push the
+    batch onto the batch-parallel path.  Compared: status, size(m), and the orientation that did not refuse slot for slot."""
+    rng = np.random.default_rng(3 + pad)
+    keys = np.arange(1, 51, dtype=np.int64) * 3                       # rows / columns 3, 6, ..., 150
+    I0 = np.repeat(keys, 4); J0 = rng.choice(keys, len(I0))
+    V0 = rng.integers(1, 9, len(I0)).astype(np.float64)
+
+    def fresh(deleted_rows=(), deleted_cols=()):
+        ms = [dsa.dynamicsparse(I0, J0, V0, binding=b) for b in (hip, oracle)]
+        for m in ms:
+            for r in deleted_rows:
+                m.deleterow(r)
+            for c in deleted_cols:
+                m.deletecolumn(c)
+        assert_mat_equal(*ms)
+        return ms
+
+    def run(ms, I, J, V, failing):
+        """failing: 1 = rowmajor refuses (colmajor must be the reference's), 0 = colmajor refuses, None = the batch succeeds"""
+        padI = rng.choice(keys[keys < 60], pad); padJ = rng.choice(keys[keys < 60], pad)          # existing rows / columns in front of every tombstone
+        I = np.concatenate([padI, np.asarray(I, dtype=np.int64)]); J = np.concatenate([padJ, np.asarray(J, dtype=np.int64)])
+        V = np.concatenate([np.full(pad, 2.5), np.asarray(V, dtype=np.float64)])
+        codes = []
+        for m in ms:
+            try:
+                m.set_batch(I, J, V); codes.append(None)
+            except dsa.DsaError as e:
+                codes.append(e.code)
+        assert codes[0] == codes[1], codes
+        assert ms[0].size() == ms[1].size()
+        if failing is None:
+            assert codes[0] is None
+            assert_mat_equal(*ms)
+        else:
+            assert codes[0] is not None
+            assert _orientation_equal(ms[0], ms[1], 1 - failing), ("the orientation that did not refuse the write differs", failing)
+        return codes[0]
+
+    # rowmajor asserts (new row 31 in front of live row 33 while row 105 is a tombstone further up); writes behind it must not reach colmajor
+    e = run(fresh(deleted_rows=(60, 105)), [6, 9, 31, 12, 200, 15], [3, 6, 9, 12, 15, 18], [1.5, 0.0, 2.5, 3.5, 4.5, 5.5], failing=1)
+    assert e == dsa.binding.EASSERT
+    # rowmajor BoundsError: the last row is a tombstone and a larger row key arrives (reuse branch, semaphores[0])
+    e = run(fresh(deleted_rows=(150,)), [6, 151, 9, 12], [3, 6, 9, 999], [1.5, 2.5, 3.5, 4.5], failing=1)
+    assert e == dsa.binding.EBOUNDS
+    # a tombstone reused (row 59 lands on the id of row 60), a re-created row, then the assert two writes later
+    e = run(fresh(deleted_rows=(60, 105, 120)), [59, 6, 31, 9], [3, 9, 12, 15], [1.5, 3.5, 4.5, 5.5], failing=1)
+    assert e == dsa.binding.EASSERT
+    # both tombstones taken again (59 on the id of 60, 105 re-created): row 31 then shifts a table without tombstones
+    run(fresh(deleted_rows=(60, 105)), [59, 105, 6, 31, 9], [3, 6, 9, 12, 15], [1.5, 2.5, 3.5, 4.5, 5.5], failing=None)
+    # the same batch without the failing write succeeds
+    run(fresh(deleted_rows=(60, 105)), [59, 105, 6, 9], [3, 6, 9, 15], [1.5, 2.5, 3.5, 5.5], failing=None)
+    # colmajor refuses (new column 31): rowmajor holds the writes in front of it only
+    e = run(fresh(deleted_cols=(60, 105)), [3, 6, 9, 12], [6, 31, 9, 12], [1.5, 2.5, 3.5, 4.5], failing=0)
+    assert e == dsa.binding.EASSERT
+    # tombstones in BOTH tables: rowmajor refuses write 2, colmajor would have refused write 4
+    e = run(fresh(deleted_rows=(60, 105), deleted_cols=(60, 105)), [6, 9, 31, 12, 15], [3, 6, 9, 12, 31], [1.5, 2.5, 3.5, 4.5, 5.5], failing=1)
+    assert e == dsa.binding.EASSERT
+    # ... and the other way round: colmajor refuses write 1, rowmajor would have refused write 3
+    e = run(fresh(deleted_rows=(60, 105), deleted_cols=(60, 105)), [6, 9, 12, 31], [3, 31, 9, 12], [1.5, 2.5, 3.5, 4.5], failing=0)
+    assert e == dsa.binding.EASSERT
+
+
 # ---------------------------------------------------------------- SpMV
 @pytest.mark.parametrize("m,n,per_col,seed", [(50, 40, 3, 1), (3000, 2500, 7, 2), (100000, 80000, 10, 3), (64, 100000, 2, 4)])
 def test_spmv_matches_oracle(dsa, hip, oracle, m, n, per_col, seed):

@@ -39,6 +39,28 @@ def mat_equal(a, b, ctx):
         assert np.array_equal(La["col_keys"][live], Lb["col_keys"][live]), (ctx, o, "col_keys")
 
 
+def mat_equal_after_error(a, b, ctx):
+    """The state after a FAILED batch (a reference crash path): size(m) and the orientation that did not refuse the
+    write are the reference's slot for slot (src/matrix.jl:43-62: colmajor holds the failing write when the rowmajor statement threw); the
+    orientation that refused it keeps its tables where the reference leaves them half shifted — that one is not compared."""
+    assert a.size() == b.size(), (ctx, a.size(), b.size())
+    same = []
+    for o in (0, 1):
+        try:
+            La, Lb = a.export_layout(o), b.export_layout(o)
+            ok = all(La["info"][k] == Lb["info"][k] for k in ("capacity", "segment_capacity", "nb_segments", "nb_elements", "height", "nb_partitions", "table_len"))
+            ok = ok and all(np.array_equal(La[k], Lb[k]) for k in ("occ", "semaphores", "col_live"))
+            if ok:
+                occ = La["occ"].astype(bool); live = La["col_live"].astype(bool)
+                ok = (np.array_equal(La["keys"][occ], Lb["keys"][occ]) and np.array_equal(La["vals"][occ], Lb["vals"][occ])
+                      and np.array_equal(La["col_keys"][live], Lb["col_keys"][live]))
+        except Exception:
+            ok = False
+        same.append(bool(ok))
+    assert any(same), (ctx, "neither orientation is the reference's after the failed batch", same)
+    return same
+
+
 def run_matrix(seed):
     g = SplitMix64(seed)
     spans = [3000, 40000, 300000, 2000000] if BIG else [50, 400, 3000, 40000]
@@ -96,7 +118,8 @@ def run_matrix(seed):
             eb = e.code
         assert ea == eb, ("error codes", seed, step, ea, eb)
         if ea is not None:
-            return "err%d" % ea          # state after a reference crash path is a documented divergence
+            mat_equal_after_error(a, b, (seed, step, mode, nb, "after error", ea))
+            return "err%d" % ea
         mat_equal(a, b, (seed, step, mode, nb))
         if live:                              # views, lookups and the sparse-x product on the fresh state
             i0, j0 = live[g.next() % len(live)]
@@ -403,13 +426,56 @@ def run_tombstones(seed):
             I.append(1 + int(g.next() % m)); J.append(j); V.append(v)
         e = _both(lambda: a.set_batch(I, J, V), lambda: b.set_batch(I, J, V))
         if e is not None:
-            return "err%d" % e          # state after a reference crash path is a documented divergence
+            mat_equal_after_error(a, b, (seed, step, "after error", e))
+            return "err%d" % e
         mat_equal(a, b, (seed, step, "batch", len(I)))
         alive = sorted(set(alive))
     n = a.size()[1]
     if n >= 1:
         x = 1.0 + np.arange(n) % 7 / 8.0
         assert np.allclose(a.mul(x), b.mul(x), rtol=1e-12, atol=0), (seed, "spmv")
+    return "ok"
+
+
+def run_crash_paths(seed):
+    """The reference's crash paths on purpose: a sparse key space with tombstones in BOTH tables, batches whose keys
+    fall between live ones / behind a tombstoned tail, so that most scenarios end in an AssertionError or BoundsError of addpartition!
+    somewhere inside a batch.  Status, size(m) and the orientation that did not refuse the write must be the reference's
+    (src/matrix.jl:43-62: colmajor, then rowmajor, write by write)."""
+    g = SplitMix64(seed)
+    nk = [20, 60, 400][g.next() % 3]
+    keys = np.arange(1, nk + 1, dtype=np.int64) * 3
+    per = 1 + g.next() % 4
+    I0 = np.repeat(keys, per)
+    J0 = keys[(np.array([g.next() for _ in range(len(I0))], dtype=np.uint64) % np.uint64(nk)).astype(np.int64)]
+    a = dsa.dynamicsparse(I0, J0, np.ones(len(I0)), binding=hip)
+    b = dsa.dynamicsparse(I0, J0, np.ones(len(I0)), binding=ora)
+    for step in range(5):
+        for _ in range(g.next() % 4):
+            k = int(keys[g.next() % nk])
+            which = g.next() % 2
+            f = (lambda: (a.deleterow(k) if which else a.deletecolumn(k)), lambda: (b.deleterow(k) if which else b.deletecolumn(k)))
+            e = _both(*f)
+            if e is not None and e != dsa.binding.EARG:          # (EARG: the column / row was deleted before — nothing happened)
+                mat_equal_after_error(a, b, (seed, step, "delete", k)); return "err%d" % e
+            if e is None:
+                mat_equal(a, b, (seed, step, "delete", k))
+        nb = [2, 8, 40, 200, 700][g.next() % 5]
+        top = 3 * nk
+        I, J, V = [], [], []
+        for _ in range(nb):
+            r = g.next() % 16
+            i = int(keys[g.next() % nk]); j = int(keys[g.next() % nk])
+            if r == 0: i = 1 + int(g.next() % (3 * nk + 6))            # any row key: between live ones, on a tombstone, behind the tail
+            if r == 1: j = 1 + int(g.next() % (3 * nk + 6))
+            if r == 2: top += 3; i = top
+            if r == 3: top += 3; j = top
+            I.append(i); J.append(j); V.append(0.0 if g.next() % 7 == 0 else 1.0 + (g.next() % 8))
+        e = _both(lambda: a.set_batch(I, J, V), lambda: b.set_batch(I, J, V))
+        if e is not None:
+            same = mat_equal_after_error(a, b, (seed, step, "batch", nb))
+            return "err%d%s" % (e, "c" if not same[0] else ("r" if not same[1] else "x"))
+        mat_equal(a, b, (seed, step, "batch", nb))
     return "ok"
 
 
@@ -695,6 +761,8 @@ if __name__ == "__main__":
             r = run_same_leaf_matrix(seed)                  # ... in a matrix: elements, new columns, emptied columns
         elif os.environ.get("FUZZ_ONLY") == "tomb" or (os.environ.get("FUZZ_ONLY") is None and seed % 16 == 11):
             r = run_tombstones(seed)                        # deletecolumn! / deleterow! and columns next to the tombstones
+        elif os.environ.get("FUZZ_ONLY") == "crash" or (os.environ.get("FUZZ_ONLY") is None and seed % 32 == 21):
+            r = run_crash_paths(seed)                       # the reference's crash paths: state after a failed batch
         elif os.environ.get("FUZZ_ONLY") == "pcsc" or (os.environ.get("FUZZ_ONLY") is None and seed % 16 == 13):
             r = run_packedcsc(seed)                         # the PackedCSC API with explicit partition ids
         elif os.environ.get("FUZZ_ONLY") == "hot" or (os.environ.get("FUZZ_ONLY") is None and seed % 32 == 1):
