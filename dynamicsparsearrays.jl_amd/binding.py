@@ -195,10 +195,11 @@ _PRODUCT = None
 
 
 def product_library_path() -> str:
-    """csrc/libdsa_hip.so; DSA_LIBRARY names another build of the SAME sources (the footprint-check build
-    csrc/libdsa_hip_fpcheck.so: tools/fuzz.py, the suite's check test) — a path that does not exist fails loudly like the default."""
+    """csrc/libdsa_hip.so.  A development process (DSA_DEV=1, like every other code-path switch: include/dsa.h, dsa_dev_switches) may name
+    another build of the SAME sources with DSA_LIBRARY (the footprint-check build csrc/libdsa_hip_fpcheck.so: tools/fuzz.py, the suite's
+    check test) — a path that does not exist fails loudly like the default.  A release process ignores an inherited DSA_LIBRARY."""
     override = os.environ.get("DSA_LIBRARY")
-    if override:
+    if override and os.environ.get("DSA_DEV") == "1":
         return os.path.abspath(override)
     return os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libdsa_hip.so")
 

@@ -807,11 +807,11 @@ hipError_t build_prepare(const int64_t* d_part, const int64_t* d_key, const doub
 }
 
 static hipError_t emit_wide(const double* d_val, int32_t combine, BuildScratch& s, KeyArr out_keys, double* out_vals, int64_t* part_keys, int mode,
-                            int64_t nparts_explicit, hipStream_t stream);
+                            int64_t nparts_explicit, hipStream_t stream, bool wait_and_free);
 
 hipError_t build_emit(const double* d_val, int32_t combine, BuildScratch& s, KeyArr out_keys, double* out_vals,
                       int64_t* part_keys, int mode, int64_t nparts_explicit, hipStream_t stream, bool wait_and_free) {
-    if (s.wide_path) return emit_wide(d_val, combine, s, out_keys, out_vals, part_keys, mode, nparts_explicit, stream);
+    if (s.wide_path) return emit_wide(d_val, combine, s, out_keys, out_vals, part_keys, mode, nparts_explicit, stream, wait_and_free);
     const int64_t nblocks = (s.n + RS_TILE - 1) / RS_TILE;
     BuildCtl* dctl = static_cast<BuildCtl*>(s.d_ctl);
     const uint64_t* comp = s.comp[s.sorted];
@@ -898,7 +898,7 @@ static hipError_t prepare_wide(const int64_t* d_part, const int64_t* d_key, int6
 }
 
 static hipError_t emit_wide(const double* d_val, int32_t combine, BuildScratch& s, KeyArr out_keys, double* out_vals, int64_t* part_keys, int mode,
-                            int64_t nparts_explicit, hipStream_t stream) {
+                            int64_t nparts_explicit, hipStream_t stream, bool wait_and_free) {
     const unsigned blocks = (unsigned)((s.n + 255) / 256);
     hipLaunchKernelGGL(k_emit_wide, dim3(blocks), dim3(256), 0, stream, mode == 1 ? (const int64_t*)nullptr : s.p2, s.k2, s.idx2, d_val,
                        s.fpart, s.fcell, s.spart, s.scell, s.n, combine, out_keys, out_vals, part_keys, mode);
@@ -906,6 +906,7 @@ static hipError_t emit_wide(const double* d_val, int32_t combine, BuildScratch& 
         hipLaunchKernelGGL(k_emit_sems_wide, dim3((unsigned)((nparts_explicit + 255) / 256)), dim3(256), 0, stream, s.p2, s.scell, s.n,
                            nparts_explicit, out_keys, out_vals);
     hipError_t e = hipGetLastError();
+    if (!wait_and_free) return e;            // (enqueue only, like the composite path: the caller waits and calls build_abort)
     if (e == hipSuccess) e = hipStreamSynchronize(stream);
     free_scratch(s);
     return e;

@@ -829,9 +829,14 @@ bool seq_step(SeqRun& r) {
             }
             if ((m3_takes || m5_takes) && e != hipSuccess) {
                 // The models need 140 KB of LDS per workgroup (gfx950 has 160): on a part that refuses the launch (hipFuncSetAttribute /
-                // launch error) the run is not lost — the per-op replay takes all of it, and the models stay off for the process.
+                // launch error) the run is not lost — the per-op replay takes all of it, and the models stay off for the process.  Only the
+                // codes such a refusal produces are taken that way (and said once on stderr: config 5 is several times slower without the
+                // models); anything else — a sticky error of earlier work on the stream, out of memory — is a failure like everywhere else.
                 (void)hipGetLastError();
-                g_models_off.store(true);
+                if (e != hipErrorInvalidValue && e != hipErrorLaunchOutOfResources && e != hipErrorInvalidConfiguration && e != hipErrorSharedObjectInitFailed)
+                    fail(DSA_EHIP, std::string("append model launch: ") + hipGetErrorString(e));
+                if (!g_models_off.exchange(true))
+                    fprintf(stderr, "libdsa_hip: append-replay models disabled for this process (%s): per-op replay from now on\n", hipGetErrorString(e));
                 m3_out = nullptr;
             }
             e = launch_append_run(P.O(), P.d_ctl, i0, R, P.has_cols ? P.run_flags : nullptr, P.has_cols ? P.run_out : nullptr, P.run_memo, m3_out, P.stream);
@@ -1275,12 +1280,36 @@ void pma_build_dev(Pma& P, const int64_t* d_part, const int64_t* d_key, const do
     // the emit with the GPU idle: 180 of the 1500 us of config 3's closefillmode!.  Duplicates folded later only leave the buffers
     // larger than needed (as after a _shrink!).  Only for a structure that holds nothing yet: growing an existing one waits for
     // the stream (old contents are copied).
+    // BEST EFFORT: the upper bound can be far above what the counts will ask for (duplicate-heavy input: a fill buffer that overwrites
+    // the same cells, a vector fed repeated keys), so it is capped at a share of the memory that is free right now, an allocation that
+    // fails here is undone (the exact sizing below gets its chance), and buffers more than 4 x too large are handed back once the
+    // counts are known.
+    bool prealloc_done = false;
+    auto release_prealloc = [&] {
+        pma_free_buffers(P);
+        P.cap_alloc = 0; P.occ_words = 0; P.occ_dirty[0] = P.occ_dirty[1] = 0;
+        pool_free(P.sems); pool_free(P.col_keys); pool_free(P.col_live);
+        P.sems = nullptr; P.col_keys = nullptr; P.col_live = nullptr; P.h_ctl->table_cap = 0;
+        prealloc_done = false;
+    };
     const std::function<void()> prealloc = [&] {
         if (P.cap_alloc != 0 || P.sems != nullptr) return;
         int64_t np_ub = mode == 2 ? nparts_explicit : 0;
         if (mode == 0) np_ub = part_range.known() ? std::min<int64_t>(nnz, (int64_t)std::min<uint64_t>((uint64_t)part_range.hi - (uint64_t)part_range.lo, (uint64_t)nnz) + 1) : nnz;
-        if (P.has_sems) ensure_tables(P, std::max<int64_t>(2 * np_ub, 64));
-        ensure_capacity_alloc(P, 2 * capacity_for(nnz + np_ub));
+        const int64_t slots_ub = 2 * capacity_for(nnz + np_ub);
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return; }
+        const double want = 2.0 * (double)slots_ub * (double)(P.kb() + sizeof(double)) + 4.0 * 17.0 * (double)np_ub;
+        if (want > 0.25 * ((double)free_b + (double)pool_idle_bytes())) return;          // not speculatively: exact sizing after the counts
+        try {
+            if (P.has_sems) ensure_tables(P, std::max<int64_t>(2 * np_ub, 64));
+            ensure_capacity_alloc(P, slots_ub);
+            prealloc_done = true;
+        } catch (const Fail&) {
+            (void)hipGetLastError();
+            (void)hipStreamSynchronize(P.stream);
+            release_prealloc();
+        }
     };
     hipError_t e;
     try { e = build_prepare(d_part, d_key, d_val, nnz, part_range, key_range, sc, counts, P.stream, &prealloc); }
@@ -1290,6 +1319,8 @@ void pma_build_dev(Pma& P, const int64_t* d_part, const int64_t* d_key, const do
     const int64_t np = mode == 0 ? counts[1] : (mode == 2 ? nparts_explicit : 0);
     const int64_t n = counts[0] + np;
     try {
+        // (build_prepare has waited for the counts on this stream: the memsets of the speculative blocks are complete)
+        if (prealloc_done && P.cap_alloc > 8 * capacity_for(n) && P.cap_alloc > (1 << 20)) release_prealloc();
         if (P.has_sems) {
             P.h_ctl->nb_partitions = np; P.h_ctl->table_len = np;
             ensure_tables(P, std::max<int64_t>(2 * np, 64));
@@ -1311,8 +1342,10 @@ void pma_build_dev(Pma& P, const int64_t* d_part, const int64_t* d_key, const do
     const bool ordered = P.device >= 0 && P.device < MAX_EMIT_DEVICES;      // (events belong to a device: one slot per device)
     if (ordered) {
         hipEvent_t& ev = g_emit_done[P.device];
-        if (ev == nullptr) HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-        else HIPCHK(hipStreamWaitEvent(P.stream, ev, 0));
+        try {
+            if (ev == nullptr) HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            else HIPCHK(hipStreamWaitEvent(P.stream, ev, 0));
+        } catch (...) { emit_order.unlock(); build_abort(sc); throw; }      // (the scratch of the sort would leak otherwise)
     }
     e = build_emit(d_val, combine, sc, P.K(), P.V(), P.has_cols ? P.col_keys : nullptr, mode, nparts_explicit, P.stream, false);
     if (e != hipSuccess) { emit_order.unlock(); build_abort(sc); fail(DSA_EHIP, std::string("K-build emit: ") + hipGetErrorString(e)); }

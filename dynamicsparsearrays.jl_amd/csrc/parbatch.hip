@@ -473,7 +473,12 @@ __global__ __launch_bounds__(PL_BLOCK) void k_plan(const DevBufs* bufs, const Ct
             if (l0 == 0) continue;
             const Iv me = sIv[j];
             const int c0 = me.lo >> CS, c1 = me.hi >> CS;
-            if (c1 - c0 > 1) { widen[u] = true; continue; }              // (a tight hull over three cells: keep it simple)
+            if (c1 - c0 > 1) {                                           // (a tight hull over three cells: keep it simple)
+                // ... a new column without a fallback window (level 0x7f) has nothing to be widened to: W = seg << 0x7f below is undefined.
+                // The prefix ends in front of it, like further down
+                if (sLvl[j] == 0x7f) atomicMin(&sC, j); else widen[u] = true;
+                continue;
+            }
             // does the leaf [a, a + seg) with c cells before the round accept every count the window's ops can leave in it?
             auto accepts = [&](int32_t a, int64_t c) {
                 const int32_t b = a + (int32_t)seg - 1;

@@ -2221,13 +2221,13 @@ def test_footprint_check_build_fires_on_the_two_resolver_bugs_of_round_4_and_is_
     fuzz = [sys.executable, os.path.join(root, "tools", "fuzz.py")]
     leaf_test = [sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_hip_parity.py"), "-m", "gpu", "-x", "-q", "-k", "two_deletes_from_a_leaf"]
     for mode in ("1", "2"):
-        env = dict(os.environ, DSA_LIBRARY=os.path.join(csrc, "libdsa_hip_fpcheck_bug1.so"), DSA_FP_MODE=mode)
+        env = dict(os.environ, DSA_DEV="1", DSA_LIBRARY=os.path.join(csrc, "libdsa_hip_fpcheck_bug1.so"), DSA_FP_MODE=mode)
         r = _run_child(leaf_test, env)
         assert r.returncode != 0 and "DSA_FP_CHECK" in r.stdout + r.stderr, (mode, r.stdout[-1500:])
-        env = dict(os.environ, DSA_LIBRARY=os.path.join(csrc, "libdsa_hip_fpcheck_bug2.so"), DSA_FP_MODE=mode, FUZZ_ONLY="leaf")
+        env = dict(os.environ, DSA_DEV="1", DSA_LIBRARY=os.path.join(csrc, "libdsa_hip_fpcheck_bug2.so"), DSA_FP_MODE=mode, FUZZ_ONLY="leaf")
         r = _run_child(fuzz + ["8", "1990"], env)
         assert r.returncode != 0 and "DSA_FP_CHECK" in r.stdout + r.stderr, (mode, r.stdout[-1500:])
-        env = dict(os.environ, DSA_LIBRARY=os.path.join(csrc, "libdsa_hip_fpcheck.so"), DSA_FP_MODE=mode)
+        env = dict(os.environ, DSA_DEV="1", DSA_LIBRARY=os.path.join(csrc, "libdsa_hip_fpcheck.so"), DSA_FP_MODE=mode)
         r = _run_child(leaf_test, env)
         assert r.returncode == 0, (mode, r.stdout[-2500:])
         r = _run_child(fuzz + ["6", "1990"], dict(env, FUZZ_ONLY="leaf"))

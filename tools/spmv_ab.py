@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """A/B of the gather kernel (dev tool): time y = A x on the three shapes bench.py reports — config 3 (uniformly random columns, x = 8 MB),
 the banded extra (every gather an L2 hit), the final config-5 matrix (2^21 slots, x = 400 KB) — with HIP events around N launches, and
-print y's bytes as a sha256 so that two variants of the kernel (run this tool once per library — DSA_LIBRARY=<another build of csrc/> —
+print y's bytes as a sha256 so that two variants of the kernel (run this tool once per library — DSA_DEV=1 DSA_LIBRARY=<another build of csrc/> —
 or per setting of the development switches, e.g. DSA_DEV=1 DSA_SPMV_SHARE=0) can be compared bit for bit (the banded shape has two
 rows longer than a span: their sums are joined by atomics and may differ in the last bits from run to run).  usage: python3 tools/spmv_ab.py [c3] [banded] [c5]"""
 import ctypes as C
