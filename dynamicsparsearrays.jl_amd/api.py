@@ -442,13 +442,15 @@ class DynamicSparseMatrix(_Handle):
     def T(self):
         return Transposed(self)
 
-    def mul(self, x, transpose=False, dense_out=None):
+    def mul(self, x, transpose=False, dense_out=None, out=None):
         """mat * v / transpose(mat) * v  (src/operations.jl:14-36).
 
         `x` is a DynamicSparseVector, a (indices, values) pair of the stored entries
         (ascending indices), or a dense numpy array.  Sparse inputs return
         (indices, values) of the touched rows, ascending — the `_mul_output` shape;
         a dense array returns a dense array of length size(mat, 1 | 2).
+        `out` = (int64 array, float64 array) the caller keeps across products (each at least as long as the result): the
+        result is fetched into them and views are returned — a long result does not pay for fresh pages every time.
         """
         if isinstance(x, np.ndarray):
             m, n = self.size()
@@ -463,20 +465,31 @@ class DynamicSparseMatrix(_Handle):
             xi, xv = x
         xi, xip = _i64(xi)
         xv, xvp = _f64(xv)
-        cap = 1024
-        while True:
-            yi = np.empty(cap, dtype=np.int64)
-            yv = np.empty(cap, dtype=np.float64)
-            n_out = C.c_int64()
-            try:
-                self.b.call("mat_spmv_sparse", self.h, 1 if transpose else 0, xip, xvp, len(xi),
-                            yi.ctypes.data_as(P_I64), yv.ctypes.data_as(P_F64), cap, C.byref(n_out))
-            except B.DsaError as e:
-                if e.code == B.ECAP:
-                    cap *= 16
-                    continue
-                raise
-            return yi[:n_out.value], yv[:n_out.value]
+        tr = 1 if transpose else 0
+        n_out = C.c_int64()
+        if "mat_spmv_sparse_begin" in self.b.SIGNATURES:
+            # compute, learn the number of touched rows, allocate exactly that, fetch (one product, whatever the result size)
+            self.b.call("mat_spmv_sparse_begin", self.h, tr, xip, xvp, len(xi), C.byref(n_out))
+            cnt = n_out.value
+            if out is not None and len(out[0]) >= cnt and len(out[1]) >= cnt:
+                yi, yv = out[0][:cnt], out[1][:cnt]
+            else:
+                yi = np.empty(cnt, dtype=np.int64)
+                yv = np.empty(cnt, dtype=np.float64)
+            if cnt:
+                self.b.call("mat_spmv_sparse_fetch", self.h, yi.ctypes.data_as(P_I64), yv.ctypes.data_as(P_F64), cnt, C.byref(n_out))
+            return yi, yv
+        m, n = self.size()
+        cap = max(n if transpose else m, 1)                # the touched rows are at most all rows
+        yi = np.empty(cap, dtype=np.int64)
+        yv = np.empty(cap, dtype=np.float64)
+        self.b.call("mat_spmv_sparse", self.h, tr, xip, xvp, len(xi), yi.ctypes.data_as(P_I64), yv.ctypes.data_as(P_F64), cap, C.byref(n_out))
+        return yi[:n_out.value].copy(), yv[:n_out.value].copy()
+
+    def mul_dev(self, d_xi, d_xv, nx, d_yi, d_yv, cap, d_count, transpose=False):
+        """the sparse product with every operand in HBM (device addresses, e.g. tensor.data_ptr()); stream-ordered, no host wait"""
+        self.b.call("mat_spmv_sparse_dev", self.h, 1 if transpose else 0, C.c_void_p(int(d_xi)), C.c_void_p(int(d_xv)), int(nx),
+                    C.c_void_p(int(d_yi)), C.c_void_p(int(d_yv)), int(cap), C.c_void_p(int(d_count)))
 
 
 def dynamicsparse(I=None, J=None, V=None, m=None, n=None, fill_mode=True,

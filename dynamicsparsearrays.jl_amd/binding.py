@@ -120,6 +120,9 @@ _DEVICE_SIGS = {
     "set_device": [I32],
     "mat_spmv_dense_dev": [VP, I32, I32, VP, I64, VP, I64],
     "mat_col_view_dev": [VP, I64, VP, VP, I64, P_I64],
+    "mat_spmv_sparse_begin": [VP, I32, P_I64, P_F64, I64, P_I64],
+    "mat_spmv_sparse_fetch": [VP, P_I64, P_F64, I64, P_I64],
+    "mat_spmv_sparse_dev": [VP, I32, VP, VP, I64, VP, VP, I64, VP],
     "mat_row_view_dev": [VP, I64, VP, VP, I64, P_I64],
     "shard_range": [I64, I32, I32, P_I64, P_I64],
     "shard_create_from_coo": [P_I64, P_I64, P_F64, I64, I64, I64, I32, I32, C.POINTER(VP)],

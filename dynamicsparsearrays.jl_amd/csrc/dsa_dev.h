@@ -283,6 +283,14 @@ hipError_t launch_compact_range(KeyArr keys, const double* vals, const uint64_t*
 // sparse-x SpMV result: touched flags (bytes, or the doubles of a pattern pass) -> (row, y[row]) pairs in ascending row order
 hipError_t launch_touched_compact(const uint8_t* bytes, const double* pattern, const double* y, int64_t ny, uint64_t* bm,
                                   int64_t* out_i, double* out_v, RebalanceWork* work, int64_t* count, hipStream_t stream);
+// sparse-x product (sparsex.hip): accumulate driven by x's stored entries, touched-row bitmap of a pattern pass, count + emit
+hipError_t launch_spx_accum(KeyArr keys, const double* vals, const uint64_t* occ, int64_t capacity, const int64_t* sems, const int64_t* col_keys,
+                            const uint8_t* col_live, int64_t table_len, const int64_t* xi, const double* xv, int64_t nx, double* acc,
+                            uint64_t* bm, int64_t ny, hipStream_t stream);
+hipError_t launch_spx_pattern_bits(const double* pattern, int64_t ny, uint64_t* bm, hipStream_t stream);
+hipError_t launch_spx_finish(uint64_t* bm, int64_t ny, uint32_t* tile_cnt, uint32_t* tile_off, unsigned int* ticket, double* src, int clear_src,
+                             int64_t* out_i, double* out_v, int64_t cap, int64_t* d_count, long long* host, int64_t pin_cells,
+                             unsigned long long seq, hipStream_t stream);
 hipError_t launch_scatter_x(const int64_t* xi, const double* xv, int64_t nx, double* xd, double* xf, int64_t nxd, hipStream_t stream);
 // whole-vector operations on packed streams (rebalance.hip)
 hipError_t launch_packed_equal(KeyArr ka, const double* va, KeyArr kb, const double* vb, int64_t n, int32_t* differ, hipStream_t stream);

@@ -11,6 +11,10 @@
 #include "dsa_dev.h"
 
 #include <dlfcn.h>
+#include <sys/mman.h>
+#ifndef MADV_HUGEPAGE
+#define MADV_HUGEPAGE 14      /* <linux/mman.h>; hidden by the feature-test macros of this compilation */
+#endif
 
 #include <algorithm>
 #include <atomic>
@@ -108,6 +112,7 @@ static const char* const k_dev_switches[] = {
     "DSA_SMALL_BUILD",    // 0: small vectors through the general builder
     "DSA_SMALL_ROUNDS",   // 0: small matrix batches on two sequencers
     "DSA_SPMV_SHARE", "DSA_SPMV_STREAM", "DSA_SPMV_ZFILL", "DSA_SPMV_COMPACT",     // variants of the gather kernel
+    "DSA_SPX_XDRIVEN",    // 0 / 1: the sparse-x product always through the gather kernel / always driven by x's entries
     "DSA_TIGHT",          // 0..3: tight footprints of leaf-accepted ops
     "DSA_TOMBSTONE_PAR",  // 0: orientations one after the other whenever tombstones exist
     "DSA_TWIN_ROUNDS",    // 0: the twin's deletes of deletecolumn! on a second sequencer
@@ -1493,9 +1498,21 @@ struct dsa_mat {
     bool has_major = false;
     Pma col, row;          // colmajor / rowmajor MappedPackedCSC
     double* d_x = nullptr; double* d_y = nullptr; int64_t x_cap = 0, y_cap = 0;
-    void* sp_base = nullptr; size_t sp_bytes = 0;             // scratch of the sparse-x SpMV (grown, never shrunk)
-    void* sp_pin = nullptr; size_t sp_pin_bytes = 0;          // pinned staging of its x upload and result download
-    RebalanceWork sp_work{nullptr, nullptr, 0};
+    // sparse-x product (sparsex.hip): acc / bm keep a ZERO INVARIANT between two products; everything grown, never shrunk
+    struct Spx {
+        double* acc = nullptr; uint64_t* bm = nullptr; int64_t rows_cap = 0;      // sums per row, one bit per touched row
+        uint32_t* tile_cnt = nullptr; uint32_t* tile_off = nullptr; unsigned int* ticket = nullptr; int64_t tiles_cap = 0;
+        int64_t* oi = nullptr; double* ov = nullptr; int64_t out_cap = 0;         // packed result in HBM
+        int64_t* dx = nullptr; int64_t x_cap = 0;                                 // xi | xv uploaded
+        int64_t* d_count = nullptr;
+        long long* pin = nullptr;                                                 // landing area: 8 header words + 2 x SPX_PIN_CELLS
+        void* stage = nullptr; size_t stage_bytes = 0;                            // pinned staging: x on the way up, long results on the way down
+        unsigned long long seq = 0;
+        std::vector<hipEvent_t> ev;                                               // behind the pieces of a long result on their way down
+        bool dl_started = false; int dl_np = 0; size_t dl_off[8] = {}, dl_bytes[8] = {}; // ... its pieces: offset in [rows | values], bytes
+        int64_t res_count = -1;                                                   // result of the last begin (-1: none)
+        hipStream_t res_stream = nullptr;
+    } spx;
     std::vector<int64_t> pi, pj; std::vector<double> pv;      // queued single writes (non-fill mode)
 };
 
@@ -2455,9 +2472,15 @@ int32_t dsa_mat_destroy(dsa_mat_t* h) {
         fill_release(h->buf);
         if (h->d_x) hipFree(h->d_x);
         if (h->d_y) hipFree(h->d_y);
-        if (h->sp_base) hipFree(h->sp_base);
-        if (h->sp_pin) hipHostFree(h->sp_pin);
-        if (h->sp_work.tile_cnt) { hipFree(h->sp_work.tile_cnt); hipFree(h->sp_work.tile_off); }
+        {
+            dsa_mat::Spx& x = h->spx;
+            if (x.res_stream) (void)hipStreamSynchronize(x.res_stream);
+            pool_free(x.acc); pool_free(x.bm); pool_free(x.tile_cnt); pool_free(x.tile_off); pool_free(x.ticket);
+            pool_free(x.oi); pool_free(x.ov); pool_free(x.dx); pool_free(x.d_count);
+            pinned_free(x.pin);
+            for (hipEvent_t e : x.ev) if (e) (void)hipEventDestroy(e);
+            if (x.stage) (void)hipHostFree(x.stage);
+        }
         delete h;
     }
     return DSA_OK;
@@ -2892,103 +2915,306 @@ int32_t dsa_mat_spmv_dense(dsa_mat_t* h, int32_t transpose, const double* x, int
     API_CATCH
 }
 
-// sparse x (the shape Coluna uses): two device strategies, same result shape (_mul_output, src/operations.jl:11-12)
-//   nx small  : k_spmv_xdriven over the reference's own orientation (colmajor for mat*v) — work ~ matched cells
-//   nx large  : densify x, gather kernel over the twin for the values + once more on the 0/1 pattern of x
-int32_t dsa_mat_spmv_sparse(dsa_mat_t* h, int32_t transpose, const int64_t* xi, const double* xv, int64_t nx,
-                            int64_t* yi, double* yv, int64_t cap, int64_t* n_out) {
-    API_TRY
-    static const bool dbg_time = dev_env("DSA_DBG_TIME") != nullptr;
-    const auto tq0 = std::chrono::steady_clock::now();
-    auto tq = [&](const char* what) { if (dbg_time) fprintf(stderr, "  [spmv_sparse] %s at %.1f us\n", what, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tq0).count()); };
-    if (dbg_time) fprintf(stderr, "  [spmv_sparse] enter at %.1f us (steady clock)\n", std::chrono::duration<double, std::micro>(tq0.time_since_epoch()).count());
-    mat_flush(h);
-    tq("flushed");
-    if (!h->has_major) fail(DSA_EMODE, "matrix is in fill mode");
-    const int64_t ny = transpose ? h->n : h->m;
-    const int64_t ncols = transpose ? h->m : h->n;
-    int64_t nxd = 0;
-    for (int64_t i = 0; i < nx; ++i) {
-        if (i > 0 && xi[i] <= xi[i - 1]) fail(DSA_EARG, "indices of x must be strictly ascending");
-        nxd = std::max(nxd, xi[i]);
+// ---- sparse x (the product Coluna calls): the touched rows, ascending, stored zeros kept (_mul_output, src/operations.jl:11-12) ----
+// Two device strategies (sparsex.hip), one result form:
+//   few stored entries : k_spx_accum over the reference's own orientation (colmajor for mat * v) — work ~ matched cells
+//   many               : densify x, gather kernel over the twin for the values + once more on the 0/1 pattern of x
+// then count + emit of the touched rows from a bitmap.  dsa_mat_spmv_sparse_begin computes and leaves the packed result with the
+// handle (HBM; short results also in a pinned landing area the emit kernel writes to directly), dsa_mat_spmv_sparse_fetch copies it
+// out: the caller allocates exactly what the product needs (until round 6 the wrappers guessed a capacity and REPEATED the whole
+// product on DSA_ECAP: four products for one at 394 k stored entries).
+}  // extern "C"
+namespace {
+int P_device_of(dsa_mat* h) { return h->col.device; }
+constexpr int64_t SPX_PIN_CELLS = 4096;          // result pairs the emit kernel hands over through pinned memory (64 KB)
+constexpr int64_t SPX_DIRECT_X = 4096;           // stored entries read by k_spx_accum straight from pinned host memory (no copy command)
+
+// host copy between a pinned staging area and the caller's pageable array: above 1 MB on up to four threads (first-touch page faults
+// of a freshly allocated result array are most of the cost, and they parallelise)
+void par_memcpy(void* dst, const void* src, size_t bytes) {
+    if (bytes < ((size_t)1 << 20)) { std::memcpy(dst, src, bytes); return; }
+    const int nt = bytes >= ((size_t)4 << 20) ? 4 : 2;
+    const size_t part = ((bytes / nt) + 4095) & ~(size_t)4095;
+    std::thread th[3];
+    int started = 0;
+    for (int t = 1; t < nt; ++t) {
+        const size_t off = (size_t)t * part;
+        if (off >= bytes) break;
+        const size_t b = std::min(part, bytes - off);
+        th[started++] = std::thread([=] { std::memcpy((char*)dst + off, (const char*)src + off, b); });
     }
-    *n_out = 0;
-    if (ny <= 0 || nx <= 0) return DSA_OK;
-    const bool xdriven = nx * 8 < std::max<int64_t>(ncols, 1) || nxd <= 0 || xi[0] < 1;
-    // Everything stays on the device until the compacted result: x is uploaded in its sparse form, the touched rows are
-    // packed on the device (bitmap + K-pack) and only the (row, value) pairs come back.
-    // scratch: xi | xv | xf (dense 0/1 pattern of x) | touched bytes | bitmap | out rows | out values
-    const int64_t nxdd = xdriven ? 0 : nxd;
-    const int64_t nwords = (ny + 63) >> 6, ntiles = (nwords + 63) / 64, nwp = ntiles * 64;
-    const size_t off_xv = (size_t)nx * 8, off_xf = off_xv + (size_t)nx * 8, off_t = off_xf + (size_t)nxdd * 8,
-                 off_bm = off_t + (size_t)((ny + 7) / 8) * 8, off_oi = off_bm + (size_t)nwp * 8, off_ov = off_oi + (size_t)ny * 8,
-                 bytes = off_ov + (size_t)ny * 8;
-    if (bytes > h->sp_bytes) {
-        if (h->sp_base) hipFree(h->sp_base);
-        h->sp_base = nullptr; h->sp_bytes = 0;
-        const size_t want = bytes + bytes / 2;
-        HIPCHK(hipMalloc(&h->sp_base, want));
-        h->sp_bytes = want;
+    std::memcpy(dst, src, std::min(part, bytes));
+    for (int t = 0; t < started; ++t) th[t].join();
+}
+void spx_ensure(dsa_mat* h, int64_t ny, int64_t nx_upload, hipStream_t s) {
+    dsa_mat::Spx& x = h->spx;
+    if (ny > x.rows_cap) {
+        if (x.res_stream) HIPCHK(hipStreamSynchronize(x.res_stream));
+        pool_free(x.acc); pool_free(x.bm); pool_free(x.oi); pool_free(x.ov); pool_free(x.tile_cnt); pool_free(x.tile_off);
+        x.acc = nullptr; x.bm = nullptr; x.oi = nullptr; x.ov = nullptr; x.tile_cnt = nullptr; x.tile_off = nullptr; x.rows_cap = 0; x.out_cap = 0; x.tiles_cap = 0;
+        const int64_t rows = std::max<int64_t>(ny + ny / 4, 4096);
+        const int64_t nwords = (rows + 63) >> 6, ntiles = (nwords + 63) / 64;
+        HIPCHK(pool_alloc(reinterpret_cast<void**>(&x.acc), (size_t)rows * sizeof(double)));
+        HIPCHK(pool_alloc(reinterpret_cast<void**>(&x.bm), (size_t)(ntiles * 64) * sizeof(uint64_t)));
+        HIPCHK(pool_alloc(reinterpret_cast<void**>(&x.oi), (size_t)rows * sizeof(int64_t)));
+        HIPCHK(pool_alloc(reinterpret_cast<void**>(&x.ov), (size_t)rows * sizeof(double)));
+        HIPCHK(pool_alloc(reinterpret_cast<void**>(&x.tile_cnt), (size_t)(ntiles + 1) * sizeof(uint32_t)));
+        HIPCHK(pool_alloc(reinterpret_cast<void**>(&x.tile_off), (size_t)(ntiles + 2) * sizeof(uint32_t)));
+        HIPCHK(hipMemsetAsync(x.acc, 0, (size_t)rows * sizeof(double), s));               // the zero invariant starts here
+        HIPCHK(hipMemsetAsync(x.bm, 0, (size_t)(ntiles * 64) * sizeof(uint64_t), s));
+        x.rows_cap = rows; x.out_cap = rows; x.tiles_cap = ntiles;
     }
-    if (ntiles + 1 > h->sp_work.tiles_cap) {
-        if (h->sp_work.tile_cnt) { hipFree(h->sp_work.tile_cnt); hipFree(h->sp_work.tile_off); h->sp_work = RebalanceWork{nullptr, nullptr, 0}; }
-        const int64_t tc = 2 * ntiles + 8;
-        HIPCHK(hipMalloc(&h->sp_work.tile_cnt, (size_t)tc * sizeof(uint32_t)));
-        HIPCHK(hipMalloc(&h->sp_work.tile_off, (size_t)tc * sizeof(uint32_t)));
-        h->sp_work.tiles_cap = tc;
+    if (!x.ticket) {
+        HIPCHK(pool_alloc(reinterpret_cast<void**>(&x.ticket), 4 * sizeof(unsigned int)));
+        HIPCHK(hipMemsetAsync(x.ticket, 0, 4 * sizeof(unsigned int), s));
+        HIPCHK(pool_alloc(reinterpret_cast<void**>(&x.d_count), sizeof(int64_t)));
+        HIPCHK(pinned_alloc(reinterpret_cast<void**>(&x.pin), (size_t)(8 + 2 * SPX_PIN_CELLS) * sizeof(long long)));
+        std::memset(x.pin, 0, 8 * sizeof(long long));
     }
-    char* base = (char*)h->sp_base;
-    int64_t* d_xi = (int64_t*)base; double* d_xv = (double*)(base + off_xv); double* d_xf = (double*)(base + off_xf);
-    uint8_t* d_t = (uint8_t*)(base + off_t); uint64_t* d_bm = (uint64_t*)(base + off_bm);
-    int64_t* d_oi = (int64_t*)(base + off_oi); double* d_ov = (double*)(base + off_ov);
-    ensure_xy(h, std::max<int64_t>(nxdd, 1), 2 * ny);
+    if (nx_upload > x.x_cap) {
+        if (x.res_stream) HIPCHK(hipStreamSynchronize(x.res_stream));
+        pool_free(x.dx); x.dx = nullptr; x.x_cap = 0;
+        const int64_t c = nx_upload + nx_upload / 2;
+        HIPCHK(pool_alloc(reinterpret_cast<void**>(&x.dx), (size_t)c * 16));
+        x.x_cap = c;
+    }
+}
+void spx_stage(dsa_mat* h, size_t bytes, hipStream_t s) {
+    dsa_mat::Spx& x = h->spx;
+    if (bytes <= x.stage_bytes) return;
+    if (x.stage) { HIPCHK(hipStreamSynchronize(s)); if (x.res_stream && x.res_stream != s) HIPCHK(hipStreamSynchronize(x.res_stream)); HIPCHK(hipHostFree(x.stage)); }
+    x.stage = nullptr; x.stage_bytes = 0;
+    const size_t want = std::max<size_t>(bytes + bytes / 2, 1u << 16);
+    HIPCHK(hipHostMalloc(&x.stage, want, hipHostMallocDefault));
+    x.stage_bytes = want;
+}
+// which strategy: the x-driven kernel costs ~ the stored entries (a handful of dependent round trips per entry, one wave each), the
+// gather kernel ~ the slot array (twice: values, pattern).  DSA_SPX_XDRIVEN=0/1 forces one (A/B, coverage).
+bool spx_xdriven(int64_t nx, int64_t ncols) {
+    static const int force = [] { const char* e = dev_env("DSA_SPX_XDRIVEN"); return e ? atoi(e) : -1; }();
+    if (force == 0 || force == 1) return force == 1;
+    return nx * 8 < std::max<int64_t>(ncols, 1);
+}
+// enqueues the whole product on the walked structure's stream; x entries at (d_xi, d_xv): HBM, or pinned host memory for the
+// x-driven kernel.  Result: out_i / out_v / d_count (HBM) and, when `host`, the landing area + sequence number.
+hipStream_t spx_enqueue(dsa_mat* h, int32_t transpose, bool xdriven, const int64_t* d_xi, const double* d_xv, int64_t nx, int64_t ny, int64_t ncols,
+                        int64_t* out_i, double* out_v, int64_t cap, int64_t* d_count, long long* host, unsigned long long seq) {
+    dsa_mat::Spx& x = h->spx;
     Pma& P = xdriven ? (transpose ? h->row : h->col) : (transpose ? h->col : h->row);      // the structure that is walked
     hipStream_t s = P.stream;
-    // x up and the result down through a pinned staging area of the handle: copies between the device and the caller's PAGEABLE
-    // arrays take anything from 3 to 14 ms for these 16 MB depending on the state of the caller's pages (measured: the same call 4.5
-    // or 15 ms from one bench run to the next); DMA to pinned memory + a host memcpy does not
-    {
-        const size_t need = 16 * (size_t)std::max<int64_t>(nx, ny);
-        if (need > h->sp_pin_bytes) {
-            if (h->sp_pin) { HIPCHK(hipStreamSynchronize(s)); HIPCHK(hipHostFree(h->sp_pin)); }
-            h->sp_pin = nullptr; h->sp_pin_bytes = 0;
-            HIPCHK(hipHostMalloc(&h->sp_pin, need + need / 2, hipHostMallocDefault));
-            h->sp_pin_bytes = need + need / 2;
+    // acc / bm are shared by the products of both orientations: one on another stream than the last one waits for that one's emit
+    if (x.res_stream && x.res_stream != s) HIPCHK(hipStreamSynchronize(x.res_stream));
+    hipError_t e;
+    if (xdriven) {
+        e = launch_spx_accum(P.K(), P.V(), P.O(), P.capacity(), P.sems, P.col_keys, P.col_live, P.h_ctl->table_len, d_xi, d_xv, nx, x.acc, x.bm, ny, s);
+        if (e != hipSuccess) fail(DSA_EHIP, std::string("sparse-x accumulate launch: ") + hipGetErrorString(e));
+        e = launch_spx_finish(x.bm, ny, x.tile_cnt, x.tile_off, x.ticket, x.acc, 1, out_i, out_v, cap, d_count, host, SPX_PIN_CELLS, seq, s);
+    } else {
+        ensure_xy(h, std::max<int64_t>(2 * ncols, 1), 2 * ny);
+        double* d_xd = h->d_x; double* d_xf = h->d_x + ncols;
+        e = launch_scatter_x(d_xi, d_xv, nx, d_xd, d_xf, ncols, s);
+        if (e != hipSuccess) fail(DSA_EHIP, std::string("scatter launch: ") + hipGetErrorString(e));
+        spmv_dev(h, transpose, 0, d_xd, ncols, h->d_y, ny, s);
+        spmv_dev(h, transpose, 0, d_xf, ncols, h->d_y + ny, ny, s, 1);                      // pattern pass: touched rows
+        e = launch_spx_pattern_bits(h->d_y + ny, ny, x.bm, s);
+        if (e != hipSuccess) fail(DSA_EHIP, std::string("pattern launch: ") + hipGetErrorString(e));
+        e = launch_spx_finish(x.bm, ny, x.tile_cnt, x.tile_off, x.ticket, h->d_y, 0, out_i, out_v, cap, d_count, host, SPX_PIN_CELLS, seq, s);
+    }
+    if (e != hipSuccess) fail(DSA_EHIP, std::string("sparse-x finish launch: ") + hipGetErrorString(e));
+    return s;
+}
+// a long result (more pairs than the landing area holds) starts its way down as soon as its size is known: DMA into pinned staging in
+// up to 8 pieces, an event behind each; dsa_mat_spmv_sparse_fetch copies a piece to the caller's arrays (four threads for long ones)
+// while the next ones are still on the wire.  (Copies between the device and the caller's PAGEABLE arrays take anything from 3 to 14 ms
+// for 16 MB depending on the state of the caller's pages; one DMA + one single-threaded copy of the whole result: 1.6 ms.)
+void spx_start_download(dsa_mat* h) {
+    dsa_mat::Spx& x = h->spx;
+    const int64_t cnt = x.res_count;
+    hipStream_t s = x.res_stream;
+    spx_stage(h, (size_t)cnt * 16, s);
+    char* st = static_cast<char*>(x.stage);
+    const size_t tot = (size_t)cnt * 8;
+    const size_t step = std::max<size_t>(((tot / 4) + 4095) & ~(size_t)4095, 1u << 18);
+    int np = 0;
+    for (int arr = 0; arr < 2; ++arr)
+        for (size_t off = 0; off < tot; off += step) { x.dl_off[np] = (size_t)arr * tot + off; x.dl_bytes[np] = std::min(step, tot - off); ++np; }
+    if ((int)x.ev.size() < np) { const size_t old = x.ev.size(); x.ev.resize((size_t)np, nullptr); for (size_t q = old; q < x.ev.size(); ++q) HIPCHK(hipEventCreateWithFlags(&x.ev[q], hipEventDisableTiming)); }
+    for (int q = 0; q < np; ++q) {
+        const size_t off = x.dl_off[q];
+        const char* src = off < tot ? (const char*)x.oi + off : (const char*)x.ov + (off - tot);
+        HIPCHK(hipMemcpyAsync(st + off, src, x.dl_bytes[q], hipMemcpyDeviceToHost, s));
+        HIPCHK(hipEventRecord(x.ev[(size_t)q], s));
+    }
+    x.dl_np = np; x.dl_started = true;
+}
+}  // namespace
+extern "C" {
+
+int32_t dsa_mat_spmv_sparse_begin(dsa_mat_t* h, int32_t transpose, const int64_t* xi, const double* xv, int64_t nx, int64_t* n_out) {
+    API_TRY
+    mat_flush(h);
+    if (!h->has_major) fail(DSA_EMODE, "matrix is in fill mode");
+    if (nx < 0) fail(DSA_EARG, "negative length");
+    dsa_mat::Spx& x = h->spx;
+    x.res_count = -1; x.dl_started = false;
+    static const bool dbg_time = dev_env("DSA_DBG_TIME") != nullptr;
+    const auto tq0 = std::chrono::steady_clock::now();
+    auto tq = [&](const char* what) { if (dbg_time) fprintf(stderr, "  [spmv_sparse_begin] %s at %.1f us\n", what, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tq0).count()); };
+    const int64_t ny = transpose ? h->n : h->m;
+    const int64_t ncols = transpose ? h->m : h->n;
+    bool in_range = nx > 0 && xi[0] >= 1;
+    const bool big_x = nx >= (int64_t)1 << 16;          // (a long x: checked while its pieces are copied to the staging area, below)
+    if (!big_x) { int bad = 0; for (int64_t i = 1; i < nx; ++i) bad |= xi[i] <= xi[i - 1]; if (bad) fail(DSA_EARG, "indices of x must be strictly ascending"); }
+    *n_out = 0;
+    if (ny <= 0 || nx <= 0) { x.res_count = 0; return DSA_OK; }
+    // (column keys below 1 are legal — test/functional/sparsematrix.jl:251 — and only the x-driven kernel can address them)
+    const bool xdriven = spx_xdriven(nx, ncols) || !in_range;
+    Pma& P = xdriven ? (transpose ? h->row : h->col) : (transpose ? h->col : h->row);
+    hipStream_t s = P.stream;
+    const bool direct = xdriven && nx <= SPX_DIRECT_X;
+    spx_ensure(h, ny, direct ? 0 : nx, s);
+    spx_stage(h, (size_t)nx * 16, s);
+    tq("validated, scratch ready");
+    char* st = static_cast<char*>(x.stage);
+    const int64_t* d_xi; const double* d_xv;
+    if (big_x) {
+        // four threads, a quarter of x each: order check, copy into the staging area, and the piece goes on the wire while the
+        // others are still being copied (one pass over the caller's arrays; 117 us check + 230 us copy + 120 us DMA one after the other before)
+        constexpr int NT = 4;
+        std::atomic<int> bad{0}; std::atomic<int> herr{0};
+        const int64_t part = (nx + NT - 1) / NT;
+        auto work = [&](int t) {
+            const int64_t a = (int64_t)t * part, b = std::min<int64_t>(nx, a + part);
+            if (a >= b) return;
+            (void)hipSetDevice(P.device);
+            int bd = 0;
+            for (int64_t i = std::max<int64_t>(a, 1); i < b; ++i) bd |= xi[i] <= xi[i - 1];
+            if (bd) bad.store(1);
+            std::memcpy(st + (size_t)a * 8, xi + a, (size_t)(b - a) * 8);
+            std::memcpy(st + (size_t)(nx + a) * 8, xv + a, (size_t)(b - a) * 8);
+            if (hipMemcpyAsync(x.dx + a, st + (size_t)a * 8, (size_t)(b - a) * 8, hipMemcpyHostToDevice, s) != hipSuccess) herr.store(1);
+            if (hipMemcpyAsync(x.dx + nx + a, st + (size_t)(nx + a) * 8, (size_t)(b - a) * 8, hipMemcpyHostToDevice, s) != hipSuccess) herr.store(1);
+        };
+        std::thread th[NT - 1];
+        for (int t = 1; t < NT; ++t) th[t - 1] = std::thread(work, t);
+        work(0);
+        for (int t = 1; t < NT; ++t) th[t - 1].join();
+        if (bad.load()) { (void)hipStreamSynchronize(s); fail(DSA_EARG, "indices of x must be strictly ascending"); }
+        if (herr.load()) { (void)hipGetLastError(); (void)hipStreamSynchronize(s); fail(DSA_EHIP, "upload of x failed"); }
+        d_xi = x.dx; d_xv = reinterpret_cast<const double*>(x.dx + nx);
+    } else {
+        std::memcpy(st, xi, (size_t)nx * 8);
+        std::memcpy(st + (size_t)nx * 8, xv, (size_t)nx * 8);
+        if (direct) { d_xi = reinterpret_cast<const int64_t*>(st); d_xv = reinterpret_cast<const double*>(st + (size_t)nx * 8); }
+        else {
+            HIPCHK(hipMemcpyAsync(x.dx, st, (size_t)nx * 16, hipMemcpyHostToDevice, s));
+            d_xi = x.dx; d_xv = reinterpret_cast<const double*>(x.dx + nx);
         }
     }
-    tq("scratch ready");
-    char* pin = static_cast<char*>(h->sp_pin);
-    std::memcpy(pin, xi, (size_t)nx * 8);
-    std::memcpy(pin + (size_t)nx * 8, xv, (size_t)nx * 8);
-    HIPCHK(hipMemcpyAsync(d_xi, pin, (size_t)nx * 16, hipMemcpyHostToDevice, s));           // d_xi and d_xv are adjacent
-    hipError_t e;
-    int64_t cnt = 0;
-    if (xdriven) {
-        e = launch_spmv_xdriven(P.K(), P.V(), P.O(), P.capacity(), P.sems, P.col_keys, P.col_live, P.h_ctl->table_len,
-                                d_xi, d_xv, nx, h->d_y, d_t, ny, s);
-        if (e != hipSuccess) fail(DSA_EHIP, std::string("spmv launch: ") + hipGetErrorString(e));
-        e = launch_touched_compact(d_t, nullptr, h->d_y, ny, d_bm, d_oi, d_ov, &h->sp_work, &cnt, s);
-    } else {
-        e = launch_scatter_x(d_xi, d_xv, nx, h->d_x, d_xf, nxd, s);
-        if (e != hipSuccess) fail(DSA_EHIP, std::string("scatter launch: ") + hipGetErrorString(e));
-        spmv_dev(h, transpose, 0, h->d_x, nxd, h->d_y, ny, s);
-        spmv_dev(h, transpose, 0, d_xf, nxd, h->d_y + ny, ny, s, 1);                      // pattern pass: touched rows
-        e = launch_touched_compact(nullptr, h->d_y + ny, h->d_y, ny, d_bm, d_oi, d_ov, &h->sp_work, &cnt, s);
+    const unsigned long long seq = ++x.seq;
+    __atomic_thread_fence(__ATOMIC_RELEASE);
+    tq("x staged");
+    spx_enqueue(h, transpose, xdriven, d_xi, d_xv, nx, ny, ncols, x.oi, x.ov, x.out_cap, x.d_count, x.pin, seq);
+    x.res_stream = s;
+    tq("enqueued");
+    // the count (and a short result) arrive in the landing area: poll, asking the stream now and then (a failed launch cannot hang the host)
+    wait_policy_block(P);
+    volatile long long* seqp = x.pin + 1;
+    auto next_query = std::chrono::steady_clock::now() + std::chrono::milliseconds(2);
+    while ((unsigned long long)__atomic_load_n(seqp, __ATOMIC_ACQUIRE) != seq) {
+        if (std::chrono::steady_clock::now() < next_query) continue;
+        const hipError_t q = hipStreamQuery(s);
+        if (q == hipErrorNotReady) { next_query = std::chrono::steady_clock::now() + std::chrono::milliseconds(2); continue; }
+        if (q != hipSuccess) fail(DSA_EHIP, std::string("sparse-x product: ") + hipGetErrorString(q));
+        if ((unsigned long long)__atomic_load_n(seqp, __ATOMIC_ACQUIRE) != seq) fail(DSA_EHIP, "sparse-x product finished without publishing its result");
     }
-    if (e != hipSuccess) fail(DSA_EHIP, std::string("touched-row compaction: ") + hipGetErrorString(e));
-    tq("product + count back");
-    if (cnt > cap) { HIPCHK(hipStreamSynchronize(s)); fail(DSA_ECAP, "output buffers too small"); }
-    if (cnt > 0) {
-        HIPCHK(hipMemcpyAsync(pin, d_oi, (size_t)cnt * 8, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipMemcpyAsync(pin + (size_t)cnt * 8, d_ov, (size_t)cnt * 8, hipMemcpyDeviceToHost, s));
-    }
-    HIPCHK(hipStreamSynchronize(s));
-    if (cnt > 0) {
-        std::memcpy(yi, pin, (size_t)cnt * 8);
-        std::memcpy(yv, pin + (size_t)cnt * 8, (size_t)cnt * 8);
-    }
+    x.res_count = x.pin[0];
+    *n_out = x.res_count;
+    tq("count back");
+    if (x.res_count > SPX_PIN_CELLS) spx_start_download(h);
+    API_CATCH
+}
+
+int32_t dsa_mat_spmv_sparse_fetch(dsa_mat_t* h, int64_t* yi, double* yv, int64_t cap, int64_t* n_out) {
+    API_TRY
+    dsa_mat::Spx& x = h->spx;
+    if (x.res_count < 0) fail(DSA_EMODE, "no sparse-x product to fetch (dsa_mat_spmv_sparse_begin first)");
+    const int64_t cnt = x.res_count;
     *n_out = cnt;
-    tq("done");
+    if (cnt > cap) fail(DSA_ECAP, "output buffers too small");
+    if (cnt == 0) return DSA_OK;
+    if (cnt <= SPX_PIN_CELLS) {
+        std::memcpy(yi, x.pin + 8, (size_t)cnt * 8);
+        std::memcpy(yv, x.pin + 8 + SPX_PIN_CELLS, (size_t)cnt * 8);
+        return DSA_OK;
+    }
+    // a long result: DMA into pinned staging in pieces, each piece copied to the caller's arrays (by up to four threads) while the
+    // next ones are still on the wire (copies between the device and the caller's PAGEABLE arrays take anything from 3 to 14 ms for
+    // 16 MB depending on the state of the caller's pages; one DMA + one single-threaded copy of the whole result: 1.6 ms)
+    // a freshly allocated result array of several MB is all page faults: ask for huge pages where the system grants them on request
+    // (transparent_hugepage = madvise: 2 MB faults instead of 4 KB ones; advice only, nothing changes for the caller otherwise)
+    if ((size_t)cnt * 8 >= ((size_t)4 << 20))
+        for (void* base : {(void*)yi, (void*)yv}) {
+            const uintptr_t a = ((uintptr_t)base + 4095) & ~(uintptr_t)4095, e = ((uintptr_t)base + (size_t)cnt * 8) & ~(uintptr_t)4095;
+            if (e > a) (void)madvise((void*)a, e - a, MADV_HUGEPAGE);
+        }
+    if (!x.dl_started) spx_start_download(h);          // (normally on the wire since _begin learnt the count)
+    const size_t tot = (size_t)cnt * 8;
+    const int np = x.dl_np;
+    struct Piece { char* pin; char* dst; size_t bytes; };
+    Piece pc[8];
+    for (int q = 0; q < np; ++q) {
+        const size_t off = x.dl_off[q];
+        pc[q] = Piece{static_cast<char*>(x.stage) + off, (off < tot ? (char*)yi + off : (char*)yv + (off - tot)), x.dl_bytes[q]};
+    }
+    static const bool dbg_time = dev_env("DSA_DBG_TIME") != nullptr;
+    const auto tf0 = std::chrono::steady_clock::now();
+    // every piece is copied by all workers (a quarter each) as soon as its event has fired; the workers are started ONCE per fetch
+    // (a thread per piece and quarter cost more than the copies)
+    const int nt = tot >= ((size_t)2 << 20) ? 4 : 1;
+    std::atomic<int> herr{0};
+    const int dev = P_device_of(h);
+    auto work = [&](int t) {
+        if (t > 0) (void)hipSetDevice(dev);
+        for (int q = 0; q < np; ++q) {
+            if (hipEventSynchronize(x.ev[(size_t)q]) != hipSuccess) { herr.store(1); return; }
+            const size_t part = ((pc[q].bytes / nt) + 63) & ~(size_t)63;
+            const size_t off = (size_t)t * part;
+            if (off < pc[q].bytes) std::memcpy(pc[q].dst + off, pc[q].pin + off, std::min(part, pc[q].bytes - off));
+        }
+    };
+    std::thread th[3];
+    for (int t = 1; t < nt; ++t) th[t - 1] = std::thread(work, t);
+    work(0);
+    for (int t = 1; t < nt; ++t) th[t - 1].join();
+    if (herr.load()) { (void)hipGetLastError(); fail(DSA_EHIP, "download of the sparse-x result failed"); }
+    if (dbg_time) fprintf(stderr, "  [spmv_sparse_fetch] %lld pairs in %d pieces, %d threads: %.1f us\n", (long long)cnt, np, nt,
+                          std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tf0).count());
+    API_CATCH
+}
+
+int32_t dsa_mat_spmv_sparse(dsa_mat_t* h, int32_t transpose, const int64_t* xi, const double* xv, int64_t nx,
+                            int64_t* yi, double* yv, int64_t cap, int64_t* n_out) {
+    int64_t cnt = 0;
+    const int32_t rc = dsa_mat_spmv_sparse_begin(h, transpose, xi, xv, nx, &cnt);
+    if (rc != DSA_OK) { *n_out = 0; return rc; }
+    return dsa_mat_spmv_sparse_fetch(h, yi, yv, cap, n_out);          // (DSA_ECAP: *n_out says how much; the result stays fetchable)
+}
+
+int32_t dsa_mat_spmv_sparse_dev(dsa_mat_t* h, int32_t transpose, const int64_t* d_xi, const double* d_xv, int64_t nx,
+                                int64_t* d_yi, double* d_yv, int64_t cap, int64_t* d_count) {
+    API_TRY
+    mat_flush(h);
+    if (!h->has_major) fail(DSA_EMODE, "matrix is in fill mode");
+    if (nx < 0 || cap < 0) fail(DSA_EARG, "negative length");
+    const int64_t ny = transpose ? h->n : h->m;
+    const int64_t ncols = transpose ? h->m : h->n;
+    const bool xdriven = spx_xdriven(nx, ncols);
+    Pma& P = xdriven ? (transpose ? h->row : h->col) : (transpose ? h->col : h->row);
+    if (ny <= 0 || nx <= 0) { HIPCHK(hipMemsetAsync(d_count, 0, sizeof(int64_t), P.stream)); return DSA_OK; }
+    spx_ensure(h, ny, 0, P.stream);
+    h->spx.res_count = -1; h->spx.dl_started = false;
+    h->spx.res_stream = spx_enqueue(h, transpose, xdriven, d_xi, d_xv, nx, ny, ncols, d_yi, d_yv, cap, d_count, nullptr, 0ull);
     API_CATCH
 }
 

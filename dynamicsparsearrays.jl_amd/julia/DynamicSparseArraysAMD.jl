@@ -23,7 +23,7 @@ using SparseArrays
 export DynamicSparseVector, DynamicSparseMatrix, DynamicMatrixColView, PackedCSC, dynamicsparsevec, dynamicsparse, nbpartitions,
        deletecolumn!, deleterow!, deletepartition!, addrow!, closefillmode!, shrink_size!, set_device!, shard_range, dynamicsparse_shard, comm_unique_id, ShardComm, shard_allreduce!,
        shard_spmv_allreduce!, set_wait_policy!, WAIT_SPIN, WAIT_BLOCK, pool_idle_bytes, pool_trim!,
-       keyint, keyfrom, col_view_dev!, row_view_dev!
+       keyint, keyfrom, col_view_dev!, row_view_dev!, spmv_sparse_dev!
 
 const libdsa = get(ENV, "DSA_HIP_LIB", joinpath(@__DIR__, "..", "csrc", "libdsa_hip.so"))
 
@@ -460,17 +460,24 @@ Base.size(t::Transposed) = reverse(size(t.array))
 # y = A x for a sparse x given by its stored entries: the touched rows in ascending order (_mul_output, src/operations.jl:11-12);
 # Integer output keys -> sparsevec, any other key type -> Dict (the reference returns its accumulator Dict there)
 function _spmv_sparse(a::DynamicSparseMatrix, tr::Bool, xi::Vector{Int64}, xv::Vector{Float64}, out_keys::KeyMap{KO}, n::Int64) where {KO}
-    cap = 1024
-    while true
-        yi = Vector{Int64}(undef, cap); yv = Vector{Float64}(undef, cap); k = Ref{Int64}(0)
-        rc = GC.@preserve xi xv yi yv ccall((:dsa_mat_spmv_sparse, libdsa), Int32,
-            (Ptr{Cvoid}, Int32, Ptr{Int64}, Ptr{Float64}, Int64, Ptr{Int64}, Ptr{Float64}, Int64, Ref{Int64}),
-            a.h, tr ? 1 : 0, xi, xv, length(xi), yi, yv, cap, k)
-        rc == 8 && (cap *= 16; continue)
-        _check(rc)
-        resize!(yi, k[]); resize!(yv, k[])
-        return KO <: Integer ? sparsevec(KO.(yi), yv, n) : Dict{KO,Float64}(_out(out_keys, yi[j]) => yv[j] for j in eachindex(yi))
+    # two ccalls: the product (result left with the handle), then the copy-out into vectors of exactly the result's size
+    k = Ref{Int64}(0)
+    _check(GC.@preserve xi xv ccall((:dsa_mat_spmv_sparse_begin, libdsa), Int32,
+        (Ptr{Cvoid}, Int32, Ptr{Int64}, Ptr{Float64}, Int64, Ref{Int64}), a.h, tr ? 1 : 0, xi, xv, length(xi), k))
+    yi = Vector{Int64}(undef, k[]); yv = Vector{Float64}(undef, k[])
+    if k[] > 0
+        _check(GC.@preserve yi yv ccall((:dsa_mat_spmv_sparse_fetch, libdsa), Int32,
+            (Ptr{Cvoid}, Ptr{Int64}, Ptr{Float64}, Int64, Ref{Int64}), a.h, yi, yv, k[], k))
     end
+    return KO <: Integer ? sparsevec(KO.(yi), yv, n) : Dict{KO,Float64}(_out(out_keys, yi[j]) => yv[j] for j in eachindex(yi))
+end
+"the sparse product with every operand in HBM (device pointers; mapped key integers): xi / xv in, the touched rows yi / yv and their count
+out, stream-ordered, no host wait — dsa_mat_spmv_sparse_dev"
+function spmv_sparse_dev!(a::DynamicSparseMatrix, tr::Bool, d_xi::Ptr{Cvoid}, d_xv::Ptr{Cvoid}, nx::Integer, d_yi::Ptr{Cvoid}, d_yv::Ptr{Cvoid},
+                          cap::Integer, d_count::Ptr{Cvoid})
+    _check(ccall((:dsa_mat_spmv_sparse_dev, libdsa), Int32, (Ptr{Cvoid}, Int32, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}),
+                 a.h, tr ? 1 : 0, d_xi, d_xv, nx, d_yi, d_yv, cap, d_count))
+    return a
 end
 _entries(km::KeyMap, v::DynamicSparseVector) = _stored_int(v)
 _entries(km::KeyMap, v::SparseVector) = (_in(km, rowvals(v)), Vector{Float64}(nonzeros(v)))

@@ -204,6 +204,19 @@ int32_t dsa_mat_spmv_dense(dsa_mat_t* h, int32_t transpose, const double* x, int
  * stored zeros kept: the shape of _mul_output(result, n)  src/operations.jl:11-12 */
 int32_t dsa_mat_spmv_sparse(dsa_mat_t* h, int32_t transpose, const int64_t* xi, const double* xv,
                             int64_t nx, int64_t* yi, double* yv, int64_t cap, int64_t* n_out);
+/* The same product in two steps, so that the caller allocates exactly what the result needs: _begin computes (result left with the
+ * handle: packed in HBM, short ones also in pinned memory) and returns the number of touched rows, _fetch copies the pairs out
+ * (DSA_ECAP when cap is too small: the result stays fetchable).  dsa_mat_spmv_sparse == _begin + _fetch.  One result per handle: the
+ * next _begin / dsa_mat_spmv_sparse* call replaces it. */
+int32_t dsa_mat_spmv_sparse_begin(dsa_mat_t* h, int32_t transpose, const int64_t* xi, const double* xv, int64_t nx, int64_t* n_out);
+int32_t dsa_mat_spmv_sparse_fetch(dsa_mat_t* h, int64_t* yi, double* yv, int64_t cap, int64_t* n_out);
+/* The sparse product with every operand in HBM, stream-ordered, no host wait: d_xi / d_xv = the nx stored entries of x (ascending
+ * indices; not checked), d_yi / d_yv = cap entries for the touched rows (ascending), *d_count (device) = their number — pairs beyond
+ * cap are dropped, the count still says how many there are (cap = size(m, 1 | 2) always suffices).  Enqueued on the stream of the
+ * orientation that is walked (dsa_mat_set_stream / dsa_mat_sync).  With many stored entries (8 nx >= number of columns: gather over the
+ * twin orientation) entries of x outside 1..n are ignored — column keys below 1 need the host entry point or fewer entries. */
+int32_t dsa_mat_spmv_sparse_dev(dsa_mat_t* h, int32_t transpose, const int64_t* d_xi, const double* d_xv, int64_t nx,
+                                int64_t* d_yi, double* d_yv, int64_t cap, int64_t* d_count);
 /* same as dsa_mat_spmv_dense with x, y resident in HBM; asynchronous on the handle's stream.
  * algo: 0 = gather over the twin orientation (default), 1 = scatter over the reference's own
  * orientation with fp64 atomics (the literal _mul loop nest) */

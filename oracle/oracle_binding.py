@@ -15,7 +15,8 @@ _DEVICE_ONLY = ("device_count", "set_device", "mat_spmv_dense_dev", "shard_range
                 "vec_check", "mat_check", "mat_set_stream", "vec_set_stream", "mat_sync", "vec_sync", "vec_dev_relayout",
                 "vec_set_wait_policy", "mat_set_wait_policy", "pool_idle_bytes", "pool_trim", "dev_switches",
                 "dbg_raw_find", "dbg_raw_insert", "dbg_raw_delete", "dbg_raw_purge", "dbg_raw_rebalance", "shard_allreduce_dev",
-                "shard_spmv_allreduce_dev", "mat_col_view_dev", "mat_row_view_dev")
+                "shard_spmv_allreduce_dev", "mat_col_view_dev", "mat_row_view_dev", "mat_spmv_sparse_begin", "mat_spmv_sparse_fetch",
+                "mat_spmv_sparse_dev")
 
 
 def build():

@@ -763,6 +763,83 @@ def test_state_after_a_failed_batch_is_the_references(dsa, hip, oracle, pad):
 
 
 # ---------------------------------------------------------------- SpMV
+@pytest.mark.parametrize("force", [None, "0", "1"])
+def test_sparse_x_product_two_step_and_device_entry_points(dsa, hip, oracle, force):
+    """the product Coluna calls (_mul + _mul_output, src/operations.jl:11-12,107-135).  dsa_mat_spmv_sparse_begin / _fetch (one
+    product whatever the result size) and dsa_mat_spmv_sparse_dev (xi / xv in, yi / yv / count out, all HBM) against the oracle's Dict
+    accumulator: touched rows identical — stored zeros of x and cancelling sums kept —, values within 1e-12; both strategies (driven by
+    x's entries / gather over the twin + pattern pass, forced through the development switch in child processes), both transposes, results
+    above and below the pinned landing area, repeated products on the same handle (the zero invariant of the accumulator), a negative
+    column key, tombstones."""
+    if force is not None:
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        env = dict(os.environ, DSA_DEV="1", DSA_SPX_XDRIVEN=force)
+        r = _run_child([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_hip_parity.py"), "-m", "gpu", "-x", "-q", "-k",
+                        "two_step_and_device_entry_points and None"], env)
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+        return
+    import torch
+    m, n, per = 30000, 20000, 6
+    rows = 1 + (splitmix_array(11, n * per) % np.uint64(m)).astype(np.int64)
+    cols = np.repeat(np.arange(1, n + 1, dtype=np.int64), per)
+    vals = (1 + splitmix_array(12, n * per) % np.uint64(9)).astype(np.float64)
+    vals[::7] *= -1.0                                              # cancelling sums: a touched row may sum to exactly 0
+    a = dsa.dynamicsparse(rows, cols, vals, m, n, binding=hip)
+    b = dsa.dynamicsparse(rows, cols, vals, m, n, binding=oracle)
+    for mm in (a, b):
+        mm.deletecolumn(17); mm.deleterow(23)                      # tombstones in both tables
+    dev = torch.device("cuda")
+    d_yi = torch.empty(max(m, n), dtype=torch.int64, device=dev); d_yv = torch.empty(max(m, n), dtype=torch.float64, device=dev)
+    d_cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+    for rep in range(2):
+        for cnt in (1, 40, 700, 2600, 9000, n):
+            xi = np.unique(1 + (splitmix_array(100 + cnt + rep, cnt) % np.uint64(n)).astype(np.int64))
+            xv = unit12_array(7 + rep, len(xi))
+            xv[::5] = 0.0                                          # stored zeros of x still touch their rows (src/operations.jl:101)
+            for tr in (False, True):
+                xi3 = xi if not tr else xi[xi <= m]
+                xv3 = xv[: len(xi3)]
+                ib, vb = b.mul((xi3, xv3), transpose=tr)
+                ia, va = a.mul((xi3, xv3), transpose=tr)           # _begin + _fetch
+                assert np.array_equal(ia, ib), (cnt, tr, len(ia), len(ib))
+                np.testing.assert_allclose(va, vb, rtol=RTOL, atol=1e-13)
+                d_xi = torch.from_numpy(xi3).to(dev); d_xv = torch.from_numpy(xv3).to(dev)
+                a.mul_dev(d_xi.data_ptr(), d_xv.data_ptr(), len(xi3), d_yi.data_ptr(), d_yv.data_ptr(), d_yi.numel(), d_cnt.data_ptr(), transpose=tr)
+                a.sync()
+                k = int(d_cnt.item())
+                assert k == len(ib)
+                assert np.array_equal(d_yi[:k].cpu().numpy(), ib)
+                np.testing.assert_allclose(d_yv[:k].cpu().numpy(), vb, rtol=RTOL, atol=1e-13)
+                # a result buffer that is too small: the count still says how much, the pairs that fit are the first ones
+                if k > 10:
+                    a.mul_dev(d_xi.data_ptr(), d_xv.data_ptr(), len(xi3), d_yi.data_ptr(), d_yv.data_ptr(), 10, d_cnt.data_ptr(), transpose=tr)
+                    a.sync()
+                    assert int(d_cnt.item()) == k and np.array_equal(d_yi[:10].cpu().numpy(), ib[:10])
+    # a column key below 1 (test/functional/sparsematrix.jl:251): only the kernel driven by x's entries can address it — also when
+    # nearly every column is stored
+    a2 = dsa.dynamicsparse(rows[:6000], cols[:6000], vals[:6000], m, n, binding=hip)
+    b2 = dsa.dynamicsparse(rows[:6000], cols[:6000], vals[:6000], m, n, binding=oracle)
+    for mm in (a2, b2):
+        mm[5, -3] = 2.0
+    for xi in ([-3, 5], np.concatenate([[-3], np.arange(1, n + 1, dtype=np.int64)])):
+        xv = unit12_array(3, len(xi))
+        ia, va = a2.mul((xi, xv)); ib, vb = b2.mul((xi, xv))
+        assert np.array_equal(ia, ib) and np.allclose(va, vb, rtol=RTOL, atol=1e-13)
+    # the one-shot entry point with a buffer that is too small reports DSA_ECAP and the size; the result stays fetchable
+    import ctypes as C
+    xi = np.arange(1, 2001, dtype=np.int64); xv = np.ones(2000)
+    yi = np.empty(4, dtype=np.int64); yv = np.empty(4); k = C.c_int64()
+    P_I64, P_F64 = C.POINTER(C.c_int64), C.POINTER(C.c_double)
+    with pytest.raises(dsa.DsaError) as ei:
+        hip.call("mat_spmv_sparse", a.h, 0, xi.ctypes.data_as(P_I64), xv.ctypes.data_as(P_F64), 2000, yi.ctypes.data_as(P_I64), yv.ctypes.data_as(P_F64), 4, C.byref(k))
+    assert ei.value.code == dsa.binding.ECAP and k.value > 4
+    yi = np.empty(k.value, dtype=np.int64); yv = np.empty(k.value)
+    hip.call("mat_spmv_sparse_fetch", a.h, yi.ctypes.data_as(P_I64), yv.ctypes.data_as(P_F64), k.value, C.byref(k))
+    ib, vb = b.mul((xi, xv))
+    assert np.array_equal(yi, ib) and np.allclose(yv, vb, rtol=RTOL, atol=1e-13)
+    assert_mat_equal(a, b)
+
+
 @pytest.mark.parametrize("m,n,per_col,seed", [(50, 40, 3, 1), (3000, 2500, 7, 2), (100000, 80000, 10, 3), (64, 100000, 2, 4)])
 def test_spmv_matches_oracle(dsa, hip, oracle, m, n, per_col, seed):
     rows = 1 + (splitmix_array(seed, n * per_col) % np.uint64(m)).astype(np.int64)
