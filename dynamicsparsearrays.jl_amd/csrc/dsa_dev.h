@@ -414,7 +414,20 @@ struct RoundState {
     int64_t why[8];        // dev: what cut the prefixes (index = Plan::count of the first BARRIER op; 7 = a conflict)
     int32_t tight;         // tight footprints (parbatch.hip): bit 0 leaf-accepted inserts / deletes, bit 1 leaf-accepted new columns (dev knob DSA_TIGHT, default 3)
     int32_t seq;           // number of the burst (set by the host): k_publish hands it back with the state
+    // ---- run-ahead (round 6): a round applies every op of its window that conflicts with no EARLIER op and lies outside the sealed zones
+    // of the deferred ones, not only the prefix in front of the first conflict.  The window of a round is the PENDING list (ops deferred
+    // by earlier rounds, ascending op index, DevBufs::pend[cur]) followed by fresh ops from `cursor`.  (cursor, np, cur) describe the round
+    // whose k_apply runs; (cursor_n, np_n, cur_n) the next one (written by the resolve step, committed by the next round's).
+    int64_t cursor_n;      // first fresh op of the next round
+    int64_t pend0;         // op index of position 0 of the next window (what the sequencer takes when that op cannot be planned)
+    int32_t np, np_n;      // pending ops in front of the window: of the round in flight / of the next one
+    int32_t cur, cur_n;    // which half of DevBufs::pend holds that list
+    int32_t run_ahead;     // 0: prefix rule (the host: batches whose ops can fail, A/B)   1: run-ahead
+    int32_t drain;         // 1: the window is the pending list alone (the host is about to hand over to the sequencer / the local rounds)
+    int64_t deferred;      // instrumentation: ops deferred behind a conflict inside the applied range (sum over the rounds)
 };
+// a pending op and the zone it may still touch (the intersection of the sealed zones it was deferred with; lo = 0: no constraint)
+struct PendOp { int64_t op; int32_t zlo, zhi; };
 // where a burst leaves its result for the host: the pinned mirrors of the round state and of the control block, and the word the
 // host polls (the burst number) — written by k_publish, the last kernel of a burst, with system-scope stores: no copy commands, no
 // stream synchronisation on the host side (nullptr: the host copies and synchronises itself)
@@ -433,7 +446,7 @@ struct BurstGraph {        // cached hipGraph of one burst of rounds (host-side)
 // the arrays the rounds work on, read by the kernels from device memory: a root rebalance swaps the slot buffers and the tables
 // grow, but the launch arguments — and with them the cached graph — stay the same (re-instantiating the graphs after every
 // _extend! cost ~1 ms a time while an array was growing)
-struct DevBufs { void* keys; double* vals; uint64_t* occ; int64_t* sems; int64_t* col_keys; uint8_t* col_live; int32_t wide, pad; };
+struct DevBufs { void* keys; double* vals; uint64_t* occ; int64_t* sems; int64_t* col_keys; uint8_t* col_live; int32_t wide, pad; PendOp* pend; /* 2 x ROUND_GMAX */ };
 hipError_t launch_burst(const DevBufs* bufs, Ctl* ctl, const Op* ops, RoundState* rs, Plan* plans, int rounds, BurstGraph* cache,
                         BurstPublish pub, hipStream_t stream);
 void burst_graph_destroy(BurstGraph* cache);

@@ -108,6 +108,7 @@ static const char* const k_dev_switches[] = {
     "DSA_PARBATCH",       // 0: no batch-parallel rounds
     "DSA_POS_WIDE",       // 1: 64-bit positions in the append replay
     "DSA_PUBLISH",        // 0: device-to-host copies + stream synchronisation instead of the pinned hand-overs
+    "DSA_RUN_AHEAD",      // 0: the rounds apply the conflict-free PREFIX only (rounds 2-5)
     "DSA_SEQ_CHUNK",      // n: first sequencer chunk after a stop by short prefixes
     "DSA_SMALL_BUILD",    // 0: small vectors through the general builder
     "DSA_SMALL_ROUNDS",   // 0: small matrix batches on two sequencers
@@ -175,8 +176,10 @@ struct Pma {
     double* d_q = nullptr; int64_t q_cap = 0;      // scratch for lookups (3 arrays of q_cap)
     int32_t* d_err = nullptr;
     int64_t stat_par_rounds = 0, stat_par_ops = 0, stat_seq_ops = 0, stat_seq_launches = 0;      // batch-parallel instrumentation
+    int64_t stat_deferred = 0;              // ops a run-ahead round deferred behind a conflict (each is planned again in a later round)
     BurstGraph burst, burst_short;      // cached graphs of a full burst of rounds and of a short one (conflict-heavy phases)
     Plan* d_plans = nullptr; RoundState* d_rs = nullptr; RoundState* h_rs = nullptr;   // batch-parallel writes
+    PendOp* d_pend = nullptr;                   // the pending lists of the rounds (2 x ROUND_GMAX: ops deferred behind a conflict, parbatch.hip)
     unsigned long long* h_pub = nullptr; unsigned int pub_seq = 0;      // pinned word k_publish writes the burst number to, and the last number handed out
     DevBufs* d_bufs = nullptr; DevBufs* h_bufs = nullptr;      // the arrays the rounds work on, read from device memory (pinned mirror)
     TableMerge tmerge{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; int64_t tmerge_cap = 0;   // scratch of the grid-wide table merge (tables.hip)
@@ -232,6 +235,7 @@ void pma_destroy(Pma& P) {
     burst_graph_destroy(&P.burst);
     burst_graph_destroy(&P.burst_short);
     if (P.d_plans) hipFree(P.d_plans);
+    if (P.d_pend) hipFree(P.d_pend);
     if (P.d_bufs) hipFree(P.d_bufs);
     if (P.h_bufs) hipHostFree(P.h_bufs);
     if (P.d_rs) hipFree(P.d_rs);
@@ -879,7 +883,7 @@ int64_t run_ops(Pma& P, const std::vector<Op>& ops, int32_t* err) {
 // Batch-parallel execution of vector writes (parbatch.hip): rounds of plan / resolve / apply for the prefix of ops whose
 // footprints are pairwise disjoint; the op that cuts a short prefix (and a growing chunk after it while prefixes stay
 // short: ascending appends, hammering one key) goes through the sequential sequencer.  Same final state as run_ops.
-int64_t run_ops_parallel(Pma& P, const OpBatch& ops, int32_t* err) {
+int64_t run_ops_parallel(Pma& P, const OpBatch& ops, int32_t* err, bool can_fail = false) {
     *err = 0;
     const int64_t n = ops.n;
     if (n == 0) return 0;
@@ -902,6 +906,8 @@ int64_t run_ops_parallel(Pma& P, const OpBatch& ops, int32_t* err) {
 #else
         HIPCHK(hipMalloc(&P.d_plans, (size_t)GMAX * sizeof(Plan)));
 #endif
+        HIPCHK(hipMalloc(&P.d_pend, (size_t)2 * GMAX * sizeof(PendOp)));
+        HIPCHK(hipMemsetAsync(P.d_pend, 0, (size_t)2 * GMAX * sizeof(PendOp), P.stream));
         HIPCHK(hipMalloc(&P.d_bufs, sizeof(DevBufs)));
         HIPCHK(hipHostMalloc(&P.h_bufs, sizeof(DevBufs), hipHostMallocDefault));
         std::memset(P.h_bufs, 0, sizeof(DevBufs));
@@ -913,6 +919,14 @@ int64_t run_ops_parallel(Pma& P, const OpBatch& ops, int32_t* err) {
     static const int64_t SEQ_CHUNK0 = [] { const char* e = dev_env("DSA_SEQ_CHUNK"); return e ? (int64_t)atoi(e) : (int64_t)8; }();
     static const int64_t BARRIER_CHUNK0 = [] { const char* e = dev_env("DSA_BARRIER_CHUNK"); return e ? (int64_t)atoi(e) : (int64_t)1; }();
     int64_t i = 0, seq_chunk = SEQ_CHUNK0;
+    // run-ahead (parbatch.hip): a round applies every op that conflicts with no earlier one, the deferred ones wait in a pending list in
+    // front of the fresh ops.  Only where no op can fail (a failing op must find exactly the ops in front of it applied): no tombstones,
+    // not the cut batches of the tombstone path.  DSA_RUN_AHEAD=0: the prefix rule of rounds 2-5 (A/B).
+    static const bool run_ahead_on = [] { const char* e = dev_env("DSA_RUN_AHEAD"); return !(e && e[0] == '0'); }();
+    const bool run_ahead = run_ahead_on && !can_fail && (!P.has_cols || P.h_ctl->nb_partitions == P.h_ctl->table_len);
+    int np = 0, cur = 0;                    // pending ops of the rounds and which half of d_pend holds them
+    bool drain = false;                     // the next bursts work on the pending list alone ...
+    int after_drain = 0;                    // ... and then: 1 switch to the local rounds, 2 the sequencer takes the chunk at the cursor
     int G = 256;
     int ema = 16 * 16;                      // RoundState::ema, carried across the bursts of the batch
     // local rounds (parbatch.hip: k_local_rounds) while the prefixes are short; a small array starts with them
@@ -943,14 +957,16 @@ int64_t run_ops_parallel(Pma& P, const OpBatch& ops, int32_t* err) {
             }
         }
     }
-    while (i < n) {
+    while (i < n || np > 0) {
         const auto tb0 = now();
+        bool to_sequencer = seq_first;
         if (!seq_first) {
         // ---- a burst of rounds driven by the device-resident cursor; one host synchronisation per burst
         RoundState& rs = *P.h_rs;
         std::memset(&rs, 0, sizeof(rs));
         static const int tight = [] { const char* e = dev_env("DSA_TIGHT"); return e ? atoi(e) : 3; }();
         rs.cursor = i; rs.limit = n; rs.G = G; rs.min_prefix = MIN_PREFIX; rs.ema = ema; rs.tight = tight;
+        rs.cursor_n = i; rs.np = rs.np_n = np; rs.cur = rs.cur_n = cur; rs.run_ahead = run_ahead ? 1 : 0; rs.drain = drain ? 1 : 0; rs.pend0 = i;
 #ifdef DSA_FP_CHECK
         {   // the footprint-check build: DSA_FP_MODE = 1 recorded read / touch sets (default), 2 sequential shadow re-plan, 0 neither
             static const int fp_mode = [] { const char* e = dev_env("DSA_FP_MODE"); return e ? atoi(e) : 1; }();
@@ -967,7 +983,7 @@ int64_t run_ops_parallel(Pma& P, const OpBatch& ops, int32_t* err) {
             ++P.layout_epoch;
             // (every burst is followed by a stream wait, so the pinned mirror is never rewritten under a copy in flight)
             const DevBufs bufs_now{P.K().p, P.V(), P.O(), P.has_sems ? P.sems : nullptr, P.has_cols ? P.col_keys : nullptr,
-                                   P.has_cols ? P.col_live : nullptr, P.wide ? 1 : 0, 0};
+                                   P.has_cols ? P.col_live : nullptr, P.wide ? 1 : 0, 0, P.d_pend};
             if (std::memcmp(&bufs_now, P.h_bufs, sizeof(DevBufs)) != 0) {
                 *P.h_bufs = bufs_now;
                 HIPCHK(hipMemcpyAsync(P.d_bufs, P.h_bufs, sizeof(DevBufs), hipMemcpyHostToDevice, P.stream));
@@ -989,28 +1005,61 @@ int64_t run_ops_parallel(Pma& P, const OpBatch& ops, int32_t* err) {
         if (use_local) { t_local += ms(tb0, now()); ++n_local; r_local += rs.rounds; o_local += rs.par_ops; }
         // the prefix of the last round of the burst has been applied but is folded into the cursor only by the next round's resolve step
         if (rs.pad >= 10) fail(DSA_EASSERT, "DSA_FP_CHECK: a round of the batch-parallel writes is not equivalent to the sequential order (code " + std::to_string(rs.pad) + ", details on stdout)");
+        if (rs.pad == 9) fail(DSA_EASSERT, "batch-parallel writes: a deferred op left the zone it was sealed in (internal invariant of the run-ahead rounds)");
         if (rs.pad != 0) fail(DSA_EASSERT, "batch-parallel column creation left its footprint (internal invariant)");
         static const bool dbg_burst = dev_env("DSA_DBG_BURST") != nullptr;
         if (dbg_burst)
             fprintf(stderr, "    burst%s: rounds %lld ops %lld (+ last prefix %d) stop %d G %d ema %.1f pending %lld table %lld/%lld cap %lld\n", use_local ? " (local)" : "",
                     (long long)rs.rounds, (long long)rs.par_ops, rs.d, rs.stop, rs.G, rs.ema / 16.0, (long long)P.h_ctl->n_pending,
                     (long long)P.h_ctl->table_len, (long long)P.h_ctl->table_cap, (long long)P.h_ctl->capacity);
-        const int64_t reached = rs.cursor + rs.d;
         // what the sequencer takes after a stop: the op that cannot be planned alone when the rounds were otherwise making progress
         // (the ops behind it are cheaper in a round: ~1 us each against 5-15 us), a chunk of SEQ_CHUNK0 ops when short prefixes
         // stopped them (the ops around the cursor collide); doubled while the rounds apply fewer than two ops each
-        if (reached - i >= 2 * std::max<int64_t>(1, rs.rounds)) seq_chunk = rs.why[7] > 0 ? SEQ_CHUNK0 : BARRIER_CHUNK0;
+        if (rs.par_ops >= 2 * std::max<int64_t>(1, rs.rounds)) seq_chunk = rs.why[7] > 0 ? SEQ_CHUNK0 : BARRIER_CHUNK0;
         // new partitions of the rounds sit at the end of the tables: back into key order with the whole chip once enough have piled up
         if (P.h_ctl->n_pending >= MERGE_AT) merge_tables(P);
-        P.stat_par_rounds += rs.rounds + (rs.d > 0 ? 1 : 0); P.stat_par_ops += rs.par_ops + rs.d;
+        P.stat_par_rounds += rs.rounds; P.stat_par_ops += rs.par_ops; P.stat_deferred += rs.deferred;
         for (int q = 0; q < 8; ++q) P.stat_why[q] += rs.why[q];
-        i = reached;
+        i = rs.cursor_n; np = rs.np_n; cur = rs.cur_n;
         G = rs.G; ema = rs.ema;
         burst_rounds = (rs.stop == 1 && rs.rounds <= ROUNDS_SHORT) ? ROUNDS_SHORT : ROUNDS_PER_SYNC;
-        if (use_local) { if (rs.stop == 3) { use_local = false; ema = 16 * 64; G = 64; } }   // full prefixes: the grid rounds pay again
-        else if (local_ok && rs.rounds > 0 && ema < 16 * LOCAL_BELOW) use_local = true;  // prefixes of a few ops: one workgroup is enough
-        if (rs.stop != 1) continue;                       // burst used up (0), batch finished (2), or a switch of round kind (3)
+        if (rs.stop == 5 || (drain && np == 0)) {          // the pending list is drained: what it was drained for
+            drain = false;
+            const int what = after_drain; after_drain = 0;
+            if (what == 1) { use_local = true; continue; }
+            if (what != 2) continue;
+            to_sequencer = true;
+        } else if (rs.stop == 1 && np > 0) {
+            // the op at the head of the pending list cannot be planned (it needs the sequencer: a wide window, _extend!): everything in
+            // front of it has been applied, so the sequencer takes exactly that op; then it leaves the list
+            const int64_t op0 = rs.pend0;
+            SeqRun r;
+            r.P = &P; r.n = op0 + 1; r.n_avail = op0 + 1; r.active = true; r.defer_merge = true;
+            P.h_ctl->next_op = op0; P.h_ctl->status = 0; P.h_ctl->err = 0; P.h_ctl->no_run_at = op0;       // (no append run from a pending op: the ops behind it are not its successors)
+            seq_launch(r);
+            while (seq_step(r)) ++n_yield;
+            ++n_seq;
+            if (r.err) fail(DSA_EASSERT, "batch-parallel writes: a deferred op failed in the sequencer (no op of a run-ahead batch can fail)");
+            P.stat_seq_ops += 1; P.stat_seq_launches += 1;
+            std::vector<PendOp> lst((size_t)np);
+            HIPCHK(hipMemcpyAsync(lst.data(), P.d_pend + (size_t)cur * GMAX, (size_t)np * sizeof(PendOp), hipMemcpyDeviceToHost, P.stream));
+            HIPCHK(hipStreamSynchronize(P.stream));
+            if (lst[0].op != op0) fail(DSA_EASSERT, "batch-parallel writes: pending list out of step with the round state");
+            --np;
+            if (np > 0) { HIPCHK(hipMemcpyAsync(P.d_pend + (size_t)cur * GMAX, lst.data() + 1, (size_t)np * sizeof(PendOp), hipMemcpyHostToDevice, P.stream)); HIPCHK(hipStreamSynchronize(P.stream)); }
+            continue;
+        } else {
+            bool want_local = false;
+            if (use_local) { if (rs.stop == 3) { use_local = false; ema = 16 * 64; G = 64; } }   // full prefixes: the grid rounds pay again
+            else if (local_ok && rs.rounds > 0 && ema < 16 * LOCAL_BELOW) want_local = true;     // prefixes of a few ops: one workgroup is enough
+            // (the local rounds and the sequencer work on the contiguous rest of the batch: the pending list is drained first)
+            if (want_local) { if (np > 0) { drain = true; after_drain = 1; continue; } use_local = true; }
+            if (rs.stop != 1) continue;                       // burst used up (0), batch finished (2), or a switch of round kind (3)
+            to_sequencer = true;
         }
+        }
+        if (!to_sequencer) continue;
+        if (np > 0) { drain = true; after_drain = 2; continue; }
         seq_first = false;
         // ---- short prefix at op i: sequential sequencer for ops [i, i + seq_chunk)
         const auto ts0 = now();
@@ -1816,12 +1865,12 @@ void mat_apply_sets(dsa_mat* h, const int64_t* I, const int64_t* J, const double
         const int64_t end = std::min(n, f + 1);
         std::vector<Op> pc(oc.begin() + pos, oc.begin() + end), pr(orw.begin() + pos, orw.begin() + end);
         int32_t err = 0;
-        const int64_t done = (par_seq ? run_ops_parallel(h->col, pc, &err) : run_ops(h->col, pc, &err)) + pos;
+        const int64_t done = (par_seq ? run_ops_parallel(h->col, pc, &err, true) : run_ops(h->col, pc, &err)) + pos;
         if (err) {
             // colmajor refused write `done` (<= f): rowmajor gets the writes in front of it — none of which its table refuses
             pr.resize((size_t)(done - pos));
             int32_t e2 = 0;
-            const int64_t d2 = (par_seq ? run_ops_parallel(h->row, pr, &e2) : run_ops(h->row, pr, &e2)) + pos;
+            const int64_t d2 = (par_seq ? run_ops_parallel(h->row, pr, &e2, true) : run_ops(h->row, pr, &e2)) + pos;
             // Which write fails FIRST in the reference's order (colmajor then rowmajor of write 0, of write 1, ...): the rowmajor half of an
             // earlier write d2 < done comes before the colmajor half of write `done`.  (Rounds 1-4 reported the colmajor error regardless:
             // tools/fuzz.py run_tombstones seed 503707, EBOUNDS where the reference throws the AssertionError of src/pcsr.jl:132 three writes earlier.)
@@ -1832,7 +1881,7 @@ void mat_apply_sets(dsa_mat* h, const int64_t* I, const int64_t* J, const double
             fail(err, err_text(err));
         }
         int32_t e2 = 0;
-        const int64_t d2 = (par_seq ? run_ops_parallel(h->row, pr, &e2) : run_ops(h->row, pr, &e2)) + pos;
+        const int64_t d2 = (par_seq ? run_ops_parallel(h->row, pr, &e2, true) : run_ops(h->row, pr, &e2)) + pos;
         if (e2) {
             for (int64_t k = 0; k <= d2 && k < n; ++k) if (V[k] != 0.0) { h->m = std::max(h->m, I[k]); h->n = std::max(h->n, J[k]); }
             fail(e2, err_text(e2));

@@ -29,7 +29,8 @@ constexpr int PB_MAX_W_LOG2 = 11;
 constexpr int PB_MAX_W = 1 << PB_MAX_W_LOG2;  // largest window a single wave rebalances (32 KB of LDS per wave, 128 KB per workgroup)
 constexpr int PB_GMAX = ROUND_GMAX;           // ops planned per round at most (one wave each)
 
-enum : int32_t { PB_NOOP = 0, PB_OVERWRITE = 1, PB_INS_R = 2, PB_INS_L = 3, PB_DELETE = 4, PB_BARRIER = 5, PB_NEWCOL = 6 };
+enum : int32_t { PB_NOOP = 0, PB_OVERWRITE = 1, PB_INS_R = 2, PB_INS_L = 3, PB_DELETE = 4, PB_BARRIER = 5, PB_NEWCOL = 6,
+                 PB_DEFER = 7 /* written by the resolve step over the action of an op it defers: k_apply skips it */ };
 constexpr int64_t PB_PEND_MAX = TABLE_PEND_MAX;  // the sequencer imports, tables.hip merges the pending table entries
 
 // ---- footprint-check build (-DDSA_FP_CHECK; make libdsa_hip_fpcheck.so) -------------------------------------------------------------
@@ -332,14 +333,25 @@ __global__ __launch_bounds__(PL_BLOCK) void k_plan(const DevBufs* bufs, const Ct
     const int64_t cap0 = ctl->capacity, seg0 = ctl->segment_capacity, lo00 = ctl->lo[0], hi00 = ctl->hi[0];
     // (the fields of the round state the resolve step folds at its very end: read now, scalar loads, instead of as dependent round trips of one
     // thread behind the last barrier — nobody writes them while this kernel runs)
-    const int d_prev = rs->d, ema_prev = rs->ema, min_prefix = rs->min_prefix;
-    const int64_t rounds_prev = rs->rounds, par_ops_prev = rs->par_ops;
-    const int64_t i0 = rs->cursor + d_prev;           // the resolve step of this round folds the previous prefix into the cursor
-    const int64_t left = rs->limit - i0;
-    const int G = (int)(left < rs->G ? left : rs->G);
+    const int ema_prev = rs->ema, min_prefix = rs->min_prefix;
+    const int64_t rounds_prev = rs->rounds, par_ops_prev = rs->par_ops, deferred_prev = rs->deferred;
+    // the window of this round (written by the previous round's resolve step, committed by this one's): the pending ops — deferred by
+    // earlier rounds, ascending op index — followed by fresh ops
+    const int64_t i0 = rs->cursor_n;
+    const int np = rs->np_n, cur = rs->cur_n, run_ahead = rs->run_ahead, drain = rs->drain;
+    const PendOp* pend = db.pend + (size_t)cur * PB_GMAX;
+    const int64_t left = drain ? 0 : (rs->limit - i0 > 0 ? rs->limit - i0 : 0);
+    int G;
+    {
+        int Gt = rs->G > np ? rs->G : np;                 // the pending ops are always part of the window
+        if (Gt > PB_GMAX) Gt = PB_GMAX;
+        const int64_t avail = (int64_t)np + left;
+        G = (int)(avail < Gt ? avail : Gt);
+    }
     const int w = blockIdx.x * (PL_BLOCK / 64) + (threadIdx.x >> 6);
+    auto op_index = [&](int q) -> int64_t { return q < np ? pend[q].op : i0 + (q - np); };
     if (w < G) {
-    const Plan pl = pb_plan_one(keys, vals, occ, sems, col_keys, col_live, ctl, ops[i0 + w], w, PB_MAX_W);
+    const Plan pl = pb_plan_one(keys, vals, occ, sems, col_keys, col_live, ctl, ops[op_index(w)], w, PB_MAX_W);
     {
         // device-scope (write-through) stores: the workgroup that resolves the round may sit on another XCD; a release FENCE per
         // workgroup instead would write back that XCD's L2 (measured slower).  Seven lanes store one 8-byte field each: ONE store
@@ -396,6 +408,14 @@ __global__ __launch_bounds__(PL_BLOCK) void k_plan(const DevBufs* bufs, const Ct
     __shared__ signed char sCnt02[PB_GMAX];                            // cells of the NEXT leaf if the op needs that one to accept as well (-1: no)
     __shared__ int32_t sLeafLo[PB_GMAX];                               // first slot of the op's leaf if it is leaf-only, else 0
     __shared__ int32_t sCnt0[PB_GMAX];                                 // cells of that leaf before the round
+    // run-ahead: ops that conflict with an earlier op (sConf), ops deferred because they lie in the sealed zone of an earlier deferred op
+    // (sDefer), the zone a deferred op is sealed in (sZlo / sZhi; 0: none), which ops are "simple" (nothing but their tight hull and
+    // their leaf's count ties them to the array), the compact list of the conflicting ops
+    __shared__ unsigned char sAct[PB_GMAX], sConf[PB_GMAX], sDefer[PB_GMAX], sSimple[PB_GMAX];
+    __shared__ int32_t sZlo[PB_GMAX], sZhi[PB_GMAX];
+    __shared__ int sConfList[PB_GMAX];
+    __shared__ int sNConf, sNApplied, sNDeferred, sFault;
+    __shared__ uint32_t sScan[PL_BLOCK / 64];
     const int64_t seg = seg0;
     // (spatial hash of the overlap test below; emptied here, under the latency of the plan loads, behind the same barrier)
     constexpr int CS = PB_MAX_W_LOG2 + 1, NB = 4096;
@@ -404,7 +424,8 @@ __global__ __launch_bounds__(PL_BLOCK) void k_plan(const DevBufs* bufs, const Ct
     __shared__ int sWide[PB_GMAX];
     __shared__ int sNWide;
     for (int k = tid; k < NB; k += PL_BLOCK) sHead[k] = -1;
-    if (tid == 0) sNWide = 0;
+    if (tid == 0) { sNWide = 0; sNConf = 0; sNApplied = 0; sNDeferred = 0; sFault = 0; }
+    for (int j = tid; j < PB_GMAX; j += PL_BLOCK) { sConf[j] = 0; sDefer[j] = 0; sSimple[j] = 0; sZlo[j] = 0; sZhi[j] = 0; sAct[j] = PB_BARRIER; }
     for (int j = tid; j < G + 8; j += PL_BLOCK) {
         Iv iv{INT32_MAX, INT32_MIN};                                   // an empty footprint overlaps nothing
         if (j < G) {
@@ -418,6 +439,7 @@ __global__ __launch_bounds__(PL_BLOCK) void k_plan(const DevBufs* bufs, const Ct
             const int32_t cnt = __hip_atomic_load(&q->count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const int32_t act = __hip_atomic_load(&q->action, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (act == PB_BARRIER) atomicMin(&sB, j);
+            sAct[j] = (unsigned char)act;
             const bool leaf_only = pb_is_leaf_only(act, ws, we, seg, cnt);
             const int dl = pb_delta(act, leaf_only);
             const int64_t chg = pb_changed_slot(act, pos, aux);
@@ -514,6 +536,8 @@ __global__ __launch_bounds__(PL_BLOCK) void k_plan(const DevBufs* bufs, const Ct
             // a new column without a fallback window (level 0x7f) cannot be widened: the prefix ends in front of it (alone at the head
             // of the next round it is handed to the sequencer — d = 0 stops the rounds)
             if (widen[u] && sLvl[j] == 0x7f) { widen[u] = false; atomicMin(&sC, j); }
+            // "simple" (run-ahead): a leaf-accepted right insert / delete that keeps its tight hull
+            if (!widen[u] && (sAct[j] == PB_INS_R || sAct[j] == PB_DELETE)) sSimple[j] = 1;
         }
         __syncthreads();                                               // every walk has read the tight hulls
 #pragma unroll
@@ -552,7 +576,7 @@ __global__ __launch_bounds__(PL_BLOCK) void k_plan(const DevBufs* bufs, const Ct
                 const Iv o = sIv[i];
                 hit = hit | ((i < j) & (o.lo <= me.hi) & (me.lo <= o.hi));
             }
-        if (hit) atomicMin(&sC, j);
+        if (hit) { if (run_ahead) sConf[j] = 1; else atomicMin(&sC, j); }
     }
     __syncthreads();
     const int nwide = sNWide;
@@ -561,61 +585,253 @@ __global__ __launch_bounds__(PL_BLOCK) void k_plan(const DevBufs* bufs, const Ct
         const Iv me = sIv[j];
         for (int i = tid; i < Gc; i += PL_BLOCK) {
             const Iv o = sIv[i];
-            if (i != j && o.lo <= me.hi && me.lo <= o.hi) atomicMin(&sC, i > j ? i : j);
+            if (i != j && o.lo <= me.hi && me.lo <= o.hi) { if (run_ahead) sConf[i > j ? i : j] = 1; else atomicMin(&sC, i > j ? i : j); }
         }
     }
     __syncthreads();
+    if (run_ahead) {
+        // ---- run-ahead: which conflicting ops can be DEFERRED without holding back the ops behind them --------------------------------
+        // An op j that conflicts with an earlier one is deferred to the next round.  Ops behind it may still run in THIS round if nothing
+        // that j can touch when it is finally executed — on the state its earlier partners leave, which is not the state it was planned
+        // on — is theirs.  j is SEALED in a zone Z' = [A, B] + [B + 1, B + W]: the aligned window of some level h (W = seg << h slots,
+        // 64 <= W <= RA_MAX_W) that holds j's footprint and the footprints of the earlier ops it overlaps, plus the window to its right,
+        // such that
+        //   (0) more than D cells lie between A and the leftmost op inside (a predecessor moves left by one cell per deleted cell: it
+        //       stays inside);
+        //   (1) every op of the round's window that touches Z' lies inside [A, B] and is a plain write (overwrite, missing-key delete,
+        //       right-shifting insert, delete; whatever window <= [A, B] its density scan was planned to rebalance): I potential
+        //       inserts (every op with a value), D potential deletes (every op without);
+        //   (2) both windows accept at level h whatever those ops do: lo[h] <= c - D and c + I <= hi[h] for the cell counts c of
+        //       [A, B] and of [B + 1, B + W]: no density scan at a position inside Z' climbs above level h, rebalances stay inside;
+        //   (3) the right window keeps more than I + 1 gaps (W - hi[h] >= I + 2): an insert position can drift right by one slot per
+        //       earlier insert, to B + 1 + I at most, and a gap is left beyond it: every shifted run ends inside Z', nobody takes the
+        //       left branch of _insert!.
+        // So whatever happens in Z' from now on stays in Z', and Z' is touched by nobody else: ops behind j that lie inside [A, B] are
+        // deferred with it (in order), ops that touch Z' otherwise end the round in front of them (prefix rule from there), and
+        // everything else is applied.  The zone travels with the pending op (PendOp); when the op is applied its footprint must lie
+        // inside it — checked below, a violation fails the batch instead of diverging from the sequential order.  Whatever cannot be
+        // proven (no level fits, a new column or a left-shifting insert nearby, arrays beyond 2^31 slots) cuts the round at j.
+        constexpr int RA_MAX_W = 1024, RA_MAX_DEL = 8;
+        __shared__ int32_t sZmid[PB_GMAX];                                 // B: end of the left window of the zone (members lie in [A, B])
+        __shared__ int32_t sInhLo[PB_GMAX], sInhHi[PB_GMAX];                // zone a member inherits
+        for (int j = tid; j < PB_GMAX; j += PL_BLOCK) { sZmid[j] = 0; sInhLo[j] = 0; sInhHi[j] = 0; }
+        for (int j = tid; j < Gc; j += PL_BLOCK) {
+            const int a = sAct[j];
+            sSimple[j] = (a == PB_OVERWRITE || a == PB_NOOP || a == PB_INS_R || a == PB_DELETE) ? 1 : 0;      // "plain write"
+            if (sConf[j]) sConfList[atomicAdd(&sNConf, 1)] = j;
+        }
+        __syncthreads();
+        const int nconf = sNConf;
+        // visits every op of the window whose footprint overlaps [a, b] (an op in two cells of the walk once; a widened op that is also in
+        // the list of wide ops twice — the counts below are upper bounds)
+        auto for_overlapping = [&](int64_t a, int64_t b, auto fn) {
+            const int ca = (int)(a >> CS), cb = (int)(b >> CS);
+            for (int cl = ca; cl <= cb; ++cl)
+                for (int e = sHead[bucket(cl)]; e >= 0; e = sNext[e]) {
+                    const int i = e >> 1;
+                    const Iv o = sIv[i];
+                    const int ci = (o.lo >> CS) + (e & 1);                 // the cell this entry stands for
+                    if (ci != cl) continue;                               // (another cell of the same bucket)
+                    if ((e & 1) && (o.lo >> CS) >= ca) continue;          // the op's first cell lies in the walked range too: visited there
+                    if (o.lo <= b && a <= o.hi) fn(i);
+                }
+            const int nw = sNWide;
+            for (int q = 0; q < nw; ++q) { const int i = sWide[q]; const Iv o = sIv[i]; if (o.lo <= b && a <= o.hi) fn(i); }
+        };
+        for (int q = tid; q < nconf; q += PL_BLOCK) {
+            const int j = sConfList[q];
+            const Iv me = sIv[j];
+            bool ok = shift == 0 && sSimple[j] && me.lo <= me.hi && me.lo >= 1;
+            int64_t A = 0, B = 0, W = 0;
+            if (ok) {
+                int64_t a = me.lo, b = me.hi;
+                for_overlapping(me.lo, me.hi, [&](int i) { if (i < j) { const Iv o = sIv[i]; if (o.lo < a) a = o.lo; if (o.hi > b) b = o.hi; } });
+                if (ok) {
+                    ok = false;
+                    for (int h = 0; h < MAX_LEVELS; ++h) {
+                        W = seg << h;
+                        if (W < 64) continue;
+                        if (W > RA_MAX_W) break;
+                        A = ((a - 1) / W) * W + 1; B = A + W - 1;
+                        if (b > B) continue;
+                        if (B + W > cap0) break;
+                        int ins = 0, del = 0;
+                        bool fits = true;
+                        int32_t min_lo = INT32_MAX;
+                        for_overlapping(A, B + W, [&](int i) {
+                            const Iv o = sIv[i];
+                            if (!sSimple[i] || o.lo < A || o.hi > B) fits = false;
+                            if (sAct[i] == PB_OVERWRITE || sAct[i] == PB_INS_R) ++ins; else ++del;
+                            if (o.lo < min_lo) min_lo = o.lo;
+                        });
+                        if (!fits || del > RA_MAX_DEL) continue;
+                        const int64_t lh = ctl->lo[h], hh = ctl->hi[h];
+                        if (W - hh < ins + 2) continue;
+                        // (0) a predecessor moves left by one cell per deleted cell: more than `del` cells lie between A and the leftmost op
+                        {
+                            int64_t cm = 0;
+                            const int64_t m0 = A - 1, m1 = (int64_t)min_lo - 2;             // 0-based slots [A - 1, min_lo - 2] = slots A .. min_lo - 1
+                            for (int64_t wd = m0 >> 6; m1 >= m0 && wd <= m1 >> 6; ++wd) cm += popc64(occ[wd] & word_range_mask(wd, m0, m1));
+                            if (cm < del + 1) continue;
+                        }
+                        int64_t cl = 0, cr = 0;
+                        for (int64_t wd = (A - 1) >> 6; wd <= (B - 1) >> 6; ++wd) cl += popc64(occ[wd]);
+                        for (int64_t wd = B >> 6; wd <= (B + W - 1) >> 6; ++wd) cr += popc64(occ[wd]);
+                        if (lh <= cl - del && cl + ins <= hh && lh <= cr - del && cr + ins <= hh) { ok = true; break; }
+                    }
+                }
+            }
+#ifdef DSA_FP_CHECK
+            if (ok && (rs->tight & 0x400)) printf("DSA_FP_CHECK run-ahead: op %lld (position %d, act %d, footprint [%d,%d]) sealed in [%lld,%lld]+[..%lld]\n", (long long)op_index(j), j, (int)sAct[j], me.lo, me.hi, (long long)A, (long long)B, (long long)(B + W));
+#endif
+            if (ok) { sZlo[j] = (int32_t)A; sZmid[j] = (int32_t)B; sZhi[j] = (int32_t)(B + W); }
+            else atomicMin(&sC, j);                                                    // not provable: the round ends in front of this op
+        }
+        __syncthreads();
+        // zones must not touch each other: a later conflicting op inside the left window of an earlier zone is a member of that one,
+        // otherwise the round ends at it
+        for (int q = tid; q < nconf; q += PL_BLOCK) {
+            const int j = sConfList[q];
+            if (sZlo[j] == 0) continue;
+            const Iv me = sIv[j];
+            bool member = false, cut = false;
+            for (int r = 0; r < nconf; ++r) {
+                const int i = sConfList[r];
+                if (i >= j || sZlo[i] == 0) continue;
+                if (sZlo[i] <= sZhi[j] && sZlo[j] <= sZhi[i]) { if (me.lo >= sZlo[i] && me.hi <= sZmid[i]) member = true; else cut = true; }
+            }
+            if (cut) atomicMin(&sC, j);
+            else if (member) sDefer[j] = 2;                                            // (its own zone is dropped below, behind the barrier)
+        }
+        __syncthreads();
+        for (int q = tid; q < nconf; q += PL_BLOCK) { const int j = sConfList[q]; if (sDefer[j] == 2) { sZlo[j] = 0; sZhi[j] = 0; sZmid[j] = 0; } }
+        __syncthreads();
+        // every op behind a sealed op: inside the left window of the zone -> deferred with it; touching the zone otherwise -> the round ends there
+        for (int x = tid; x < Gc; x += PL_BLOCK) {
+            const Iv me = sIv[x];
+            if (me.lo > me.hi) continue;
+            int32_t zl = 0, zh = 0;
+            for (int r = 0; r < nconf; ++r) {
+                const int j = sConfList[r];
+                if (j >= x || sZlo[j] == 0 || sDefer[j] == 2) continue;
+                if (me.lo <= sZhi[j] && sZlo[j] <= me.hi) {
+                    if (me.lo >= sZlo[j] && me.hi <= sZmid[j] && sSimple[x]) { if (zl == 0) { zl = sZlo[j]; zh = sZhi[j]; } }
+                    else atomicMin(&sC, x);
+                }
+            }
+            sInhLo[x] = zl; sInhHi[x] = zh;
+        }
+        __syncthreads();
+        // (the zones members inherit are written behind the barrier: the loop above reads the owners' entries of the same arrays)
+        for (int x = tid; x < Gc; x += PL_BLOCK)
+            if (sInhLo[x] != 0) { if (!sDefer[x]) sDefer[x] = 1; if (sZlo[x] == 0) { sZlo[x] = sInhLo[x]; sZhi[x] = sInhHi[x]; } }
+        __syncthreads();
+    }
 #ifdef DSA_FP_CHECK
     {   // the final footprints, for the brute-force re-derivation of this verdict (k_fp_pre)
         FpIv* fiv = reinterpret_cast<FpIv*>(reinterpret_cast<FpRec*>(plans + PB_GMAX) + PB_GMAX);
         for (int j = tid; j < Gc; j += PL_BLOCK) { fiv[j].lo = sIv[j].lo; fiv[j].hi = sIv[j].hi; }
     }
 #endif
-    {   // what the prefix's inserts / deletes do to the element count and the rebalance statistics: added to the control block ONCE, here
-        // (k_apply's waves used to add them one by one: ~500 atomics per round on the same words)
-        int dd = sC < sB ? sC : sB;
-        if (dd > G) dd = G;
-        int dn = 0, rn = 0;
+    // ---- the decision: ops [0, dd) are looked at; of those, the ones that neither conflict with an earlier op nor are sealed behind one
+    //      are applied by k_apply; the others go (in order) to the pending list of the next round, in front of the fresh ops
+    int dd = sC < sB ? sC : sB;
+    if (dd > G) dd = G;
+    bool stop_short = false;
+    {
+        // applied ops: element count and rebalance statistics, added to the control block ONCE, here (k_apply's waves used to add them
+        // one by one: ~500 atomics per round on the same words); zone check of the pending ones
+        int dn = 0, rn = 0, na = 0, nd = 0, bad = 0;
         unsigned int rw = 0u;
-        for (int j = tid; j < dd; j += PL_BLOCK) { dn += sDn[j]; const unsigned int w = sRebW[j]; if (w) { ++rn; rw += w; } }
+        for (int j = tid; j < dd; j += PL_BLOCK) {
+            if (sConf[j] || sDefer[j]) { ++nd; continue; }
+            ++na;
+            dn += sDn[j]; const unsigned int w2 = sRebW[j]; if (w2) { ++rn; rw += w2; }
+            if (j < np) {                                              // deferred earlier: it must still act inside the zone it was sealed in
+                const PendOp po = pend[j];
+                const Iv me = sIv[j];
+                if (po.zlo != 0 && sAct[j] != PB_NOOP && me.lo <= me.hi && (me.lo < po.zlo || me.hi > po.zhi)) {      // (a missing-key delete writes nothing)
+                    bad = 1;
+#ifdef DSA_FP_CHECK
+                    printf("DSA_FP_CHECK run-ahead: pending op %lld (window position %d of %d pending) is applied with the footprint [%d,%d] (act %d), outside the zone [%d,%d] it was sealed in\n",
+                           (long long)po.op, j, np, me.lo, me.hi, (int)sAct[j], po.zlo, po.zhi);
+#endif
+                }
+            }
+        }
+        if (tid == 0 && sB == 0 && np > 0 && pend[0].zlo != 0) bad = 1;          // a sealed op that cannot be planned any more
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { dn += __shfl_xor(dn, o, 64); rn += __shfl_xor(rn, o, 64); rw += __shfl_xor(rw, o, 64); }
-        if ((tid & 63) == 0 && (dn != 0 || rn != 0)) { atomicAdd(&sSumDn, dn); atomicAdd(&sSumRebN, rn); atomicAdd(&sSumRebW, rw); }
+        for (int o = 32; o > 0; o >>= 1) {
+            dn += __shfl_xor(dn, o, 64); rn += __shfl_xor(rn, o, 64); rw += __shfl_xor(rw, o, 64);
+            na += __shfl_xor(na, o, 64); nd += __shfl_xor(nd, o, 64); bad |= __shfl_xor(bad, o, 64);
+        }
+        if ((tid & 63) == 0) {
+            if (dn != 0 || rn != 0) { atomicAdd(&sSumDn, dn); atomicAdd(&sSumRebN, rn); atomicAdd(&sSumRebW, rw); }
+            if (na) atomicAdd(&sNApplied, na);
+            if (nd) atomicAdd(&sNDeferred, nd);
+            if (bad) atomicExch(&sFault, 1);
+        }
+    }
+    __syncthreads();
+    const int na = sNApplied;
+    const int ema = (3 * ema_prev + 16 * na) >> 2;
+    // short rounds one after the other mean the ops around the cursor collide (appends, one hot key): hand over to the
+    // sequencer.  A single short round between long ones (a small array, where windows are wide) is still cheaper as a round
+    // of >= 1 ops than as a sequencer launch.
+    // (with pending ops in the window only an op that cannot be planned stops the rounds: the sequencer takes ONE pending op at a time)
+    if (G > 0 && na < min_prefix && dd < G && (na == 0 || (np == 0 && ema < 16 * min_prefix))) stop_short = true;
+    if (G <= 0) stop_short = false;
+    // ---- the next window: pending list = the deferred ops of [0, dd) and the pending ops at or behind dd, in window order
+    PendOp* pend_next = const_cast<PendOp*>(db.pend) + (size_t)(1 - cur) * PB_GMAX;
+    int np_next = np;
+    int64_t cursor_next = i0;
+    if (!stop_short && G > 0) {
+        // (G <= PL_BLOCK: one window position per thread)
+        const int j = tid;
+        const bool keep = j < G && ((j < dd && (sConf[j] || sDefer[j])) || (j >= dd && j < np));
+        const uint64_t bal = __ballot(keep);
+        const uint32_t inw = (uint32_t)popc64(bal & mask_lt(tid & 63));
+        if ((tid & 63) == 0) sScan[tid >> 6] = (uint32_t)popc64(bal);
+        __syncthreads();
+        uint32_t base = 0, total = 0;
+#pragma unroll
+        for (int v = 0; v < PL_BLOCK / 64; ++v) { const uint32_t c = sScan[v]; if (v < (tid >> 6)) base += c; total += c; }
+        if (keep) {
+            PendOp po;
+            po.op = op_index(j);
+            int32_t zl = j < dd ? sZlo[j] : 0, zh = j < dd ? sZhi[j] : 0;
+            if (j < np) {                                              // intersect with the zone it carries
+                const PendOp old = pend[j];
+                if (old.zlo != 0) { if (zl == 0) { zl = old.zlo; zh = old.zhi; } else { zl = zl > old.zlo ? zl : old.zlo; zh = zh < old.zhi ? zh : old.zhi; } }
+            }
+            po.zlo = zl; po.zhi = zh;
+            pend_next[base + inw] = po;
+        }
+        np_next = (int)total;
+        cursor_next = i0 + (dd > np ? dd - np : 0);
     }
     __syncthreads();
     if (tid == 0) {
 #ifdef DSA_PB_PROF
-        printf("resolve: G %d sB %d sC %d load %lld clk conflicts %lld clk | this workgroup: entry -> planned %lld clk, -> ticket %lld clk\n", G, sB, sC, tr1 - tr0,
-               (long long)clock64() - tr1, tk1 - tk0, tr0 - tk1);
-        if (sC < G && sC <= sB) {      // who cut the prefix: the op at sC and the first earlier op it overlaps (actions, levels, footprints)
-            const Iv me = sIv[sC];
-            for (int i = 0; i < sC; ++i) {
-                const Iv o = sIv[i];
-                if (o.lo <= me.hi && me.lo <= o.hi) {
-                    printf("  cut: j %d act %d lvl %d tight %d [%d,%d] pos %lld  by i %d act %d lvl %d tight %d [%d,%d] pos %lld\n", sC, plans[sC].action, sLvl[sC],
-                           sLeafLo[sC] != 0, me.lo, me.hi, (long long)plans[sC].pos, i, plans[i].action, sLvl[i], sLeafLo[i] != 0, o.lo, o.hi, (long long)plans[i].pos);
-                    break;
-                }
-            }
-        } else if (sB < G) printf("  cut: barrier why %d\n", plans[sB].count & 7);
+        printf("resolve: G %d np %d sB %d sC %d applied %d deferred %d\n", G, np, sB, sC, na, sNDeferred);
 #endif
         rs->ticket = 0u;                                               // re-armed for the next round
-        rs->cursor = i0;
-        if (d_prev > 0) { rs->rounds = rounds_prev + 1; rs->par_ops = par_ops_prev + d_prev; }
-        if (left <= 0) { rs->stop = 2; rs->d = 0; return; }           // finished
-        int d = sC < sB ? sC : sB;
-        if (d > G) d = G;
-        // short prefixes one after the other mean the ops around the cursor collide (appends, one hot key): hand over to the
-        // sequencer.  A single short prefix between long ones (a small array, where windows are wide) is still cheaper as a round
-        // of d >= 1 ops than as a sequencer launch.
-        const int ema = (3 * ema_prev + 16 * d) >> 2;
+        // commit the window of THIS round (k_apply reads it) ...
+        rs->cursor = i0; rs->np = np; rs->cur = cur;
+        if (sFault) atomicMax(&rs->pad, 9);
+        if (G <= 0) { rs->stop = drain ? 5 : 2; rs->d = 0; return; }    // finished (5: the pending list is drained)
         rs->ema = ema;
-        if (d < min_prefix && d < G && (d == 0 || ema < 16 * min_prefix)) {
+        if (stop_short) {
             rs->why[sB <= sC ? (__hip_atomic_load(&plans[sB < G ? sB : 0].count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 7) : 7] += 1;
-            rs->stop = 1; rs->d = 0; return;
+            rs->stop = 1; rs->d = 0;
+            rs->pend0 = op_index(0);
+            return;                                                    // (the next window stays what this one was)
         }
-        rs->d = d;
-        if (d > 0) {
+        rs->d = dd;
+        // ... and describe the next one
+        rs->cursor_n = cursor_next; rs->np_n = np_next; rs->cur_n = 1 - cur;
+        rs->rounds = rounds_prev + (na > 0 ? 1 : 0); rs->par_ops = par_ops_prev + na; rs->deferred = deferred_prev + sNDeferred;
+        if (na > 0) {
             Ctl* c = const_cast<Ctl*>(ctl);
             if (sSumDn != 0) atomicAdd((unsigned long long*)&c->nb_elements, (unsigned long long)(long long)sSumDn);
             if (sSumRebN != 0) {
@@ -624,11 +840,15 @@ __global__ __launch_bounds__(PL_BLOCK) void k_plan(const DevBufs* bufs, const Ct
                 atomicAdd((unsigned long long*)&c->stat_small_rebalances, (unsigned long long)sSumRebN);
             }
         }
-        int Gn = d + (d >> 1) + 32;                                      // the next window: half as much again as what ran (the resolve step costs per planned op)
+        int Gn = na + (na >> 1) + 32;                                    // the next window: half as much again as what ran (the resolve step costs per planned op)
         if (Gn < 64) Gn = 64;
         if (Gn > PB_GMAX) Gn = PB_GMAX;
         rs->G_next = Gn;
     }
+    // the ops k_apply must skip: deferred ones inside [0, dd)
+    if (!stop_short && G > 0)
+        for (int j = tid; j < dd; j += PL_BLOCK)
+            if (sConf[j] || sDefer[j]) __hip_atomic_store(&plans[j].action, (int32_t)PB_DEFER, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ---- apply ----------------------------------------------------------------------------------------------------------
@@ -925,7 +1145,7 @@ __global__ __launch_bounds__(PB_BLOCK) void k_apply(const DevBufs* bufs, Ctl* ct
     double* vals = db.vals; uint64_t* occ = db.occ;
     int64_t* sems = db.sems; int64_t* col_keys = db.col_keys; uint8_t* col_live = db.col_live;
     const int64_t i0 = rs->cursor;
-    const int d = rs->d;
+    const int d = rs->d, np = rs->np;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int w = blockIdx.x * (PB_BLOCK / 64) + wv;
     if (w == 0 && lane == 0) const_cast<RoundState*>(rs)->G = rs->G_next;     // group size of the NEXT round (G is not read any more)
@@ -933,7 +1153,8 @@ __global__ __launch_bounds__(PB_BLOCK) void k_apply(const DevBufs* bufs, Ctl* ct
     int64_t* sK = reinterpret_cast<int64_t*>(pb_lds) + (size_t)wv * PB_MAX_W;
     double* sV = reinterpret_cast<double*>(pb_lds + (size_t)(PB_BLOCK / 64) * PB_MAX_W * sizeof(int64_t)) + (size_t)wv * PB_MAX_W;
     const Plan pl = plans[w];
-    const Op op = ops[i0 + w];
+    if (pl.action == PB_DEFER) return;                                          // deferred by the resolve step: pending for the next round
+    const Op op = ops[w < np ? db.pend[(size_t)rs->cur * PB_GMAX + w].op : i0 + (w - np)];
 #ifdef DSA_FP_CHECK
     if (rs->tight & FP_MODE_SHADOW) return;                       // (the prefix was applied one op after the other by k_fp_pre)
 #endif
@@ -985,9 +1206,12 @@ __global__ __launch_bounds__(PL_BLOCK) void k_fp_pre(const DevBufs* bufs, Ctl* c
         if (tid >= 64) return;
         int64_t* sK = reinterpret_cast<int64_t*>(pb_lds);
         double* sV = reinterpret_cast<double*>(pb_lds + (size_t)PB_MAX_W * sizeof(int64_t));
+        const int np = rs->np;
+        const PendOp* pend = db.pend + (size_t)rs->cur * PB_GMAX;
         for (int j = 0; j < d; ++j) {
-            const Op op = ops[i0 + j];
             const Plan want = plans[j];
+            if (want.action == PB_DEFER) continue;                  // deferred: not part of this round
+            const Op op = ops[j < np ? pend[j].op : i0 + (j - np)];
             // (w = 0: the table entries of the earlier new columns exist by now)
             const Plan live = pb_plan_one(keys, vals, occ, sems, col_keys, col_live, ctl, op, 0, PB_MAX_W);
             if (!fp_same_plan(want, live, seg)) {
@@ -1014,11 +1238,14 @@ __global__ __launch_bounds__(PL_BLOCK) void k_fp_pre(const DevBufs* bufs, Ctl* c
     __shared__ int32_t sLo[PB_GMAX], sHi[PB_GMAX], sC1[PB_GMAX], sC2[PB_GMAX], sWs[PB_GMAX], sWe[PB_GMAX], sTLo[PB_GMAX], sTHi[PB_GMAX];
     __shared__ signed char sD1[PB_GMAX];
     __shared__ unsigned char sTight[PB_GMAX];
+    __shared__ unsigned char sOff[PB_GMAX];                          // deferred by the resolve step: not part of this round
     for (int j = tid; j < d; j += PL_BLOCK) {
         const Plan q = plans[j];
+        sOff[j] = q.action == PB_DEFER ? 1 : 0;
         const bool leaf_only = pb_is_leaf_only(q.action, q.ws, q.we, seg, q.count);
         const int dl = pb_delta(q.action, leaf_only);
         sLo[j] = fiv[j].lo; sHi[j] = fiv[j].hi;
+        if (sOff[j]) { sLo[j] = INT32_MAX; sHi[j] = INT32_MIN; }
         sD1[j] = (signed char)dl;
         sC1[j] = dl != 0 ? (int32_t)pb_changed_slot(q.action, q.pos, q.aux) : 0;
         sC2[j] = (q.action == PB_NEWCOL && leaf_only) ? (int32_t)q.hi : 0;
@@ -1032,10 +1259,12 @@ __global__ __launch_bounds__(PL_BLOCK) void k_fp_pre(const DevBufs* bufs, Ctl* c
         // else anything inside the final footprint (a new column that was widened scans and rebalances live inside its window)
         const bool hull_only = leaf_only && q.action != PB_NEWCOL;
         sTLo[j] = hull_only ? (int32_t)q.lo : fiv[j].lo; sTHi[j] = hull_only ? (int32_t)q.hi : fiv[j].hi;
+        if (sOff[j]) { sTLo[j] = INT32_MAX; sTHi[j] = INT32_MIN; }
     }
     __syncthreads();
     const int64_t lo0 = ctl->lo[0], hi0 = ctl->hi[0];
     for (int j = tid; j < d; j += PL_BLOCK) {
+        if (sOff[j]) continue;
         const int32_t lo = sLo[j], hi = sHi[j];
         const FpRec r = recs[j];
         // (a) nothing an EARLIER op of the prefix writes lies in the final footprint of a later one (which holds everything that one read for
@@ -1099,6 +1328,7 @@ __global__ __launch_bounds__(PL_BLOCK) void k_fp_post(RoundState* rs, const Plan
     for (int j = threadIdx.x; j < d; j += PL_BLOCK) {
         const FpRec r = recs[j];
         const Plan q = plans[j];
+        if (q.action == PB_DEFER) continue;
         const bool hull_only = q.action != PB_NEWCOL && pb_is_leaf_only(q.action, q.ws, q.we, seg, q.count);      // (see k_fp_pre)
         const int64_t tlo = hull_only ? q.lo : (int64_t)fiv[j].lo, thi = hull_only ? q.hi : (int64_t)fiv[j].hi;
         if (r.tlo <= r.thi && (r.tlo < tlo || r.thi > thi)) {
@@ -1134,7 +1364,7 @@ __global__ __launch_bounds__(LR_BLOCK) void k_local_rounds(const DevBufs* bufs, 
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     int64_t* sK = reinterpret_cast<int64_t*>(lr_lds) + (size_t)wv * LR_MAX_W;
     double* sV = reinterpret_cast<double*>(lr_lds + (size_t)LR_WAVES * LR_MAX_W * sizeof(int64_t)) + (size_t)wv * LR_MAX_W;
-    int64_t cursor = rs->cursor + rs->d;
+    int64_t cursor = rs->cursor_n;                    // (the host drains the pending list of the grid rounds before it comes here: np_n == 0)
     const int64_t limit = rs->limit;
     int rounds = 0, stop = 0, why = 0, full_streak = 0, single_streak = 0;
     int64_t par_ops = 0;
@@ -1241,7 +1471,7 @@ __global__ __launch_bounds__(LR_BLOCK) void k_local_rounds(const DevBufs* bufs, 
         if (single_streak >= 16) { stop = 1; why = 7; break; }          // every op collides with its predecessor (appends, one hot key): the sequencer's
     }
     if (threadIdx.x == 0) {
-        rs->cursor = cursor; rs->d = 0;
+        rs->cursor = cursor; rs->cursor_n = cursor; rs->d = 0; rs->pend0 = cursor;
         rs->rounds += rounds; rs->par_ops += par_ops;
         rs->stop = stop;
         if (stop == 1) rs->why[why] += 1;
