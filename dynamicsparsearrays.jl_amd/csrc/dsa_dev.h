@@ -436,7 +436,8 @@ struct BurstPublish { RoundState* host_rs; Ctl* host_ctl; unsigned long long* ho
 // plan array carries behind the plans for the recorded read / touch sets and the final footprints
 constexpr int FP_MODE_SETS = 0x100, FP_MODE_SHADOW = 0x200;
 constexpr size_t FP_BYTES_PER_OP = 160;
-constexpr int ROUND_GMAX = 1024;       // ops planned per round at most (parbatch.hip: one wave each; the host sizes the plan array)
+constexpr int ROUND_GMAX = 1024;       // ops planned per round at most (parbatch.hip: one wave each; the host sizes the plan array and the pending lists).
+                                       // 2048 was measured in round 6: the resolve step costs per planned op, a round of twice the size takes twice as long
 struct BurstGraph {        // cached hipGraph of one burst of rounds (host-side)
     hipGraphExec_t exec = nullptr; hipGraph_t graph = nullptr; hipStream_t stream = nullptr;
     const void* key[12] = {};

@@ -409,11 +409,14 @@ __global__ __launch_bounds__(PL_BLOCK) void k_plan(const DevBufs* bufs, const Ct
     __shared__ int32_t sLeafLo[PB_GMAX];                               // first slot of the op's leaf if it is leaf-only, else 0
     __shared__ int32_t sCnt0[PB_GMAX];                                 // cells of that leaf before the round
     // run-ahead: ops that conflict with an earlier op (sConf), ops deferred because they lie in the sealed zone of an earlier deferred op
-    // (sDefer), the zone a deferred op is sealed in (sZlo / sZhi; 0: none), which ops are "simple" (nothing but their tight hull and
+    // (sDefer), the zone a deferred op is sealed in (sZid -> sZone; 0: none), which ops are plain writes (sSimple: nothing but a hull and
     // their leaf's count ties them to the array), the compact list of the conflicting ops
+    constexpr int RA_MAX_CONF = 96;                                    // conflicting ops a round seals at most (more: the prefix rule)
     __shared__ unsigned char sAct[PB_GMAX], sConf[PB_GMAX], sDefer[PB_GMAX], sSimple[PB_GMAX];
-    __shared__ int32_t sZlo[PB_GMAX], sZhi[PB_GMAX];
-    __shared__ int sConfList[PB_GMAX];
+    __shared__ unsigned char sZid[PB_GMAX];                            // zone the op is sealed in: 1 + index into the zone table (0: none)
+    struct Zone { int32_t lo, mid, hi; };                              // [A, B] + [B + 1, B + W]: lo = A, mid = B, hi = B + W (lo = 0: no zone)
+    __shared__ Zone sZone[RA_MAX_CONF];                                // ... of the q-th conflicting op (owner sConfList[q])
+    __shared__ int sConfList[RA_MAX_CONF];
     __shared__ int sNConf, sNApplied, sNDeferred, sFault;
     __shared__ uint32_t sScan[PL_BLOCK / 64];
     const int64_t seg = seg0;
@@ -423,9 +426,13 @@ __global__ __launch_bounds__(PL_BLOCK) void k_plan(const DevBufs* bufs, const Ct
     __shared__ int sNext[2 * PB_GMAX];
     __shared__ int sWide[PB_GMAX];
     __shared__ int sNWide;
+    __shared__ int64_t sLoH[24], sHiH[24];                            // density bounds of the lower levels (run-ahead: the sealed zones)
+    __shared__ int sMinConf;
+    if (tid < 24) { sLoH[tid] = ctl->lo[tid]; sHiH[tid] = ctl->hi[tid]; }
     for (int k = tid; k < NB; k += PL_BLOCK) sHead[k] = -1;
-    if (tid == 0) { sNWide = 0; sNConf = 0; sNApplied = 0; sNDeferred = 0; sFault = 0; }
-    for (int j = tid; j < PB_GMAX; j += PL_BLOCK) { sConf[j] = 0; sDefer[j] = 0; sSimple[j] = 0; sZlo[j] = 0; sZhi[j] = 0; sAct[j] = PB_BARRIER; }
+    if (tid == 0) { sNWide = 0; sNConf = 0; sNApplied = 0; sNDeferred = 0; sFault = 0; sMinConf = INT32_MAX; }
+    for (int j = tid; j < G + 8 && j < PB_GMAX; j += PL_BLOCK) { sConf[j] = 0; sDefer[j] = 0; sSimple[j] = 0; sZid[j] = 0; sAct[j] = PB_BARRIER; }
+    if (tid < RA_MAX_CONF) { sZone[tid].lo = 0; sZone[tid].mid = 0; sZone[tid].hi = 0; }
     for (int j = tid; j < G + 8; j += PL_BLOCK) {
         Iv iv{INT32_MAX, INT32_MIN};                                   // an empty footprint overlaps nothing
         if (j < G) {
@@ -576,7 +583,7 @@ __global__ __launch_bounds__(PL_BLOCK) void k_plan(const DevBufs* bufs, const Ct
                 const Iv o = sIv[i];
                 hit = hit | ((i < j) & (o.lo <= me.hi) & (me.lo <= o.hi));
             }
-        if (hit) { if (run_ahead) sConf[j] = 1; else atomicMin(&sC, j); }
+        if (hit) { if (run_ahead) { sConf[j] = 1; atomicMin(&sMinConf, j); } else atomicMin(&sC, j); }
     }
     __syncthreads();
     const int nwide = sNWide;
@@ -585,11 +592,18 @@ __global__ __launch_bounds__(PL_BLOCK) void k_plan(const DevBufs* bufs, const Ct
         const Iv me = sIv[j];
         for (int i = tid; i < Gc; i += PL_BLOCK) {
             const Iv o = sIv[i];
-            if (i != j && o.lo <= me.hi && me.lo <= o.hi) { if (run_ahead) sConf[i > j ? i : j] = 1; else atomicMin(&sC, i > j ? i : j); }
+            if (i != j && o.lo <= me.hi && me.lo <= o.hi) { if (run_ahead) { sConf[i > j ? i : j] = 1; atomicMin(&sMinConf, i > j ? i : j); } else atomicMin(&sC, i > j ? i : j); }
         }
     }
     __syncthreads();
-    if (run_ahead) {
+    [[maybe_unused]] const long long tr2 = clock64();
+    // Sealing costs the resolving workgroup a few dependent round trips to memory per round; it does not pay when the first conflict
+    // sits in the last eighth of the window anyway (a long prefix: the array is large against the window): the prefix rule then
+    if (run_ahead && sMinConf != INT32_MAX && sMinConf >= Gc - (Gc >> 3)) {
+        if (tid == 0) atomicMin(&sC, sMinConf);
+        __syncthreads();
+    } else
+    if (run_ahead && sMinConf != INT32_MAX) {
         // ---- run-ahead: which conflicting ops can be DEFERRED without holding back the ops behind them --------------------------------
         // An op j that conflicts with an earlier one is deferred to the next round.  Ops behind it may still run in THIS round if nothing
         // that j can touch when it is finally executed — on the state its earlier partners leave, which is not the state it was planned
@@ -612,16 +626,15 @@ __global__ __launch_bounds__(PL_BLOCK) void k_plan(const DevBufs* bufs, const Ct
         // inside it — checked below, a violation fails the batch instead of diverging from the sequential order.  Whatever cannot be
         // proven (no level fits, a new column or a left-shifting insert nearby, arrays beyond 2^31 slots) cuts the round at j.
         constexpr int RA_MAX_W = 1024, RA_MAX_DEL = 8;
-        __shared__ int32_t sZmid[PB_GMAX];                                 // B: end of the left window of the zone (members lie in [A, B])
-        __shared__ int32_t sInhLo[PB_GMAX], sInhHi[PB_GMAX];                // zone a member inherits
-        for (int j = tid; j < PB_GMAX; j += PL_BLOCK) { sZmid[j] = 0; sInhLo[j] = 0; sInhHi[j] = 0; }
         for (int j = tid; j < Gc; j += PL_BLOCK) {
             const int a = sAct[j];
             sSimple[j] = (a == PB_OVERWRITE || a == PB_NOOP || a == PB_INS_R || a == PB_DELETE) ? 1 : 0;      // "plain write"
-            if (sConf[j]) sConfList[atomicAdd(&sNConf, 1)] = j;
+            if (sConf[j]) { const int q = atomicAdd(&sNConf, 1); if (q < RA_MAX_CONF) sConfList[q] = j; }
         }
         __syncthreads();
-        const int nconf = sNConf;
+        // (a window full of conflicts — hammering one leaf, a tiny array — is the prefix rule's: most zones would not hold anyway)
+        const int nconf = sNConf > RA_MAX_CONF ? 0 : sNConf;
+        if (sNConf > RA_MAX_CONF && tid == 0) atomicMin(&sC, sMinConf);
         // visits every op of the window whose footprint overlaps [a, b] (an op in two cells of the walk once; a widened op that is also in
         // the list of wide ops twice — the counts below are upper bounds)
         auto for_overlapping = [&](int64_t a, int64_t b, auto fn) {
@@ -638,14 +651,19 @@ __global__ __launch_bounds__(PL_BLOCK) void k_plan(const DevBufs* bufs, const Ct
             const int nw = sNWide;
             for (int q = 0; q < nw; ++q) { const int i = sWide[q]; const Iv o = sIv[i]; if (o.lo <= b && a <= o.hi) fn(i); }
         };
-        for (int q = tid; q < nconf; q += PL_BLOCK) {
-            const int j = sConfList[q];
-            const Iv me = sIv[j];
-            bool ok = shift == 0 && sSimple[j] && me.lo <= me.hi && me.lo >= 1;
-            int64_t A = 0, B = 0, W = 0;
-            if (ok) {
+        // one WAVE per conflicting op: lane 0 walks the hash chains (LDS), lanes 0..15 / 16..31 load the occupancy words of the left /
+        // right window in ONE round (a single thread took one dependent round trip per word: 5-20 us per round for one conflict)
+        {
+            const int lane = tid & 63, wave = tid >> 6;
+            for (int q = wave; q < nconf; q += PL_BLOCK / 64) {
+                const int j = sConfList[q];
+                const Iv me = sIv[j];
+                bool ok = shift == 0 && sSimple[j] && me.lo <= me.hi && me.lo >= 1;
+                int64_t A = 0, B = 0, W = 0;
                 int64_t a = me.lo, b = me.hi;
-                for_overlapping(me.lo, me.hi, [&](int i) { if (i < j) { const Iv o = sIv[i]; if (o.lo < a) a = o.lo; if (o.hi > b) b = o.hi; } });
+                if (ok && lane == 0)
+                    for_overlapping(me.lo, me.hi, [&](int i) { if (i < j) { const Iv o = sIv[i]; if (o.lo < a) a = o.lo; if (o.hi > b) b = o.hi; } });
+                a = __shfl(a, 0, 64); b = __shfl(b, 0, 64);
                 if (ok) {
                     ok = false;
                     for (int h = 0; h < MAX_LEVELS; ++h) {
@@ -655,78 +673,81 @@ __global__ __launch_bounds__(PL_BLOCK) void k_plan(const DevBufs* bufs, const Ct
                         A = ((a - 1) / W) * W + 1; B = A + W - 1;
                         if (b > B) continue;
                         if (B + W > cap0) break;
-                        int ins = 0, del = 0;
-                        bool fits = true;
+                        int ins = 0, del = 0, fits = 1;
                         int32_t min_lo = INT32_MAX;
-                        for_overlapping(A, B + W, [&](int i) {
-                            const Iv o = sIv[i];
-                            if (!sSimple[i] || o.lo < A || o.hi > B) fits = false;
-                            if (sAct[i] == PB_OVERWRITE || sAct[i] == PB_INS_R) ++ins; else ++del;
-                            if (o.lo < min_lo) min_lo = o.lo;
-                        });
+                        if (lane == 0)
+                            for_overlapping(A, B + W, [&](int i) {
+                                const Iv o = sIv[i];
+                                if (!sSimple[i] || o.lo < A || o.hi > B) fits = 0;
+                                if (sAct[i] == PB_OVERWRITE || sAct[i] == PB_INS_R) ++ins; else ++del;
+                                if (o.lo < min_lo) min_lo = o.lo;
+                            });
+                        ins = __shfl(ins, 0, 64); del = __shfl(del, 0, 64); fits = __shfl(fits, 0, 64); min_lo = __shfl(min_lo, 0, 64);
                         if (!fits || del > RA_MAX_DEL) continue;
-                        const int64_t lh = ctl->lo[h], hh = ctl->hi[h];
+                        const int64_t lh = h < 24 ? sLoH[h] : ctl->lo[h], hh = h < 24 ? sHiH[h] : ctl->hi[h];
                         if (W - hh < ins + 2) continue;
                         // (0) a predecessor moves left by one cell per deleted cell: more than `del` cells lie between A and the leftmost op
-                        {
-                            int64_t cm = 0;
-                            const int64_t m0 = A - 1, m1 = (int64_t)min_lo - 2;             // 0-based slots [A - 1, min_lo - 2] = slots A .. min_lo - 1
-                            for (int64_t wd = m0 >> 6; m1 >= m0 && wd <= m1 >> 6; ++wd) cm += popc64(occ[wd] & word_range_mask(wd, m0, m1));
-                            if (cm < del + 1) continue;
-                        }
-                        int64_t cl = 0, cr = 0;
-                        for (int64_t wd = (A - 1) >> 6; wd <= (B - 1) >> 6; ++wd) cl += popc64(occ[wd]);
-                        for (int64_t wd = B >> 6; wd <= (B + W - 1) >> 6; ++wd) cr += popc64(occ[wd]);
+                        const int nwd = (int)(W >> 6);                                  // <= 16
+                        const int64_t wl0 = (A - 1) >> 6, wr0 = B >> 6;
+                        const int64_t m0 = A - 1, m1 = (int64_t)min_lo - 2;             // 0-based slots of [A, min_lo - 1]
+                        const int t = lane & 15;
+                        uint64_t word = 0ull;
+                        if (lane < 32 && t < nwd) word = occ[(lane < 16 ? wl0 : wr0) + t];
+                        int64_t cl = lane < 16 ? popc64(word) : 0, cr = (lane >= 16 && lane < 32) ? popc64(word) : 0;
+                        int64_t cm = (lane < 16 && t < nwd && m1 >= m0) ? popc64(word & word_range_mask(wl0 + t, m0, m1)) : 0;
+                        cl = pb_wave_sum(cl); cr = pb_wave_sum(cr); cm = pb_wave_sum(cm);
+                        if (cm < del + 1) continue;
                         if (lh <= cl - del && cl + ins <= hh && lh <= cr - del && cr + ins <= hh) { ok = true; break; }
                     }
                 }
-            }
+                if (lane == 0) {
 #ifdef DSA_FP_CHECK
-            if (ok && (rs->tight & 0x400)) printf("DSA_FP_CHECK run-ahead: op %lld (position %d, act %d, footprint [%d,%d]) sealed in [%lld,%lld]+[..%lld]\n", (long long)op_index(j), j, (int)sAct[j], me.lo, me.hi, (long long)A, (long long)B, (long long)(B + W));
+                    if (ok && (rs->tight & 0x400)) printf("DSA_FP_CHECK run-ahead: op %lld (position %d, act %d, footprint [%d,%d]) sealed in [%lld,%lld]+[..%lld]\n", (long long)op_index(j), j, (int)sAct[j], me.lo, me.hi, (long long)A, (long long)B, (long long)(B + W));
 #endif
-            if (ok) { sZlo[j] = (int32_t)A; sZmid[j] = (int32_t)B; sZhi[j] = (int32_t)(B + W); }
-            else atomicMin(&sC, j);                                                    // not provable: the round ends in front of this op
+                    if (ok) { sZone[q].lo = (int32_t)A; sZone[q].mid = (int32_t)B; sZone[q].hi = (int32_t)(B + W); }
+                    else atomicMin(&sC, j);                                                    // not provable: the round ends in front of this op
+                }
+            }
         }
         __syncthreads();
         // zones must not touch each other: a later conflicting op inside the left window of an earlier zone is a member of that one,
         // otherwise the round ends at it
         for (int q = tid; q < nconf; q += PL_BLOCK) {
+            const Zone zq = sZone[q];
+            if (zq.lo == 0) continue;
             const int j = sConfList[q];
-            if (sZlo[j] == 0) continue;
             const Iv me = sIv[j];
             bool member = false, cut = false;
             for (int r = 0; r < nconf; ++r) {
                 const int i = sConfList[r];
-                if (i >= j || sZlo[i] == 0) continue;
-                if (sZlo[i] <= sZhi[j] && sZlo[j] <= sZhi[i]) { if (me.lo >= sZlo[i] && me.hi <= sZmid[i]) member = true; else cut = true; }
+                const Zone zr = sZone[r];
+                if (i >= j || zr.lo == 0) continue;
+                if (zr.lo <= zq.hi && zq.lo <= zr.hi) { if (me.lo >= zr.lo && me.hi <= zr.mid) member = true; else cut = true; }
             }
             if (cut) atomicMin(&sC, j);
             else if (member) sDefer[j] = 2;                                            // (its own zone is dropped below, behind the barrier)
         }
         __syncthreads();
-        for (int q = tid; q < nconf; q += PL_BLOCK) { const int j = sConfList[q]; if (sDefer[j] == 2) { sZlo[j] = 0; sZhi[j] = 0; sZmid[j] = 0; } }
+        for (int q = tid; q < nconf; q += PL_BLOCK) { if (sDefer[sConfList[q]] == 2) sZone[q].lo = 0; else if (sZone[q].lo != 0) sZid[sConfList[q]] = (unsigned char)(q + 1); }
         __syncthreads();
         // every op behind a sealed op: inside the left window of the zone -> deferred with it; touching the zone otherwise -> the round ends there
         for (int x = tid; x < Gc; x += PL_BLOCK) {
             const Iv me = sIv[x];
             if (me.lo > me.hi) continue;
-            int32_t zl = 0, zh = 0;
+            int zid = 0;
             for (int r = 0; r < nconf; ++r) {
-                const int j = sConfList[r];
-                if (j >= x || sZlo[j] == 0 || sDefer[j] == 2) continue;
-                if (me.lo <= sZhi[j] && sZlo[j] <= me.hi) {
-                    if (me.lo >= sZlo[j] && me.hi <= sZmid[j] && sSimple[x]) { if (zl == 0) { zl = sZlo[j]; zh = sZhi[j]; } }
+                const Zone zr = sZone[r];
+                if (sConfList[r] >= x || zr.lo == 0) continue;
+                if (me.lo <= zr.hi && zr.lo <= me.hi) {
+                    if (me.lo >= zr.lo && me.hi <= zr.mid && sSimple[x]) { if (zid == 0) zid = r + 1; }
                     else atomicMin(&sC, x);
                 }
             }
-            sInhLo[x] = zl; sInhHi[x] = zh;
+            if (zid != 0) { if (!sDefer[x]) sDefer[x] = 1; if (sZid[x] == 0) sZid[x] = (unsigned char)zid; }      // (only x's own entries: the owners' zones are final)
         }
         __syncthreads();
-        // (the zones members inherit are written behind the barrier: the loop above reads the owners' entries of the same arrays)
-        for (int x = tid; x < Gc; x += PL_BLOCK)
-            if (sInhLo[x] != 0) { if (!sDefer[x]) sDefer[x] = 1; if (sZlo[x] == 0) { sZlo[x] = sInhLo[x]; sZhi[x] = sInhHi[x]; } }
-        __syncthreads();
     }
+    [[maybe_unused]] const long long tr3 = clock64();
 #ifdef DSA_FP_CHECK
     {   // the final footprints, for the brute-force re-derivation of this verdict (k_fp_pre)
         FpIv* fiv = reinterpret_cast<FpIv*>(reinterpret_cast<FpRec*>(plans + PB_GMAX) + PB_GMAX);
@@ -785,27 +806,42 @@ __global__ __launch_bounds__(PL_BLOCK) void k_plan(const DevBufs* bufs, const Ct
     PendOp* pend_next = const_cast<PendOp*>(db.pend) + (size_t)(1 - cur) * PB_GMAX;
     int np_next = np;
     int64_t cursor_next = i0;
-    if (!stop_short && G > 0) {
-        // (G <= PL_BLOCK: one window position per thread)
-        const int j = tid;
-        const bool keep = j < G && ((j < dd && (sConf[j] || sDefer[j])) || (j >= dd && j < np));
-        const uint64_t bal = __ballot(keep);
-        const uint32_t inw = (uint32_t)popc64(bal & mask_lt(tid & 63));
-        if ((tid & 63) == 0) sScan[tid >> 6] = (uint32_t)popc64(bal);
+    const bool any_pending = sNDeferred > 0 || np > dd;               // (uniform: LDS word / kernel scalars)
+    if (!stop_short && G > 0 && !any_pending) { np_next = 0; cursor_next = i0 + (dd > np ? dd - np : 0); }
+    if (!stop_short && G > 0 && any_pending) {
+        // (PB_GMAX / PL_BLOCK consecutive window positions per thread)
+        constexpr int R = PB_GMAX / PL_BLOCK;
+        bool keep[R];
+        uint32_t mine = 0;
+#pragma unroll
+        for (int u = 0; u < R; ++u) {
+            const int j = tid * R + u;
+            keep[u] = j < G && ((j < dd && (sConf[j] || sDefer[j])) || (j >= dd && j < np));
+            mine += keep[u] ? 1u : 0u;
+        }
+        uint32_t inc = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(inc, o, 64); if ((tid & 63) >= o) inc += y; }
+        if ((tid & 63) == 63) sScan[tid >> 6] = inc;
         __syncthreads();
         uint32_t base = 0, total = 0;
 #pragma unroll
         for (int v = 0; v < PL_BLOCK / 64; ++v) { const uint32_t c = sScan[v]; if (v < (tid >> 6)) base += c; total += c; }
-        if (keep) {
+        uint32_t at = base + inc - mine;
+#pragma unroll
+        for (int u = 0; u < R; ++u) {
+            if (!keep[u]) continue;
+            const int j = tid * R + u;
             PendOp po;
             po.op = op_index(j);
-            int32_t zl = j < dd ? sZlo[j] : 0, zh = j < dd ? sZhi[j] : 0;
+            int32_t zl = 0, zh = 0;
+            if (j < dd && sZid[j] != 0) { const Zone z = sZone[sZid[j] - 1]; zl = z.lo; zh = z.hi; }
             if (j < np) {                                              // intersect with the zone it carries
                 const PendOp old = pend[j];
                 if (old.zlo != 0) { if (zl == 0) { zl = old.zlo; zh = old.zhi; } else { zl = zl > old.zlo ? zl : old.zlo; zh = zh < old.zhi ? zh : old.zhi; } }
             }
             po.zlo = zl; po.zhi = zh;
-            pend_next[base + inw] = po;
+            pend_next[at++] = po;
         }
         np_next = (int)total;
         cursor_next = i0 + (dd > np ? dd - np : 0);
@@ -813,7 +849,8 @@ __global__ __launch_bounds__(PL_BLOCK) void k_plan(const DevBufs* bufs, const Ct
     __syncthreads();
     if (tid == 0) {
 #ifdef DSA_PB_PROF
-        printf("resolve: G %d np %d sB %d sC %d applied %d deferred %d\n", G, np, sB, sC, na, sNDeferred);
+        printf("resolve: G %d np %d sB %d sC %d applied %d deferred %d nconf %d | clk: entry->planned %lld ->ticket %lld | load %lld conflicts %lld seal %lld decide+list %lld\n", G, np, sB, sC, na,
+               sNDeferred, sNConf, tk1 - tk0, tr0 - tk1, tr1 - tr0, tr2 - tr1, tr3 - tr2, (long long)clock64() - tr3);
 #endif
         rs->ticket = 0u;                                               // re-armed for the next round
         // commit the window of THIS round (k_apply reads it) ...
@@ -846,7 +883,7 @@ __global__ __launch_bounds__(PL_BLOCK) void k_plan(const DevBufs* bufs, const Ct
         rs->G_next = Gn;
     }
     // the ops k_apply must skip: deferred ones inside [0, dd)
-    if (!stop_short && G > 0)
+    if (!stop_short && G > 0 && sNDeferred > 0)
         for (int j = tid; j < dd; j += PL_BLOCK)
             if (sConf[j] || sDefer[j]) __hip_atomic_store(&plans[j].action, (int32_t)PB_DEFER, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
