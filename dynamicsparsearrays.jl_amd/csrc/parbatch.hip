@@ -338,7 +338,7 @@ __global__ __launch_bounds__(PL_BLOCK) void k_plan(const DevBufs* bufs, const Ct
     // the window of this round (written by the previous round's resolve step, committed by this one's): the pending ops — deferred by
     // earlier rounds, ascending op index — followed by fresh ops
     const int64_t i0 = rs->cursor_n;
-    const int np = rs->np_n, cur = rs->cur_n, run_ahead = rs->run_ahead, drain = rs->drain;
+    const int np = rs->np_n, cur = rs->cur_n, run_ahead_rs = rs->run_ahead, drain = rs->drain;
     const PendOp* pend = db.pend + (size_t)cur * PB_GMAX;
     const int64_t left = drain ? 0 : (rs->limit - i0 > 0 ? rs->limit - i0 : 0);
     int G;
@@ -349,6 +349,9 @@ __global__ __launch_bounds__(PL_BLOCK) void k_plan(const DevBufs* bufs, const Ct
         G = (int)(avail < Gt ? avail : Gt);
     }
     const int w = blockIdx.x * (PL_BLOCK / 64) + (threadIdx.x >> 6);
+    // (short windows — a small, fast-growing array whose ops collide all the time: config 5's first batches plan ~60 ops a round — are the
+    //  prefix rule's: sealing costs the resolve step more than the few ops behind the first conflict are worth; pending ops keep the mode on)
+    const int run_ahead = run_ahead_rs && (G >= 128 || np > 0) ? 1 : 0;
     auto op_index = [&](int q) -> int64_t { return q < np ? pend[q].op : i0 + (q - np); };
     if (w < G) {
     const Plan pl = pb_plan_one(keys, vals, occ, sems, col_keys, col_live, ctl, ops[op_index(w)], w, PB_MAX_W);
