@@ -557,6 +557,34 @@ def extras(dsa, hip, torch, A, dev):
             sweep.append(row)
             del vv
     res["rebalance_sweep"] = sweep
+    # the 2^24 window from the two sources side by side (the quoted case is the benign one — cells already spread; a
+    # source with every gap at the left is what dsa_vec_dev_relayout(2) builds: only the tiles that hold cells write)
+    for row in sweep:
+        if row["window_slots"] == 1 << 24 and row["density"] > 0.5 and "gaps_left_us" in row:
+            gl = row["gaps_left_us"]
+            res["roofline_rebalance"]["skewed_sources_2^24"] = {
+                "even_us": row["us"], "gaps_left_us": gl, "packed_left_us": row.get("packed_left_us"),
+                "gaps_left_frac": round(32 * (1 << 24) / gl / 1e3 / HBM_PEAK_GBS, 4),
+                "gaps_left_physical_frac": round(2 * (12 * (1 << 24) + (1 << 21)) / gl / 1e3 / HBM_PEAK_GBS, 4),
+                "note": "a vector's 2^24-slot root window at density 0.70: cells already spread / all cells in the last n slots / in the first n slots"}
+    # --- wide keys: ONE key outside Int32 widens the whole slot array to 16-byte slots (KeyArr) — the slot size SURVEY's byte formula
+    #     assumes.  The 2^24 rebalance and the C3 product on such structures: algorithmic == physical bytes here (+ the bitmap).
+    try:
+        capw = 1 << 24
+        nw = int(0.7 * capw)
+        kw = np.arange(1, nw + 1, dtype=np.int64) * 3
+        kw[-1] = np.int64(1) << 40
+        vw = dsa.dynamicsparsevec(kw, unit12(44, nw), binding=hip)
+        assert vw.info()["capacity"] == capw
+        hip.call("vec_set_stream", vw.h, C.c_void_p(stream.cuda_stream))
+        usw = timed(vw.rebalance_root, 20)
+        physw = 2 * (16 * capw + capw // 8)
+        res["wide_keys"] = {"rebalance_2^24": {"us": round(usw, 2), "frac": round(32 * capw / usw / 1e3 / HBM_PEAK_GBS, 4),
+                                               "physical_bytes": physw, "physical_frac": round(physw / usw / 1e3 / HBM_PEAK_GBS, 4),
+                                               "kernel": "k_move2<false, WIDE=true>"}}
+        del vw, kw
+    except Exception as e:
+        res["wide_keys"] = {"rebalance_2^24": {"error": str(e)[:200]}}
     # --- one C4 shard (BASELINE config 4 per GPU: 10M rows, 1.25M columns, 12.5M nnz, capacity 2^25, y = 10M doubles)
     try:
         m4, n4 = 10_000_000, 1_250_000
@@ -592,6 +620,38 @@ def extras(dsa, hip, torch, A, dev):
         del A4, x4, y4
     except Exception as e:           # an extra must never cost the headline line
         res["c4_shard_spmv"] = {"error": str(e)[:200]}
+    # --- the C3 product on 16-byte slots: the same matrix plus ONE cell whose column key lies outside Int32 (the twin orientation the
+    #     gather kernel walks keeps column keys: it is widened; the cell itself is beyond x and contributes nothing)
+    try:
+        m3w = n3w = 1_000_000
+        Iw, Jw, Vw = c3_triplets(m3w, n3w, 10, 0, seed_rows=5, seed_vals=6)
+        Iw = np.concatenate([Iw, [1]]); Jw = np.concatenate([Jw, [np.int64(1) << 33]]); Vw = np.concatenate([Vw, [1.5]])
+        Aw = dsa.dynamicsparse(Iw, Jw, Vw, m3w, n3w, binding=hip)
+        hip.call("mat_set_stream", Aw.h, C.c_void_p(stream.cuda_stream))
+        capw3 = Aw.info(dsa.ROWMAJOR)["capacity"]
+        xw = torch.from_numpy(unit12(7, n3w)).to(dev)
+        yw = torch.zeros(m3w, dtype=torch.float64, device=dev)
+        fw = lambda: hip.call("mat_spmv_dense_dev", Aw.h, 0, 0, C.c_void_p(xw.data_ptr()), n3w, C.c_void_p(yw.data_ptr()), m3w)
+        for _ in range(3):
+            fw()
+        torch.cuda.synchronize()
+        r0, r1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        r0.record(stream)
+        for _ in range(20):
+            fw()
+        r1.record(stream)
+        torch.cuda.synchronize()
+        usw3 = r0.elapsed_time(r1) / 20 * 1e3
+        bw3 = 16 * capw3 + 8 * n3w + 8 * m3w
+        res.setdefault("wide_keys", {})["spmv_c3"] = {"us": round(usw3, 2), "capacity_slots": capw3, "algorithmic_bytes": bw3,
+                                                      "frac": round(bw3 / usw3 / 1e3 / HBM_PEAK_GBS, 4),
+                                                      "physical_bytes": bw3 + capw3 // 8,
+                                                      "physical_frac": round((bw3 + capw3 // 8) / usw3 / 1e3 / HBM_PEAK_GBS, 4),
+                                                      "kernel": "k_spmv_gather<WIDE=true, ...>",
+                                                      "note": "config 3 + one cell with a column key of 2^33: 16-byte slots in HBM, algorithmic == physical bytes"}
+        del Aw, xw, yw, Iw, Jw, Vw
+    except Exception as e:
+        res.setdefault("wide_keys", {})["spmv_c3"] = {"error": str(e)[:200]}
     # --- an EXTRA, never the headline: the same kernel on a matrix WITH column locality — config 3's shape (1M x 1M, 10 distinct rows
     #     per column) but rows within +-4096 of the column index (banded).  The x entries a stretch of rows gathers then sit in a few
     #     hundred KB: every gather is an L2 hit, the kernel leaves the fabric-bound regime of the uniformly random matrix
@@ -630,9 +690,50 @@ def extras(dsa, hip, torch, A, dev):
             t = time.perf_counter()
             yi, yv = A.mul((xi, xv))
             ts.append(time.perf_counter() - t)
-        sp.append({"stored_x_entries": int(len(xi)), "touched_rows": int(len(yi)), "ms": round(float(np.median(ts)) * 1e3, 3),
-                   "ms_max": round(max(ts) * 1e3, 3)})
+        row = {"stored_x_entries": int(len(xi)), "touched_rows": int(len(yi)), "ms": round(float(np.median(ts)) * 1e3, 3),
+               "ms_max": round(max(ts) * 1e3, 3)}
+        try:      # every operand in HBM (dsa_mat_spmv_sparse_dev: xi / xv in, yi / yv / count out): one event pair around 10 enqueued products
+            d_xi = torch.from_numpy(xi).to(dev); d_xv = torch.from_numpy(xv).to(dev)
+            d_yi = torch.empty(m3, dtype=torch.int64, device=dev); d_yv = torch.empty(m3, dtype=torch.float64, device=dev)
+            d_c = torch.zeros(1, dtype=torch.int64, device=dev)
+            f = lambda: A.mul_dev(d_xi.data_ptr(), d_xv.data_ptr(), len(xi), d_yi.data_ptr(), d_yv.data_ptr(), m3, d_c.data_ptr())
+            for _ in range(3):
+                f()
+            q0, q1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            q0.record(stream)
+            for _ in range(10):
+                f()
+            q1.record(stream)
+            torch.cuda.synchronize()
+            row["dev_us"] = round(q0.elapsed_time(q1) * 100, 1)
+            assert int(d_c.item()) == len(yi)
+            del d_xi, d_xv, d_yi, d_yv, d_c
+        except Exception as e:
+            row["dev_error"] = str(e)[:120]
+        sp.append(row)
     res["spmv_sparse_x"] = sp
+    # --- m[:, j] as a new device vector: built device to device; creation per call with the handles kept alive
+    try:
+        rngs = np.random.default_rng(5)
+        ms_, ns_ = 200000, 1000
+        sizes = {1: 16, 2: 1000, 3: 16000}
+        Is = np.concatenate([rngs.choice(ms_, c, replace=False) + 1 for c in sizes.values()] + [rngs.integers(1, ms_ + 1, 50000)])
+        Js = np.concatenate([np.full(c, j) for j, c in sizes.items()] + [rngs.integers(4, ns_ + 1, 50000)])
+        As = dsa.dynamicsparse(Is, Js, rngs.random(len(Is)) + 1.0, ms_, ns_, binding=hip)
+        sl = {}
+        for j, c in sizes.items():
+            for _ in range(10):
+                As.col_slice(j)
+            t = time.perf_counter()
+            for _ in range(200):
+                v_ = As.col_slice(j)          # (the previous slice is destroyed here: its blocks go back to the library's pool and are found again)
+            sl["%d_entries_us" % c] = round((time.perf_counter() - t) / 200 * 1e6, 1)
+            del v_
+        sl["note"] = "m[:, j] -> a new device vector, create + destroy per call through the Python mirror (ctypes + GC included); no cell crosses PCIe"
+        res["col_slice"] = sl
+        del As
+    except Exception as e:
+        res["col_slice"] = {"error": str(e)[:200]}
     # --- C2: 2^20-slot PMA, 100k ascending appends (batch A) and 100k uniform odd keys (batch B)
     n0 = 700000
     keys0 = np.arange(1, n0 + 1, dtype=np.int64) * 2

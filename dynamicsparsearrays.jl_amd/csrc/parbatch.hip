@@ -1192,9 +1192,11 @@ __global__ __launch_bounds__(PB_BLOCK) void k_apply(const DevBufs* bufs, Ctl* ct
     if (w >= d) return;
     int64_t* sK = reinterpret_cast<int64_t*>(pb_lds) + (size_t)wv * PB_MAX_W;
     double* sV = reinterpret_cast<double*>(pb_lds + (size_t)(PB_BLOCK / 64) * PB_MAX_W * sizeof(int64_t)) + (size_t)wv * PB_MAX_W;
+    // (plan and op are requested together: the op's address does not depend on the plan)
+    const int64_t oi = w < np ? db.pend[(size_t)rs->cur * PB_GMAX + w].op : i0 + (w - np);
+    const Op op = ops[oi];
     const Plan pl = plans[w];
     if (pl.action == PB_DEFER) return;                                          // deferred by the resolve step: pending for the next round
-    const Op op = ops[w < np ? db.pend[(size_t)rs->cur * PB_GMAX + w].op : i0 + (w - np)];
 #ifdef DSA_FP_CHECK
     if (rs->tight & FP_MODE_SHADOW) return;                       // (the prefix was applied one op after the other by k_fp_pre)
 #endif
