@@ -431,7 +431,7 @@ __global__ __launch_bounds__(PL_BLOCK) void k_plan(const DevBufs* bufs, const Ct
     __shared__ int sNWide;
     __shared__ int64_t sLoH[24], sHiH[24];                            // density bounds of the lower levels (run-ahead: the sealed zones)
     __shared__ int sMinConf;
-    if (tid < 24) { sLoH[tid] = ctl->lo[tid]; sHiH[tid] = ctl->hi[tid]; }
+    if (run_ahead && tid >= PL_BLOCK - 24) { const int q = tid - (PL_BLOCK - 24); sLoH[q] = ctl->lo[q]; sHiH[q] = ctl->hi[q]; }      // (the LAST wave: fewest plans to load)
     for (int k = tid; k < NB; k += PL_BLOCK) sHead[k] = -1;
     if (tid == 0) { sNWide = 0; sNConf = 0; sNApplied = 0; sNDeferred = 0; sFault = 0; sMinConf = INT32_MAX; }
     for (int j = tid; j < G + 8 && j < PB_GMAX; j += PL_BLOCK) { sConf[j] = 0; sDefer[j] = 0; sSimple[j] = 0; sZid[j] = 0; sAct[j] = PB_BARRIER; }
@@ -767,8 +767,9 @@ __global__ __launch_bounds__(PL_BLOCK) void k_plan(const DevBufs* bufs, const Ct
         // one by one: ~500 atomics per round on the same words); zone check of the pending ones
         int dn = 0, rn = 0, na = 0, nd = 0, bad = 0;
         unsigned int rw = 0u;
+        const bool plain_round = sMinConf == INT32_MAX && np == 0;          // no conflict, nothing pending: every op of [0, dd) is applied
         for (int j = tid; j < dd; j += PL_BLOCK) {
-            if (sConf[j] || sDefer[j]) { ++nd; continue; }
+            if (!plain_round && (sConf[j] || sDefer[j])) { ++nd; continue; }
             ++na;
             dn += sDn[j]; const unsigned int w2 = sRebW[j]; if (w2) { ++rn; rw += w2; }
             if (j < np) {                                              // deferred earlier: it must still act inside the zone it was sealed in
@@ -785,15 +786,19 @@ __global__ __launch_bounds__(PL_BLOCK) void k_plan(const DevBufs* bufs, const Ct
         }
         if (tid == 0 && sB == 0 && np > 0 && pend[0].zlo != 0) bad = 1;          // a sealed op that cannot be planned any more
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            dn += __shfl_xor(dn, o, 64); rn += __shfl_xor(rn, o, 64); rw += __shfl_xor(rw, o, 64);
-            na += __shfl_xor(na, o, 64); nd += __shfl_xor(nd, o, 64); bad |= __shfl_xor(bad, o, 64);
+        for (int o = 32; o > 0; o >>= 1) { dn += __shfl_xor(dn, o, 64); rn += __shfl_xor(rn, o, 64); rw += __shfl_xor(rw, o, 64); }
+        if (!plain_round) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { na += __shfl_xor(na, o, 64); nd += __shfl_xor(nd, o, 64); bad |= __shfl_xor(bad, o, 64); }
         }
         if ((tid & 63) == 0) {
             if (dn != 0 || rn != 0) { atomicAdd(&sSumDn, dn); atomicAdd(&sSumRebN, rn); atomicAdd(&sSumRebW, rw); }
-            if (na) atomicAdd(&sNApplied, na);
-            if (nd) atomicAdd(&sNDeferred, nd);
-            if (bad) atomicExch(&sFault, 1);
+            if (plain_round) { if (tid == 0) sNApplied = dd; }
+            else {
+                if (na) atomicAdd(&sNApplied, na);
+                if (nd) atomicAdd(&sNDeferred, nd);
+                if (bad) atomicExch(&sFault, 1);
+            }
         }
     }
     __syncthreads();
@@ -849,7 +854,6 @@ __global__ __launch_bounds__(PL_BLOCK) void k_plan(const DevBufs* bufs, const Ct
         np_next = (int)total;
         cursor_next = i0 + (dd > np ? dd - np : 0);
     }
-    __syncthreads();
     if (tid == 0) {
 #ifdef DSA_PB_PROF
         printf("resolve: G %d np %d sB %d sC %d applied %d deferred %d nconf %d | clk: entry->planned %lld ->ticket %lld | load %lld conflicts %lld seal %lld decide+list %lld\n", G, np, sB, sC, na,

@@ -7,7 +7,7 @@ TAG=${1:-soak}; SEC=${2:-300}; MODE=${3:-1}; SEED=${4:-70000}
 C=$R/dynamicsparsearrays.jl_amd/csrc
 O=$R/gpurun_out/$TAG
 mkdir -p $O
-export DSA_LIBRARY=$C/libdsa_hip_fpcheck.so DSA_FP_MODE=$MODE
+export DSA_DEV=1 DSA_LIBRARY=$C/libdsa_hip_fpcheck.so DSA_FP_MODE=$MODE
 rc=0
 timeout -k 10 $((SEC + 120)) python tools/fuzz.py $SEC $SEED > $O/mix_mode$MODE.log 2>&1 || rc=1
 tail -1 $O/mix_mode$MODE.log
