@@ -299,6 +299,7 @@ hipError_t launch_merge_axpby(KeyArr ka, const double* va, int64_t na, double al
 hipError_t launch_widen_keys(const void* src32, void* dst64, int64_t n, hipStream_t stream);
 // a structure made of fresh (uninitialised) blocks in ONE launch: both occupancy bitmaps and the status table of the grid rebalance
 // zeroed, the control block written from the argument (no copy command)
+hipError_t launch_store_ctl(Ctl* d_ctl, const Ctl& ctl, hipStream_t stream);
 hipError_t launch_init_fresh(uint64_t* occ0, uint64_t* occ1, int64_t occ_words, unsigned long long* status, int64_t status_words,
                              Ctl* d_ctl, const Ctl& ctl, hipStream_t stream);
 // clears occupancy bits of slots [from, to] (1-based, inclusive); from/to word-aligned or inside one word

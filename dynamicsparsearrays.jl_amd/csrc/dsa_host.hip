@@ -2366,7 +2366,9 @@ int32_t dsa_vec_dev_relayout(dsa_vec_t* h, int32_t mode) {
         if (mode == 3) { c.capacity *= 2; c.nb_segments *= 2; c.height += 1; } else { c.capacity /= 2; c.nb_segments /= 2; c.height -= 1; }
         compute_bounds(P);
         root_rebalance(P, old_cap, c.capacity, m, false);
-        upload_ctl(P);
+        // (stream-ordered like the write path's own _extend! — which re-uploads the block with its relaunch —: no host wait in the hook)
+        hipError_t e = launch_store_ctl(P.d_ctl, c, P.stream);
+        if (e != hipSuccess) fail(DSA_EHIP, std::string("control block store: ") + hipGetErrorString(e));
     } else fail(DSA_EARG, "mode must be 1..4");
     API_CATCH
 }

@@ -726,6 +726,18 @@ __global__ __launch_bounds__(256) void k_init_fresh(FreshInit a) {
         for (int i = threadIdx.x; i < (int)(sizeof(Ctl) / 8); i += blockDim.x) dst[i] = src[i];
     }
 }
+// the control block written from a launch argument (stream-ordered, no copy command: the pinned mirror is not a DMA source)
+struct CtlStore { Ctl* d_ctl; Ctl ctl; };
+__global__ __launch_bounds__(256) void k_store_ctl(CtlStore a) {
+    const int64_t* src = reinterpret_cast<const int64_t*>(&a.ctl);
+    int64_t* dst = reinterpret_cast<int64_t*>(a.d_ctl);
+    for (int i = threadIdx.x; i < (int)(sizeof(Ctl) / 8); i += blockDim.x) dst[i] = src[i];
+}
+hipError_t launch_store_ctl(Ctl* d_ctl, const Ctl& ctl, hipStream_t stream) {
+    CtlStore a{d_ctl, ctl};
+    hipLaunchKernelGGL(k_store_ctl, dim3(1), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
 hipError_t launch_init_fresh(uint64_t* occ0, uint64_t* occ1, int64_t occ_words, unsigned long long* status, int64_t status_words,
                              Ctl* d_ctl, const Ctl& ctl, hipStream_t stream) {
     FreshInit a{occ0, occ1, occ_words, status, status_words, d_ctl, ctl};
