@@ -280,9 +280,6 @@ hipError_t launch_permute(KeyArr src_keys, const double* src_vals, const uint64_
 hipError_t launch_compact_range(KeyArr keys, const double* vals, const uint64_t* occ, int64_t from, int64_t to,
                                 KeyArr out_keys, double* out_vals, int64_t out_cap, RebalanceWork* work, int64_t* count,
                                 hipStream_t stream);
-// sparse-x SpMV result: touched flags (bytes, or the doubles of a pattern pass) -> (row, y[row]) pairs in ascending row order
-hipError_t launch_touched_compact(const uint8_t* bytes, const double* pattern, const double* y, int64_t ny, uint64_t* bm,
-                                  int64_t* out_i, double* out_v, RebalanceWork* work, int64_t* count, hipStream_t stream);
 // sparse-x product (sparsex.hip): accumulate driven by x's stored entries, touched-row bitmap of a pattern pass, count + emit
 hipError_t launch_spx_accum(KeyArr keys, const double* vals, const uint64_t* occ, int64_t capacity, const int64_t* sems, const int64_t* col_keys,
                             const uint8_t* col_live, int64_t table_len, const int64_t* xi, const double* xv, int64_t nx, double* acc,
@@ -508,9 +505,5 @@ hipError_t launch_spmv_scatter(KeyArr keys, const double* vals, const uint64_t* 
 
 // sparse x driven by its stored entries over the orientation whose partitions are x's index space (colmajor for mat*v):
 // y (dense, zeroed here) += x_j * column j ; touched[row] = 1 for every row that received a term
-hipError_t launch_spmv_xdriven(KeyArr keys, const double* vals, const uint64_t* occ, int64_t capacity,
-                               const int64_t* sems, const int64_t* col_keys, const uint8_t* col_live, int64_t table_len,
-                               const int64_t* xi, const double* xv, int64_t nx, double* y, uint8_t* touched, int64_t ny,
-                               hipStream_t stream);
 
 }  // namespace dsa

@@ -540,64 +540,6 @@ hipError_t launch_merge_axpby(KeyArr ka, const double* va, int64_t na, double al
     return hipGetLastError();
 }
 
-// ---- result of a sparse-x SpMV: (row, value) of the touched rows in ascending row order (the sparsevec of _mul_output,
-// src/operations.jl:11-12,127-134) — K-pack over a bitmap of touched rows instead of the occupancy bitmap
-__global__ __launch_bounds__(256) void k_touched_bitmap(const uint8_t* __restrict__ bytes, const double* __restrict__ pattern,
-                                                        int64_t ny, uint64_t* __restrict__ bm, int64_t nwords_padded) {
-    const int lane = threadIdx.x & 63;
-    const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (w >= nwords_padded) return;
-    const int64_t r = (w << 6) + lane;
-    bool t = false;
-    if (r < ny) t = bytes != nullptr ? bytes[r] != 0 : pattern[r] != 0.0;
-    const uint64_t b = __ballot(t);
-    if (lane == 0) bm[w] = b;
-}
-__global__ __launch_bounds__(64) void k_compact_touched(const uint64_t* __restrict__ bm, int64_t nwords, const uint32_t* __restrict__ tile_off,
-                                                        const double* __restrict__ y, int64_t* __restrict__ out_i, double* __restrict__ out_v) {
-    const int lane = threadIdx.x;
-    const int64_t t = blockIdx.x;
-    const int64_t wl = t * SRC_TILE_WORDS + lane;
-    const uint64_t myword = wl < nwords ? bm[wl] : 0ull;
-    const uint32_t myoff = wave_excl_scan((uint32_t)popc64(myword));
-    const int64_t base = tile_off[t];
-    for (int w = 0; w < SRC_TILE_WORDS; ++w) {
-        const uint64_t mask = __shfl(myword, w, 64);
-        const int64_t woff = base + (int64_t)__shfl(myoff, w, 64);
-        if (mask == 0) continue;
-        if ((mask >> lane) & 1ull) {
-            const int64_t r = woff + popc64(mask & mask_lt(lane));
-            const int64_t row0 = ((t * SRC_TILE_WORDS + w) << 6) + lane;
-            out_i[r] = row0 + 1;
-            out_v[r] = y[row0];
-        }
-    }
-}
-// touched flags (one byte per row, or the doubles of a pattern pass) -> bitmap -> compacted (row, y[row]) pairs on the device;
-// *count (host) = number of touched rows.  Synchronises the stream once (the count sizes the caller's copy-out).
-hipError_t launch_touched_compact(const uint8_t* bytes, const double* pattern, const double* y, int64_t ny, uint64_t* bm,
-                                  int64_t* out_i, double* out_v, RebalanceWork* work, int64_t* count, hipStream_t stream) {
-    *count = 0;
-    if (ny <= 0) return hipSuccess;
-    const int64_t nwords = (ny + 63) >> 6;
-    const int64_t ntiles = (nwords + SRC_TILE_WORDS - 1) / SRC_TILE_WORDS;
-    const int64_t nwp = ntiles * SRC_TILE_WORDS;
-    if (ntiles + 1 > work->tiles_cap) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_touched_bitmap, dim3((unsigned)((nwp + 3) / 4)), dim3(256), 0, stream, bytes, pattern, ny, bm, nwp);
-    hipLaunchKernelGGL(k_tile_count, dim3((unsigned)((ntiles + CNT_TILES - 1) / CNT_TILES)), dim3(256), 0, stream, (const uint64_t*)bm, (int64_t)0,
-                       ny - 1, (int64_t)0, nwords, ntiles, work->tile_cnt);
-    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, stream, work->tile_cnt, work->tile_off, ntiles);
-    uint32_t total = 0;
-    hipError_t e = hipMemcpyAsync(&total, work->tile_off + ntiles, sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
-    if (e != hipSuccess) return e;
-    e = hipStreamSynchronize(stream);
-    if (e != hipSuccess) return e;
-    *count = total;
-    if (total == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_compact_touched, dim3((unsigned)ntiles), dim3(64), 0, stream, (const uint64_t*)bm, nwords, work->tile_off, y, out_i, out_v);
-    return hipGetLastError();
-}
-
 // ---- K-permute: order-preserving move between two occupancy bitmaps ---------------------------------------------------
 // The cells of a PMA always keep their relative order, so the layout after ANY sequence of inserts is fully determined by
 // the final occupancy bitmap: the r-th cell (old bitmap order, followed by the appended cells in op order) sits at the r-th

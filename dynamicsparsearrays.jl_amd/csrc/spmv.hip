@@ -455,74 +455,7 @@ __global__ __launch_bounds__(SP_BLOCK) void k_spmv_gather(KeyArr keys, const dou
     }
 }
 
-// ---- sparse x, driven by x's stored entries ------------------------------------------------------------------------
-// The literal shape of _mul (src/operations.jl:107-135): for every stored (j, x_j) locate the column partition of j
-// (64-ary search of the sorted live column keys, one wave per entry), walk its slot range — semaphore+1 .. next live
-// semaphore-1 (src/operations.jl:81-95) — and accumulate x_j * coeff into y[row] with fp64 atomics; every touched
-// row is flagged (a row whose products cancel or are zero still belongs to the result, src/operations.jl:101).
-// Work is proportional to the cells of the matched columns, not to the capacity.
-__global__ __launch_bounds__(256) void k_spmv_xdriven(KeyArr keys, const double* __restrict__ vals,
-                                                      const uint64_t* __restrict__ occ, int64_t capacity,
-                                                      const int64_t* __restrict__ sems, const int64_t* __restrict__ col_keys,
-                                                      const uint8_t* __restrict__ col_live, int64_t table_len,
-                                                      const int64_t* __restrict__ xi, const double* __restrict__ xv, int64_t nx,
-                                                      double* __restrict__ y, uint8_t* __restrict__ touched, int64_t ny) {
-    const int lane = threadIdx.x & 63;
-    const int64_t e = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (e >= nx) return;
-    const int64_t col = xi[e];
-    const double xval = xv[e];
-    // largest live table index with col_keys <= col  (64-ary narrowing; live keys ascend with the index)
-    int64_t L = 0, H = table_len;
-    while (H - L > 64) {
-        const int64_t width = H - L;
-        const int64_t p = L + (width * (lane + 1)) / 64;
-        int64_t q = p;
-        while (q > L && !col_live[q - 1]) --q;
-        bool pr = true;
-        if (q > L) pr = col_keys[q - 1] <= col;
-        const uint64_t nb = ~__ballot(pr);
-        const int j = nb ? __ffsll((unsigned long long)nb) - 1 : 64;
-        const int64_t pj = L + (width * (j + 1)) / 64;
-        const int64_t pj1 = L + (width * j) / 64;
-        if (j < 64) H = pj - 1;
-        L = pj1;
-    }
-    const int64_t p = L + 1 + lane;
-    bool viol = false;
-    if (p <= H && col_live[p - 1]) viol = col_keys[p - 1] > col;
-    const uint64_t b = __ballot(viol);
-    int64_t pos = b ? L + __ffsll((unsigned long long)b) - 1 : H;
-    while (pos > 0 && !col_live[pos - 1]) --pos;
-    if (pos == 0 || col_keys[pos - 1] != col) return;            // no such column: x entry skipped (src/operations.jl:76-79)
-    const int64_t from = sems[pos - 1] + 1;
-    int64_t nxt = pos + 1;
-    while (nxt <= table_len && sems[nxt - 1] == 0) ++nxt;
-    const int64_t to = nxt <= table_len ? sems[nxt - 1] - 1 : capacity;
-    for (int64_t s = from + lane; s <= to; s += 64) {
-        if ((occ[(s - 1) >> 6] >> ((s - 1) & 63)) & 1ull) {
-            const int64_t row = keys[s - 1];
-            if (row >= 1 && row <= ny) {
-                atomicAdd(&y[row - 1], xval * vals[s - 1]);
-                touched[row - 1] = 1;
-            }
-        }
-    }
-}
-
-hipError_t launch_spmv_xdriven(KeyArr keys, const double* vals, const uint64_t* occ, int64_t capacity,
-                               const int64_t* sems, const int64_t* col_keys, const uint8_t* col_live, int64_t table_len,
-                               const int64_t* xi, const double* xv, int64_t nx, double* y, uint8_t* touched, int64_t ny,
-                               hipStream_t stream) {
-    hipError_t e = hipMemsetAsync(y, 0, (size_t)ny * sizeof(double), stream);
-    if (e != hipSuccess) return e;
-    e = hipMemsetAsync(touched, 0, (size_t)ny, stream);
-    if (e != hipSuccess) return e;
-    if (nx > 0)
-        hipLaunchKernelGGL(k_spmv_xdriven, dim3((unsigned)((nx + 3) / 4)), dim3(256), 0, stream, keys, vals, occ, capacity, sems,
-                           col_keys, col_live, table_len, xi, xv, nx, y, touched, ny);
-    return hipGetLastError();
-}
+// (the sparse-x product driven by x's stored entries lives in sparsex.hip since round 6: k_spx_accum)
 
 // dense form of a sparse x on the device: xd[j] = x_j, xf[j] = 1 for every STORED entry (explicit zeros included: the
 // touched-row pattern of _mul counts stored entries, src/operations.jl:101); both vectors zeroed first
