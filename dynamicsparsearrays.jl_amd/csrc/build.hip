@@ -44,7 +44,7 @@ struct BuildCtl {
     unsigned long long nlong;              // runs handed to k_fold_long
     unsigned long long zeros;              // k_minmax: bit 0 = a partition key is 0, bit 1 = a key is 0 (the reserved semaphore key)
 };
-struct LongRun { int64_t next; int64_t pos; double acc; uint64_t comp; };
+struct LongRun { int64_t next; int64_t pos; double acc; uint64_t comp; int64_t dpos; };
 
 // min / max of the key arrays when the caller does not know them: per-workgroup partials, folded by the workgroup that finishes
 // last (64-bit signed atomic min / max from thousands of waves on four words cost 450 us at 10 M triples)
@@ -377,7 +377,11 @@ __global__ __launch_bounds__(RS_BLOCK) void k_bf_emit(const uint64_t* __restrict
                                                       int64_t pmin, int64_t kmin, int mode, int32_t combine,
                                                       const uint32_t* __restrict__ off_c, const uint32_t* __restrict__ off_p,
                                                       KeyArr out_keys, double* __restrict__ out_vals, int64_t* __restrict__ part_keys,
-                                                      uint32_t* __restrict__ scell, BuildCtl* ctl, LongRun* __restrict__ queue) {
+                                                      uint32_t* __restrict__ scell, BuildCtl* ctl, LongRun* __restrict__ queue,
+                                                      uint64_t* __restrict__ der_comp, double* __restrict__ der_val, int pbits) {
+    // der_comp / der_val (or nullptr): the folded cells once more, in this orientation's order, as the composites of the TWIN orientation
+    // — (key - kmin) << pbits | (partition - pmin) — with their values: what the twin's builder sorts by its own partition bits
+    // alone instead of starting from the caller's triples again (mat_build_both_dev)
     __shared__ uint32_t sC[RS_WAVES], sP[RS_WAVES];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int64_t tile0 = (int64_t)blockIdx.x * RS_TILE;
@@ -431,12 +435,16 @@ __global__ __launch_bounds__(RS_BLOCK) void k_bf_emit(const uint64_t* __restrict
                     }
                     if (t < n && len == FOLD_INLINE && (comp[t] >> ibits) == cc) {      // a long run: a wave finishes it (k_fold_long)
                         const unsigned long long q = atomicAdd(&ctl->nlong, 1ull);
-                        LongRun lr; lr.next = t; lr.pos = pos; lr.acc = acc; lr.comp = cc;
+                        LongRun lr; lr.next = t; lr.pos = pos; lr.acc = acc; lr.comp = cc; lr.dpos = (int64_t)rank - 1;
                         queue[q] = lr;
                     }
                 }
                 out_keys[pos] = key;
                 out_vals[pos] = acc;
+                if (der_comp != nullptr) {
+                    der_comp[rank - 1] = ((cc & kmask) << pbits) | (kbits >= 64 ? 0ull : (cc >> kbits));
+                    der_val[rank - 1] = acc;
+                }
                 if (mode == 0 && ((fpb[j] >> lane) & 1ull)) {
                     out_keys[pos - 1] = SEM_KEY;
                     out_vals[pos - 1] = (double)pid;
@@ -450,7 +458,8 @@ __global__ __launch_bounds__(RS_BLOCK) void k_bf_emit(const uint64_t* __restrict
 
 // the rest of the duplicate runs longer than FOLD_INLINE: one wave per run, 64 values per coalesced load, folded in order
 __global__ __launch_bounds__(64) void k_fold_long(const uint64_t* __restrict__ comp, const double* __restrict__ val, int64_t n, int ibits, int32_t combine,
-                                                  const BuildCtl* ctl, const LongRun* __restrict__ queue, double* __restrict__ out_vals) {
+                                                  const BuildCtl* ctl, const LongRun* __restrict__ queue, double* __restrict__ out_vals,
+                                                  double* __restrict__ der_val) {
     const uint64_t imask = ibits > 0 ? ((1ull << ibits) - 1ull) : 0ull;
     const int lane = threadIdx.x;
     const unsigned long long nl = ctl->nlong;
@@ -469,7 +478,7 @@ __global__ __launch_bounds__(64) void k_fold_long(const uint64_t* __restrict__ c
             if (cnt < 64) break;
             t += 64;
         }
-        if (lane == 0) out_vals[lr.pos] = acc;
+        if (lane == 0) { out_vals[lr.pos] = acc; if (der_val != nullptr) der_val[lr.dpos] = acc; }
     }
 }
 
@@ -806,20 +815,81 @@ hipError_t build_prepare(const int64_t* d_part, const int64_t* d_key, const doub
     return hipGetLastError();
 }
 
+// ---- the TWIN orientation of a matrix from the cells its sibling has just emitted (mat_build_both_dev) ------------------------------
+// The sibling's emit leaves the n folded cells as composites of THIS orientation — partition bits above the key bits — in the
+// sibling's order: ascending by (key, partition).  A stable sort by the partition bits alone (ceil(pbits / 8) passes instead of
+// ceil((pbits + kbits) / 8), 16-byte records: word + value) puts them into (partition, key) order; nothing is folded (the cells are
+// distinct), no composite pass, no gather of the values at the emit.  build_derived_alloc: the scratch, whose comp[0] / val[0] the
+// sibling's emit fills; build_derived_sort: passes, flags, counts (one stream wait); then build_emit as for any other build.
+hipError_t build_derived_alloc(BuildScratch& s, int64_t n, int kbits, int pbits, int64_t kmin, int64_t pmin, hipStream_t stream) {
+    s = BuildScratch();
+    s.n = n; s.stream = stream;
+    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const int64_t nblocks = (n + RS_TILE - 1) / RS_TILE;
+    BCHK(pinned_ctl_get(&s.h_ctl));
+    const size_t nn = (size_t)n;
+    const size_t b_ctl = up(sizeof(BuildCtl)), b_gh = up(8 * RS_BINS * 4 + 4 * MM_BLOCKS * 8 + 64), b_comp = up(nn * 8),
+                 b_hist = up((size_t)RS_BINS * nblocks * 4), b_cnt = up((size_t)(nblocks + 1) * 4), b_queue = up((nn / FOLD_INLINE + 2) * sizeof(LongRun));
+    BCHK(pool_alloc(&s.base, b_ctl + b_gh + 2 * b_comp + b_hist + 2 * b_cnt + b_queue));
+    char* q = static_cast<char*>(s.base);
+    auto take = [&q](size_t b) { char* r = q; q += b; return r; };
+    s.d_ctl = take(b_ctl); s.ghist = (uint32_t*)take(b_gh);
+    s.comp[0] = (uint64_t*)take(b_comp); s.comp[1] = (uint64_t*)take(b_comp);
+    s.hist = (uint32_t*)take(b_hist); s.cnt_c = (uint32_t*)take(b_cnt); s.cnt_p = (uint32_t*)take(b_cnt);
+    s.queue = take(b_queue); s.scell = nullptr;
+    BCHK(pool_alloc(&s.base_val, 2 * b_comp));
+    s.val[0] = static_cast<double*>(s.base_val); s.val[1] = reinterpret_cast<double*>(static_cast<char*>(s.base_val) + b_comp);
+    s.kmin = kmin; s.pmin = pmin; s.kbits = kbits; s.pbits = pbits; s.ibits = 0;
+    return hipSuccess;
+}
+hipError_t build_derived_sort(BuildScratch& s, int64_t counts[2], hipStream_t stream, const std::function<void()>* while_sorting) {
+    const int64_t n = s.n;
+    const int64_t nblocks = (n + RS_TILE - 1) / RS_TILE;
+    BuildCtl* dctl = static_cast<BuildCtl*>(s.d_ctl);
+    BuildCtl* hctl = static_cast<BuildCtl*>(s.h_ctl);
+    static PerDeviceOnce once;
+    const size_t lds_bytes = (size_t)RS_TILE * (sizeof(uint64_t) + sizeof(double));
+    BCHK(once.run([&] { return hipFuncSetAttribute(reinterpret_cast<const void*>(k_rs_scatter<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); }));
+    const int npass = (s.pbits + 7) / 8;
+    const dim3 grid((unsigned)nblocks), block(RS_BLOCK);
+    int cur = 0;
+    for (int pass = 0; pass < npass; ++pass) {
+        const int shift = s.kbits + 8 * pass;
+        uint32_t* dtot = s.ghist + pass * RS_BINS;
+        hipLaunchKernelGGL(k_rs_hist, grid, block, 0, stream, (const uint64_t*)s.comp[cur], n, shift, s.hist, nblocks);
+        hipLaunchKernelGGL(k_rs_scan, dim3(RS_BINS), block, 0, stream, s.hist, dtot, nblocks);
+        hipLaunchKernelGGL(k_rs_scatter<true>, grid, block, lds_bytes, stream, (const uint64_t*)s.comp[cur], (const double*)s.val[cur], n, shift, (const uint32_t*)s.hist,
+                           (const uint32_t*)dtot, s.comp[1 - cur], s.val[1 - cur], nblocks);
+        cur = 1 - cur;
+    }
+    s.sorted = cur;
+    s.vsorted = s.val[cur];
+    hipLaunchKernelGGL(k_bf_count, grid, block, 0, stream, (const uint64_t*)s.comp[cur], n, s.kbits, 0, 1, s.cnt_c, s.cnt_p);
+    hipLaunchKernelGGL(k_bf_scan, dim3(1), dim3(1024), 0, stream, s.cnt_c, s.cnt_p, nblocks, dctl);
+    BCHK(hipMemcpyAsync(hctl, dctl, sizeof(BuildCtl), hipMemcpyDeviceToHost, stream));
+    if (while_sorting && *while_sorting) {
+        try { (*while_sorting)(); } catch (...) { (void)hipStreamSynchronize(stream); throw; }
+    }
+    BCHK(hipStreamSynchronize(stream));
+    counts[0] = (int64_t)hctl->ncells; counts[1] = (int64_t)hctl->nparts;
+    return hipGetLastError();
+}
+
 static hipError_t emit_wide(const double* d_val, int32_t combine, BuildScratch& s, KeyArr out_keys, double* out_vals, int64_t* part_keys, int mode,
                             int64_t nparts_explicit, hipStream_t stream, bool wait_and_free);
 
 hipError_t build_emit(const double* d_val, int32_t combine, BuildScratch& s, KeyArr out_keys, double* out_vals,
-                      int64_t* part_keys, int mode, int64_t nparts_explicit, hipStream_t stream, bool wait_and_free) {
+                      int64_t* part_keys, int mode, int64_t nparts_explicit, hipStream_t stream, bool wait_and_free,
+                      uint64_t* der_comp, double* der_val) {
     if (s.wide_path) return emit_wide(d_val, combine, s, out_keys, out_vals, part_keys, mode, nparts_explicit, stream, wait_and_free);
     const int64_t nblocks = (s.n + RS_TILE - 1) / RS_TILE;
     BuildCtl* dctl = static_cast<BuildCtl*>(s.d_ctl);
     const uint64_t* comp = s.comp[s.sorted];
     hipLaunchKernelGGL(k_bf_emit, dim3((unsigned)nblocks), dim3(RS_BLOCK), 0, stream, comp, s.vsorted, s.n, s.kbits, s.ibits, s.pmin, s.kmin, mode, combine,
                        (const uint32_t*)s.cnt_c, (const uint32_t*)s.cnt_p, out_keys, out_vals, part_keys, mode == 2 ? s.scell : (uint32_t*)nullptr,
-                       dctl, static_cast<LongRun*>(s.queue));
+                       dctl, static_cast<LongRun*>(s.queue), der_comp, der_val, s.pbits);
     hipLaunchKernelGGL(k_fold_long, dim3(256), dim3(64), 0, stream, comp, s.vsorted, s.n, s.ibits, combine, (const BuildCtl*)dctl,
-                       (const LongRun*)s.queue, out_vals);
+                       (const LongRun*)s.queue, out_vals, der_val);
     if (mode == 2 && nparts_explicit > 0)
         hipLaunchKernelGGL(k_emit_sems, dim3((unsigned)((nparts_explicit + 255) / 256)), dim3(256), 0, stream, comp, s.kbits, s.ibits, s.pmin,
                            (const uint32_t*)s.scell, s.n, nparts_explicit, out_keys, out_vals);

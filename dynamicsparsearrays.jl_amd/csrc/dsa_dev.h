@@ -347,7 +347,12 @@ hipError_t build_prepare(const int64_t* d_part, const int64_t* d_key, const doub
 // ids 1..nparts_explicit in d_part (PackedCSC: empty partitions keep their semaphore)
 // wait_and_free = false: the kernels are only enqueued; the caller waits for the stream itself and releases the scratch with build_abort
 hipError_t build_emit(const double* d_val, int32_t combine, BuildScratch& s, KeyArr out_keys, double* out_vals,
-                      int64_t* part_keys, int mode, int64_t nparts_explicit, hipStream_t stream, bool wait_and_free = true);
+                      int64_t* part_keys, int mode, int64_t nparts_explicit, hipStream_t stream, bool wait_and_free = true,
+                      uint64_t* der_comp = nullptr, double* der_val = nullptr);
+// the twin orientation of a matrix from the cells its sibling's emit leaves behind (der_comp / der_val above == comp[0] / val[0] of the
+// twin's scratch): build_derived_alloc before the sibling's emit, build_derived_sort behind it, then build_emit on the twin's scratch
+hipError_t build_derived_alloc(BuildScratch& s, int64_t n, int kbits, int pbits, int64_t kmin, int64_t pmin, hipStream_t stream);
+hipError_t build_derived_sort(BuildScratch& s, int64_t counts[2], hipStream_t stream, const std::function<void()>* while_sorting = nullptr);
 void build_abort(BuildScratch& s);
 // a vector of up to 1024 entries by one launch; io = pinned landing area (see k_build_small_vec)
 hipError_t launch_build_small_vec(int64_t* io, int n, int cap, int32_t combine, KeyArr out_k, double* out_v, unsigned long long seq, hipStream_t stream);

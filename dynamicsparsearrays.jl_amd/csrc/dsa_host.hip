@@ -92,6 +92,7 @@ static const char* const k_dev_switches[] = {
     "DSA_BARRIER_CHUNK",  // n: first sequencer chunk after a stop at an op that cannot be planned
     "DSA_BUILD_IDXSORT",  // 0: K-build always carries the values through the sort
     "DSA_BUILD_MINMAX",   // 1: key ranges by the device scan even when the host knows them
+    "DSA_BUILD_TWIN",     // 0: the two orientations of a matrix are built independently from the triples
     "DSA_BUILD_WIDE",     // 1: K-build through the general (> 64-bit composite) path
     "DSA_BURST_GRAPH",    // 0: rounds as eager launches instead of a cached graph
     "DSA_COUNT_MODEL",    // 0: bitmap-only append replay (no model v2)
@@ -1420,6 +1421,102 @@ void pma_build_dev(Pma& P, const int64_t* d_part, const int64_t* d_key, const do
     }
 }
 
+// Both orientations of a matrix from ONE sort of the caller's triples (round 6).  A = the orientation whose partitions are d_part
+// (sorted as before: composite of (partition, key) + input index, values gathered at the emit); its emit also leaves the folded cells
+// as composites of the TWIN B — partition bits and key bits swapped — which B's builder only has to sort by its partition bits
+// (build_derived_*: 3 passes of 16-byte records instead of 5 passes + a composite pass, and no 10 M random gathers at its emit).
+// B's sort runs on B's stream behind A's emit (an event) while A's spread is still running; A's slot buffers and tables are sized
+// while A's sort runs, B's while B's.  Returns false — with nothing done to B and A built as usual — when A's composite does not fit
+// 64 bits (the general path of build.hip): the caller then builds B from the triples.
+bool mat_build_both_dev(Pma& A, Pma& B, const int64_t* d_part, const int64_t* d_key, const double* d_val, int64_t nnz, bool wideA, bool wideB,
+                        KeyRange part_range, KeyRange key_range) {
+    A.wide = wideA; B.wide = wideB;
+    BuildScratch sa, sb;
+    int64_t ca[2] = {0, 0}, cb[2] = {0, 0};
+    bool sb_live = false;
+    auto size_for = [](Pma& P, int64_t ncells, int64_t np) {
+        P.h_ctl->nb_partitions = np; P.h_ctl->table_len = np;
+        ensure_tables(P, std::max<int64_t>(2 * np, 64));
+        const int64_t n = ncells + np;
+        set_geometry_for_new(P, capacity_for(n), n);
+        ensure_capacity_alloc(P, 2 * P.capacity());
+        if (np > 0) HIPCHK(hipMemsetAsync(P.col_live, 1, (size_t)np, P.stream));
+        ++P.layout_epoch;
+        P.h_ctl->stat_rebalances = 0; P.h_ctl->stat_window_slots = 0;
+        if (P.capacity() != P.h_ctl->segment_capacity) { P.h_ctl->stat_rebalances = 1; P.h_ctl->stat_window_slots = P.capacity(); }
+        return n;
+    };
+    // best-effort sizing under the sort kernels (see pma_build_dev): the upper bounds, when a quarter of the free memory covers them
+    // (the memsets of the fresh blocks — tables, bitmaps: ~60 us per orientation — go to the OTHER orientation's stream, idle at that
+    //  moment, instead of queueing behind the sort on the orientation's own; its emit waits for them through an event)
+    auto prealloc_for = [&](Pma& P, int64_t cells_ub, const KeyRange& pr, hipStream_t side) {
+        return [&P, cells_ub, pr, side] {
+            if (P.cap_alloc != 0 || P.sems != nullptr) return;
+            struct Swap { Pma& P; hipStream_t own; Swap(Pma& p, hipStream_t s) : P(p), own(p.stream) { P.stream = s; }
+                          ~Swap() { P.stream = own; } };
+            const int64_t np_ub = pr.known() ? std::min<int64_t>(cells_ub, (int64_t)std::min<uint64_t>((uint64_t)pr.hi - (uint64_t)pr.lo, (uint64_t)cells_ub) + 1) : cells_ub;
+            const int64_t slots_ub = 2 * capacity_for(cells_ub + np_ub);
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return; }
+            if (2.0 * (double)slots_ub * (double)(P.kb() + sizeof(double)) + 68.0 * (double)np_ub > 0.25 * ((double)free_b + (double)pool_idle_bytes())) return;
+            try {
+                {
+                    Swap sw(P, side);
+                    ensure_tables(P, std::max<int64_t>(2 * np_ub, 64)); ensure_capacity_alloc(P, slots_ub);
+                }
+                if (P.ev_handoff == nullptr) HIPCHK(hipEventCreateWithFlags(&P.ev_handoff, hipEventDisableTiming));
+                HIPCHK(hipEventRecord(P.ev_handoff, side));
+                HIPCHK(hipStreamWaitEvent(P.stream, P.ev_handoff, 0));
+            } catch (const Fail&) {
+                (void)hipGetLastError(); (void)hipStreamSynchronize(side); (void)hipStreamSynchronize(P.stream);
+                pma_free_buffers(P); P.cap_alloc = 0; P.occ_words = 0; P.occ_dirty[0] = P.occ_dirty[1] = 0;
+                pool_free(P.sems); pool_free(P.col_keys); pool_free(P.col_live);
+                P.sems = nullptr; P.col_keys = nullptr; P.col_live = nullptr; P.h_ctl->table_cap = 0;
+            }
+        };
+    };
+    try {
+        const std::function<void()> pa = prealloc_for(A, nnz, part_range, B.stream);
+        hipError_t e = build_prepare(d_part, d_key, d_val, nnz, part_range, key_range, sa, ca, A.stream, &pa);
+        if (e != hipSuccess) fail(DSA_EHIP, std::string("K-build prepare: ") + hipGetErrorString(e));
+        const bool derive = !sa.wide_path;
+        const int64_t na = size_for(A, ca[0], ca[1]);
+        if (derive) {
+            e = build_derived_alloc(sb, ca[0], /*kbits*/ sa.pbits, /*pbits*/ sa.kbits, /*kmin*/ sa.pmin, /*pmin*/ sa.kmin, B.stream);
+            sb_live = true;
+            if (e != hipSuccess) fail(DSA_EHIP, std::string("K-build (twin) scratch: ") + hipGetErrorString(e));
+        }
+        e = build_emit(d_val, DSA_COMBINE_ADD, sa, A.K(), A.V(), A.col_keys, 0, 0, A.stream, false, derive ? sb.comp[0] : nullptr, derive ? sb.val[0] : nullptr);
+        if (e != hipSuccess) fail(DSA_EHIP, std::string("K-build emit: ") + hipGetErrorString(e));
+        if (derive) {
+            if (A.ev_handoff == nullptr) HIPCHK(hipEventCreateWithFlags(&A.ev_handoff, hipEventDisableTiming));
+            HIPCHK(hipEventRecord(A.ev_handoff, A.stream));
+            HIPCHK(hipStreamWaitEvent(B.stream, A.ev_handoff, 0));
+        }
+        root_rebalance(A, na, A.capacity(), na, true);
+        if (derive) {
+            // B: sort the cells A's emit left by B's partition bits (behind the event), flags, counts
+            const KeyRange kb = key_range;      // B's partitions are A's keys
+            const std::function<void()> pb = prealloc_for(B, ca[0], kb, A.stream);
+            e = build_derived_sort(sb, cb, B.stream, &pb);
+            if (e != hipSuccess) fail(DSA_EHIP, std::string("K-build (twin) sort: ") + hipGetErrorString(e));
+            if (cb[0] != ca[0]) fail(DSA_EASSERT, "K-build: the twin orientation counts other cells than its sibling emitted");
+            const int64_t nb = size_for(B, cb[0], cb[1]);
+            e = build_emit(nullptr, DSA_COMBINE_ADD, sb, B.K(), B.V(), B.col_keys, 0, 0, B.stream, false);
+            if (e != hipSuccess) fail(DSA_EHIP, std::string("K-build (twin) emit: ") + hipGetErrorString(e));
+            root_rebalance(B, nb, B.capacity(), nb, true);
+        }
+        upload_ctl(A);                   // (waits for A's stream: its scratch is free)
+        build_abort(sa);
+        if (derive) { upload_ctl(B); build_abort(sb); sb_live = false; }
+        return derive;
+    } catch (...) {
+        build_abort(sa);
+        if (sb_live) build_abort(sb);
+        throw;
+    }
+}
+
 // uploads host arrays (any of them may be nullptr) and runs the device builder
 void pma_build_from_host(Pma& P, const int64_t* part, const int64_t* key, const double* val, int64_t nnz, int32_t combine,
                          int mode, int64_t nparts_explicit) {
@@ -1580,6 +1677,17 @@ void mat_build_major_dev(dsa_mat* h, const int64_t* dI, const int64_t* dJ, const
         if (dbg_time) fprintf(stderr, "[mat_build_major] handles (streams, control blocks) %.2f ms\n", std::chrono::duration<double, std::milli>(tb0 - ti0).count());
         // the two orientations are independent structures on their own streams and both only read the triples: built side by side
         // (the rowmajor one on a helper thread; each build waits once for its cell / partition counts)
+        // large builds: ONE sort of the triples, the rowmajor orientation from the cells colmajor's emit leaves behind (mat_build_both_dev).
+        // DSA_BUILD_TWIN=0: two independent builds side by side, as in rounds 3-5 (A/B, coverage)
+        static const bool twin = [] { const char* e = dev_env("DSA_BUILD_TWIN"); return !(e && e[0] == '0'); }();
+        if (twin && nnz >= (1 << 16) && h->col.stream != h->row.stream && dev_env("DSA_FAIL_BUILD") == nullptr) {
+            const bool both = mat_build_both_dev(h->col, h->row, dJ, dI, dV, nnz, wide_rows, wide_cols, cols, rows);
+            if (!both) pma_build_dev(h->row, dI, dJ, dV, nnz, DSA_COMBINE_ADD, 0, 0, wide_cols, rows, cols);
+            if (dbg_time) fprintf(stderr, "[mat_build_major] nnz=%lld both orientations (%s) %.1f ms\n", (long long)nnz, both ? "twin derived" : "general path",
+                                  std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tb0).count());
+            h->has_major = true;
+            return;
+        }
         std::exception_ptr row_exc;
         std::thread row_thread;
         const bool side_by_side = h->col.stream != h->row.stream && nnz > 0;

@@ -16,7 +16,7 @@ for rep in range(3):
     t1 = time.perf_counter()
     A.closefillmode()
     t2 = time.perf_counter()
-    print("fill mode: 10 batches of 1M triples %.1f ms, closefillmode (last chunk + build) %.1f ms, nnz %d" % ((t1 - t) * 1e3, (t2 - t1) * 1e3, A.nnz()))
+    print("fill mode: 10 batches of 1M triples %.1f ms, closefillmode (last chunk + build) %.2f ms, nnz %d" % ((t1 - t) * 1e3, (t2 - t1) * 1e3, A.nnz()))
     del A
 t = time.perf_counter()
 B = dsa.dynamicsparse(I, J, V, 1000000, 1000000, binding=hip)
