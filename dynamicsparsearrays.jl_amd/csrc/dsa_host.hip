@@ -1341,6 +1341,7 @@ void pma_build_dev(Pma& P, const int64_t* d_part, const int64_t* d_key, const do
     // counts are known.
     bool prealloc_done = false;
     auto release_prealloc = [&] {
+        (void)hipStreamSynchronize(P.stream);      // (the counts arrive through pinned memory: the memsets of the speculative blocks may still be queued)
         pma_free_buffers(P);
         P.cap_alloc = 0; P.occ_words = 0; P.occ_dirty[0] = P.occ_dirty[1] = 0;
         pool_free(P.sems); pool_free(P.col_keys); pool_free(P.col_live);
@@ -1374,7 +1375,6 @@ void pma_build_dev(Pma& P, const int64_t* d_part, const int64_t* d_key, const do
     const int64_t np = mode == 0 ? counts[1] : (mode == 2 ? nparts_explicit : 0);
     const int64_t n = counts[0] + np;
     try {
-        // (build_prepare has waited for the counts on this stream: the memsets of the speculative blocks are complete)
         if (prealloc_done && P.cap_alloc > 8 * capacity_for(n) && P.cap_alloc > (1 << 20)) release_prealloc();
         if (P.has_sems) {
             P.h_ctl->nb_partitions = np; P.h_ctl->table_len = np;
