@@ -169,9 +169,9 @@ __global__ __launch_bounds__(SP_BLOCK) void k_spmv_scatter(KeyArr keys, const do
 // cache-line requests a CU can keep in flight (tools/gatherbench.hip: the slot streams and the x gathers queue for the
 // same miss slots of the CU and their times add), so everything a wave will need is requested up front in ONE round of
 // straight-line code: 9 words of (key, value) — its own 8 plus the word behind them —, the keys of the word in front,
-// then one gather per lane and word: x[key] for a cell, part_keys[id] for a semaphore (its output row).  The products go
-// to the wave's own LDS slice; the semaphores of the span are compacted (ballot + popcount) and one lane per semaphore
-// sums its row from LDS left to right — the reference's accumulation order (src/operations.jl:101), so a row comes
+// then one gather per lane and word: x[key] for a cell (the row key of a partition is fetched once per row by the lane
+// that sums it).  The products go to the wave's own LDS slice; the semaphores of the span are compacted (ballot +
+// popcount) and one lane per semaphore sums its row from LDS left to right — the reference's accumulation order (src/operations.jl:101), so a row comes
 // out bit-identical to the reference unless it is longer than a span.  Who writes a row is decided by where its semaphore is:
 //   * a wave writes every row whose semaphore lies in its 512 slots, running past its end (at most one more span,
 //     SW_WORDS words) until the next semaphore: plain store, each y entry written once;
@@ -207,13 +207,14 @@ __device__ __forceinline__ void zero_fill_front(double* __restrict__ y, int64_t 
 //     instead of loading the keys of the word in front.  Only wave 3 loads a ninth word, only wave 0 the word in front: 33 + 1 words
 //     of requests per workgroup instead of 36 + 4.  Needs every wave of the grid alive at the barrier: capacity a multiple of SP_TILE
 //     (decided by launch_spmv).  Same sums in the same order as without it.
+// the work of ONE tile (4 spans, one per wave); `tile` is the tile index after the XCD mapping of the caller
 template <bool WIDE, bool NT, bool ZFILL, bool SHARE>
-__global__ __launch_bounds__(SP_BLOCK) void k_spmv_gather(KeyArr keys, const double* __restrict__ vals,
-                                                          const uint64_t* __restrict__ occ, int64_t capacity,
-                                                          const int64_t* __restrict__ sems,
-                                                          const int64_t* __restrict__ part_keys, int64_t table_len,
-                                                          const double* __restrict__ x, int64_t nx,
-                                                          double* __restrict__ y, int64_t ny, int pattern) {
+__device__ __forceinline__ void gather_tile(KeyArr keys, const double* __restrict__ vals,
+                                            const uint64_t* __restrict__ occ, int64_t capacity,
+                                            const int64_t* __restrict__ sems,
+                                            const int64_t* __restrict__ part_keys, int64_t table_len,
+                                            const double* __restrict__ x, int64_t nx,
+                                            double* __restrict__ y, int64_t ny, int pattern, int64_t tile, int tid) {
     typedef typename std::conditional<WIDE, int64_t, int32_t>::type key_t;      // physical key width, fixed at compile time for the streams
     const key_t* __restrict__ kp = static_cast<const key_t*>(keys.p);
     // Products: with SHARE the 4 spans + the word behind the last one, FLAT (wave w at w * 512, running on into wave w + 1's slice);
@@ -228,23 +229,15 @@ __global__ __launch_bounds__(SP_BLOCK) void k_spmv_gather(KeyArr keys, const dou
     // measured FASTER where the gathers hit (banded shape 84-87 vs 90 us, same box, twice) and equal on config 3 (117.6 vs 117.8).
     // 3 per CU: config 3 +2 %; 5 per CU: no gain.
     __shared__ double sPad[NT ? 2048 : 1];
-    if (capacity == -2) { sPad[threadIdx.x] = 1.0; __syncthreads(); y[0] = sPad[0]; }        // (never true: keeps the array allocated)
-    const int lane = threadIdx.x & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (capacity == -2) { sPad[tid] = 1.0; __syncthreads(); y[0] = sPad[0]; }        // (never true: keeps the array allocated)
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     // SHARE: one flat product array over the same storage — wave w's slots at [w * SW_WORDS * 64, ...), running on into wave w + 1's; behind
     // the four spans the ninth word of wave 3, then the four front keys
     constexpr int SPAN = SW_WORDS * 64;
     double* sP = SHARE ? sPw + wv * SPAN : sPw + wv * SW_SLOTS;
     const bool ninth = !SHARE || wv == SP_WAVES - 1;    // this wave loads the word behind its span itself
     uint16_t* sList = sListw[wv];
-    // XCD-aware tile mapping (see k_spmv): XCD g streams the g-th contiguous eighth of the slot array
-    const int64_t ntiles = (capacity + SP_TILE - 1) / SP_TILE;
-    int64_t tile = blockIdx.x;
-    if (ntiles >= 64 && !(pattern & 4)) {
-        const int64_t per = (ntiles + 7) / 8;
-        tile = (int64_t)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
-        if (tile >= ntiles) return;
-    }
     const int64_t nwords = (capacity + 63) >> 6;      // slot buffers are allocated in whole words (cap_alloc >= 4096)
     const int64_t w0 = tile * (SP_TILE / 64) + (int64_t)wv * SW_WORDS;
     if (w0 >= nwords) return;
@@ -301,56 +294,67 @@ __global__ __launch_bounds__(SP_BLOCK) void k_spmv_gather(KeyArr keys, const dou
         for (int j = 0; j <= SW_WORDS; ++j) if (w0 + j >= nwords) ow[j] = 0ull;
     }
 
-    // ---- cell / semaphore masks (wave-uniform 64-bit words), one x gather per lane and word ----------------------------------
-    // Everything a lane decides comes from a compare whose result IS the mask (v_cmp -> SGPR pair); the occupancy bit of a lane is
-    // the inverse ballot of the uniform word (no per-lane shifts).  Semaphores do not gather here: the row key of a partition is
+    // ---- one x gather per lane and word -------------------------------------------------------------------------------------
+    // The occupancy bit is folded into the key first (a gap becomes key -1: neither a cell nor a semaphore), so that the occupancy
+    // words die here and every later question — cell? semaphore? — is ONE compare on the key whose result is the mask (v_cmp -> SGPR
+    // pair), asked again where it is needed instead of being kept: no mask word lives from this loop to the next one (27 of them did
+    // until round 5, which is what a tile loop around this body spilled).  Semaphores do not gather here: the row key of a partition is
     // fetched once per ROW by the lane that sums it (below), together with the key of the partition in front of it (ZFILL).
-    uint64_t sb[SW_WORDS + 1], cm[SW_WORDS + 1];
     double xq[SW_WORDS + 1];
     const double* xs = nx > 0 ? x : (const double*)occ;          // what idle lanes read: the first 8 bytes of something that exists
     const uint32_t nx32 = nx < 0x7fffffff ? (uint32_t)(nx > 0 ? nx : 0) : 0x7fffffffu;
     const uint32_t tlen = table_len < 0x7fffffff ? (uint32_t)table_len : 0x7fffffffu;
+    auto is_cell = [&](key_t key) -> bool {                      // 1 <= key <= nx (a semaphore and a gap wrap around)
+        if (WIDE) return (uint64_t)((int64_t)key - 1) < (uint64_t)(nx > 0 ? nx : 0);
+        return (uint32_t)key - 1u < nx32;
+    };
 #pragma unroll
     for (int j = 0; j <= SW_WORDS; ++j) {
-        if (SHARE && j == SW_WORDS && !ninth) { sb[j] = 0; cm[j] = 0; xq[j] = 0.0; continue; }
-        uint64_t inr;
-        if (WIDE) inr = __ballot((uint64_t)((int64_t)k[j] - 1) < (uint64_t)(nx > 0 ? nx : 0));      // 1 <= key <= nx (a semaphore wraps around)
-        else inr = __ballot((uint32_t)k[j] - 1u < nx32);
-        sb[j] = __ballot(k[j] == SEM_KEY) & ow[j];
-        cm[j] = inr & ow[j];
-        // the word behind the span: only the cells in front of its first semaphore matter
-        if (j == SW_WORDS) cm[j] &= sb[j] ? ((sb[j] & (0ull - sb[j])) - 1ull) : ~0ull;
-        const bool cell = __builtin_amdgcn_inverse_ballot_w64(cm[j]);
+        if (SHARE && j == SW_WORDS && !ninth) { k[j] = (key_t)-1; xq[j] = 0.0; continue; }
+        k[j] = __builtin_amdgcn_inverse_ballot_w64(ow[j]) ? k[j] : (key_t)-1;
+        if (j == SW_WORDS) {
+            // the word behind the span: only the cells in front of its first semaphore matter (and that semaphore itself)
+            const uint64_t s8 = __ballot(k[j] == SEM_KEY);
+            const uint64_t keep = s8 ? ((s8 & (0ull - s8)) << 1) - 1ull : ~0ull;
+            k[j] = __builtin_amdgcn_inverse_ballot_w64(keep) ? k[j] : (key_t)-1;
+        }
+        const bool cell = is_cell(k[j]);
         if (WIDE) { const int64_t idx = cell ? (int64_t)k[j] - 1 : 0; xq[j] = xs[idx]; }
         else { const uint32_t idx = cell ? (uint32_t)k[j] - 1u : 0u; xq[j] = xs[idx]; }
     }
     // ---- products -> LDS ; the semaphores of the span are compacted, their slot keeps the partition id (the stored Float64) -------
     int nsem = 0;
+    uint64_t sb0 = 0ull;
 #pragma unroll
     for (int j = 0; j <= SW_WORDS; ++j) {
         if (SHARE && j == SW_WORDS && !ninth) continue;
-        const bool cell = __builtin_amdgcn_inverse_ballot_w64(cm[j]);
+        const bool cell = is_cell(k[j]);
         const double p = product_of(v[j], xq[j], count_pass);
         sP[j * 64 + lane] = cell ? p : 0.0;
-        if (j < SW_WORDS && sb[j] != 0ull) {
-            if (__builtin_amdgcn_inverse_ballot_w64(sb[j])) {
-                const int r = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(sb[j] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)sb[j], 0u));
-                sP[j * 64 + lane] = v[j];            // partition ids are stored as Float64 (src/pcsr.jl:104)
-                sList[nsem + r] = (uint16_t)(j * 64 + lane);
+        if (j < SW_WORDS) {
+            const uint64_t sbj = __ballot(k[j] == SEM_KEY);
+            if (j == 0) sb0 = sbj;
+            if (sbj != 0ull) {
+                if (__builtin_amdgcn_inverse_ballot_w64(sbj)) {
+                    const int r = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(sbj >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)sbj, 0u));
+                    sP[j * 64 + lane] = v[j];            // partition ids are stored as Float64 (src/pcsr.jl:104)
+                    sList[nsem + r] = (uint16_t)(j * 64 + lane);
+                }
+                nsem += popc64(sbj);
             }
-            nsem += popc64(sb[j]);
         }
     }
+    uint64_t sb8 = (SHARE && !ninth) ? 0ull : __ballot(k[SW_WORDS] == SEM_KEY);      // first semaphore behind the span
     const int own_words = (int)(nwords - w0 < SW_WORDS ? nwords - w0 : SW_WORDS);
     // end of the row that is open at the end of the span, as far as the 9 words show it
     const bool behind_valid = w0 + SW_WORDS < nwords;
     if (SHARE) {
-        if (lane == 0) { sSb0[wv] = sb[0]; sNsem[wv] = nsem; }
+        if (lane == 0) { sSb0[wv] = sb0; sNsem[wv] = nsem; }
         __syncthreads();
-        if (!ninth) sb[SW_WORDS] = sSb0[wv + 1];
+        if (!ninth) sb8 = sSb0[wv + 1];
     }
-    const int endpos = !behind_valid ? own_words * 64 : (sb[SW_WORDS] ? SW_WORDS * 64 + __ffsll((unsigned long long)sb[SW_WORDS]) - 1 : SW_SLOTS);
-    bool closed = !behind_valid || sb[SW_WORDS] != 0;
+    const int endpos = !behind_valid ? own_words * 64 : (sb8 ? SW_WORDS * 64 + __ffsll((unsigned long long)sb8) - 1 : SW_SLOTS);
+    bool closed = !behind_valid || sb8 != 0;
     if (!SHARE) __builtin_amdgcn_wave_barrier();
 
     // row key of the partition whose id sits in slot a of the span (0: no such partition) and — ZFILL — the key of the partition in
@@ -453,6 +457,24 @@ __global__ __launch_bounds__(SP_BLOCK) void k_spmv_gather(KeyArr keys, const dou
             }
         }
     }
+}
+
+template <bool WIDE, bool NT, bool ZFILL, bool SHARE>
+__global__ __launch_bounds__(SP_BLOCK) void k_spmv_gather(KeyArr keys, const double* __restrict__ vals,
+                                                          const uint64_t* __restrict__ occ, int64_t capacity,
+                                                          const int64_t* __restrict__ sems,
+                                                          const int64_t* __restrict__ part_keys, int64_t table_len,
+                                                          const double* __restrict__ x, int64_t nx,
+                                                          double* __restrict__ y, int64_t ny, int pattern) {
+    // XCD-aware tile mapping (see k_spmv): XCD g streams the g-th contiguous eighth of the slot array
+    const int64_t ntiles = (capacity + SP_TILE - 1) / SP_TILE;
+    int64_t tile = blockIdx.x;
+    if (ntiles >= 64 && !(pattern & 4)) {
+        const int64_t per = (ntiles + 7) / 8;
+        tile = (int64_t)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
+        if (tile >= ntiles) return;
+    }
+    gather_tile<WIDE, NT, ZFILL, SHARE>(keys, vals, occ, capacity, sems, part_keys, table_len, x, nx, y, ny, pattern, tile, (int)threadIdx.x);
 }
 
 // (the sparse-x product driven by x's stored entries lives in sparsex.hip since round 6: k_spx_accum)
@@ -594,7 +616,8 @@ static void launch_gather_t(int64_t grid, hipStream_t stream, KeyArr keys, const
     static const bool share_ok = [] { const char* e = dev_env("DSA_SPMV_SHARE"); return !(e && e[0] == '0'); }();
     // SHARE pays where the gathers miss (config 3: 118.1 vs 121.2 us without it); where x is L2-resident the barrier costs more than the
     // ninth word saves (banded shape: 90.9 vs 86.9 us), so the plain-stream instantiations run without it
-    if (NT && share_ok && capacity >= SP_TILE && capacity % SP_TILE == 0)
+    const bool share = NT && share_ok && capacity >= SP_TILE && capacity % SP_TILE == 0;
+    if (share)
         hipLaunchKernelGGL((k_spmv_gather<WIDE, NT, ZFILL, true>), dim3((unsigned)grid), dim3(SP_BLOCK), 0, stream, keys, vals, occ, capacity, sems,
                            part_keys, table_len, x, nx, y, ny, pattern);
     else

@@ -3,7 +3,7 @@
 the banded extra (every gather an L2 hit), the final config-5 matrix (2^21 slots, x = 400 KB) — with HIP events around N launches, and
 print y's bytes as a sha256 so that two variants of the kernel (run this tool once per library — DSA_DEV=1 DSA_LIBRARY=<another build of csrc/> —
 or per setting of the development switches, e.g. DSA_DEV=1 DSA_SPMV_SHARE=0) can be compared bit for bit (the banded shape has two
-rows longer than a span: their sums are joined by atomics and may differ in the last bits from run to run).  usage: python3 tools/spmv_ab.py [c3] [banded] [c5]"""
+rows longer than a span: their sums are joined by atomics and may differ in the last bits from run to run).  usage: python3 tools/spmv_ab.py [c3] [banded] [c4] [c5]"""
 import ctypes as C
 import hashlib
 import json
@@ -64,6 +64,12 @@ if "banded" in which:
     _, firstb = np.unique(keyb, return_index=True)
     A = dsa.dynamicsparse(rowb[firstb], colb[firstb], bench.unit12(52, len(firstb)), mb, nb, binding=hip)
     run("banded", A, nb, mb, bench.unit12(53, nb))
+    del A
+if "c4" in which:
+    m4, n4 = 10_000_000, 1_250_000
+    I4, J4, V4 = bench.c3_triplets(m4, n4, 10, 0, seed_rows=8, seed_vals=9)
+    A = dsa.dynamicsparse(I4, J4, V4, m4, n4, binding=hip)
+    run("c4_shard", A, n4, m4, bench.unit12(10, n4), reps=20)
     del A
 if "c5" in which:
     m5, ncols5, per5, every = bench.C5_FULL
