@@ -21,6 +21,9 @@
 #include "find_dev.h"
 
 namespace dsa {
+#ifdef DSA_PB_PROF
+__device__ unsigned long long g_pbprof[16];
+#endif
 
 constexpr int PB_BLOCK = 256;                 // k_apply: 4 waves = 4 ops per workgroup (32 KB of LDS per wave)
 constexpr int PL_BLOCK = 1024;                // k_plan: 16 waves = 16 ops per workgroup; the workgroup that finishes last resolves the round with
@@ -654,10 +657,14 @@ __global__ __launch_bounds__(PL_BLOCK) void k_plan(const DevBufs* bufs, const Ct
             const int nw = sNWide;
             for (int q = 0; q < nw; ++q) { const int i = sWide[q]; const Iv o = sIv[i]; if (o.lo <= b && a <= o.hi) fn(i); }
         };
-        // one WAVE per conflicting op: lane 0 walks the hash chains (LDS), lanes 0..15 / 16..31 load the occupancy words of the left /
-        // right window in ONE round (a single thread took one dependent round trip per word: 5-20 us per round for one conflict)
+        // one WAVE per conflicting op, ONE pass for all candidate levels: every zone a level could offer lies inside R = the aligned window
+        // of the widest level (RA_MAX_W slots) plus the window to its right.  Lane 0 walks the hash chains of R once and lists the ops it
+        // meets (one per lane from then on), lanes 0..31 load R's occupancy words in one round and a prefix sum over their popcounts
+        // gives the cell count of any aligned window; the levels are then tried narrowest first without touching memory again.  (Round 6's
+        // first form walked the chains and loaded the words once per level: 13-47 k cycles of the resolve step for 1-7 conflicts.)
         {
             const int lane = tid & 63, wave = tid >> 6;
+            __shared__ int sSealList[PL_BLOCK / 64][64];
             for (int q = wave; q < nconf; q += PL_BLOCK / 64) {
                 const int j = sConfList[q];
                 const Iv me = sIv[j];
@@ -667,42 +674,73 @@ __global__ __launch_bounds__(PL_BLOCK) void k_plan(const DevBufs* bufs, const Ct
                 if (ok && lane == 0)
                     for_overlapping(me.lo, me.hi, [&](int i) { if (i < j) { const Iv o = sIv[i]; if (o.lo < a) a = o.lo; if (o.hi > b) b = o.hi; } });
                 a = __shfl(a, 0, 64); b = __shfl(b, 0, 64);
-                if (ok) {
+                int hmin = -1, hmax = -1;
+                for (int h = 0; h < MAX_LEVELS; ++h) {
+                    const int64_t Wh = seg << h;
+                    if (Wh < 64) continue;
+                    if (Wh > RA_MAX_W) break;
+                    if (hmin < 0) hmin = h;
+                    hmax = h;
+                }
+                if (ok && hmax >= 0) {
                     ok = false;
-                    for (int h = 0; h < MAX_LEVELS; ++h) {
+                    const int64_t Wx = seg << hmax;
+                    const int64_t Ax = ((a - 1) / Wx) * Wx + 1;
+                    const int64_t Rhi = Ax + 2 * Wx - 1 < cap0 ? Ax + 2 * Wx - 1 : cap0;          // R = [Ax, Rhi]: whole words (64 | Wx, 64 | cap0)
+                    int n = 0;
+                    if (lane == 0) for_overlapping(Ax, Rhi, [&](int i) { if (n < 64) sSealList[wave][n] = i; ++n; });
+                    n = __shfl(n, 0, 64);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    // the ops that touch R, one per lane (more than 64: nothing is proven, the round ends in front of j)
+                    Iv o{INT32_MAX, INT32_MIN};
+                    bool osimple = false, oins = false;
+                    if (n <= 64 && lane < n) {
+                        const int i = sSealList[wave][lane];
+                        o = sIv[i]; osimple = sSimple[i] != 0; oins = sAct[i] == PB_OVERWRITE || sAct[i] == PB_INS_R;
+                    }
+                    // the occupancy words of R and the inclusive prefix sum of their popcounts (lane t <-> word t of R)
+                    const int64_t w0 = (Ax - 1) >> 6;
+                    const int nwR = (int)((Rhi - Ax + 1) >> 6);                                   // <= 32
+                    const uint64_t word = (n <= 64 && lane < nwR) ? occ[w0 + lane] : 0ull;
+                    int incl = popc64(word);
+#pragma unroll
+                    for (int d = 1; d < 64; d <<= 1) { const int up = __shfl_up(incl, d, 64); if (lane >= d) incl += up; }
+                    auto cells_before = [&](int k) -> int { const int v = __shfl(incl, k > 0 ? k - 1 : 0, 64); return k > 0 ? v : 0; };      // words [0, k) of R
+                    for (int h = hmin; n <= 64 && h <= hmax; ++h) {
                         W = seg << h;
-                        if (W < 64) continue;
-                        if (W > RA_MAX_W) break;
                         A = ((a - 1) / W) * W + 1; B = A + W - 1;
                         if (b > B) continue;
                         if (B + W > cap0) break;
-                        int ins = 0, del = 0, fits = 1;
-                        int32_t min_lo = INT32_MAX;
-                        if (lane == 0)
-                            for_overlapping(A, B + W, [&](int i) {
-                                const Iv o = sIv[i];
-                                if (!sSimple[i] || o.lo < A || o.hi > B) fits = 0;
-                                if (sAct[i] == PB_OVERWRITE || sAct[i] == PB_INS_R) ++ins; else ++del;
-                                if (o.lo < min_lo) min_lo = o.lo;
-                            });
-                        ins = __shfl(ins, 0, 64); del = __shfl(del, 0, 64); fits = __shfl(fits, 0, 64); min_lo = __shfl(min_lo, 0, 64);
-                        if (!fits || del > RA_MAX_DEL) continue;
+                        // (1) every op that touches Z' lies inside [A, B] and is a plain write
+                        const bool ov = o.lo <= B + W && A <= o.hi;                               // (an idle lane's empty interval overlaps nothing)
+                        const uint64_t ovm = __ballot(ov);
+                        if (__ballot(ov && (!osimple || o.lo < A || o.hi > B)) != 0ull) continue;
+                        const int ins = popc64(__ballot(ov && oins)), del = popc64(ovm) - ins;
+                        if (del > RA_MAX_DEL) continue;
                         const int64_t lh = h < 24 ? sLoH[h] : ctl->lo[h], hh = h < 24 ? sHiH[h] : ctl->hi[h];
                         if (W - hh < ins + 2) continue;
+                        int min_lo = ov ? o.lo : INT32_MAX;
+#pragma unroll
+                        for (int d = 32; d > 0; d >>= 1) { const int other = __shfl_xor(min_lo, d, 64); min_lo = other < min_lo ? other : min_lo; }
+                        const int wl = (int)(((A - 1) >> 6) - w0), nwd = (int)(W >> 6);
+                        const int c_a = cells_before(wl), c_b = cells_before(wl + nwd), c_c = cells_before(wl + 2 * nwd);
+                        const int64_t cl = c_b - c_a, cr = c_c - c_b;
                         // (0) a predecessor moves left by one cell per deleted cell: more than `del` cells lie between A and the leftmost op
-                        const int nwd = (int)(W >> 6);                                  // <= 16
-                        const int64_t wl0 = (A - 1) >> 6, wr0 = B >> 6;
-                        const int64_t m0 = A - 1, m1 = (int64_t)min_lo - 2;             // 0-based slots of [A, min_lo - 1]
-                        const int t = lane & 15;
-                        uint64_t word = 0ull;
-                        if (lane < 32 && t < nwd) word = occ[(lane < 16 ? wl0 : wr0) + t];
-                        int64_t cl = lane < 16 ? popc64(word) : 0, cr = (lane >= 16 && lane < 32) ? popc64(word) : 0;
-                        int64_t cm = (lane < 16 && t < nwd && m1 >= m0) ? popc64(word & word_range_mask(wl0 + t, m0, m1)) : 0;
-                        cl = pb_wave_sum(cl); cr = pb_wave_sum(cr); cm = pb_wave_sum(cm);
+                        int64_t cm = 0;
+                        const int64_t m1 = (int64_t)min_lo - 2;                                   // 0-based slots [A - 1, min_lo - 2]
+                        if (min_lo != INT32_MAX && m1 >= A - 1) {
+                            const int kw = (int)((m1 >> 6) - w0);
+                            const uint32_t wlo = (uint32_t)__shfl((int)(uint32_t)word, kw, 64), whi = (uint32_t)__shfl((int)(uint32_t)(word >> 32), kw, 64);
+                            const uint64_t wk = ((uint64_t)whi << 32) | wlo;
+                            const int r = (int)(m1 & 63);
+                            cm = cells_before(kw) - c_a + popc64(r == 63 ? wk : (wk & ((1ull << (r + 1)) - 1ull)));
+                        }
                         if (cm < del + 1) continue;
                         if (lh <= cl - del && cl + ins <= hh && lh <= cr - del && cr + ins <= hh) { ok = true; break; }
                     }
-                }
+                } else ok = false;
                 if (lane == 0) {
 #ifdef DSA_FP_CHECK
                     if (ok && (rs->tight & 0x400)) printf("DSA_FP_CHECK run-ahead: op %lld (position %d, act %d, footprint [%d,%d]) sealed in [%lld,%lld]+[..%lld]\n", (long long)op_index(j), j, (int)sAct[j], me.lo, me.hi, (long long)A, (long long)B, (long long)(B + W));
@@ -856,8 +894,12 @@ __global__ __launch_bounds__(PL_BLOCK) void k_plan(const DevBufs* bufs, const Ct
     }
     if (tid == 0) {
 #ifdef DSA_PB_PROF
-        printf("resolve: G %d np %d sB %d sC %d applied %d deferred %d nconf %d | clk: entry->planned %lld ->ticket %lld | load %lld conflicts %lld seal %lld decide+list %lld\n", G, np, sB, sC, na,
-               sNDeferred, sNConf, tk1 - tk0, tr0 - tk1, tr1 - tr0, tr2 - tr1, tr3 - tr2, (long long)clock64() - tr3);
+        {   // dev profile: cycle sums per phase of the resolving workgroup, read and reset by dsa_dbg_pbprof_dump (no printf: it distorts what it measures)
+            const long long ph[7] = {tk1 - tk0, tr0 - tk1, tr1 - tr0, tr2 - tr1, tr3 - tr2, (long long)clock64() - tr3, (long long)sNConf};
+            atomicAdd(&g_pbprof[0], 1ull);
+            for (int q = 0; q < 7; ++q) atomicAdd(&g_pbprof[1 + q], (unsigned long long)ph[q]);
+            atomicAdd(&g_pbprof[8], (unsigned long long)G); atomicAdd(&g_pbprof[9], (unsigned long long)na);
+        }
 #endif
         rs->ticket = 0u;                                               // re-armed for the next round
         // commit the window of THIS round (k_apply reads it) ...
@@ -1699,3 +1741,15 @@ hipError_t launch_dbg_raw_wave(KeyArr keys, double* vals, uint64_t* occ, int64_t
 }
 
 }  // namespace dsa
+
+#ifdef DSA_PB_PROF
+extern "C" void dsa_dbg_pbprof_dump(void) {
+    unsigned long long h[16] = {0};
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(dsa::g_pbprof), sizeof(h)) != hipSuccess) return;
+    const double r = h[0] ? (double)h[0] : 1.0;
+    fprintf(stderr, "pbprof: %llu resolves, G %.0f applied %.0f conflicts %.2f | cycles per round: entry->planned %.0f ->ticket %.0f | load %.0f conflicts %.0f seal %.0f decide+list %.0f\n",
+            h[0], h[8] / r, h[9] / r, h[7] / r, h[1] / r, h[2] / r, h[3] / r, h[4] / r, h[5] / r, h[6] / r);
+    unsigned long long z[16] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(dsa::g_pbprof), z, sizeof(z));
+}
+#endif

@@ -22,6 +22,11 @@ for rep in range(6):
 tb = float(np.median(ts[1:]))
 print("batch B: %.2f ms  %.1f M inserts/s  rounds %d par ops %d seq ops %d  [%s]" % (tb * 1e3, len(odd) / tb / 1e6, inf["stat_par_rounds"], inf["stat_par_ops"], inf["stat_seq_ops"],
                                                                                   ", ".join("%.2f" % (x * 1e3) for x in ts)))
+def pbprof(tag):      # DSA_LIBRARY=<a -DDSA_PB_PROF build of csrc/>: cycle sums per phase of the resolve step (printed to stderr)
+    lib = getattr(hip, "lib", None)
+    if lib is not None and hasattr(lib, "dsa_dbg_pbprof_dump"):
+        sys.stderr.write(tag + " "); sys.stderr.flush(); lib.dsa_dbg_pbprof_dump()
+pbprof("batch B")
 mm, nn = 20000, 30000
 ri = 1 + (bench.splitmix_array(31, 600000) % np.uint64(mm)).astype(np.int64)
 ci = 1 + (bench.splitmix_array(32, 600000) % np.uint64(nn)).astype(np.int64)
@@ -39,3 +44,4 @@ for rep in range(6):
 tm = float(np.median(ts[1:]))
 print("matrix random updates: %.2f ms  %.1f M updates/s  rounds col %d row %d  [%s]" % (tm * 1e3, len(ui) / tm / 1e6, infs[0]["stat_par_rounds"], infs[1]["stat_par_rounds"],
                                                                                      ", ".join("%.2f" % (x * 1e3) for x in ts)))
+pbprof("matrix updates")
