@@ -22,7 +22,10 @@
 
 namespace dsa {
 #ifdef DSA_PB_PROF
-__device__ unsigned long long g_pbprof[16];
+__device__ unsigned long long g_pbprof[32];
+#define PBW(j_, code_) (sCutWhy[(j_)] = (unsigned char)(code_))
+#else
+#define PBW(j_, code_) ((void)0)
 #endif
 
 constexpr int PB_BLOCK = 256;                 // k_apply: 4 waves = 4 ops per workgroup (32 KB of LDS per wave)
@@ -434,6 +437,9 @@ __global__ __launch_bounds__(PL_BLOCK) void k_plan(const DevBufs* bufs, const Ct
     __shared__ int sNWide;
     __shared__ int64_t sLoH[24], sHiH[24];                            // density bounds of the lower levels (run-ahead: the sealed zones)
     __shared__ int sMinConf;
+#ifdef DSA_PB_PROF
+    __shared__ unsigned char sCutWhy[PB_GMAX + 8];      // dev profile: what cut the round at op j (see dsa_dbg_pbprof_dump)
+#endif
     if (run_ahead && tid >= PL_BLOCK - 24) { const int q = tid - (PL_BLOCK - 24); sLoH[q] = ctl->lo[q]; sHiH[q] = ctl->hi[q]; }      // (the LAST wave: fewest plans to load)
     for (int k = tid; k < NB; k += PL_BLOCK) sHead[k] = -1;
     if (tid == 0) { sNWide = 0; sNConf = 0; sNApplied = 0; sNDeferred = 0; sFault = 0; sMinConf = INT32_MAX; }
@@ -511,7 +517,7 @@ __global__ __launch_bounds__(PL_BLOCK) void k_plan(const DevBufs* bufs, const Ct
             if (c1 - c0 > 1) {                                           // (a tight hull over three cells: keep it simple)
                 // ... a new column without a fallback window (level 0x7f) has nothing to be widened to: W = seg << 0x7f below is undefined.
                 // The prefix ends in front of it, like further down
-                if (sLvl[j] == 0x7f) atomicMin(&sC, j); else widen[u] = true;
+                if (sLvl[j] == 0x7f) { PBW(j, 9); atomicMin(&sC, j); } else widen[u] = true;
                 continue;
             }
             // does the leaf [a, a + seg) with c cells before the round accept every count the window's ops can leave in it?
@@ -548,7 +554,7 @@ __global__ __launch_bounds__(PL_BLOCK) void k_plan(const DevBufs* bufs, const Ct
             widen[u] = !ok || !((tight_mask >> (sChg2[j] != 0 ? 1 : 0)) & 1);
             // a new column without a fallback window (level 0x7f) cannot be widened: the prefix ends in front of it (alone at the head
             // of the next round it is handed to the sequencer — d = 0 stops the rounds)
-            if (widen[u] && sLvl[j] == 0x7f) { widen[u] = false; atomicMin(&sC, j); }
+            if (widen[u] && sLvl[j] == 0x7f) { widen[u] = false; PBW(j, 9); atomicMin(&sC, j); }
             // "simple" (run-ahead): a leaf-accepted right insert / delete that keeps its tight hull
             if (!widen[u] && (sAct[j] == PB_INS_R || sAct[j] == PB_DELETE)) sSimple[j] = 1;
         }
@@ -589,7 +595,7 @@ __global__ __launch_bounds__(PL_BLOCK) void k_plan(const DevBufs* bufs, const Ct
                 const Iv o = sIv[i];
                 hit = hit | ((i < j) & (o.lo <= me.hi) & (me.lo <= o.hi));
             }
-        if (hit) { if (run_ahead) { sConf[j] = 1; atomicMin(&sMinConf, j); } else atomicMin(&sC, j); }
+        if (hit) { if (run_ahead) { sConf[j] = 1; atomicMin(&sMinConf, j); } else { PBW(j, 1); atomicMin(&sC, j); } }
     }
     __syncthreads();
     const int nwide = sNWide;
@@ -598,7 +604,7 @@ __global__ __launch_bounds__(PL_BLOCK) void k_plan(const DevBufs* bufs, const Ct
         const Iv me = sIv[j];
         for (int i = tid; i < Gc; i += PL_BLOCK) {
             const Iv o = sIv[i];
-            if (i != j && o.lo <= me.hi && me.lo <= o.hi) { if (run_ahead) { sConf[i > j ? i : j] = 1; atomicMin(&sMinConf, i > j ? i : j); } else atomicMin(&sC, i > j ? i : j); }
+            if (i != j && o.lo <= me.hi && me.lo <= o.hi) { if (run_ahead) { sConf[i > j ? i : j] = 1; atomicMin(&sMinConf, i > j ? i : j); } else { PBW(i > j ? i : j, 1); atomicMin(&sC, i > j ? i : j); } }
         }
     }
     __syncthreads();
@@ -606,7 +612,7 @@ __global__ __launch_bounds__(PL_BLOCK) void k_plan(const DevBufs* bufs, const Ct
     // Sealing costs the resolving workgroup a few dependent round trips to memory per round; it does not pay when the first conflict
     // sits in the last eighth of the window anyway (a long prefix: the array is large against the window): the prefix rule then
     if (run_ahead && sMinConf != INT32_MAX && sMinConf >= Gc - (Gc >> 3)) {
-        if (tid == 0) atomicMin(&sC, sMinConf);
+        if (tid == 0) { PBW(sMinConf, 2); atomicMin(&sC, sMinConf); }
         __syncthreads();
     } else
     if (run_ahead && sMinConf != INT32_MAX) {
@@ -640,7 +646,7 @@ __global__ __launch_bounds__(PL_BLOCK) void k_plan(const DevBufs* bufs, const Ct
         __syncthreads();
         // (a window full of conflicts — hammering one leaf, a tiny array — is the prefix rule's: most zones would not hold anyway)
         const int nconf = sNConf > RA_MAX_CONF ? 0 : sNConf;
-        if (sNConf > RA_MAX_CONF && tid == 0) atomicMin(&sC, sMinConf);
+        if (sNConf > RA_MAX_CONF && tid == 0) { PBW(sMinConf, 3); atomicMin(&sC, sMinConf); }
         // visits every op of the window whose footprint overlaps [a, b] (an op in two cells of the walk once; a widened op that is also in
         // the list of wide ops twice — the counts below are upper bounds)
         auto for_overlapping = [&](int64_t a, int64_t b, auto fn) {
@@ -674,7 +680,7 @@ __global__ __launch_bounds__(PL_BLOCK) void k_plan(const DevBufs* bufs, const Ct
                 if (ok && lane == 0)
                     for_overlapping(me.lo, me.hi, [&](int i) { if (i < j) { const Iv o = sIv[i]; if (o.lo < a) a = o.lo; if (o.hi > b) b = o.hi; } });
                 a = __shfl(a, 0, 64); b = __shfl(b, 0, 64);
-                int hmin = -1, hmax = -1;
+                int hmin = -1, hmax = -1, n = 0;
                 for (int h = 0; h < MAX_LEVELS; ++h) {
                     const int64_t Wh = seg << h;
                     if (Wh < 64) continue;
@@ -687,7 +693,6 @@ __global__ __launch_bounds__(PL_BLOCK) void k_plan(const DevBufs* bufs, const Ct
                     const int64_t Wx = seg << hmax;
                     const int64_t Ax = ((a - 1) / Wx) * Wx + 1;
                     const int64_t Rhi = Ax + 2 * Wx - 1 < cap0 ? Ax + 2 * Wx - 1 : cap0;          // R = [Ax, Rhi]: whole words (64 | Wx, 64 | cap0)
-                    int n = 0;
                     if (lane == 0) for_overlapping(Ax, Rhi, [&](int i) { if (n < 64) sSealList[wave][n] = i; ++n; });
                     n = __shfl(n, 0, 64);
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -746,7 +751,7 @@ __global__ __launch_bounds__(PL_BLOCK) void k_plan(const DevBufs* bufs, const Ct
                     if (ok && (rs->tight & 0x400)) printf("DSA_FP_CHECK run-ahead: op %lld (position %d, act %d, footprint [%d,%d]) sealed in [%lld,%lld]+[..%lld]\n", (long long)op_index(j), j, (int)sAct[j], me.lo, me.hi, (long long)A, (long long)B, (long long)(B + W));
 #endif
                     if (ok) { sZone[q].lo = (int32_t)A; sZone[q].mid = (int32_t)B; sZone[q].hi = (int32_t)(B + W); }
-                    else atomicMin(&sC, j);                                                    // not provable: the round ends in front of this op
+                    else { PBW(j, !sSimple[j] ? 5 : (n > 64 ? 4 : 6)); atomicMin(&sC, j); }                                                    // not provable: the round ends in front of this op
                 }
             }
         }
@@ -765,7 +770,7 @@ __global__ __launch_bounds__(PL_BLOCK) void k_plan(const DevBufs* bufs, const Ct
                 if (i >= j || zr.lo == 0) continue;
                 if (zr.lo <= zq.hi && zq.lo <= zr.hi) { if (me.lo >= zr.lo && me.hi <= zr.mid) member = true; else cut = true; }
             }
-            if (cut) atomicMin(&sC, j);
+            if (cut) { PBW(j, 7); atomicMin(&sC, j); }
             else if (member) sDefer[j] = 2;                                            // (its own zone is dropped below, behind the barrier)
         }
         __syncthreads();
@@ -781,7 +786,7 @@ __global__ __launch_bounds__(PL_BLOCK) void k_plan(const DevBufs* bufs, const Ct
                 if (sConfList[r] >= x || zr.lo == 0) continue;
                 if (me.lo <= zr.hi && zr.lo <= me.hi) {
                     if (me.lo >= zr.lo && me.hi <= zr.mid && sSimple[x]) { if (zid == 0) zid = r + 1; }
-                    else atomicMin(&sC, x);
+                    else { PBW(x, 8); atomicMin(&sC, x); }
                 }
             }
             if (zid != 0) { if (!sDefer[x]) sDefer[x] = 1; if (sZid[x] == 0) sZid[x] = (unsigned char)zid; }      // (only x's own entries: the owners' zones are final)
@@ -899,6 +904,10 @@ __global__ __launch_bounds__(PL_BLOCK) void k_plan(const DevBufs* bufs, const Ct
             atomicAdd(&g_pbprof[0], 1ull);
             for (int q = 0; q < 7; ++q) atomicAdd(&g_pbprof[1 + q], (unsigned long long)ph[q]);
             atomicAdd(&g_pbprof[8], (unsigned long long)G); atomicAdd(&g_pbprof[9], (unsigned long long)na);
+            // why the round ended where it did: 0 the whole window, 10 a BARRIER op (11..17: its reason + 11), 1..9 see the cut sites
+            int code = 0;
+            if (dd < G) code = sB <= sC ? 11 + (__hip_atomic_load(&plans[sB < G ? sB : 0].count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 7) : (int)sCutWhy[sC];
+            atomicAdd(&g_pbprof[12 + code], 1ull);
         }
 #endif
         rs->ticket = 0u;                                               // re-armed for the next round
@@ -926,7 +935,10 @@ __global__ __launch_bounds__(PL_BLOCK) void k_plan(const DevBufs* bufs, const Ct
                 atomicAdd((unsigned long long*)&c->stat_small_rebalances, (unsigned long long)sSumRebN);
             }
         }
-        int Gn = na + (na >> 1) + 32;                                    // the next window: half as much again as what ran (the resolve step costs per planned op)
+        // the next window: half as much again as what ran.  (The resolve step costs per planned op where ops collide: with a floor of 256 /
+        // 512 / 1024 ops under the window config 5's first batch takes 50.7 / 58.1 / 68.0 ms instead of 34.0, its first 14 batches 143 / 168 /
+        // 192 ms instead of 119; batch B and the matrix updates gain 0-3 % at 1024.)
+        int Gn = na + (na >> 1) + 32;
         if (Gn < 64) Gn = 64;
         if (Gn > PB_GMAX) Gn = PB_GMAX;
         rs->G_next = Gn;
@@ -1744,12 +1756,15 @@ hipError_t launch_dbg_raw_wave(KeyArr keys, double* vals, uint64_t* occ, int64_t
 
 #ifdef DSA_PB_PROF
 extern "C" void dsa_dbg_pbprof_dump(void) {
-    unsigned long long h[16] = {0};
+    unsigned long long h[32] = {0};
     if (hipMemcpyFromSymbol(h, HIP_SYMBOL(dsa::g_pbprof), sizeof(h)) != hipSuccess) return;
     const double r = h[0] ? (double)h[0] : 1.0;
     fprintf(stderr, "pbprof: %llu resolves, G %.0f applied %.0f conflicts %.2f | cycles per round: entry->planned %.0f ->ticket %.0f | load %.0f conflicts %.0f seal %.0f decide+list %.0f\n",
             h[0], h[8] / r, h[9] / r, h[7] / r, h[1] / r, h[2] / r, h[3] / r, h[4] / r, h[5] / r, h[6] / r);
-    unsigned long long z[16] = {0};
+    fprintf(stderr, "        rounds ended by: whole window %llu | prefix rule (run-ahead off) %llu, first conflict in the last eighth %llu, > 96 conflicts %llu | sealing: > 64 ops in the zone %llu, "
+            "not a plain write %llu, no level fits %llu, zones touch %llu, a later op straddles a zone %llu | new column without a window %llu | barrier op [unplannable %llu newcol %llu limits %llu shifts %llu "
+            "semleaf %llu window %llu scan %llu other %llu]\n", h[12], h[13], h[14], h[15], h[16], h[17], h[18], h[19], h[20], h[21], h[23], h[24], h[25], h[26], h[27], h[28], h[29], h[30]);
+    unsigned long long z[32] = {0};
     (void)hipMemcpyToSymbol(HIP_SYMBOL(dsa::g_pbprof), z, sizeof(z));
 }
 #endif

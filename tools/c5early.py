@@ -20,4 +20,7 @@ for b in range(14):
         d = {k: inf[k] - prev[o][k] for k in keys[2:]}
         prev[o] = {k: inf[k] for k in keys}
         out.append("cap %d n %d reb %d ext %d rounds %d par %d seq %d" % (inf["capacity"], inf["nb_elements"], d["stat_rebalances"], d["stat_extends"], d["stat_par_rounds"], d["stat_par_ops"], d["stat_seq_ops"]))
-    print("batch %2d %.2f ms | col: %s | row: %s" % (b, dt * 1e3, out[0], out[1]))
+    print("batch %2d %.2f ms | col: %s | row: %s" % (b, dt * 1e3, out[0], out[1]), flush=True)
+    lib = getattr(hip, "lib", None)      # a -DDSA_PB_PROF build (DSA_LIBRARY): the resolve step's phases of this batch, to stderr
+    if lib is not None and hasattr(lib, "dsa_dbg_pbprof_dump"):
+        sys.stderr.flush(); lib.dsa_dbg_pbprof_dump()
