@@ -430,7 +430,18 @@ __global__ __launch_bounds__(PL_BLOCK) void k_plan(const DevBufs* bufs, const Ct
     __shared__ uint32_t sScan[PL_BLOCK / 64];
     const int64_t seg = seg0;
     // (spatial hash of the overlap test below; emptied here, under the latency of the plan loads, behind the same barrier)
-    constexpr int CS = PB_MAX_W_LOG2 + 1, NB = 4096;
+    // Cell size: 2 * PB_MAX_W slots on large arrays; on a small array ~1/128 of it (not below the leaf, not below 64 slots) — with 4096-slot
+    // cells every op of a 32 k-slot array is chained into the same few buckets and each walk visits the whole window (config 5's first
+    // batch: 26 k cycles of the resolve step for 83 planned ops).  Footprints over more than two cells go to the list of wide ops.
+    constexpr int CS_MAX = PB_MAX_W_LOG2 + 1, NB = 4096;
+    int CS = CS_MAX;
+    {
+        const int lgcap = 63 - __clzll((unsigned long long)(cap0 > 1 ? cap0 : 1)), lgseg = 63 - __clzll((unsigned long long)(seg > 1 ? seg : 1));
+        int c = lgcap - 7;
+        if (c < lgseg) c = lgseg;
+        if (c < 6) c = 6;
+        if (shift == 0 && c < CS_MAX) CS = c;
+    }
     __shared__ int sHead[NB];
     __shared__ int sNext[2 * PB_GMAX];
     __shared__ int sWide[PB_GMAX];
