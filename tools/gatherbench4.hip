@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <utility>
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
 
@@ -106,6 +107,57 @@ __global__ __launch_bounds__(256) void k_loop(const int32_t* __restrict__ kp, co
     }
 }
 
+
+// ---- round 6: what ends a tile in the product — a dependent row-key load per summing lane (the key of the partition whose id sits in LDS) and
+// a SCATTERED 8-byte store through it — instead of one coalesced store.  Q1 one span per wave; Q2 the loop; Q3 the loop with the stores of
+// tile i issued behind the stream loads and gathers of tile i + 1 (nothing of a tile is waited for before the next tile's requests are out).
+__device__ __forceinline__ int rowkey_of(const int* __restrict__ rk, int sp, int lane) { return rk[(int64_t)sp * 32 + (lane >> 1)]; }
+
+__global__ __launch_bounds__(256) void k_one_rk(const int32_t* __restrict__ kp, const double* __restrict__ vp, const double* __restrict__ x,
+                                                int nspans, const int* __restrict__ rk, double* __restrict__ y) {
+    __shared__ double sPw[4][W * 64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int per = nspans / 8;
+    const int li = (blockIdx.x >> 3) * 4 + wv;
+    if (li >= per) return;
+    const int span = (blockIdx.x & 7) * per + li;
+    Span s;
+    load_span(s, kp, vp, span, lane);
+    double xv[W];
+#pragma unroll
+    for (int j = 0; j < W; ++j) xv[j] = x[s.k[j] >= 0 ? s.k[j] : 0];
+    const int row = (lane & 1) == 0 ? rowkey_of(rk, span, lane) : 0;          // requested first, needed last (like the product)
+    const double sum = compute_phase(s, xv, sPw[wv], lane, true);
+    if ((lane & 1) == 0) y[row] = sum;
+}
+
+template <bool DEFER>
+__global__ __launch_bounds__(256) void k_loop_rk(const int32_t* __restrict__ kp, const double* __restrict__ vp, const double* __restrict__ x,
+                                                 int nspans, int T, const int* __restrict__ rk, double* __restrict__ y) {
+    __shared__ double sPw[4][W * 64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int per = nspans / 8;
+    const int wpx = gridDim.x >> 3;
+    const int xcd = blockIdx.x & 7, wg = blockIdx.x >> 3;
+    auto span_of = [&](int i) { const int tile = wg + i * wpx; const int li = tile * 4 + wv; return li < per ? xcd * per + li : -1; };
+    int prow = -1; double psum = 0.0;                 // DEFER: the store of the previous tile
+    for (int i = 0; i < T; ++i) {
+        const int sp = span_of(i);
+        if (sp < 0) break;                             // (uniform per wave; no workgroup barrier in this kernel)
+        Span cur;
+        load_span(cur, kp, vp, sp, lane);
+        double xv[W];
+#pragma unroll
+        for (int j = 0; j < W; ++j) xv[j] = x[cur.k[j] >= 0 ? cur.k[j] : 0];
+        if (DEFER && prow >= 0) y[prow] = psum;        // behind this tile's requests: nothing waited for it
+        const int row = (lane & 1) == 0 ? rowkey_of(rk, sp, lane) : -1;
+        const double sum = compute_phase(cur, xv, sPw[wv], lane, false);
+        if (DEFER) { prow = row; psum = sum; }
+        else if ((lane & 1) == 0) y[row] = sum;
+    }
+    if (DEFER && prow >= 0) y[prow] = psum;
+}
+
 template <typename F> static float timeit(F f, int reps = 20) {
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
     for (int i = 0; i < 3; ++i) f();
@@ -151,6 +203,32 @@ int main(int argc, char** argv) {
         const float a = timeit([&] { hipLaunchKernelGGL(k_loop<false>, dim3(grid), dim3(256), 0, 0, keys, vals, x, nspans, T, y); });
         const float b = timeit([&] { hipLaunchKernelGGL(k_loop<true>, dim3(grid), dim3(256), 0, 0, keys, vals, x, nspans, T, y); });
         printf("T = %d spans per wave (grid %d): P2 loop, no prefetch %.1f us | P3 loop + prefetch %.1f us\n", T, grid, a, b);
+    }
+    {
+        // row keys: span-local ids mapped through a table to rows that are ascending on the whole but scattered within +-2048 (8-byte stores, not coalesced)
+        const int64_t NR = (int64_t)nspans * 32;
+        std::vector<int> hr((size_t)NR);
+        uint64_t st = 4242;
+        for (int64_t i = 0; i < NR; i += 4096) {
+            const int64_t n = NR - i < 4096 ? NR - i : 4096;
+            for (int64_t q = 0; q < n; ++q) hr[(size_t)(i + q)] = (int)(i + q);
+            for (int64_t q = n - 1; q > 0; --q) {
+                uint64_t z = (st += 0x9E3779B97F4A7C15ull); z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z ^= z >> 31;
+                const int64_t r = (int64_t)(z % (uint64_t)(q + 1));
+                std::swap(hr[(size_t)(i + q)], hr[(size_t)(i + r)]);
+            }
+        }
+        int* rk; CK(hipMalloc(&rk, (size_t)NR * 4)); CK(hipMemcpy(rk, hr.data(), (size_t)NR * 4, hipMemcpyHostToDevice));
+        printf("Q1 row-key load + scattered store, one span per wave   %.1f us\n", timeit([&] { hipLaunchKernelGGL(k_one_rk, dim3(grid1), dim3(256), 0, 0, keys, vals, x, nspans, rk, y); }));
+        for (int T : {2, 4, 8}) {
+            const int tiles_per_xcd = nspans / 8 / 4;
+            const int wpx = (tiles_per_xcd + T - 1) / T;
+            const int grid = wpx * 8;
+            const float a = timeit([&] { hipLaunchKernelGGL(k_loop_rk<false>, dim3(grid), dim3(256), 0, 0, keys, vals, x, nspans, T, rk, y); });
+            const float b = timeit([&] { hipLaunchKernelGGL(k_loop_rk<true>, dim3(grid), dim3(256), 0, 0, keys, vals, x, nspans, T, rk, y); });
+            printf("T = %d (grid %d): Q2 loop %.1f us | Q3 loop, stores deferred behind the next tile's requests %.1f us\n", T, grid, a, b);
+        }
+        CK(hipFree(rk));
     }
     CK(hipDeviceSynchronize());
     printf("done\n");
