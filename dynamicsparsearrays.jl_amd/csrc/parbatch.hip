@@ -636,8 +636,9 @@ __global__ __launch_bounds__(PL_BLOCK) void k_plan(const DevBufs* bufs, const Ct
         //   (0) more than D cells lie between A and the leftmost op inside (a predecessor moves left by one cell per deleted cell: it
         //       stays inside);
         //   (1) every op of the round's window that touches Z' lies inside [A, B] and is a plain write (overwrite, missing-key delete,
-        //       right-shifting insert, delete; whatever window <= [A, B] its density scan was planned to rebalance): I potential
-        //       inserts (every op with a value), D potential deletes (every op without);
+        //       right-shifting insert, delete; whatever window <= [A, B] its density scan was planned to rebalance) or a new column IN
+        //       FRONT of j (applied in this round: a semaphore + its first element, two inserts): I potential inserts (every op with a
+        //       value, two per new column), D potential deletes (every op without);
         //   (2) both windows accept at level h whatever those ops do: lo[h] <= c - D and c + I <= hi[h] for the cell counts c of
         //       [A, B] and of [B + 1, B + W]: no density scan at a position inside Z' climbs above level h, rebalances stay inside;
         //   (3) the right window keeps more than I + 1 gaps (W - hi[h] >= I + 2): an insert position can drift right by one slot per
@@ -711,10 +712,13 @@ __global__ __launch_bounds__(PL_BLOCK) void k_plan(const DevBufs* bufs, const Ct
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                     // the ops that touch R, one per lane (more than 64: nothing is proven, the round ends in front of j)
                     Iv o{INT32_MAX, INT32_MIN};
-                    bool osimple = false, oins = false;
+                    bool osimple = false, oins = false, onew = false;
                     if (n <= 64 && lane < n) {
                         const int i = sSealList[wave][lane];
                         o = sIv[i]; osimple = sSimple[i] != 0; oins = sAct[i] == PB_OVERWRITE || sAct[i] == PB_INS_R;
+                        // an EARLIER new column (applied in this round — if it conflicted itself the round would end in front of it): a
+                        // semaphore and its first element, two right-shifting inserts as far as the zone is concerned
+                        onew = sAct[i] == PB_NEWCOL && i < j;
                     }
                     // the occupancy words of R and the inclusive prefix sum of their popcounts (lane t <-> word t of R)
                     const int64_t w0 = (Ax - 1) >> 6;
@@ -732,8 +736,9 @@ __global__ __launch_bounds__(PL_BLOCK) void k_plan(const DevBufs* bufs, const Ct
                         // (1) every op that touches Z' lies inside [A, B] and is a plain write
                         const bool ov = o.lo <= B + W && A <= o.hi;                               // (an idle lane's empty interval overlaps nothing)
                         const uint64_t ovm = __ballot(ov);
-                        if (__ballot(ov && (!osimple || o.lo < A || o.hi > B)) != 0ull) continue;
-                        const int ins = popc64(__ballot(ov && oins)), del = popc64(ovm) - ins;
+                        if (__ballot(ov && (!(osimple || onew) || o.lo < A || o.hi > B)) != 0ull) continue;
+                        const int nins = popc64(__ballot(ov && oins)), nnew = popc64(__ballot(ov && onew));
+                        const int ins = nins + 2 * nnew, del = popc64(ovm) - nins - nnew;
                         if (del > RA_MAX_DEL) continue;
                         const int64_t lh = h < 24 ? sLoH[h] : ctl->lo[h], hh = h < 24 ? sHiH[h] : ctl->hi[h];
                         if (W - hh < ins + 2) continue;
